@@ -1,0 +1,161 @@
+/*
+ * solr_hip.h - C-ABI drop-in boundary of the MI355X (gfx950) rendering engine.
+ *
+ * Part 1 re-declares, name for name and argument for argument, the ten
+ * extern "C" entry points through which the reference's host engine class
+ * drives its device code (reference: solr/engines/cuda/CudaRayTracer.h:25-67;
+ * the only caller is solr/engines/cuda/CudaKernel.cpp:138,144,160,201,204,210,
+ * 219,228,293,307).  A host built against the reference headers links against
+ * libsolr_hip.so instead of the CUDA object and keeps working: same symbols,
+ * same by-value SysV argument passing, same ownership (host arrays are
+ * borrowed for the duration of the call, device buffers are owned here).
+ *
+ * Part 2 adds what a one-process-per-GPU deployment needs and the reference
+ * never had: device/stream selection, the framebuffer row strip this process
+ * renders, device-pointer access for the RCCL gather, pointer-argument twins
+ * of the by-value calls for FFI callers (ctypes/cgo cannot align a by-value
+ * struct to 16 bytes), timing and ray counting for bench.py, and an error
+ * query (the reference exits the process on a CUDA error,
+ * helper_cuda.h:749-763; this library records the error, makes every later
+ * call a no-op and lets the host decide - set SOLR_HIP_FATAL=1 to get the
+ * reference's exit(EXIT_FAILURE) behaviour back).
+ *
+ * No torch / HIP types appear in any signature: plain pointers and sizes.
+ */
+#ifndef SOLR_HIP_H
+#define SOLR_HIP_H
+
+#include "solr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================= */
+/* Part 1 - the reference boundary                                          */
+/* ======================================================================= */
+
+/* CudaRayTracer.h:25 / CudaRayTracer.cu:1408-1491.  occupancyParameters.x is
+ * the reference's in-process GPU count; this engine is one process per GPU
+ * and ignores any value other than 1 there (multi-GPU = solr_hip_set_strip +
+ * an RCCL gather done by the launcher).  The nb* capacities are hints: device
+ * arrays are sized to the scene actually uploaded, not to NB_MAX_*. */
+void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int nbPrimitives, int nbLamps,
+                      int nbMaterials);
+
+/* CudaRayTracer.h:34 / CudaRayTracer.cu:1499-1532 */
+void finalize_scene(vec2i occupancyParameters);
+
+/* CudaRayTracer.h:41 / CudaRayTracer.cu:1360-1400: (re)allocates the
+ * per-pixel buffers (float framebuffer, RGB bitmap, primitive ids, randoms) */
+void reshape_scene(vec2i occupancyParameters, SceneInfo sceneInfo);
+
+/* CudaRayTracer.h:43 / CudaRayTracer.cu:1540-1555: uploads the flattened box
+ * tree, the primitives (in box order) and the lamp index list; the AoS host
+ * records are re-packed into the device plane layout here */
+void h2d_scene(vec2i occupancyParameters, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *primitives,
+               int nbPrimitives, Lamp *lamps, int nbLamps);
+
+/* CudaRayTracer.h:46 / CudaRayTracer.cu:1557-1565 */
+void h2d_materials(vec2i occupancyParameters, Material *materials, int nbActiveMaterials);
+
+/* CudaRayTracer.h:48 / CudaRayTracer.cu:1567-1576: always MAX_BITMAP_SIZE floats */
+void h2d_randoms(vec2i occupancyParameters, float *randoms);
+
+/* CudaRayTracer.h:50 / CudaRayTracer.cu:1578-1613: packs every non-null
+ * texture at its TextureInfo.offset into one byte atlas */
+void h2d_textures(vec2i occupancyParameters, int activeTextures, TextureInfo *textureInfos);
+
+/* CudaRayTracer.h:52 / CudaRayTracer.cu:1615-1625 */
+void h2d_lightInformation(vec2i occupancyParameters, LightInformation *lightInformation, int lightInformationSize);
+
+/* CudaRayTracer.h:55 / CudaRayTracer.cu:1647-1672: waits for the frame and
+ * copies the RGB bitmap (W*H*3 bytes) and the primitive-id buffer (W*H*16
+ * bytes) of this process's strip to the strip's position in the host arrays */
+void d2h_bitmap(vec2i occupancyParameters, SceneInfo sceneInfo, BitmapBuffer *bitmap,
+                PrimitiveXYIdBuffer *primitivesXYIds);
+
+/* CudaRayTracer.h:58 / CudaRayTracer.cu:1680-1908: launches the renderer and
+ * the post-processing stage; asynchronous, ordered on the engine's stream.
+ * objects = {nbBoxes, nbPrimitives, nbLamps, lightInformationSize}.
+ * blockSize is accepted for signature compatibility; the wave64 tile shape
+ * is chosen by the engine. */
+void cudaRender(vec2i occupancyParameters, vec4i blockSize, SceneInfo sceneInfo, vec4i objects,
+                PostProcessingInfo postProcessingInfo, vec3f origin, vec3f direction, vec4f angles);
+
+/* ======================================================================= */
+/* Part 2 - extensions                                                      */
+/* ======================================================================= */
+
+/* 0 when no error is pending; otherwise the HIP error code (or -1 for an
+ * argument/state error) and, if buf != NULL, its text. Does not clear. */
+int solr_hip_last_error(char *buf, int len);
+void solr_hip_clear_error(void);
+
+/* number of visible GPUs (0 when none / no driver); never sets the error */
+int solr_hip_device_count(void);
+/* device this process renders on (call before initialize_scene; default 0) */
+void solr_hip_set_device(int device);
+/* stream (a hipStream_t passed as void*) every copy and launch is issued on;
+ * NULL = a stream owned by the engine */
+void solr_hip_set_stream(void *stream);
+void solr_hip_synchronize(void);
+
+/* Row strip rendered by this process: rows [firstRow, firstRow + nbRows) of
+ * the full sceneInfo.size image.  nbRows <= 0 restores the full frame.  The
+ * device buffers then hold only the strip (row 0 of the buffer = firstRow);
+ * d2h_bitmap places it at its position in a full-size host image. */
+void solr_hip_set_strip(int firstRow, int nbRows);
+
+/* Device pointers of the current per-pixel buffers (strip-sized), for
+ * collectives issued by the launcher (RCCL gather of the RGB strip). */
+void *solr_hip_device_bitmap(void);
+void *solr_hip_device_primitive_ids(void);
+void *solr_hip_device_postprocessing(void);
+/* Render into caller-owned device memory instead (e.g. a torch tensor that
+ * is the send buffer of the gather); NULL restores the engine's own buffer. */
+void solr_hip_bind_device_bitmap(void *deviceBitmap);
+
+/* Float framebuffer of the strip back to the host (parity tests) */
+void solr_hip_d2h_postprocessing(PostProcessingBuffer *hostBuffer);
+/* Host float framebuffer / primitive ids into the strip (accumulation tests) */
+void solr_hip_h2d_postprocessing(const PostProcessingBuffer *hostBuffer, const PrimitiveXYIdBuffer *ids);
+
+/* Pointer-argument twins of the by-value entry points */
+void solr_hip_initialize(const SceneInfo *sceneInfo);
+void solr_hip_reshape(const SceneInfo *sceneInfo);
+void solr_hip_render(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
+                     const float origin[3], const float direction[3], const float angles[4]);
+void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds);
+
+/* Kernel timing: when enabled every cudaRender/solr_hip_render brackets its
+ * launches with HIP events on the engine's stream.  solr_hip_kernel_time
+ * synchronises, returns the summed milliseconds of the renderer kernel and
+ * writes the number of timed launches; reset != 0 clears both afterwards. */
+void solr_hip_enable_timing(int enable);
+double solr_hip_kernel_time(int *nbLaunches, int reset);
+
+/* Renders the frame once with the counting variant of the kernel and returns
+ * the number of box-tree traversals: counts[0] = closest-hit walks
+ * (intersectionWithPrimitives calls), counts[1] = shadow walks
+ * (processShadows calls), counts[2] = box nodes visited (summed over lanes),
+ * counts[3] = primitive tests (summed over lanes).  Output buffers are
+ * written exactly as by the normal variant. */
+void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
+                              const PostProcessingInfo *postProcessingInfo, const float origin[3],
+                              const float direction[3], const float angles[4], unsigned long long counts[4]);
+
+/* Kernel variant selection (A/B measurements): 0 = automatic, 1 = scene read
+ * through the scalar cache from HBM, 2 = scene staged in LDS (small scenes
+ * only; falls back to 1 when it does not fit). */
+void solr_hip_set_variant(int variant);
+int solr_hip_get_variant(void);
+
+/* Bytes of HBM this engine currently holds for {scene planes, materials,
+ * textures, per-pixel buffers}; for DESIGN.md's layout table and tests. */
+void solr_hip_memory_usage(unsigned long long bytes[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOLR_HIP_H */

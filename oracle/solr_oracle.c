@@ -1,0 +1,1945 @@
+/*
+ * solr_oracle.c - CPU restatement of Sol-R's per-pixel rendering path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see solr_oracle.h).  PARITY UNPINNED: checked
+ * against hand-derived known answers, not against reference outputs.
+ *
+ * Every function cites the reference file:line it restates.  "ref:" paths are
+ * relative to the reference tree, with
+ *   CRT = solr/engines/cuda/CudaRayTracer.cu
+ *   GI  = solr/engines/cuda/GeometryIntersections.cuh
+ *   GS  = solr/engines/cuda/GeometryShaders.cuh
+ *   TM  = solr/engines/cuda/TextureMapping.cuh
+ *   VU  = solr/engines/cuda/VectorUtils.cuh
+ *   HM  = solr/engines/cuda/helper_math.h
+ *
+ * Numerical definition (DESIGN.md "numerics"): IEEE-754 binary32 for every
+ * operation in source order, no fused multiply-add (build with
+ * -ffp-contract=off), correctly rounded division and square root,
+ * rsqrtf(x) = 1.0f / sqrtf(x) (HM:62-65, the host definition; the CUDA
+ * build's --use_fast_math approximations are not reproducible and are not the
+ * target), min/max on floats = fminf/fmaxf (the CUDA overloads), libm
+ * transcendentals in binary32 (powf, sinf, cosf, atan2f, asinf).
+ */
+#include "solr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef vec3f v3;
+
+typedef struct
+{
+    float x, y, z;
+} c3; /* colour triple; the reference carries float4 colours whose w never reaches the output */
+
+typedef struct
+{
+    v3 origin;
+    v3 direction;
+    v3 inv_direction;
+    int sx, sy, sz;
+} Ray; /* ref: solr/types.h:171-178 */
+
+typedef struct
+{
+    unsigned long long closest, shadow, boxes, prims;
+    int randomFault;
+} Stats;
+
+/* ---- helper_math.h vector operators (HM:349-365,579-593,804-818,997,1248,1291,1309) */
+static inline v3 V(float x, float y, float z)
+{
+    v3 r = {x, y, z};
+    return r;
+}
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vscale(v3 a, float b) { return V(a.x * b, a.y * b, a.z * b); }
+static inline v3 vdivs(v3 a, float b) { return V(a.x / b, a.y / b, a.z / b); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float vlength(v3 v) { return sqrtf(vdot(v, v)); }
+static inline float rsqrt_host(float x) { return 1.0f / sqrtf(x); } /* HM:62-65 */
+static inline v3 vnormalize(v3 v)
+{
+    float invLen = rsqrt_host(vdot(v, v)); /* HM:1309-1313 */
+    return vscale(v, invLen);
+}
+
+/* ref VU:45-52 */
+static inline v3 crossProduct(v3 b, v3 c)
+{
+    v3 a;
+    a.x = b.y * c.z - b.z * c.y;
+    a.y = b.z * c.x - b.x * c.z;
+    a.z = b.x * c.y - b.y * c.x;
+    return a;
+}
+
+/* ref VU:31-42 (colour part) */
+static inline float sat1(float v)
+{
+    v = (v < 0.f) ? 0.f : v;
+    v = (v > 1.f) ? 1.f : v;
+    return v;
+}
+static inline void saturate3(c3 *v)
+{
+    v->x = sat1(v->x);
+    v->y = sat1(v->y);
+    v->z = sat1(v->z);
+}
+
+/* ref VU:61-64: r = i - 2.f * dot(i, n) * n */
+static inline v3 vectorReflection(v3 i, v3 n)
+{
+    float k = 2.f * vdot(i, n);
+    return vsub(i, vscale(n, k));
+}
+
+/* ref VU:73-87 */
+static inline v3 vectorRefraction(v3 incident, float n1, v3 normal, float n2)
+{
+    v3 refracted = incident;
+    if (n2 != 0.f)
+    {
+        float eta = n1 / n2;
+        float c1 = -vdot(incident, normal);
+        float cs2 = 1.f - eta * eta * (1.f - c1 * c1);
+        if (cs2 >= 0.f)
+        {
+            float k = eta * c1 - sqrtf(cs2);
+            refracted = vadd(vscale(incident, eta), vscale(normal, k));
+        }
+    }
+    return refracted;
+}
+
+/* ref VU:92-95 */
+static inline v3 project(v3 A, v3 B) { return vscale(B, vdot(A, B) / vdot(B, B)); }
+
+/* ref VU:104-142; the six sinf/cosf values depend only on the camera angles */
+typedef struct
+{
+    float cx, cy, cz, sx, sy, sz;
+} Trig;
+static Trig makeTrig(const float angles[3])
+{
+    Trig t;
+    t.cx = cosf(angles[0]);
+    t.cy = cosf(angles[1]);
+    t.cz = cosf(angles[2]);
+    t.sx = sinf(angles[0]);
+    t.sy = sinf(angles[1]);
+    t.sz = sinf(angles[2]);
+    return t;
+}
+static v3 vectorRotation(v3 v, v3 c, const Trig *t)
+{
+    float vx = v.x - c.x, vy = v.y - c.y, vz = v.z - c.z;
+    float rx = vx, ry, rz;
+    /* X axis */
+    ry = vy * t->cx - vz * t->sx;
+    rz = vy * t->sx + vz * t->cx;
+    vy = ry;
+    vz = rz;
+    /* Y axis */
+    rz = vz * t->cy - vx * t->sy;
+    rx = vz * t->sy + vx * t->cy;
+    vz = rz;
+    vx = rx;
+    /* Z axis */
+    rx = vx * t->cz - vy * t->sz;
+    ry = vx * t->sz + vy * t->cz;
+    return V(rx + c.x, ry + c.y, rz + c.z);
+}
+
+void oracle_vector_rotation(float v[3], const float center[3], const float angles[3])
+{
+    Trig t = makeTrig(angles);
+    v3 r = vectorRotation(V(v[0], v[1], v[2]), V(center[0], center[1], center[2]), &t);
+    v[0] = r.x;
+    v[1] = r.y;
+    v[2] = r.z;
+}
+
+/* ---- random buffer access with bounds check (the reference reads past the
+ * end at full HD; the oracle reports that instead) */
+static inline float rnd(const OracleScene *s, long i, Stats *st)
+{
+    if (!s->randoms || i < 0 || i >= s->nbRandoms)
+    {
+        st->randomFault = 1;
+        return 0.f;
+    }
+    return s->randoms[i];
+}
+
+/* ref GI:36-44 */
+static inline void computeRayAttributes(Ray *ray)
+{
+    ray->inv_direction.x = ray->direction.x != 0.f ? 1.f / ray->direction.x : 1.f;
+    ray->inv_direction.y = ray->direction.y != 0.f ? 1.f / ray->direction.y : 1.f;
+    ray->inv_direction.z = ray->direction.z != 0.f ? 1.f / ray->direction.z : 1.f;
+    ray->sx = (ray->inv_direction.x < 0);
+    ray->sy = (ray->inv_direction.y < 0);
+    ray->sz = (ray->inv_direction.z < 0);
+}
+
+/* ref GI:52-79 */
+static inline int boxIntersection(const BoundingBox *box, const Ray *ray, float t0, float t1)
+{
+    float tmin, tmax, tymin, tymax, tzmin, tzmax;
+    tmin = (box->parameters[ray->sx].x - ray->origin.x) * ray->inv_direction.x;
+    tmax = (box->parameters[1 - ray->sx].x - ray->origin.x) * ray->inv_direction.x;
+    tymin = (box->parameters[ray->sy].y - ray->origin.y) * ray->inv_direction.y;
+    tymax = (box->parameters[1 - ray->sy].y - ray->origin.y) * ray->inv_direction.y;
+    if ((tmin > tymax) || (tymin > tmax))
+        return 0;
+    if (tymin > tmin)
+        tmin = tymin;
+    if (tymax < tmax)
+        tmax = tymax;
+    tzmin = (box->parameters[ray->sz].z - ray->origin.z) * ray->inv_direction.z;
+    tzmax = (box->parameters[1 - ray->sz].z - ray->origin.z) * ray->inv_direction.z;
+    if ((tmin > tzmax) || (tzmin > tmax))
+        return 0;
+    if (tzmin > tmin)
+        tmin = tzmin;
+    if (tzmax < tmax)
+        tmax = tzmax;
+    return ((tmin < t1) && (tmax > t0));
+}
+
+int oracle_box_intersection(const BoundingBox *box, const float origin[3], const float direction[3], float t0,
+                            float t1)
+{
+    Ray r;
+    r.origin = V(origin[0], origin[1], origin[2]);
+    r.direction = V(direction[0], direction[1], direction[2]);
+    computeRayAttributes(&r);
+    return boxIntersection(box, &r, t0, t1);
+}
+
+/* ---- texture tier ---------------------------------------------------- */
+
+typedef struct
+{
+    float x, y, z, w;
+} f4;
+
+/* ref TM:30-40 */
+static inline void normalMap(int index, const Material *m, const BitmapBuffer *tex, v3 *normal, float strength)
+{
+    int i = m->textureOffset.y + index;
+    BitmapBuffer r = tex[i], g = tex[i + 1];
+    normal->x -= strength * (r / 256.f - 0.5f);
+    normal->y -= strength * (g / 256.f - 0.5f);
+    normal->z = 0.f;
+}
+/* ref TM:45-57 */
+static inline void bumpMap(int index, const Material *m, const BitmapBuffer *tex, float *value)
+{
+    int i = m->textureOffset.z + index;
+    BitmapBuffer r = tex[i], g = tex[i + 1], b = tex[i + 2];
+    *value = 10.f * (r + g + b) / 768.f;
+}
+/* ref TM:62-73 */
+static inline void specularMap(int index, const Material *m, const BitmapBuffer *tex, f4 *specular)
+{
+    int i = m->textureOffset.w + index;
+    BitmapBuffer r = tex[i], g = tex[i + 1], b = tex[i + 2];
+    specular->x = r / 256.f;
+    specular->y = 1000.f * g / 256.f;
+    specular->z = b / 256.f;
+}
+/* ref TM:78-87 */
+static inline void reflectionMap(int index, const Material *m, const BitmapBuffer *tex, f4 *attributes)
+{
+    int i = m->advancedTextureOffset.x + index;
+    BitmapBuffer r = tex[i], g = tex[i + 1], b = tex[i + 2];
+    attributes->x *= (r + g + b) / 768.f;
+}
+/* ref TM:92-102 */
+static inline void transparencyMap(int index, const Material *m, const BitmapBuffer *tex, f4 *attributes)
+{
+    int i = m->advancedTextureOffset.y + index;
+    BitmapBuffer r = tex[i], g = tex[i + 1], b = tex[i + 2];
+    attributes->y *= (r + g + b) / 768.f;
+}
+/* ref TM:107-116 */
+static inline void ambientOcclusionMap(int index, const Material *m, const BitmapBuffer *tex, f4 *adv)
+{
+    int i = m->advancedTextureOffset.z + index;
+    BitmapBuffer r = tex[i], g = tex[i + 1], b = tex[i + 2];
+    adv->x = (r + g + b) / 768.f;
+}
+
+/* ref TM:118-158 */
+static void juliaSet(const Material *material, const SceneInfo *si, float x, float y, f4 *color)
+{
+    float W = (float)material->textureMapping.x;
+    float H = (float)material->textureMapping.y;
+    float cRe = -0.7f + 0.4f * sinf(si->timestamp / 1500.f);
+    float cIm = 0.27015f + 0.4f * cosf(si->timestamp / 2000.f);
+    float newRe = 1.5f * (x - W / 2.f) / (0.5f * W);
+    float newIm = (y - H / 2.f) / (0.5f * H);
+    int n;
+    float maxIterations = 40.f + si->pathTracingIteration;
+    for (n = 0; n < maxIterations; n++)
+    {
+        float oldRe = newRe;
+        float oldIm = newIm;
+        newRe = oldRe * oldRe - oldIm * oldIm + cRe;
+        newIm = 2.f * oldRe * oldIm + cIm;
+        if ((newRe * newRe + newIm * newIm) > 4.f)
+            break;
+    }
+    color->x = 1.f - color->x * (n / maxIterations);
+    color->y = 1.f - color->y * (n / maxIterations);
+    color->z = 1.f - color->z * (n / maxIterations);
+    color->w = 1.f - (n / maxIterations);
+}
+
+/* ref TM:160-197 (note the double Im_factor, TM:172-175) */
+static void mandelbrotSet(const Material *material, const SceneInfo *si, float x, float y, f4 *color)
+{
+    float W = (float)material->textureMapping.x;
+    float H = (float)material->textureMapping.y;
+    float MinRe = -2.f;
+    float MaxRe = 1.f;
+    float MinIm = -1.2f;
+    float MaxIm = MinIm + (MaxRe - MinRe) * H / W;
+    float Re_factor = (MaxRe - MinRe) / (W - 1.f);
+    double Im_factor = (MaxIm - MinIm) / (H - 1.f);
+    float maxIterations = NB_MAX_ITERATIONS + si->pathTracingIteration;
+    float c_im = (float)(MaxIm - y * Im_factor);
+    float c_re = MinRe + x * Re_factor;
+    float Z_re = c_re;
+    float Z_im = c_im;
+    int isInside = 1;
+    unsigned n;
+    for (n = 0; isInside && n < maxIterations; ++n)
+    {
+        float Z_re2 = Z_re * Z_re;
+        float Z_im2 = Z_im * Z_im;
+        if (Z_re2 + Z_im2 > 4.f)
+            isInside = 0;
+        Z_im = 2.f * Z_re * Z_im + c_im;
+        Z_re = Z_re2 - Z_im2 + c_re;
+    }
+    color->x = 1.f - color->x * (n / maxIterations);
+    color->y = 1.f - color->y * (n / maxIterations);
+    color->z = 1.f - color->z * (n / maxIterations);
+    color->w = 1.f - (n / maxIterations);
+}
+
+static inline f4 colorOf(const Material *m)
+{
+    f4 c = {m->color.x, m->color.y, m->color.z, m->color.w};
+    return c;
+}
+
+/* common tail of the three mappers (TM:238-279, 311-343, 410-441) */
+static inline void fetchTexel(const Material *material, const BitmapBuffer *textures, int u, int v, f4 *result,
+                              v3 *normal, f4 *specular, f4 *attributes, f4 *advancedAttributes)
+{
+    int A = (v * material->textureMapping.x + u) * material->textureMapping.w;
+    int B = material->textureMapping.x * material->textureMapping.y * material->textureMapping.w;
+    int index = A % B;
+    int i = material->textureOffset.x + index;
+    BitmapBuffer r = textures[i], g = textures[i + 1], b = textures[i + 2];
+    result->x = r / 256.f;
+    result->y = g / 256.f;
+    result->z = b / 256.f;
+    float strength = 3.f;
+    if (material->textureIds.z != TEXTURE_NONE)
+        bumpMap(index, material, textures, &strength);
+    if (material->textureIds.y != TEXTURE_NONE)
+        normalMap(index, material, textures, normal, strength);
+    if (material->textureIds.w != TEXTURE_NONE)
+        specularMap(index, material, textures, specular);
+    if (material->advancedTextureIds.x != TEXTURE_NONE)
+        reflectionMap(index, material, textures, attributes);
+    if (material->advancedTextureIds.y != TEXTURE_NONE)
+        transparencyMap(index, material, textures, attributes);
+    if (material->advancedTextureIds.z != TEXTURE_NONE)
+        ambientOcclusionMap(index, material, textures, advancedAttributes);
+}
+
+/* ref TM:205-283 */
+static f4 triangleUVMapping(const SceneInfo *si, const Primitive *primitive, const Material *materials,
+                            const BitmapBuffer *textures, v3 areas, v3 *normal, f4 *specular, f4 *attributes,
+                            f4 *advancedAttributes)
+{
+    const Material *material = &materials[primitive->materialId];
+    f4 result = colorOf(material);
+    float sum = areas.x + areas.y + areas.z;
+    float Tx = (primitive->vt0.x * areas.x + primitive->vt1.x * areas.y + primitive->vt2.x * areas.z) / sum;
+    float Ty = (primitive->vt0.y * areas.x + primitive->vt1.y * areas.y + primitive->vt2.y * areas.z) / sum;
+    float mox = 0.f, moy = 0.f;
+    if (material->attributes.y == 1)
+    {
+        mox = material->mappingOffset.x * si->timestamp;
+        moy = material->mappingOffset.y * si->timestamp;
+    }
+    int u = (int)(Tx * material->textureMapping.x + mox);
+    int v = (int)(Ty * material->textureMapping.y + moy);
+    u = u % material->textureMapping.x;
+    v = v % material->textureMapping.y;
+    if (u >= 0 && u < material->textureMapping.x && v >= 0 && v < material->textureMapping.y)
+    {
+        switch (material->textureIds.x)
+        {
+        case TEXTURE_MANDELBROT:
+            mandelbrotSet(material, si, (float)u, (float)v, &result);
+            break;
+        case TEXTURE_JULIA:
+            juliaSet(material, si, (float)u, (float)v, &result);
+            break;
+        default:
+            fetchTexel(material, textures, u, v, &result, normal, specular, attributes, advancedAttributes);
+        }
+    }
+    return result;
+}
+
+/* ref TM:291-346 */
+static f4 sphereUVMapping(const Primitive *primitive, const Material *materials, const BitmapBuffer *textures,
+                          v3 intersection, v3 *normal, f4 *specular, f4 *attributes, f4 *advancedAttributes)
+{
+    const Material *material = &materials[primitive->materialId];
+    f4 result = colorOf(material);
+    v3 I = vnormalize(vsub(intersection, primitive->p0));
+    float U = ((atan2f(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
+    float V_ = (asinf(I.y) / SOLR_PI) + .5f;
+    int u = (int)(material->textureMapping.x * (U * primitive->vt1.x));
+    int v = (int)(material->textureMapping.y * (V_ * primitive->vt1.y));
+    if (material->textureMapping.x != 0)
+        u = u % material->textureMapping.x;
+    if (material->textureMapping.y != 0)
+        v = v % material->textureMapping.y;
+    if (u >= 0 && u < material->textureMapping.x && v >= 0 && v < material->textureMapping.y)
+        fetchTexel(material, textures, u, v, &result, normal, specular, attributes, advancedAttributes);
+    return result;
+}
+
+/* ref TM:354-447 (non-Kinect build) */
+static f4 cubeMapping(const SceneInfo *si, const Primitive *primitive, const Material *materials,
+                      const BitmapBuffer *textures, v3 intersection, v3 *normal, f4 *specular, f4 *attributes,
+                      f4 *advancedAttributes)
+{
+    const Material *material = &materials[primitive->materialId];
+    f4 result = colorOf(material);
+    int u = (int)(((primitive->type == ptCheckboard) || (primitive->type == ptXZPlane) ||
+                   (primitive->type == ptXYPlane))
+                      ? (intersection.x - primitive->p0.x + primitive->size.x)
+                      : (intersection.z - primitive->p0.z + primitive->size.z));
+    int v = (int)(((primitive->type == ptCheckboard) || (primitive->type == ptXZPlane))
+                      ? (intersection.z + primitive->p0.z + primitive->size.z)
+                      : (intersection.y - primitive->p0.y + primitive->size.y));
+    if (material->textureMapping.x != 0)
+        u = u % material->textureMapping.x;
+    if (material->textureMapping.y != 0)
+        v = v % material->textureMapping.y;
+    /* TM:398 compares v against textureMapping.x (sic) */
+    if (u >= 0 && u < material->textureMapping.x && v >= 0 && v < material->textureMapping.x)
+    {
+        switch (material->textureIds.x)
+        {
+        case TEXTURE_MANDELBROT:
+            mandelbrotSet(material, si, (float)u, (float)v, &result);
+            break;
+        case TEXTURE_JULIA:
+            juliaSet(material, si, (float)u, (float)v, &result);
+            break;
+        default:
+            fetchTexel(material, textures, u, v, &result, normal, specular, attributes, advancedAttributes);
+        }
+    }
+    return result;
+}
+
+/* ref TM:449-456 */
+static inline int wireFrameMapping(float x, float y, int width)
+{
+    int X = (int)fabsf(x);
+    int Y = (int)fabsf(y);
+    int A = 100;
+    int B = 100;
+    return (X % A <= width) || (Y % B <= width);
+}
+
+/* ref GI:87-151 */
+static c3 skyboxMapping(const SceneInfo *si, const Material *materials, const BitmapBuffer *textures,
+                        const Ray *ray)
+{
+    const Material *material = &materials[si->skyboxMaterialId];
+    c3 result = {material->color.x, material->color.y, material->color.z};
+    v3 dir = vnormalize(vsub(ray->direction, ray->origin));
+    float a = 2.f * vdot(dir, dir);
+    float b = 2.f * vdot(ray->origin, dir);
+    float c = vdot(ray->origin, ray->origin) - (float)(si->skyboxRadius * si->skyboxRadius);
+    float d = b * b - 2.f * a * c;
+    if (d <= 0.f || a == 0.f)
+        return result;
+    float r = sqrtf(d);
+    float t1 = (-b - r) / a;
+    float t2 = (-b + r) / a;
+    if (t1 <= si->geometryEpsilon && t2 <= si->geometryEpsilon)
+        return result;
+    float t = 0.f;
+    if (t1 <= si->geometryEpsilon)
+        t = t2;
+    else if (t2 <= si->geometryEpsilon)
+        t = t1;
+    else
+        t = (t1 < t2) ? t1 : t2;
+    if (t < si->geometryEpsilon)
+        return result;
+    v3 intersection = vnormalize(vadd(ray->origin, vscale(dir, t)));
+    float U = ((atan2f(intersection.x, intersection.z) / SOLR_PI) + 1.f) * .5f;
+    float V_ = (asinf(intersection.y) / SOLR_PI) + .5f;
+    int u = (int)(material->textureMapping.x * U);
+    int v = (int)(material->textureMapping.y * V_);
+    if (material->textureMapping.x != 0)
+        u %= material->textureMapping.x;
+    if (material->textureMapping.y != 0)
+        v %= material->textureMapping.y;
+    if (u >= 0 && u < material->textureMapping.x && v >= 0 && v < material->textureMapping.y)
+    {
+        int A = (v * material->textureMapping.x + u) * material->textureMapping.w;
+        int B = material->textureMapping.x * material->textureMapping.y * material->textureMapping.w;
+        int index = A % B;
+        int i = material->textureOffset.x + index;
+        result.x = textures[i] / 256.f;
+        result.y = textures[i + 1] / 256.f;
+        result.z = textures[i + 2] / 256.f;
+    }
+    return result;
+}
+
+/* ---- primitive intersections ------------------------------------------ */
+
+/* ref GI:159-212 */
+static int ellipsoidIntersection(const SceneInfo *si, const Primitive *e, const Ray *ray, v3 *intersection,
+                                 v3 *normal, float *shadowIntensity)
+{
+    *shadowIntensity = 1.f;
+    v3 O_C = vsub(ray->origin, e->p0);
+    v3 dir = vnormalize(ray->direction);
+    float a = ((dir.x * dir.x) / (e->size.x * e->size.x)) + ((dir.y * dir.y) / (e->size.y * e->size.y)) +
+              ((dir.z * dir.z) / (e->size.z * e->size.z));
+    float b = ((2.f * O_C.x * dir.x) / (e->size.x * e->size.x)) + ((2.f * O_C.y * dir.y) / (e->size.y * e->size.y)) +
+              ((2.f * O_C.z * dir.z) / (e->size.z * e->size.z));
+    float c = ((O_C.x * O_C.x) / (e->size.x * e->size.x)) + ((O_C.y * O_C.y) / (e->size.y * e->size.y)) +
+              ((O_C.z * O_C.z) / (e->size.z * e->size.z)) - 1.f;
+    float d = ((b * b) - (4.f * a * c));
+    if (d < 0.f || a == 0.f || b == 0.f || c == 0.f)
+        return 0;
+    d = sqrtf(d);
+    float t1 = (-b + d) / (2.f * a);
+    float t2 = (-b - d) / (2.f * a);
+    if (t1 <= si->geometryEpsilon && t2 <= si->geometryEpsilon)
+        return 0;
+    float t = 0.f;
+    if (t1 <= si->geometryEpsilon)
+        t = t2;
+    else if (t2 <= si->geometryEpsilon)
+        t = t1;
+    else
+        t = (t1 < t2) ? t1 : t2;
+    if (t < si->geometryEpsilon)
+        return 0;
+    *intersection = vadd(ray->origin, vscale(dir, t));
+    v3 n = vsub(*intersection, e->p0);
+    n.x = 2.f * n.x / (e->size.x * e->size.x);
+    n.y = 2.f * n.y / (e->size.y * e->size.y);
+    n.z = 2.f * n.z / (e->size.z * e->size.z);
+    *normal = vnormalize(n);
+    return 1;
+}
+
+/* ref GI:220-284 */
+static int sphereIntersection(const SceneInfo *si, const Primitive *sphere, const Material *materials,
+                              const Ray *ray, v3 *intersection, v3 *normal, float *shadowIntensity)
+{
+    int back = 0;
+    v3 O_C = vsub(ray->origin, sphere->p0);
+    v3 dir = vnormalize(ray->direction);
+    float a = 2.f * vdot(dir, dir);
+    float b = 2.f * vdot(O_C, dir);
+    float c = vdot(O_C, O_C) - (sphere->size.x * sphere->size.x);
+    float d = b * b - 2.f * a * c;
+    if (d <= 0.f || a == 0.f)
+        return 0;
+    float r = sqrtf(d);
+    float t1 = (-b - r) / a;
+    float t2 = (-b + r) / a;
+    if (t1 <= si->geometryEpsilon && t2 <= si->geometryEpsilon)
+        return 0;
+    float t = 0.f;
+    if (t1 <= si->geometryEpsilon)
+    {
+        t = t2;
+        back = 1;
+    }
+    else if (t2 <= si->geometryEpsilon)
+        t = t1;
+    else
+        t = (t1 < t2) ? t1 : t2;
+    if (t < si->geometryEpsilon)
+        return 0;
+    *intersection = vadd(ray->origin, vscale(dir, t));
+    v3 n;
+    if (materials[sphere->materialId].attributes.y == 0)
+        n = vsub(*intersection, sphere->p0);
+    else
+    {
+        /* procedural bumps, GI:268-273: timestamp (int) + coordinate (float) in binary32 */
+        v3 newCenter;
+        newCenter.x = sphere->p0.x + 0.008f * sphere->size.x * cosf(si->timestamp + intersection->x);
+        newCenter.y = sphere->p0.y + 0.008f * sphere->size.y * sinf(si->timestamp + intersection->y);
+        newCenter.z = sphere->p0.z + 0.008f * sphere->size.z * sinf(cosf(si->timestamp + intersection->z));
+        n = vsub(*intersection, newCenter);
+    }
+    n = vnormalize(n);
+    if (back)
+        n = vscale(n, -1.f);
+    *normal = n;
+    r = vdot(dir, n);
+    *shadowIntensity = (materials[sphere->materialId].transparency != 0.f) ? (1.f - fabsf(r)) : 1.f;
+    return 1;
+}
+
+/* ref GI:293-349 (cylinder) and GI:358-416 (cone: identical arithmetic) */
+static int cylinderIntersection(const SceneInfo *si, const Primitive *cyl, const Ray *ray, v3 *intersection,
+                                v3 *normal, float *shadowIntensity)
+{
+    v3 O_C = vsub(ray->origin, cyl->p0);
+    v3 dir = ray->direction;
+    v3 n = crossProduct(dir, cyl->n1);
+    float ln = vlength(n);
+    if ((ln < si->geometryEpsilon) && (ln > -si->geometryEpsilon))
+        return 0;
+    n = vnormalize(n);
+    float d = fabsf(vdot(O_C, n));
+    if (d > cyl->size.y)
+        return 0;
+    v3 O = crossProduct(O_C, cyl->n1);
+    float t = -vdot(O, n) / ln;
+    if (t < 0.f)
+        return 0;
+    O = vnormalize(crossProduct(n, cyl->n1));
+    float s = fabsf(sqrtf(cyl->size.x * cyl->size.x - d * d) / vdot(dir, O));
+    float t1 = t - s;
+    float t2 = t + s;
+    *intersection = vadd(ray->origin, vscale(dir, t1));
+    v3 HB1 = vsub(*intersection, cyl->p0);
+    v3 HB2 = vsub(*intersection, cyl->p1);
+    float scale1 = vdot(HB1, cyl->n1);
+    float scale2 = vdot(HB2, cyl->n1);
+    if (scale1 < si->geometryEpsilon || scale2 > si->geometryEpsilon)
+    {
+        *intersection = vadd(ray->origin, vscale(dir, t2));
+        HB1 = vsub(*intersection, cyl->p0);
+        HB2 = vsub(*intersection, cyl->p1);
+        scale1 = vdot(HB1, cyl->n1);
+        scale2 = vdot(HB2, cyl->n1);
+        if (scale1 < si->geometryEpsilon || scale2 > si->geometryEpsilon)
+            return 0;
+    }
+    v3 Vv = vsub(*intersection, cyl->p2);
+    *normal = vnormalize(vsub(Vv, project(Vv, cyl->n1)));
+    *shadowIntensity = 1.f;
+    return 1;
+}
+
+/* one side of an axis plane (GI:439-445, 451-461, 479-494, 518-528) */
+#define PLANE_HIT(U, V_, W_)                                                                                     \
+    do                                                                                                           \
+    {                                                                                                            \
+        float k = ray->origin.W_ - primitive->p0.W_;                                                             \
+        intersection->U = ray->origin.U + k * ray->direction.U / -ray->direction.W_;                             \
+        intersection->W_ = primitive->p0.W_;                                                                     \
+        intersection->V_ = ray->origin.V_ + k * ray->direction.V_ / -ray->direction.W_;                          \
+        collision = fabsf(intersection->U - primitive->p0.U) < primitive->size.U &&                              \
+                    fabsf(intersection->V_ - primitive->p0.V_) < primitive->size.V_;                             \
+    } while (0)
+
+/* ref GI:424-567 */
+static int planeIntersection(const SceneInfo *si, const Primitive *primitive, const Material *materials,
+                             const BitmapBuffer *textures, const Ray *ray, v3 *intersection, v3 *normal,
+                             float *shadowIntensity, int reverse)
+{
+    int collision = 0;
+    float reverted = reverse ? -1.f : 1.f;
+    const Material *mat = &materials[primitive->materialId];
+    *normal = primitive->n0;
+    switch (primitive->type)
+    {
+    case ptMagicCarpet:
+    case ptCheckboard:
+    {
+        intersection->y = primitive->p0.y;
+        float y = ray->origin.y - primitive->p0.y;
+        if (reverted * ray->direction.y < 0.f && reverted * ray->origin.y > reverted * primitive->p0.y)
+        {
+            intersection->x = ray->origin.x + y * ray->direction.x / -ray->direction.y;
+            intersection->z = ray->origin.z + y * ray->direction.z / -ray->direction.y;
+            collision = fabsf(intersection->x - primitive->p0.x) < primitive->size.x &&
+                        fabsf(intersection->z - primitive->p0.z) < primitive->size.z;
+        }
+        break;
+    }
+    case ptXZPlane:
+    {
+        if (reverted * ray->direction.y < 0.f && reverted * ray->origin.y > reverted * primitive->p0.y)
+        {
+            PLANE_HIT(x, z, y);
+            if (mat->attributes.z == 2)
+                collision &= wireFrameMapping(intersection->x, intersection->z, mat->attributes.w);
+        }
+        if (!collision && reverted * ray->direction.y > 0.f && reverted * ray->origin.y < reverted * primitive->p0.y)
+        {
+            *normal = vneg(*normal);
+            PLANE_HIT(x, z, y);
+            if (mat->attributes.z == 2)
+                collision &= wireFrameMapping(intersection->x, intersection->z, mat->attributes.w);
+        }
+        break;
+    }
+    case ptYZPlane:
+    {
+        if (reverted * ray->direction.x < 0.f && reverted * ray->origin.x > reverted * primitive->p0.x)
+        {
+            PLANE_HIT(y, z, x);
+            if (mat->innerIllumination.x != 0.f)
+                collision &= (int)fabsf(intersection->z) % 4000 < 2000 && (int)fabsf(intersection->y) % 4000 < 2000;
+            if (mat->attributes.z == 2)
+                collision &= wireFrameMapping(intersection->y, intersection->z, mat->attributes.w);
+        }
+        if (!collision && reverted * ray->direction.x > 0.f && reverted * ray->origin.x < reverted * primitive->p0.x)
+        {
+            *normal = vneg(*normal);
+            PLANE_HIT(y, z, x);
+            if (mat->innerIllumination.x != 0.f)
+                collision &= (int)fabsf(intersection->z) % 4000 < 2000 && (int)fabsf(intersection->y) % 4000 < 2000;
+            if (mat->attributes.z == 2)
+                collision &= wireFrameMapping(intersection->y, intersection->z, mat->attributes.w);
+        }
+        break;
+    }
+    case ptXYPlane:
+    case ptCamera:
+    {
+        if (reverted * ray->direction.z < 0.f && reverted * ray->origin.z > reverted * primitive->p0.z)
+        {
+            PLANE_HIT(x, y, z);
+            if (mat->attributes.z == 2)
+                collision &= wireFrameMapping(intersection->x, intersection->y, mat->attributes.w);
+        }
+        if (!collision && reverted * ray->direction.z > 0.f && reverted * ray->origin.z < reverted * primitive->p0.z)
+        {
+            *normal = vneg(*normal);
+            PLANE_HIT(x, y, z);
+            if (mat->attributes.z == 2)
+                collision &= wireFrameMapping(intersection->x, intersection->y, mat->attributes.w);
+        }
+        break;
+    }
+    default:
+        break;
+    }
+
+    if (collision)
+    {
+        *shadowIntensity = 1.f;
+        f4 color = colorOf(mat);
+        if (primitive->type == ptCamera || mat->textureIds.x != TEXTURE_NONE)
+        {
+            f4 specular = {0.f, 0.f, 0.f, 0.f};
+            f4 attributes = {0.f, 0.f, 0.f, 0.f};
+            f4 advancedAttributes = {0.f, 0.f, 0.f, 0.f};
+            color = cubeMapping(si, primitive, materials, textures, *intersection, normal, &specular, &attributes,
+                                &advancedAttributes);
+            *shadowIntensity = color.w;
+        }
+        if ((color.x + color.y + color.z) / 3.f >= si->transparentColor)
+            collision = 0;
+    }
+    return collision;
+}
+
+/* ref GI:575-659 */
+static int triangleIntersection(const SceneInfo *si, const Primitive *tri, const Ray *ray, v3 *intersection,
+                                v3 *normal, v3 *areas, float *shadowIntensity, int processingShadows)
+{
+    v3 E01 = vsub(tri->p1, tri->p0);
+    v3 E03 = vsub(tri->p2, tri->p0);
+    v3 P = crossProduct(ray->direction, E03);
+    float det = vdot(E01, P);
+    if (fabsf(det) < si->geometryEpsilon)
+        return 0;
+    v3 T = vsub(ray->origin, tri->p0);
+    float a = vdot(T, P) / det;
+    if (a < 0.f || a > 1.f)
+        return 0;
+    v3 Q = crossProduct(T, E01);
+    float b = vdot(ray->direction, Q) / det;
+    if (b < 0.f || b > 1.f)
+        return 0;
+    if ((a + b) > 1.f)
+    {
+        /* GI:603-616: E21 = p1 - p1 is the zero vector (sic) */
+        v3 E23 = vsub(tri->p0, tri->p1);
+        v3 E21 = vsub(tri->p1, tri->p1);
+        v3 P_ = crossProduct(ray->direction, E21);
+        float det_ = vdot(E23, P_);
+        if (fabsf(det_) < si->geometryEpsilon)
+            return 0;
+        v3 T_ = vsub(ray->origin, tri->p2);
+        float a_ = vdot(T_, P_) / det_;
+        if (a_ < 0.f)
+            return 0;
+        v3 Q_ = crossProduct(T_, E23);
+        float b_ = vdot(ray->direction, Q_) / det_;
+        if (b_ < 0.f)
+            return 0;
+    }
+    float t = vdot(E03, Q) / det;
+    if (t < 0)
+        return 0;
+    *intersection = vadd(ray->origin, vscale(ray->direction, t));
+    v3 v0 = vsub(tri->p0, *intersection);
+    v3 v1 = vsub(tri->p1, *intersection);
+    v3 v2 = vsub(tri->p2, *intersection);
+    areas->x = 0.5f * vlength(crossProduct(v1, v2));
+    areas->y = 0.5f * vlength(crossProduct(v0, v2));
+    areas->z = 0.5f * vlength(crossProduct(v0, v1));
+    v3 wn = vadd(vadd(vscale(tri->n0, areas->x), vscale(tri->n1, areas->y)), vscale(tri->n2, areas->z));
+    *normal = vnormalize(vdivs(wn, areas->x + areas->y + areas->z));
+    if (si->doubleSidedTriangles)
+    {
+        /* GI:643-647: the else binds to the inner if */
+        v3 N = vnormalize(ray->direction);
+        if (processingShadows)
+        {
+            if (vdot(N, *normal) <= 0.f)
+                return 0;
+            else if (vdot(N, *normal) >= 0.f)
+                return 0;
+        }
+    }
+    v3 dir = vnormalize(ray->direction);
+    float r = vdot(dir, *normal);
+    if (r > 0.f)
+        *normal = vscale(*normal, -1.f);
+    *shadowIntensity = 1.f;
+    return 1;
+}
+
+/* dispatch of the closest-hit walk, GI:712-747 */
+static inline int testPrimitive(const SceneInfo *si, const Primitive *primitive, const Material *materials,
+                                const BitmapBuffer *textures, const Ray *r, v3 *intersection, v3 *normal, v3 *areas,
+                                float *shadowIntensity)
+{
+    if (si->extendedGeometry)
+    {
+        switch (primitive->type)
+        {
+        case ptEnvironment:
+        case ptSphere:
+            return sphereIntersection(si, primitive, materials, r, intersection, normal, shadowIntensity);
+        case ptCylinder:
+        case ptCone:
+            return cylinderIntersection(si, primitive, r, intersection, normal, shadowIntensity);
+        case ptEllipsoid:
+            return ellipsoidIntersection(si, primitive, r, intersection, normal, shadowIntensity);
+        case ptTriangle:
+            return triangleIntersection(si, primitive, r, intersection, normal, areas, shadowIntensity, 0);
+        default:
+            return planeIntersection(si, primitive, materials, textures, r, intersection, normal, shadowIntensity,
+                                     0);
+        }
+    }
+    return triangleIntersection(si, primitive, r, intersection, normal, areas, shadowIntensity, 0);
+}
+
+/* dispatch of the shadow walk, GI:833-870 */
+static inline int testPrimitiveShadow(const SceneInfo *si, const Primitive *primitive, const Material *materials,
+                                      const BitmapBuffer *textures, const Ray *r, v3 *intersection, v3 *normal,
+                                      v3 *areas, float *shadowIntensity)
+{
+    if (si->extendedGeometry)
+    {
+        switch (primitive->type)
+        {
+        case ptSphere:
+            return sphereIntersection(si, primitive, materials, r, intersection, normal, shadowIntensity);
+        case ptEllipsoid:
+            return ellipsoidIntersection(si, primitive, r, intersection, normal, shadowIntensity);
+        case ptCylinder:
+        case ptCone:
+            return cylinderIntersection(si, primitive, r, intersection, normal, shadowIntensity);
+        case ptTriangle:
+            return triangleIntersection(si, primitive, r, intersection, normal, areas, shadowIntensity, 1);
+        case ptCamera:
+            return 0;
+        default:
+            return planeIntersection(si, primitive, materials, textures, r, intersection, normal, shadowIntensity,
+                                     0);
+        }
+    }
+    return triangleIntersection(si, primitive, r, intersection, normal, areas, shadowIntensity, 1);
+}
+
+int oracle_primitive_intersection(const SceneInfo *sceneInfo, const Primitive *primitive, const Material *materials,
+                                  const BitmapBuffer *textures, const float origin[3], const float direction[3],
+                                  int processingShadows, float intersection[3], float normal[3], float areas[3],
+                                  float *shadowIntensity)
+{
+    Ray r;
+    r.origin = V(origin[0], origin[1], origin[2]);
+    r.direction = V(direction[0], direction[1], direction[2]);
+    computeRayAttributes(&r);
+    v3 i = V(intersection[0], intersection[1], intersection[2]);
+    v3 n = V(normal[0], normal[1], normal[2]);
+    v3 a = V(0.f, 0.f, 0.f);
+    int hit = processingShadows
+                  ? testPrimitiveShadow(sceneInfo, primitive, materials, textures, &r, &i, &n, &a, shadowIntensity)
+                  : testPrimitive(sceneInfo, primitive, materials, textures, &r, &i, &n, &a, shadowIntensity);
+    intersection[0] = i.x;
+    intersection[1] = i.y;
+    intersection[2] = i.z;
+    normal[0] = n.x;
+    normal[1] = n.y;
+    normal[2] = n.z;
+    areas[0] = a.x;
+    areas[1] = a.y;
+    areas[2] = a.z;
+    return hit;
+}
+
+/* ref GI:667-772 */
+static int intersectionWithPrimitives(const OracleScene *s, const SceneInfo *si, const Ray *ray, int iteration,
+                                      int *closestPrimitive, v3 *closestIntersection, v3 *closestNormal,
+                                      v3 *closestAreas, c3 *colorBox, int currentMaterialId, Stats *st)
+{
+    int intersections = 0;
+    float minDistance = (iteration < 2) ? si->viewDistance : si->viewDistance / (iteration + 1);
+    Ray r;
+    r.origin = ray->origin;
+    r.direction = vsub(ray->direction, ray->origin);
+    computeRayAttributes(&r);
+
+    v3 intersection = {0.f, 0.f, 0.f};
+    v3 normal = {0.f, 0.f, 0.f};
+    int i = 0;
+    float shadowIntensity = 0.f;
+    st->closest++;
+
+    int cptBoxes = 0;
+    while (cptBoxes < s->nbBoxes)
+    {
+        const BoundingBox *box = &s->boxes[cptBoxes];
+        st->boxes++;
+        if (boxIntersection(box, &r, 0.f, minDistance))
+        {
+            if (si->renderBoxes != 0)
+            {
+                /* GI:695: NB_MAX_MATERIALS is unsigned in the reference */
+                const Material *m = &s->materials[(unsigned)box->startIndex % (unsigned)NB_MAX_MATERIALS];
+                colorBox->x += m->color.x / 200.f;
+                colorBox->y += m->color.y / 200.f;
+                colorBox->z += m->color.z / 200.f;
+            }
+            else
+            {
+                for (int cptPrimitives = 0; cptPrimitives < box->nbPrimitives; ++cptPrimitives)
+                {
+                    const Primitive *primitive = &s->primitives[box->startIndex + cptPrimitives];
+                    const Material *material = &s->materials[primitive->materialId];
+                    if (material->attributes.x == 0 ||
+                        (material->attributes.x == 1 && currentMaterialId != primitive->materialId))
+                    {
+                        v3 areas = {0.f, 0.f, 0.f};
+                        st->prims++;
+                        i = testPrimitive(si, primitive, s->materials, s->textures, &r, &intersection, &normal,
+                                          &areas, &shadowIntensity);
+                        float distance = vlength(vsub(intersection, r.origin));
+                        if (i && distance > si->geometryEpsilon && distance < minDistance)
+                        {
+                            minDistance = distance;
+                            *closestPrimitive = box->startIndex + cptPrimitives;
+                            *closestIntersection = intersection;
+                            *closestNormal = normal;
+                            *closestAreas = areas;
+                            intersections = 1;
+                        }
+                    }
+                }
+            }
+            ++cptBoxes;
+        }
+        else
+            cptBoxes += box->indexForNextBox.x;
+    }
+    return intersections;
+}
+
+int oracle_closest_hit(const OracleScene *scene, const SceneInfo *sceneInfo, const float origin[3],
+                       const float target[3], int iteration, int currentMaterialId, int *closestPrimitive,
+                       float closestIntersection[3], float closestNormal[3], float closestAreas[3])
+{
+    Ray ray;
+    Stats st;
+    memset(&st, 0, sizeof(st));
+    ray.origin = V(origin[0], origin[1], origin[2]);
+    ray.direction = V(target[0], target[1], target[2]);
+    v3 ci = V(closestIntersection[0], closestIntersection[1], closestIntersection[2]);
+    v3 cn = V(closestNormal[0], closestNormal[1], closestNormal[2]);
+    v3 ca = V(closestAreas[0], closestAreas[1], closestAreas[2]);
+    c3 colorBox = {0.f, 0.f, 0.f};
+    int hit = intersectionWithPrimitives(scene, sceneInfo, &ray, iteration, closestPrimitive, &ci, &cn, &ca,
+                                         &colorBox, currentMaterialId, &st);
+    closestIntersection[0] = ci.x;
+    closestIntersection[1] = ci.y;
+    closestIntersection[2] = ci.z;
+    closestNormal[0] = cn.x;
+    closestNormal[1] = cn.y;
+    closestNormal[2] = cn.z;
+    closestAreas[0] = ca.x;
+    closestAreas[1] = ca.y;
+    closestAreas[2] = ca.z;
+    return hit;
+}
+
+/* ref GI:798-908.  objectId is the FLATTENED index of the shaded primitive,
+ * compared against Primitive.index (the original index), exactly as the
+ * reference does (GI:829, call site GI:995-997). */
+static float processShadows(const OracleScene *s, const SceneInfo *si, v3 lampCenter, v3 origin, int lightId,
+                            int iteration, c3 *color, int objectId, Stats *st)
+{
+    float result = 0.f;
+    int cptBoxes = 0;
+    color->x = 0.f;
+    color->y = 0.f;
+    color->z = 0.f;
+    Ray r;
+    r.direction = vsub(lampCenter, origin);
+    r.origin = vadd(origin, vscale(vnormalize(r.direction), si->rayEpsilon));
+    computeRayAttributes(&r);
+    const float minDistance = (iteration < 2) ? si->viewDistance : si->viewDistance / (iteration + 1);
+    st->shadow++;
+
+    while (result < (si->shadowIntensity) && cptBoxes < s->nbBoxes)
+    {
+        const BoundingBox *box = &s->boxes[cptBoxes];
+        st->boxes++;
+        if (boxIntersection(box, &r, 0.f, minDistance))
+        {
+            int cptPrimitives = 0;
+            while (result < si->shadowIntensity && cptPrimitives < box->nbPrimitives)
+            {
+                v3 intersection = {0.f, 0.f, 0.f};
+                v3 normal = {0.f, 0.f, 0.f};
+                v3 areas = {0.f, 0.f, 0.f};
+                float shadowIntensity = 0.f;
+                const Primitive *primitive = &s->primitives[box->startIndex + cptPrimitives];
+                const Material *pm = &s->materials[primitive->materialId];
+                if (primitive->index != lightId && primitive->index != objectId && pm->attributes.x == 0)
+                {
+                    st->prims++;
+                    int hit = testPrimitiveShadow(si, primitive, s->materials, s->textures, &r, &intersection,
+                                                  &normal, &areas, &shadowIntensity);
+                    if (hit)
+                    {
+                        v3 O_I = vsub(intersection, r.origin);
+                        v3 O_L = r.direction;
+                        float l = vlength(O_I);
+                        if (l > si->geometryEpsilon && l < vlength(O_L))
+                        {
+                            float ratio = shadowIntensity * si->shadowIntensity;
+                            if (pm->transparency != 0.f)
+                            {
+                                O_L = vnormalize(O_L);
+                                float a = fabsf(vdot(O_L, normal));
+                                float rr = (pm->transparency == 0.f) ? 1.f : (1.f - pm->transparency);
+                                ratio *= rr * a;
+                                color->x += ratio * (0.3f - 0.3f * pm->color.x);
+                                color->y += ratio * (0.3f - 0.3f * pm->color.y);
+                                color->z += ratio * (0.3f - 0.3f * pm->color.z);
+                            }
+                            result += ratio;
+                        }
+                    }
+                }
+                ++cptPrimitives;
+            }
+            ++cptBoxes;
+        }
+        else
+            cptBoxes += box->indexForNextBox.x;
+    }
+    /* GI:906: max/min are the float overloads on the device */
+    result = fmaxf(0.f, fminf(result, si->shadowIntensity));
+    return result;
+}
+
+float oracle_shadow(const OracleScene *scene, const SceneInfo *sceneInfo, const float lampCenter[3],
+                    const float origin[3], int lightId, int iteration, int objectId, float color[3])
+{
+    Stats st;
+    memset(&st, 0, sizeof(st));
+    c3 c;
+    float r = processShadows(scene, sceneInfo, V(lampCenter[0], lampCenter[1], lampCenter[2]),
+                             V(origin[0], origin[1], origin[2]), lightId, iteration, &c, objectId, &st);
+    color[0] = c.x;
+    color[1] = c.y;
+    color[2] = c.z;
+    return r;
+}
+
+/* ref GS:36-124.  normal here is the shader's bumpNormal accumulator. */
+static f4 intersectionShader(const SceneInfo *si, const Primitive *primitive, const Material *materials,
+                             const BitmapBuffer *textures, v3 intersection, v3 areas, v3 *normal, f4 *specular,
+                             f4 *attributes, f4 *advancedAttributes)
+{
+    const Material *m = &materials[primitive->materialId];
+    f4 c = colorOf(m);
+    c.w = 0.f;
+    if (si->extendedGeometry)
+    {
+        switch (primitive->type)
+        {
+        case ptCone:
+        case ptCylinder:
+        case ptEnvironment:
+        case ptSphere:
+        case ptEllipsoid:
+            if (m->textureIds.x != TEXTURE_NONE)
+                c = sphereUVMapping(primitive, materials, textures, intersection, normal, specular, attributes,
+                                    advancedAttributes);
+            break;
+        case ptCheckboard:
+            if (m->textureIds.x != TEXTURE_NONE)
+                c = cubeMapping(si, primitive, materials, textures, intersection, normal, specular, attributes,
+                                advancedAttributes);
+            else
+            {
+                int x = (int)(si->viewDistance + ((intersection.x - primitive->p0.x) / primitive->size.x));
+                int z = (int)(si->viewDistance + ((intersection.z - primitive->p0.z) / primitive->size.x));
+                if (x % 2 == 0)
+                {
+                    if (z % 2 == 0)
+                    {
+                        c.x = 1.f - c.x;
+                        c.y = 1.f - c.y;
+                        c.z = 1.f - c.z;
+                    }
+                }
+                else
+                {
+                    if (z % 2 != 0)
+                    {
+                        c.x = 1.f - c.x;
+                        c.y = 1.f - c.y;
+                        c.z = 1.f - c.z;
+                    }
+                }
+            }
+            break;
+        case ptXYPlane:
+        case ptYZPlane:
+        case ptXZPlane:
+        case ptCamera:
+            if (m->textureIds.x != TEXTURE_NONE)
+                c = cubeMapping(si, primitive, materials, textures, intersection, normal, specular, attributes,
+                                advancedAttributes);
+            break;
+        case ptTriangle:
+            if (m->textureIds.x != TEXTURE_NONE)
+                c = triangleUVMapping(si, primitive, materials, textures, areas, normal, specular, attributes,
+                                      advancedAttributes);
+            break;
+        default:
+            break;
+        }
+    }
+    else
+    {
+        if (m->textureIds.x != TEXTURE_NONE)
+            c = triangleUVMapping(si, primitive, materials, textures, areas, normal, specular, attributes,
+                                  advancedAttributes);
+    }
+    return c;
+}
+
+/* ref GI:916-1080.  closestColor, totalBlinn and normal are in/out and
+ * persist across bounces. */
+static c3 primitiveShader(const OracleScene *s, int index, const SceneInfo *si, v3 origin, v3 *normal, int objectId,
+                          v3 intersection, v3 areas, c3 *closestColor, int iteration, float *shadowIntensity,
+                          c3 *totalBlinn, f4 *attributes, Stats *st)
+{
+    const Primitive *primitive = &s->primitives[objectId];
+    const Material *material = &s->materials[primitive->materialId];
+    c3 lampsColor = {0.f, 0.f, 0.f};
+    *shadowIntensity = 0.f;
+    v3 bumpNormal = {0.f, 0.f, 0.f};
+    f4 advancedAttributes = {0.f, 0.f, 0.f, 0.f};
+    f4 specular;
+    specular.x = material->specular.x;
+    specular.y = material->specular.y;
+    specular.z = material->specular.z;
+    specular.w = 0.f;
+
+    f4 ic4 = intersectionShader(si, primitive, s->materials, s->textures, intersection, areas, &bumpNormal, &specular,
+                                attributes, &advancedAttributes);
+    c3 intersectionColor = {ic4.x, ic4.y, ic4.z};
+    *normal = vadd(*normal, bumpNormal);
+    *normal = vnormalize(*normal);
+
+    if (material->attributes.z == 1)
+        return intersectionColor; /* wireframe: constant colour */
+
+    if (si->graphicsLevel > glNoShading)
+    {
+        closestColor->x *= material->innerIllumination.x;
+        closestColor->y *= material->innerIllumination.x;
+        closestColor->z *= material->innerIllumination.x;
+        for (int cpt = 0; cpt < s->nbLights; ++cpt)
+        {
+            /* GI:958-960: lamp 0 is applied nbLights times below iteration 10 */
+            int cptLamp = (si->pathTracingIteration >= NB_MAX_ITERATIONS) ? (si->pathTracingIteration % s->nbLights) : 0;
+            const LightInformation *li = &s->lights[cptLamp];
+            if (li->primitiveId != primitive->index)
+            {
+                v3 center = li->location;
+                int t = (index + si->timestamp) % (MAX_BITMAP_SIZE - 3);
+                const Material *m = &s->materials[li->materialId];
+                if (si->pathTracingIteration >= NB_MAX_ITERATIONS)
+                {
+                    float a = m->innerIllumination.y * 10.f * si->pathTracingIteration / si->maxPathTracingIterations;
+                    center.x += rnd(s, t, st) * a;
+                    center.y += rnd(s, t + 1, st) * a;
+                    center.z += rnd(s, t + 2, st) * a;
+                }
+                v3 lightRay = vsub(center, intersection);
+                float lightRayLength = vlength(lightRay);
+                if (lightRayLength < m->innerIllumination.z)
+                {
+                    c3 shadowColor = {0.f, 0.f, 0.f};
+                    lightRay = vnormalize(lightRay);
+                    float lambert = material->innerIllumination.x + vdot(*normal, lightRay);
+                    if (lambert > 0.f && si->graphicsLevel > 3 && iteration < 4 && material->innerIllumination.x == 0.f)
+                        *shadowIntensity = processShadows(s, si, center, intersection, li->primitiveId, iteration,
+                                                          &shadowColor, objectId, st);
+                    if (si->graphicsLevel > glNoShading)
+                    {
+                        float photonEnergy = sqrtf(lightRayLength / m->innerIllumination.z);
+                        photonEnergy = (photonEnergy > 1.f) ? 1.f : photonEnergy;
+                        photonEnergy = (photonEnergy < 0.f) ? 0.f : photonEnergy;
+                        lambert *= (lambert < 0.f) ? -s->materials[primitive->materialId].transparency : 1.f;
+                        if (li->materialId != MATERIAL_NONE)
+                            lambert *= s->materials[li->materialId].innerIllumination.x;
+                        else
+                            lambert *= li->color.w;
+                        if (material->innerIllumination.w != 0.f)
+                            lambert *= (1.f + rnd(s, t, st) * material->innerIllumination.w * 100.f);
+                        lambert *= (1.f - *shadowIntensity);
+                        lambert += si->backgroundColor.w;
+                        lambert *= (1.f - photonEnergy);
+                        lampsColor.x += lambert * li->color.x - shadowColor.x;
+                        lampsColor.y += lambert * li->color.y - shadowColor.y;
+                        lampsColor.z += lambert * li->color.z - shadowColor.z;
+                        if (si->graphicsLevel > 1 && *shadowIntensity < si->shadowIntensity)
+                        {
+                            v3 viewRay = vnormalize(vsub(intersection, origin));
+                            v3 blinnDir = vsub(lightRay, viewRay);
+                            float temp = sqrtf(vdot(blinnDir, blinnDir));
+                            if (temp != 0.f)
+                            {
+                                blinnDir = vscale(blinnDir, 1.f / temp);
+                                float blinnTerm = vdot(blinnDir, *normal);
+                                blinnTerm = (blinnTerm < 0.f) ? 0.f : blinnTerm;
+                                blinnTerm = specular.x * powf(blinnTerm, specular.y);
+                                blinnTerm *= (1.f - photonEnergy);
+                                totalBlinn->x += li->color.x * li->color.w * blinnTerm;
+                                totalBlinn->y += li->color.y * li->color.w * blinnTerm;
+                                totalBlinn->z += li->color.z * li->color.w * blinnTerm;
+                            }
+                        }
+                    }
+                }
+            }
+            closestColor->x += intersectionColor.x * lampsColor.x;
+            closestColor->y += intersectionColor.y * lampsColor.y;
+            closestColor->z += intersectionColor.z * lampsColor.z;
+            if (material->advancedTextureIds.z != TEXTURE_NONE)
+            {
+                closestColor->x *= advancedAttributes.x;
+                closestColor->y *= advancedAttributes.x;
+                closestColor->z *= advancedAttributes.x;
+            }
+            saturate3(closestColor);
+            saturate3(totalBlinn);
+        }
+    }
+    else
+        *closestColor = intersectionColor;
+    return *closestColor;
+}
+
+/* ref CRT:69-408 */
+static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, const SceneInfo *si, float *depthOfField,
+                           PrimitiveXYIdBuffer *primitiveXYId, Stats *st)
+{
+    c3 intersectionColor = {0.f, 0.f, 0.f};
+    v3 closestIntersection = {0.f, 0.f, 0.f};
+    v3 firstIntersection = {0.f, 0.f, 0.f};
+    v3 normal = {0.f, 0.f, 0.f};
+    int closestPrimitive = -1;
+    int carryon = 1;
+    Ray rayOrigin = *ray;
+    float initialRefraction = 1.f;
+    int iteration = 0;
+    primitiveXYId->x = -1;
+    primitiveXYId->z = 0;
+    primitiveXYId->w = 0;
+    int currentMaterialId = -2;
+
+    float colorContributions[NB_MAX_ITERATIONS + 1];
+    c3 colors[NB_MAX_ITERATIONS + 1];
+    memset(colorContributions, 0, sizeof(colorContributions));
+    memset(colors, 0, sizeof(colors));
+
+    c3 recursiveBlinn = {0.f, 0.f, 0.f};
+    float shadowIntensity = 0.f;
+    v3 reflectedTarget = {0.f, 0.f, 0.f};
+    c3 closestColor = {0.f, 0.f, 0.f};
+    c3 colorBox = {0.f, 0.f, 0.f};
+    v3 latestIntersection = ray->origin;
+    float rayLength = 0.f;
+    *depthOfField = si->viewDistance;
+
+    int reflectedRays = -1;
+    Ray reflectedRay;
+    float reflectedRatio = 0.f;
+    memset(&reflectedRay, 0, sizeof(reflectedRay));
+
+    Ray pathTracingRay;
+    memset(&pathTracingRay, 0, sizeof(pathTracingRay)); /* uninitialised in the reference (UB); zero here */
+    float pathTracingRatio = 0.f;
+    c3 pathTracingColor = {0.f, 0.f, 0.f};
+    int useGlobalIllumination = 0;
+
+    c3 rBlinn = {0.f, 0.f, 0.f};
+    int currentMaxIteration =
+        (si->graphicsLevel < glReflectionsAndRefractions) ? 1 : si->nbRayIterations + si->pathTracingIteration;
+    currentMaxIteration = (currentMaxIteration > NB_MAX_ITERATIONS) ? NB_MAX_ITERATIONS : currentMaxIteration;
+
+    while (iteration < currentMaxIteration && rayLength < si->viewDistance && carryon)
+    {
+        v3 areas = {0.f, 0.f, 0.f};
+        if (carryon)
+            carryon = intersectionWithPrimitives(s, si, &rayOrigin, iteration, &closestPrimitive, &closestIntersection,
+                                                 &normal, &areas, &colorBox, currentMaterialId, st);
+        if (carryon)
+        {
+            const Primitive *cp = &s->primitives[closestPrimitive];
+            const Material *cm = &s->materials[cp->materialId];
+            currentMaterialId = cp->materialId;
+
+            f4 attributes;
+            attributes.x = cm->reflection;
+            attributes.y = cm->transparency;
+            attributes.z = cm->refraction;
+            attributes.w = cm->opacity;
+
+            if (iteration == 0)
+            {
+                colors[iteration].x = 0.f;
+                colors[iteration].y = 0.f;
+                colors[iteration].z = 0.f;
+                colorContributions[iteration] = 1.f;
+                firstIntersection = closestIntersection;
+                latestIntersection = closestIntersection;
+                *depthOfField = vlength(vsub(firstIntersection, ray->origin));
+
+                if (cm->innerIllumination.x == 0.f &&
+                    (si->advancedIllumination == aiBasic || si->advancedIllumination == aiFull))
+                {
+                    int t = (index + si->pathTracingIteration * 100 + si->timestamp) % (MAX_BITMAP_SIZE - 3);
+                    pathTracingRay.origin = vadd(closestIntersection, vscale(normal, si->rayEpsilon));
+                    pathTracingRay.direction.x = normal.x + 100.f * rnd(s, t, st);
+                    pathTracingRay.direction.y = normal.y + 100.f * rnd(s, t + 1, st);
+                    pathTracingRay.direction.z = normal.z + 100.f * rnd(s, t + 2, st);
+                    float cos_theta = vdot(vnormalize(pathTracingRay.direction), normal);
+                    if (cos_theta < 0.f)
+                        pathTracingRay.direction = vneg(pathTracingRay.direction);
+                    pathTracingRay.direction = vadd(pathTracingRay.direction, closestIntersection);
+                    pathTracingRatio = (1.f - attributes.y) * fabsf(cos_theta);
+                    useGlobalIllumination = 1;
+                }
+                primitiveXYId->x = cp->index;
+            }
+
+            colors[iteration] = primitiveShader(s, index, si, rayOrigin.origin, &normal, closestPrimitive,
+                                                closestIntersection, areas, &closestColor, iteration,
+                                                &shadowIntensity, &rBlinn, &attributes, st);
+
+            /* CRT:190: int += float*int, evaluated in float then truncated */
+            primitiveXYId->z = (int)((float)primitiveXYId->z + cm->innerIllumination.x * 256);
+
+            float segmentLength = vlength(vsub(closestIntersection, latestIntersection));
+            latestIntersection = closestIntersection;
+
+            float transparency = attributes.y;
+            float a = 0.f;
+            if (attributes.y != 0.f)
+            {
+                float refraction = attributes.z;
+                if (initialRefraction == refraction)
+                {
+                    refraction = 1.f;
+                    float length = segmentLength * (attributes.w * (1.f - transparency));
+                    rayLength += length;
+                    rayLength = (rayLength > si->viewDistance) ? si->viewDistance : rayLength;
+                    a = (rayLength / si->viewDistance);
+                    colors[iteration].x -= a;
+                    colors[iteration].y -= a;
+                    colors[iteration].z -= a;
+                }
+                v3 O_E = vnormalize(vsub(closestIntersection, rayOrigin.origin));
+                reflectedTarget = vectorRefraction(O_E, refraction, normal, initialRefraction);
+                colorContributions[iteration] = transparency - a;
+                initialRefraction = refraction;
+                if (reflectedRays == -1 && attributes.x != 0.f)
+                {
+                    reflectedRay.direction = vectorReflection(O_E, normal);
+                    reflectedRay.origin = vadd(closestIntersection, vscale(reflectedRay.direction, si->rayEpsilon));
+                    reflectedRay.direction = vadd(closestIntersection, reflectedRay.direction);
+                    reflectedRatio = attributes.x;
+                    reflectedRays = iteration;
+                }
+            }
+            else if (attributes.x != 0.f)
+            {
+                v3 O_E = vnormalize(vsub(closestIntersection, rayOrigin.origin));
+                reflectedTarget = vectorReflection(O_E, normal);
+                colorContributions[iteration] = attributes.x;
+            }
+            else
+            {
+                carryon = 0;
+                colorContributions[iteration] = 1.f;
+            }
+
+            /* CRT:248: float4 /= int -> division by (float)(iteration+1) */
+            rBlinn.x /= (float)(iteration + 1);
+            rBlinn.y /= (float)(iteration + 1);
+            rBlinn.z /= (float)(iteration + 1);
+            recursiveBlinn.x = (rBlinn.x > recursiveBlinn.x) ? rBlinn.x : recursiveBlinn.x;
+            recursiveBlinn.y = (rBlinn.y > recursiveBlinn.y) ? rBlinn.y : recursiveBlinn.y;
+            recursiveBlinn.z = (rBlinn.z > recursiveBlinn.z) ? rBlinn.z : recursiveBlinn.z;
+
+            rayOrigin.origin = vadd(closestIntersection, vscale(reflectedTarget, si->rayEpsilon));
+            rayOrigin.direction = vadd(closestIntersection, reflectedTarget);
+
+            if (si->pathTracingIteration != 0 && cm->color.w != 0.f)
+            {
+                float ratio = cm->color.w;
+                ratio *= (attributes.y == 0.f) ? 1000.f : 1.f;
+                int rindex = (index + si->timestamp) % (MAX_BITMAP_SIZE - 3);
+                rayOrigin.direction.x += rnd(s, rindex, st) * ratio;
+                rayOrigin.direction.y += rnd(s, rindex + 1, st) * ratio;
+                rayOrigin.direction.z += rnd(s, rindex + 2, st) * ratio;
+            }
+        }
+        else
+        {
+            if (si->skyboxMaterialId != MATERIAL_NONE)
+            {
+                colors[iteration] = skyboxMapping(si, s->materials, s->textures, &rayOrigin);
+                float rad = colors[iteration].x + colors[iteration].y + colors[iteration].z;
+                primitiveXYId->z = (int)((float)primitiveXYId->z + ((rad > 2.5f) ? rad * 256.f : 0.f));
+            }
+            else if (si->gradientBackground)
+            {
+                v3 up = {0.f, 1.f, 0.f};
+                v3 dir = vnormalize(vsub(rayOrigin.direction, rayOrigin.origin));
+                float angle = 0.5f - vdot(up, dir);
+                angle = (angle > 1.f) ? 1.f : angle;
+                colors[iteration].x = (1.f - angle) * si->backgroundColor.x;
+                colors[iteration].y = (1.f - angle) * si->backgroundColor.y;
+                colors[iteration].z = (1.f - angle) * si->backgroundColor.z;
+            }
+            else
+            {
+                colors[iteration].x = si->backgroundColor.x;
+                colors[iteration].y = si->backgroundColor.y;
+                colors[iteration].z = si->backgroundColor.z;
+            }
+            colorContributions[iteration] = 1.f;
+        }
+        iteration++;
+    }
+
+    v3 areas = {0.f, 0.f, 0.f};
+    if (si->graphicsLevel >= glReflectionsAndRefractions && reflectedRays != -1)
+        if (intersectionWithPrimitives(s, si, &reflectedRay, reflectedRays, &closestPrimitive, &closestIntersection,
+                                       &normal, &areas, &colorBox, currentMaterialId, st))
+        {
+            f4 attributes = {0.f, 0.f, 0.f, 0.f}; /* only .x is set in the reference (CRT:305-306) */
+            attributes.x = s->materials[s->primitives[closestPrimitive].materialId].reflection;
+            c3 color = primitiveShader(s, index, si, reflectedRay.origin, &normal, closestPrimitive,
+                                       closestIntersection, areas, &closestColor, reflectedRays, &shadowIntensity,
+                                       &rBlinn, &attributes, st);
+            colors[reflectedRays].x += color.x * reflectedRatio;
+            colors[reflectedRays].y += color.y * reflectedRatio;
+            colors[reflectedRays].z += color.z * reflectedRatio;
+            primitiveXYId->w = (int)(shadowIntensity * 255);
+        }
+
+    int test = 1;
+    if ((si->advancedIllumination == aiBasic || si->advancedIllumination == aiFull) &&
+        si->pathTracingIteration >= NB_MAX_ITERATIONS)
+    {
+        if (useGlobalIllumination && si->advancedIllumination == aiFull)
+        {
+            if (intersectionWithPrimitives(s, si, &pathTracingRay, 30, &closestPrimitive, &closestIntersection,
+                                           &normal, &areas, &colorBox, MATERIAL_NONE, st))
+            {
+                if (s->primitives[closestPrimitive].materialId != MATERIAL_NONE)
+                {
+                    const Material *material = &s->materials[s->primitives[closestPrimitive].materialId];
+                    if (material->innerIllumination.x == 0.f)
+                    {
+                        colors[0].x = material->color.x * material->innerIllumination.x * pathTracingRatio;
+                        colors[0].y = material->color.y * material->innerIllumination.x * pathTracingRatio;
+                        colors[0].z = material->color.z * material->innerIllumination.x * pathTracingRatio;
+                        test = 0;
+                    }
+                    else
+                    {
+                        colors[0].x = material->color.x * pathTracingRatio;
+                        colors[0].y = material->color.y * pathTracingRatio;
+                        colors[0].z = material->color.z * pathTracingRatio;
+                    }
+                }
+                if (test)
+                {
+                    pathTracingRatio *= STANDARD_LUNINANCE_STRENGTH;
+                    f4 attributes = {0.f, 0.f, 0.f, 0.f};
+                    const Material *material = &s->materials[s->primitives[closestPrimitive].materialId];
+                    if (material->innerIllumination.x == 0.f)
+                    {
+                        colors[0].x -= si->shadowIntensity;
+                        colors[0].y -= si->shadowIntensity;
+                        colors[0].z -= si->shadowIntensity;
+                    }
+                    else
+                        pathTracingColor =
+                            primitiveShader(s, index, si, pathTracingRay.origin, &normal, closestPrimitive,
+                                            closestIntersection, areas, &closestColor, iteration, &shadowIntensity,
+                                            &rBlinn, &attributes, st);
+                }
+            }
+            else if (si->skyboxMaterialId != MATERIAL_NONE)
+            {
+                pathTracingColor = skyboxMapping(si, s->materials, s->textures, &pathTracingRay);
+                pathTracingRatio *= SKYBOX_LUNINANCE_STRENGTH;
+            }
+        }
+        else if (si->skyboxMaterialId != MATERIAL_NONE)
+        {
+            pathTracingColor = skyboxMapping(si, s->materials, s->textures, &pathTracingRay);
+            pathTracingRatio *= SKYBOX_LUNINANCE_STRENGTH;
+        }
+        if (test)
+        {
+            colors[0].x += pathTracingColor.x * pathTracingRatio;
+            colors[0].y += pathTracingColor.y * pathTracingRatio;
+            colors[0].z += pathTracingColor.z * pathTracingRatio;
+        }
+    }
+
+    if (test)
+    {
+        for (int i = iteration - 2; i >= 0; --i)
+        {
+            colors[i].x = colors[i].x * (1.f - colorContributions[i]) + colors[i + 1].x * colorContributions[i];
+            colors[i].y = colors[i].y * (1.f - colorContributions[i]) + colors[i + 1].y * colorContributions[i];
+            colors[i].z = colors[i].z * (1.f - colorContributions[i]) + colors[i + 1].z * colorContributions[i];
+        }
+        intersectionColor = colors[0];
+        intersectionColor.x += recursiveBlinn.x;
+        intersectionColor.y += recursiveBlinn.y;
+        intersectionColor.z += recursiveBlinn.z;
+    }
+    else
+        intersectionColor = colors[0];
+
+    float D1 = si->viewDistance * 0.95f;
+    if (si->atmosphericEffect == aeFog && *depthOfField > D1)
+    {
+        float D2 = si->viewDistance * 0.05f;
+        float a = *depthOfField - D1;
+        float b = 1.f - (a / D2);
+        intersectionColor.x = intersectionColor.x * b + si->backgroundColor.x * (1.f - b);
+        intersectionColor.y = intersectionColor.y * b + si->backgroundColor.y * (1.f - b);
+        intersectionColor.z = intersectionColor.z * b + si->backgroundColor.z * (1.f - b);
+    }
+
+    primitiveXYId->y = iteration;
+    intersectionColor.x -= colorBox.x;
+    intersectionColor.y -= colorBox.y;
+    intersectionColor.z -= colorBox.z;
+    return intersectionColor;
+}
+
+/* ref GS:132-165 */
+static void makeColor(const SceneInfo *si, c3 color, BitmapBuffer *bitmap, int index)
+{
+    int mdc_index = index * SOLR_COLOR_DEPTH;
+    color.x = (color.x > 1.f) ? 1.f : color.x;
+    color.y = (color.y > 1.f) ? 1.f : color.y;
+    color.z = (color.z > 1.f) ? 1.f : color.z;
+    color.x = (color.x < 0.f) ? 0.f : color.x;
+    color.y = (color.y < 0.f) ? 0.f : color.y;
+    color.z = (color.z < 0.f) ? 0.f : color.z;
+    switch (si->frameBufferType)
+    {
+    case ftBGR:
+    {
+        int y = index / si->size.y;
+        int x = index % si->size.x;
+        int i = (y + 1) * si->size.y - x - 1;
+        i *= SOLR_COLOR_DEPTH;
+        bitmap[i] = (BitmapBuffer)(color.z * 255.f);
+        bitmap[i + 1] = (BitmapBuffer)(color.y * 255.f);
+        bitmap[i + 2] = (BitmapBuffer)(color.x * 255.f);
+        break;
+    }
+    default:
+        bitmap[mdc_index] = (BitmapBuffer)(color.x * 255.f);
+        bitmap[mdc_index + 1] = (BitmapBuffer)(color.y * 255.f);
+        bitmap[mdc_index + 2] = (BitmapBuffer)(color.z * 255.f);
+        break;
+    }
+}
+
+void oracle_make_color(const SceneInfo *sceneInfo, const float color[3], BitmapBuffer *bitmap, int index)
+{
+    c3 c = {color[0], color[1], color[2]};
+    makeColor(sceneInfo, c, bitmap, index);
+}
+
+/* ref CRT:437-563 for one pixel.  yLocal is the row inside the strip,
+ * firstRow the reference's device_split.  Random indices use the GLOBAL pixel
+ * index so that an N-strip render equals the 1-strip render (deviation from
+ * the reference's strip-local index, which only matters when nbGPUs > 1). */
+static void standardRendererPixel(const OracleScene *s, const SceneInfo *si, const PostProcessingInfo *ppi, v3 origin,
+                                  v3 direction, const float angles[4], const Trig *trig, int x, int yLocal,
+                                  int firstRow, PostProcessingBuffer *pp, PrimitiveXYIdBuffer *ids, Stats *st)
+{
+    static const float AAx[4] = {3.f, 5.f, -3.f, -5.f};
+    static const float AAy[4] = {5.f, -3.f, -5.f, 3.f};
+    int index = yLocal * si->size.x + x;
+    int gindex = (firstRow + yLocal) * si->size.x + x;
+
+    if (si->pathTracingIteration > ids[index].y && ids[index].w == 0 && si->pathTracingIteration > 0 &&
+        si->pathTracingIteration <= NB_MAX_ITERATIONS)
+        return;
+
+    Ray ray;
+    memset(&ray, 0, sizeof(ray));
+    ray.origin = origin;
+    ray.direction = direction;
+    v3 rotationCenter = {0.f, 0.f, 0.f};
+    if (si->cameraType == ctVR)
+        rotationCenter = origin;
+    int antialiasingActivated = (si->cameraType == ctAntialiazed);
+
+    if (ppi->type != ppe_depthOfField && si->pathTracingIteration >= NB_MAX_ITERATIONS)
+    {
+        float a = (ppi->param1 / 20000.f);
+        long rindex = (long)gindex + si->timestamp % (MAX_BITMAP_SIZE - 2); /* CRT:475 precedence */
+        ray.origin.x += rnd(s, rindex, st) * pp[index].colorInfo.w * a;
+        ray.origin.y += rnd(s, rindex + 1, st) * pp[index].colorInfo.w * a;
+    }
+
+    float dof = 0.f;
+    int yGlobal = firstRow + yLocal;
+    if (si->cameraType == ctOrthographic)
+    {
+        ray.direction.x = ray.origin.z * 0.001f * (float)(x - (si->size.x / 2));
+        ray.direction.y = -ray.origin.z * 0.001f * (float)(yGlobal - (si->size.y / 2));
+        ray.origin.x = ray.direction.x;
+        ray.origin.y = ray.direction.y;
+    }
+    else
+    {
+        float ratio = (float)si->size.x / (float)si->size.y;
+        float stepx = ratio * angles[3] / (float)si->size.x;
+        float stepy = angles[3] / (float)si->size.y;
+        ray.direction.x = ray.direction.x - stepx * (float)(x - (si->size.x / 2));
+        ray.direction.y = ray.direction.y + stepy * (float)(yGlobal - (si->size.y / 2));
+    }
+
+    ray.origin = vectorRotation(ray.origin, rotationCenter, trig);
+    ray.direction = vectorRotation(ray.direction, rotationCenter, trig);
+
+    c3 color = {0.f, 0.f, 0.f};
+    Ray r = ray;
+    if (antialiasingActivated)
+    {
+        for (int I = 0; I < 4; ++I)
+        {
+            r.origin.x += AAx[I];
+            r.origin.y += AAy[I];
+            c3 c = launchRayTracing(s, gindex, &r, si, &dof, &ids[index], st);
+            color.x += c.x;
+            color.y += c.y;
+            color.z += c.z;
+        }
+    }
+    else if (si->pathTracingIteration >= NB_MAX_ITERATIONS)
+    {
+        r.direction.x += AAx[si->pathTracingIteration % 4];
+        r.direction.y += AAy[si->pathTracingIteration % 4];
+    }
+    {
+        c3 c = launchRayTracing(s, gindex, &r, si, &dof, &ids[index], st);
+        color.x += c.x;
+        color.y += c.y;
+        color.z += c.z;
+    }
+
+    if (si->advancedIllumination == aiRandomIllumination)
+    {
+        int rindex = (gindex + si->timestamp) % MAX_BITMAP_SIZE;
+        float rv = rnd(s, rindex, st);
+        color.x += si->backgroundColor.x * rv * 5.f;
+        color.y += si->backgroundColor.y * rv * 5.f;
+        color.z += si->backgroundColor.z * rv * 5.f;
+    }
+
+    if (antialiasingActivated)
+    {
+        color.x /= 5.f;
+        color.y /= 5.f;
+        color.z /= 5.f;
+    }
+
+    if (si->pathTracingIteration == 0)
+        pp[index].colorInfo.w = dof;
+
+    if (si->pathTracingIteration <= NB_MAX_ITERATIONS)
+    {
+        pp[index].colorInfo.x = color.x;
+        pp[index].colorInfo.y = color.y;
+        pp[index].colorInfo.z = color.z;
+        pp[index].sceneInfo.x = color.x;
+        pp[index].sceneInfo.y = color.y;
+        pp[index].sceneInfo.z = color.z;
+    }
+    else
+    {
+        pp[index].sceneInfo.x = (ids[index].z > 0) ? fmaxf(pp[index].sceneInfo.x, color.x) : color.x;
+        pp[index].sceneInfo.y = (ids[index].z > 0) ? fmaxf(pp[index].sceneInfo.y, color.y) : color.y;
+        pp[index].sceneInfo.z = (ids[index].z > 0) ? fmaxf(pp[index].sceneInfo.z, color.z) : color.z;
+        pp[index].colorInfo.x += pp[index].sceneInfo.x;
+        pp[index].colorInfo.y += pp[index].sceneInfo.y;
+        pp[index].colorInfo.z += pp[index].sceneInfo.z;
+    }
+}
+
+/* ---- post-processing stage --------------------------------------------- */
+
+/* ref CRT:1057-1073 */
+static void postDefault(const SceneInfo *si, const PostProcessingBuffer *pp, BitmapBuffer *bitmap, int index)
+{
+    c3 c = {pp[index].colorInfo.x, pp[index].colorInfo.y, pp[index].colorInfo.z};
+    if (si->pathTracingIteration > NB_MAX_ITERATIONS)
+    {
+        float d = (float)(si->pathTracingIteration - NB_MAX_ITERATIONS + 1);
+        c.x /= d;
+        c.y /= d;
+        c.z /= d;
+    }
+    makeColor(si, c, bitmap, index);
+}
+
+/* ref CRT:1081-1120.  Gathers stay inside the strip that owns the pixel: the
+ * oracle is only asked for this effect on full frames (firstRow == 0). */
+static void postDepthOfField(const OracleScene *s, const SceneInfo *si, const PostProcessingInfo *ppi,
+                             const PostProcessingBuffer *pp, BitmapBuffer *bitmap, int x, int y, int rows, Stats *st)
+{
+    int index = y * si->size.x + x;
+    c3 localColor = {0.f, 0.f, 0.f};
+    float depth = fabsf(pp[index].colorInfo.w - ppi->param1) / si->viewDistance;
+    int wh = si->size.x * rows;
+    for (int i = 0; i < ppi->param3; ++i)
+    {
+        int ix = i % wh;
+        int iy = (i + 1000) % wh;
+        int xx = (int)(x + depth * rnd(s, ix, st) * ppi->param2);
+        int yy = (int)(y + depth * rnd(s, iy, st) * ppi->param2);
+        if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
+        {
+            int localIndex = yy * si->size.x + xx;
+            if (localIndex >= 0 && localIndex < wh)
+            {
+                localColor.x += pp[localIndex].colorInfo.x;
+                localColor.y += pp[localIndex].colorInfo.y;
+                localColor.z += pp[localIndex].colorInfo.z;
+            }
+        }
+        else
+        {
+            localColor.x += pp[index].colorInfo.x;
+            localColor.y += pp[index].colorInfo.y;
+            localColor.z += pp[index].colorInfo.z;
+        }
+    }
+    localColor.x /= (float)ppi->param3;
+    localColor.y /= (float)ppi->param3;
+    localColor.z /= (float)ppi->param3;
+    if (si->pathTracingIteration > NB_MAX_ITERATIONS)
+    {
+        float d = (float)(si->pathTracingIteration - NB_MAX_ITERATIONS + 1);
+        localColor.x /= d;
+        localColor.y /= d;
+        localColor.z /= d;
+    }
+    makeColor(si, localColor, bitmap, index);
+}
+
+/* ref CRT:1128-1181 */
+static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, const PostProcessingInfo *ppi,
+                                 const PostProcessingBuffer *pp, BitmapBuffer *bitmap, int x, int y, int rows,
+                                 Stats *st)
+{
+    int index = y * si->size.x + x;
+    int wh = si->size.x * rows;
+    float occ = 0.f;
+    c3 localColor = {pp[index].colorInfo.x, pp[index].colorInfo.y, pp[index].colorInfo.z};
+    float depth = pp[index].colorInfo.w;
+    const int step = 16;
+    int i = 0;
+    float c = 0.f;
+    for (int X = -step; X < step; X += 2)
+        for (int Y = -step; Y < step; Y += 2)
+        {
+            int ix = i % wh;
+            int iy = (i + 100) % wh;
+            ++i;
+            c += 1.f;
+            int xx = (int)(x + (X * ppi->param2 * rnd(s, ix, st) / 10.f));
+            int yy = (int)(y + (Y * ppi->param2 * rnd(s, iy, st) / 10.f));
+            if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
+            {
+                int localIndex = yy * si->size.x + xx;
+                if (pp[localIndex].colorInfo.w >= depth)
+                    occ += 1.f;
+            }
+            else
+                occ += 1.f;
+        }
+    occ /= (float)c;
+    occ += 0.3f;
+    if (occ < 1.f)
+    {
+        localColor.x *= occ;
+        localColor.y *= occ;
+        localColor.z *= occ;
+    }
+    if (si->pathTracingIteration > NB_MAX_ITERATIONS)
+    {
+        float d = (float)(si->pathTracingIteration - NB_MAX_ITERATIONS + 1);
+        localColor.x /= d;
+        localColor.y /= d;
+        localColor.z /= d;
+    }
+    saturate3(&localColor);
+    makeColor(si, localColor, bitmap, index);
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const PostProcessingInfo *ppInfo,
+                  const float origin[3], const float direction[3], const float angles[4], int firstRow, int nbRows,
+                  PostProcessingBuffer *pp, PrimitiveXYIdBuffer *ids, BitmapBuffer *bitmap, oracle_counts_t counts,
+                  int nthreads)
+{
+    const int W = sceneInfo->size.x;
+    Trig trig = makeTrig(angles);
+    v3 o = V(origin[0], origin[1], origin[2]);
+    v3 d = V(direction[0], direction[1], direction[2]);
+    Stats total;
+    memset(&total, 0, sizeof(total));
+#ifdef _OPENMP
+    if (nthreads <= 0)
+        nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+
+#pragma omp parallel num_threads(nthreads)
+    {
+        Stats st;
+        memset(&st, 0, sizeof(st));
+#pragma omp for schedule(dynamic, 2)
+        for (int y = 0; y < nbRows; ++y)
+            for (int x = 0; x < W; ++x)
+                standardRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
+#pragma omp for schedule(dynamic, 2)
+        for (int y = 0; y < nbRows; ++y)
+            for (int x = 0; x < W; ++x)
+            {
+                int index = y * W + x;
+                switch (ppInfo->type)
+                {
+                case ppe_depthOfField:
+                    postDepthOfField(scene, sceneInfo, ppInfo, pp, bitmap, x, y, nbRows, &st);
+                    break;
+                case ppe_ambientOcclusion:
+                    postAmbientOcclusion(scene, sceneInfo, ppInfo, pp, bitmap, x, y, nbRows, &st);
+                    break;
+                default:
+                    postDefault(sceneInfo, pp, bitmap, index);
+                    break;
+                }
+            }
+#pragma omp critical
+        {
+            total.closest += st.closest;
+            total.shadow += st.shadow;
+            total.boxes += st.boxes;
+            total.prims += st.prims;
+            total.randomFault |= st.randomFault;
+        }
+    }
+    if (counts)
+    {
+        counts[0] = total.closest;
+        counts[1] = total.shadow;
+        counts[2] = total.boxes;
+        counts[3] = total.prims;
+    }
+    return total.randomFault ? -1 : 0;
+}

@@ -1,0 +1,95 @@
+/*
+ * solr_oracle.h - CPU oracle for the Sol-R per-pixel rendering path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
+ * for this path, its CPU engine does not compile
+ *  and its CUDA engine cannot be built in this image without
+ * writing stand-ins for the CUDA SDK headers and the cmake-generated
+ * defines.h, which the build rules forbid.  This oracle is therefore a
+ * line-by-line restatement of the reference's device code with IEEE fp32
+ * semantics (no FMA contraction, correctly rounded / and sqrt, glibc libm for
+ * pow/sin/cos/atan2/asin) that is checked against hand-derived known-answer
+ * cases in tests/, not against outputs of the reference itself.
+ */
+#ifndef SOLR_ORACLE_H
+#define SOLR_ORACLE_H
+
+#include "../include/solr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OracleScene_s
+{
+    const BoundingBox *boxes;
+    int nbBoxes;
+    const Primitive *primitives;
+    int nbPrimitives;
+    const LightInformation *lights;
+    int nbLights; /* lightInformationSize */
+    int nbLamps;
+    const Material *materials;
+    const BitmapBuffer *textures; /* may be NULL when no material is textured */
+    const float *randoms;         /* may be NULL when the frame does not read randoms */
+    long nbRandoms;               /* number of floats behind randoms (bounds checked) */
+} OracleScene;
+
+/* counts[0] closest-hit walks, [1] shadow walks, [2] box nodes visited,
+ * [3] primitive tests; may be NULL */
+typedef unsigned long long oracle_counts_t[4];
+
+/* One frame of the reference's k_standardRenderer (CudaRayTracer.cu:437-563)
+ * followed by its post-processing stage (k_default / k_ambiantOcclusion /
+ * k_depthOfField, CudaRayTracer.cu:1057-1181) for rows
+ * [firstRow, firstRow+nbRows) of the image.  pp / ids / bitmap are strip
+ * sized (nbRows*W records; W*3 bytes per row for bitmap) and in/out: the
+ * progressive-refinement and accumulation modes read the previous pass.
+ * nthreads <= 0 uses every core (OpenMP over rows).  Returns 0, or -1 when a
+ * random index would fall outside [0, nbRandoms). */
+int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const PostProcessingInfo *ppInfo,
+                  const float origin[3], const float direction[3], const float angles[4], int firstRow, int nbRows,
+                  PostProcessingBuffer *pp, PrimitiveXYIdBuffer *ids, BitmapBuffer *bitmap, oracle_counts_t counts,
+                  int nthreads);
+
+/* Function-level entry points for known-answer tests ------------------- */
+
+/* boxIntersection (GeometryIntersections.cuh:52-79) for the ray
+ * origin -> origin + direction (direction is NOT normalised, as in the
+ * reference's walk) */
+int oracle_box_intersection(const BoundingBox *box, const float origin[3], const float direction[3], float t0,
+                            float t1);
+
+/* One primitive test exactly as the closest-hit walk dispatches it
+ * (GeometryIntersections.cuh:712-747).  Returns hit; writes intersection,
+ * normal, areas and the primitive's shadow intensity. */
+int oracle_primitive_intersection(const SceneInfo *sceneInfo, const Primitive *primitive, const Material *materials,
+                                  const BitmapBuffer *textures, const float origin[3], const float direction[3],
+                                  int processingShadows, float intersection[3], float normal[3], float areas[3],
+                                  float *shadowIntensity);
+
+/* intersectionWithPrimitives (GeometryIntersections.cuh:667-772) */
+int oracle_closest_hit(const OracleScene *scene, const SceneInfo *sceneInfo, const float origin[3],
+                       const float target[3], int iteration, int currentMaterialId, int *closestPrimitive,
+                       float closestIntersection[3], float closestNormal[3], float closestAreas[3]);
+
+/* processShadows (GeometryIntersections.cuh:798-908) */
+float oracle_shadow(const OracleScene *scene, const SceneInfo *sceneInfo, const float lampCenter[3],
+                    const float origin[3], int lightId, int iteration, int objectId, float color[3]);
+
+/* vectorRotation (VectorUtils.cuh:104-142) */
+void oracle_vector_rotation(float v[3], const float center[3], const float angles[3]);
+
+/* makeColor (GeometryShaders.cuh:132-165) for one pixel */
+void oracle_make_color(const SceneInfo *sceneInfo, const float color[3], BitmapBuffer *bitmap, int index);
+
+int oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1749 @@
+/*
+ * rt_device.h - gfx950 device code of the Sol-R per-pixel rendering path.
+ *
+ * Written for CDNA4 wave64 execution, not translated from the reference's
+ * one-thread-one-pixel CUDA code.  The unit of work is a WAVE (an 8x8 pixel
+ * tile):
+ *
+ *  - The flattened box tree (depth-first order, skip pointers = subtree
+ *    sizes) is walked by the whole wave with ONE scalar cursor `cur`.  Every
+ *    lane keeps its own cursor (the index of the next node ITS ray would
+ *    visit); a lane takes part in node `cur` only when its cursor equals
+ *    `cur`.  Because subtrees are nested intervals, the smallest cursor in
+ *    the wave is always `cur + 1` when any lane entered the node (ballot) and
+ *    `cur + skip` otherwise, so the next node is found with a single
+ *    __ballot and no cross-lane reduction.  Each lane therefore visits exactly
+ *    the nodes, in exactly the order, of the reference's scalar walk
+ *    (GeometryIntersections.cuh:687-770) - closest-hit ties resolve the same
+ *    way - while all node and primitive data is wave-uniform and arrives
+ *    through the scalar cache (s_load_dwordx4) or as LDS broadcast reads,
+ *    leaving the vector memory path to the framebuffer alone.
+ *  - Scene records are stored as planes of float4 (SoA, see scene_layout.h),
+ *    split by the phase that reads them: traversal planes and shading planes.
+ *  - The per-bounce colour stack of launchRayTracing (CudaRayTracer.cu:92-95)
+ *    lives in LDS, one column per lane, instead of in scratch memory.
+ *
+ * Arithmetic: every expression keeps the reference's operand order and is
+ * compiled with -ffp-contract=off, IEEE division and square root, no
+ * fast-math, so results are bit-identical to the CPU oracle except where a
+ * libm transcendental is involved (pow, sin/cos of procedural spheres,
+ * atan2/asin of UV maps), which are evaluated in binary64 and rounded once.
+ *
+ * Reference citations use the same abbreviations as oracle/solr_oracle.c:
+ *   CRT CudaRayTracer.cu, GI GeometryIntersections.cuh, GS GeometryShaders.cuh,
+ *   TM TextureMapping.cuh, VU VectorUtils.cuh, HM helper_math.h.
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/solr_types.h"
+#include "scene_layout.h"
+
+namespace solrdev
+{
+#define SOLR_DEV __device__ __forceinline__
+
+struct v3
+{
+    float x, y, z;
+};
+
+SOLR_DEV v3 V(float x, float y, float z)
+{
+    v3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+SOLR_DEV v3 V4(const float4 &a) { return V(a.x, a.y, a.z); }
+SOLR_DEV v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+SOLR_DEV v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+SOLR_DEV v3 operator*(v3 a, float b) { return V(a.x * b, a.y * b, a.z * b); }
+SOLR_DEV v3 vdivs(v3 a, float b) { return V(a.x / b, a.y / b, a.z / b); }
+SOLR_DEV v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+SOLR_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+SOLR_DEV float length(v3 v) { return __fsqrt_rn(dot(v, v)); }
+/* HM:62-65,1309-1313: v * (1 / sqrt(dot)) - two roundings, as on the host */
+SOLR_DEV v3 normalize(v3 v)
+{
+    float invLen = 1.0f / __fsqrt_rn(dot(v, v));
+    return v * invLen;
+}
+/* VU:45-52 */
+SOLR_DEV v3 cross(v3 b, v3 c)
+{
+    v3 a;
+    a.x = b.y * c.z - b.z * c.y;
+    a.y = b.z * c.x - b.x * c.z;
+    a.z = b.x * c.y - b.y * c.x;
+    return a;
+}
+SOLR_DEV float sat1(float v)
+{
+    v = (v < 0.f) ? 0.f : v;
+    v = (v > 1.f) ? 1.f : v;
+    return v;
+}
+SOLR_DEV void saturate3(v3 &v)
+{
+    v.x = sat1(v.x);
+    v.y = sat1(v.y);
+    v.z = sat1(v.z);
+}
+/* VU:61-64 */
+SOLR_DEV v3 vectorReflection(v3 i, v3 n)
+{
+    float k = 2.f * dot(i, n);
+    return i - n * k;
+}
+/* VU:73-87 */
+SOLR_DEV v3 vectorRefraction(v3 incident, float n1, v3 normal, float n2)
+{
+    v3 refracted = incident;
+    if (n2 != 0.f)
+    {
+        float eta = n1 / n2;
+        float c1 = -dot(incident, normal);
+        float cs2 = 1.f - eta * eta * (1.f - c1 * c1);
+        if (cs2 >= 0.f)
+        {
+            float k = eta * c1 - __fsqrt_rn(cs2);
+            refracted = incident * eta + normal * k;
+        }
+    }
+    return refracted;
+}
+/* VU:92-95 */
+SOLR_DEV v3 project(v3 A, v3 B) { return B * (dot(A, B) / dot(B, B)); }
+
+/* transcendental stand-ins: binary64 evaluation, one rounding to binary32 */
+SOLR_DEV float pow_f(float a, float b) { return (float)pow((double)a, (double)b); }
+SOLR_DEV float cos_f(float a) { return (float)cos((double)a); }
+SOLR_DEV float sin_f(float a) { return (float)sin((double)a); }
+SOLR_DEV float atan2_f(float a, float b) { return (float)atan2((double)a, (double)b); }
+SOLR_DEV float asin_f(float a) { return (float)asin((double)a); }
+
+SOLR_DEV int asint(float f) { return __float_as_int(f); }
+
+/* VU:104-142 with the six sin/cos values hoisted to the host (they depend on
+ * the camera angles only) */
+struct Trig
+{
+    float cx, cy, cz, sx, sy, sz;
+};
+SOLR_DEV v3 vectorRotation(v3 v, v3 c, const Trig &t)
+{
+    float vx = v.x - c.x, vy = v.y - c.y, vz = v.z - c.z;
+    float rx = vx, ry, rz;
+    ry = vy * t.cx - vz * t.sx;
+    rz = vy * t.sx + vz * t.cx;
+    vy = ry;
+    vz = rz;
+    rz = vz * t.cy - vx * t.sy;
+    rx = vz * t.sy + vx * t.cy;
+    vz = rz;
+    vx = rx;
+    rx = vx * t.cz - vy * t.sz;
+    ry = vx * t.sz + vy * t.cz;
+    return V(rx + c.x, ry + c.y, rz + c.z);
+}
+
+/* per-lane ray of a walk: origin, un-normalised direction, reciprocal, signs
+ * (GI:36-44, types.h:171-178) */
+struct WalkRay
+{
+    v3 o, d, inv;
+    bool sx, sy, sz;
+};
+SOLR_DEV WalkRay makeWalkRay(v3 origin, v3 direction)
+{
+    WalkRay r;
+    r.o = origin;
+    r.d = direction;
+    r.inv.x = direction.x != 0.f ? 1.f / direction.x : 1.f;
+    r.inv.y = direction.y != 0.f ? 1.f / direction.y : 1.f;
+    r.inv.z = direction.z != 0.f ? 1.f / direction.z : 1.f;
+    r.sx = (r.inv.x < 0);
+    r.sy = (r.inv.y < 0);
+    r.sz = (r.inv.z < 0);
+    return r;
+}
+
+/* GI:52-79; lo/hi are wave-uniform */
+SOLR_DEV bool boxIntersection(const float4 &lo, const float4 &hi, const WalkRay &r, float t0, float t1)
+{
+    float ax = (lo.x - r.o.x) * r.inv.x, bx = (hi.x - r.o.x) * r.inv.x;
+    float tmin = r.sx ? bx : ax;
+    float tmax = r.sx ? ax : bx;
+    float ay = (lo.y - r.o.y) * r.inv.y, by = (hi.y - r.o.y) * r.inv.y;
+    float tymin = r.sy ? by : ay;
+    float tymax = r.sy ? ay : by;
+    if ((tmin > tymax) || (tymin > tmax))
+        return false;
+    if (tymin > tmin)
+        tmin = tymin;
+    if (tymax < tmax)
+        tmax = tymax;
+    float az = (lo.z - r.o.z) * r.inv.z, bz = (hi.z - r.o.z) * r.inv.z;
+    float tzmin = r.sz ? bz : az;
+    float tzmax = r.sz ? az : bz;
+    if ((tmin > tzmax) || (tzmin > tmax))
+        return false;
+    if (tzmin > tmin)
+        tmin = tzmin;
+    if (tzmax < tmax)
+        tmax = tzmax;
+    return ((tmin < t1) && (tmax > t0));
+}
+
+/* ---------------------------------------------------------------------- */
+/* Texture tier (TM)                                                       */
+/* ---------------------------------------------------------------------- */
+
+struct TexOut
+{
+    v3 *normal;          /* bump accumulator */
+    float4 *specular;    /* x value, y power, z transparency-from-specular */
+    float4 *attributes;  /* x reflection, y transparency */
+    float *ambientOcclusion;
+};
+
+/* TM:238-279 (and its two copies): texel fetch plus the optional maps */
+SOLR_DEV void fetchTexel(const MaterialCold &mc, const unsigned char *__restrict__ tex, int u, int v, float4 &result,
+                         const TexOut &o)
+{
+    int A = (v * mc.textureMapping.x + u) * mc.textureMapping.w;
+    int B = mc.textureMapping.x * mc.textureMapping.y * mc.textureMapping.w;
+    int index = A % B;
+    int i = mc.textureOffset.x + index;
+    unsigned char r = tex[i], g = tex[i + 1], b = tex[i + 2];
+    result.x = r / 256.f;
+    result.y = g / 256.f;
+    result.z = b / 256.f;
+    float strength = 3.f;
+    if (mc.textureIds.z != TEXTURE_NONE) /* TM:45-57 */
+    {
+        int j = mc.textureOffset.z + index;
+        unsigned char br = tex[j], bg = tex[j + 1], bb = tex[j + 2];
+        strength = 10.f * (br + bg + bb) / 768.f;
+    }
+    if (mc.textureIds.y != TEXTURE_NONE) /* TM:30-40 */
+    {
+        int j = mc.textureOffset.y + index;
+        unsigned char nr = tex[j], ng = tex[j + 1];
+        o.normal->x -= strength * (nr / 256.f - 0.5f);
+        o.normal->y -= strength * (ng / 256.f - 0.5f);
+        o.normal->z = 0.f;
+    }
+    if (mc.textureIds.w != TEXTURE_NONE) /* TM:62-73 */
+    {
+        int j = mc.textureOffset.w + index;
+        unsigned char sr = tex[j], sg = tex[j + 1], sb = tex[j + 2];
+        o.specular->x = sr / 256.f;
+        o.specular->y = 1000.f * sg / 256.f;
+        o.specular->z = sb / 256.f;
+    }
+    if (mc.advancedTextureIds.x != TEXTURE_NONE) /* TM:78-87 */
+    {
+        int j = mc.advancedTextureOffset.x + index;
+        unsigned char rr = tex[j], rg = tex[j + 1], rb = tex[j + 2];
+        o.attributes->x *= (rr + rg + rb) / 768.f;
+    }
+    if (mc.advancedTextureIds.y != TEXTURE_NONE) /* TM:92-102 */
+    {
+        int j = mc.advancedTextureOffset.y + index;
+        unsigned char tr = tex[j], tg = tex[j + 1], tb = tex[j + 2];
+        o.attributes->y *= (tr + tg + tb) / 768.f;
+    }
+    if (mc.advancedTextureIds.z != TEXTURE_NONE) /* TM:107-116 */
+    {
+        int j = mc.advancedTextureOffset.z + index;
+        unsigned char ar = tex[j], ag = tex[j + 1], ab = tex[j + 2];
+        *o.ambientOcclusion = (ar + ag + ab) / 768.f;
+    }
+}
+
+/* TM:118-158 */
+SOLR_DEV void juliaSet(const MaterialCold &mc, const SceneInfo &si, float x, float y, float4 &color)
+{
+    float W = (float)mc.textureMapping.x;
+    float H = (float)mc.textureMapping.y;
+    float cRe = -0.7f + 0.4f * sin_f(si.timestamp / 1500.f);
+    float cIm = 0.27015f + 0.4f * cos_f(si.timestamp / 2000.f);
+    float newRe = 1.5f * (x - W / 2.f) / (0.5f * W);
+    float newIm = (y - H / 2.f) / (0.5f * H);
+    int n;
+    float maxIterations = 40.f + si.pathTracingIteration;
+    for (n = 0; n < maxIterations; n++)
+    {
+        float oldRe = newRe;
+        float oldIm = newIm;
+        newRe = oldRe * oldRe - oldIm * oldIm + cRe;
+        newIm = 2.f * oldRe * oldIm + cIm;
+        if ((newRe * newRe + newIm * newIm) > 4.f)
+            break;
+    }
+    color.x = 1.f - color.x * (n / maxIterations);
+    color.y = 1.f - color.y * (n / maxIterations);
+    color.z = 1.f - color.z * (n / maxIterations);
+    color.w = 1.f - (n / maxIterations);
+}
+
+/* TM:160-197 */
+SOLR_DEV void mandelbrotSet(const MaterialCold &mc, const SceneInfo &si, float x, float y, float4 &color)
+{
+    float W = (float)mc.textureMapping.x;
+    float H = (float)mc.textureMapping.y;
+    float MinRe = -2.f;
+    float MaxRe = 1.f;
+    float MinIm = -1.2f;
+    float MaxIm = MinIm + (MaxRe - MinRe) * H / W;
+    float Re_factor = (MaxRe - MinRe) / (W - 1.f);
+    double Im_factor = (MaxIm - MinIm) / (H - 1.f);
+    float maxIterations = NB_MAX_ITERATIONS + si.pathTracingIteration;
+    float c_im = (float)(MaxIm - y * Im_factor);
+    float c_re = MinRe + x * Re_factor;
+    float Z_re = c_re;
+    float Z_im = c_im;
+    bool isInside = true;
+    unsigned n;
+    for (n = 0; isInside && n < maxIterations; ++n)
+    {
+        float Z_re2 = Z_re * Z_re;
+        float Z_im2 = Z_im * Z_im;
+        if (Z_re2 + Z_im2 > 4.f)
+            isInside = false;
+        Z_im = 2.f * Z_re * Z_im + c_im;
+        Z_re = Z_re2 - Z_im2 + c_re;
+    }
+    color.x = 1.f - color.x * (n / maxIterations);
+    color.y = 1.f - color.y * (n / maxIterations);
+    color.z = 1.f - color.z * (n / maxIterations);
+    color.w = 1.f - (n / maxIterations);
+}
+
+/* TM:354-447 (non-Kinect build) */
+SOLR_DEV float4 cubeMapping(const SceneInfo &si, int type, v3 p0, v3 size, const float4 &matColor,
+                            const MaterialCold &mc, const unsigned char *__restrict__ tex, v3 intersection,
+                            const TexOut &o)
+{
+    float4 result = matColor;
+    int u = (int)(((type == ptCheckboard) || (type == ptXZPlane) || (type == ptXYPlane))
+                      ? (intersection.x - p0.x + size.x)
+                      : (intersection.z - p0.z + size.z));
+    int v = (int)(((type == ptCheckboard) || (type == ptXZPlane)) ? (intersection.z + p0.z + size.z)
+                                                                  : (intersection.y - p0.y + size.y));
+    if (mc.textureMapping.x != 0)
+        u = u % mc.textureMapping.x;
+    if (mc.textureMapping.y != 0)
+        v = v % mc.textureMapping.y;
+    if (u >= 0 && u < mc.textureMapping.x && v >= 0 && v < mc.textureMapping.x) /* sic, TM:398 */
+    {
+        switch (mc.textureIds.x)
+        {
+        case TEXTURE_MANDELBROT:
+            mandelbrotSet(mc, si, (float)u, (float)v, result);
+            break;
+        case TEXTURE_JULIA:
+            juliaSet(mc, si, (float)u, (float)v, result);
+            break;
+        default:
+            fetchTexel(mc, tex, u, v, result, o);
+        }
+    }
+    return result;
+}
+
+/* TM:291-346 */
+SOLR_DEV float4 sphereUVMapping(v3 p0, float vt1x, float vt1y, const float4 &matColor, const MaterialCold &mc,
+                                const unsigned char *__restrict__ tex, v3 intersection, const TexOut &o)
+{
+    float4 result = matColor;
+    v3 I = normalize(intersection - p0);
+    float U = ((atan2_f(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
+    float Vv = (asin_f(I.y) / SOLR_PI) + .5f;
+    int u = (int)(mc.textureMapping.x * (U * vt1x));
+    int v = (int)(mc.textureMapping.y * (Vv * vt1y));
+    if (mc.textureMapping.x != 0)
+        u = u % mc.textureMapping.x;
+    if (mc.textureMapping.y != 0)
+        v = v % mc.textureMapping.y;
+    if (u >= 0 && u < mc.textureMapping.x && v >= 0 && v < mc.textureMapping.y)
+        fetchTexel(mc, tex, u, v, result, o);
+    return result;
+}
+
+/* TM:205-283 */
+SOLR_DEV float4 triangleUVMapping(const SceneInfo &si, float2 vt0, float2 vt1, float2 vt2, int procedural,
+                                  const float4 &matColor, const MaterialCold &mc,
+                                  const unsigned char *__restrict__ tex, v3 areas, const TexOut &o)
+{
+    float4 result = matColor;
+    float sum = areas.x + areas.y + areas.z;
+    float Tx = (vt0.x * areas.x + vt1.x * areas.y + vt2.x * areas.z) / sum;
+    float Ty = (vt0.y * areas.x + vt1.y * areas.y + vt2.y * areas.z) / sum;
+    float mox = 0.f, moy = 0.f;
+    if (procedural == 1)
+    {
+        mox = mc.mappingOffset.x * si.timestamp;
+        moy = mc.mappingOffset.y * si.timestamp;
+    }
+    int u = (int)(Tx * mc.textureMapping.x + mox);
+    int v = (int)(Ty * mc.textureMapping.y + moy);
+    /* x % 0 traps on the host; the device returns the dividend unchanged */
+    u = mc.textureMapping.x != 0 ? u % mc.textureMapping.x : u;
+    v = mc.textureMapping.y != 0 ? v % mc.textureMapping.y : v;
+    if (u >= 0 && u < mc.textureMapping.x && v >= 0 && v < mc.textureMapping.y)
+    {
+        switch (mc.textureIds.x)
+        {
+        case TEXTURE_MANDELBROT:
+            mandelbrotSet(mc, si, (float)u, (float)v, result);
+            break;
+        case TEXTURE_JULIA:
+            juliaSet(mc, si, (float)u, (float)v, result);
+            break;
+        default:
+            fetchTexel(mc, tex, u, v, result, o);
+        }
+    }
+    return result;
+}
+
+/* TM:449-456 */
+SOLR_DEV bool wireFrameMapping(float x, float y, int width)
+{
+    int X = (int)fabsf(x);
+    int Y = (int)fabsf(y);
+    return (X % 100 <= width) || (Y % 100 <= width);
+}
+
+/* ---------------------------------------------------------------------- */
+/* Primitive intersections (GI); primitive data is wave-uniform            */
+/* ---------------------------------------------------------------------- */
+
+struct Hit
+{
+    v3 intersection;
+    v3 normal;
+    v3 areas;
+    float shadowIntensity;
+};
+
+/* GI:159-212 */
+SOLR_DEV bool ellipsoidIntersection(const SceneInfo &si, v3 p0, v3 size, const WalkRay &ray, Hit &h)
+{
+    h.shadowIntensity = 1.f;
+    v3 O_C = ray.o - p0;
+    v3 dir = normalize(ray.d);
+    float a = ((dir.x * dir.x) / (size.x * size.x)) + ((dir.y * dir.y) / (size.y * size.y)) +
+              ((dir.z * dir.z) / (size.z * size.z));
+    float b = ((2.f * O_C.x * dir.x) / (size.x * size.x)) + ((2.f * O_C.y * dir.y) / (size.y * size.y)) +
+              ((2.f * O_C.z * dir.z) / (size.z * size.z));
+    float c = ((O_C.x * O_C.x) / (size.x * size.x)) + ((O_C.y * O_C.y) / (size.y * size.y)) +
+              ((O_C.z * O_C.z) / (size.z * size.z)) - 1.f;
+    float d = ((b * b) - (4.f * a * c));
+    if (d < 0.f || a == 0.f || b == 0.f || c == 0.f)
+        return false;
+    d = __fsqrt_rn(d);
+    float t1 = (-b + d) / (2.f * a);
+    float t2 = (-b - d) / (2.f * a);
+    if (t1 <= si.geometryEpsilon && t2 <= si.geometryEpsilon)
+        return false;
+    float t = 0.f;
+    if (t1 <= si.geometryEpsilon)
+        t = t2;
+    else if (t2 <= si.geometryEpsilon)
+        t = t1;
+    else
+        t = (t1 < t2) ? t1 : t2;
+    if (t < si.geometryEpsilon)
+        return false;
+    h.intersection = ray.o + dir * t;
+    v3 n = h.intersection - p0;
+    n.x = 2.f * n.x / (size.x * size.x);
+    n.y = 2.f * n.y / (size.y * size.y);
+    n.z = 2.f * n.z / (size.z * size.z);
+    h.normal = normalize(n);
+    return true;
+}
+
+/* GI:220-284 */
+SOLR_DEV bool sphereIntersection(const SceneInfo &si, v3 p0, v3 size, bool procedural, bool transparent,
+                                 const WalkRay &ray, Hit &h)
+{
+    bool back = false;
+    v3 O_C = ray.o - p0;
+    v3 dir = normalize(ray.d);
+    float a = 2.f * dot(dir, dir);
+    float b = 2.f * dot(O_C, dir);
+    float c = dot(O_C, O_C) - (size.x * size.x);
+    float d = b * b - 2.f * a * c;
+    if (d <= 0.f || a == 0.f)
+        return false;
+    float r = __fsqrt_rn(d);
+    float t1 = (-b - r) / a;
+    float t2 = (-b + r) / a;
+    if (t1 <= si.geometryEpsilon && t2 <= si.geometryEpsilon)
+        return false;
+    float t = 0.f;
+    if (t1 <= si.geometryEpsilon)
+    {
+        t = t2;
+        back = true;
+    }
+    else if (t2 <= si.geometryEpsilon)
+        t = t1;
+    else
+        t = (t1 < t2) ? t1 : t2;
+    if (t < si.geometryEpsilon)
+        return false;
+    h.intersection = ray.o + dir * t;
+    v3 n;
+    if (!procedural)
+        n = h.intersection - p0;
+    else
+    {
+        v3 newCenter;
+        newCenter.x = p0.x + 0.008f * size.x * cos_f(si.timestamp + h.intersection.x);
+        newCenter.y = p0.y + 0.008f * size.y * sin_f(si.timestamp + h.intersection.y);
+        newCenter.z = p0.z + 0.008f * size.z * sin_f(cos_f(si.timestamp + h.intersection.z));
+        n = h.intersection - newCenter;
+    }
+    n = normalize(n);
+    if (back)
+        n = n * -1.f;
+    h.normal = n;
+    r = dot(dir, n);
+    h.shadowIntensity = transparent ? (1.f - fabsf(r)) : 1.f;
+    return true;
+}
+
+/* GI:293-349 and GI:358-416 (the cone repeats the cylinder's arithmetic) */
+SOLR_DEV bool cylinderIntersection(const SceneInfo &si, v3 p0, v3 p1, v3 p2, v3 n1, v3 size, const WalkRay &ray,
+                                   Hit &h)
+{
+    v3 O_C = ray.o - p0;
+    v3 dir = ray.d;
+    v3 n = cross(dir, n1);
+    float ln = length(n);
+    if ((ln < si.geometryEpsilon) && (ln > -si.geometryEpsilon))
+        return false;
+    n = normalize(n);
+    float d = fabsf(dot(O_C, n));
+    if (d > size.y)
+        return false;
+    v3 O = cross(O_C, n1);
+    float t = -dot(O, n) / ln;
+    if (t < 0.f)
+        return false;
+    O = normalize(cross(n, n1));
+    float s = fabsf(__fsqrt_rn(size.x * size.x - d * d) / dot(dir, O));
+    float t1 = t - s;
+    float t2 = t + s;
+    v3 I = ray.o + dir * t1;
+    v3 HB1 = I - p0;
+    v3 HB2 = I - p1;
+    float scale1 = dot(HB1, n1);
+    float scale2 = dot(HB2, n1);
+    if (scale1 < si.geometryEpsilon || scale2 > si.geometryEpsilon)
+    {
+        I = ray.o + dir * t2;
+        HB1 = I - p0;
+        HB2 = I - p1;
+        scale1 = dot(HB1, n1);
+        scale2 = dot(HB2, n1);
+        if (scale1 < si.geometryEpsilon || scale2 > si.geometryEpsilon)
+            return false;
+    }
+    h.intersection = I;
+    v3 Vv = I - p2;
+    h.normal = normalize(Vv - project(Vv, n1));
+    h.shadowIntensity = 1.f;
+    return true;
+}
+
+/* one face of an axis-aligned rectangle; U,V in-plane axes, W the normal axis */
+#define SOLR_PLANE_HIT(U, Vx, Wx)                                                                                \
+    do                                                                                                           \
+    {                                                                                                            \
+        float k = ray.o.Wx - p0.Wx;                                                                              \
+        I.U = ray.o.U + k * ray.d.U / -ray.d.Wx;                                                                 \
+        I.Wx = p0.Wx;                                                                                            \
+        I.Vx = ray.o.Vx + k * ray.d.Vx / -ray.d.Wx;                                                              \
+        collision = fabsf(I.U - p0.U) < size.U && fabsf(I.Vx - p0.Vx) < size.Vx;                                 \
+    } while (0)
+
+/* GI:424-567.  pm carries the uniform material facts the test needs. */
+struct PlaneMaterial
+{
+    int wireframe;      /* attributes.z */
+    int wireframeWidth; /* attributes.w */
+    bool emissive;      /* innerIllumination.x != 0 */
+    bool textured;      /* textureIds.x != TEXTURE_NONE */
+    float4 color;
+};
+
+SOLR_DEV bool planeIntersection(const SceneInfo &si, int type, v3 p0, v3 size, v3 n0, const PlaneMaterial &pm,
+                                const MaterialCold *__restrict__ cold, int materialId,
+                                const unsigned char *__restrict__ tex, const WalkRay &ray, Hit &h)
+{
+    bool collision = false;
+    const float reverted = 1.f; /* every call site passes reverse = false */
+    v3 I = h.intersection;
+    v3 normal = n0;
+    switch (type)
+    {
+    case ptMagicCarpet:
+    case ptCheckboard:
+    {
+        I.y = p0.y;
+        float y = ray.o.y - p0.y;
+        if (reverted * ray.d.y < 0.f && reverted * ray.o.y > reverted * p0.y)
+        {
+            I.x = ray.o.x + y * ray.d.x / -ray.d.y;
+            I.z = ray.o.z + y * ray.d.z / -ray.d.y;
+            collision = fabsf(I.x - p0.x) < size.x && fabsf(I.z - p0.z) < size.z;
+        }
+        break;
+    }
+    case ptXZPlane:
+    {
+        if (reverted * ray.d.y < 0.f && reverted * ray.o.y > reverted * p0.y)
+        {
+            SOLR_PLANE_HIT(x, z, y);
+            if (pm.wireframe == 2)
+                collision &= wireFrameMapping(I.x, I.z, pm.wireframeWidth);
+        }
+        if (!collision && reverted * ray.d.y > 0.f && reverted * ray.o.y < reverted * p0.y)
+        {
+            normal = vneg(normal);
+            SOLR_PLANE_HIT(x, z, y);
+            if (pm.wireframe == 2)
+                collision &= wireFrameMapping(I.x, I.z, pm.wireframeWidth);
+        }
+        break;
+    }
+    case ptYZPlane:
+    {
+        if (reverted * ray.d.x < 0.f && reverted * ray.o.x > reverted * p0.x)
+        {
+            SOLR_PLANE_HIT(y, z, x);
+            if (pm.emissive)
+                collision &= (int)fabsf(I.z) % 4000 < 2000 && (int)fabsf(I.y) % 4000 < 2000;
+            if (pm.wireframe == 2)
+                collision &= wireFrameMapping(I.y, I.z, pm.wireframeWidth);
+        }
+        if (!collision && reverted * ray.d.x > 0.f && reverted * ray.o.x < reverted * p0.x)
+        {
+            normal = vneg(normal);
+            SOLR_PLANE_HIT(y, z, x);
+            if (pm.emissive)
+                collision &= (int)fabsf(I.z) % 4000 < 2000 && (int)fabsf(I.y) % 4000 < 2000;
+            if (pm.wireframe == 2)
+                collision &= wireFrameMapping(I.y, I.z, pm.wireframeWidth);
+        }
+        break;
+    }
+    case ptXYPlane:
+    case ptCamera:
+    {
+        if (reverted * ray.d.z < 0.f && reverted * ray.o.z > reverted * p0.z)
+        {
+            SOLR_PLANE_HIT(x, y, z);
+            if (pm.wireframe == 2)
+                collision &= wireFrameMapping(I.x, I.y, pm.wireframeWidth);
+        }
+        if (!collision && reverted * ray.d.z > 0.f && reverted * ray.o.z < reverted * p0.z)
+        {
+            normal = vneg(normal);
+            SOLR_PLANE_HIT(x, y, z);
+            if (pm.wireframe == 2)
+                collision &= wireFrameMapping(I.x, I.y, pm.wireframeWidth);
+        }
+        break;
+    }
+    default:
+        break;
+    }
+
+    if (collision)
+    {
+        h.shadowIntensity = 1.f;
+        float4 color = pm.color;
+        if (type == ptCamera || pm.textured)
+        {
+            float4 specular = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 attributes = make_float4(0.f, 0.f, 0.f, 0.f);
+            float ao = 0.f;
+            TexOut o = {&normal, &specular, &attributes, &ao};
+            color = cubeMapping(si, type, p0, size, pm.color, cold[materialId], tex, I, o);
+            h.shadowIntensity = color.w;
+        }
+        if ((color.x + color.y + color.z) / 3.f >= si.transparentColor)
+            collision = false;
+    }
+    h.intersection = I;
+    h.normal = normal;
+    return collision;
+}
+
+/* GI:575-659 */
+SOLR_DEV bool triangleIntersection(const SceneInfo &si, v3 p0, v3 p1, v3 p2, v3 n0, v3 n1, v3 n2,
+                                   const WalkRay &ray, Hit &h, bool processingShadows)
+{
+    v3 E01 = p1 - p0;
+    v3 E03 = p2 - p0;
+    v3 P = cross(ray.d, E03);
+    float det = dot(E01, P);
+    if (fabsf(det) < si.geometryEpsilon)
+        return false;
+    v3 T = ray.o - p0;
+    float a = dot(T, P) / det;
+    if (a < 0.f || a > 1.f)
+        return false;
+    v3 Q = cross(T, E01);
+    float b = dot(ray.d, Q) / det;
+    if (b < 0.f || b > 1.f)
+        return false;
+    if ((a + b) > 1.f)
+    {
+        /* GI:603-616 with E21 = p1 - p1 (sic) */
+        v3 E23 = p0 - p1;
+        v3 E21 = p1 - p1;
+        v3 P_ = cross(ray.d, E21);
+        float det_ = dot(E23, P_);
+        if (fabsf(det_) < si.geometryEpsilon)
+            return false;
+        v3 T_ = ray.o - p2;
+        float a_ = dot(T_, P_) / det_;
+        if (a_ < 0.f)
+            return false;
+        v3 Q_ = cross(T_, E23);
+        float b_ = dot(ray.d, Q_) / det_;
+        if (b_ < 0.f)
+            return false;
+    }
+    float t = dot(E03, Q) / det;
+    if (t < 0)
+        return false;
+    h.intersection = ray.o + ray.d * t;
+    v3 v0 = p0 - h.intersection;
+    v3 v1 = p1 - h.intersection;
+    v3 v2 = p2 - h.intersection;
+    h.areas.x = 0.5f * length(cross(v1, v2));
+    h.areas.y = 0.5f * length(cross(v0, v2));
+    h.areas.z = 0.5f * length(cross(v0, v1));
+    v3 wn = (n0 * h.areas.x + n1 * h.areas.y) + n2 * h.areas.z;
+    h.normal = normalize(vdivs(wn, h.areas.x + h.areas.y + h.areas.z));
+    if (si.doubleSidedTriangles)
+    {
+        /* GI:643-647: dangling else - shadow tests always miss */
+        v3 N = normalize(ray.d);
+        if (processingShadows)
+        {
+            if (dot(N, h.normal) <= 0.f)
+                return false;
+            else if (dot(N, h.normal) >= 0.f)
+                return false;
+        }
+    }
+    v3 dir = normalize(ray.d);
+    float r = dot(dir, h.normal);
+    if (r > 0.f)
+        h.normal = h.normal * -1.f;
+    h.shadowIntensity = 1.f;
+    return true;
+}
+
+/* ---------------------------------------------------------------------- */
+/* Scene access                                                            */
+/* ---------------------------------------------------------------------- */
+
+/* All pointers are read-only for the lifetime of the launch.  Indices that
+ * are wave-uniform (box cursor, leaf primitive index, light index, material
+ * of a uniform primitive) make the compiler select scalar loads. */
+struct Scene
+{
+    ScenePlanes p;
+    int nbBoxes;
+    int nbPrimitives;
+    int nbLights;
+    int nbLamps;
+    int nested;      /* 1: skip pointers form nested intervals (validated on upload) */
+    long nbRandoms;
+};
+
+struct Counters
+{
+    unsigned int closest, shadow, boxes, prims;
+};
+
+template <bool COUNT>
+SOLR_DEV void countAdd(unsigned int &c, unsigned int v)
+{
+    if (COUNT)
+        c += v;
+}
+
+SOLR_DEV int waveMinInt(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        int o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+#define SOLR_CURSOR_DONE 0x7fffffff
+
+/* uniform primitive test shared by both walks; `lanes` = lanes that test it */
+template <bool SHADOW>
+SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, int type, int materialId,
+                            const MaterialHot &mh, const WalkRay &ray, Hit &h)
+{
+    const float4 A = S.p.primA[pi];
+    const float4 D = S.p.primD[pi];
+    const v3 p0 = V4(A);
+    const v3 size = V4(D);
+    int t = si.extendedGeometry ? type : (int)ptTriangle;
+    if (SHADOW)
+    {
+        /* GI:835-864: ptEnvironment is not a sphere here; ptCamera never shadows */
+        if (si.extendedGeometry && type == ptCamera)
+            return false;
+        if (si.extendedGeometry && type == ptEnvironment)
+            t = ptQuad; /* falls to planeIntersection, which has no case for it */
+    }
+    switch (t)
+    {
+    case ptEnvironment:
+    case ptSphere:
+        return sphereIntersection(si, p0, size, mh.attributes.y != 0, mh.transparency != 0.f, ray, h);
+    case ptCylinder:
+    case ptCone:
+    {
+        const v3 p1 = V4(S.p.primB[pi]);
+        const v3 p2 = V4(S.p.primC[pi]);
+        const v3 n1 = V4(S.p.primN1[pi]);
+        return cylinderIntersection(si, p0, p1, p2, n1, size, ray, h);
+    }
+    case ptEllipsoid:
+        return ellipsoidIntersection(si, p0, size, ray, h);
+    case ptTriangle:
+    {
+        const v3 p1 = V4(S.p.primB[pi]);
+        const v3 p2 = V4(S.p.primC[pi]);
+        const v3 n0 = V4(S.p.primN0[pi]);
+        const v3 n1 = V4(S.p.primN1[pi]);
+        const v3 n2 = V4(S.p.primN2[pi]);
+        return triangleIntersection(si, p0, p1, p2, n0, n1, n2, ray, h, SHADOW);
+    }
+    default:
+    {
+        const v3 n0 = V4(S.p.primN0[pi]);
+        PlaneMaterial pm;
+        pm.wireframe = mh.attributes.z;
+        pm.wireframeWidth = mh.attributes.w;
+        pm.emissive = mh.innerIllumination.x != 0.f;
+        pm.textured = mh.ids.x != TEXTURE_NONE;
+        pm.color = mh.color;
+        return planeIntersection(si, type, p0, size, n0, pm, S.p.matCold, materialId, S.p.textures, ray, h);
+    }
+    }
+}
+
+/* next node for the wave: see the file header */
+SOLR_DEV int nextNode(const Scene &S, int cur, int skip, bool anyEntered, int cursor)
+{
+    if (S.nested)
+        return anyEntered ? cur + 1 : cur + skip;
+    return waveMinInt(cursor);
+}
+
+/* GI:667-772, wave-synchronous.  `active` lanes trace origin -> target. */
+template <bool COUNT>
+SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v3 origin, v3 target, int iteration,
+                             int currentMaterialId, int &closestPrimitive, v3 &closestIntersection,
+                             v3 &closestNormal, v3 &closestAreas, v3 &colorBox, Counters &cnt)
+{
+    bool intersections = false;
+    if (__ballot(active) == 0ull)
+        return false;
+    float minDistance = (iteration < 2) ? si.viewDistance : si.viewDistance / (iteration + 1);
+    const WalkRay r = makeWalkRay(origin, target - origin);
+    if (active)
+        countAdd<COUNT>(cnt.closest, 1);
+
+    int cursor = active ? 0 : SOLR_CURSOR_DONE;
+    int cur = 0;
+    while (cur < S.nbBoxes)
+    {
+        const float4 lo = S.p.boxLo[cur];
+        const float4 hi = S.p.boxHi[cur];
+        const int nbPrimitives = asint(lo.w);
+        const int skip = asint(hi.w);
+        const bool here = (cursor == cur);
+        bool entered = false;
+        if (here)
+        {
+            countAdd<COUNT>(cnt.boxes, 1);
+            entered = boxIntersection(lo, hi, r, 0.f, minDistance);
+            cursor = entered ? cur + 1 : cur + skip;
+        }
+        const bool anyEntered = __ballot(entered) != 0ull;
+        if (anyEntered)
+        {
+            if (si.renderBoxes != 0)
+            {
+                if (entered)
+                {
+                    const int start = S.p.boxStart[cur];
+                    const float4 c = S.p.matHot[(unsigned)start % (unsigned)NB_MAX_MATERIALS].color;
+                    colorBox.x += c.x / 200.f;
+                    colorBox.y += c.y / 200.f;
+                    colorBox.z += c.z / 200.f;
+                }
+            }
+            else if (nbPrimitives > 0)
+            {
+                const int start = S.p.boxStart[cur];
+                for (int k = 0; k < nbPrimitives; ++k)
+                {
+                    const int pi = start + k;
+                    const int type = asint(S.p.primA[pi].w);
+                    const int materialId = asint(S.p.primB[pi].w);
+                    const MaterialHot &mh = S.p.matHot[materialId];
+                    const int fast = mh.attributes.x;
+                    const bool lanes = entered && (fast == 0 || (fast == 1 && currentMaterialId != materialId));
+                    if (__ballot(lanes) == 0ull)
+                        continue;
+                    if (lanes)
+                    {
+                        countAdd<COUNT>(cnt.prims, 1);
+                        Hit h;
+                        h.intersection = V(0.f, 0.f, 0.f);
+                        h.normal = V(0.f, 0.f, 0.f);
+                        h.areas = V(0.f, 0.f, 0.f);
+                        h.shadowIntensity = 0.f;
+                        const bool i = testPrimitive<false>(S, si, pi, type, materialId, mh, r, h);
+                        const float distance = length(h.intersection - r.o);
+                        if (i && distance > si.geometryEpsilon && distance < minDistance)
+                        {
+                            minDistance = distance;
+                            closestPrimitive = pi;
+                            closestIntersection = h.intersection;
+                            closestNormal = h.normal;
+                            closestAreas = h.areas;
+                            intersections = true;
+                        }
+                    }
+                }
+            }
+        }
+        cur = nextNode(S, cur, skip, anyEntered, cursor);
+    }
+    return intersections;
+}
+
+/* GI:798-908, wave-synchronous.  objectId is the flattened index of the
+ * shaded primitive, compared with Primitive.index like the reference does. */
+template <bool COUNT>
+SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 lampCenter, v3 origin, int lightId,
+                          int iteration, v3 &color, int objectId, Counters &cnt)
+{
+    float result = 0.f;
+    color = V(0.f, 0.f, 0.f);
+    if (__ballot(active) == 0ull)
+        return 0.f;
+    WalkRay r;
+    {
+        v3 d = lampCenter - origin;
+        v3 o = origin + normalize(d) * si.rayEpsilon;
+        r = makeWalkRay(o, d);
+    }
+    const float minDistance = (iteration < 2) ? si.viewDistance : si.viewDistance / (iteration + 1);
+    const float lengthOL = length(r.d);
+    if (active)
+        countAdd<COUNT>(cnt.shadow, 1);
+
+    int cursor = (active && result < si.shadowIntensity) ? 0 : SOLR_CURSOR_DONE;
+    int cur = 0;
+    while (cur < S.nbBoxes)
+    {
+        if (__ballot(cursor != SOLR_CURSOR_DONE) == 0ull)
+            break;
+        const float4 lo = S.p.boxLo[cur];
+        const float4 hi = S.p.boxHi[cur];
+        const int nbPrimitives = asint(lo.w);
+        const int skip = asint(hi.w);
+        const bool here = (cursor == cur);
+        bool entered = false;
+        if (here)
+        {
+            countAdd<COUNT>(cnt.boxes, 1);
+            entered = boxIntersection(lo, hi, r, 0.f, minDistance);
+            cursor = entered ? cur + 1 : cur + skip;
+        }
+        const bool anyEntered = __ballot(entered) != 0ull;
+        if (anyEntered && nbPrimitives > 0)
+        {
+            const int start = S.p.boxStart[cur];
+            for (int k = 0; k < nbPrimitives; ++k)
+            {
+                const int pi = start + k;
+                const int type = asint(S.p.primA[pi].w);
+                const int materialId = asint(S.p.primB[pi].w);
+                const int index = asint(S.p.primC[pi].w);
+                const MaterialHot &mh = S.p.matHot[materialId];
+                const bool lanes = entered && result < si.shadowIntensity && index != lightId && index != objectId &&
+                                   mh.attributes.x == 0;
+                if (__ballot(lanes) == 0ull)
+                    continue;
+                if (lanes)
+                {
+                    countAdd<COUNT>(cnt.prims, 1);
+                    Hit h;
+                    h.intersection = V(0.f, 0.f, 0.f);
+                    h.normal = V(0.f, 0.f, 0.f);
+                    h.areas = V(0.f, 0.f, 0.f);
+                    h.shadowIntensity = 0.f;
+                    const bool hit = testPrimitive<true>(S, si, pi, type, materialId, mh, r, h);
+                    if (hit)
+                    {
+                        const float l = length(h.intersection - r.o);
+                        if (l > si.geometryEpsilon && l < lengthOL)
+                        {
+                            float ratio = h.shadowIntensity * si.shadowIntensity;
+                            if (mh.transparency != 0.f)
+                            {
+                                v3 O_L = normalize(r.d);
+                                float a = fabsf(dot(O_L, h.normal));
+                                float rr = (mh.transparency == 0.f) ? 1.f : (1.f - mh.transparency);
+                                ratio *= rr * a;
+                                color.x += ratio * (0.3f - 0.3f * mh.color.x);
+                                color.y += ratio * (0.3f - 0.3f * mh.color.y);
+                                color.z += ratio * (0.3f - 0.3f * mh.color.z);
+                            }
+                            result += ratio;
+                        }
+                    }
+                }
+            }
+        }
+        /* the reference re-tests `result < shadowIntensity` before every node */
+        if (cursor != SOLR_CURSOR_DONE && !(result < si.shadowIntensity))
+            cursor = SOLR_CURSOR_DONE;
+        cur = nextNode(S, cur, skip, anyEntered, cursor);
+    }
+    result = fmaxf(0.f, fminf(result, si.shadowIntensity));
+    return result;
+}
+
+/* ---------------------------------------------------------------------- */
+/* Shading                                                                 */
+/* ---------------------------------------------------------------------- */
+
+SOLR_DEV float rnd(const Scene &S, long i)
+{
+    /* out-of-range reads (reference UB) return 0 */
+    return (i >= 0 && i < S.nbRandoms) ? S.p.randoms[i] : 0.f;
+}
+
+/* GS:36-124 for the lane's own primitive (per-lane gathers) */
+SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, int type, int materialId,
+                                   const MaterialHot &mh, v3 intersection, v3 areas, const TexOut &o)
+{
+    float4 c = mh.color;
+    c.w = 0.f;
+    const bool textured = mh.ids.x != TEXTURE_NONE;
+    if (si.extendedGeometry)
+    {
+        switch (type)
+        {
+        case ptCone:
+        case ptCylinder:
+        case ptEnvironment:
+        case ptSphere:
+        case ptEllipsoid:
+            if (textured)
+            {
+                const v3 p0 = V4(S.p.primA[pi]);
+                const float vt1x = S.p.primN2[pi].w;
+                const float vt1y = S.p.primT[pi].x;
+                c = sphereUVMapping(p0, vt1x, vt1y, mh.color, S.p.matCold[materialId], S.p.textures, intersection, o);
+            }
+            break;
+        case ptCheckboard:
+        {
+            const v3 p0 = V4(S.p.primA[pi]);
+            const v3 size = V4(S.p.primD[pi]);
+            if (textured)
+                c = cubeMapping(si, type, p0, size, mh.color, S.p.matCold[materialId], S.p.textures, intersection, o);
+            else
+            {
+                int x = (int)(si.viewDistance + ((intersection.x - p0.x) / size.x));
+                int z = (int)(si.viewDistance + ((intersection.z - p0.z) / size.x));
+                if (x % 2 == 0)
+                {
+                    if (z % 2 == 0)
+                    {
+                        c.x = 1.f - c.x;
+                        c.y = 1.f - c.y;
+                        c.z = 1.f - c.z;
+                    }
+                }
+                else
+                {
+                    if (z % 2 != 0)
+                    {
+                        c.x = 1.f - c.x;
+                        c.y = 1.f - c.y;
+                        c.z = 1.f - c.z;
+                    }
+                }
+            }
+            break;
+        }
+        case ptXYPlane:
+        case ptYZPlane:
+        case ptXZPlane:
+        case ptCamera:
+            if (textured)
+            {
+                const v3 p0 = V4(S.p.primA[pi]);
+                const v3 size = V4(S.p.primD[pi]);
+                c = cubeMapping(si, type, p0, size, mh.color, S.p.matCold[materialId], S.p.textures, intersection, o);
+            }
+            break;
+        case ptTriangle:
+            if (textured)
+            {
+                const float2 vt0 = make_float2(S.p.primN0[pi].w, S.p.primN1[pi].w);
+                const float4 T = S.p.primT[pi];
+                const float2 vt1 = make_float2(S.p.primN2[pi].w, T.x);
+                const float2 vt2 = make_float2(T.y, T.z);
+                c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, S.p.matCold[materialId],
+                                      S.p.textures, areas, o);
+            }
+            break;
+        default:
+            break;
+        }
+    }
+    else if (textured)
+    {
+        const float2 vt0 = make_float2(S.p.primN0[pi].w, S.p.primN1[pi].w);
+        const float4 T = S.p.primT[pi];
+        const float2 vt1 = make_float2(S.p.primN2[pi].w, T.x);
+        const float2 vt2 = make_float2(T.y, T.z);
+        c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, S.p.matCold[materialId], S.p.textures,
+                              areas, o);
+    }
+    return c;
+}
+
+/* GI:916-1080.  Every lane of the wave calls this together; `active` marks
+ * the lanes that actually shade.  The light loop is wave-uniform, the shadow
+ * walk inside it is wave-synchronous. */
+template <bool COUNT>
+SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneInfo &si, v3 origin, v3 &normal,
+                            int objectId, v3 intersection, v3 areas, v3 &closestColor, int iteration,
+                            float &shadowIntensity, v3 &totalBlinn, float4 &attributes, Counters &cnt)
+{
+    const int pi = active ? objectId : 0;
+    const int type = asint(S.p.primA[pi].w);
+    const int materialId = asint(S.p.primB[pi].w);
+    const int primIndex = asint(S.p.primC[pi].w);
+    const MaterialHot mh = S.p.matHot[materialId];
+    v3 lampsColor = V(0.f, 0.f, 0.f);
+    v3 intersectionColor = V(0.f, 0.f, 0.f);
+    float4 specular = make_float4(mh.specular.x, mh.specular.y, mh.specular.z, 0.f);
+    float ambientOcclusion = 0.f;
+    bool shade = active;
+
+    if (active)
+    {
+        shadowIntensity = 0.f;
+        v3 bumpNormal = V(0.f, 0.f, 0.f);
+        TexOut o = {&bumpNormal, &specular, &attributes, &ambientOcclusion};
+        float4 ic = intersectionShader(S, si, pi, type, materialId, mh, intersection, areas, o);
+        intersectionColor = V(ic.x, ic.y, ic.z);
+        normal = normal + bumpNormal;
+        normal = normalize(normal);
+        if (mh.attributes.z == 1)
+            shade = false; /* wireframe: returns the texel, GI:947-951 */
+    }
+    const bool wire = active && !shade;
+
+    if (si.graphicsLevel > glNoShading)
+    {
+        if (shade)
+        {
+            closestColor.x *= mh.innerIllumination.x;
+            closestColor.y *= mh.innerIllumination.x;
+            closestColor.z *= mh.innerIllumination.x;
+        }
+        for (int cpt = 0; cpt < S.nbLights; ++cpt)
+        {
+            const int cptLamp =
+                (si.pathTracingIteration >= NB_MAX_ITERATIONS) ? (si.pathTracingIteration % S.nbLights) : 0;
+            const LightPlane li = S.p.lights[cptLamp];
+            const int lightPrimitiveId = asint(li.location.w);
+            const int lightMaterialId = li.materialId;
+            /* materials[MATERIAL_NONE] is read out of bounds by the reference */
+            const MaterialHot &m = S.p.matHot[lightMaterialId < 0 ? 0 : lightMaterialId];
+            const bool lit = shade && (lightPrimitiveId != primIndex);
+
+            v3 center = V4(li.location);
+            const int t = (index + si.timestamp) % (MAX_BITMAP_SIZE - 3);
+            if (si.pathTracingIteration >= NB_MAX_ITERATIONS)
+            {
+                float a = m.innerIllumination.y * 10.f * si.pathTracingIteration / si.maxPathTracingIterations;
+                center.x += rnd(S, t) * a;
+                center.y += rnd(S, t + 1) * a;
+                center.z += rnd(S, t + 2) * a;
+            }
+            v3 lightRay = center - intersection;
+            const float lightRayLength = length(lightRay);
+            const bool inRange = lit && (lightRayLength < m.innerIllumination.z);
+            v3 shadowColor = V(0.f, 0.f, 0.f);
+            float lambert = 0.f;
+            if (inRange)
+            {
+                lightRay = normalize(lightRay);
+                lambert = mh.innerIllumination.x + dot(normal, lightRay);
+            }
+            const bool wantShadow = inRange && lambert > 0.f && si.graphicsLevel > 3 && iteration < 4 &&
+                                    mh.innerIllumination.x == 0.f;
+            {
+                v3 sc;
+                float s = shadowWalk<COUNT>(S, si, wantShadow, center, intersection, lightPrimitiveId, iteration, sc,
+                                            objectId, cnt);
+                if (wantShadow)
+                {
+                    shadowIntensity = s;
+                    shadowColor = sc;
+                }
+            }
+            if (inRange) /* graphicsLevel > glNoShading holds here, GI:1000 */
+            {
+                float photonEnergy = __fsqrt_rn(lightRayLength / m.innerIllumination.z);
+                photonEnergy = (photonEnergy > 1.f) ? 1.f : photonEnergy;
+                photonEnergy = (photonEnergy < 0.f) ? 0.f : photonEnergy;
+                lambert *= (lambert < 0.f) ? -mh.transparency : 1.f;
+                if (lightMaterialId != MATERIAL_NONE)
+                    lambert *= m.innerIllumination.x;
+                else
+                    lambert *= li.color.w;
+                if (mh.innerIllumination.w != 0.f)
+                    lambert *= (1.f + rnd(S, t) * mh.innerIllumination.w * 100.f);
+                lambert *= (1.f - shadowIntensity);
+                lambert += si.backgroundColor.w;
+                lambert *= (1.f - photonEnergy);
+                lampsColor.x += lambert * li.color.x - shadowColor.x;
+                lampsColor.y += lambert * li.color.y - shadowColor.y;
+                lampsColor.z += lambert * li.color.z - shadowColor.z;
+                if (si.graphicsLevel > 1 && shadowIntensity < si.shadowIntensity)
+                {
+                    v3 viewRay = normalize(intersection - origin);
+                    v3 blinnDir = lightRay - viewRay;
+                    float temp = __fsqrt_rn(dot(blinnDir, blinnDir));
+                    if (temp != 0.f)
+                    {
+                        blinnDir = blinnDir * (1.f / temp);
+                        float blinnTerm = dot(blinnDir, normal);
+                        blinnTerm = (blinnTerm < 0.f) ? 0.f : blinnTerm;
+                        blinnTerm = specular.x * pow_f(blinnTerm, specular.y);
+                        blinnTerm *= (1.f - photonEnergy);
+                        totalBlinn.x += li.color.x * li.color.w * blinnTerm;
+                        totalBlinn.y += li.color.y * li.color.w * blinnTerm;
+                        totalBlinn.z += li.color.z * li.color.w * blinnTerm;
+                    }
+                }
+            }
+            if (shade)
+            {
+                closestColor.x += intersectionColor.x * lampsColor.x;
+                closestColor.y += intersectionColor.y * lampsColor.y;
+                closestColor.z += intersectionColor.z * lampsColor.z;
+                if (mh.ids.y != TEXTURE_NONE) /* ambient-occlusion map, GI:1063 */
+                {
+                    closestColor.x *= ambientOcclusion;
+                    closestColor.y *= ambientOcclusion;
+                    closestColor.z *= ambientOcclusion;
+                }
+                saturate3(closestColor);
+                saturate3(totalBlinn);
+            }
+        }
+    }
+    else if (shade)
+        closestColor = intersectionColor;
+
+    return wire ? intersectionColor : closestColor;
+}
+
+/* GI:87-151 (per lane) */
+SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 target)
+{
+    const MaterialHot &mh = S.p.matHot[si.skyboxMaterialId];
+    v3 result = V(mh.color.x, mh.color.y, mh.color.z);
+    v3 dir = normalize(target - origin);
+    float a = 2.f * dot(dir, dir);
+    float b = 2.f * dot(origin, dir);
+    float c = dot(origin, origin) - (float)(si.skyboxRadius * si.skyboxRadius);
+    float d = b * b - 2.f * a * c;
+    if (d <= 0.f || a == 0.f)
+        return result;
+    float r = __fsqrt_rn(d);
+    float t1 = (-b - r) / a;
+    float t2 = (-b + r) / a;
+    if (t1 <= si.geometryEpsilon && t2 <= si.geometryEpsilon)
+        return result;
+    float t = 0.f;
+    if (t1 <= si.geometryEpsilon)
+        t = t2;
+    else if (t2 <= si.geometryEpsilon)
+        t = t1;
+    else
+        t = (t1 < t2) ? t1 : t2;
+    if (t < si.geometryEpsilon)
+        return result;
+    v3 I = normalize(origin + dir * t);
+    float U = ((atan2_f(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
+    float Vv = (asin_f(I.y) / SOLR_PI) + .5f;
+    const MaterialCold &mc = S.p.matCold[si.skyboxMaterialId];
+    int u = (int)(mc.textureMapping.x * U);
+    int v = (int)(mc.textureMapping.y * Vv);
+    if (mc.textureMapping.x != 0)
+        u %= mc.textureMapping.x;
+    if (mc.textureMapping.y != 0)
+        v %= mc.textureMapping.y;
+    if (u >= 0 && u < mc.textureMapping.x && v >= 0 && v < mc.textureMapping.y)
+    {
+        int A = (v * mc.textureMapping.x + u) * mc.textureMapping.w;
+        int B = mc.textureMapping.x * mc.textureMapping.y * mc.textureMapping.w;
+        int idx = A % B;
+        int i = mc.textureOffset.x + idx;
+        result.x = S.p.textures[i] / 256.f;
+        result.y = S.p.textures[i + 1] / 256.f;
+        result.z = S.p.textures[i + 2] / 256.f;
+    }
+    return result;
+}
+
+/* per-lane column of the LDS colour stack: slot s, component c */
+struct ColorStack
+{
+    float *base;  /* &lds[lane] */
+    int stride;   /* floats between consecutive (slot, component) cells = block size */
+    SOLR_DEV float &at(int slot, int c) const { return base[(slot * 4 + c) * stride]; }
+    SOLR_DEV void set(int slot, v3 v) const
+    {
+        at(slot, 0) = v.x;
+        at(slot, 1) = v.y;
+        at(slot, 2) = v.z;
+    }
+    SOLR_DEV v3 get(int slot) const { return V(at(slot, 0), at(slot, 1), at(slot, 2)); }
+};
+
+/* CRT:69-408.  Called by the whole wave; `active` lanes own a pixel.
+ *
+ * The reference traces up to three kinds of rays per pixel: the bounce loop
+ * (CRT:125-294), one deferred reflection of the first transparent hit
+ * (CRT:296-315) and one global-illumination ray (CRT:317-378).  Here they are
+ * phases 0, 1 and 2 of one wave-uniform loop with a single walk and a single
+ * shader call site, which keeps the instruction footprint and the live
+ * register set of the kernel small. */
+template <bool COUNT>
+SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3 rayD, const SceneInfo &si,
+                             float &depthOfField, int4 &primitiveXYId, const ColorStack &cs, Counters &cnt)
+{
+    v3 intersectionColor = V(0.f, 0.f, 0.f);
+    v3 closestIntersection = V(0.f, 0.f, 0.f);
+    v3 normal = V(0.f, 0.f, 0.f);
+    int closestPrimitive = -1;
+    bool carryon = true;
+    v3 roO = rayO, roD = rayD;
+    float initialRefraction = 1.f;
+    int iteration = 0;     /* loop trip counter of phase 0, identical in every running lane */
+    int lastIteration = 0; /* per lane: trips it took part in = the reference's final `iteration` */
+    primitiveXYId.x = -1;
+    primitiveXYId.z = 0;
+    primitiveXYId.w = 0;
+    int currentMaterialId = -2;
+
+    int currentMaxIteration =
+        (si.graphicsLevel < glReflectionsAndRefractions) ? 1 : si.nbRayIterations + si.pathTracingIteration;
+    currentMaxIteration = (currentMaxIteration > NB_MAX_ITERATIONS) ? NB_MAX_ITERATIONS : currentMaxIteration;
+
+    for (int s = 0; s <= currentMaxIteration; ++s)
+    {
+        cs.at(s, 0) = 0.f;
+        cs.at(s, 1) = 0.f;
+        cs.at(s, 2) = 0.f;
+        cs.at(s, 3) = 0.f;
+    }
+
+    v3 recursiveBlinn = V(0.f, 0.f, 0.f);
+    float shadowIntensity = 0.f;
+    v3 closestColor = V(0.f, 0.f, 0.f);
+    v3 colorBox = V(0.f, 0.f, 0.f);
+    v3 latestIntersection = rayO;
+    float rayLength = 0.f;
+    depthOfField = si.viewDistance;
+
+    int reflectedRays = -1;
+    v3 rrO = V(0.f, 0.f, 0.f), rrD = V(0.f, 0.f, 0.f);
+    float reflectedRatio = 0.f;
+
+    const bool giEnabled = (si.advancedIllumination == aiBasic || si.advancedIllumination == aiFull);
+    const bool giPass = giEnabled && si.pathTracingIteration >= NB_MAX_ITERATIONS;
+    v3 ptO = V(0.f, 0.f, 0.f), ptD = V(0.f, 0.f, 0.f);
+    float pathTracingRatio = 0.f;
+    v3 pathTracingColor = V(0.f, 0.f, 0.f);
+    bool useGlobalIllumination = false;
+    bool test = true;
+
+    v3 rBlinn = V(0.f, 0.f, 0.f);
+    bool running = active;
+    int phase = 0;
+
+    while (true)
+    {
+        /* ---- which ray does each lane trace in this trip? ---- */
+        bool want;
+        v3 tO, tD;
+        int tIter, tMat;
+        if (phase == 0)
+        {
+            running = running && (iteration < currentMaxIteration) && (rayLength < si.viewDistance) && carryon;
+            if (__ballot(running) == 0ull)
+            {
+                phase = 1;
+                continue;
+            }
+            want = running;
+            tO = roO;
+            tD = roD;
+            tIter = iteration;
+            tMat = currentMaterialId;
+        }
+        else if (phase == 1)
+        {
+            want = active && si.graphicsLevel >= glReflectionsAndRefractions && reflectedRays != -1;
+            tO = rrO;
+            tD = rrD;
+            tIter = reflectedRays;
+            tMat = currentMaterialId;
+        }
+        else
+        {
+            want = active && useGlobalIllumination && si.advancedIllumination == aiFull;
+            tO = ptO;
+            tD = ptD;
+            tIter = 30; /* only consider close geometry (max distance / 31), CRT:326 */
+            tMat = MATERIAL_NONE;
+        }
+
+        v3 areas = V(0.f, 0.f, 0.f);
+        const bool hit = closestHitWalk<COUNT>(S, si, want, tO, tD, tIter, tMat, closestPrimitive,
+                                               closestIntersection, normal, areas, colorBox, cnt);
+        const bool hitLane = want && hit;
+
+        /* material of the hit (per-lane gather) */
+        const int cp = hitLane ? closestPrimitive : 0;
+        const int cpMaterial = asint(S.p.primB[cp].w);
+        const MaterialHot cm = S.p.matHot[cpMaterial < 0 ? 0 : cpMaterial];
+        float4 attributes = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool shadeLane = hitLane;
+        int shadeIteration = tIter;
+
+        if (phase == 0)
+        {
+            if (running)
+                carryon = hit;
+            attributes = make_float4(cm.reflection, cm.transparency, cm.refraction, cm.opacity);
+            if (hitLane)
+            {
+                currentMaterialId = cpMaterial;
+                if (iteration == 0)
+                {
+                    cs.set(0, V(0.f, 0.f, 0.f));
+                    cs.at(0, 3) = 1.f;
+                    latestIntersection = closestIntersection;
+                    depthOfField = length(closestIntersection - rayO);
+                    if (giEnabled && cm.innerIllumination.x == 0.f)
+                    {
+                        int t = (index + si.pathTracingIteration * 100 + si.timestamp) % (MAX_BITMAP_SIZE - 3);
+                        ptO = closestIntersection + normal * si.rayEpsilon;
+                        ptD.x = normal.x + 100.f * rnd(S, t);
+                        ptD.y = normal.y + 100.f * rnd(S, t + 1);
+                        ptD.z = normal.z + 100.f * rnd(S, t + 2);
+                        float cos_theta = dot(normalize(ptD), normal);
+                        if (cos_theta < 0.f)
+                            ptD = vneg(ptD);
+                        ptD = ptD + closestIntersection;
+                        pathTracingRatio = (1.f - attributes.y) * fabsf(cos_theta);
+                        useGlobalIllumination = true;
+                    }
+                    primitiveXYId.x = asint(S.p.primC[cp].w);
+                }
+            }
+        }
+        else if (phase == 1)
+        {
+            attributes.x = cm.reflection; /* the only field the reference sets, CRT:305-306 */
+        }
+        else
+        {
+            shadeLane = false;
+            if (hitLane)
+            {
+                if (cpMaterial != MATERIAL_NONE)
+                {
+                    if (cm.innerIllumination.x == 0.f)
+                    {
+                        cs.at(0, 0) = cm.color.x * cm.innerIllumination.x * pathTracingRatio;
+                        cs.at(0, 1) = cm.color.y * cm.innerIllumination.x * pathTracingRatio;
+                        cs.at(0, 2) = cm.color.z * cm.innerIllumination.x * pathTracingRatio;
+                        test = false;
+                    }
+                    else
+                    {
+                        cs.at(0, 0) = cm.color.x * pathTracingRatio;
+                        cs.at(0, 1) = cm.color.y * pathTracingRatio;
+                        cs.at(0, 2) = cm.color.z * pathTracingRatio;
+                    }
+                }
+                if (test)
+                {
+                    pathTracingRatio *= STANDARD_LUNINANCE_STRENGTH;
+                    if (cm.innerIllumination.x == 0.f)
+                    {
+                        cs.at(0, 0) -= si.shadowIntensity;
+                        cs.at(0, 1) -= si.shadowIntensity;
+                        cs.at(0, 2) -= si.shadowIntensity;
+                    }
+                    else
+                        shadeLane = true;
+                }
+            }
+            shadeIteration = lastIteration;
+        }
+
+        const v3 shaded = primitiveShader<COUNT>(S, shadeLane, index, si, tO, normal, closestPrimitive,
+                                                 closestIntersection, areas, closestColor, shadeIteration,
+                                                 shadowIntensity, rBlinn, attributes, cnt);
+
+        if (phase == 0)
+        {
+            if (hitLane)
+            {
+                v3 colorIt = shaded;
+                float contribution;
+                v3 reflectedTarget = V(0.f, 0.f, 0.f);
+                primitiveXYId.z = (int)((float)primitiveXYId.z + cm.innerIllumination.x * 256);
+
+                float segmentLength = length(closestIntersection - latestIntersection);
+                latestIntersection = closestIntersection;
+
+                float transparency = attributes.y;
+                float a = 0.f;
+                if (attributes.y != 0.f)
+                {
+                    float refraction = attributes.z;
+                    if (initialRefraction == refraction)
+                    {
+                        refraction = 1.f;
+                        float len = segmentLength * (attributes.w * (1.f - transparency));
+                        rayLength += len;
+                        rayLength = (rayLength > si.viewDistance) ? si.viewDistance : rayLength;
+                        a = (rayLength / si.viewDistance);
+                        colorIt.x -= a;
+                        colorIt.y -= a;
+                        colorIt.z -= a;
+                    }
+                    v3 O_E = normalize(closestIntersection - roO);
+                    reflectedTarget = vectorRefraction(O_E, refraction, normal, initialRefraction);
+                    contribution = transparency - a;
+                    initialRefraction = refraction;
+                    if (reflectedRays == -1 && attributes.x != 0.f)
+                    {
+                        v3 rd = vectorReflection(O_E, normal);
+                        rrO = closestIntersection + rd * si.rayEpsilon;
+                        rrD = closestIntersection + rd;
+                        reflectedRatio = attributes.x;
+                        reflectedRays = iteration;
+                    }
+                }
+                else if (attributes.x != 0.f)
+                {
+                    v3 O_E = normalize(closestIntersection - roO);
+                    reflectedTarget = vectorReflection(O_E, normal);
+                    contribution = attributes.x;
+                }
+                else
+                {
+                    carryon = false;
+                    contribution = 1.f;
+                    /* the reference keeps the previous bounce's reflectedTarget
+                     * here; the ray it builds from it is never traced */
+                }
+                cs.set(iteration, colorIt);
+                cs.at(iteration, 3) = contribution;
+
+                rBlinn.x /= (float)(iteration + 1);
+                rBlinn.y /= (float)(iteration + 1);
+                rBlinn.z /= (float)(iteration + 1);
+                recursiveBlinn.x = (rBlinn.x > recursiveBlinn.x) ? rBlinn.x : recursiveBlinn.x;
+                recursiveBlinn.y = (rBlinn.y > recursiveBlinn.y) ? rBlinn.y : recursiveBlinn.y;
+                recursiveBlinn.z = (rBlinn.z > recursiveBlinn.z) ? rBlinn.z : recursiveBlinn.z;
+
+                roO = closestIntersection + reflectedTarget * si.rayEpsilon;
+                roD = closestIntersection + reflectedTarget;
+
+                if (si.pathTracingIteration != 0 && cm.color.w != 0.f)
+                {
+                    float ratio = cm.color.w;
+                    ratio *= (attributes.y == 0.f) ? 1000.f : 1.f;
+                    int rindex = (index + si.timestamp) % (MAX_BITMAP_SIZE - 3);
+                    roD.x += rnd(S, rindex) * ratio;
+                    roD.y += rnd(S, rindex + 1) * ratio;
+                    roD.z += rnd(S, rindex + 2) * ratio;
+                }
+            }
+            else if (running)
+            {
+                v3 c;
+                if (si.skyboxMaterialId != MATERIAL_NONE)
+                {
+                    c = skyboxMapping(S, si, roO, roD);
+                    float rad = c.x + c.y + c.z;
+                    primitiveXYId.z = (int)((float)primitiveXYId.z + ((rad > 2.5f) ? rad * 256.f : 0.f));
+                }
+                else if (si.gradientBackground)
+                {
+                    v3 up = V(0.f, 1.f, 0.f);
+                    v3 dir = normalize(roD - roO);
+                    float angle = 0.5f - dot(up, dir);
+                    angle = (angle > 1.f) ? 1.f : angle;
+                    c.x = (1.f - angle) * si.backgroundColor.x;
+                    c.y = (1.f - angle) * si.backgroundColor.y;
+                    c.z = (1.f - angle) * si.backgroundColor.z;
+                }
+                else
+                    c = V(si.backgroundColor.x, si.backgroundColor.y, si.backgroundColor.z);
+                cs.set(iteration, c);
+                cs.at(iteration, 3) = 1.f;
+            }
+            if (running)
+                lastIteration = iteration + 1;
+            iteration++;
+        }
+        else if (phase == 1)
+        {
+            if (hitLane)
+            {
+                cs.at(reflectedRays, 0) += shaded.x * reflectedRatio;
+                cs.at(reflectedRays, 1) += shaded.y * reflectedRatio;
+                cs.at(reflectedRays, 2) += shaded.z * reflectedRatio;
+                primitiveXYId.w = (int)(shadowIntensity * 255);
+            }
+            if (!giPass)
+                break;
+            phase = 2;
+        }
+        else
+        {
+            if (shadeLane)
+                pathTracingColor = shaded;
+            if (active && !hitLane && si.skyboxMaterialId != MATERIAL_NONE)
+            {
+                pathTracingColor = skyboxMapping(S, si, ptO, ptD);
+                pathTracingRatio *= SKYBOX_LUNINANCE_STRENGTH;
+            }
+            if (active && test)
+            {
+                cs.at(0, 0) += pathTracingColor.x * pathTracingRatio;
+                cs.at(0, 1) += pathTracingColor.y * pathTracingRatio;
+                cs.at(0, 2) += pathTracingColor.z * pathTracingRatio;
+            }
+            break;
+        }
+    }
+
+    if (active)
+    {
+        const int iterations = lastIteration;
+        if (test)
+        {
+            /* back-to-front blend, CRT:382-386 */
+            v3 next = cs.get(iterations >= 1 ? iterations - 1 : 0);
+            for (int i = iterations - 2; i >= 0; --i)
+            {
+                v3 ci = cs.get(i);
+                float k = cs.at(i, 3);
+                next.x = ci.x * (1.f - k) + next.x * k;
+                next.y = ci.y * (1.f - k) + next.y * k;
+                next.z = ci.z * (1.f - k) + next.z * k;
+            }
+            intersectionColor = next;
+            intersectionColor.x += recursiveBlinn.x;
+            intersectionColor.y += recursiveBlinn.y;
+            intersectionColor.z += recursiveBlinn.z;
+        }
+        else
+            intersectionColor = cs.get(0);
+
+        float D1 = si.viewDistance * 0.95f;
+        if (si.atmosphericEffect == aeFog && depthOfField > D1)
+        {
+            float D2 = si.viewDistance * 0.05f;
+            float a = depthOfField - D1;
+            float b = 1.f - (a / D2);
+            intersectionColor.x = intersectionColor.x * b + si.backgroundColor.x * (1.f - b);
+            intersectionColor.y = intersectionColor.y * b + si.backgroundColor.y * (1.f - b);
+            intersectionColor.z = intersectionColor.z * b + si.backgroundColor.z * (1.f - b);
+        }
+        primitiveXYId.y = iterations;
+        intersectionColor.x -= colorBox.x;
+        intersectionColor.y -= colorBox.y;
+        intersectionColor.z -= colorBox.z;
+    }
+    return intersectionColor;
+}
+
+/* GS:132-165 */
+SOLR_DEV void makeColor(const SceneInfo &si, v3 color, unsigned char *__restrict__ bitmap, int index)
+{
+    color.x = (color.x > 1.f) ? 1.f : color.x;
+    color.y = (color.y > 1.f) ? 1.f : color.y;
+    color.z = (color.z > 1.f) ? 1.f : color.z;
+    color.x = (color.x < 0.f) ? 0.f : color.x;
+    color.y = (color.y < 0.f) ? 0.f : color.y;
+    color.z = (color.z < 0.f) ? 0.f : color.z;
+    if (si.frameBufferType == ftBGR)
+    {
+        int y = index / si.size.y;
+        int x = index % si.size.x;
+        int i = (y + 1) * si.size.y - x - 1;
+        i *= SOLR_COLOR_DEPTH;
+        bitmap[i] = (unsigned char)(color.z * 255.f);
+        bitmap[i + 1] = (unsigned char)(color.y * 255.f);
+        bitmap[i + 2] = (unsigned char)(color.x * 255.f);
+    }
+    else
+    {
+        int i = index * SOLR_COLOR_DEPTH;
+        bitmap[i] = (unsigned char)(color.x * 255.f);
+        bitmap[i + 1] = (unsigned char)(color.y * 255.f);
+        bitmap[i + 2] = (unsigned char)(color.z * 255.f);
+    }
+}
+} // namespace solrdev

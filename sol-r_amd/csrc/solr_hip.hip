@@ -1,0 +1,1162 @@
+/*
+ * solr_hip.hip - kernels and the C-ABI of the MI355X rendering engine
+ * (include/solr_hip.h).  gfx950 only.
+ *
+ * Kernels
+ *   k_standardRenderer   one wave = one 8x8 pixel tile; primary-ray setup
+ *                        (CudaRayTracer.cu:437-563), the bounce loop, and - when
+ *                        no neighbourhood post-process is requested - the
+ *                        float->RGB8 conversion of k_default fused in
+ *                        (CudaRayTracer.cu:1057-1073, GeometryShaders.cuh:132-165)
+ *   k_default            stand-alone conversion (bound bitmap / non-fused path)
+ *   k_ambientOcclusion   CudaRayTracer.cu:1128-1181
+ *   k_depthOfField       CudaRayTracer.cu:1081-1120
+ *
+ * Host layer: device memory, AoS -> plane re-packing, launches, timing.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/solr_hip.h"
+#include "rt_device.h"
+
+using namespace solrdev;
+
+/* ======================================================================= */
+/* Kernels                                                                  */
+/* ======================================================================= */
+
+struct FrameArgs
+{
+    SceneInfo si;
+    PostProcessingInfo ppi;
+    float ox, oy, oz;     /* camera position */
+    float dx, dy, dz;     /* camera look-at */
+    float ax, ay, az, aw; /* camera angles, w = field scale */
+    Trig trig;            /* cos/sin of the angles, evaluated on the host */
+    int firstRow;         /* first image row of this process's strip */
+    int nbRows;           /* rows in the strip */
+    int tilesX;
+    int fuseDefault;      /* 1: write the RGB bitmap from the renderer */
+    int stackSlots;       /* colour-stack slots per lane in LDS */
+};
+
+#define TILE 8
+#define WAVE 64
+
+/* device view of PostProcessingBuffer (same 32-byte layout, HIP vector types) */
+struct PixelRecord
+{
+    float4 colorInfo;
+    float4 sceneInfo;
+};
+static_assert(sizeof(PixelRecord) == sizeof(PostProcessingBuffer), "PixelRecord layout");
+
+template <bool COUNT>
+__global__ __launch_bounds__(WAVE) void k_standardRenderer(const Scene S, const FrameArgs F,
+                                                           PixelRecord *__restrict__ pp,
+                                                           int4 *__restrict__ ids, unsigned char *__restrict__ bitmap,
+                                                           unsigned long long *__restrict__ counters)
+{
+    extern __shared__ float ldsStack[];
+    const SceneInfo &si = F.si;
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tx = tile % F.tilesX;
+    const int ty = tile / F.tilesX;
+    const int x = tx * TILE + (lane & (TILE - 1));
+    const int yLocal = ty * TILE + (lane >> 3);
+    const int W = si.size.x;
+    const bool inside = (x < W) && (yLocal < F.nbRows);
+    const int index = inside ? yLocal * W + x : 0;
+    const int yGlobal = F.firstRow + yLocal;
+    const int gindex = yGlobal * W + x; /* global pixel index: random-buffer addressing */
+
+    int4 id = make_int4(0, 0, 0, 0);
+    bool active = inside;
+    if (inside && si.pathTracingIteration > 0 && si.pathTracingIteration <= NB_MAX_ITERATIONS)
+    {
+        /* progressive refinement: skip pixels whose previous pass ended early (CRT:454-458) */
+        id = ids[index];
+        if (si.pathTracingIteration > id.y && id.w == 0)
+            active = false;
+    }
+
+    ColorStack cs;
+    cs.base = ldsStack + lane;
+    cs.stride = WAVE;
+
+    Counters cnt = {0u, 0u, 0u, 0u};
+
+    v3 rayO = V(F.ox, F.oy, F.oz);
+    v3 rayD = V(F.dx, F.dy, F.dz);
+    v3 rotationCenter = V(0.f, 0.f, 0.f);
+    if (si.cameraType == ctVR)
+        rotationCenter = rayO;
+    const bool antialiasingActivated = (si.cameraType == ctAntialiazed);
+
+    float4 ppColor = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ppScene = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool needPrevious = si.pathTracingIteration >= NB_MAX_ITERATIONS; /* DOF jitter / accumulation */
+    if (active && (needPrevious || si.pathTracingIteration > 0))
+    {
+        ppColor = pp[index].colorInfo;
+        ppScene = pp[index].sceneInfo;
+    }
+
+    if (F.ppi.type != ppe_depthOfField && si.pathTracingIteration >= NB_MAX_ITERATIONS)
+    {
+        /* natural depth of field, CRT:470-479 */
+        float a = (F.ppi.param1 / 20000.f);
+        long rindex = (long)gindex + si.timestamp % (MAX_BITMAP_SIZE - 2);
+        rayO.x += rnd(S, rindex) * ppColor.w * a;
+        rayO.y += rnd(S, rindex + 1) * ppColor.w * a;
+    }
+
+    float dof = 0.f;
+    if (si.cameraType == ctOrthographic)
+    {
+        rayD.x = rayO.z * 0.001f * (float)(x - (si.size.x / 2));
+        rayD.y = -rayO.z * 0.001f * (float)(yGlobal - (si.size.y / 2));
+        rayO.x = rayD.x;
+        rayO.y = rayD.y;
+    }
+    else
+    {
+        float ratio = (float)si.size.x / (float)si.size.y;
+        float stepx = ratio * F.aw / (float)si.size.x;
+        float stepy = F.aw / (float)si.size.y;
+        rayD.x = rayD.x - stepx * (float)(x - (si.size.x / 2));
+        rayD.y = rayD.y + stepy * (float)(yGlobal - (si.size.y / 2));
+    }
+    rayO = vectorRotation(rayO, rotationCenter, F.trig);
+    rayD = vectorRotation(rayD, rotationCenter, F.trig);
+
+    v3 color = V(0.f, 0.f, 0.f);
+    v3 rO = rayO, rD = rayD;
+    if (!antialiasingActivated && si.pathTracingIteration >= NB_MAX_ITERATIONS)
+    {
+        /* rotated-grid jitter of the accumulation passes, CRT:515-522 */
+        const int k = si.pathTracingIteration % 4;
+        rD.x += (k == 0) ? 3.f : (k == 1) ? 5.f : (k == 2) ? -3.f : -5.f;
+        rD.y += (k == 0) ? 5.f : (k == 1) ? -3.f : (k == 2) ? -5.f : 3.f;
+    }
+    /* ctAntialiazed: four rotated-grid rays with cumulative origin offsets,
+     * then the centre ray (CRT:504-514, 523-525); otherwise the centre ray only */
+    const int nbRays = antialiasingActivated ? 5 : 1;
+#pragma unroll 1
+    for (int I = 0; I < nbRays; ++I)
+    {
+        if (I < nbRays - 1)
+        {
+            rO.x += (I == 0) ? 3.f : (I == 1) ? 5.f : (I == 2) ? -3.f : -5.f;
+            rO.y += (I == 0) ? 5.f : (I == 1) ? -3.f : (I == 2) ? -5.f : 3.f;
+        }
+        v3 c = launchRayTracing<COUNT>(S, active, gindex, rO, rD, si, dof, id, cs, cnt);
+        color = color + c;
+    }
+
+    if (si.advancedIllumination == aiRandomIllumination)
+    {
+        int rindex = (gindex + si.timestamp) % MAX_BITMAP_SIZE;
+        float rv = rnd(S, rindex);
+        color.x += si.backgroundColor.x * rv * 5.f;
+        color.y += si.backgroundColor.y * rv * 5.f;
+        color.z += si.backgroundColor.z * rv * 5.f;
+    }
+    if (antialiasingActivated)
+    {
+        color.x /= 5.f;
+        color.y /= 5.f;
+        color.z /= 5.f;
+    }
+
+    if (active)
+    {
+        if (si.pathTracingIteration == 0)
+            ppColor.w = dof;
+        if (si.pathTracingIteration <= NB_MAX_ITERATIONS)
+        {
+            ppColor.x = color.x;
+            ppColor.y = color.y;
+            ppColor.z = color.z;
+            ppScene.x = color.x;
+            ppScene.y = color.y;
+            ppScene.z = color.z;
+        }
+        else
+        {
+            ppScene.x = (id.z > 0) ? fmaxf(ppScene.x, color.x) : color.x;
+            ppScene.y = (id.z > 0) ? fmaxf(ppScene.y, color.y) : color.y;
+            ppScene.z = (id.z > 0) ? fmaxf(ppScene.z, color.z) : color.z;
+            ppColor.x += ppScene.x;
+            ppColor.y += ppScene.y;
+            ppColor.z += ppScene.z;
+        }
+        pp[index].colorInfo = ppColor;
+        pp[index].sceneInfo = ppScene;
+        ids[index] = id;
+
+        if (F.fuseDefault)
+        {
+            v3 c = V(ppColor.x, ppColor.y, ppColor.z);
+            if (si.pathTracingIteration > NB_MAX_ITERATIONS)
+            {
+                float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
+                c.x /= d;
+                c.y /= d;
+                c.z /= d;
+            }
+            makeColor(si, c, bitmap, index);
+        }
+    }
+
+    if (COUNT)
+    {
+        unsigned int vals[4] = {cnt.closest, cnt.shadow, cnt.boxes, cnt.prims};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            unsigned int v = vals[k];
+            for (int off = 32; off > 0; off >>= 1)
+                v += __shfl_xor(v, off, 64);
+            if (lane == 0)
+                atomicAdd(&counters[k], (unsigned long long)v);
+        }
+    }
+}
+
+/* CRT:1057-1073 */
+__global__ __launch_bounds__(256) void k_default(const SceneInfo si, int nbPixels,
+                                                 const PixelRecord *__restrict__ pp,
+                                                 unsigned char *__restrict__ bitmap)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= nbPixels)
+        return;
+    float4 c4 = pp[index].colorInfo;
+    v3 c = V(c4.x, c4.y, c4.z);
+    if (si.pathTracingIteration > NB_MAX_ITERATIONS)
+    {
+        float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
+        c.x /= d;
+        c.y /= d;
+        c.z /= d;
+    }
+    makeColor(si, c, bitmap, index);
+}
+
+/* CRT:1128-1181; gathers stay inside this process's strip */
+__global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
+                                                          const PixelRecord *__restrict__ pp,
+                                                          const float *__restrict__ randoms, long nbRandoms,
+                                                          unsigned char *__restrict__ bitmap)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = si.size.x;
+    const int wh = W * nbRows;
+    if (index >= wh)
+        return;
+    const int x = index % W;
+    const int y = index / W;
+    float occ = 0.f;
+    float4 local = pp[index].colorInfo;
+    float depth = local.w;
+    const int step = 16;
+    int i = 0;
+    float c = 0.f;
+    for (int X = -step; X < step; X += 2)
+        for (int Y = -step; Y < step; Y += 2)
+        {
+            int ix = i % wh;
+            int iy = (i + 100) % wh;
+            ++i;
+            c += 1.f;
+            float rx = (ix < nbRandoms) ? randoms[ix] : 0.f;
+            float ry = (iy < nbRandoms) ? randoms[iy] : 0.f;
+            int xx = (int)(x + (X * ppi.param2 * rx / 10.f));
+            int yy = (int)(y + (Y * ppi.param2 * ry / 10.f));
+            if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
+            {
+                int localIndex = yy * W + xx;
+                if (pp[localIndex].colorInfo.w >= depth)
+                    occ += 1.f;
+            }
+            else
+                occ += 1.f;
+        }
+    occ /= (float)c;
+    occ += 0.3f;
+    v3 col = V(local.x, local.y, local.z);
+    if (occ < 1.f)
+    {
+        col.x *= occ;
+        col.y *= occ;
+        col.z *= occ;
+    }
+    if (si.pathTracingIteration > NB_MAX_ITERATIONS)
+    {
+        float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
+        col.x /= d;
+        col.y /= d;
+        col.z /= d;
+    }
+    saturate3(col);
+    makeColor(si, col, bitmap, index);
+}
+
+/* CRT:1081-1120 */
+__global__ __launch_bounds__(256) void k_depthOfField(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
+                                                      const PixelRecord *__restrict__ pp,
+                                                      const float *__restrict__ randoms, long nbRandoms,
+                                                      unsigned char *__restrict__ bitmap)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = si.size.x;
+    const int wh = W * nbRows;
+    if (index >= wh)
+        return;
+    const int x = index % W;
+    const int y = index / W;
+    v3 local = V(0.f, 0.f, 0.f);
+    const float4 own = pp[index].colorInfo;
+    float depth = fabsf(own.w - ppi.param1) / si.viewDistance;
+    for (int i = 0; i < ppi.param3; ++i)
+    {
+        int ix = i % wh;
+        int iy = (i + 1000) % wh;
+        float rx = (ix < nbRandoms) ? randoms[ix] : 0.f;
+        float ry = (iy < nbRandoms) ? randoms[iy] : 0.f;
+        int xx = (int)(x + depth * rx * ppi.param2);
+        int yy = (int)(y + depth * ry * ppi.param2);
+        if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
+        {
+            int localIndex = yy * W + xx;
+            if (localIndex >= 0 && localIndex < wh)
+            {
+                float4 o = pp[localIndex].colorInfo;
+                local.x += o.x;
+                local.y += o.y;
+                local.z += o.z;
+            }
+        }
+        else
+        {
+            local.x += own.x;
+            local.y += own.y;
+            local.z += own.z;
+        }
+    }
+    local.x /= (float)ppi.param3;
+    local.y /= (float)ppi.param3;
+    local.z /= (float)ppi.param3;
+    if (si.pathTracingIteration > NB_MAX_ITERATIONS)
+    {
+        float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
+        local.x /= d;
+        local.y /= d;
+        local.z /= d;
+    }
+    makeColor(si, local, bitmap, index);
+}
+
+/* ======================================================================= */
+/* Host layer                                                               */
+/* ======================================================================= */
+
+namespace
+{
+struct DeviceBuffer
+{
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct Engine
+{
+    bool initialized = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    int errorCode = 0;
+    std::string errorText;
+
+    /* scene planes */
+    DeviceBuffer boxLo, boxHi, boxStart;
+    DeviceBuffer primA, primB, primC, primD, primN0, primN1, primN2, primT;
+    DeviceBuffer matHot, matCold, lights, textures, randoms, lamps;
+    int nbBoxes = 0, nbPrimitives = 0, nbLights = 0, nbLamps = 0, nbMaterials = 0;
+    int nested = 1;
+    long nbRandoms = 0;
+
+    /* per-pixel buffers of the strip */
+    DeviceBuffer pp, ids, bitmap, counters;
+    void *boundBitmap = nullptr;
+    int width = 0, height = 0;       /* full image */
+    int firstRow = 0, nbRows = 0;    /* strip; nbRows == 0 -> full frame */
+    int allocW = 0, allocRows = 0;
+
+    /* timing */
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double timedMs = 0.0;
+    int timedLaunches = 0;
+
+    int variant = 0;
+};
+
+Engine g;
+
+void setError(int code, const char *what, const char *file, int line)
+{
+    if (g.errorCode != 0)
+        return;
+    g.errorCode = code;
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s (%s:%d)", what, file, line);
+    g.errorText = buf;
+    fprintf(stderr, "solr_hip: error %d: %s\n", code, buf);
+    const char *fatal = getenv("SOLR_HIP_FATAL");
+    if (fatal && fatal[0] == '1')
+        exit(EXIT_FAILURE); /* the reference's behaviour, helper_cuda.h:749-763 */
+}
+
+#define HIPCHECK(expr)                                                                                           \
+    do                                                                                                           \
+    {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess)                                                                                    \
+        {                                                                                                        \
+            std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);                                  \
+            setError((int)e_, m_.c_str(), __FILE__, __LINE__);                                                   \
+        }                                                                                                        \
+    } while (0)
+
+#define ARGCHECK(cond, msg)                                                                                      \
+    do                                                                                                           \
+    {                                                                                                            \
+        if (!(cond))                                                                                             \
+            setError(-1, msg, __FILE__, __LINE__);                                                               \
+    } while (0)
+
+bool ok()
+{
+    return g.errorCode == 0;
+}
+
+bool ready(const char *who)
+{
+    if (!ok())
+        return false;
+    if (!g.initialized)
+    {
+        setError(-1, (std::string(who) + ": initialize_scene has not been called").c_str(), __FILE__, __LINE__);
+        return false;
+    }
+    return true;
+}
+
+void release(DeviceBuffer &b)
+{
+    if (b.ptr)
+        (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.bytes = 0;
+}
+
+/* grow-only device allocation */
+void reserve(DeviceBuffer &b, size_t bytes)
+{
+    if (bytes < 16)
+        bytes = 16;
+    if (b.ptr && b.bytes >= bytes)
+        return;
+    release(b);
+    HIPCHECK(hipMalloc(&b.ptr, bytes));
+    if (ok())
+        b.bytes = bytes;
+}
+
+template <class T>
+void upload(DeviceBuffer &b, const std::vector<T> &host)
+{
+    reserve(b, host.size() * sizeof(T));
+    if (ok() && !host.empty())
+    {
+        /* pageable source: the copy is complete for the caller when this returns */
+        HIPCHECK(hipMemcpyAsync(b.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, g.stream));
+        HIPCHECK(hipStreamSynchronize(g.stream));
+    }
+}
+
+inline float bitsf(int v)
+{
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+int stripRows()
+{
+    return g.nbRows > 0 ? g.nbRows : g.height;
+}
+
+void allocateFrame()
+{
+    const int rows = stripRows();
+    const size_t pixels = (size_t)std::max(g.width, 1) * (size_t)std::max(rows, 1);
+    const bool grow = pixels * sizeof(PostProcessingBuffer) > g.pp.bytes;
+    reserve(g.pp, pixels * sizeof(PostProcessingBuffer));
+    reserve(g.ids, pixels * sizeof(PrimitiveXYIdBuffer));
+    reserve(g.bitmap, pixels * SOLR_COLOR_DEPTH);
+    reserve(g.counters, 4 * sizeof(unsigned long long));
+    if (ok() && (grow || g.allocW != g.width || g.allocRows != rows))
+    {
+        HIPCHECK(hipMemsetAsync(g.pp.ptr, 0, g.pp.bytes, g.stream));
+        HIPCHECK(hipMemsetAsync(g.ids.ptr, 0, g.ids.bytes, g.stream));
+        HIPCHECK(hipMemsetAsync(g.bitmap.ptr, 0, g.bitmap.bytes, g.stream));
+    }
+    g.allocW = g.width;
+    g.allocRows = rows;
+}
+
+/* skip pointers must describe nested intervals for the ballot-only walk */
+int validateNesting(const BoundingBox *boxes, int n)
+{
+    std::vector<int> ends;
+    for (int i = 0; i < n; ++i)
+    {
+        const int skip = boxes[i].indexForNextBox.x;
+        if (skip < 1 || (long)i + skip > n)
+            return 0;
+        while (!ends.empty() && ends.back() <= i)
+            ends.pop_back();
+        const int end = i + skip;
+        if (!ends.empty() && end > ends.back())
+            return 0;
+        ends.push_back(end);
+    }
+    return 1;
+}
+
+Scene makeScene()
+{
+    Scene S;
+    S.p.boxLo = (const float4 *)g.boxLo.ptr;
+    S.p.boxHi = (const float4 *)g.boxHi.ptr;
+    S.p.boxStart = (const int *)g.boxStart.ptr;
+    S.p.primA = (const float4 *)g.primA.ptr;
+    S.p.primB = (const float4 *)g.primB.ptr;
+    S.p.primC = (const float4 *)g.primC.ptr;
+    S.p.primD = (const float4 *)g.primD.ptr;
+    S.p.primN0 = (const float4 *)g.primN0.ptr;
+    S.p.primN1 = (const float4 *)g.primN1.ptr;
+    S.p.primN2 = (const float4 *)g.primN2.ptr;
+    S.p.primT = (const float4 *)g.primT.ptr;
+    S.p.matHot = (const MaterialHot *)g.matHot.ptr;
+    S.p.matCold = (const MaterialCold *)g.matCold.ptr;
+    S.p.lights = (const LightPlane *)g.lights.ptr;
+    S.p.textures = (const unsigned char *)g.textures.ptr;
+    S.p.randoms = (const float *)g.randoms.ptr;
+    S.nbBoxes = g.nbBoxes;
+    S.nbPrimitives = g.nbPrimitives;
+    S.nbLights = g.nbLights;
+    S.nbLamps = g.nbLamps;
+    S.nested = g.nested;
+    S.nbRandoms = g.randoms.ptr ? g.nbRandoms : 0;
+    return S;
+}
+
+void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProcessingInfo &ppInfo,
+                const float origin[3], const float direction[3], const float angles[4], bool counting,
+                unsigned long long counts[4])
+{
+    if (!ready("cudaRender"))
+        return;
+    ARGCHECK(sceneInfo.size.x > 0 && sceneInfo.size.y > 0, "cudaRender: empty image");
+    ARGCHECK(objects.x <= g.nbBoxes && objects.y <= g.nbPrimitives, "cudaRender: more objects than were uploaded");
+    ARGCHECK(objects.w <= g.nbLights, "cudaRender: more lights than were uploaded");
+    ARGCHECK(g.matHot.ptr != nullptr, "cudaRender: no materials uploaded");
+    if (!ok())
+        return;
+    HIPCHECK(hipSetDevice(g.device));
+    if (sceneInfo.size.x != g.width || sceneInfo.size.y != g.height)
+    {
+        g.width = sceneInfo.size.x;
+        g.height = sceneInfo.size.y;
+    }
+    allocateFrame();
+    if (!ok())
+        return;
+
+    Scene S = makeScene();
+    S.nbBoxes = objects.x;
+    S.nbPrimitives = objects.y;
+    S.nbLamps = objects.z;
+    S.nbLights = objects.w;
+
+    FrameArgs F;
+    memset(&F, 0, sizeof(F));
+    F.si = sceneInfo;
+    F.ppi = ppInfo;
+    F.ox = origin[0];
+    F.oy = origin[1];
+    F.oz = origin[2];
+    F.dx = direction[0];
+    F.dy = direction[1];
+    F.dz = direction[2];
+    F.ax = angles[0];
+    F.ay = angles[1];
+    F.az = angles[2];
+    F.aw = angles[3];
+    /* VectorUtils.cuh:108-114 evaluates these per pixel; they are uniform */
+    F.trig.cx = cosf(angles[0]);
+    F.trig.cy = cosf(angles[1]);
+    F.trig.cz = cosf(angles[2]);
+    F.trig.sx = sinf(angles[0]);
+    F.trig.sy = sinf(angles[1]);
+    F.trig.sz = sinf(angles[2]);
+    F.firstRow = g.nbRows > 0 ? g.firstRow : 0;
+    F.nbRows = stripRows();
+    F.tilesX = (sceneInfo.size.x + TILE - 1) / TILE;
+    const int tilesY = (F.nbRows + TILE - 1) / TILE;
+    const bool neighbourhood = (ppInfo.type == ppe_ambientOcclusion || ppInfo.type == ppe_depthOfField);
+    unsigned char *bitmap = (unsigned char *)(g.boundBitmap ? g.boundBitmap : g.bitmap.ptr);
+    F.fuseDefault = neighbourhood ? 0 : 1;
+
+    int maxIt = (sceneInfo.graphicsLevel < glReflectionsAndRefractions)
+                    ? 1
+                    : sceneInfo.nbRayIterations + sceneInfo.pathTracingIteration;
+    maxIt = maxIt > NB_MAX_ITERATIONS ? NB_MAX_ITERATIONS : maxIt;
+    maxIt = maxIt < 1 ? 1 : maxIt;
+    F.stackSlots = maxIt + 1;
+    const size_t ldsBytes = (size_t)F.stackSlots * 4 * WAVE * sizeof(float);
+
+    const dim3 grid(F.tilesX * tilesY), block(WAVE);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g.timing && !counting)
+    {
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        HIPCHECK(hipEventRecord(e0, g.stream));
+    }
+    if (counting)
+    {
+        HIPCHECK(hipMemsetAsync(g.counters.ptr, 0, 4 * sizeof(unsigned long long), g.stream));
+        hipLaunchKernelGGL(k_standardRenderer<true>, grid, block, ldsBytes, g.stream, S, F,
+                           (PixelRecord *)g.pp.ptr, (int4 *)g.ids.ptr, bitmap,
+                           (unsigned long long *)g.counters.ptr);
+    }
+    else
+        hipLaunchKernelGGL(k_standardRenderer<false>, grid, block, ldsBytes, g.stream, S, F,
+                           (PixelRecord *)g.pp.ptr, (int4 *)g.ids.ptr, bitmap,
+                           (unsigned long long *)g.counters.ptr);
+    HIPCHECK(hipGetLastError());
+    if (e0)
+    {
+        HIPCHECK(hipEventRecord(e1, g.stream));
+        g.events.push_back(std::make_pair(e0, e1));
+    }
+
+    if (neighbourhood)
+    {
+        const int nbPixels = sceneInfo.size.x * F.nbRows;
+        const dim3 pgrid((nbPixels + 255) / 256), pblock(256);
+        if (ppInfo.type == ppe_ambientOcclusion)
+            hipLaunchKernelGGL(k_ambientOcclusion, pgrid, pblock, 0, g.stream, sceneInfo, ppInfo, F.nbRows,
+                               (const PixelRecord *)g.pp.ptr, (const float *)g.randoms.ptr,
+                               g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
+        else
+            hipLaunchKernelGGL(k_depthOfField, pgrid, pblock, 0, g.stream, sceneInfo, ppInfo, F.nbRows,
+                               (const PixelRecord *)g.pp.ptr, (const float *)g.randoms.ptr,
+                               g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
+        HIPCHECK(hipGetLastError());
+    }
+
+    if (counting && counts)
+    {
+        HIPCHECK(hipMemcpyAsync(counts, g.counters.ptr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                g.stream));
+        HIPCHECK(hipStreamSynchronize(g.stream));
+    }
+}
+
+void collectEvents()
+{
+    for (auto &ev : g.events)
+    {
+        float ms = 0.f;
+        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess)
+        {
+            g.timedMs += ms;
+            g.timedLaunches++;
+        }
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    g.events.clear();
+}
+} // namespace
+
+/* ======================================================================= */
+/* C ABI                                                                    */
+/* ======================================================================= */
+
+extern "C" {
+
+int solr_hip_last_error(char *buf, int len)
+{
+    if (buf && len > 0)
+    {
+        strncpy(buf, g.errorText.c_str(), len - 1);
+        buf[len - 1] = 0;
+    }
+    return g.errorCode;
+}
+
+void solr_hip_clear_error(void)
+{
+    g.errorCode = 0;
+    g.errorText.clear();
+}
+
+int solr_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+void solr_hip_set_device(int device)
+{
+    g.device = device;
+}
+
+void solr_hip_set_stream(void *stream)
+{
+    if (g.ownStream && g.stream)
+    {
+        (void)hipStreamSynchronize(g.stream);
+        (void)hipStreamDestroy(g.stream);
+        g.ownStream = false;
+    }
+    g.stream = (hipStream_t)stream;
+    if (!g.stream && g.initialized)
+    {
+        HIPCHECK(hipStreamCreate(&g.stream));
+        g.ownStream = ok();
+    }
+}
+
+void solr_hip_synchronize(void)
+{
+    if (!ready("solr_hip_synchronize"))
+        return;
+    HIPCHECK(hipStreamSynchronize(g.stream));
+}
+
+void solr_hip_set_strip(int firstRow, int nbRows)
+{
+    g.firstRow = nbRows > 0 ? firstRow : 0;
+    g.nbRows = nbRows > 0 ? nbRows : 0;
+    if (g.initialized && g.width > 0)
+        allocateFrame();
+}
+
+void *solr_hip_device_bitmap(void)
+{
+    return g.boundBitmap ? g.boundBitmap : g.bitmap.ptr;
+}
+void *solr_hip_device_primitive_ids(void)
+{
+    return g.ids.ptr;
+}
+void *solr_hip_device_postprocessing(void)
+{
+    return g.pp.ptr;
+}
+void solr_hip_bind_device_bitmap(void *deviceBitmap)
+{
+    g.boundBitmap = deviceBitmap;
+}
+
+void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, int)
+{
+    if (!ok())
+        return;
+    (void)occupancyParameters;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+    {
+        setError(e != hipSuccess ? (int)e : -1,
+                 "initialize_scene: no HIP device available (this engine has no CPU fallback)", __FILE__, __LINE__);
+        return;
+    }
+    ARGCHECK(g.device >= 0 && g.device < n, "initialize_scene: device index out of range");
+    if (!ok())
+        return;
+    HIPCHECK(hipSetDevice(g.device));
+    if (!g.stream)
+    {
+        HIPCHECK(hipStreamCreate(&g.stream));
+        g.ownStream = ok();
+    }
+    g.initialized = ok();
+    g.width = sceneInfo.size.x;
+    g.height = sceneInfo.size.y;
+}
+
+void solr_hip_initialize(const SceneInfo *sceneInfo)
+{
+    vec2i occ;
+    occ.x = 1;
+    occ.y = 1;
+    initialize_scene(occ, *sceneInfo, 0, 0, 0);
+}
+
+void finalize_scene(vec2i)
+{
+    if (!g.initialized)
+        return;
+    (void)hipSetDevice(g.device);
+    if (g.stream)
+        (void)hipStreamSynchronize(g.stream);
+    collectEvents();
+    DeviceBuffer *all[] = {&g.boxLo,  &g.boxHi,  &g.boxStart, &g.primA,   &g.primB,    &g.primC,   &g.primD,
+                           &g.primN0, &g.primN1, &g.primN2,   &g.primT,   &g.matHot,   &g.matCold, &g.lights,
+                           &g.textures, &g.randoms, &g.lamps, &g.pp,      &g.ids,      &g.bitmap,  &g.counters};
+    for (DeviceBuffer *b : all)
+        release(*b);
+    if (g.ownStream && g.stream)
+        (void)hipStreamDestroy(g.stream);
+    g.stream = nullptr;
+    g.ownStream = false;
+    g.initialized = false;
+    g.nbBoxes = g.nbPrimitives = g.nbLights = g.nbLamps = g.nbMaterials = 0;
+    g.allocW = g.allocRows = 0;
+    g.boundBitmap = nullptr;
+    /* no hipDeviceReset: the process may share the device with torch/RCCL */
+}
+
+void reshape_scene(vec2i, SceneInfo sceneInfo)
+{
+    if (!ready("reshape_scene"))
+        return;
+    g.width = sceneInfo.size.x;
+    g.height = sceneInfo.size.y;
+    allocateFrame();
+}
+
+void solr_hip_reshape(const SceneInfo *sceneInfo)
+{
+    vec2i occ;
+    occ.x = 1;
+    occ.y = 1;
+    reshape_scene(occ, *sceneInfo);
+}
+
+void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *primitives, int nbPrimitives,
+               Lamp *lamps, int nbLamps)
+{
+    if (!ready("h2d_scene"))
+        return;
+    ARGCHECK(nbActiveBoxes >= 0 && nbPrimitives >= 0 && nbLamps >= 0, "h2d_scene: negative count");
+    ARGCHECK(nbActiveBoxes == 0 || boundingBoxes, "h2d_scene: null boxes");
+    ARGCHECK(nbPrimitives == 0 || primitives, "h2d_scene: null primitives");
+    if (!ok())
+        return;
+    std::vector<float4> lo(nbActiveBoxes), hi(nbActiveBoxes);
+    std::vector<int> start(nbActiveBoxes);
+    for (int i = 0; i < nbActiveBoxes; ++i)
+    {
+        const BoundingBox &b = boundingBoxes[i];
+        ARGCHECK(b.nbPrimitives >= 0 && (b.nbPrimitives == 0 || (b.startIndex >= 0 &&
+                                                                  (long)b.startIndex + b.nbPrimitives <= nbPrimitives)),
+                 "h2d_scene: box primitive range outside the primitive array");
+        lo[i] = make_float4(b.parameters[0].x, b.parameters[0].y, b.parameters[0].z, bitsf(b.nbPrimitives));
+        hi[i] = make_float4(b.parameters[1].x, b.parameters[1].y, b.parameters[1].z, bitsf(b.indexForNextBox.x));
+        start[i] = b.startIndex;
+    }
+    if (!ok())
+        return;
+    g.nested = validateNesting(boundingBoxes, nbActiveBoxes);
+    if (!g.nested)
+    {
+        /* the general walk needs at least forward progress */
+        for (int i = 0; i < nbActiveBoxes; ++i)
+            ARGCHECK(boundingBoxes[i].indexForNextBox.x >= 1, "h2d_scene: skip pointer < 1");
+        if (!ok())
+            return;
+    }
+    std::vector<float4> A(nbPrimitives), B(nbPrimitives), C(nbPrimitives), D(nbPrimitives), N0(nbPrimitives),
+        N1(nbPrimitives), N2(nbPrimitives), T(nbPrimitives);
+    for (int i = 0; i < nbPrimitives; ++i)
+    {
+        const Primitive &p = primitives[i];
+        A[i] = make_float4(p.p0.x, p.p0.y, p.p0.z, bitsf(p.type));
+        B[i] = make_float4(p.p1.x, p.p1.y, p.p1.z, bitsf(p.materialId));
+        C[i] = make_float4(p.p2.x, p.p2.y, p.p2.z, bitsf(p.index));
+        D[i] = make_float4(p.size.x, p.size.y, p.size.z, 0.f);
+        N0[i] = make_float4(p.n0.x, p.n0.y, p.n0.z, p.vt0.x);
+        N1[i] = make_float4(p.n1.x, p.n1.y, p.n1.z, p.vt0.y);
+        N2[i] = make_float4(p.n2.x, p.n2.y, p.n2.z, p.vt1.x);
+        T[i] = make_float4(p.vt1.y, p.vt2.x, p.vt2.y, 0.f);
+    }
+    HIPCHECK(hipSetDevice(g.device));
+    upload(g.boxLo, lo);
+    upload(g.boxHi, hi);
+    upload(g.boxStart, start);
+    upload(g.primA, A);
+    upload(g.primB, B);
+    upload(g.primC, C);
+    upload(g.primD, D);
+    upload(g.primN0, N0);
+    upload(g.primN1, N1);
+    upload(g.primN2, N2);
+    upload(g.primT, T);
+    std::vector<int> l(lamps, lamps + (lamps ? nbLamps : 0));
+    upload(g.lamps, l);
+    if (ok())
+    {
+        g.nbBoxes = nbActiveBoxes;
+        g.nbPrimitives = nbPrimitives;
+        g.nbLamps = nbLamps;
+    }
+}
+
+void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
+{
+    if (!ready("h2d_materials"))
+        return;
+    ARGCHECK(nbActiveMaterials >= 0 && (nbActiveMaterials == 0 || materials), "h2d_materials: bad arguments");
+    if (!ok())
+        return;
+    /* always NB_MAX_MATERIALS + 1 records on the device (zero beyond the
+     * active ones) so that every id a primitive or the box-debug view can
+     * produce stays inside the allocation */
+    const int capacity = NB_MAX_MATERIALS + 1;
+    std::vector<MaterialHot> hot(capacity);
+    std::vector<MaterialCold> cold(capacity);
+    memset(hot.data(), 0, hot.size() * sizeof(MaterialHot));
+    memset(cold.data(), 0, cold.size() * sizeof(MaterialCold));
+    for (int i = 0; i < nbActiveMaterials && i < capacity; ++i)
+    {
+        const Material &m = materials[i];
+        MaterialHot &h = hot[i];
+        h.innerIllumination = make_float4(m.innerIllumination.x, m.innerIllumination.y, m.innerIllumination.z,
+                                          m.innerIllumination.w);
+        h.color = make_float4(m.color.x, m.color.y, m.color.z, m.color.w);
+        h.specular = make_float4(m.specular.x, m.specular.y, m.specular.z, m.specular.w);
+        h.reflection = m.reflection;
+        h.refraction = m.refraction;
+        h.transparency = m.transparency;
+        h.opacity = m.opacity;
+        h.attributes = make_int4(m.attributes.x, m.attributes.y, m.attributes.z, m.attributes.w);
+        h.ids = make_int4(m.textureIds.x, m.advancedTextureIds.z, 0, 0);
+        MaterialCold &c = cold[i];
+        c.textureMapping = make_int4(m.textureMapping.x, m.textureMapping.y, m.textureMapping.z, m.textureMapping.w);
+        c.textureOffset = make_int4(m.textureOffset.x, m.textureOffset.y, m.textureOffset.z, m.textureOffset.w);
+        c.textureIds = make_int4(m.textureIds.x, m.textureIds.y, m.textureIds.z, m.textureIds.w);
+        c.advancedTextureOffset = make_int4(m.advancedTextureOffset.x, m.advancedTextureOffset.y,
+                                            m.advancedTextureOffset.z, m.advancedTextureOffset.w);
+        c.advancedTextureIds = make_int4(m.advancedTextureIds.x, m.advancedTextureIds.y, m.advancedTextureIds.z,
+                                         m.advancedTextureIds.w);
+        c.mappingOffset = make_float2(m.mappingOffset.x, m.mappingOffset.y);
+        c.pad = make_float2(0.f, 0.f);
+    }
+    HIPCHECK(hipSetDevice(g.device));
+    upload(g.matHot, hot);
+    upload(g.matCold, cold);
+    if (ok())
+        g.nbMaterials = nbActiveMaterials;
+}
+
+void h2d_randoms(vec2i, float *randoms)
+{
+    if (!ready("h2d_randoms"))
+        return;
+    ARGCHECK(randoms != nullptr, "h2d_randoms: null buffer");
+    if (!ok())
+        return;
+    std::vector<float> r(randoms, randoms + MAX_BITMAP_SIZE);
+    HIPCHECK(hipSetDevice(g.device));
+    upload(g.randoms, r);
+    if (ok())
+        g.nbRandoms = MAX_BITMAP_SIZE;
+}
+
+void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
+{
+    if (!ready("h2d_textures"))
+        return;
+    size_t total = 0;
+    for (int i = 0; i < activeTextures; ++i)
+        if (textureInfos[i].buffer)
+        {
+            size_t sz = (size_t)textureInfos[i].size.x * textureInfos[i].size.y * textureInfos[i].size.z;
+            size_t end = (size_t)textureInfos[i].offset + sz;
+            total = end > total ? end : total;
+        }
+    /* 4 bytes of slack: texel fetches read index .. index+2 */
+    std::vector<unsigned char> atlas(total + 4, 0);
+    for (int i = 0; i < activeTextures; ++i)
+        if (textureInfos[i].buffer)
+        {
+            size_t sz = (size_t)textureInfos[i].size.x * textureInfos[i].size.y * textureInfos[i].size.z;
+            memcpy(atlas.data() + textureInfos[i].offset, textureInfos[i].buffer, sz);
+        }
+    HIPCHECK(hipSetDevice(g.device));
+    upload(g.textures, atlas);
+}
+
+void h2d_lightInformation(vec2i, LightInformation *lightInformation, int lightInformationSize)
+{
+    if (!ready("h2d_lightInformation"))
+        return;
+    ARGCHECK(lightInformationSize >= 0 && (lightInformationSize == 0 || lightInformation),
+             "h2d_lightInformation: bad arguments");
+    if (!ok())
+        return;
+    std::vector<LightPlane> l(lightInformationSize);
+    for (int i = 0; i < lightInformationSize; ++i)
+    {
+        const LightInformation &s = lightInformation[i];
+        l[i].location = make_float4(s.location.x, s.location.y, s.location.z, bitsf(s.primitiveId));
+        l[i].color = make_float4(s.color.x, s.color.y, s.color.z, s.color.w);
+        l[i].materialId = s.materialId;
+        l[i].pad[0] = l[i].pad[1] = l[i].pad[2] = 0;
+    }
+    HIPCHECK(hipSetDevice(g.device));
+    upload(g.lights, l);
+    if (ok())
+        g.nbLights = lightInformationSize;
+}
+
+void d2h_bitmap(vec2i, SceneInfo sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds)
+{
+    if (!ready("d2h_bitmap"))
+        return;
+    HIPCHECK(hipSetDevice(g.device));
+    const int rows = stripRows();
+    const int first = g.nbRows > 0 ? g.firstRow : 0;
+    const size_t pixels = (size_t)sceneInfo.size.x * rows;
+    const size_t offset = (size_t)sceneInfo.size.x * first;
+    const void *src = g.boundBitmap ? g.boundBitmap : g.bitmap.ptr;
+    if (bitmap && src)
+        HIPCHECK(hipMemcpyAsync(bitmap + offset * SOLR_COLOR_DEPTH, src, pixels * SOLR_COLOR_DEPTH,
+                                hipMemcpyDeviceToHost, g.stream));
+    if (primitivesXYIds && g.ids.ptr)
+        HIPCHECK(hipMemcpyAsync(primitivesXYIds + offset, g.ids.ptr, pixels * sizeof(PrimitiveXYIdBuffer),
+                                hipMemcpyDeviceToHost, g.stream));
+    HIPCHECK(hipStreamSynchronize(g.stream));
+}
+
+void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds)
+{
+    vec2i occ;
+    occ.x = 1;
+    occ.y = 1;
+    d2h_bitmap(occ, *sceneInfo, bitmap, primitivesXYIds);
+}
+
+void solr_hip_d2h_postprocessing(PostProcessingBuffer *hostBuffer)
+{
+    if (!ready("solr_hip_d2h_postprocessing"))
+        return;
+    ARGCHECK(hostBuffer != nullptr && g.pp.ptr != nullptr, "solr_hip_d2h_postprocessing: no buffer");
+    if (!ok())
+        return;
+    const size_t pixels = (size_t)g.width * stripRows();
+    HIPCHECK(hipMemcpyAsync(hostBuffer, g.pp.ptr, pixels * sizeof(PostProcessingBuffer), hipMemcpyDeviceToHost,
+                            g.stream));
+    HIPCHECK(hipStreamSynchronize(g.stream));
+}
+
+void solr_hip_h2d_postprocessing(const PostProcessingBuffer *hostBuffer, const PrimitiveXYIdBuffer *ids)
+{
+    if (!ready("solr_hip_h2d_postprocessing"))
+        return;
+    allocateFrame();
+    if (!ok())
+        return;
+    const size_t pixels = (size_t)g.width * stripRows();
+    if (hostBuffer)
+        HIPCHECK(hipMemcpyAsync(g.pp.ptr, hostBuffer, pixels * sizeof(PostProcessingBuffer), hipMemcpyHostToDevice,
+                                g.stream));
+    if (ids)
+        HIPCHECK(hipMemcpyAsync(g.ids.ptr, ids, pixels * sizeof(PrimitiveXYIdBuffer), hipMemcpyHostToDevice,
+                                g.stream));
+    HIPCHECK(hipStreamSynchronize(g.stream));
+}
+
+void cudaRender(vec2i, vec4i, SceneInfo sceneInfo, vec4i objects, PostProcessingInfo postProcessingInfo,
+                vec3f origin, vec3f direction, vec4f angles)
+{
+    const float o[3] = {origin.x, origin.y, origin.z};
+    const float d[3] = {direction.x, direction.y, direction.z};
+    const float a[4] = {angles.x, angles.y, angles.z, angles.w};
+    renderImpl(sceneInfo, objects, postProcessingInfo, o, d, a, false, nullptr);
+}
+
+void solr_hip_render(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
+                     const float origin[3], const float direction[3], const float angles[4])
+{
+    renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, false, nullptr);
+}
+
+void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
+                              const PostProcessingInfo *postProcessingInfo, const float origin[3],
+                              const float direction[3], const float angles[4], unsigned long long counts[4])
+{
+    renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, true, counts);
+}
+
+void solr_hip_enable_timing(int enable)
+{
+    g.timing = enable != 0;
+}
+
+double solr_hip_kernel_time(int *nbLaunches, int reset)
+{
+    if (g.initialized && g.stream)
+        (void)hipStreamSynchronize(g.stream);
+    collectEvents();
+    double ms = g.timedMs;
+    if (nbLaunches)
+        *nbLaunches = g.timedLaunches;
+    if (reset)
+    {
+        g.timedMs = 0.0;
+        g.timedLaunches = 0;
+    }
+    return ms;
+}
+
+void solr_hip_set_variant(int variant)
+{
+    g.variant = variant;
+}
+
+int solr_hip_get_variant(void)
+{
+    return g.variant;
+}
+
+void solr_hip_memory_usage(unsigned long long bytes[4])
+{
+    bytes[0] = g.boxLo.bytes + g.boxHi.bytes + g.boxStart.bytes + g.primA.bytes + g.primB.bytes + g.primC.bytes +
+               g.primD.bytes + g.primN0.bytes + g.primN1.bytes + g.primN2.bytes + g.primT.bytes + g.lights.bytes +
+               g.lamps.bytes;
+    bytes[1] = g.matHot.bytes + g.matCold.bytes;
+    bytes[2] = g.textures.bytes;
+    bytes[3] = g.pp.bytes + g.ids.bytes + g.bitmap.bytes + g.randoms.bytes;
+}
+}

@@ -1,0 +1,282 @@
+/*
+ * GPUKernel.h - host-side scene store and box-tree builder in front of the
+ * rendering engine.
+ *
+ * Mirrors the public interface of the reference's solr::GPUKernel
+ * (reference: solr/engines/GPUKernel.h:79-444) for everything that feeds the
+ * per-pixel rendering path: primitives, materials, textures, camera, scene
+ * and post-processing settings, the box-grid build (compactBoxes) and the
+ * render_begin / render_end / getBitmap frame protocol.  Method names,
+ * argument order and the dirty-flag protocol (GPUKernel.h:371-374,387) are the
+ * reference's, so code written against the reference class reads the same
+ * here.  Out of scope (and absent): file loaders, fake-GL vertex assembly,
+ * Kinect/Oculus hooks, JPEG screenshots.
+ *
+ * The flattened arrays this class produces (BoundingBox[], Primitive[],
+ * Lamp[], LightInformation[], Material[]) are bit-for-bit what the reference
+ * builder would hand to its device layer for the same calls: same grid hash,
+ * same std::map key order, same depth-first flattening with subtree sizes as
+ * skip pointers (reference: GPUKernel.cpp:741-1281).  Storage differs (vectors
+ * sized to the scene instead of NB_MAX_* arrays).
+ */
+#pragma once
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/solr_types.h"
+
+namespace solr
+{
+/* reference: GPUKernel.h:46-65 */
+struct CPUPrimitive
+{
+    bool belongsToModel;
+    bool movable;
+    vec3f p0, p1, p2;
+    vec3f n0, n1, n2;
+    vec3f size;
+    int type;
+    int materialId;
+    vec2f vt0, vt1, vt2;
+    vec3f speed0, speed1, speed2;
+};
+
+/* reference: GPUKernel.h:67-73 */
+struct CPUBoundingBox
+{
+    vec3f parameters[2];
+    vec3f center;
+    std::vector<long> primitives; /* primitive ids (level 0) or child box keys (level > 0) */
+    long indexForNextBox;
+};
+
+typedef std::map<unsigned int, CPUBoundingBox> BoxContainer;
+typedef std::map<unsigned int, CPUPrimitive> PrimitiveContainer;
+
+inline vec2i make_vec2i(int x = 0, int y = 0) { vec2i v; v.x = x; v.y = y; return v; }
+inline vec4i make_vec4i(int x = 0, int y = 0, int z = 0, int w = 0) { vec4i v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
+inline vec2f make_vec2f(float x = 0.f, float y = 0.f) { vec2f v; v.x = x; v.y = y; return v; }
+inline vec3f make_vec3f(float x = 0.f, float y = 0.f, float z = 0.f) { vec3f v; v.x = x; v.y = y; v.z = z; return v; }
+inline vec4f make_vec4f(float x = 0.f, float y = 0.f, float z = 0.f, float w = 0.f) { vec4f v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
+
+class GPUKernel
+{
+public:
+    GPUKernel();
+    virtual ~GPUKernel();
+
+    /* reference: GPUKernel.h:85-87 */
+    virtual void initBuffers();
+    virtual void cleanup();
+    virtual void reshape();
+
+    /* reference: GPUKernel.h:90-96,289 (engine selection hooks) */
+    virtual void setPlatformId(const int) {}
+    virtual void setDeviceId(const int) {}
+    virtual void setKernelFilename(const std::string &) {}
+    virtual void queryDevice() {}
+    virtual void recompileKernels() {}
+    virtual std::string getGPUDescription() { return m_gpuDescription; }
+
+    /* ---------- Rendering (GPUKernel.h:100-102) ---------- */
+    virtual void render_begin(const float timer);
+    virtual void render_end() = 0;
+    BitmapBuffer *getBitmap() { return m_bitmap.empty() ? nullptr : m_bitmap.data(); }
+    /* 0 = ok, otherwise the engine's pending error (no reference equivalent:
+     * the reference exits the process on a device error) */
+    virtual int lastError(std::string *message = nullptr) { (void)message; return 0; }
+
+    /* ---------- Primitives (GPUKernel.h:108-149) ---------- */
+    int addPrimitive(PrimitiveType type, bool belongsToModel = false);
+    void setPrimitive(const int &index, float x0, float y0, float z0, float w, float h, float d, int materialId);
+    void setPrimitive(const int &index, float x0, float y0, float z0, float x1, float y1, float z1, float w, float h,
+                      float d, int materialId);
+    void setPrimitive(const int &index, float x0, float y0, float z0, float x1, float y1, float z1, float x2, float y2,
+                      float z2, float w, float h, float d, int materialId);
+    unsigned int getPrimitiveAt(int x, int y);
+    void setPrimitiveIsMovable(const int &index, bool movable);
+    void setPrimitiveBellongsToModel(const int &index, bool bellongsToModel);
+    void setPrimitiveMaterial(unsigned int index, int materialId);
+    int getPrimitiveMaterial(unsigned int index);
+    vec4f getPrimitiveCenter(unsigned int index);
+    void setPrimitiveCenter(unsigned int index, const vec3f &center);
+    void setPrimitiveTextureCoordinates(const unsigned int index, const vec2f &vt0, const vec2f &vt1,
+                                        const vec2f &vt2);
+    void setPrimitiveNormals(unsigned int index, vec3f n0, vec3f n1, vec3f n2);
+    CPUPrimitive *getPrimitive(const unsigned int index);
+    int getLight(int index);
+
+    /* rotation of the whole scene about a centre (GPUKernel.h:122-125) */
+    void rotatePrimitives(const vec3f &rotationCenter, const vec4f &angles);
+    void translatePrimitives(const vec3f &translation);
+    void scalePrimitives(float scale, unsigned int from, unsigned int to);
+
+    /* ---------- Complex objects (GPUKernel.h:162-164) ---------- */
+    int addCube(float x, float y, float z, float radius, int materialId);
+    int addRectangle(float x, float y, float z, float w, float h, float d, int materialId);
+
+    /* ---------- Materials (GPUKernel.h:168-190) ---------- */
+    int addMaterial();
+    void setMaterial(unsigned int index, const Material &material);
+    void setMaterial(unsigned int index, float r, float g, float b, float noise, float reflection, float refraction,
+                     bool procedural, bool wireframe, int wireframeWidth, float transparency, float opacity,
+                     int diffuseTextureId, int normalTextureId, int bumpTextureId, int specularTextureId,
+                     int reflectionTextureId, int transparentTextureId, int ambientOcclusionTextureId, float specValue,
+                     float specPower, float specCoef, float innerIllumination, float illuminationDiffusion,
+                     float illuminationPropagation, bool fastTransparency);
+    void setMaterialColor(unsigned int index, float r, float g, float b);
+    Material *getMaterial(const int index);
+
+    /* ---------- Camera (GPUKernel.h:194) ---------- */
+    void setCamera(const vec3f &eye, const vec3f &dir, const vec4f &angles);
+
+    /* ---------- Textures (GPUKernel.h:198-205) ---------- */
+    void setTexture(const int index, const TextureInfo &textureInfo);
+    void getTexture(const int index, TextureInfo &textureInfo);
+    void setTexturesTransfered(const bool transfered) { m_texturesTransfered = transfered; }
+    void realignTexturesAndMaterials();
+    void processTextureOffsets();
+    TextureInfo &getTextureInformation(const int index);
+
+    /* ---------- Scene (GPUKernel.h:208-221) ---------- */
+    void setSceneInfo(int width, int height, float transparentColor, int graphicsLevel, float viewDistance,
+                      float shadowIntensity, int nbRayIterations, vec4f backgroundColor, int cameraType,
+                      float eyeSeparation, bool renderBoxes, int pathTracingIteration, int maxPathTracingIterations,
+                      FrameBufferType frameBufferType, int timestamp, int atmosphericEffect, int skyboxSize,
+                      int skyboxMaterialId);
+    void setSceneInfo(const SceneInfo &sceneInfo);
+    SceneInfo &getSceneInfo();
+    void setPostProcessingInfo(PostProcessingType type, float param1, float param2, int param3);
+    void setPostProcessingInfo(const PostProcessingInfo &postProcessingInfo);
+    PostProcessingInfo &getPostProcessingInfo() { return m_postProcessingInfo; }
+
+    /* ---------- Counters / frames (GPUKernel.h:267-298) ---------- */
+    unsigned int getNbActiveBoxes();
+    unsigned int getNbActivePrimitives();
+    unsigned int getNbActiveLamps();
+    unsigned int getNbActiveMaterials();
+    unsigned int getNbActiveTextures();
+    void resetFrame();
+    void resetAll();
+    void setNbFrames(const int nbFrames) { m_nbFrames = nbFrames; }
+    void setFrame(const int frame) { m_frame = frame; }
+    int getNbFrames() { return m_nbFrames; }
+    int getFrame() { return m_frame; }
+
+    /* ---------- Box tree (GPUKernel.h:304-309) ---------- */
+    int compactBoxes(bool reconstructBoxes);
+    void streamDataToGPU();
+    void resetBoxes(bool resetPrimitives);
+    void setPrimitivesTransfered(const bool value) { m_primitivesTransfered = value; }
+
+    vec3f &getViewPos() { return m_viewPos; }
+    vec3f &getViewDir() { return m_viewDir; }
+    vec4f &getViewAngles() { return m_angles; }
+
+    /* ---------- Extensions (no reference equivalent) ---------- */
+    /* The reference draws sceneInfo.timestamp and the random buffer from
+     * rand()/time(0) in render_begin (GPUKernel.cpp:2719-2726).  With a
+     * non-negative seed the timestamp given in SceneInfo is kept and the
+     * random buffer is filled once from a 32-bit LCG with the reference's
+     * distribution 5e-6 * (k % 2000 - 1000); -1 restores rand(). */
+    void setDeterministic(long seed);
+    /* flattened arrays of the current frame, as handed to the device layer */
+    const std::vector<BoundingBox> &hostBoxes() const { return m_hBoundingBoxes; }
+    const std::vector<Primitive> &hostPrimitives() const { return m_hPrimitives; }
+    const std::vector<Lamp> &hostLamps() const { return m_hLamps; }
+    const std::vector<LightInformation> &hostLights() const { return m_lightInformation; }
+    int lightInformationSize() const { return m_lightInformationSize; }
+    const Material *hostMaterials() const { return m_hMaterials.data(); }
+    const std::vector<RandomBuffer> &hostRandoms() const { return m_hRandoms; }
+    const std::vector<BitmapBuffer> &hostTextureAtlas();
+    PrimitiveXYIdBuffer *hostPrimitiveIds() { return m_hPrimitivesXYIds.data(); }
+    unsigned int treeDepth() const { return m_treeDepth; }
+
+protected:
+    struct Frame
+    {
+        BoxContainer boundingBoxes[BOUNDING_BOXES_TREE_DEPTH];
+        PrimitiveContainer primitives;
+        int nbActiveBoxes = 0;
+        int nbActivePrimitives = 0;
+        int nbActiveLamps = 0;
+        vec3f minPos = {0.f, 0.f, 0.f};
+        vec3f maxPos = {0.f, 0.f, 0.f};
+    };
+    Frame &frame() { return m_frames[m_frame]; }
+
+    /* box-tree build (GPUKernel.h:318-324) */
+    int processBoxes(const int boxSize, bool simulate);
+    int processOutterBoxes(const int boxSize, const int boundingBoxesDepth);
+    bool updateBoundingBox(CPUBoundingBox &box);
+    bool updateOutterBoundingBox(CPUBoundingBox &box, const int depth);
+    void resetBox(CPUBoundingBox &box, bool resetPrimitives);
+    void recursiveDataStreamToGPU(const int depth, std::vector<long> &elements);
+    void appendPrimitive(long id);
+    void fillRandoms();
+
+    float vectorLength(const vec3f &v);
+    void normalizeVector(vec3f &v);
+    vec3f crossProduct(const vec3f &b, const vec3f &c);
+    void rotateVector(vec3f &v, const vec3f &rotationCenter, const vec3f &cosAngles, const vec3f &sinAngles);
+
+protected:
+    /* flattened, device-bound arrays (reference: GPUKernel.h:328-339) */
+    std::vector<BoundingBox> m_hBoundingBoxes;
+    std::vector<Primitive> m_hPrimitives;
+    std::vector<Lamp> m_hLamps;
+    std::vector<Material> m_hMaterials;
+    TextureInfo m_hTextures[NB_MAX_TEXTURES];
+    std::vector<BitmapBuffer> m_textureAtlas;
+    std::vector<RandomBuffer> m_hRandoms;
+    std::vector<PrimitiveXYIdBuffer> m_hPrimitivesXYIds;
+    std::vector<LightInformation> m_lightInformation;
+    std::vector<BitmapBuffer> m_bitmap;
+
+    std::map<unsigned int, Frame> m_frames;
+    int m_nbActiveMaterials;
+    int m_nbActiveTextures;
+    int m_lightInformationSize;
+    size_t m_maxPrimitivesPerBox;
+    bool m_doneWithAdding;
+    int m_addingIndex;
+
+    vec3f m_viewPos;
+    vec3f m_viewDir;
+    vec4f m_angles;
+
+    unsigned int m_frame;
+    unsigned int m_nbFrames;
+    unsigned int m_treeDepth;
+
+    bool m_primitivesTransfered;
+    bool m_materialsTransfered;
+    bool m_texturesTransfered;
+    bool m_randomsTransfered;
+
+    SceneInfo m_sceneInfo;
+    PostProcessingInfo m_postProcessingInfo;
+    bool m_refresh;
+    std::string m_gpuDescription;
+    vec2i m_occupancyParameters;
+    bool m_buffersInitialized;
+    long m_deterministicSeed;
+};
+
+/* reference: GPUKernel.h:446-455 */
+class SingletonKernel
+{
+public:
+    static GPUKernel *kernel();
+    /* extension: "hip" (default) or "host-only" (scene store without a
+     * device, render_begin fails loudly; used by the CPU test-suite) */
+    static void selectEngine(const char *name);
+    static void destroy();
+
+private:
+    SingletonKernel();
+    static GPUKernel *m_kernel;
+};
+}

@@ -1,0 +1,182 @@
+/*
+ * HipKernel.cpp - see HipKernel.h.  Frame protocol after the reference's
+ * CudaKernel.cpp:116-166 (device lifetime), :174-302 (render_begin) and
+ * :304-312 (render_end, minus the OpenGL blit).
+ */
+#include "HipKernel.h"
+
+#include <cstring>
+#include <iostream>
+
+#include "../../include/solr_hip.h"
+
+namespace solr
+{
+HipKernel::HipKernel()
+    : GPUKernel()
+    , m_sharedMemSize(0)
+    , m_deviceInitialized(false)
+{
+    /* reference default 12x12 (CudaKernel.cpp:85-88); informational here */
+    m_blockSize = make_vec4i(8, 8, 1, 0);
+    m_occupancyParameters = make_vec2i(1, 1);
+    m_gpuDescription = "HIP device";
+}
+
+HipKernel::~HipKernel()
+{
+    releaseDevice();
+}
+
+void HipKernel::initBuffers()
+{
+    GPUKernel::initBuffers();
+    queryDevice();
+    initializeDevice();
+}
+
+void HipKernel::cleanup()
+{
+    GPUKernel::cleanup();
+    releaseDevice();
+}
+
+void HipKernel::queryDevice()
+{
+    int n = solr_hip_device_count();
+    m_gpuDescription = n > 0 ? "AMD Instinct (HIP), " + std::to_string(n) + " device(s) visible" : "no HIP device";
+}
+
+void HipKernel::initializeDevice()
+{
+    if (m_deviceInitialized)
+        releaseDevice();
+    initialize_scene(m_occupancyParameters, m_sceneInfo, NB_MAX_PRIMITIVES, NB_MAX_LAMPS, NB_MAX_MATERIALS);
+    reshape_scene(m_occupancyParameters, m_sceneInfo);
+    m_deviceInitialized = true;
+}
+
+void HipKernel::releaseDevice()
+{
+    if (m_deviceInitialized)
+        finalize_scene(m_occupancyParameters);
+    m_deviceInitialized = false;
+}
+
+void HipKernel::reshape()
+{
+    GPUKernel::reshape();
+    if (m_deviceInitialized)
+        reshape_scene(m_occupancyParameters, m_sceneInfo);
+}
+
+int HipKernel::lastError(std::string *message)
+{
+    char buf[512];
+    buf[0] = 0;
+    int code = solr_hip_last_error(buf, sizeof(buf));
+    if (message)
+        *message = buf;
+    return code;
+}
+
+void HipKernel::render_begin(const float timer)
+{
+    GPUKernel::render_begin(timer);
+    if (m_refresh)
+    {
+        Frame &f = frame();
+        int nbBoxes = f.nbActiveBoxes;
+        int nbPrimitives = f.nbActivePrimitives;
+        int nbLamps = f.nbActiveLamps;
+        int nbMaterials = m_nbActiveMaterials + 1;
+
+        if (!m_primitivesTransfered)
+        {
+            h2d_scene(m_occupancyParameters, m_hBoundingBoxes.data(), nbBoxes, m_hPrimitives.data(), nbPrimitives,
+                      m_hLamps.data(), nbLamps);
+            h2d_lightInformation(m_occupancyParameters, m_lightInformation.data(), m_lightInformationSize);
+            m_primitivesTransfered = true;
+        }
+        if (!m_randomsTransfered)
+        {
+            h2d_randoms(m_occupancyParameters, m_hRandoms.data());
+            m_randomsTransfered = true;
+        }
+        if (!m_materialsTransfered)
+        {
+            realignTexturesAndMaterials();
+            h2d_materials(m_occupancyParameters, m_hMaterials.data(), nbMaterials);
+            m_materialsTransfered = true;
+        }
+        if (!m_texturesTransfered)
+        {
+            h2d_textures(m_occupancyParameters, NB_MAX_TEXTURES, m_hTextures);
+            m_texturesTransfered = true;
+        }
+
+        vec4i objects = make_vec4i(nbBoxes, nbPrimitives, nbLamps, m_lightInformationSize);
+        SceneInfo sceneInfo = m_sceneInfo;
+        /* draft-mode overrides, CudaKernel.cpp:287-291 */
+        if (m_sceneInfo.draftMode && m_sceneInfo.pathTracingIteration == 0)
+            sceneInfo.graphicsLevel = glNoShading;
+        if (m_sceneInfo.draftMode && m_sceneInfo.pathTracingIteration == m_sceneInfo.maxPathTracingIterations)
+            sceneInfo.cameraType = ctAntialiazed;
+
+        cudaRender(m_occupancyParameters, m_blockSize, sceneInfo, objects, m_postProcessingInfo, m_viewPos, m_viewDir,
+                   m_angles);
+    }
+    m_refresh = (m_sceneInfo.pathTracingIteration < m_sceneInfo.maxPathTracingIterations);
+}
+
+void HipKernel::render_end()
+{
+    d2h_bitmap(m_occupancyParameters, m_sceneInfo, m_bitmap.data(), m_hPrimitivesXYIds.data());
+}
+
+void HostOnlyKernel::render_begin(const float)
+{
+    m_failed = true;
+    std::cerr << "HostOnlyKernel::render_begin: this engine has no device; rendering requires the HIP engine"
+              << std::endl;
+}
+
+void HostOnlyKernel::render_end()
+{
+    m_failed = true;
+}
+
+int HostOnlyKernel::lastError(std::string *message)
+{
+    if (m_failed && message)
+        *message = "host-only engine cannot render";
+    return m_failed ? -1 : 0;
+}
+
+/* reference: GPUKernel.cpp:115-128 (compile-time there, run-time here) */
+static std::string gEngineName = "hip";
+
+void SingletonKernel::selectEngine(const char *name)
+{
+    destroy();
+    gEngineName = name ? name : "hip";
+}
+
+void SingletonKernel::destroy()
+{
+    delete m_kernel;
+    m_kernel = nullptr;
+}
+
+GPUKernel *SingletonKernel::kernel()
+{
+    if (!m_kernel)
+    {
+        if (gEngineName == "host-only")
+            m_kernel = new HostOnlyKernel();
+        else
+            m_kernel = new HipKernel();
+    }
+    return m_kernel;
+}
+}

@@ -1,0 +1,69 @@
+/*
+ * HipKernel.h - the engine class that drives the MI355X device layer.
+ *
+ * Takes the place of the reference's solr::CudaKernel
+ * (reference: solr/engines/cuda/CudaKernel.h:27-72, CudaKernel.cpp:81-389):
+ * a GPUKernel subclass whose render_begin performs the dirty-flag driven
+ * uploads and launches the frame through the ten extern "C" entry points of
+ * include/solr_hip.h, and whose render_end brings the bitmap and primitive
+ * ids back.  No OpenGL calls (the reference blits in render_end,
+ * CudaKernel.cpp:313-388; see INTEGRATION.md for where that block goes).
+ */
+#pragma once
+
+#include "GPUKernel.h"
+
+namespace solr
+{
+class HipKernel : public GPUKernel
+{
+public:
+    HipKernel();
+    ~HipKernel();
+
+    void initBuffers() override;
+    void cleanup() override;
+    void reshape() override;
+    void queryDevice() override;
+    std::string getGPUDescription() override { return m_gpuDescription; }
+
+    /* reference: CudaKernel.h:44-47 */
+    void initializeDevice();
+    void releaseDevice();
+    void resetBoxesAndPrimitives() {}
+
+    /* reference: CudaKernel.cpp:174-302 / 304-389 */
+    void render_begin(const float timer) override;
+    void render_end() override;
+    int lastError(std::string *message = nullptr) override;
+
+    /* reference: CudaKernel.h:59-65; accepted and forwarded, the wave64 tile
+     * shape is the engine's choice */
+    void setBlockSize(int x, int y, int z)
+    {
+        m_blockSize.x = x;
+        m_blockSize.y = y;
+        m_blockSize.z = z;
+    }
+    void setSharedMemSize(int sharedMemSize) { m_sharedMemSize = sharedMemSize; }
+
+private:
+    vec4i m_blockSize;
+    int m_sharedMemSize;
+    bool m_deviceInitialized;
+};
+
+/* Scene store without a device: everything up to compactBoxes works, any
+ * attempt to render fails loudly.  Exists so that the host logic can be
+ * tested on machines without a GPU; it is NOT a CPU rendering fallback. */
+class HostOnlyKernel : public GPUKernel
+{
+public:
+    void render_begin(const float timer) override;
+    void render_end() override;
+    int lastError(std::string *message = nullptr) override;
+
+private:
+    bool m_failed = false;
+};
+}

@@ -1,0 +1,115 @@
+/*
+ * SolRStub.h - flat extern "C" facade over the singleton engine.
+ *
+ * Same names, argument order and return conventions as the reference's
+ * solr/SolRStub.h:36-135 (0 / -1 ints, doubles converted to floats, no C++
+ * exceptions across the boundary) for every call that feeds or runs the
+ * rendering path.  Not provided (out of scope): the
+ * OpenCL queries, file loaders (SolR_LoadMolecule, SolR_LoadOBJModel,
+ * SolR_LoadTextureFromFile, SolR_SaveToFile, SolR_LoadFromFile),
+ * SolR_GenerateScreenshot and the Kinect call.
+ *
+ * SolRx_* are extensions used by the test-suite and bench.py: engine
+ * selection, deterministic timestamps/randoms, access to the flattened arrays
+ * and to the float framebuffer.
+ */
+#pragma once
+
+#include "../../include/solr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------- Scene (SolRStub.h:44-60) ---------- */
+int SolR_SetSceneInfo(int width, int height, int graphicsLevel, int nbRayIterations, double transparentColor,
+                      double viewDistance, double shadowIntensity, double eyeSeparation, double bgColorR,
+                      double bgColorG, double bgColorB, double bgColorA, int renderBoxes, int pathTracingIteration,
+                      int maxPathTracingIterations, int frameBufferType, int timestamp, int atmosphericEffect,
+                      int cameraType, int doubleSidedTriangles, int extendedGeometry, int advancedIllumination,
+                      int skyboxSize, int skyboxMaterialId, double geometryEpsilon, double rayEpsilon);
+int SolR_SetPostProcessingInfo(int type, double param1, double param2, int param3);
+int SolR_SetDraftMode(int draft);
+int SolR_InitializeKernel(bool activeLogging, int platform, int device);
+int SolR_FinalizeKernel();
+int SolR_ResetKernel();
+
+/* ---------- Camera (SolRStub.h:65-66) ---------- */
+void SolR_SetCamera(double eye_x, double eye_y, double eye_z, double dir_x, double dir_y, double dir_z,
+                    double angle_x, double angle_y, double angle_z);
+
+/* ---------- Rendering (SolRStub.h:69) ---------- */
+int SolR_RunKernel(double timer, BitmapBuffer *image);
+
+/* ---------- Primitives (SolRStub.h:72-103) ---------- */
+int SolR_AddPrimitive(int type, int movable);
+int SolR_SetPrimitive(int index, double p0_x, double p0_y, double p0_z, double p1_x, double p1_y, double p1_z,
+                      double p2_x, double p2_y, double p2_z, double size_x, double size_y, double size_z,
+                      int materialId);
+int SolR_GetPrimitive(int index, double *p0_x, double *p0_y, double *p0_z, double *p1_x, double *p1_y, double *p1_z,
+                      double *p2_x, double *p2_y, double *p2_z, double *size_x, double *size_y, double *size_z,
+                      int *materialId);
+int SolR_GetPrimitiveAt(int x, int y);
+int SolR_GetPrimitiveCenter(int index, double *x, double *y, double *z);
+int SolR_RotatePrimitives(int fromBoxId, int toBoxId, double rx, double ry, double rz, double ax, double ay,
+                          double az);
+int SolR_SetPrimitiveMaterial(int index, int materialId);
+int SolR_GetPrimitiveMaterial(int index);
+int SolR_SetPrimitiveNormals(int index, double n0_x, double n0_y, double n0_z, double n1_x, double n1_y, double n1_z,
+                             double n2_x, double n2_y, double n2_z);
+int SolR_SetPrimitiveTextureCoordinates(int index, double t0_x, double t0_y, double t1_x, double t1_y, double t2_x,
+                                        double t2_y);
+
+/* ---------- Materials (SolRStub.h:106-125) ---------- */
+int SolR_AddMaterial();
+int SolR_SetMaterial(int index, double color_r, double color_g, double color_b, double noise, double reflection,
+                     double refraction, int procedural, int wireframe, int wireframeDepth, double transparency,
+                     double opacity, int diffuseTextureId, int normalTextureId, int bumpTextureId,
+                     int specularTextureId, int reflectionTextureId, int transparencyTextureId,
+                     int ambientOcclusionTextureId, double specValue, double specPower, double specCoef,
+                     double innerIllumination, double illuminationDiffusion, double illuminationPropagation,
+                     int fastTransparency);
+
+/* ---------- Boxes / lights (SolRStub.h:128-131) ---------- */
+int SolR_CompactBoxes(bool update);
+int SolR_GetLight(int index);
+
+/* ---------- Textures (SolRStub.h:134-138).  The reference's SolR_SetTexture
+ * is an empty TODO (SolRStub.cpp:357-366); this one takes the pixels. */
+int SolR_SetTexture(int index, const unsigned char *pixels, int width, int height, int depth, int textureType);
+int SolR_GetTextureSize(int index, int *width, int *height, int *depth);
+int SolR_GetNbTextures(int *nbTextures);
+
+/* ---------- Extensions ---------- */
+/* "hip" (default) or "host-only"; destroys the current singleton */
+int SolRx_SelectEngine(const char *name);
+/* seed >= 0: keep SceneInfo.timestamp and fill the random buffer from a seeded
+ * LCG; seed < 0: reference behaviour (rand()/time(0)) */
+int SolRx_SetDeterministic(long seed);
+/* pending engine error: 0 = none; copies the text into buf when non-null */
+int SolRx_LastError(char *buf, int len);
+/* render_begin + render_end without copying the bitmap */
+int SolRx_Render(double timer);
+/* flattened arrays of the current frame (owned by the engine, valid until
+ * the next compactBoxes / material change) */
+int SolRx_GetBoxes(const BoundingBox **boxes, int *nbBoxes);
+int SolRx_GetPrimitives(const Primitive **primitives, int *nbPrimitives);
+int SolRx_GetLights(const LightInformation **lights, int *nbLights, int *nbLamps);
+int SolRx_GetMaterials(const Material **materials, int *nbMaterials);
+int SolRx_GetRandoms(const float **randoms, int *nbRandoms);
+int SolRx_GetTextureAtlas(const unsigned char **atlas, long *nbBytes);
+int SolRx_GetPrimitiveIds(const PrimitiveXYIdBuffer **ids, int *nbPixels);
+int SolRx_GetSceneInfo(SceneInfo *sceneInfo, PostProcessingInfo *postProcessingInfo, float eye[3], float dir[3],
+                       float angles[4]);
+int SolRx_GetTreeDepth();
+/* float framebuffer of the last frame, W*H records */
+int SolRx_GetPostProcessingBuffer(PostProcessingBuffer *buffer);
+/* camera with an explicit angles.w (SolR_SetCamera forces 6400) */
+void SolRx_SetCameraW(double eye_x, double eye_y, double eye_z, double dir_x, double dir_y, double dir_z,
+                      double angle_x, double angle_y, double angle_z, double angle_w);
+int SolRx_AddRectangle(double x, double y, double z, double w, double h, double d, int materialId);
+int SolRx_SetSceneInfoExtras(int gradientBackground, int draftMode);
+
+#ifdef __cplusplus
+}
+#endif
