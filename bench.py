@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py - Mrays/s of the Sol-R per-pixel rendering path on MI355X.
+
+Workload (BASELINE.json configs[1]): Cornell box, 1920x1080, 3 reflection bounces +
+shadow rays, synthetic scene from sol-r_amd/scenes.py.  One "step" = one frame:
+k_standardRenderer over this rank's row strip (scene resident in HBM, uploaded before
+the timed region) and, for N > 1, the RCCL gather of the RGB strips to rank 0.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` = (closest-hit walks + shadow walks of the whole
+frame) * steps / wall time / 1e6, summed over all ranks, max wall time over ranks.
+`roofline` prices the renderer kernel against HBM bandwidth with the algorithmic bytes
+of DESIGN.md (67 B per pixel + one read of the scene), timed with HIP events on the
+launch stream.  `cpu_baseline` times the CPU oracle (a port of the reference algorithm,
+see oracle/solr_oracle.h) on the host cores of the same box on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_PIXEL = 67    # 16 (ids write) + 32 (float framebuffer write) + 16 (ids read, refinement passes) + 3 (RGB)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--iterations", type=int, default=3)
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "height_field", "molecule"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    solr = importlib.import_module("sol-r_amd")
+    hip = solr.hip_lib()
+    if hip.solr_hip_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+
+    torch = dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    rows_per_rank = (H + world - 1) // world
+    first_row = rank * rows_per_rank
+    nb_rows = max(0, min(rows_per_rank, H - first_row))
+
+    # ---- scene (built once on every rank: the scene is replicated, pixels are sharded)
+    k = solr.Kernel(engine="hip")
+    hip.solr_hip_set_device(local_rank)
+    builder = getattr(solr.scenes, args.scene)
+    kw = dict(width=W, height=H, iterations=args.iterations)
+    if args.scene != "cornell":
+        kw.pop("iterations")
+    builder(k, **kw)
+    hip.solr_hip_set_variant(args.variant)
+    if world > 1:
+        hip.solr_hip_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        hip.solr_hip_set_strip(first_row, nb_rows)
+        strip = torch.zeros((nb_rows * W * 3,), dtype=torch.uint8, device="cuda")
+        hip.solr_hip_bind_device_bitmap(C.c_void_p(strip.data_ptr()))
+        gathered = ([torch.zeros((rows_per_rank * W * 3,), dtype=torch.uint8, device="cuda") for _ in range(world)]
+                    if rank == 0 else None)
+        padded = strip
+        if nb_rows != rows_per_rank:  # last strip may be shorter: gather needs equal sizes
+            padded = torch.zeros((rows_per_rank * W * 3,), dtype=torch.uint8, device="cuda")
+
+    # first frame through the full host protocol: uploads scene, materials, randoms
+    k.L.SolRx_Render(0.0)
+    k.check(0, "first frame")
+    flat = k.flat_scene()
+    si, ppi, eye, direction, angles = k.frame_parameters()
+    objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+
+    def frame():
+        hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+        if world > 1:
+            if padded is not strip:
+                padded[: strip.numel()].copy_(strip)
+            dist.gather(padded, gathered, dst=0)
+
+    def sync():
+        if world > 1:
+            torch.cuda.synchronize()
+        else:
+            hip.solr_hip_synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- ray census of this rank's strip (untimed; input-determined)
+    counts = (C.c_ulonglong * 4)()
+    hip.solr_hip_render_counting(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles),
+                                 counts)
+    k.check(0, "ray census")
+    rays_local = int(counts[0]) + int(counts[1])
+
+    for _ in range(args.warmup):
+        frame()
+    sync()
+    hip.solr_hip_kernel_time(None, 1)
+    hip.solr_hip_enable_timing(1)
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    sync()
+    barrier()
+    t1 = time.perf_counter()
+    hip.solr_hip_enable_timing(0)
+    k.check(0, "timed frames")
+    elapsed = t1 - t0
+    launches = C.c_int(0)
+    kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
+
+    rays_total = rays_local
+    if world > 1:
+        t = torch.tensor([elapsed, float(rays_local), kernel_ms / max(launches.value, 1)], dtype=torch.float64,
+                         device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rays_total = int(tsum[1])
+        kernel_avg_ms = float(tmax[2])
+    else:
+        kernel_avg_ms = kernel_ms / max(launches.value, 1)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    mrays = rays_total * args.steps / elapsed / 1e6
+    scene_bytes = (48 * len(flat.boxes) + 128 * len(flat.primitives) + 48 * len(flat.lights) +
+                   176 * len(set(int(m) for m in flat.primitives["materialId"])))
+    algo_bytes = nb_rows * W * BYTES_PER_PIXEL + scene_bytes  # per launch, rank 0's strip
+    achieved = algo_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+    out = {
+        "metric": "Mrays/s @1920x1080, 3-bounce Cornell",
+        "value": round(mrays, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, row strips of %d" %
+                   (args.scene, W, H, args.iterations, len(flat.boxes), len(flat.primitives), rows_per_rank),
+                   "rays_per_frame": rays_total, "closest_hit_walks_rank0": int(counts[0]),
+                   "shadow_walks_rank0": int(counts[1]), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 2),
+                   "parallelism": "tile%d" % world},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                     "kernel": "k_standardRenderer", "kernel_ms": round(kernel_avg_ms, 5),
+                     "algorithmic_bytes": algo_bytes},
+    }
+
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(flat, si, ppi, eye, direction, angles, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(flat, si, ppi, eye, direction, angles, budget_s):
+    """The CPU oracle on all host cores, on a bounded sample of the same frame."""
+    from oracle import loader
+    threads = loader.max_threads()
+    H = si.size_y
+    # calibrate on a 1/8 centre band, then size the sample to about budget_s seconds of work
+    band = max(8, H // 8)
+    first = (H - band) // 2
+    t0 = time.perf_counter()
+    _, _, _, c, status = loader.render(flat, si, ppi, eye, direction, angles, first_row=first, nb_rows=band)
+    dt = time.perf_counter() - t0
+    rate = (c[0] + c[1]) / dt
+    frames = 0
+    rays = 0
+    t0 = time.perf_counter()
+    while True:
+        _, _, _, c, status = loader.render(flat, si, ppi, eye, direction, angles)
+        rays += c[0] + c[1]
+        frames += 1
+        if time.perf_counter() - t0 > budget_s or frames >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%d full %dx%d frames of the same scene in %.1f s (OpenMP over rows, %d threads); "
+                      "calibration band %.1f Mrays/s" % (frames, si.size_x, si.size_y, dt, threads, rate / 1e6)}
+
+
+if __name__ == "__main__":
+    main()

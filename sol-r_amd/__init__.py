@@ -25,7 +25,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-HIP_LIB = os.path.join(_HERE, "csrc", "libsolr_hip.so")
+HIP_LIB = os.environ.get("SOLR_HIP_LIB") or os.path.join(_HERE, "csrc", "libsolr_hip.so")
 HOST_LIB = os.path.join(_HERE, "host", "libsolr.so")
 
 # ---- constants (include/solr_types.h) ---------------------------------------

@@ -64,11 +64,15 @@ SOLR_DEV v3 operator*(v3 a, float b) { return V(a.x * b, a.y * b, a.z * b); }
 SOLR_DEV v3 vdivs(v3 a, float b) { return V(a.x / b, a.y / b, a.z / b); }
 SOLR_DEV v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
 SOLR_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-SOLR_DEV float length(v3 v) { return __fsqrt_rn(dot(v, v)); }
+/* correctly rounded square root: __builtin_sqrtf gets hipcc's IEEE expansion
+ * (v_sqrt_f32 + one fma-based correction step); __fsqrt_rn does NOT - it
+ * lowers to the bare 1-ULP v_sqrt_f32 on gfx950 */
+SOLR_DEV float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
+SOLR_DEV float length(v3 v) { return sqrt_ieee(dot(v, v)); }
 /* HM:62-65,1309-1313: v * (1 / sqrt(dot)) - two roundings, as on the host */
 SOLR_DEV v3 normalize(v3 v)
 {
-    float invLen = 1.0f / __fsqrt_rn(dot(v, v));
+    float invLen = 1.0f / sqrt_ieee(dot(v, v));
     return v * invLen;
 }
 /* VU:45-52 */
@@ -109,7 +113,7 @@ SOLR_DEV v3 vectorRefraction(v3 incident, float n1, v3 normal, float n2)
         float cs2 = 1.f - eta * eta * (1.f - c1 * c1);
         if (cs2 >= 0.f)
         {
-            float k = eta * c1 - __fsqrt_rn(cs2);
+            float k = eta * c1 - sqrt_ieee(cs2);
             refracted = incident * eta + normal * k;
         }
     }
@@ -119,7 +123,11 @@ SOLR_DEV v3 vectorRefraction(v3 incident, float n1, v3 normal, float n2)
 SOLR_DEV v3 project(v3 A, v3 B) { return B * (dot(A, B) / dot(B, B)); }
 
 /* transcendental stand-ins: binary64 evaluation, one rounding to binary32 */
+#ifdef SOLR_EXP_NO_POW
+SOLR_DEV float pow_f(float a, float b) { return a * b; }
+#else
 SOLR_DEV float pow_f(float a, float b) { return (float)pow((double)a, (double)b); }
+#endif
 SOLR_DEV float cos_f(float a) { return (float)cos((double)a); }
 SOLR_DEV float sin_f(float a) { return (float)sin((double)a); }
 SOLR_DEV float atan2_f(float a, float b) { return (float)atan2((double)a, (double)b); }
@@ -211,7 +219,7 @@ struct TexOut
 };
 
 /* TM:238-279 (and its two copies): texel fetch plus the optional maps */
-SOLR_DEV void fetchTexel(const MaterialCold &mc, const unsigned char *__restrict__ tex, int u, int v, float4 &result,
+SOLR_DEV void fetchTexel(const MaterialCold &mc, cbp tex, int u, int v, float4 &result,
                          const TexOut &o)
 {
     int A = (v * mc.textureMapping.x + u) * mc.textureMapping.w;
@@ -326,7 +334,7 @@ SOLR_DEV void mandelbrotSet(const MaterialCold &mc, const SceneInfo &si, float x
 
 /* TM:354-447 (non-Kinect build) */
 SOLR_DEV float4 cubeMapping(const SceneInfo &si, int type, v3 p0, v3 size, const float4 &matColor,
-                            const MaterialCold &mc, const unsigned char *__restrict__ tex, v3 intersection,
+                            const MaterialCold &mc, cbp tex, v3 intersection,
                             const TexOut &o)
 {
     float4 result = matColor;
@@ -358,7 +366,7 @@ SOLR_DEV float4 cubeMapping(const SceneInfo &si, int type, v3 p0, v3 size, const
 
 /* TM:291-346 */
 SOLR_DEV float4 sphereUVMapping(v3 p0, float vt1x, float vt1y, const float4 &matColor, const MaterialCold &mc,
-                                const unsigned char *__restrict__ tex, v3 intersection, const TexOut &o)
+                                cbp tex, v3 intersection, const TexOut &o)
 {
     float4 result = matColor;
     v3 I = normalize(intersection - p0);
@@ -378,7 +386,7 @@ SOLR_DEV float4 sphereUVMapping(v3 p0, float vt1x, float vt1y, const float4 &mat
 /* TM:205-283 */
 SOLR_DEV float4 triangleUVMapping(const SceneInfo &si, float2 vt0, float2 vt1, float2 vt2, int procedural,
                                   const float4 &matColor, const MaterialCold &mc,
-                                  const unsigned char *__restrict__ tex, v3 areas, const TexOut &o)
+                                  cbp tex, v3 areas, const TexOut &o)
 {
     float4 result = matColor;
     float sum = areas.x + areas.y + areas.z;
@@ -447,7 +455,7 @@ SOLR_DEV bool ellipsoidIntersection(const SceneInfo &si, v3 p0, v3 size, const W
     float d = ((b * b) - (4.f * a * c));
     if (d < 0.f || a == 0.f || b == 0.f || c == 0.f)
         return false;
-    d = __fsqrt_rn(d);
+    d = sqrt_ieee(d);
     float t1 = (-b + d) / (2.f * a);
     float t2 = (-b - d) / (2.f * a);
     if (t1 <= si.geometryEpsilon && t2 <= si.geometryEpsilon)
@@ -483,7 +491,7 @@ SOLR_DEV bool sphereIntersection(const SceneInfo &si, v3 p0, v3 size, bool proce
     float d = b * b - 2.f * a * c;
     if (d <= 0.f || a == 0.f)
         return false;
-    float r = __fsqrt_rn(d);
+    float r = sqrt_ieee(d);
     float t1 = (-b - r) / a;
     float t2 = (-b + r) / a;
     if (t1 <= si.geometryEpsilon && t2 <= si.geometryEpsilon)
@@ -540,7 +548,7 @@ SOLR_DEV bool cylinderIntersection(const SceneInfo &si, v3 p0, v3 p1, v3 p2, v3 
     if (t < 0.f)
         return false;
     O = normalize(cross(n, n1));
-    float s = fabsf(__fsqrt_rn(size.x * size.x - d * d) / dot(dir, O));
+    float s = fabsf(sqrt_ieee(size.x * size.x - d * d) / dot(dir, O));
     float t1 = t - s;
     float t2 = t + s;
     v3 I = ray.o + dir * t1;
@@ -587,8 +595,7 @@ struct PlaneMaterial
 };
 
 SOLR_DEV bool planeIntersection(const SceneInfo &si, int type, v3 p0, v3 size, v3 n0, const PlaneMaterial &pm,
-                                const MaterialCold *__restrict__ cold, int materialId,
-                                const unsigned char *__restrict__ tex, const WalkRay &ray, Hit &h)
+                                const ScenePlanes &planes, int materialId, const WalkRay &ray, Hit &h)
 {
     bool collision = false;
     const float reverted = 1.f; /* every call site passes reverse = false */
@@ -673,13 +680,17 @@ SOLR_DEV bool planeIntersection(const SceneInfo &si, int type, v3 p0, v3 size, v
     {
         h.shadowIntensity = 1.f;
         float4 color = pm.color;
+#ifdef SOLR_EXP_NO_TEX
+        if (false)
+#else
         if (type == ptCamera || pm.textured)
+#endif
         {
             float4 specular = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 attributes = make_float4(0.f, 0.f, 0.f, 0.f);
             float ao = 0.f;
             TexOut o = {&normal, &specular, &attributes, &ao};
-            color = cubeMapping(si, type, p0, size, pm.color, cold[materialId], tex, I, o);
+            color = cubeMapping(si, type, p0, size, pm.color, loadMaterialCold(planes, materialId), planes.textures, I, o);
             h.shadowIntensity = color.w;
         }
         if ((color.x + color.y + color.z) / 3.f >= si.transparentColor)
@@ -765,6 +776,17 @@ SOLR_DEV bool triangleIntersection(const SceneInfo &si, v3 p0, v3 p1, v3 p2, v3 
 /* All pointers are read-only for the lifetime of the launch.  Indices that
  * are wave-uniform (box cursor, leaf primitive index, light index, material
  * of a uniform primitive) make the compiler select scalar loads. */
+struct SceneArgs /* kernel argument */
+{
+    ScenePointers q;
+    int nbBoxes;
+    int nbPrimitives;
+    int nbLights;
+    int nbLamps;
+    int nested;
+    long nbRandoms;
+};
+
 struct Scene
 {
     ScenePlanes p;
@@ -806,8 +828,8 @@ template <bool SHADOW>
 SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, int type, int materialId,
                             const MaterialHot &mh, const WalkRay &ray, Hit &h)
 {
-    const float4 A = S.p.primA[pi];
-    const float4 D = S.p.primD[pi];
+    const float4 A = ld4(S.p.primA, pi);
+    const float4 D = ld4(S.p.primD, pi);
     const v3 p0 = V4(A);
     const v3 size = V4(D);
     int t = si.extendedGeometry ? type : (int)ptTriangle;
@@ -827,42 +849,50 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, int typ
     case ptCylinder:
     case ptCone:
     {
-        const v3 p1 = V4(S.p.primB[pi]);
-        const v3 p2 = V4(S.p.primC[pi]);
-        const v3 n1 = V4(S.p.primN1[pi]);
+        const v3 p1 = V4(ld4(S.p.primB, pi));
+        const v3 p2 = V4(ld4(S.p.primC, pi));
+        const v3 n1 = V4(ld4(S.p.primN1, pi));
         return cylinderIntersection(si, p0, p1, p2, n1, size, ray, h);
     }
     case ptEllipsoid:
         return ellipsoidIntersection(si, p0, size, ray, h);
     case ptTriangle:
     {
-        const v3 p1 = V4(S.p.primB[pi]);
-        const v3 p2 = V4(S.p.primC[pi]);
-        const v3 n0 = V4(S.p.primN0[pi]);
-        const v3 n1 = V4(S.p.primN1[pi]);
-        const v3 n2 = V4(S.p.primN2[pi]);
+        const v3 p1 = V4(ld4(S.p.primB, pi));
+        const v3 p2 = V4(ld4(S.p.primC, pi));
+        const v3 n0 = V4(ld4(S.p.primN0, pi));
+        const v3 n1 = V4(ld4(S.p.primN1, pi));
+        const v3 n2 = V4(ld4(S.p.primN2, pi));
         return triangleIntersection(si, p0, p1, p2, n0, n1, n2, ray, h, SHADOW);
     }
     default:
     {
-        const v3 n0 = V4(S.p.primN0[pi]);
+        const v3 n0 = V4(ld4(S.p.primN0, pi));
         PlaneMaterial pm;
         pm.wireframe = mh.attributes.z;
         pm.wireframeWidth = mh.attributes.w;
         pm.emissive = mh.innerIllumination.x != 0.f;
+#ifdef SOLR_EXP_NO_TEX
+        pm.textured = false;
+#else
         pm.textured = mh.ids.x != TEXTURE_NONE;
+#endif
         pm.color = mh.color;
-        return planeIntersection(si, type, p0, size, n0, pm, S.p.matCold, materialId, S.p.textures, ray, h);
+        return planeIntersection(si, type, p0, size, n0, pm, S.p, materialId, ray, h);
     }
     }
 }
 
 /* next node for the wave: see the file header */
+SOLR_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 SOLR_DEV int nextNode(const Scene &S, int cur, int skip, bool anyEntered, int cursor)
 {
+    /* readfirstlane pins the result to an SGPR: every plane access indexed
+     * with it becomes a scalar load */
     if (S.nested)
-        return anyEntered ? cur + 1 : cur + skip;
-    return waveMinInt(cursor);
+        return uniform(anyEntered ? cur + 1 : cur + skip);
+    return uniform(waveMinInt(cursor));
 }
 
 /* GI:667-772, wave-synchronous.  `active` lanes trace origin -> target. */
@@ -883,10 +913,10 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     int cur = 0;
     while (cur < S.nbBoxes)
     {
-        const float4 lo = S.p.boxLo[cur];
-        const float4 hi = S.p.boxHi[cur];
-        const int nbPrimitives = asint(lo.w);
-        const int skip = asint(hi.w);
+        const float4 lo = ld4(S.p.boxLo, cur);
+        const float4 hi = ld4(S.p.boxHi, cur);
+        const int nbPrimitives = uniform(asint(lo.w));
+        const int skip = uniform(asint(hi.w));
         const bool here = (cursor == cur);
         bool entered = false;
         if (here)
@@ -903,7 +933,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 if (entered)
                 {
                     const int start = S.p.boxStart[cur];
-                    const float4 c = S.p.matHot[(unsigned)start % (unsigned)NB_MAX_MATERIALS].color;
+                    const float4 c = loadMaterialHot(S.p, (int)((unsigned)start % (unsigned)NB_MAX_MATERIALS)).color;
                     colorBox.x += c.x / 200.f;
                     colorBox.y += c.y / 200.f;
                     colorBox.z += c.z / 200.f;
@@ -911,13 +941,13 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             }
             else if (nbPrimitives > 0)
             {
-                const int start = S.p.boxStart[cur];
+                const int start = uniform(S.p.boxStart[cur]);
                 for (int k = 0; k < nbPrimitives; ++k)
                 {
                     const int pi = start + k;
-                    const int type = asint(S.p.primA[pi].w);
-                    const int materialId = asint(S.p.primB[pi].w);
-                    const MaterialHot &mh = S.p.matHot[materialId];
+                    const int type = uniform(asint(ld4(S.p.primA, pi).w));
+                    const int materialId = uniform(asint(ld4(S.p.primB, pi).w));
+                    const MaterialHot mh = loadMaterialHot(S.p, materialId);
                     const int fast = mh.attributes.x;
                     const bool lanes = entered && (fast == 0 || (fast == 1 && currentMaterialId != materialId));
                     if (__ballot(lanes) == 0ull)
@@ -977,10 +1007,10 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     {
         if (__ballot(cursor != SOLR_CURSOR_DONE) == 0ull)
             break;
-        const float4 lo = S.p.boxLo[cur];
-        const float4 hi = S.p.boxHi[cur];
-        const int nbPrimitives = asint(lo.w);
-        const int skip = asint(hi.w);
+        const float4 lo = ld4(S.p.boxLo, cur);
+        const float4 hi = ld4(S.p.boxHi, cur);
+        const int nbPrimitives = uniform(asint(lo.w));
+        const int skip = uniform(asint(hi.w));
         const bool here = (cursor == cur);
         bool entered = false;
         if (here)
@@ -992,14 +1022,14 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         const bool anyEntered = __ballot(entered) != 0ull;
         if (anyEntered && nbPrimitives > 0)
         {
-            const int start = S.p.boxStart[cur];
+            const int start = uniform(S.p.boxStart[cur]);
             for (int k = 0; k < nbPrimitives; ++k)
             {
                 const int pi = start + k;
-                const int type = asint(S.p.primA[pi].w);
-                const int materialId = asint(S.p.primB[pi].w);
-                const int index = asint(S.p.primC[pi].w);
-                const MaterialHot &mh = S.p.matHot[materialId];
+                const int type = uniform(asint(ld4(S.p.primA, pi).w));
+                const int materialId = uniform(asint(ld4(S.p.primB, pi).w));
+                const int index = uniform(asint(ld4(S.p.primC, pi).w));
+                const MaterialHot mh = loadMaterialHot(S.p, materialId);
                 const bool lanes = entered && result < si.shadowIntensity && index != lightId && index != objectId &&
                                    mh.attributes.x == 0;
                 if (__ballot(lanes) == 0ull)
@@ -1060,7 +1090,11 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
 {
     float4 c = mh.color;
     c.w = 0.f;
+#ifdef SOLR_EXP_NO_TEX
+    const bool textured = false;
+#else
     const bool textured = mh.ids.x != TEXTURE_NONE;
+#endif
     if (si.extendedGeometry)
     {
         switch (type)
@@ -1072,18 +1106,18 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
         case ptEllipsoid:
             if (textured)
             {
-                const v3 p0 = V4(S.p.primA[pi]);
-                const float vt1x = S.p.primN2[pi].w;
-                const float vt1y = S.p.primT[pi].x;
-                c = sphereUVMapping(p0, vt1x, vt1y, mh.color, S.p.matCold[materialId], S.p.textures, intersection, o);
+                const v3 p0 = V4(ld4(S.p.primA, pi));
+                const float vt1x = ld4(S.p.primN2, pi).w;
+                const float vt1y = ld4(S.p.primT, pi).x;
+                c = sphereUVMapping(p0, vt1x, vt1y, mh.color, loadMaterialCold(S.p, materialId), S.p.textures, intersection, o);
             }
             break;
         case ptCheckboard:
         {
-            const v3 p0 = V4(S.p.primA[pi]);
-            const v3 size = V4(S.p.primD[pi]);
+            const v3 p0 = V4(ld4(S.p.primA, pi));
+            const v3 size = V4(ld4(S.p.primD, pi));
             if (textured)
-                c = cubeMapping(si, type, p0, size, mh.color, S.p.matCold[materialId], S.p.textures, intersection, o);
+                c = cubeMapping(si, type, p0, size, mh.color, loadMaterialCold(S.p, materialId), S.p.textures, intersection, o);
             else
             {
                 int x = (int)(si.viewDistance + ((intersection.x - p0.x) / size.x));
@@ -1115,19 +1149,19 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
         case ptCamera:
             if (textured)
             {
-                const v3 p0 = V4(S.p.primA[pi]);
-                const v3 size = V4(S.p.primD[pi]);
-                c = cubeMapping(si, type, p0, size, mh.color, S.p.matCold[materialId], S.p.textures, intersection, o);
+                const v3 p0 = V4(ld4(S.p.primA, pi));
+                const v3 size = V4(ld4(S.p.primD, pi));
+                c = cubeMapping(si, type, p0, size, mh.color, loadMaterialCold(S.p, materialId), S.p.textures, intersection, o);
             }
             break;
         case ptTriangle:
             if (textured)
             {
-                const float2 vt0 = make_float2(S.p.primN0[pi].w, S.p.primN1[pi].w);
-                const float4 T = S.p.primT[pi];
-                const float2 vt1 = make_float2(S.p.primN2[pi].w, T.x);
+                const float2 vt0 = make_float2(ld4(S.p.primN0, pi).w, ld4(S.p.primN1, pi).w);
+                const float4 T = ld4(S.p.primT, pi);
+                const float2 vt1 = make_float2(ld4(S.p.primN2, pi).w, T.x);
                 const float2 vt2 = make_float2(T.y, T.z);
-                c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, S.p.matCold[materialId],
+                c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, loadMaterialCold(S.p, materialId),
                                       S.p.textures, areas, o);
             }
             break;
@@ -1137,11 +1171,11 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
     }
     else if (textured)
     {
-        const float2 vt0 = make_float2(S.p.primN0[pi].w, S.p.primN1[pi].w);
-        const float4 T = S.p.primT[pi];
-        const float2 vt1 = make_float2(S.p.primN2[pi].w, T.x);
+        const float2 vt0 = make_float2(ld4(S.p.primN0, pi).w, ld4(S.p.primN1, pi).w);
+        const float4 T = ld4(S.p.primT, pi);
+        const float2 vt1 = make_float2(ld4(S.p.primN2, pi).w, T.x);
         const float2 vt2 = make_float2(T.y, T.z);
-        c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, S.p.matCold[materialId], S.p.textures,
+        c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, loadMaterialCold(S.p, materialId), S.p.textures,
                               areas, o);
     }
     return c;
@@ -1156,10 +1190,10 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
                             float &shadowIntensity, v3 &totalBlinn, float4 &attributes, Counters &cnt)
 {
     const int pi = active ? objectId : 0;
-    const int type = asint(S.p.primA[pi].w);
-    const int materialId = asint(S.p.primB[pi].w);
-    const int primIndex = asint(S.p.primC[pi].w);
-    const MaterialHot mh = S.p.matHot[materialId];
+    const int type = asint(ld4(S.p.primA, pi).w);
+    const int materialId = asint(ld4(S.p.primB, pi).w);
+    const int primIndex = asint(ld4(S.p.primC, pi).w);
+    const MaterialHot mh = loadMaterialHot(S.p, materialId);
     v3 lampsColor = V(0.f, 0.f, 0.f);
     v3 intersectionColor = V(0.f, 0.f, 0.f);
     float4 specular = make_float4(mh.specular.x, mh.specular.y, mh.specular.z, 0.f);
@@ -1192,11 +1226,11 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
         {
             const int cptLamp =
                 (si.pathTracingIteration >= NB_MAX_ITERATIONS) ? (si.pathTracingIteration % S.nbLights) : 0;
-            const LightPlane li = S.p.lights[cptLamp];
+            const LightPlane li = loadLight(S.p, cptLamp);
             const int lightPrimitiveId = asint(li.location.w);
             const int lightMaterialId = li.materialId;
             /* materials[MATERIAL_NONE] is read out of bounds by the reference */
-            const MaterialHot &m = S.p.matHot[lightMaterialId < 0 ? 0 : lightMaterialId];
+            const MaterialHot m = loadMaterialHot(S.p, lightMaterialId < 0 ? 0 : lightMaterialId);
             const bool lit = shade && (lightPrimitiveId != primIndex);
 
             v3 center = V4(li.location);
@@ -1232,7 +1266,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
             }
             if (inRange) /* graphicsLevel > glNoShading holds here, GI:1000 */
             {
-                float photonEnergy = __fsqrt_rn(lightRayLength / m.innerIllumination.z);
+                float photonEnergy = sqrt_ieee(lightRayLength / m.innerIllumination.z);
                 photonEnergy = (photonEnergy > 1.f) ? 1.f : photonEnergy;
                 photonEnergy = (photonEnergy < 0.f) ? 0.f : photonEnergy;
                 lambert *= (lambert < 0.f) ? -mh.transparency : 1.f;
@@ -1252,7 +1286,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
                 {
                     v3 viewRay = normalize(intersection - origin);
                     v3 blinnDir = lightRay - viewRay;
-                    float temp = __fsqrt_rn(dot(blinnDir, blinnDir));
+                    float temp = sqrt_ieee(dot(blinnDir, blinnDir));
                     if (temp != 0.f)
                     {
                         blinnDir = blinnDir * (1.f / temp);
@@ -1291,7 +1325,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
 /* GI:87-151 (per lane) */
 SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 target)
 {
-    const MaterialHot &mh = S.p.matHot[si.skyboxMaterialId];
+    const MaterialHot mh = loadMaterialHot(S.p, si.skyboxMaterialId);
     v3 result = V(mh.color.x, mh.color.y, mh.color.z);
     v3 dir = normalize(target - origin);
     float a = 2.f * dot(dir, dir);
@@ -1300,7 +1334,7 @@ SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 tar
     float d = b * b - 2.f * a * c;
     if (d <= 0.f || a == 0.f)
         return result;
-    float r = __fsqrt_rn(d);
+    float r = sqrt_ieee(d);
     float t1 = (-b - r) / a;
     float t2 = (-b + r) / a;
     if (t1 <= si.geometryEpsilon && t2 <= si.geometryEpsilon)
@@ -1317,7 +1351,7 @@ SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 tar
     v3 I = normalize(origin + dir * t);
     float U = ((atan2_f(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
     float Vv = (asin_f(I.y) / SOLR_PI) + .5f;
-    const MaterialCold &mc = S.p.matCold[si.skyboxMaterialId];
+    const MaterialCold mc = loadMaterialCold(S.p, si.skyboxMaterialId);
     int u = (int)(mc.textureMapping.x * U);
     int v = (int)(mc.textureMapping.y * Vv);
     if (mc.textureMapping.x != 0)
@@ -1402,7 +1436,11 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
     v3 rrO = V(0.f, 0.f, 0.f), rrD = V(0.f, 0.f, 0.f);
     float reflectedRatio = 0.f;
 
+#ifdef SOLR_EXP_NO_GI
+    const bool giEnabled = false;
+#else
     const bool giEnabled = (si.advancedIllumination == aiBasic || si.advancedIllumination == aiFull);
+#endif
     const bool giPass = giEnabled && si.pathTracingIteration >= NB_MAX_ITERATIONS;
     v3 ptO = V(0.f, 0.f, 0.f), ptD = V(0.f, 0.f, 0.f);
     float pathTracingRatio = 0.f;
@@ -1458,8 +1496,8 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
 
         /* material of the hit (per-lane gather) */
         const int cp = hitLane ? closestPrimitive : 0;
-        const int cpMaterial = asint(S.p.primB[cp].w);
-        const MaterialHot cm = S.p.matHot[cpMaterial < 0 ? 0 : cpMaterial];
+        const int cpMaterial = asint(ld4(S.p.primB, cp).w);
+        const MaterialHot cm = loadMaterialHot(S.p, cpMaterial < 0 ? 0 : cpMaterial);
         float4 attributes = make_float4(0.f, 0.f, 0.f, 0.f);
         bool shadeLane = hitLane;
         int shadeIteration = tIter;
@@ -1492,7 +1530,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                         pathTracingRatio = (1.f - attributes.y) * fabsf(cos_theta);
                         useGlobalIllumination = true;
                     }
-                    primitiveXYId.x = asint(S.p.primC[cp].w);
+                    primitiveXYId.x = asint(ld4(S.p.primC, cp).w);
                 }
             }
         }

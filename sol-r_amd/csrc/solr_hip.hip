@@ -59,12 +59,23 @@ struct PixelRecord
 static_assert(sizeof(PixelRecord) == sizeof(PostProcessingBuffer), "PixelRecord layout");
 
 template <bool COUNT>
-__global__ __launch_bounds__(WAVE) void k_standardRenderer(const Scene S, const FrameArgs F,
+#ifndef SOLR_WAVES_PER_EU
+#define SOLR_WAVES_PER_EU 3
+#endif
+__global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(const SceneArgs SA, const FrameArgs F,
                                                            PixelRecord *__restrict__ pp,
                                                            int4 *__restrict__ ids, unsigned char *__restrict__ bitmap,
                                                            unsigned long long *__restrict__ counters)
 {
     extern __shared__ float ldsStack[];
+    Scene S;
+    S.p = makePlanes(SA.q);
+    S.nbBoxes = SA.nbBoxes;
+    S.nbPrimitives = SA.nbPrimitives;
+    S.nbLights = SA.nbLights;
+    S.nbLamps = SA.nbLamps;
+    S.nested = SA.nested;
+    S.nbRandoms = SA.nbRandoms;
     const SceneInfo &si = F.si;
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
@@ -545,25 +556,25 @@ int validateNesting(const BoundingBox *boxes, int n)
     return 1;
 }
 
-Scene makeScene()
+SceneArgs makeScene()
 {
-    Scene S;
-    S.p.boxLo = (const float4 *)g.boxLo.ptr;
-    S.p.boxHi = (const float4 *)g.boxHi.ptr;
-    S.p.boxStart = (const int *)g.boxStart.ptr;
-    S.p.primA = (const float4 *)g.primA.ptr;
-    S.p.primB = (const float4 *)g.primB.ptr;
-    S.p.primC = (const float4 *)g.primC.ptr;
-    S.p.primD = (const float4 *)g.primD.ptr;
-    S.p.primN0 = (const float4 *)g.primN0.ptr;
-    S.p.primN1 = (const float4 *)g.primN1.ptr;
-    S.p.primN2 = (const float4 *)g.primN2.ptr;
-    S.p.primT = (const float4 *)g.primT.ptr;
-    S.p.matHot = (const MaterialHot *)g.matHot.ptr;
-    S.p.matCold = (const MaterialCold *)g.matCold.ptr;
-    S.p.lights = (const LightPlane *)g.lights.ptr;
-    S.p.textures = (const unsigned char *)g.textures.ptr;
-    S.p.randoms = (const float *)g.randoms.ptr;
+    SceneArgs S;
+    S.q.boxLo = g.boxLo.ptr;
+    S.q.boxHi = g.boxHi.ptr;
+    S.q.boxStart = g.boxStart.ptr;
+    S.q.primA = g.primA.ptr;
+    S.q.primB = g.primB.ptr;
+    S.q.primC = g.primC.ptr;
+    S.q.primD = g.primD.ptr;
+    S.q.primN0 = g.primN0.ptr;
+    S.q.primN1 = g.primN1.ptr;
+    S.q.primN2 = g.primN2.ptr;
+    S.q.primT = g.primT.ptr;
+    S.q.matHot = g.matHot.ptr;
+    S.q.matCold = g.matCold.ptr;
+    S.q.lights = g.lights.ptr;
+    S.q.textures = g.textures.ptr;
+    S.q.randoms = g.randoms.ptr;
     S.nbBoxes = g.nbBoxes;
     S.nbPrimitives = g.nbPrimitives;
     S.nbLights = g.nbLights;
@@ -595,7 +606,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     if (!ok())
         return;
 
-    Scene S = makeScene();
+    SceneArgs S = makeScene();
     S.nbBoxes = objects.x;
     S.nbPrimitives = objects.y;
     S.nbLamps = objects.z;
