@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--iterations", type=int, default=3)
     ap.add_argument("--scene", default="cornell", choices=["cornell", "height_field", "molecule"])
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--graphics-level", type=int, default=4, help="experiments only; the metric is quoted at 4 (glFull)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -83,6 +84,8 @@ def main():
     if args.scene != "cornell":
         kw.pop("iterations")
     builder(k, **kw)
+    if args.graphics_level != 4:
+        k.set_scene_info(graphicsLevel=args.graphics_level)
     hip.solr_hip_set_variant(args.variant)
     if world > 1:
         hip.solr_hip_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -121,7 +124,7 @@ def main():
             dist.barrier()
 
     # ---- ray census of this rank's strip (untimed; input-determined)
-    counts = (C.c_ulonglong * 4)()
+    counts = (C.c_ulonglong * 8)()
     hip.solr_hip_render_counting(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles),
                                  counts)
     k.check(0, "ray census")
@@ -186,7 +189,8 @@ def main():
         "config": {"workload": "%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, row strips of %d" %
                    (args.scene, W, H, args.iterations, len(flat.boxes), len(flat.primitives), rows_per_rank),
                    "rays_per_frame": rays_total, "closest_hit_walks_rank0": int(counts[0]),
-                   "shadow_walks_rank0": int(counts[1]), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 2),
+                   "shadow_walks_rank0": int(counts[1]), "lane_nodes": int(counts[2]), "lane_prim_tests": int(counts[3]),
+                   "wave_nodes": int(counts[4]), "wave_prim_tests": int(counts[5]), "wave_walks": int(counts[6]) + int(counts[7]), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 2),
                    "parallelism": "tile%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,

@@ -139,11 +139,14 @@ double solr_hip_kernel_time(int *nbLaunches, int reset);
  * the number of box-tree traversals: counts[0] = closest-hit walks
  * (intersectionWithPrimitives calls), counts[1] = shadow walks
  * (processShadows calls), counts[2] = box nodes visited (summed over lanes),
- * counts[3] = primitive tests (summed over lanes).  Output buffers are
- * written exactly as by the normal variant. */
+ * counts[3] = primitive tests (summed over lanes); counts[4..7] are the same
+ * four quantities counted once per WAVE (nodes the wave stepped through,
+ * primitive tests it issued, closest-hit and shadow walks it ran), which
+ * gives the SIMD efficiency of the wave-synchronous walk.  Output buffers
+ * are written exactly as by the normal variant. */
 void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
                               const PostProcessingInfo *postProcessingInfo, const float origin[3],
-                              const float direction[3], const float angles[4], unsigned long long counts[4]);
+                              const float direction[3], const float angles[4], unsigned long long counts[8]);
 
 /* Kernel variant selection (A/B measurements): 0 = automatic, 1 = scene read
  * through the scalar cache from HBM, 2 = scene staged in LDS (small scenes

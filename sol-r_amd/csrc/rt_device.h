@@ -123,11 +123,7 @@ SOLR_DEV v3 vectorRefraction(v3 incident, float n1, v3 normal, float n2)
 SOLR_DEV v3 project(v3 A, v3 B) { return B * (dot(A, B) / dot(B, B)); }
 
 /* transcendental stand-ins: binary64 evaluation, one rounding to binary32 */
-#ifdef SOLR_EXP_NO_POW
-SOLR_DEV float pow_f(float a, float b) { return a * b; }
-#else
 SOLR_DEV float pow_f(float a, float b) { return (float)pow((double)a, (double)b); }
-#endif
 SOLR_DEV float cos_f(float a) { return (float)cos((double)a); }
 SOLR_DEV float sin_f(float a) { return (float)sin((double)a); }
 SOLR_DEV float atan2_f(float a, float b) { return (float)atan2((double)a, (double)b); }
@@ -163,6 +159,8 @@ SOLR_DEV v3 vectorRotation(v3 v, v3 c, const Trig &t)
 struct WalkRay
 {
     v3 o, d, inv;
+    v3 dn;    /* normalize(d): the reference recomputes it in every sphere / ellipsoid /
+                 triangle test of the walk (GI:168,227,642,650); it only depends on the ray */
     bool sx, sy, sz;
 };
 SOLR_DEV WalkRay makeWalkRay(v3 origin, v3 direction)
@@ -170,6 +168,7 @@ SOLR_DEV WalkRay makeWalkRay(v3 origin, v3 direction)
     WalkRay r;
     r.o = origin;
     r.d = direction;
+    r.dn = normalize(direction);
     r.inv.x = direction.x != 0.f ? 1.f / direction.x : 1.f;
     r.inv.y = direction.y != 0.f ? 1.f / direction.y : 1.f;
     r.inv.z = direction.z != 0.f ? 1.f / direction.z : 1.f;
@@ -445,7 +444,7 @@ SOLR_DEV bool ellipsoidIntersection(const SceneInfo &si, v3 p0, v3 size, const W
 {
     h.shadowIntensity = 1.f;
     v3 O_C = ray.o - p0;
-    v3 dir = normalize(ray.d);
+    v3 dir = ray.dn;
     float a = ((dir.x * dir.x) / (size.x * size.x)) + ((dir.y * dir.y) / (size.y * size.y)) +
               ((dir.z * dir.z) / (size.z * size.z));
     float b = ((2.f * O_C.x * dir.x) / (size.x * size.x)) + ((2.f * O_C.y * dir.y) / (size.y * size.y)) +
@@ -484,7 +483,7 @@ SOLR_DEV bool sphereIntersection(const SceneInfo &si, v3 p0, v3 size, bool proce
 {
     bool back = false;
     v3 O_C = ray.o - p0;
-    v3 dir = normalize(ray.d);
+    v3 dir = ray.dn;
     float a = 2.f * dot(dir, dir);
     float b = 2.f * dot(O_C, dir);
     float c = dot(O_C, O_C) - (size.x * size.x);
@@ -591,11 +590,11 @@ struct PlaneMaterial
     int wireframeWidth; /* attributes.w */
     bool emissive;      /* innerIllumination.x != 0 */
     bool textured;      /* textureIds.x != TEXTURE_NONE */
-    float4 color;
+    int materialId;     /* colour is fetched only on a collision */
 };
 
 SOLR_DEV bool planeIntersection(const SceneInfo &si, int type, v3 p0, v3 size, v3 n0, const PlaneMaterial &pm,
-                                const ScenePlanes &planes, int materialId, const WalkRay &ray, Hit &h)
+                                const Scene &planes, int materialId, const WalkRay &ray, Hit &h)
 {
     bool collision = false;
     const float reverted = 1.f; /* every call site passes reverse = false */
@@ -679,18 +678,15 @@ SOLR_DEV bool planeIntersection(const SceneInfo &si, int type, v3 p0, v3 size, v
     if (collision)
     {
         h.shadowIntensity = 1.f;
-        float4 color = pm.color;
-#ifdef SOLR_EXP_NO_TEX
-        if (false)
-#else
+        const float4 matColor = loadMaterialHot(planes, pm.materialId).color;
+        float4 color = matColor;
         if (type == ptCamera || pm.textured)
-#endif
         {
             float4 specular = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 attributes = make_float4(0.f, 0.f, 0.f, 0.f);
             float ao = 0.f;
             TexOut o = {&normal, &specular, &attributes, &ao};
-            color = cubeMapping(si, type, p0, size, pm.color, loadMaterialCold(planes, materialId), planes.textures, I, o);
+            color = cubeMapping(si, type, p0, size, matColor, loadMaterialCold(planes, materialId), planes.textures, I, o);
             h.shadowIntensity = color.w;
         }
         if ((color.x + color.y + color.z) / 3.f >= si.transparentColor)
@@ -752,7 +748,7 @@ SOLR_DEV bool triangleIntersection(const SceneInfo &si, v3 p0, v3 p1, v3 p2, v3 
     if (si.doubleSidedTriangles)
     {
         /* GI:643-647: dangling else - shadow tests always miss */
-        v3 N = normalize(ray.d);
+        v3 N = ray.dn;
         if (processingShadows)
         {
             if (dot(N, h.normal) <= 0.f)
@@ -761,7 +757,7 @@ SOLR_DEV bool triangleIntersection(const SceneInfo &si, v3 p0, v3 p1, v3 p2, v3 
                 return false;
         }
     }
-    v3 dir = normalize(ray.d);
+    v3 dir = ray.dn;
     float r = dot(dir, h.normal);
     if (r > 0.f)
         h.normal = h.normal * -1.f;
@@ -776,31 +772,10 @@ SOLR_DEV bool triangleIntersection(const SceneInfo &si, v3 p0, v3 p1, v3 p2, v3 
 /* All pointers are read-only for the lifetime of the launch.  Indices that
  * are wave-uniform (box cursor, leaf primitive index, light index, material
  * of a uniform primitive) make the compiler select scalar loads. */
-struct SceneArgs /* kernel argument */
-{
-    ScenePointers q;
-    int nbBoxes;
-    int nbPrimitives;
-    int nbLights;
-    int nbLamps;
-    int nested;
-    long nbRandoms;
-};
-
-struct Scene
-{
-    ScenePlanes p;
-    int nbBoxes;
-    int nbPrimitives;
-    int nbLights;
-    int nbLamps;
-    int nested;      /* 1: skip pointers form nested intervals (validated on upload) */
-    long nbRandoms;
-};
-
 struct Counters
 {
-    unsigned int closest, shadow, boxes, prims;
+    unsigned int closest, shadow, boxes, prims; /* per lane */
+    unsigned int wNodes, wPrims, wClosest, wShadow; /* per wave (only lane 0's copy is reported) */
 };
 
 template <bool COUNT>
@@ -823,15 +798,15 @@ SOLR_DEV int waveMinInt(int v)
 
 #define SOLR_CURSOR_DONE 0x7fffffff
 
-/* uniform primitive test shared by both walks; `lanes` = lanes that test it */
+/* Uniform primitive test shared by both walks.  `head` holds rows 0-1 of the
+ * record (p0 + tag, size + materialId); the other rows are fetched per type. */
 template <bool SHADOW>
-SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, int type, int materialId,
-                            const MaterialHot &mh, const WalkRay &ray, Hit &h)
+SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const Row2 &head, int tag,
+                            const WalkRay &ray, Hit &h)
 {
-    const float4 A = ld4(S.p.primA, pi);
-    const float4 D = ld4(S.p.primD, pi);
-    const v3 p0 = V4(A);
-    const v3 size = V4(D);
+    const int type = tag & PRIM_TYPE_MASK;
+    const v3 p0 = V4(head.a);
+    const v3 size = V4(head.b);
     int t = si.extendedGeometry ? type : (int)ptTriangle;
     if (SHADOW)
     {
@@ -845,40 +820,38 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, int typ
     {
     case ptEnvironment:
     case ptSphere:
-        return sphereIntersection(si, p0, size, mh.attributes.y != 0, mh.transparency != 0.f, ray, h);
+        return sphereIntersection(si, p0, size, (tag & PRIM_PROCEDURAL) != 0, (tag & PRIM_TRANSPARENT) != 0, ray,
+                                  h);
     case ptCylinder:
     case ptCone:
     {
-        const v3 p1 = V4(ld4(S.p.primB, pi));
-        const v3 p2 = V4(ld4(S.p.primC, pi));
-        const v3 n1 = V4(ld4(S.p.primN1, pi));
+        const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
+        const v3 p2 = V4(primRow(S, pi, ROW_P2));
+        const v3 n1 = V4(primRow(S, pi, ROW_N1));
         return cylinderIntersection(si, p0, p1, p2, n1, size, ray, h);
     }
     case ptEllipsoid:
         return ellipsoidIntersection(si, p0, size, ray, h);
     case ptTriangle:
     {
-        const v3 p1 = V4(ld4(S.p.primB, pi));
-        const v3 p2 = V4(ld4(S.p.primC, pi));
-        const v3 n0 = V4(ld4(S.p.primN0, pi));
-        const v3 n1 = V4(ld4(S.p.primN1, pi));
-        const v3 n2 = V4(ld4(S.p.primN2, pi));
+        const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
+        const v3 p2 = V4(primRow(S, pi, ROW_P2));
+        const v3 n0 = V4(primRow(S, pi, ROW_N0));
+        const v3 n1 = V4(primRow(S, pi, ROW_N1));
+        const v3 n2 = V4(primRow(S, pi, ROW_N2));
         return triangleIntersection(si, p0, p1, p2, n0, n1, n2, ray, h, SHADOW);
     }
     default:
     {
-        const v3 n0 = V4(ld4(S.p.primN0, pi));
+        const v3 n0 = V4(primRow(S, pi, ROW_N0));
+        const int materialId = asint(head.b.w);
         PlaneMaterial pm;
-        pm.wireframe = mh.attributes.z;
-        pm.wireframeWidth = mh.attributes.w;
-        pm.emissive = mh.innerIllumination.x != 0.f;
-#ifdef SOLR_EXP_NO_TEX
-        pm.textured = false;
-#else
-        pm.textured = mh.ids.x != TEXTURE_NONE;
-#endif
-        pm.color = mh.color;
-        return planeIntersection(si, type, p0, size, n0, pm, S.p, materialId, ray, h);
+        pm.wireframe = (tag & PRIM_WIRE2) ? 2 : ((tag & PRIM_WIRE1) ? 1 : 0);
+        pm.wireframeWidth = ((tag >> PRIM_WIDTH_SHIFT) & 0xff) - 1;
+        pm.emissive = (tag & PRIM_EMISSIVE) != 0;
+        pm.textured = (tag & PRIM_TEXTURED) != 0;
+        pm.materialId = materialId;
+        return planeIntersection(si, type, p0, size, n0, pm, S, materialId, ray, h);
     }
     }
 }
@@ -888,15 +861,19 @@ SOLR_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 SOLR_DEV int nextNode(const Scene &S, int cur, int skip, bool anyEntered, int cursor)
 {
-    /* readfirstlane pins the result to an SGPR: every plane access indexed
-     * with it becomes a scalar load */
+    /* readfirstlane pins the result to an SGPR: every access indexed with it
+     * becomes a scalar load */
     if (S.nested)
         return uniform(anyEntered ? cur + 1 : cur + skip);
     return uniform(waveMinInt(cursor));
 }
 
-/* GI:667-772, wave-synchronous.  `active` lanes trace origin -> target. */
-template <bool COUNT>
+/* GI:667-772, wave-synchronous.  `active` lanes trace origin -> target.
+ * The record of node cur+1 is requested while node cur is being tested: the
+ * depth-first order makes it the next node whenever any lane enters cur (and
+ * always for leaves, whose skip is 1), so the scalar-load latency of the walk
+ * is paid only after a subtree is skipped. */
+template <bool COUNT, bool FULL>
 SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v3 origin, v3 target, int iteration,
                              int currentMaterialId, int &closestPrimitive, v3 &closestIntersection,
                              v3 &closestNormal, v3 &closestAreas, v3 &colorBox, Counters &cnt)
@@ -908,17 +885,22 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     const WalkRay r = makeWalkRay(origin, target - origin);
     if (active)
         countAdd<COUNT>(cnt.closest, 1);
+    countAdd<COUNT>(cnt.wClosest, 1);
 
+    const int nbBoxes = S.nbBoxes;
     int cursor = active ? 0 : SOLR_CURSOR_DONE;
     int cur = 0;
-    while (cur < S.nbBoxes)
+    Row2 node = boxNode(S, 0);
+    while (cur < nbBoxes)
     {
-        const float4 lo = ld4(S.p.boxLo, cur);
-        const float4 hi = ld4(S.p.boxHi, cur);
+        const Row2 ahead = boxNode(S, (cur + 1 < nbBoxes) ? cur + 1 : cur);
+        const float4 lo = node.a;
+        const float4 hi = node.b;
         const int nbPrimitives = uniform(asint(lo.w));
         const int skip = uniform(asint(hi.w));
         const bool here = (cursor == cur);
         bool entered = false;
+        countAdd<COUNT>(cnt.wNodes, 1);
         if (here)
         {
             countAdd<COUNT>(cnt.boxes, 1);
@@ -928,12 +910,12 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         const bool anyEntered = __ballot(entered) != 0ull;
         if (anyEntered)
         {
-            if (si.renderBoxes != 0)
+            if (FULL && si.renderBoxes != 0)
             {
                 if (entered)
                 {
-                    const int start = S.p.boxStart[cur];
-                    const float4 c = loadMaterialHot(S.p, (int)((unsigned)start % (unsigned)NB_MAX_MATERIALS)).color;
+                    const int start = boxStart(S, cur);
+                    const float4 c = loadMaterialHot(S, (int)((unsigned)start % (unsigned)NB_MAX_MATERIALS)).color;
                     colorBox.x += c.x / 200.f;
                     colorBox.y += c.y / 200.f;
                     colorBox.z += c.z / 200.f;
@@ -941,17 +923,19 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             }
             else if (nbPrimitives > 0)
             {
-                const int start = uniform(S.p.boxStart[cur]);
+                const int start = uniform(boxStart(S, cur));
                 for (int k = 0; k < nbPrimitives; ++k)
                 {
                     const int pi = start + k;
-                    const int type = uniform(asint(ld4(S.p.primA, pi).w));
-                    const int materialId = uniform(asint(ld4(S.p.primB, pi).w));
-                    const MaterialHot mh = loadMaterialHot(S.p, materialId);
-                    const int fast = mh.attributes.x;
-                    const bool lanes = entered && (fast == 0 || (fast == 1 && currentMaterialId != materialId));
+                    const Row2 head = primHead(S, pi);
+                    const int tag = uniform(asint(head.a.w));
+                    const int materialId = uniform(asint(head.b.w));
+                    /* GI:704-705 */
+                    const bool lanes = entered && ((tag & PRIM_FAST0) != 0 ||
+                                                   ((tag & PRIM_FAST1) != 0 && currentMaterialId != materialId));
                     if (__ballot(lanes) == 0ull)
                         continue;
+                    countAdd<COUNT>(cnt.wPrims, 1);
                     if (lanes)
                     {
                         countAdd<COUNT>(cnt.prims, 1);
@@ -960,7 +944,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                         h.normal = V(0.f, 0.f, 0.f);
                         h.areas = V(0.f, 0.f, 0.f);
                         h.shadowIntensity = 0.f;
-                        const bool i = testPrimitive<false>(S, si, pi, type, materialId, mh, r, h);
+                        const bool i = testPrimitive<false>(S, si, pi, head, tag, r, h);
                         const float distance = length(h.intersection - r.o);
                         if (i && distance > si.geometryEpsilon && distance < minDistance)
                         {
@@ -975,7 +959,9 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 }
             }
         }
-        cur = nextNode(S, cur, skip, anyEntered, cursor);
+        const int next = nextNode(S, cur, skip, anyEntered, cursor);
+        node = (next == cur + 1) ? ahead : boxNode(S, next < nbBoxes ? next : cur);
+        cur = next;
     }
     return intersections;
 }
@@ -990,29 +976,30 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     color = V(0.f, 0.f, 0.f);
     if (__ballot(active) == 0ull)
         return 0.f;
-    WalkRay r;
-    {
-        v3 d = lampCenter - origin;
-        v3 o = origin + normalize(d) * si.rayEpsilon;
-        r = makeWalkRay(o, d);
-    }
+    WalkRay r = makeWalkRay(origin, lampCenter - origin);
+    r.o = origin + r.dn * si.rayEpsilon; /* GI:810-811 */
     const float minDistance = (iteration < 2) ? si.viewDistance : si.viewDistance / (iteration + 1);
     const float lengthOL = length(r.d);
     if (active)
         countAdd<COUNT>(cnt.shadow, 1);
+    countAdd<COUNT>(cnt.wShadow, 1);
 
+    const int nbBoxes = S.nbBoxes;
     int cursor = (active && result < si.shadowIntensity) ? 0 : SOLR_CURSOR_DONE;
     int cur = 0;
-    while (cur < S.nbBoxes)
+    Row2 node = boxNode(S, 0);
+    while (cur < nbBoxes)
     {
         if (__ballot(cursor != SOLR_CURSOR_DONE) == 0ull)
             break;
-        const float4 lo = ld4(S.p.boxLo, cur);
-        const float4 hi = ld4(S.p.boxHi, cur);
+        const Row2 ahead = boxNode(S, (cur + 1 < nbBoxes) ? cur + 1 : cur);
+        const float4 lo = node.a;
+        const float4 hi = node.b;
         const int nbPrimitives = uniform(asint(lo.w));
         const int skip = uniform(asint(hi.w));
         const bool here = (cursor == cur);
         bool entered = false;
+        countAdd<COUNT>(cnt.wNodes, 1);
         if (here)
         {
             countAdd<COUNT>(cnt.boxes, 1);
@@ -1022,18 +1009,19 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         const bool anyEntered = __ballot(entered) != 0ull;
         if (anyEntered && nbPrimitives > 0)
         {
-            const int start = uniform(S.p.boxStart[cur]);
+            const int start = uniform(boxStart(S, cur));
             for (int k = 0; k < nbPrimitives; ++k)
             {
                 const int pi = start + k;
-                const int type = uniform(asint(ld4(S.p.primA, pi).w));
-                const int materialId = uniform(asint(ld4(S.p.primB, pi).w));
-                const int index = uniform(asint(ld4(S.p.primC, pi).w));
-                const MaterialHot mh = loadMaterialHot(S.p, materialId);
+                const Row2 head = primHead(S, pi);
+                const int tag = uniform(asint(head.a.w));
+                const int index = uniform(asint(primRow(S, pi, ROW_P1_INDEX).w));
+                /* GI:829-830 */
                 const bool lanes = entered && result < si.shadowIntensity && index != lightId && index != objectId &&
-                                   mh.attributes.x == 0;
+                                   (tag & PRIM_FAST0) != 0;
                 if (__ballot(lanes) == 0ull)
                     continue;
+                countAdd<COUNT>(cnt.wPrims, 1);
                 if (lanes)
                 {
                     countAdd<COUNT>(cnt.prims, 1);
@@ -1042,16 +1030,18 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                     h.normal = V(0.f, 0.f, 0.f);
                     h.areas = V(0.f, 0.f, 0.f);
                     h.shadowIntensity = 0.f;
-                    const bool hit = testPrimitive<true>(S, si, pi, type, materialId, mh, r, h);
+                    const bool hit = testPrimitive<true>(S, si, pi, head, tag, r, h);
                     if (hit)
                     {
                         const float l = length(h.intersection - r.o);
                         if (l > si.geometryEpsilon && l < lengthOL)
                         {
                             float ratio = h.shadowIntensity * si.shadowIntensity;
-                            if (mh.transparency != 0.f)
+                            if (tag & PRIM_TRANSPARENT)
                             {
-                                v3 O_L = normalize(r.d);
+                                /* coloured shadow through a transparent primitive, GI:880-892 */
+                                const MaterialHot mh = loadMaterialHot(S, uniform(asint(head.b.w)));
+                                v3 O_L = r.dn;
                                 float a = fabsf(dot(O_L, h.normal));
                                 float rr = (mh.transparency == 0.f) ? 1.f : (1.f - mh.transparency);
                                 ratio *= rr * a;
@@ -1068,7 +1058,9 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         /* the reference re-tests `result < shadowIntensity` before every node */
         if (cursor != SOLR_CURSOR_DONE && !(result < si.shadowIntensity))
             cursor = SOLR_CURSOR_DONE;
-        cur = nextNode(S, cur, skip, anyEntered, cursor);
+        const int next = nextNode(S, cur, skip, anyEntered, cursor);
+        node = (next == cur + 1) ? ahead : boxNode(S, next < nbBoxes ? next : cur);
+        cur = next;
     }
     result = fmaxf(0.f, fminf(result, si.shadowIntensity));
     return result;
@@ -1081,7 +1073,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
 SOLR_DEV float rnd(const Scene &S, long i)
 {
     /* out-of-range reads (reference UB) return 0 */
-    return (i >= 0 && i < S.nbRandoms) ? S.p.randoms[i] : 0.f;
+    return (i >= 0 && i < S.nbRandoms) ? S.randoms[i] : 0.f;
 }
 
 /* GS:36-124 for the lane's own primitive (per-lane gathers) */
@@ -1090,11 +1082,7 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
 {
     float4 c = mh.color;
     c.w = 0.f;
-#ifdef SOLR_EXP_NO_TEX
-    const bool textured = false;
-#else
     const bool textured = mh.ids.x != TEXTURE_NONE;
-#endif
     if (si.extendedGeometry)
     {
         switch (type)
@@ -1106,18 +1094,18 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
         case ptEllipsoid:
             if (textured)
             {
-                const v3 p0 = V4(ld4(S.p.primA, pi));
-                const float vt1x = ld4(S.p.primN2, pi).w;
-                const float vt1y = ld4(S.p.primT, pi).x;
-                c = sphereUVMapping(p0, vt1x, vt1y, mh.color, loadMaterialCold(S.p, materialId), S.p.textures, intersection, o);
+                const v3 p0 = V4(primRow(S, pi, ROW_P0_TYPE));
+                const float vt1x = primRow(S, pi, ROW_N2).w;
+                const float vt1y = primRow(S, pi, ROW_UV).x;
+                c = sphereUVMapping(p0, vt1x, vt1y, mh.color, loadMaterialCold(S, materialId), S.textures, intersection, o);
             }
             break;
         case ptCheckboard:
         {
-            const v3 p0 = V4(ld4(S.p.primA, pi));
-            const v3 size = V4(ld4(S.p.primD, pi));
+            const v3 p0 = V4(primRow(S, pi, ROW_P0_TYPE));
+            const v3 size = V4(primRow(S, pi, ROW_SIZE_MAT));
             if (textured)
-                c = cubeMapping(si, type, p0, size, mh.color, loadMaterialCold(S.p, materialId), S.p.textures, intersection, o);
+                c = cubeMapping(si, type, p0, size, mh.color, loadMaterialCold(S, materialId), S.textures, intersection, o);
             else
             {
                 int x = (int)(si.viewDistance + ((intersection.x - p0.x) / size.x));
@@ -1149,20 +1137,20 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
         case ptCamera:
             if (textured)
             {
-                const v3 p0 = V4(ld4(S.p.primA, pi));
-                const v3 size = V4(ld4(S.p.primD, pi));
-                c = cubeMapping(si, type, p0, size, mh.color, loadMaterialCold(S.p, materialId), S.p.textures, intersection, o);
+                const v3 p0 = V4(primRow(S, pi, ROW_P0_TYPE));
+                const v3 size = V4(primRow(S, pi, ROW_SIZE_MAT));
+                c = cubeMapping(si, type, p0, size, mh.color, loadMaterialCold(S, materialId), S.textures, intersection, o);
             }
             break;
         case ptTriangle:
             if (textured)
             {
-                const float2 vt0 = make_float2(ld4(S.p.primN0, pi).w, ld4(S.p.primN1, pi).w);
-                const float4 T = ld4(S.p.primT, pi);
-                const float2 vt1 = make_float2(ld4(S.p.primN2, pi).w, T.x);
+                const float2 vt0 = make_float2(primRow(S, pi, ROW_N0).w, primRow(S, pi, ROW_N1).w);
+                const float4 T = primRow(S, pi, ROW_UV);
+                const float2 vt1 = make_float2(primRow(S, pi, ROW_N2).w, T.x);
                 const float2 vt2 = make_float2(T.y, T.z);
-                c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, loadMaterialCold(S.p, materialId),
-                                      S.p.textures, areas, o);
+                c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, loadMaterialCold(S, materialId),
+                                      S.textures, areas, o);
             }
             break;
         default:
@@ -1171,11 +1159,11 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
     }
     else if (textured)
     {
-        const float2 vt0 = make_float2(ld4(S.p.primN0, pi).w, ld4(S.p.primN1, pi).w);
-        const float4 T = ld4(S.p.primT, pi);
-        const float2 vt1 = make_float2(ld4(S.p.primN2, pi).w, T.x);
+        const float2 vt0 = make_float2(primRow(S, pi, ROW_N0).w, primRow(S, pi, ROW_N1).w);
+        const float4 T = primRow(S, pi, ROW_UV);
+        const float2 vt1 = make_float2(primRow(S, pi, ROW_N2).w, T.x);
         const float2 vt2 = make_float2(T.y, T.z);
-        c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, loadMaterialCold(S.p, materialId), S.p.textures,
+        c = triangleUVMapping(si, vt0, vt1, vt2, mh.attributes.y, mh.color, loadMaterialCold(S, materialId), S.textures,
                               areas, o);
     }
     return c;
@@ -1190,10 +1178,10 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
                             float &shadowIntensity, v3 &totalBlinn, float4 &attributes, Counters &cnt)
 {
     const int pi = active ? objectId : 0;
-    const int type = asint(ld4(S.p.primA, pi).w);
-    const int materialId = asint(ld4(S.p.primB, pi).w);
-    const int primIndex = asint(ld4(S.p.primC, pi).w);
-    const MaterialHot mh = loadMaterialHot(S.p, materialId);
+    const int type = asint(primRow(S, pi, ROW_P0_TYPE).w);
+    const int materialId = asint(primRow(S, pi, ROW_SIZE_MAT).w);
+    const int primIndex = asint(primRow(S, pi, ROW_P1_INDEX).w);
+    const MaterialHot mh = loadMaterialHot(S, materialId);
     v3 lampsColor = V(0.f, 0.f, 0.f);
     v3 intersectionColor = V(0.f, 0.f, 0.f);
     float4 specular = make_float4(mh.specular.x, mh.specular.y, mh.specular.z, 0.f);
@@ -1226,11 +1214,11 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
         {
             const int cptLamp =
                 (si.pathTracingIteration >= NB_MAX_ITERATIONS) ? (si.pathTracingIteration % S.nbLights) : 0;
-            const LightPlane li = loadLight(S.p, cptLamp);
+            const LightPlane li = loadLight(S, cptLamp);
             const int lightPrimitiveId = asint(li.location.w);
             const int lightMaterialId = li.materialId;
             /* materials[MATERIAL_NONE] is read out of bounds by the reference */
-            const MaterialHot m = loadMaterialHot(S.p, lightMaterialId < 0 ? 0 : lightMaterialId);
+            const MaterialHot m = loadMaterialHot(S, lightMaterialId < 0 ? 0 : lightMaterialId);
             const bool lit = shade && (lightPrimitiveId != primIndex);
 
             v3 center = V4(li.location);
@@ -1325,7 +1313,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
 /* GI:87-151 (per lane) */
 SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 target)
 {
-    const MaterialHot mh = loadMaterialHot(S.p, si.skyboxMaterialId);
+    const MaterialHot mh = loadMaterialHot(S, si.skyboxMaterialId);
     v3 result = V(mh.color.x, mh.color.y, mh.color.z);
     v3 dir = normalize(target - origin);
     float a = 2.f * dot(dir, dir);
@@ -1351,7 +1339,7 @@ SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 tar
     v3 I = normalize(origin + dir * t);
     float U = ((atan2_f(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
     float Vv = (asin_f(I.y) / SOLR_PI) + .5f;
-    const MaterialCold mc = loadMaterialCold(S.p, si.skyboxMaterialId);
+    const MaterialCold mc = loadMaterialCold(S, si.skyboxMaterialId);
     int u = (int)(mc.textureMapping.x * U);
     int v = (int)(mc.textureMapping.y * Vv);
     if (mc.textureMapping.x != 0)
@@ -1364,9 +1352,9 @@ SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 tar
         int B = mc.textureMapping.x * mc.textureMapping.y * mc.textureMapping.w;
         int idx = A % B;
         int i = mc.textureOffset.x + idx;
-        result.x = S.p.textures[i] / 256.f;
-        result.y = S.p.textures[i + 1] / 256.f;
-        result.z = S.p.textures[i + 2] / 256.f;
+        result.x = S.textures[i] / 256.f;
+        result.y = S.textures[i + 1] / 256.f;
+        result.z = S.textures[i + 2] / 256.f;
     }
     return result;
 }
@@ -1394,7 +1382,7 @@ struct ColorStack
  * phases 0, 1 and 2 of one wave-uniform loop with a single walk and a single
  * shader call site, which keeps the instruction footprint and the live
  * register set of the kernel small. */
-template <bool COUNT>
+template <bool COUNT, bool FULL>
 SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3 rayD, const SceneInfo &si,
                              float &depthOfField, int4 &primitiveXYId, const ColorStack &cs, Counters &cnt)
 {
@@ -1436,11 +1424,9 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
     v3 rrO = V(0.f, 0.f, 0.f), rrD = V(0.f, 0.f, 0.f);
     float reflectedRatio = 0.f;
 
-#ifdef SOLR_EXP_NO_GI
-    const bool giEnabled = false;
-#else
-    const bool giEnabled = (si.advancedIllumination == aiBasic || si.advancedIllumination == aiFull);
-#endif
+    /* FULL = false is the lean instantiation the host selects when neither
+     * global illumination nor the box-debug view is requested */
+    const bool giEnabled = FULL && (si.advancedIllumination == aiBasic || si.advancedIllumination == aiFull);
     const bool giPass = giEnabled && si.pathTracingIteration >= NB_MAX_ITERATIONS;
     v3 ptO = V(0.f, 0.f, 0.f), ptD = V(0.f, 0.f, 0.f);
     float pathTracingRatio = 0.f;
@@ -1490,14 +1476,14 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
         }
 
         v3 areas = V(0.f, 0.f, 0.f);
-        const bool hit = closestHitWalk<COUNT>(S, si, want, tO, tD, tIter, tMat, closestPrimitive,
+        const bool hit = closestHitWalk<COUNT, FULL>(S, si, want, tO, tD, tIter, tMat, closestPrimitive,
                                                closestIntersection, normal, areas, colorBox, cnt);
         const bool hitLane = want && hit;
 
         /* material of the hit (per-lane gather) */
         const int cp = hitLane ? closestPrimitive : 0;
-        const int cpMaterial = asint(ld4(S.p.primB, cp).w);
-        const MaterialHot cm = loadMaterialHot(S.p, cpMaterial < 0 ? 0 : cpMaterial);
+        const int cpMaterial = asint(primRow(S, cp, ROW_SIZE_MAT).w);
+        const MaterialHot cm = loadMaterialHot(S, cpMaterial < 0 ? 0 : cpMaterial);
         float4 attributes = make_float4(0.f, 0.f, 0.f, 0.f);
         bool shadeLane = hitLane;
         int shadeIteration = tIter;
@@ -1515,7 +1501,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                     cs.set(0, V(0.f, 0.f, 0.f));
                     cs.at(0, 3) = 1.f;
                     latestIntersection = closestIntersection;
-                    depthOfField = length(closestIntersection - rayO);
+                    depthOfField = length(closestIntersection - tO); /* tO is the primary origin in trip 0 */
                     if (giEnabled && cm.innerIllumination.x == 0.f)
                     {
                         int t = (index + si.pathTracingIteration * 100 + si.timestamp) % (MAX_BITMAP_SIZE - 3);
@@ -1530,7 +1516,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                         pathTracingRatio = (1.f - attributes.y) * fabsf(cos_theta);
                         useGlobalIllumination = true;
                     }
-                    primitiveXYId.x = asint(ld4(S.p.primC, cp).w);
+                    primitiveXYId.x = asint(primRow(S, cp, ROW_P1_INDEX).w);
                 }
             }
         }

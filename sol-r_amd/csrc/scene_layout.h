@@ -1,38 +1,47 @@
 /*
- * scene_layout.h - how the scene lives in HBM (and, for small scenes, LDS).
+ * scene_layout.h - how the scene lives in HBM.
  *
  * The host hands over arrays of structures (BoundingBox 48 B, Primitive 128 B,
  * Material 176 B, LightInformation 48 B; include/solr_types.h).  h2d_scene /
- * h2d_materials / h2d_lightInformation re-pack them into planes of float4,
- * one plane per group of fields that a phase of the kernel reads together:
+ * h2d_materials / h2d_lightInformation re-pack them into ROWS of 16 bytes
+ * (one dwordx4 each) inside two arenas, grouped by the phase of the kernel
+ * that reads them together:
  *
- *   box tree      boxLo[i]   = { min.x, min.y, min.z, bits(nbPrimitives) }
- *                 boxHi[i]   = { max.x, max.y, max.z, bits(skip) }
- *                 boxStart[i]= startIndex                     (leaves only)
- *   primitives,   primA[i]   = { p0.xyz,   bits(type) }
- *   traversal     primB[i]   = { p1.xyz,   bits(materialId) }
- *                 primC[i]   = { p2.xyz,   bits(index) }
- *                 primD[i]   = { size.xyz, 0 }
- *   primitives,   primN0[i]  = { n0.xyz, vt0.x }
- *   normals / uv  primN1[i]  = { n1.xyz, vt0.y }
- *                 primN2[i]  = { n2.xyz, vt1.x }
- *                 primT[i]   = { vt1.y, vt2.x, vt2.y, 0 }
- *   materials     matHot[m]  = 96-byte record: everything traversal and
- *                              untextured shading read
- *                 matCold[m] = 96-byte record: texture mapping tables, only
- *                              touched when a textured material is hit
- *   lights        lights[l]  = 48-byte record
+ *   geometry arena
+ *     box node i        row 2i   = { min.x, min.y, min.z, bits(nbPrimitives) }
+ *                       row 2i+1 = { max.x, max.y, max.z, bits(skip) }
+ *     boxStart[i]       int plane: first primitive of a leaf
+ *     primitive i       row 8i   = { p0.xyz,   bits(tag) }         \ sphere / ellipsoid / plane tests
+ *                       row 8i+1 = { size.xyz, bits(materialId) }  / read these 32 bytes only
+ *                       row 8i+2 = { p1.xyz,   bits(index) }       \ + cylinder, triangle: one 64-byte
+ *                       row 8i+3 = { p2.xyz,   0 }                 /   scalar-cache line in total
+ *                       row 8i+4 = { n0.xyz, vt0.x }               \
+ *                       row 8i+5 = { n1.xyz, vt0.y }                | normals / texture coordinates:
+ *                       row 8i+6 = { n2.xyz, vt1.x }                | second cache line, triangle and
+ *                       row 8i+7 = { vt1.y, vt2.x, vt2.y, 0 }      /  textured shading only
+ *     light l           rows 3l..3l+2 = location+bits(primitiveId), colour, materialId
+ *   material arena
+ *     hot record m      rows 6m..6m+5: illumination, colour, specular, {reflection, refraction,
+ *                       transparency, opacity}, attributes, {diffuse id, ambient-occlusion id}
+ *     cold record m     rows 6m..6m+5 (after the hot block): texture mapping tables, only touched
+ *                       when a textured material is hit
  *
- * A sphere test touches primA + primD (32 B) instead of a 128-byte record; a
- * box visit touches 32 B instead of 48 B, and consecutive nodes of the
- * depth-first order are consecutive in both planes, so the scalar cache line
- * fetched for node i already holds nodes i+1..i+3.  All plane elements are
- * 16-byte aligned so that every access is one dwordx4 (s_load_dwordx4 for
- * wave-uniform indices, global_load_dwordx4 / ds_read_b128 for per-lane
- * gathers in the shading phase).
+ * tag = primitive type in bits 0-7 plus the material facts the walks need, joined in at
+ * upload time (PRIM_* below) so that the hot loops never chase materialId -> material record
+ * with a second, dependent scalar load.  The join is redone whenever either side changes.
  *
- * Bytes per element: box 36, primitive 128 (64 traversal + 64 shading),
- * material 192, light 48.
+ * Why rows in an arena and not one plane per field: every access of the walk
+ * is wave-uniform (one node / one primitive for the whole wave) and goes
+ * through the scalar cache, so what matters is (a) the number of 64-byte
+ * scalar-cache lines per test - a sphere is half a line, a triangle two lines -
+ * and (b) the number of SGPRs that address the scene: ONE 64-bit base per arena
+ * plus 32-bit row offsets, instead of a 64-bit base per plane (16 planes cost
+ * 32 of the 102 SGPRs and pushed the kernel into v_readlane/v_writelane spill
+ * traffic: 19 % of its vector instructions).  Per-lane gathers (the shading
+ * phase reads the record of the lane's own hit) fetch rows with
+ * global_load_dwordx4, one or two cache lines per record.
+ *
+ * Bytes per element: box 32 + 4, primitive 128, material 192, light 48.
  */
 #pragma once
 
@@ -72,17 +81,54 @@ struct alignas(16) LightPlane
 };
 static_assert(sizeof(LightPlane) == 48, "LightPlane");
 
-/* What the host passes to the kernel: untyped device pointers. */
-struct ScenePointers
+/* bits of the primitive tag (row 0, w) */
+enum PrimTag
 {
-    const void *boxLo, *boxHi, *boxStart;
-    const void *primA, *primB, *primC, *primD, *primN0, *primN1, *primN2, *primT;
-    const void *matHot, *matCold, *lights, *textures, *randoms;
+    PRIM_TYPE_MASK = 0xff,
+    PRIM_FAST0 = 1 << 8,        /* material.attributes.x == 0 */
+    PRIM_FAST1 = 1 << 9,        /* material.attributes.x == 1 (fast transparency) */
+    PRIM_PROCEDURAL = 1 << 10,  /* material.attributes.y != 0 */
+    PRIM_TRANSPARENT = 1 << 11, /* material.transparency != 0 */
+    PRIM_WIRE1 = 1 << 12,       /* material.attributes.z == 1 */
+    PRIM_WIRE2 = 1 << 13,       /* material.attributes.z == 2 */
+    PRIM_EMISSIVE = 1 << 14,    /* material.innerIllumination.x != 0 */
+    PRIM_TEXTURED = 1 << 15,    /* material.textureIds.x != TEXTURE_NONE */
+    PRIM_WIDTH_SHIFT = 16       /* clamp(material.attributes.w, -1, 100) + 1 */
 };
 
-/* Device view: every plane is read through the CONSTANT address space.  The
+enum PrimRow
+{
+    ROW_P0_TYPE = 0,
+    ROW_SIZE_MAT = 1,
+    ROW_P1_INDEX = 2,
+    ROW_P2 = 3,
+    ROW_N0 = 4,
+    ROW_N1 = 5,
+    ROW_N2 = 6,
+    ROW_UV = 7,
+    PRIM_ROWS = 8
+};
+
+/* What the host passes to the kernel. Offsets are in rows of 16 bytes from the
+ * arena base (offBoxStart: in ints). */
+struct SceneArgs
+{
+    const void *geometry;
+    const void *materials;
+    const void *textures;
+    const void *randoms;
+    unsigned offBoxes, offBoxStart, offPrims, offLights, offMatCold;
+    int nbBoxes;
+    int nbPrimitives;
+    int nbLights;
+    int nbLamps;
+    int nested;
+    long nbRandoms;
+};
+
+/* Device view: everything is read through the CONSTANT address space.  The
  * scene is immutable for the lifetime of a launch, and for loads from this
- * address space hipcc always selects the scalar path (s_load_dwordx4 through
+ * address space hipcc always selects the scalar path (s_load_dwordx4/x8 through
  * the scalar cache into SGPRs) when the index is wave-uniform and the vector
  * path when it is per-lane - without depending on alias analysis, which gives
  * up on a function of this size and silently falls back to vector loads. */
@@ -95,92 +141,121 @@ typedef const SOLR_CONST_AS int *cip;
 typedef const SOLR_CONST_AS float *cfp;
 typedef const SOLR_CONST_AS unsigned char *cbp;
 
-struct ScenePlanes
+struct Scene
 {
-    cf4p boxLo, boxHi;
-    cip boxStart;
-    cf4p primA, primB, primC, primD, primN0, primN1, primN2, primT;
-    cf4p matHot;  /* 6 rows of 16 bytes per material */
-    ci4p matCold; /* 6 rows of 16 bytes per material */
-    cf4p lights;  /* 3 rows of 16 bytes per light */
+    cf4p geo;
+    cf4p mat;
     cbp textures;
     cfp randoms;
+    unsigned offBoxes, offBoxStart, offPrims, offLights, offMatCold;
+    int nbBoxes;
+    int nbPrimitives;
+    int nbLights;
+    int nbLamps;
+    int nested; /* 1: skip pointers form nested intervals (validated on upload) */
+    long nbRandoms;
 };
 
-__device__ __forceinline__ ScenePlanes makePlanes(const ScenePointers &q)
+__device__ __forceinline__ Scene makeScene(const SceneArgs &a)
 {
-    ScenePlanes p;
-    p.boxLo = (cf4p)q.boxLo;
-    p.boxHi = (cf4p)q.boxHi;
-    p.boxStart = (cip)q.boxStart;
-    p.primA = (cf4p)q.primA;
-    p.primB = (cf4p)q.primB;
-    p.primC = (cf4p)q.primC;
-    p.primD = (cf4p)q.primD;
-    p.primN0 = (cf4p)q.primN0;
-    p.primN1 = (cf4p)q.primN1;
-    p.primN2 = (cf4p)q.primN2;
-    p.primT = (cf4p)q.primT;
-    p.matHot = (cf4p)q.matHot;
-    p.matCold = (ci4p)q.matCold;
-    p.lights = (cf4p)q.lights;
-    p.textures = (cbp)q.textures;
-    p.randoms = (cfp)q.randoms;
-    return p;
+    Scene s;
+    s.geo = (cf4p)a.geometry;
+    s.mat = (cf4p)a.materials;
+    s.textures = (cbp)a.textures;
+    s.randoms = (cfp)a.randoms;
+    s.offBoxes = a.offBoxes;
+    s.offBoxStart = a.offBoxStart;
+    s.offPrims = a.offPrims;
+    s.offLights = a.offLights;
+    s.offMatCold = a.offMatCold;
+    s.nbBoxes = a.nbBoxes;
+    s.nbPrimitives = a.nbPrimitives;
+    s.nbLights = a.nbLights;
+    s.nbLamps = a.nbLamps;
+    s.nested = a.nested;
+    s.nbRandoms = a.nbRandoms;
+    return s;
 }
 
-__device__ __forceinline__ float4 ld4(cf4p p, int i)
+typedef float f8v __attribute__((ext_vector_type(8)));
+typedef const SOLR_CONST_AS f8v *cf8p;
+typedef const SOLR_CONST_AS char *ccp;
+
+/* 32-bit byte offset from the arena base: selects the s_load sbase+soffset form
+ * without 64-bit address arithmetic (arenas are < 4 GiB: 2.5 M primitives = 320 MB) */
+__device__ __forceinline__ float4 ld4(cf4p p, unsigned row)
 {
-    const f4v v = p[i];
+    const f4v v = *(cf4p)((ccp)p + (row << 4));
     return make_float4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ int4 ld4i(ci4p p, int i)
+struct Row2
 {
-    const i4v v = p[i];
-    return make_int4(v.x, v.y, v.z, v.w);
+    float4 a, b;
+};
+/* two consecutive rows (32 bytes, 32-byte aligned): one s_load_dwordx8 */
+__device__ __forceinline__ Row2 ld8(cf4p p, unsigned row)
+{
+    const f8v v = *(cf8p)((ccp)p + (row << 4));
+    Row2 r;
+    r.a = make_float4(v[0], v[1], v[2], v[3]);
+    r.b = make_float4(v[4], v[5], v[6], v[7]);
+    return r;
+}
+__device__ __forceinline__ int4 asint4(const float4 &v)
+{
+    return make_int4(__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w));
+}
+
+__device__ __forceinline__ Row2 boxNode(const Scene &s, int i) { return ld8(s.geo, s.offBoxes + 2u * (unsigned)i); }
+__device__ __forceinline__ Row2 primHead(const Scene &s, int i) { return ld8(s.geo, s.offPrims + 8u * (unsigned)i); }
+__device__ __forceinline__ float4 boxLo(const Scene &s, int i) { return ld4(s.geo, s.offBoxes + 2u * (unsigned)i); }
+__device__ __forceinline__ float4 boxHi(const Scene &s, int i) { return ld4(s.geo, s.offBoxes + 2u * (unsigned)i + 1u); }
+__device__ __forceinline__ int boxStart(const Scene &s, int i) { return ((cip)s.geo)[s.offBoxStart + (unsigned)i]; }
+__device__ __forceinline__ float4 primRow(const Scene &s, int i, int row)
+{
+    return ld4(s.geo, s.offPrims + 8u * (unsigned)i + (unsigned)row);
 }
 
 /* unused fields are never loaded: each row is an independent 16-byte load */
-__device__ __forceinline__ MaterialHot loadMaterialHot(const ScenePlanes &p, int id)
+__device__ __forceinline__ MaterialHot loadMaterialHot(const Scene &s, int id)
 {
     MaterialHot m;
-    const int r = id * 6;
-    m.innerIllumination = ld4(p.matHot, r);
-    m.color = ld4(p.matHot, r + 1);
-    m.specular = ld4(p.matHot, r + 2);
-    const float4 a = ld4(p.matHot, r + 3);
+    const unsigned r = 6u * (unsigned)id;
+    m.innerIllumination = ld4(s.mat, r);
+    m.color = ld4(s.mat, r + 1);
+    m.specular = ld4(s.mat, r + 2);
+    const float4 a = ld4(s.mat, r + 3);
     m.reflection = a.x;
     m.refraction = a.y;
     m.transparency = a.z;
     m.opacity = a.w;
-    const float4 b = ld4(p.matHot, r + 4);
-    m.attributes = make_int4(__float_as_int(b.x), __float_as_int(b.y), __float_as_int(b.z), __float_as_int(b.w));
-    const float4 c = ld4(p.matHot, r + 5);
-    m.ids = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
+    m.attributes = asint4(ld4(s.mat, r + 4));
+    m.ids = asint4(ld4(s.mat, r + 5));
     return m;
 }
 
-__device__ __forceinline__ MaterialCold loadMaterialCold(const ScenePlanes &p, int id)
+__device__ __forceinline__ MaterialCold loadMaterialCold(const Scene &s, int id)
 {
     MaterialCold m;
-    const int r = id * 6;
-    m.textureMapping = ld4i(p.matCold, r);
-    m.textureOffset = ld4i(p.matCold, r + 1);
-    m.textureIds = ld4i(p.matCold, r + 2);
-    m.advancedTextureOffset = ld4i(p.matCold, r + 3);
-    m.advancedTextureIds = ld4i(p.matCold, r + 4);
-    const int4 t = ld4i(p.matCold, r + 5);
-    m.mappingOffset = make_float2(__int_as_float(t.x), __int_as_float(t.y));
+    const unsigned r = s.offMatCold + 6u * (unsigned)id;
+    m.textureMapping = asint4(ld4(s.mat, r));
+    m.textureOffset = asint4(ld4(s.mat, r + 1));
+    m.textureIds = asint4(ld4(s.mat, r + 2));
+    m.advancedTextureOffset = asint4(ld4(s.mat, r + 3));
+    m.advancedTextureIds = asint4(ld4(s.mat, r + 4));
+    const float4 t = ld4(s.mat, r + 5);
+    m.mappingOffset = make_float2(t.x, t.y);
     m.pad = make_float2(0.f, 0.f);
     return m;
 }
 
-__device__ __forceinline__ LightPlane loadLight(const ScenePlanes &p, int i)
+__device__ __forceinline__ LightPlane loadLight(const Scene &s, int i)
 {
     LightPlane l;
-    l.location = ld4(p.lights, i * 3);
-    l.color = ld4(p.lights, i * 3 + 1);
-    const float4 t = ld4(p.lights, i * 3 + 2);
+    const unsigned r = s.offLights + 3u * (unsigned)i;
+    l.location = ld4(s.geo, r);
+    l.color = ld4(s.geo, r + 1);
+    const float4 t = ld4(s.geo, r + 2);
     l.materialId = __float_as_int(t.x);
     l.pad[0] = l.pad[1] = l.pad[2] = 0;
     return l;

@@ -58,7 +58,7 @@ struct PixelRecord
 };
 static_assert(sizeof(PixelRecord) == sizeof(PostProcessingBuffer), "PixelRecord layout");
 
-template <bool COUNT>
+template <bool COUNT, bool FULL>
 #ifndef SOLR_WAVES_PER_EU
 #define SOLR_WAVES_PER_EU 3
 #endif
@@ -68,14 +68,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
                                                            unsigned long long *__restrict__ counters)
 {
     extern __shared__ float ldsStack[];
-    Scene S;
-    S.p = makePlanes(SA.q);
-    S.nbBoxes = SA.nbBoxes;
-    S.nbPrimitives = SA.nbPrimitives;
-    S.nbLights = SA.nbLights;
-    S.nbLamps = SA.nbLamps;
-    S.nested = SA.nested;
-    S.nbRandoms = SA.nbRandoms;
+    const Scene S = makeScene(SA);
     const SceneInfo &si = F.si;
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
@@ -103,7 +96,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     cs.base = ldsStack + lane;
     cs.stride = WAVE;
 
-    Counters cnt = {0u, 0u, 0u, 0u};
+    Counters cnt = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 
     v3 rayO = V(F.ox, F.oy, F.oz);
     v3 rayD = V(F.dx, F.dy, F.dz);
@@ -112,22 +105,15 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
         rotationCenter = rayO;
     const bool antialiasingActivated = (si.cameraType == ctAntialiazed);
 
-    float4 ppColor = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 ppScene = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool needPrevious = si.pathTracingIteration >= NB_MAX_ITERATIONS; /* DOF jitter / accumulation */
-    if (active && (needPrevious || si.pathTracingIteration > 0))
-    {
-        ppColor = pp[index].colorInfo;
-        ppScene = pp[index].sceneInfo;
-    }
-
+    /* first-hit distance of the previous pass, only needed for the natural
+     * depth-of-field jitter of the accumulation passes (CRT:470-479) */
     if (F.ppi.type != ppe_depthOfField && si.pathTracingIteration >= NB_MAX_ITERATIONS)
     {
-        /* natural depth of field, CRT:470-479 */
+        const float previousDepth = active ? pp[index].colorInfo.w : 0.f;
         float a = (F.ppi.param1 / 20000.f);
         long rindex = (long)gindex + si.timestamp % (MAX_BITMAP_SIZE - 2);
-        rayO.x += rnd(S, rindex) * ppColor.w * a;
-        rayO.y += rnd(S, rindex + 1) * ppColor.w * a;
+        rayO.x += rnd(S, rindex) * previousDepth * a;
+        rayO.y += rnd(S, rindex + 1) * previousDepth * a;
     }
 
     float dof = 0.f;
@@ -150,26 +136,44 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     rayD = vectorRotation(rayD, rotationCenter, F.trig);
 
     v3 color = V(0.f, 0.f, 0.f);
-    v3 rO = rayO, rD = rayD;
     if (!antialiasingActivated && si.pathTracingIteration >= NB_MAX_ITERATIONS)
     {
         /* rotated-grid jitter of the accumulation passes, CRT:515-522 */
         const int k = si.pathTracingIteration % 4;
-        rD.x += (k == 0) ? 3.f : (k == 1) ? 5.f : (k == 2) ? -3.f : -5.f;
-        rD.y += (k == 0) ? 5.f : (k == 1) ? -3.f : (k == 2) ? -5.f : 3.f;
+        rayD.x += (k == 0) ? 3.f : (k == 1) ? 5.f : (k == 2) ? -3.f : -5.f;
+        rayD.y += (k == 0) ? 5.f : (k == 1) ? -3.f : (k == 2) ? -5.f : 3.f;
     }
-    /* ctAntialiazed: four rotated-grid rays with cumulative origin offsets,
-     * then the centre ray (CRT:504-514, 523-525); otherwise the centre ray only */
+    /* ctAntialiazed: four rotated-grid rays with cumulative origin offsets
+     * (+3,+5) (+8,+2) (+5,-3) (0,0), then the centre ray, which therefore
+     * starts from the same origin as the fourth (CRT:504-514, 523-525);
+     * otherwise the centre ray only.  The offsets are re-applied from the
+     * unjittered origin with the reference's order of additions. */
     const int nbRays = antialiasingActivated ? 5 : 1;
 #pragma unroll 1
     for (int I = 0; I < nbRays; ++I)
     {
-        if (I < nbRays - 1)
+        v3 rO = rayO;
+        if (antialiasingActivated)
         {
-            rO.x += (I == 0) ? 3.f : (I == 1) ? 5.f : (I == 2) ? -3.f : -5.f;
-            rO.y += (I == 0) ? 5.f : (I == 1) ? -3.f : (I == 2) ? -5.f : 3.f;
+            rO.x += 3.f;
+            rO.y += 5.f;
+            if (I >= 1)
+            {
+                rO.x += 5.f;
+                rO.y += -3.f;
+            }
+            if (I >= 2)
+            {
+                rO.x += -3.f;
+                rO.y += -5.f;
+            }
+            if (I >= 3)
+            {
+                rO.x += -5.f;
+                rO.y += 3.f;
+            }
         }
-        v3 c = launchRayTracing<COUNT>(S, active, gindex, rO, rD, si, dof, id, cs, cnt);
+        v3 c = launchRayTracing<COUNT, FULL>(S, active, gindex, rO, rayD, si, dof, id, cs, cnt);
         color = color + c;
     }
 
@@ -190,6 +194,13 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
 
     if (active)
     {
+        float4 ppColor = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 ppScene = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (si.pathTracingIteration > 0)
+        {
+            ppColor = pp[index].colorInfo;
+            ppScene = pp[index].sceneInfo;
+        }
         if (si.pathTracingIteration == 0)
             ppColor.w = dof;
         if (si.pathTracingIteration <= NB_MAX_ITERATIONS)
@@ -239,6 +250,13 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
                 v += __shfl_xor(v, off, 64);
             if (lane == 0)
                 atomicAdd(&counters[k], (unsigned long long)v);
+        }
+        if (lane == 0)
+        {
+            atomicAdd(&counters[4], (unsigned long long)cnt.wNodes);
+            atomicAdd(&counters[5], (unsigned long long)cnt.wPrims);
+            atomicAdd(&counters[6], (unsigned long long)cnt.wClosest);
+            atomicAdd(&counters[7], (unsigned long long)cnt.wShadow);
         }
     }
 }
@@ -399,9 +417,15 @@ struct Engine
     std::string errorText;
 
     /* scene planes */
-    DeviceBuffer boxLo, boxHi, boxStart;
-    DeviceBuffer primA, primB, primC, primD, primN0, primN1, primN2, primT;
-    DeviceBuffer matHot, matCold, lights, textures, randoms, lamps;
+    /* two arenas (scene_layout.h) and their host images */
+    DeviceBuffer geometry, materials, textures, randoms, lamps;
+    std::vector<float4> hostBoxes, hostBoxesCompact, hostPrims, hostLights;
+    std::vector<int> hostBoxStart, hostBoxStartCompact;
+    std::vector<int> materialTags; /* PRIM_* bits per material id */
+    unsigned offBoxes = 0, offBoxesCompact = 0, offBoxStart = 0, offBoxStartCompact = 0, offPrims = 0, offLights = 0;
+    unsigned offMatCold = 0;
+    bool geometryDirty = true;
+    int nbBoxesCompact = 0;
     int nbBoxes = 0, nbPrimitives = 0, nbLights = 0, nbLamps = 0, nbMaterials = 0;
     int nested = 1;
     long nbRandoms = 0;
@@ -526,7 +550,7 @@ void allocateFrame()
     reserve(g.pp, pixels * sizeof(PostProcessingBuffer));
     reserve(g.ids, pixels * sizeof(PrimitiveXYIdBuffer));
     reserve(g.bitmap, pixels * SOLR_COLOR_DEPTH);
-    reserve(g.counters, 4 * sizeof(unsigned long long));
+    reserve(g.counters, 8 * sizeof(unsigned long long));
     if (ok() && (grow || g.allocW != g.width || g.allocRows != rows))
     {
         HIPCHECK(hipMemsetAsync(g.pp.ptr, 0, g.pp.bytes, g.stream));
@@ -556,26 +580,101 @@ int validateNesting(const BoundingBox *boxes, int n)
     return 1;
 }
 
-SceneArgs makeScene()
+/* join the material facts the walks need into every primitive's tag (scene_layout.h) */
+int materialTag(const Material &m)
+{
+    int tag = 0;
+    if (m.attributes.x == 0)
+        tag |= PRIM_FAST0;
+    if (m.attributes.x == 1)
+        tag |= PRIM_FAST1;
+    if (m.attributes.y != 0)
+        tag |= PRIM_PROCEDURAL;
+    if (m.transparency != 0.f)
+        tag |= PRIM_TRANSPARENT;
+    if (m.attributes.z == 1)
+        tag |= PRIM_WIRE1;
+    if (m.attributes.z == 2)
+        tag |= PRIM_WIRE2;
+    if (m.innerIllumination.x != 0.f)
+        tag |= PRIM_EMISSIVE;
+    if (m.textureIds.x != TEXTURE_NONE)
+        tag |= PRIM_TEXTURED;
+    int w = m.attributes.w;
+    w = w < -1 ? -1 : (w > 100 ? 100 : w); /* wireFrameMapping compares X % 100 <= width */
+    tag |= (w + 1) << PRIM_WIDTH_SHIFT;
+    return tag;
+}
+
+void retagPrimitives()
+{
+    const size_t n = g.hostPrims.size() / PRIM_ROWS;
+    for (size_t i = 0; i < n; ++i)
+    {
+        float4 *r = &g.hostPrims[PRIM_ROWS * i];
+        int tag, mat;
+        memcpy(&tag, &r[ROW_P0_TYPE].w, 4);
+        memcpy(&mat, &r[ROW_SIZE_MAT].w, 4);
+        const int type = tag & PRIM_TYPE_MASK;
+        /* a material that was never uploaded reads as all zeros on the device */
+        const int facts = (mat >= 0 && (size_t)mat < g.materialTags.size()) ? g.materialTags[mat] : (PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
+        r[ROW_P0_TYPE].w = bitsf(type | facts);
+    }
+    g.geometryDirty = true;
+}
+
+/* assemble and upload the geometry arena from its host images (scene_layout.h) */
+void flushGeometry()
+{
+    if (!g.geometryDirty)
+        return;
+    auto rowsOfInts = [](size_t n) { return (unsigned)((n + 3) / 4); };
+    unsigned row = 0;
+    g.offBoxes = row;
+    row += (unsigned)g.hostBoxes.size();
+    g.offBoxesCompact = row;
+    row += (unsigned)g.hostBoxesCompact.size();
+    row = (row + 3u) & ~3u; /* primitive records start on a 64-byte line */
+    g.offPrims = row;
+    row += (unsigned)g.hostPrims.size();
+    g.offLights = row;
+    row += (unsigned)g.hostLights.size();
+    const unsigned startRow = row;
+    row += rowsOfInts(g.hostBoxStart.size());
+    const unsigned startRowCompact = row;
+    row += rowsOfInts(g.hostBoxStartCompact.size());
+    g.offBoxStart = startRow * 4;
+    g.offBoxStartCompact = startRowCompact * 4;
+    std::vector<float4> arena(std::max(row, 1u), make_float4(0.f, 0.f, 0.f, 0.f));
+    auto put = [&](unsigned at, const void *src, size_t bytes) {
+        if (bytes)
+            memcpy((char *)arena.data() + (size_t)at * 16, src, bytes);
+    };
+    put(g.offBoxes, g.hostBoxes.data(), g.hostBoxes.size() * 16);
+    put(g.offBoxesCompact, g.hostBoxesCompact.data(), g.hostBoxesCompact.size() * 16);
+    put(g.offPrims, g.hostPrims.data(), g.hostPrims.size() * 16);
+    put(g.offLights, g.hostLights.data(), g.hostLights.size() * 16);
+    put(startRow, g.hostBoxStart.data(), g.hostBoxStart.size() * 4);
+    put(startRowCompact, g.hostBoxStartCompact.data(), g.hostBoxStartCompact.size() * 4);
+    upload(g.geometry, arena);
+    if (ok())
+        g.geometryDirty = false;
+}
+
+SceneArgs makeScene(bool exactNodes)
 {
     SceneArgs S;
-    S.q.boxLo = g.boxLo.ptr;
-    S.q.boxHi = g.boxHi.ptr;
-    S.q.boxStart = g.boxStart.ptr;
-    S.q.primA = g.primA.ptr;
-    S.q.primB = g.primB.ptr;
-    S.q.primC = g.primC.ptr;
-    S.q.primD = g.primD.ptr;
-    S.q.primN0 = g.primN0.ptr;
-    S.q.primN1 = g.primN1.ptr;
-    S.q.primN2 = g.primN2.ptr;
-    S.q.primT = g.primT.ptr;
-    S.q.matHot = g.matHot.ptr;
-    S.q.matCold = g.matCold.ptr;
-    S.q.lights = g.lights.ptr;
-    S.q.textures = g.textures.ptr;
-    S.q.randoms = g.randoms.ptr;
-    S.nbBoxes = g.nbBoxes;
+    memset(&S, 0, sizeof(S));
+    S.geometry = g.geometry.ptr;
+    S.materials = g.materials.ptr;
+    S.textures = g.textures.ptr;
+    S.randoms = g.randoms.ptr;
+    S.offBoxes = exactNodes ? g.offBoxes : g.offBoxesCompact;
+    S.offBoxStart = exactNodes ? g.offBoxStart : g.offBoxStartCompact;
+    S.offPrims = g.offPrims;
+    S.offLights = g.offLights;
+    S.offMatCold = g.offMatCold;
+    S.nbBoxes = exactNodes ? g.nbBoxes : g.nbBoxesCompact;
     S.nbPrimitives = g.nbPrimitives;
     S.nbLights = g.nbLights;
     S.nbLamps = g.nbLamps;
@@ -586,14 +685,14 @@ SceneArgs makeScene()
 
 void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProcessingInfo &ppInfo,
                 const float origin[3], const float direction[3], const float angles[4], bool counting,
-                unsigned long long counts[4])
+                unsigned long long counts[8])
 {
     if (!ready("cudaRender"))
         return;
     ARGCHECK(sceneInfo.size.x > 0 && sceneInfo.size.y > 0, "cudaRender: empty image");
     ARGCHECK(objects.x <= g.nbBoxes && objects.y <= g.nbPrimitives, "cudaRender: more objects than were uploaded");
     ARGCHECK(objects.w <= g.nbLights, "cudaRender: more lights than were uploaded");
-    ARGCHECK(g.matHot.ptr != nullptr, "cudaRender: no materials uploaded");
+    ARGCHECK(g.materials.ptr != nullptr, "cudaRender: no materials uploaded");
     if (!ok())
         return;
     HIPCHECK(hipSetDevice(g.device));
@@ -606,8 +705,16 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     if (!ok())
         return;
 
-    SceneArgs S = makeScene();
-    S.nbBoxes = objects.x;
+    /* the box-debug view and the census count every node of the original tree */
+    const bool full = sceneInfo.renderBoxes != 0 || sceneInfo.advancedIllumination == aiBasic ||
+                      sceneInfo.advancedIllumination == aiFull;
+    const bool exactNodes = counting || sceneInfo.renderBoxes != 0 || objects.x != g.nbBoxes || g.variant == 3;
+    flushGeometry();
+    if (!ok())
+        return;
+    SceneArgs S = makeScene(exactNodes);
+    if (exactNodes)
+        S.nbBoxes = objects.x;
     S.nbPrimitives = objects.y;
     S.nbLamps = objects.z;
     S.nbLights = objects.w;
@@ -657,17 +764,25 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         HIPCHECK(hipEventCreate(&e1));
         HIPCHECK(hipEventRecord(e0, g.stream));
     }
+    PixelRecord *ppPtr = (PixelRecord *)g.pp.ptr;
+    int4 *idPtr = (int4 *)g.ids.ptr;
+    unsigned long long *cntPtr = (unsigned long long *)g.counters.ptr;
     if (counting)
     {
-        HIPCHECK(hipMemsetAsync(g.counters.ptr, 0, 4 * sizeof(unsigned long long), g.stream));
-        hipLaunchKernelGGL(k_standardRenderer<true>, grid, block, ldsBytes, g.stream, S, F,
-                           (PixelRecord *)g.pp.ptr, (int4 *)g.ids.ptr, bitmap,
-                           (unsigned long long *)g.counters.ptr);
+        HIPCHECK(hipMemsetAsync(g.counters.ptr, 0, 8 * sizeof(unsigned long long), g.stream));
+        if (full)
+            hipLaunchKernelGGL((k_standardRenderer<true, true>), grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr,
+                               bitmap, cntPtr);
+        else
+            hipLaunchKernelGGL((k_standardRenderer<true, false>), grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr,
+                               bitmap, cntPtr);
     }
+    else if (full)
+        hipLaunchKernelGGL((k_standardRenderer<false, true>), grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr,
+                           bitmap, cntPtr);
     else
-        hipLaunchKernelGGL(k_standardRenderer<false>, grid, block, ldsBytes, g.stream, S, F,
-                           (PixelRecord *)g.pp.ptr, (int4 *)g.ids.ptr, bitmap,
-                           (unsigned long long *)g.counters.ptr);
+        hipLaunchKernelGGL((k_standardRenderer<false, false>), grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr,
+                           bitmap, cntPtr);
     HIPCHECK(hipGetLastError());
     if (e0)
     {
@@ -692,7 +807,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
 
     if (counting && counts)
     {
-        HIPCHECK(hipMemcpyAsync(counts, g.counters.ptr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+        HIPCHECK(hipMemcpyAsync(counts, g.counters.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                 g.stream));
         HIPCHECK(hipStreamSynchronize(g.stream));
     }
@@ -841,9 +956,8 @@ void finalize_scene(vec2i)
     if (g.stream)
         (void)hipStreamSynchronize(g.stream);
     collectEvents();
-    DeviceBuffer *all[] = {&g.boxLo,  &g.boxHi,  &g.boxStart, &g.primA,   &g.primB,    &g.primC,   &g.primD,
-                           &g.primN0, &g.primN1, &g.primN2,   &g.primT,   &g.matHot,   &g.matCold, &g.lights,
-                           &g.textures, &g.randoms, &g.lamps, &g.pp,      &g.ids,      &g.bitmap,  &g.counters};
+    DeviceBuffer *all[] = {&g.geometry, &g.materials, &g.textures, &g.randoms, &g.lamps,
+                           &g.pp,       &g.ids,       &g.bitmap,   &g.counters};
     for (DeviceBuffer *b : all)
         release(*b);
     if (g.ownStream && g.stream)
@@ -854,6 +968,14 @@ void finalize_scene(vec2i)
     g.nbBoxes = g.nbPrimitives = g.nbLights = g.nbLamps = g.nbMaterials = 0;
     g.allocW = g.allocRows = 0;
     g.boundBitmap = nullptr;
+    g.hostBoxes.clear();
+    g.hostBoxesCompact.clear();
+    g.hostPrims.clear();
+    g.hostLights.clear();
+    g.hostBoxStart.clear();
+    g.hostBoxStartCompact.clear();
+    g.materialTags.clear();
+    g.geometryDirty = true;
     /* no hipDeviceReset: the process may share the device with torch/RCCL */
 }
 
@@ -884,7 +1006,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     ARGCHECK(nbPrimitives == 0 || primitives, "h2d_scene: null primitives");
     if (!ok())
         return;
-    std::vector<float4> lo(nbActiveBoxes), hi(nbActiveBoxes);
+    std::vector<float4> boxes(2 * (size_t)nbActiveBoxes);
     std::vector<int> start(nbActiveBoxes);
     for (int i = 0; i < nbActiveBoxes; ++i)
     {
@@ -892,8 +1014,9 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
         ARGCHECK(b.nbPrimitives >= 0 && (b.nbPrimitives == 0 || (b.startIndex >= 0 &&
                                                                   (long)b.startIndex + b.nbPrimitives <= nbPrimitives)),
                  "h2d_scene: box primitive range outside the primitive array");
-        lo[i] = make_float4(b.parameters[0].x, b.parameters[0].y, b.parameters[0].z, bitsf(b.nbPrimitives));
-        hi[i] = make_float4(b.parameters[1].x, b.parameters[1].y, b.parameters[1].z, bitsf(b.indexForNextBox.x));
+        boxes[2 * i] = make_float4(b.parameters[0].x, b.parameters[0].y, b.parameters[0].z, bitsf(b.nbPrimitives));
+        boxes[2 * i + 1] =
+            make_float4(b.parameters[1].x, b.parameters[1].y, b.parameters[1].z, bitsf(b.indexForNextBox.x));
         start[i] = b.startIndex;
     }
     if (!ok())
@@ -907,37 +1030,71 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
         if (!ok())
             return;
     }
-    std::vector<float4> A(nbPrimitives), B(nbPrimitives), C(nbPrimitives), D(nbPrimitives), N0(nbPrimitives),
-        N1(nbPrimitives), N2(nbPrimitives), T(nbPrimitives);
+
+    /* Collapsed walk order.  The reference's grid builder wraps most leaves in
+     * a chain of inner nodes with bit-identical bounds (one per tree level,
+     * GPUKernel.cpp:1008-1035).  A ray that enters the first node of such a
+     * chain enters all of them - same slabs, same ray, same minDistance since
+     * no primitive is tested in between - and a ray that misses it skips all
+     * of them, so dropping every inner node whose only child has the same
+     * bounds changes no result.  Skip pointers are recomputed in the compacted
+     * numbering and stay nested. */
+    std::vector<char> keep(nbActiveBoxes, 1);
+    if (g.nested)
+        for (int i = 0; i + 1 < nbActiveBoxes; ++i)
+        {
+            const BoundingBox &a = boundingBoxes[i];
+            const BoundingBox &b = boundingBoxes[i + 1];
+            if (a.nbPrimitives == 0 && a.indexForNextBox.x >= 2 && b.indexForNextBox.x == a.indexForNextBox.x - 1 &&
+                memcmp(a.parameters, b.parameters, sizeof(a.parameters)) == 0)
+                keep[i] = 0;
+        }
+    std::vector<int> newIndex(nbActiveBoxes + 1, 0);
+    for (int i = 0; i < nbActiveBoxes; ++i)
+        newIndex[i + 1] = newIndex[i] + (keep[i] ? 1 : 0);
+    const int nc = newIndex[nbActiveBoxes];
+    std::vector<float4> boxesC(2 * (size_t)nc);
+    std::vector<int> startC(nc);
+    for (int i = 0; i < nbActiveBoxes; ++i)
+        if (keep[i])
+        {
+            const int j = newIndex[i];
+            const int end = std::min(i + boundingBoxes[i].indexForNextBox.x, nbActiveBoxes);
+            boxesC[2 * j] = boxes[2 * i];
+            boxesC[2 * j + 1] = boxes[2 * i + 1];
+            boxesC[2 * j + 1].w = bitsf(newIndex[end] - j);
+            startC[j] = start[i];
+        }
+
+    std::vector<float4> prims(8 * (size_t)nbPrimitives);
     for (int i = 0; i < nbPrimitives; ++i)
     {
         const Primitive &p = primitives[i];
-        A[i] = make_float4(p.p0.x, p.p0.y, p.p0.z, bitsf(p.type));
-        B[i] = make_float4(p.p1.x, p.p1.y, p.p1.z, bitsf(p.materialId));
-        C[i] = make_float4(p.p2.x, p.p2.y, p.p2.z, bitsf(p.index));
-        D[i] = make_float4(p.size.x, p.size.y, p.size.z, 0.f);
-        N0[i] = make_float4(p.n0.x, p.n0.y, p.n0.z, p.vt0.x);
-        N1[i] = make_float4(p.n1.x, p.n1.y, p.n1.z, p.vt0.y);
-        N2[i] = make_float4(p.n2.x, p.n2.y, p.n2.z, p.vt1.x);
-        T[i] = make_float4(p.vt1.y, p.vt2.x, p.vt2.y, 0.f);
+        float4 *r = &prims[8 * (size_t)i];
+        r[ROW_P0_TYPE] = make_float4(p.p0.x, p.p0.y, p.p0.z, bitsf(p.type & PRIM_TYPE_MASK));
+        r[ROW_SIZE_MAT] = make_float4(p.size.x, p.size.y, p.size.z, bitsf(p.materialId));
+        r[ROW_P1_INDEX] = make_float4(p.p1.x, p.p1.y, p.p1.z, bitsf(p.index));
+        r[ROW_P2] = make_float4(p.p2.x, p.p2.y, p.p2.z, 0.f);
+        r[ROW_N0] = make_float4(p.n0.x, p.n0.y, p.n0.z, p.vt0.x);
+        r[ROW_N1] = make_float4(p.n1.x, p.n1.y, p.n1.z, p.vt0.y);
+        r[ROW_N2] = make_float4(p.n2.x, p.n2.y, p.n2.z, p.vt1.x);
+        r[ROW_UV] = make_float4(p.vt1.y, p.vt2.x, p.vt2.y, 0.f);
     }
+    if (prims.empty())
+        prims.assign(8, make_float4(0.f, 0.f, 0.f, 0.f)); /* inactive lanes read record 0 */
+    g.hostBoxes.swap(boxes);
+    g.hostBoxesCompact.swap(boxesC);
+    g.hostBoxStart.swap(start);
+    g.hostBoxStartCompact.swap(startC);
+    g.hostPrims.swap(prims);
+    retagPrimitives();
     HIPCHECK(hipSetDevice(g.device));
-    upload(g.boxLo, lo);
-    upload(g.boxHi, hi);
-    upload(g.boxStart, start);
-    upload(g.primA, A);
-    upload(g.primB, B);
-    upload(g.primC, C);
-    upload(g.primD, D);
-    upload(g.primN0, N0);
-    upload(g.primN1, N1);
-    upload(g.primN2, N2);
-    upload(g.primT, T);
     std::vector<int> l(lamps, lamps + (lamps ? nbLamps : 0));
     upload(g.lamps, l);
     if (ok())
     {
         g.nbBoxes = nbActiveBoxes;
+        g.nbBoxesCompact = nc;
         g.nbPrimitives = nbPrimitives;
         g.nbLamps = nbLamps;
     }
@@ -958,9 +1115,11 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
     std::vector<MaterialCold> cold(capacity);
     memset(hot.data(), 0, hot.size() * sizeof(MaterialHot));
     memset(cold.data(), 0, cold.size() * sizeof(MaterialCold));
+    g.materialTags.assign(capacity, PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
     for (int i = 0; i < nbActiveMaterials && i < capacity; ++i)
     {
         const Material &m = materials[i];
+        g.materialTags[i] = materialTag(m);
         MaterialHot &h = hot[i];
         h.innerIllumination = make_float4(m.innerIllumination.x, m.innerIllumination.y, m.innerIllumination.z,
                                           m.innerIllumination.w);
@@ -984,10 +1143,16 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
         c.pad = make_float2(0.f, 0.f);
     }
     HIPCHECK(hipSetDevice(g.device));
-    upload(g.matHot, hot);
-    upload(g.matCold, cold);
+    std::vector<float4> arena(12 * (size_t)capacity);
+    memcpy(arena.data(), hot.data(), hot.size() * sizeof(MaterialHot));
+    memcpy(arena.data() + 6 * (size_t)capacity, cold.data(), cold.size() * sizeof(MaterialCold));
+    upload(g.materials, arena);
     if (ok())
+    {
+        g.offMatCold = 6u * (unsigned)capacity;
         g.nbMaterials = nbActiveMaterials;
+        retagPrimitives();
+    }
 }
 
 void h2d_randoms(vec2i, float *randoms)
@@ -1036,19 +1201,17 @@ void h2d_lightInformation(vec2i, LightInformation *lightInformation, int lightIn
              "h2d_lightInformation: bad arguments");
     if (!ok())
         return;
-    std::vector<LightPlane> l(lightInformationSize);
+    std::vector<float4> l(3 * (size_t)lightInformationSize);
     for (int i = 0; i < lightInformationSize; ++i)
     {
         const LightInformation &s = lightInformation[i];
-        l[i].location = make_float4(s.location.x, s.location.y, s.location.z, bitsf(s.primitiveId));
-        l[i].color = make_float4(s.color.x, s.color.y, s.color.z, s.color.w);
-        l[i].materialId = s.materialId;
-        l[i].pad[0] = l[i].pad[1] = l[i].pad[2] = 0;
+        l[3 * i] = make_float4(s.location.x, s.location.y, s.location.z, bitsf(s.primitiveId));
+        l[3 * i + 1] = make_float4(s.color.x, s.color.y, s.color.z, s.color.w);
+        l[3 * i + 2] = make_float4(bitsf(s.materialId), 0.f, 0.f, 0.f);
     }
-    HIPCHECK(hipSetDevice(g.device));
-    upload(g.lights, l);
-    if (ok())
-        g.nbLights = lightInformationSize;
+    g.hostLights.swap(l);
+    g.geometryDirty = true;
+    g.nbLights = lightInformationSize;
 }
 
 void d2h_bitmap(vec2i, SceneInfo sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds)
@@ -1125,7 +1288,7 @@ void solr_hip_render(const SceneInfo *sceneInfo, const vec4i *objects, const Pos
 
 void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
                               const PostProcessingInfo *postProcessingInfo, const float origin[3],
-                              const float direction[3], const float angles[4], unsigned long long counts[4])
+                              const float direction[3], const float angles[4], unsigned long long counts[8])
 {
     renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, true, counts);
 }
@@ -1163,10 +1326,8 @@ int solr_hip_get_variant(void)
 
 void solr_hip_memory_usage(unsigned long long bytes[4])
 {
-    bytes[0] = g.boxLo.bytes + g.boxHi.bytes + g.boxStart.bytes + g.primA.bytes + g.primB.bytes + g.primC.bytes +
-               g.primD.bytes + g.primN0.bytes + g.primN1.bytes + g.primN2.bytes + g.primT.bytes + g.lights.bytes +
-               g.lamps.bytes;
-    bytes[1] = g.matHot.bytes + g.matCold.bytes;
+    bytes[0] = g.geometry.bytes + g.lamps.bytes;
+    bytes[1] = g.materials.bytes;
     bytes[2] = g.textures.bytes;
     bytes[3] = g.pp.bytes + g.ids.bytes + g.bitmap.bytes + g.randoms.bytes;
 }
