@@ -431,6 +431,25 @@ SOLR_DEV bool wireFrameMapping(float x, float y, int width)
 /* Primitive intersections (GI); primitive data is wave-uniform            */
 /* ---------------------------------------------------------------------- */
 
+/* Scene features a kernel instantiation supports.  The host scans the uploaded
+ * scene and launches the smallest instantiation that covers it: code (and
+ * registers) for primitive types and material features that do not occur in
+ * the scene is not compiled in.  Keeping the kernel free of scratch spills this
+ * way is worth far more than any single arithmetic optimisation (a variant with
+ * the walks as real calls, i.e. state parked in scratch, ran 1.5-6x slower). */
+enum Feature
+{
+    F_SPHERE = 1,   /* plain spheres / environment */
+    F_PROC = 2,     /* procedural (bumpy) spheres: binary64 sin/cos */
+    F_CYL = 4,      /* cylinders, cones */
+    F_ELL = 8,      /* ellipsoids */
+    F_TRI = 16,     /* triangles */
+    F_PLANE = 32,   /* axis planes, checkerboards, magic carpet */
+    F_TEX = 64,     /* textured materials, ptCamera planes, textured skybox */
+    F_FULL = 128,   /* global illumination + box-debug view */
+    F_ALL = 255
+};
+
 struct Hit
 {
     v3 intersection;
@@ -593,6 +612,7 @@ struct PlaneMaterial
     int materialId;     /* colour is fetched only on a collision */
 };
 
+template <bool TEX>
 SOLR_DEV bool planeIntersection(const SceneInfo &si, int type, v3 p0, v3 size, v3 n0, const PlaneMaterial &pm,
                                 const Scene &planes, int materialId, const WalkRay &ray, Hit &h)
 {
@@ -680,7 +700,7 @@ SOLR_DEV bool planeIntersection(const SceneInfo &si, int type, v3 p0, v3 size, v
         h.shadowIntensity = 1.f;
         const float4 matColor = loadMaterialHot(planes, pm.materialId).color;
         float4 color = matColor;
-        if (type == ptCamera || pm.textured)
+        if (TEX && (type == ptCamera || pm.textured))
         {
             float4 specular = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 attributes = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -800,7 +820,7 @@ SOLR_DEV int waveMinInt(int v)
 
 /* Uniform primitive test shared by both walks.  `head` holds rows 0-1 of the
  * record (p0 + tag, size + materialId); the other rows are fetched per type. */
-template <bool SHADOW>
+template <bool SHADOW, int FEAT>
 SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const Row2 &head, int tag,
                             const WalkRay &ray, Hit &h)
 {
@@ -820,20 +840,28 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const R
     {
     case ptEnvironment:
     case ptSphere:
-        return sphereIntersection(si, p0, size, (tag & PRIM_PROCEDURAL) != 0, (tag & PRIM_TRANSPARENT) != 0, ray,
-                                  h);
+        if (!(FEAT & (F_SPHERE | F_PROC)))
+            return false;
+        return sphereIntersection(si, p0, size, (FEAT & F_PROC) && (tag & PRIM_PROCEDURAL) != 0,
+                                  (tag & PRIM_TRANSPARENT) != 0, ray, h);
     case ptCylinder:
     case ptCone:
     {
+        if (!(FEAT & F_CYL))
+            return false;
         const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
         const v3 p2 = V4(primRow(S, pi, ROW_P2));
         const v3 n1 = V4(primRow(S, pi, ROW_N1));
         return cylinderIntersection(si, p0, p1, p2, n1, size, ray, h);
     }
     case ptEllipsoid:
+        if (!(FEAT & F_ELL))
+            return false;
         return ellipsoidIntersection(si, p0, size, ray, h);
     case ptTriangle:
     {
+        if (!(FEAT & F_TRI))
+            return false;
         const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
         const v3 p2 = V4(primRow(S, pi, ROW_P2));
         const v3 n0 = V4(primRow(S, pi, ROW_N0));
@@ -843,6 +871,8 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const R
     }
     default:
     {
+        if (!(FEAT & (F_PLANE | F_TEX)))
+            return false;
         const v3 n0 = V4(primRow(S, pi, ROW_N0));
         const int materialId = asint(head.b.w);
         PlaneMaterial pm;
@@ -851,7 +881,7 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const R
         pm.emissive = (tag & PRIM_EMISSIVE) != 0;
         pm.textured = (tag & PRIM_TEXTURED) != 0;
         pm.materialId = materialId;
-        return planeIntersection(si, type, p0, size, n0, pm, S, materialId, ray, h);
+        return planeIntersection<(FEAT & F_TEX) != 0>(si, type, p0, size, n0, pm, S, materialId, ray, h);
     }
     }
 }
@@ -873,7 +903,7 @@ SOLR_DEV int nextNode(const Scene &S, int cur, int skip, bool anyEntered, int cu
  * depth-first order makes it the next node whenever any lane enters cur (and
  * always for leaves, whose skip is 1), so the scalar-load latency of the walk
  * is paid only after a subtree is skipped. */
-template <bool COUNT, bool FULL>
+template <bool COUNT, int FEAT>
 SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v3 origin, v3 target, int iteration,
                              int currentMaterialId, int &closestPrimitive, v3 &closestIntersection,
                              v3 &closestNormal, v3 &closestAreas, v3 &colorBox, Counters &cnt)
@@ -910,7 +940,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         const bool anyEntered = __ballot(entered) != 0ull;
         if (anyEntered)
         {
-            if (FULL && si.renderBoxes != 0)
+            if ((FEAT & F_FULL) && si.renderBoxes != 0)
             {
                 if (entered)
                 {
@@ -944,7 +974,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                         h.normal = V(0.f, 0.f, 0.f);
                         h.areas = V(0.f, 0.f, 0.f);
                         h.shadowIntensity = 0.f;
-                        const bool i = testPrimitive<false>(S, si, pi, head, tag, r, h);
+                        const bool i = testPrimitive<false, FEAT>(S, si, pi, head, tag, r, h);
                         const float distance = length(h.intersection - r.o);
                         if (i && distance > si.geometryEpsilon && distance < minDistance)
                         {
@@ -968,7 +998,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
 
 /* GI:798-908, wave-synchronous.  objectId is the flattened index of the
  * shaded primitive, compared with Primitive.index like the reference does. */
-template <bool COUNT>
+template <bool COUNT, int FEAT>
 SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 lampCenter, v3 origin, int lightId,
                           int iteration, v3 &color, int objectId, Counters &cnt)
 {
@@ -1030,7 +1060,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                     h.normal = V(0.f, 0.f, 0.f);
                     h.areas = V(0.f, 0.f, 0.f);
                     h.shadowIntensity = 0.f;
-                    const bool hit = testPrimitive<true>(S, si, pi, head, tag, r, h);
+                    const bool hit = testPrimitive<true, FEAT>(S, si, pi, head, tag, r, h);
                     if (hit)
                     {
                         const float l = length(h.intersection - r.o);
@@ -1077,12 +1107,13 @@ SOLR_DEV float rnd(const Scene &S, long i)
 }
 
 /* GS:36-124 for the lane's own primitive (per-lane gathers) */
+template <int FEAT>
 SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, int type, int materialId,
                                    const MaterialHot &mh, v3 intersection, v3 areas, const TexOut &o)
 {
     float4 c = mh.color;
     c.w = 0.f;
-    const bool textured = mh.ids.x != TEXTURE_NONE;
+    const bool textured = (FEAT & F_TEX) && mh.ids.x != TEXTURE_NONE;
     if (si.extendedGeometry)
     {
         switch (type)
@@ -1172,7 +1203,7 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
 /* GI:916-1080.  Every lane of the wave calls this together; `active` marks
  * the lanes that actually shade.  The light loop is wave-uniform, the shadow
  * walk inside it is wave-synchronous. */
-template <bool COUNT>
+template <bool COUNT, int FEAT>
 SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneInfo &si, v3 origin, v3 &normal,
                             int objectId, v3 intersection, v3 areas, v3 &closestColor, int iteration,
                             float &shadowIntensity, v3 &totalBlinn, float4 &attributes, Counters &cnt)
@@ -1193,7 +1224,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
         shadowIntensity = 0.f;
         v3 bumpNormal = V(0.f, 0.f, 0.f);
         TexOut o = {&bumpNormal, &specular, &attributes, &ambientOcclusion};
-        float4 ic = intersectionShader(S, si, pi, type, materialId, mh, intersection, areas, o);
+        float4 ic = intersectionShader<FEAT>(S, si, pi, type, materialId, mh, intersection, areas, o);
         intersectionColor = V(ic.x, ic.y, ic.z);
         normal = normal + bumpNormal;
         normal = normalize(normal);
@@ -1244,7 +1275,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
                                     mh.innerIllumination.x == 0.f;
             {
                 v3 sc;
-                float s = shadowWalk<COUNT>(S, si, wantShadow, center, intersection, lightPrimitiveId, iteration, sc,
+                float s = shadowWalk<COUNT, FEAT>(S, si, wantShadow, center, intersection, lightPrimitiveId, iteration, sc,
                                             objectId, cnt);
                 if (wantShadow)
                 {
@@ -1293,7 +1324,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
                 closestColor.x += intersectionColor.x * lampsColor.x;
                 closestColor.y += intersectionColor.y * lampsColor.y;
                 closestColor.z += intersectionColor.z * lampsColor.z;
-                if (mh.ids.y != TEXTURE_NONE) /* ambient-occlusion map, GI:1063 */
+                if ((FEAT & F_TEX) && mh.ids.y != TEXTURE_NONE) /* ambient-occlusion map, GI:1063 */
                 {
                     closestColor.x *= ambientOcclusion;
                     closestColor.y *= ambientOcclusion;
@@ -1311,6 +1342,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
 }
 
 /* GI:87-151 (per lane) */
+template <int FEAT>
 SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 target)
 {
     const MaterialHot mh = loadMaterialHot(S, si.skyboxMaterialId);
@@ -1336,6 +1368,8 @@ SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 tar
         t = (t1 < t2) ? t1 : t2;
     if (t < si.geometryEpsilon)
         return result;
+    if (!(FEAT & F_TEX))
+        return result; /* the host selects a F_TEX instantiation whenever the skybox material has a texture */
     v3 I = normalize(origin + dir * t);
     float U = ((atan2_f(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
     float Vv = (asin_f(I.y) / SOLR_PI) + .5f;
@@ -1382,7 +1416,7 @@ struct ColorStack
  * phases 0, 1 and 2 of one wave-uniform loop with a single walk and a single
  * shader call site, which keeps the instruction footprint and the live
  * register set of the kernel small. */
-template <bool COUNT, bool FULL>
+template <bool COUNT, int FEAT>
 SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3 rayD, const SceneInfo &si,
                              float &depthOfField, int4 &primitiveXYId, const ColorStack &cs, Counters &cnt)
 {
@@ -1426,7 +1460,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
 
     /* FULL = false is the lean instantiation the host selects when neither
      * global illumination nor the box-debug view is requested */
-    const bool giEnabled = FULL && (si.advancedIllumination == aiBasic || si.advancedIllumination == aiFull);
+    const bool giEnabled = (FEAT & F_FULL) && (si.advancedIllumination == aiBasic || si.advancedIllumination == aiFull);
     const bool giPass = giEnabled && si.pathTracingIteration >= NB_MAX_ITERATIONS;
     v3 ptO = V(0.f, 0.f, 0.f), ptD = V(0.f, 0.f, 0.f);
     float pathTracingRatio = 0.f;
@@ -1476,7 +1510,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
         }
 
         v3 areas = V(0.f, 0.f, 0.f);
-        const bool hit = closestHitWalk<COUNT, FULL>(S, si, want, tO, tD, tIter, tMat, closestPrimitive,
+        const bool hit = closestHitWalk<COUNT, FEAT>(S, si, want, tO, tD, tIter, tMat, closestPrimitive,
                                                closestIntersection, normal, areas, colorBox, cnt);
         const bool hitLane = want && hit;
 
@@ -1561,7 +1595,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
             shadeIteration = lastIteration;
         }
 
-        const v3 shaded = primitiveShader<COUNT>(S, shadeLane, index, si, tO, normal, closestPrimitive,
+        const v3 shaded = primitiveShader<COUNT, FEAT>(S, shadeLane, index, si, tO, normal, closestPrimitive,
                                                  closestIntersection, areas, closestColor, shadeIteration,
                                                  shadowIntensity, rBlinn, attributes, cnt);
 
@@ -1647,7 +1681,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                 v3 c;
                 if (si.skyboxMaterialId != MATERIAL_NONE)
                 {
-                    c = skyboxMapping(S, si, roO, roD);
+                    c = skyboxMapping<FEAT>(S, si, roO, roD);
                     float rad = c.x + c.y + c.z;
                     primitiveXYId.z = (int)((float)primitiveXYId.z + ((rad > 2.5f) ? rad * 256.f : 0.f));
                 }
@@ -1689,7 +1723,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                 pathTracingColor = shaded;
             if (active && !hitLane && si.skyboxMaterialId != MATERIAL_NONE)
             {
-                pathTracingColor = skyboxMapping(S, si, ptO, ptD);
+                pathTracingColor = skyboxMapping<FEAT>(S, si, ptO, ptD);
                 pathTracingRatio *= SKYBOX_LUNINANCE_STRENGTH;
             }
             if (active && test)

@@ -58,9 +58,9 @@ struct PixelRecord
 };
 static_assert(sizeof(PixelRecord) == sizeof(PostProcessingBuffer), "PixelRecord layout");
 
-template <bool COUNT, bool FULL>
+template <bool COUNT, int FEAT>
 #ifndef SOLR_WAVES_PER_EU
-#define SOLR_WAVES_PER_EU 3
+#define SOLR_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(const SceneArgs SA, const FrameArgs F,
                                                            PixelRecord *__restrict__ pp,
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
                 rO.y += 3.f;
             }
         }
-        v3 c = launchRayTracing<COUNT, FULL>(S, active, gindex, rO, rayD, si, dof, id, cs, cnt);
+        v3 c = launchRayTracing<COUNT, FEAT>(S, active, gindex, rO, rayD, si, dof, id, cs, cnt);
         color = color + c;
     }
 
@@ -422,6 +422,7 @@ struct Engine
     std::vector<float4> hostBoxes, hostBoxesCompact, hostPrims, hostLights;
     std::vector<int> hostBoxStart, hostBoxStartCompact;
     std::vector<int> materialTags; /* PRIM_* bits per material id */
+    int sceneFeatures = F_ALL & ~F_FULL; /* rt_device.h enum Feature, recomputed with the tags */
     unsigned offBoxes = 0, offBoxesCompact = 0, offBoxStart = 0, offBoxStartCompact = 0, offPrims = 0, offLights = 0;
     unsigned offMatCold = 0;
     bool geometryDirty = true;
@@ -609,6 +610,7 @@ int materialTag(const Material &m)
 void retagPrimitives()
 {
     const size_t n = g.hostPrims.size() / PRIM_ROWS;
+    int features = 0;
     for (size_t i = 0; i < n; ++i)
     {
         float4 *r = &g.hostPrims[PRIM_ROWS * i];
@@ -619,7 +621,33 @@ void retagPrimitives()
         /* a material that was never uploaded reads as all zeros on the device */
         const int facts = (mat >= 0 && (size_t)mat < g.materialTags.size()) ? g.materialTags[mat] : (PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
         r[ROW_P0_TYPE].w = bitsf(type | facts);
+        switch (type)
+        {
+        case ptSphere:
+        case ptEnvironment:
+            features |= (facts & PRIM_PROCEDURAL) ? F_PROC : F_SPHERE;
+            break;
+        case ptCylinder:
+        case ptCone:
+            features |= F_CYL;
+            break;
+        case ptEllipsoid:
+            features |= F_ELL;
+            break;
+        case ptTriangle:
+            features |= F_TRI;
+            break;
+        case ptCamera:
+            features |= F_PLANE | F_TEX;
+            break;
+        default:
+            features |= F_PLANE;
+            break;
+        }
+        if (facts & PRIM_TEXTURED)
+            features |= F_TEX;
     }
+    g.sceneFeatures = features;
     g.geometryDirty = true;
 }
 
@@ -767,22 +795,43 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     PixelRecord *ppPtr = (PixelRecord *)g.pp.ptr;
     int4 *idPtr = (int4 *)g.ids.ptr;
     unsigned long long *cntPtr = (unsigned long long *)g.counters.ptr;
-    if (counting)
+    /* smallest instantiation that covers the scene (rt_device.h, enum Feature) */
+    int need = g.sceneFeatures;
+    if (!sceneInfo.extendedGeometry)
+        need = F_TRI; /* every primitive is tested as a triangle, GI:743-747 */
+    if (full)
+        need |= F_FULL;
+    if (sceneInfo.skyboxMaterialId >= 0 && sceneInfo.skyboxMaterialId < (int)g.materialTags.size() &&
+        (g.materialTags[sceneInfo.skyboxMaterialId] & PRIM_TEXTURED))
+        need |= F_TEX;
+    typedef void (*KernelFn)(const SceneArgs, const FrameArgs, PixelRecord *, int4 *, unsigned char *,
+                             unsigned long long *);
+    static const struct
     {
-        HIPCHECK(hipMemsetAsync(g.counters.ptr, 0, 8 * sizeof(unsigned long long), g.stream));
-        if (full)
-            hipLaunchKernelGGL((k_standardRenderer<true, true>), grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr,
-                               bitmap, cntPtr);
-        else
-            hipLaunchKernelGGL((k_standardRenderer<true, false>), grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr,
-                               bitmap, cntPtr);
+        int features;
+        KernelFn fn;
+    } variants[] = {
+        {F_SPHERE | F_PLANE, k_standardRenderer<false, F_SPHERE | F_PLANE>},
+        {F_SPHERE | F_TRI, k_standardRenderer<false, F_SPHERE | F_TRI>},
+        {F_SPHERE | F_CYL, k_standardRenderer<false, F_SPHERE | F_CYL>},
+        {F_SPHERE | F_PLANE | F_TRI | F_CYL, k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL>},
+        {F_ALL & ~F_FULL, k_standardRenderer<false, F_ALL & ~F_FULL>},
+        {F_ALL, k_standardRenderer<false, F_ALL>},
+    };
+    KernelFn fn = k_standardRenderer<true, F_ALL>;
+    if (!counting)
+    {
+        fn = k_standardRenderer<false, F_ALL>;
+        for (const auto &v : variants)
+            if ((need & ~v.features) == 0 && g.variant != 4)
+            {
+                fn = v.fn;
+                break;
+            }
     }
-    else if (full)
-        hipLaunchKernelGGL((k_standardRenderer<false, true>), grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr,
-                           bitmap, cntPtr);
     else
-        hipLaunchKernelGGL((k_standardRenderer<false, false>), grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr,
-                           bitmap, cntPtr);
+        HIPCHECK(hipMemsetAsync(g.counters.ptr, 0, 8 * sizeof(unsigned long long), g.stream));
+    hipLaunchKernelGGL(fn, grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
     HIPCHECK(hipGetLastError());
     if (e0)
     {
