@@ -72,13 +72,10 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = args.width, args.height
-    rows_per_rank = (H + world - 1) // world
-    first_row = rank * rows_per_rank
-    nb_rows = max(0, min(rows_per_rank, H - first_row))
+    first_row, nb_rows, rows_per_rank = solr.strip_rows(rank, world, H)
 
     # ---- scene (built once on every rank: the scene is replicated, pixels are sharded)
-    k = solr.Kernel(engine="hip")
-    hip.solr_hip_set_device(local_rank)
+    k = solr.Kernel(engine="hip", device=local_rank)
     builder = getattr(solr.scenes, args.scene)
     kw = dict(width=W, height=H, iterations=args.iterations)
     if args.scene != "cornell":
@@ -92,11 +89,8 @@ def main():
         hip.solr_hip_set_strip(first_row, nb_rows)
         strip = torch.zeros((nb_rows * W * 3,), dtype=torch.uint8, device="cuda")
         hip.solr_hip_bind_device_bitmap(C.c_void_p(strip.data_ptr()))
-        gathered = ([torch.zeros((rows_per_rank * W * 3,), dtype=torch.uint8, device="cuda") for _ in range(world)]
-                    if rank == 0 else None)
-        padded = strip
-        if nb_rows != rows_per_rank:  # last strip may be shorter: gather needs equal sizes
-            padded = torch.zeros((rows_per_rank * W * 3,), dtype=torch.uint8, device="cuda")
+        slots = ([torch.zeros((rows_per_rank * W * 3,), dtype=torch.uint8, device="cuda") for _ in range(world)]
+                 if rank == 0 else None)
 
     # first frame through the full host protocol: uploads scene, materials, randoms
     k.L.SolRx_Render(0.0)
@@ -109,9 +103,8 @@ def main():
     def frame():
         hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
         if world > 1:
-            if padded is not strip:
-                padded[: strip.numel()].copy_(strip)
-            dist.gather(padded, gathered, dst=0)
+            # the single collective of the path: RGB8 strips to rank 0 (RCCL over xGMI)
+            solr.gather_strips(dist, torch, strip, rows_per_rank, W, H, rank, world, slots=slots, assemble=False)
 
     def sync():
         if world > 1:

@@ -66,6 +66,9 @@ class Scene:
         self.keep = [np.ascontiguousarray(a) for a in (flat.boxes, flat.primitives, flat.lights, flat.materials,
                                                         flat.randoms, flat.textures)]
         boxes, prims, lights, mats, rnd, tex = self.keep
+        # numpy silently re-packs padded structured dtypes in some operations (concatenate): insist on the C layout
+        assert boxes.dtype.itemsize == 48 and prims.dtype.itemsize == 128 and mats.dtype.itemsize == 176
+        assert lights.dtype.itemsize == 48 and rnd.dtype == np.float32 and tex.dtype == np.uint8
         self.c = OracleScene(boxes.ctypes.data, len(boxes), prims.ctypes.data, len(prims), lights.ctypes.data,
                              len(lights), flat.nb_lamps, mats.ctypes.data, tex.ctypes.data if len(tex) else None,
                              rnd.ctypes.data if len(rnd) else None, len(rnd))

@@ -247,11 +247,12 @@ GeometryIntersections.cuh:561)."""
 class Kernel:
     """Thin object wrapper over the flat SolR_* API (one singleton engine per process)."""
 
-    def __init__(self, engine="hip", deterministic_seed=12345):
+    def __init__(self, engine="hip", deterministic_seed=12345, device=0):
         self.L = host_lib()
         self.L.SolRx_SelectEngine(engine.encode())
         self.engine = engine
         self.seed = deterministic_seed
+        self.device = device
         self.info = dict(SCENE_DEFAULTS)
         self.pp = dict(type=ppe_none, param1=0.0, param2=0.0, param3=0)
         self.initialized = False
@@ -284,7 +285,8 @@ class Kernel:
         self.pp = dict(type=type, param1=param1, param2=param2, param3=param3)
         self.L.SolR_SetPostProcessingInfo(type, param1, param2, param3)
 
-    def initialize(self, device=0, **scene_info):
+    def initialize(self, device=None, **scene_info):
+        device = self.device if device is None else device
         self.set_scene_info(**scene_info)
         self.L.SolR_SetPostProcessingInfo(self.pp["type"], self.pp["param1"], self.pp["param2"], self.pp["param3"])
         if self.engine == "hip":
@@ -401,6 +403,36 @@ class Kernel:
         eye, d, ang = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 4)()
         self.L.SolRx_GetSceneInfo(C.byref(si), C.byref(pp), eye, d, ang)
         return si, pp, np.array(eye, dtype=np.float32), np.array(d, dtype=np.float32), np.array(ang, np.float32)
+
+
+# ---- multi-GPU: framebuffer row strips + one gather ------------------
+def strip_rows(rank, world, height):
+    """Rows [first, first + count) of the image that rank `rank` of `world` renders, and the
+    common strip height used as the gather's slot size.  The reference splits the frame into
+    contiguous row strips per device (CudaRayTracer.cu:1694-1696, d2h_bitmap :1650-1670); unlike
+    it, the last strip absorbs a remainder instead of dropping rows when height % world != 0."""
+    rows_per_rank = (height + world - 1) // world
+    first = rank * rows_per_rank
+    count = max(0, min(rows_per_rank, height - first))
+    return first, count, rows_per_rank
+
+
+def gather_strips(dist, torch, strip, rows_per_rank, width, height, rank, world, dst=0, slots=None, assemble=True):
+    """One collective: every rank's RGB8 strip (a flat uint8 tensor of count*width*3 bytes) to `dst`.
+    Returns the assembled (height, width, 3) image on `dst`, None elsewhere.  Works for the nccl
+    (= RCCL over xGMI) and gloo backends.  `slots` lets the caller keep the receive buffers across
+    frames; assemble=False skips the final concatenation (the strips then stay in `slots`)."""
+    slot = rows_per_rank * width * 3
+    send = strip
+    if strip.numel() != slot:  # the last strip may be shorter: gather needs equal slots
+        send = torch.zeros((slot,), dtype=torch.uint8, device=strip.device)
+        send[: strip.numel()].copy_(strip)
+    if rank == dst and slots is None:
+        slots = [torch.empty((slot,), dtype=torch.uint8, device=strip.device) for _ in range(world)]
+    dist.gather(send, slots if rank == dst else None, dst=dst)
+    if rank != dst or not assemble:
+        return None
+    return torch.cat(slots)[: height * width * 3].reshape(height, width, 3)
 
 
 from . import scenes  # noqa: E402,F401

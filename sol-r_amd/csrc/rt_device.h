@@ -1209,7 +1209,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
                             float &shadowIntensity, v3 &totalBlinn, float4 &attributes, Counters &cnt)
 {
     const int pi = active ? objectId : 0;
-    const int type = asint(primRow(S, pi, ROW_P0_TYPE).w);
+    const int type = asint(primRow(S, pi, ROW_P0_TYPE).w) & PRIM_TYPE_MASK; /* row 0 carries type + material facts */
     const int materialId = asint(primRow(S, pi, ROW_SIZE_MAT).w);
     const int primIndex = asint(primRow(S, pi, ROW_P1_INDEX).w);
     const MaterialHot mh = loadMaterialHot(S, materialId);

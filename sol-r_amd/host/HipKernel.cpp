@@ -134,8 +134,9 @@ void HipKernel::render_end()
     d2h_bitmap(m_occupancyParameters, m_sceneInfo, m_bitmap.data(), m_hPrimitivesXYIds.data());
 }
 
-void HostOnlyKernel::render_begin(const float)
+void HostOnlyKernel::render_begin(const float timer)
 {
+    GPUKernel::render_begin(timer); /* host-side part of the frame protocol (timestamp, random buffer) */
     m_failed = true;
     std::cerr << "HostOnlyKernel::render_begin: this engine has no device; rendering requires the HIP engine"
               << std::endl;

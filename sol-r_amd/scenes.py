@@ -63,7 +63,8 @@ def cornell(k, width=512, height=512, iterations=1, extra_spheres=16, glass=2, s
     glass spheres, a six-plane room, one emissive sphere.  Camera as the viewer's default
     (apps/solrViewer.cpp:178-181): eye (0, 0, -15000), look-at origin, angles (0,0,0,6400)."""
     rng = LCG(seed)
-    k.initialize(width=width, height=height, nbRayIterations=iterations, graphicsLevel=glFull, **scene_info)
+    scene_info.setdefault("graphicsLevel", glFull)
+    k.initialize(width=width, height=height, nbRayIterations=iterations, **scene_info)
     for cx, cy in ((2200.0, 0.0), (-2200.0, 0.0), (0.0, 2200.0), (0.0, -2200.0)):
         c = _wall_color(rng)
         m = k.add_material(c[0], c[1], c[2], reflection=0.5, specValue=1.0, specPower=234.0)

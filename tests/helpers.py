@@ -1,4 +1,6 @@
 """Shared helpers of the parity tests."""
+import ctypes as C
+
 import numpy as np
 
 
@@ -17,16 +19,45 @@ def ulp_distance(a, b):
 
 
 def compare_frames(gpu_pp, gpu_ids, gpu_rgb, ora_pp, ora_ids, ora_rgb):
-    """Returns a dict of parity figures between an engine frame and an oracle frame."""
+    """Parity figures between an engine frame and an oracle frame."""
     ulp = ulp_distance(gpu_pp[..., :3], ora_pp[..., :3])
+    last = ulp_distance(gpu_pp[..., 4:7], ora_pp[..., 4:7])
     depth = ulp_distance(gpu_pp[..., 3], ora_pp[..., 3])
     return {
-        "max_ulp": int(ulp.max()),
-        "pixels_over_1ulp": int((ulp.max(axis=-1) > 1).sum()),
-        "pixels_nonzero_ulp": int((ulp.max(axis=-1) > 0).sum()),
-        "depth_max_ulp": int(depth.max()),
+        "max_ulp": int(ulp.max()) if ulp.size else 0,
+        "last_sample_max_ulp": int(last.max()) if last.size else 0,
+        "pixels_over_1ulp": int((ulp.max(axis=-1) > 1).sum()) if ulp.size else 0,
+        "pixels_nonzero_ulp": int((ulp.max(axis=-1) > 0).sum()) if ulp.size else 0,
+        "depth_max_ulp": int(depth.max()) if depth.size else 0,
         "ids_equal": bool(np.array_equal(gpu_ids[..., :2], ora_ids[..., :2])),
         "ids_all_equal": bool(np.array_equal(gpu_ids, ora_ids)),
-        "rgb_max_diff": int(np.abs(gpu_rgb.astype(int) - ora_rgb.astype(int)).max()),
+        "rgb_max_diff": int(np.abs(gpu_rgb.astype(int) - ora_rgb.astype(int)).max()) if gpu_rgb.size else 0,
         "rgb_equal": bool(np.array_equal(gpu_rgb, ora_rgb)),
     }
+
+
+def assert_parity(res, max_ulp=1, rgb_max_diff=0, depth_ulp=0):
+    """The bar of BASELINE.json: ids exact, RGB8 exact, float colour <= 1 ULP.
+    rgb_max_diff=1 is allowed only where a 1-ULP float difference straddles a x255 truncation."""
+    assert res["ids_all_equal"], res
+    assert res["max_ulp"] <= max_ulp, res
+    assert res["last_sample_max_ulp"] <= max_ulp, res
+    assert res["depth_max_ulp"] <= depth_ulp, res
+    assert res["rgb_max_diff"] <= rgb_max_diff, res
+
+
+def gpu_frame(k):
+    rgb = k.render()
+    return k.postprocessing_buffer(), k.primitive_ids(), rgb
+
+
+def oracle_frame(k, oracle, pp=None, ids=None, first_row=0, nb_rows=None, nthreads=0):
+    flat = k.flat_scene()
+    si, ppi, eye, direction, angles = k.frame_parameters()
+    opp, oids, orgb, counts, status = oracle.render(flat, si, ppi, eye, direction, angles, first_row=first_row,
+                                                    nb_rows=nb_rows, pp=pp, ids=ids, nthreads=nthreads)
+    return opp, oids, orgb, counts, status
+
+
+def f3(*v):
+    return (C.c_float * 3)(*v)

@@ -1,0 +1,82 @@
+"""The C-ABI library: loads, exports everything include/solr_hip.h declares, record sizes match
+the reference's (CUDA flavour), and without a GPU it fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"^\s*(?:[A-Za-z_][\w \*]*?)\b(\w+)\s*\([^;{]*\)\s*;", text, flags=re.M)))
+
+
+def test_every_declared_symbol_is_exported(solr):
+    names = declared_functions("solr_hip.h")
+    reference_boundary = {"initialize_scene", "finalize_scene", "reshape_scene", "h2d_scene", "h2d_materials",
+                          "h2d_randoms", "h2d_textures", "h2d_lightInformation", "d2h_bitmap", "cudaRender"}
+    assert reference_boundary <= set(names), "the ten entry points of CudaRayTracer.h:25-67"
+    assert len(names) >= 30
+    lib = solr.hip_lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_host_library_exports_the_flat_api(solr):
+    lib = solr.host_lib()
+    for n in ("SolR_SetSceneInfo", "SolR_SetPostProcessingInfo", "SolR_SetDraftMode", "SolR_InitializeKernel",
+              "SolR_FinalizeKernel", "SolR_ResetKernel", "SolR_SetCamera", "SolR_RunKernel", "SolR_AddPrimitive",
+              "SolR_SetPrimitive", "SolR_GetPrimitive", "SolR_GetPrimitiveAt", "SolR_GetPrimitiveCenter",
+              "SolR_RotatePrimitives", "SolR_SetPrimitiveMaterial", "SolR_GetPrimitiveMaterial",
+              "SolR_SetPrimitiveNormals", "SolR_SetPrimitiveTextureCoordinates", "SolR_AddMaterial",
+              "SolR_SetMaterial", "SolR_CompactBoxes", "SolR_GetLight", "SolR_SetTexture", "SolR_GetTextureSize",
+              "SolR_GetNbTextures"):
+        assert hasattr(lib, n), n
+
+
+def test_record_layouts(solr):
+    # sizes of the CUDA-flavour records; the C side pins the same with static asserts
+    assert C.sizeof(solr.SceneInfo) == 112 and solr.SceneInfo.backgroundColor.offset == 96
+    assert solr.SceneInfo.geometryEpsilon.offset == 88 and solr.SceneInfo.pathTracingIteration.offset == 40
+    assert C.sizeof(solr.PostProcessingInfo) == 16
+    assert solr.BOX_DTYPE.itemsize == 48 and solr.PRIMITIVE_DTYPE.itemsize == 128
+    assert solr.MATERIAL_DTYPE.itemsize == 176 and solr.LIGHT_DTYPE.itemsize == 48 and solr.PP_DTYPE.itemsize == 32
+    assert solr.PRIMITIVE_DTYPE.fields["type"][1] == 84 and solr.PRIMITIVE_DTYPE.fields["vt0"][1] == 96
+    assert solr.MATERIAL_DTYPE.fields["attributes"][1] == 64 and solr.MATERIAL_DTYPE.fields["mappingOffset"][1] == 160
+
+
+def test_no_gpu_means_a_loud_failure_not_a_fallback(solr, have_gpu):
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    hip = solr.hip_lib()
+    hip.solr_hip_clear_error()
+    assert hip.solr_hip_device_count() == 0
+    si = solr.SceneInfo()
+    si.size_x, si.size_y = 8, 8
+    hip.solr_hip_initialize(C.byref(si))
+    buf = C.create_string_buffer(256)
+    assert hip.solr_hip_last_error(buf, 256) != 0 and b"no HIP device" in buf.value
+    # every later call is a no-op while the error is pending
+    hip.solr_hip_reshape(C.byref(si))
+    assert hip.solr_hip_last_error(None, 0) != 0
+    hip.solr_hip_clear_error()
+    k = solr.Kernel(engine="hip")
+    with pytest.raises(solr.SolrError):
+        k.initialize(width=8, height=8)
+    hip.solr_hip_clear_error()
+
+
+def test_calls_before_initialisation_are_rejected(solr, have_gpu):
+    if have_gpu:
+        pytest.skip("state of a live engine is exercised by the gpu tests")
+    hip = solr.hip_lib()
+    hip.solr_hip_clear_error()
+    hip.h2d_randoms(0, np.zeros(4, np.float32).ctypes.data)
+    buf = C.create_string_buffer(256)
+    assert hip.solr_hip_last_error(buf, 256) == -1 and b"initialize_scene" in buf.value
+    hip.solr_hip_clear_error()
