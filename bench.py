@@ -198,31 +198,61 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cpus():
+    """cores this process may actually use: affinity mask, capped by a cgroup CPU quota if one is set"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(flat, si, ppi, eye, direction, angles, budget_s):
-    """The CPU oracle on all host cores, on a bounded sample of the same frame."""
+    """The CPU oracle (a port of the reference algorithm) on the host cores of this box, on a bounded
+    sample of the same frame.  Thread count: the best of {quota, 2x, 4x quota, all hardware threads} in
+    a short calibration (containers here run under a CFS quota far below the hardware thread count, and
+    oversubscribing it collapses throughput), then a sustained run of about budget_s seconds."""
+    import numpy as np
     from oracle import loader
-    threads = loader.max_threads()
-    H = si.size_y
-    # calibrate on a 1/8 centre band, then size the sample to about budget_s seconds of work
-    band = max(8, H // 8)
-    first = (H - band) // 2
-    t0 = time.perf_counter()
-    _, _, _, c, status = loader.render(flat, si, ppi, eye, direction, angles, first_row=first, nb_rows=band)
-    dt = time.perf_counter() - t0
-    rate = (c[0] + c[1]) / dt
-    frames = 0
-    rays = 0
-    t0 = time.perf_counter()
+    L = loader.lib()
+    scene = loader.Scene(flat)
+    W, H = si.size_x, si.size_y
+    pp = np.zeros((H, W, 8), np.float32)
+    ids = np.zeros((H, W, 4), np.int32)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    counts = (C.c_ulonglong * 4)()
+    eye, direction, angles = (np.ascontiguousarray(a, np.float32) for a in (eye, direction, angles))
+
+    def one_frame(threads):
+        t0 = time.perf_counter()
+        L.oracle_render(C.byref(scene.c), C.addressof(si), C.addressof(ppi), eye.ctypes.data, direction.ctypes.data,
+                        angles.ctypes.data, 0, H, pp.ctypes.data, ids.ctypes.data, rgb.ctypes.data,
+                        C.addressof(counts), threads)
+        return time.perf_counter() - t0, int(counts[0]) + int(counts[1])
+
+    hw = len(os.sched_getaffinity(0))
+    quota = usable_cpus()
+    candidates = sorted(set(min(hw, c) for c in (quota, 2 * quota, 4 * quota, hw)))
+    calib = {}
+    for c in candidates:
+        one_frame(c)
+        calib[c] = min(one_frame(c)[0] for _ in range(2))
+    threads = min(calib, key=calib.get)
+    frames, rays, t0 = 0, 0, time.perf_counter()
     while True:
-        _, _, _, c, status = loader.render(flat, si, ppi, eye, direction, angles)
-        rays += c[0] + c[1]
+        _, r = one_frame(threads)
+        rays += r
         frames += 1
-        if time.perf_counter() - t0 > budget_s or frames >= 50:
+        if time.perf_counter() - t0 > budget_s or frames >= 2000:
             break
     dt = time.perf_counter() - t0
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "%d full %dx%d frames of the same scene in %.1f s (OpenMP over rows, %d threads); "
-                      "calibration band %.1f Mrays/s" % (frames, si.size_x, si.size_y, dt, threads, rate / 1e6)}
+            "sample": "%d full %dx%d frames of the same scene in %.1f s, OpenMP over rows with %d threads "
+                      "(affinity %d, CFS quota %d CPUs; calibration s/frame by threads: %s)" %
+                      (frames, W, H, dt, threads, hw, quota, {k: round(v, 4) for k, v in calib.items()})}
 
 
 if __name__ == "__main__":
