@@ -130,6 +130,8 @@ SOLR_DEV float atan2_f(float a, float b) { return (float)atan2((double)a, (doubl
 SOLR_DEV float asin_f(float a) { return (float)asin((double)a); }
 
 SOLR_DEV int asint(float f) { return __float_as_int(f); }
+/* lane mask of a predicate, without the int round trip of HIP's ballot(int) */
+SOLR_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 /* VU:104-142 with the six sin/cos values hoisted to the host (they depend on
  * the camera angles only) */
@@ -178,8 +180,9 @@ SOLR_DEV WalkRay makeWalkRay(v3 origin, v3 direction)
     return r;
 }
 
-/* GI:52-79; lo/hi are wave-uniform */
-SOLR_DEV bool boxIntersection(const float4 &lo, const float4 &hi, const WalkRay &r, float t0, float t1)
+/* GI:52-79; lo/hi are wave-uniform.  Exact form: sign-selected slabs and the
+ * reference's compare/assign chain (keeps its NaN and inverted-box behaviour). */
+SOLR_DEV bool boxIntersectionExact(const float4 &lo, const float4 &hi, const WalkRay &r, float t0, float t1)
 {
     float ax = (lo.x - r.o.x) * r.inv.x, bx = (hi.x - r.o.x) * r.inv.x;
     float tmin = r.sx ? bx : ax;
@@ -187,22 +190,40 @@ SOLR_DEV bool boxIntersection(const float4 &lo, const float4 &hi, const WalkRay 
     float ay = (lo.y - r.o.y) * r.inv.y, by = (hi.y - r.o.y) * r.inv.y;
     float tymin = r.sy ? by : ay;
     float tymax = r.sy ? ay : by;
-    if ((tmin > tymax) || (tymin > tmax))
-        return false;
-    if (tymin > tmin)
-        tmin = tymin;
-    if (tymax < tmax)
-        tmax = tymax;
+    bool ok = !((tmin > tymax) || (tymin > tmax));
+    tmin = (tymin > tmin) ? tymin : tmin;
+    tmax = (tymax < tmax) ? tymax : tmax;
     float az = (lo.z - r.o.z) * r.inv.z, bz = (hi.z - r.o.z) * r.inv.z;
     float tzmin = r.sz ? bz : az;
     float tzmax = r.sz ? az : bz;
-    if ((tmin > tzmax) || (tzmin > tmax))
-        return false;
-    if (tzmin > tmin)
-        tmin = tzmin;
-    if (tzmax < tmax)
-        tmax = tzmax;
-    return ((tmin < t1) && (tmax > t0));
+    ok = ok && !((tmin > tzmax) || (tzmin > tmax));
+    tmin = (tzmin > tmin) ? tzmin : tmin;
+    tmax = (tzmax < tmax) ? tzmax : tmax;
+    return ok && ((tmin < t1) && (tmax > t0));
+}
+
+/* Sign-free form.  Identical to the exact form whenever (a) lo <= hi on every
+ * axis and all six bounds are finite (checked for the whole node list at
+ * upload) and (b) the lane's three reciprocals are finite (checked once per
+ * walk): then every slab product is a finite number, the sign-selected near /
+ * far values are min / max of the pair, the reference's four early-outs are
+ * exactly "some near value exceeds some far value" = max3(near) > min3(far),
+ * and its running tmin / tmax are max3(near) / min3(far).  About half the
+ * vector instructions and none of the exec-mask bookkeeping of the exact form. */
+SOLR_DEV bool boxIntersectionFast(const float4 &lo, const float4 &hi, const WalkRay &r, float t0, float t1)
+{
+    const float ax = (lo.x - r.o.x) * r.inv.x, bx = (hi.x - r.o.x) * r.inv.x;
+    const float ay = (lo.y - r.o.y) * r.inv.y, by = (hi.y - r.o.y) * r.inv.y;
+    const float az = (lo.z - r.o.z) * r.inv.z, bz = (hi.z - r.o.z) * r.inv.z;
+    const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return (tmin <= tmax) && (tmin < t1) && (tmax > t0);
+}
+
+SOLR_DEV bool finiteInverse(const WalkRay &r)
+{
+    const float big = 3.0e38f;
+    return fabsf(r.inv.x) < big && fabsf(r.inv.y) < big && fabsf(r.inv.z) < big;
 }
 
 /* ---------------------------------------------------------------------- */
@@ -496,39 +517,42 @@ SOLR_DEV bool ellipsoidIntersection(const SceneInfo &si, v3 p0, v3 size, const W
     return true;
 }
 
-/* GI:220-284 */
-SOLR_DEV bool sphereIntersection(const SceneInfo &si, v3 p0, v3 size, bool procedural, bool transparent,
-                                 const WalkRay &ray, Hit &h)
+/* GI:220-284, split in two so that the walk can decide first and pay for the
+ * normal only when it keeps the hit.  sphereHit: everything up to the
+ * intersection point, branch-free apart from one wave-uniform early-out. */
+SOLR_DEV bool sphereHit(const SceneInfo &si, v3 p0, float radius, const WalkRay &ray, bool lanes, v3 &intersection,
+                        bool &back)
 {
-    bool back = false;
-    v3 O_C = ray.o - p0;
-    v3 dir = ray.dn;
-    float a = 2.f * dot(dir, dir);
-    float b = 2.f * dot(O_C, dir);
-    float c = dot(O_C, O_C) - (size.x * size.x);
-    float d = b * b - 2.f * a * c;
-    if (d <= 0.f || a == 0.f)
+    const v3 O_C = ray.o - p0;
+    const v3 dir = ray.dn;
+    const float a = 2.f * dot(dir, dir);
+    const float b = 2.f * dot(O_C, dir);
+    const float c = dot(O_C, O_C) - (radius * radius);
+    const float d = b * b - 2.f * a * c;
+    bool ok = lanes && !(d <= 0.f || a == 0.f);
+    back = false;
+    if (ballot(ok) == 0ull)
         return false;
-    float r = sqrt_ieee(d);
-    float t1 = (-b - r) / a;
-    float t2 = (-b + r) / a;
-    if (t1 <= si.geometryEpsilon && t2 <= si.geometryEpsilon)
-        return false;
-    float t = 0.f;
-    if (t1 <= si.geometryEpsilon)
-    {
-        t = t2;
-        back = true;
-    }
-    else if (t2 <= si.geometryEpsilon)
-        t = t1;
-    else
-        t = (t1 < t2) ? t1 : t2;
-    if (t < si.geometryEpsilon)
-        return false;
-    h.intersection = ray.o + dir * t;
+    const float r = sqrt_ieee(d);
+    const float t1 = (-b - r) / a;
+    const float t2 = (-b + r) / a;
+    const bool b1 = t1 <= si.geometryEpsilon;
+    const bool b2 = t2 <= si.geometryEpsilon;
+    ok = ok && !(b1 && b2); /* both intersections behind the origin */
+    const float t = b1 ? t2 : (b2 ? t1 : ((t1 < t2) ? t1 : t2));
+    back = b1;
+    ok = ok && !(t < si.geometryEpsilon);
+    intersection = ray.o + dir * t;
+    return ok;
+}
+
+/* the normal and the shadow intensity of a sphere hit (GI:261-281) */
+template <bool PROCEDURAL>
+SOLR_DEV void sphereNormal(const SceneInfo &si, v3 p0, v3 size, bool procedural, bool transparent, bool back,
+                           const WalkRay &ray, Hit &h)
+{
     v3 n;
-    if (!procedural)
+    if (!(PROCEDURAL && procedural))
         n = h.intersection - p0;
     else
     {
@@ -539,12 +563,21 @@ SOLR_DEV bool sphereIntersection(const SceneInfo &si, v3 p0, v3 size, bool proce
         n = h.intersection - newCenter;
     }
     n = normalize(n);
-    if (back)
-        n = n * -1.f;
+    n = back ? n * -1.f : n;
     h.normal = n;
-    r = dot(dir, n);
+    const float r = dot(ray.dn, n);
     h.shadowIntensity = transparent ? (1.f - fabsf(r)) : 1.f;
-    return true;
+}
+
+/* one-piece form for the code paths that want everything at once */
+SOLR_DEV bool sphereIntersection(const SceneInfo &si, v3 p0, v3 size, bool procedural, bool transparent,
+                                 const WalkRay &ray, Hit &h)
+{
+    bool back;
+    const bool hit = sphereHit(si, p0, size.x, ray, true, h.intersection, back);
+    if (hit)
+        sphereNormal<true>(si, p0, size, procedural, transparent, back, ray, h);
+    return hit;
 }
 
 /* GI:293-349 and GI:358-416 (the cone repeats the cylinder's arithmetic) */
@@ -591,126 +624,92 @@ SOLR_DEV bool cylinderIntersection(const SceneInfo &si, v3 p0, v3 p1, v3 p2, v3 
     return true;
 }
 
-/* one face of an axis-aligned rectangle; U,V in-plane axes, W the normal axis */
-#define SOLR_PLANE_HIT(U, Vx, Wx)                                                                                \
+/* GI:424-567.  The two faces of a rectangle share the intersection formula and
+ * their side conditions exclude each other, so the reference's "try the front
+ * face, else try the back face with the normal negated" is evaluated here
+ * without branches: one point, two side predicates.  U,V in-plane axes, W the
+ * normal axis. */
+#define SOLR_PLANE_POINT(U, Vx, Wx)                                                                              \
     do                                                                                                           \
     {                                                                                                            \
-        float k = ray.o.Wx - p0.Wx;                                                                              \
+        const float k = ray.o.Wx - p0.Wx;                                                                        \
         I.U = ray.o.U + k * ray.d.U / -ray.d.Wx;                                                                 \
         I.Wx = p0.Wx;                                                                                            \
         I.Vx = ray.o.Vx + k * ray.d.Vx / -ray.d.Wx;                                                              \
-        collision = fabsf(I.U - p0.U) < size.U && fabsf(I.Vx - p0.Vx) < size.Vx;                                 \
+        inside = fabsf(I.U - p0.U) < size.U && fabsf(I.Vx - p0.Vx) < size.Vx;                                    \
+        front = ray.d.Wx < 0.f && ray.o.Wx > p0.Wx;                                                              \
+        rear = ray.d.Wx > 0.f && ray.o.Wx < p0.Wx;                                                               \
     } while (0)
 
-/* GI:424-567.  pm carries the uniform material facts the test needs. */
+/* pm carries the uniform material facts the test needs. */
 struct PlaneMaterial
 {
     int wireframe;      /* attributes.z */
     int wireframeWidth; /* attributes.w */
     bool emissive;      /* innerIllumination.x != 0 */
     bool textured;      /* textureIds.x != TEXTURE_NONE */
-    int materialId;     /* colour is fetched only on a collision */
+    int materialId;
+    float averageColor; /* (r + g + b) / 3.f of the material colour, evaluated at upload */
 };
 
 template <bool TEX>
 SOLR_DEV bool planeIntersection(const SceneInfo &si, int type, v3 p0, v3 size, v3 n0, const PlaneMaterial &pm,
                                 const Scene &planes, int materialId, const WalkRay &ray, Hit &h)
 {
-    bool collision = false;
-    const float reverted = 1.f; /* every call site passes reverse = false */
+    bool inside = false, front = false, rear = false;
     v3 I = h.intersection;
-    v3 normal = n0;
     switch (type)
     {
     case ptMagicCarpet:
     case ptCheckboard:
-    {
-        I.y = p0.y;
-        float y = ray.o.y - p0.y;
-        if (reverted * ray.d.y < 0.f && reverted * ray.o.y > reverted * p0.y)
-        {
-            I.x = ray.o.x + y * ray.d.x / -ray.d.y;
-            I.z = ray.o.z + y * ray.d.z / -ray.d.y;
-            collision = fabsf(I.x - p0.x) < size.x && fabsf(I.z - p0.z) < size.z;
-        }
+        SOLR_PLANE_POINT(x, z, y);
+        rear = false; /* single sided, GI:435-446 */
         break;
-    }
     case ptXZPlane:
-    {
-        if (reverted * ray.d.y < 0.f && reverted * ray.o.y > reverted * p0.y)
-        {
-            SOLR_PLANE_HIT(x, z, y);
-            if (pm.wireframe == 2)
-                collision &= wireFrameMapping(I.x, I.z, pm.wireframeWidth);
-        }
-        if (!collision && reverted * ray.d.y > 0.f && reverted * ray.o.y < reverted * p0.y)
-        {
-            normal = vneg(normal);
-            SOLR_PLANE_HIT(x, z, y);
-            if (pm.wireframe == 2)
-                collision &= wireFrameMapping(I.x, I.z, pm.wireframeWidth);
-        }
+        SOLR_PLANE_POINT(x, z, y);
+        if (pm.wireframe == 2)
+            inside = inside && wireFrameMapping(I.x, I.z, pm.wireframeWidth);
         break;
-    }
     case ptYZPlane:
-    {
-        if (reverted * ray.d.x < 0.f && reverted * ray.o.x > reverted * p0.x)
-        {
-            SOLR_PLANE_HIT(y, z, x);
-            if (pm.emissive)
-                collision &= (int)fabsf(I.z) % 4000 < 2000 && (int)fabsf(I.y) % 4000 < 2000;
-            if (pm.wireframe == 2)
-                collision &= wireFrameMapping(I.y, I.z, pm.wireframeWidth);
-        }
-        if (!collision && reverted * ray.d.x > 0.f && reverted * ray.o.x < reverted * p0.x)
-        {
-            normal = vneg(normal);
-            SOLR_PLANE_HIT(y, z, x);
-            if (pm.emissive)
-                collision &= (int)fabsf(I.z) % 4000 < 2000 && (int)fabsf(I.y) % 4000 < 2000;
-            if (pm.wireframe == 2)
-                collision &= wireFrameMapping(I.y, I.z, pm.wireframeWidth);
-        }
+        SOLR_PLANE_POINT(y, z, x);
+        if (pm.emissive) /* chessboard-like lights, GI:486-490 */
+            inside = inside && ((int)fabsf(I.z) % 4000 < 2000 && (int)fabsf(I.y) % 4000 < 2000);
+        if (pm.wireframe == 2)
+            inside = inside && wireFrameMapping(I.y, I.z, pm.wireframeWidth);
         break;
-    }
     case ptXYPlane:
     case ptCamera:
-    {
-        if (reverted * ray.d.z < 0.f && reverted * ray.o.z > reverted * p0.z)
-        {
-            SOLR_PLANE_HIT(x, y, z);
-            if (pm.wireframe == 2)
-                collision &= wireFrameMapping(I.x, I.y, pm.wireframeWidth);
-        }
-        if (!collision && reverted * ray.d.z > 0.f && reverted * ray.o.z < reverted * p0.z)
-        {
-            normal = vneg(normal);
-            SOLR_PLANE_HIT(x, y, z);
-            if (pm.wireframe == 2)
-                collision &= wireFrameMapping(I.x, I.y, pm.wireframeWidth);
-        }
+        SOLR_PLANE_POINT(x, y, z);
+        if (pm.wireframe == 2)
+            inside = inside && wireFrameMapping(I.x, I.y, pm.wireframeWidth);
         break;
-    }
     default:
         break;
     }
+    bool collision = (front || rear) && inside;
+    v3 normal = rear ? vneg(n0) : n0;
 
-    if (collision)
+    if (TEX && (type == ptCamera || pm.textured))
     {
-        h.shadowIntensity = 1.f;
-        const float4 matColor = loadMaterialHot(planes, pm.materialId).color;
-        float4 color = matColor;
-        if (TEX && (type == ptCamera || pm.textured))
+        if (collision)
         {
+            const float4 matColor = loadMaterialHot(planes, pm.materialId).color;
             float4 specular = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 attributes = make_float4(0.f, 0.f, 0.f, 0.f);
             float ao = 0.f;
             TexOut o = {&normal, &specular, &attributes, &ao};
-            color = cubeMapping(si, type, p0, size, matColor, loadMaterialCold(planes, materialId), planes.textures, I, o);
+            const float4 color =
+                cubeMapping(si, type, p0, size, matColor, loadMaterialCold(planes, materialId), planes.textures, I, o);
             h.shadowIntensity = color.w;
+            if ((color.x + color.y + color.z) / 3.f >= si.transparentColor)
+                collision = false;
         }
-        if ((color.x + color.y + color.z) / 3.f >= si.transparentColor)
-            collision = false;
+    }
+    else
+    {
+        h.shadowIntensity = 1.f;
+        /* colour-key transparency, GI:561 */
+        collision = collision && !(pm.averageColor >= si.transparentColor);
     }
     h.intersection = I;
     h.normal = normal;
@@ -881,6 +880,7 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const R
         pm.emissive = (tag & PRIM_EMISSIVE) != 0;
         pm.textured = (tag & PRIM_TEXTURED) != 0;
         pm.materialId = materialId;
+        pm.averageColor = primRow(S, pi, ROW_P2).w;
         return planeIntersection<(FEAT & F_TEX) != 0>(si, type, p0, size, n0, pm, S, materialId, ray, h);
     }
     }
@@ -909,7 +909,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                              v3 &closestNormal, v3 &closestAreas, v3 &colorBox, Counters &cnt)
 {
     bool intersections = false;
-    if (__ballot(active) == 0ull)
+    if (ballot(active) == 0ull)
         return false;
     float minDistance = (iteration < 2) ? si.viewDistance : si.viewDistance / (iteration + 1);
     const WalkRay r = makeWalkRay(origin, target - origin);
@@ -918,6 +918,8 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     countAdd<COUNT>(cnt.wClosest, 1);
 
     const int nbBoxes = S.nbBoxes;
+    /* sign-free slab test when it is provably identical (see boxIntersectionFast) */
+    const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteInverse(r)) == 0ull);
     int cursor = active ? 0 : SOLR_CURSOR_DONE;
     int cur = 0;
     Row2 node = boxNode(S, 0);
@@ -929,15 +931,18 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         const int nbPrimitives = uniform(asint(lo.w));
         const int skip = uniform(asint(hi.w));
         const bool here = (cursor == cur);
-        bool entered = false;
         countAdd<COUNT>(cnt.wNodes, 1);
         if (here)
-        {
             countAdd<COUNT>(cnt.boxes, 1);
-            entered = boxIntersection(lo, hi, r, 0.f, minDistance);
-            cursor = entered ? cur + 1 : cur + skip;
-        }
-        const bool anyEntered = __ballot(entered) != 0ull;
+        /* evaluated by every lane: pure arithmetic, no exec-mask bookkeeping */
+        bool inBox;
+        if (fastBoxes)
+            inBox = boxIntersectionFast(lo, hi, r, 0.f, minDistance);
+        else
+            inBox = boxIntersectionExact(lo, hi, r, 0.f, minDistance);
+        const bool entered = here & inBox;
+        cursor = entered ? cur + 1 : (here ? cur + skip : cursor);
+        const bool anyEntered = ballot(entered) != 0ull;
         if (anyEntered)
         {
             if ((FEAT & F_FULL) && si.renderBoxes != 0)
@@ -963,12 +968,38 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     /* GI:704-705 */
                     const bool lanes = entered && ((tag & PRIM_FAST0) != 0 ||
                                                    ((tag & PRIM_FAST1) != 0 && currentMaterialId != materialId));
-                    if (__ballot(lanes) == 0ull)
+                    if (ballot(lanes) == 0ull)
                         continue;
                     countAdd<COUNT>(cnt.wPrims, 1);
                     if (lanes)
-                    {
                         countAdd<COUNT>(cnt.prims, 1);
+                    const int type = tag & PRIM_TYPE_MASK;
+                    if ((FEAT & (F_SPHERE | F_PROC)) && si.extendedGeometry && (type == ptSphere || type == ptEnvironment))
+                    {
+                        /* spheres: decide on the intersection point, pay for the normal only when
+                         * the hit becomes the closest one (GI:749-760 uses nothing else before) */
+                        Hit h;
+                        bool back;
+                        const bool i = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
+                        const float distance = length(h.intersection - r.o);
+                        const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
+                        if (ballot(keep) != 0ull)
+                        {
+                            if (keep)
+                            {
+                                sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b),
+                                                                   (tag & PRIM_PROCEDURAL) != 0, false, back, r, h);
+                                minDistance = distance;
+                                closestPrimitive = pi;
+                                closestIntersection = h.intersection;
+                                closestNormal = h.normal;
+                                closestAreas = V(0.f, 0.f, 0.f);
+                                intersections = true;
+                            }
+                        }
+                    }
+                    else if (lanes)
+                    {
                         Hit h;
                         h.intersection = V(0.f, 0.f, 0.f);
                         h.normal = V(0.f, 0.f, 0.f);
@@ -1004,7 +1035,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
 {
     float result = 0.f;
     color = V(0.f, 0.f, 0.f);
-    if (__ballot(active) == 0ull)
+    if (ballot(active) == 0ull)
         return 0.f;
     WalkRay r = makeWalkRay(origin, lampCenter - origin);
     r.o = origin + r.dn * si.rayEpsilon; /* GI:810-811 */
@@ -1015,12 +1046,13 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     countAdd<COUNT>(cnt.wShadow, 1);
 
     const int nbBoxes = S.nbBoxes;
+    const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteInverse(r)) == 0ull);
     int cursor = (active && result < si.shadowIntensity) ? 0 : SOLR_CURSOR_DONE;
     int cur = 0;
     Row2 node = boxNode(S, 0);
     while (cur < nbBoxes)
     {
-        if (__ballot(cursor != SOLR_CURSOR_DONE) == 0ull)
+        if (ballot(cursor != SOLR_CURSOR_DONE) == 0ull)
             break;
         const Row2 ahead = boxNode(S, (cur + 1 < nbBoxes) ? cur + 1 : cur);
         const float4 lo = node.a;
@@ -1028,15 +1060,18 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         const int nbPrimitives = uniform(asint(lo.w));
         const int skip = uniform(asint(hi.w));
         const bool here = (cursor == cur);
-        bool entered = false;
         countAdd<COUNT>(cnt.wNodes, 1);
         if (here)
-        {
             countAdd<COUNT>(cnt.boxes, 1);
-            entered = boxIntersection(lo, hi, r, 0.f, minDistance);
-            cursor = entered ? cur + 1 : cur + skip;
-        }
-        const bool anyEntered = __ballot(entered) != 0ull;
+        /* evaluated by every lane: pure arithmetic, no exec-mask bookkeeping */
+        bool inBox;
+        if (fastBoxes)
+            inBox = boxIntersectionFast(lo, hi, r, 0.f, minDistance);
+        else
+            inBox = boxIntersectionExact(lo, hi, r, 0.f, minDistance);
+        const bool entered = here & inBox;
+        cursor = entered ? cur + 1 : (here ? cur + skip : cursor);
+        const bool anyEntered = ballot(entered) != 0ull;
         if (anyEntered && nbPrimitives > 0)
         {
             const int start = uniform(boxStart(S, cur));
@@ -1049,18 +1084,34 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                 /* GI:829-830 */
                 const bool lanes = entered && result < si.shadowIntensity && index != lightId && index != objectId &&
                                    (tag & PRIM_FAST0) != 0;
-                if (__ballot(lanes) == 0ull)
+                if (ballot(lanes) == 0ull)
                     continue;
                 countAdd<COUNT>(cnt.wPrims, 1);
                 if (lanes)
-                {
                     countAdd<COUNT>(cnt.prims, 1);
-                    Hit h;
-                    h.intersection = V(0.f, 0.f, 0.f);
-                    h.normal = V(0.f, 0.f, 0.f);
-                    h.areas = V(0.f, 0.f, 0.f);
-                    h.shadowIntensity = 0.f;
-                    const bool hit = testPrimitive<true, FEAT>(S, si, pi, head, tag, r, h);
+                const int type = tag & PRIM_TYPE_MASK;
+                Hit h;
+                h.intersection = V(0.f, 0.f, 0.f);
+                h.normal = V(0.f, 0.f, 0.f);
+                h.areas = V(0.f, 0.f, 0.f);
+                h.shadowIntensity = 0.f;
+                bool hit = false;
+                if ((FEAT & (F_SPHERE | F_PROC)) && si.extendedGeometry && type == ptSphere)
+                {
+                    /* opaque spheres shadow with intensity 1 and need no normal (GI:281, 880) */
+                    bool back;
+                    hit = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
+                    h.shadowIntensity = 1.f;
+                    if ((tag & PRIM_TRANSPARENT) || ((FEAT & F_PROC) && (tag & PRIM_PROCEDURAL)))
+                    {
+                        if (hit)
+                            sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b), (tag & PRIM_PROCEDURAL) != 0,
+                                                               (tag & PRIM_TRANSPARENT) != 0, back, r, h);
+                    }
+                }
+                else if (lanes)
+                    hit = testPrimitive<true, FEAT>(S, si, pi, head, tag, r, h);
+                {
                     if (hit)
                     {
                         const float l = length(h.intersection - r.o);
@@ -1481,7 +1532,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
         if (phase == 0)
         {
             running = running && (iteration < currentMaxIteration) && (rayLength < si.viewDistance) && carryon;
-            if (__ballot(running) == 0ull)
+            if (ballot(running) == 0ull)
             {
                 phase = 1;
                 continue;

@@ -14,7 +14,7 @@
  *     primitive i       row 8i   = { p0.xyz,   bits(tag) }         \ sphere / ellipsoid / plane tests
  *                       row 8i+1 = { size.xyz, bits(materialId) }  / read these 32 bytes only
  *                       row 8i+2 = { p1.xyz,   bits(index) }       \ + cylinder, triangle: one 64-byte
- *                       row 8i+3 = { p2.xyz,   0 }                 /   scalar-cache line in total
+ *                       row 8i+3 = { p2.xyz,   avg colour }        /   scalar-cache line in total
  *                       row 8i+4 = { n0.xyz, vt0.x }               \
  *                       row 8i+5 = { n1.xyz, vt0.y }                | normals / texture coordinates:
  *                       row 8i+6 = { n2.xyz, vt1.x }                | second cache line, triangle and
@@ -123,6 +123,7 @@ struct SceneArgs
     int nbLights;
     int nbLamps;
     int nested;
+    int orderedBoxes; /* every node has finite bounds with min <= max (sign-free slab test allowed) */
     long nbRandoms;
 };
 
@@ -153,6 +154,7 @@ struct Scene
     int nbLights;
     int nbLamps;
     int nested; /* 1: skip pointers form nested intervals (validated on upload) */
+    int orderedBoxes;
     long nbRandoms;
 };
 
@@ -173,6 +175,7 @@ __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
     s.nbLights = a.nbLights;
     s.nbLamps = a.nbLamps;
     s.nested = a.nested;
+    s.orderedBoxes = a.orderedBoxes;
     s.nbRandoms = a.nbRandoms;
     return s;
 }

@@ -422,11 +422,13 @@ struct Engine
     std::vector<float4> hostBoxes, hostBoxesCompact, hostPrims, hostLights;
     std::vector<int> hostBoxStart, hostBoxStartCompact;
     std::vector<int> materialTags; /* PRIM_* bits per material id */
+    std::vector<float> materialAverage; /* (r + g + b) / 3.f per material id (plane colour key, GI:561) */
     int sceneFeatures = F_ALL & ~F_FULL; /* rt_device.h enum Feature, recomputed with the tags */
     unsigned offBoxes = 0, offBoxesCompact = 0, offBoxStart = 0, offBoxStartCompact = 0, offPrims = 0, offLights = 0;
     unsigned offMatCold = 0;
     bool geometryDirty = true;
     int nbBoxesCompact = 0;
+    int orderedExact = 0, orderedCompact = 0; /* sign-free slab test allowed on that node list */
     int nbBoxes = 0, nbPrimitives = 0, nbLights = 0, nbLamps = 0, nbMaterials = 0;
     int nested = 1;
     long nbRandoms = 0;
@@ -621,6 +623,7 @@ void retagPrimitives()
         /* a material that was never uploaded reads as all zeros on the device */
         const int facts = (mat >= 0 && (size_t)mat < g.materialTags.size()) ? g.materialTags[mat] : (PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
         r[ROW_P0_TYPE].w = bitsf(type | facts);
+        r[ROW_P2].w = (mat >= 0 && (size_t)mat < g.materialAverage.size()) ? g.materialAverage[mat] : 0.f;
         switch (type)
         {
         case ptSphere:
@@ -707,6 +710,7 @@ SceneArgs makeScene(bool exactNodes)
     S.nbLights = g.nbLights;
     S.nbLamps = g.nbLamps;
     S.nested = g.nested;
+    S.orderedBoxes = exactNodes ? g.orderedExact : g.orderedCompact;
     S.nbRandoms = g.randoms.ptr ? g.nbRandoms : 0;
     return S;
 }
@@ -1024,6 +1028,7 @@ void finalize_scene(vec2i)
     g.hostBoxStart.clear();
     g.hostBoxStartCompact.clear();
     g.materialTags.clear();
+    g.materialAverage.clear();
     g.geometryDirty = true;
     /* no hipDeviceReset: the process may share the device with torch/RCCL */
 }
@@ -1097,6 +1102,33 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
             if (a.nbPrimitives == 0 && a.indexForNextBox.x >= 2 && b.indexForNextBox.x == a.indexForNextBox.x - 1 &&
                 memcmp(a.parameters, b.parameters, sizeof(a.parameters)) == 0)
                 keep[i] = 0;
+            /* an inner node without emitted children (its cell held only lights or nothing,
+             * GPUKernel.cpp:1096) leads nowhere: entering or missing it changes nothing */
+            if (a.nbPrimitives == 0 && a.indexForNextBox.x == 1)
+                keep[i] = 0;
+        }
+    if (g.nested && nbActiveBoxes > 0)
+    {
+        const BoundingBox &last = boundingBoxes[nbActiveBoxes - 1];
+        if (last.nbPrimitives == 0 && last.indexForNextBox.x == 1)
+            keep[nbActiveBoxes - 1] = 0;
+    }
+    auto ordered = [&](int i) {
+        const BoundingBox &b = boundingBoxes[i];
+        const float *lo = &b.parameters[0].x, *hi = &b.parameters[1].x;
+        for (int k = 0; k < 3; ++k)
+            if (!(lo[k] <= hi[k]) || !(fabsf(lo[k]) < 1.0e30f) || !(fabsf(hi[k]) < 1.0e30f))
+                return false;
+        return true;
+    };
+    g.orderedExact = 1;
+    g.orderedCompact = 1;
+    for (int i = 0; i < nbActiveBoxes; ++i)
+        if (!ordered(i))
+        {
+            g.orderedExact = 0;
+            if (keep[i])
+                g.orderedCompact = 0;
         }
     std::vector<int> newIndex(nbActiveBoxes + 1, 0);
     for (int i = 0; i < nbActiveBoxes; ++i)
@@ -1165,10 +1197,12 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
     memset(hot.data(), 0, hot.size() * sizeof(MaterialHot));
     memset(cold.data(), 0, cold.size() * sizeof(MaterialCold));
     g.materialTags.assign(capacity, PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
+    g.materialAverage.assign(capacity, 0.f);
     for (int i = 0; i < nbActiveMaterials && i < capacity; ++i)
     {
         const Material &m = materials[i];
         g.materialTags[i] = materialTag(m);
+        g.materialAverage[i] = (m.color.x + m.color.y + m.color.z) / 3.f; /* same expression, same rounding */
         MaterialHot &h = hot[i];
         h.innerIllumination = make_float4(m.innerIllumination.x, m.innerIllumination.y, m.innerIllumination.z,
                                           m.innerIllumination.w);
