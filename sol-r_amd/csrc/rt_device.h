@@ -220,11 +220,6 @@ SOLR_DEV bool boxIntersectionFast(const float4 &lo, const float4 &hi, const Walk
     return (tmin <= tmax) && (tmin < t1) && (tmax > t0);
 }
 
-SOLR_DEV bool finiteInverse(const WalkRay &r)
-{
-    const float big = 3.0e38f;
-    return fabsf(r.inv.x) < big && fabsf(r.inv.y) < big && fabsf(r.inv.z) < big;
-}
 
 /* ---------------------------------------------------------------------- */
 /* Texture tier (TM)                                                       */
@@ -898,11 +893,168 @@ SOLR_DEV int nextNode(const Scene &S, int cur, int skip, bool anyEntered, int cu
     return uniform(waveMinInt(cursor));
 }
 
-/* GI:667-772, wave-synchronous.  `active` lanes trace origin -> target.
- * The record of node cur+1 is requested while node cur is being tested: the
- * depth-first order makes it the next node whenever any lane enters cur (and
- * always for leaves, whose skip is 1), so the scalar-load latency of the walk
- * is paid only after a subtree is skipped. */
+/* One node of the general walk: any skip-pointer list that makes forward
+ * progress, any bounds, any reciprocal.  Tests node `cur` (already in `node`)
+ * for the lanes whose cursor is there, moves the lane cursors, picks the next
+ * node for the wave and fetches it.  Returns whether any lane entered. */
+template <bool COUNT>
+SOLR_DEV bool stepGeneral(const Scene &S, const WalkRay &r, bool fastBoxes, float farDistance, int &cursor, int &cur,
+                          Row2 &node, int &nbPrimitives, bool &entered, Counters &cnt)
+{
+    const int nbBoxes = S.nbBoxes;
+    const Row2 ahead = boxNode(S, (cur + 1 < nbBoxes) ? cur + 1 : cur);
+    const float4 lo = nodeLo(node);
+    const float4 hi = nodeHi(node);
+    nbPrimitives = uniform(nodeCount(node));
+    const int skip = uniform(nodeSkip(node));
+    const bool here = (cursor == cur);
+    countAdd<COUNT>(cnt.wNodes, 1);
+    if (here)
+        countAdd<COUNT>(cnt.boxes, 1);
+    /* evaluated by every lane: pure arithmetic, no exec-mask bookkeeping */
+    bool inBox;
+    if (fastBoxes)
+        inBox = boxIntersectionFast(lo, hi, r, 0.f, farDistance);
+    else
+        inBox = boxIntersectionExact(lo, hi, r, 0.f, farDistance);
+    entered = here & inBox;
+    cursor = entered ? cur + 1 : (here ? cur + skip : cursor);
+    const bool anyEntered = ballot(entered) != 0ull;
+    const int next = nextNode(S, cur, skip, anyEntered, cursor);
+    node = (next == cur + 1) ? ahead : boxNode(S, next < nbBoxes ? next : cur);
+    cur = next;
+    return anyEntered;
+}
+
+/* The tidy walk: skip pointers nested, every node ordered and finite, every
+ * lane's origin and reciprocals finite (the conditions of boxIntersectionFast).
+ * Hand-scheduled because this loop is where a frame spends its time: it runs
+ * from node `cur` to the next leaf that some lane enters and costs 20 vector +
+ * 18 scalar instructions per node, about half of what hipcc makes of
+ * stepGeneral:
+ *   - the node record is one s_load_dwordx8; the record of cur+1 is requested
+ *     into the other register bank while cur is tested (two copies of the body
+ *     with the banks swapped, so nothing is ever moved), and it is the next node
+ *     whenever a lane enters cur or cur is a leaf;
+ *   - the slab products are three v_pk_add_f32 + three v_pk_mul_f32 on the
+ *     (x,y) (z,z) (x,y) pairs of the record - same IEEE operations as the
+ *     scalar form, two per issue slot;
+ *   - lane selection is a chain of v_cmpx: cursor == cur narrows exec to the
+ *     lanes at this node (they get cur+skip), the three slab conditions narrow it
+ *     to the lanes that enter (they get cur+1), exec is the `entered` mask - no
+ *     mask algebra, no v_cndmask;
+ *   - the wave's next node is one s_cselect on "mask != 0".
+ * Hazards (gfx950): every SGPR a vector instruction reads here is written by the
+ * scalar unit; v_cmpx results are only read back through s_mov from exec.
+ * Fixed registers: s[64:87], v[122:127] (sub-registers of pairs cannot be named
+ * through operands).  All scalar loads are drained before the statement ends.
+ *
+ * Returns the leaf (>= 0) with `entered` lanes and its primitive count, cur
+ * already advanced past it, or -1 when the list is exhausted. */
+typedef float f2v __attribute__((ext_vector_type(2)));
+struct PackedRay
+{
+    f2v oxy, ozz, ixy, izz;
+};
+SOLR_DEV PackedRay packRay(const WalkRay &r)
+{
+    PackedRay p;
+    p.oxy = (f2v){r.o.x, r.o.y};
+    p.ozz = (f2v){r.o.z, r.o.z};
+    p.ixy = (f2v){r.inv.x, r.inv.y};
+    p.izz = (f2v){r.inv.z, r.inv.z};
+    return p;
+}
+
+#define SOLR_WALK_HALF(SELF, OTHER, LOXY, ZZ, HIXY, NB, SKIP, SELF_REGS, OTHER_REGS)                                  \
+    "LW" SELF "_%=:\n"                                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                           \
+    "s_add_i32 s85, %[cur], 1\n"                                                                                       \
+    "s_min_i32 s84, s85, s87\n"                                                                                        \
+    "s_lshl_b32 s84, s84, 5\n"                                                                                         \
+    "s_load_dwordx8 " OTHER_REGS ", %[base], s84\n"                                                                    \
+    "s_add_i32 s86, %[cur], " SKIP "\n"                                                                                \
+    "v_pk_add_f32 v[122:123], " LOXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
+    "v_pk_add_f32 v[124:125], " HIXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
+    "v_pk_add_f32 v[126:127], " ZZ ", %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"                                              \
+    "v_pk_mul_f32 v[122:123], %[ixy], v[122:123]\n"                                                                    \
+    "v_pk_mul_f32 v[124:125], %[ixy], v[124:125]\n"                                                                    \
+    "v_pk_mul_f32 v[126:127], %[izz], v[126:127]\n"                                                                    \
+    "v_min_f32 %[t], v122, v124\n"                                                                                     \
+    "v_max_f32 v122, v122, v124\n"                                                                                     \
+    "v_min_f32 v124, v123, v125\n"                                                                                     \
+    "v_max_f32 v123, v123, v125\n"                                                                                     \
+    "v_min_f32 v125, v126, v127\n"                                                                                     \
+    "v_max_f32 v126, v126, v127\n"                                                                                     \
+    "v_max3_f32 %[t], %[t], v124, v125\n"                                                                              \
+    "v_min3_f32 v122, v122, v123, v126\n"                                                                              \
+    "v_cmpx_eq_u32_e32 vcc, %[cur], %[cursor]\n"                                                                       \
+    "v_mov_b32 %[cursor], s86\n"                                                                                       \
+    "v_cmpx_le_f32_e32 vcc, %[t], v122\n"                                                                              \
+    "v_cmpx_lt_f32_e32 vcc, %[t], %[far]\n"                                                                            \
+    "v_cmpx_lt_f32_e32 vcc, 0, v122\n"                                                                                 \
+    "v_mov_b32 %[cursor], s85\n"                                                                                       \
+    "s_mov_b64 s[82:83], exec\n"                                                                                       \
+    "s_mov_b64 exec, s[80:81]\n"                                                                                       \
+    "s_cmp_lg_u64 s[82:83], 0\n"                                                                                       \
+    "s_cselect_b32 s84, s85, s86\n"                                                                                    \
+    "s_cbranch_scc0 LN" SELF "_%=\n"                                                                                   \
+    "s_cmp_gt_i32 " NB ", 0\n"                                                                                         \
+    "s_cbranch_scc1 LL" SELF "_%=\n"                                                                                   \
+    "LN" SELF "_%=:\n"                                                                                                 \
+    "s_mov_b32 %[cur], s84\n"                                                                                          \
+    "s_cmp_ge_i32 s84, %[n]\n"                                                                                         \
+    "s_cbranch_scc1 LD_%=\n"                                                                                           \
+    "s_cmp_eq_u32 s84, s85\n"                                                                                          \
+    "s_cbranch_scc1 LW" OTHER "_%=\n"                                                                                  \
+    "s_lshl_b32 s84, s84, 5\n"                                                                                         \
+    "s_load_dwordx8 " SELF_REGS ", %[base], s84\n"                                                                     \
+    "s_branch LW" SELF "_%=\n"                                                                                         \
+    "LL" SELF "_%=:\n"                                                                                                 \
+    "s_mov_b32 %[leaf], %[cur]\n"                                                                                      \
+    "s_mov_b32 %[nb], " NB "\n"                                                                                        \
+    "s_mov_b32 %[cur], s85\n"                                                                                          \
+    "s_branch LX_%=\n"
+
+SOLR_DEV int advanceTidy(const Scene &S, const PackedRay &p, float farDistance, int &cursor, int &cur,
+                         int &nbPrimitives, bool &entered)
+{
+    const unsigned long base = (unsigned long)S.geo + ((unsigned long)S.offBoxes << 4);
+    int leaf, nb, flag;
+    float t;
+    asm volatile("s_mov_b64 s[80:81], exec\n"
+                 "s_add_i32 s87, %[n], -1\n"
+                 "s_lshl_b32 s84, %[cur], 5\n"
+                 "s_load_dwordx8 s[64:71], %[base], s84\n"
+                 SOLR_WALK_HALF("A", "B", "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[64:71]", "s[72:79]")
+                 SOLR_WALK_HALF("B", "A", "s[72:73]", "s[74:75]", "s[76:77]", "s78", "s79", "s[72:79]", "s[64:71]")
+                 "LD_%=:\n"
+                 "s_mov_b32 %[leaf], -1\n"
+                 "s_mov_b32 %[nb], 0\n"
+                 "LX_%=:\n"
+                 "s_waitcnt lgkmcnt(0)\n"
+                 "v_cndmask_b32_e64 %[flag], 0, 1, s[82:83]\n"
+                 : [cursor] "+v"(cursor), [cur] "+s"(cur), [leaf] "=&s"(leaf), [nb] "=&s"(nb), [flag] "=&v"(flag),
+                   [t] "=&v"(t)
+                 : [oxy] "v"(p.oxy), [ozz] "v"(p.ozz), [ixy] "v"(p.ixy), [izz] "v"(p.izz), [far] "v"(farDistance),
+                   [base] "s"(base), [n] "s"(S.nbBoxes)
+                 : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
+                   "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v122", "v123",
+                   "v124", "v125", "v126", "v127");
+    nbPrimitives = nb;
+    entered = flag != 0;
+    return leaf;
+}
+
+/* the conditions of boxIntersectionFast that depend on the ray */
+SOLR_DEV bool finiteRay(const WalkRay &r)
+{
+    const float big = 3.0e38f;
+    return fabsf(r.inv.x) < big && fabsf(r.inv.y) < big && fabsf(r.inv.z) < big && fabsf(r.o.x) < big &&
+           fabsf(r.o.y) < big && fabsf(r.o.z) < big;
+}
+
+/* GI:667-772, wave-synchronous.  `active` lanes trace origin -> target. */
 template <bool COUNT, int FEAT>
 SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v3 origin, v3 target, int iteration,
                              int currentMaterialId, int &closestPrimitive, v3 &closestIntersection,
@@ -919,110 +1071,105 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
 
     const int nbBoxes = S.nbBoxes;
     /* sign-free slab test when it is provably identical (see boxIntersectionFast) */
-    const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteInverse(r)) == 0ull);
+    const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteRay(r)) == 0ull);
+    const bool showBoxes = (FEAT & F_FULL) && si.renderBoxes != 0;
+    const bool tidy = !COUNT && fastBoxes && S.nested && !showBoxes;
+    const PackedRay pr = packRay(r);
     int cursor = active ? 0 : SOLR_CURSOR_DONE;
     int cur = 0;
-    Row2 node = boxNode(S, 0);
+    Row2 node;
+    node.a = node.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!tidy)
+        node = boxNode(S, 0);
     while (cur < nbBoxes)
     {
-        const Row2 ahead = boxNode(S, (cur + 1 < nbBoxes) ? cur + 1 : cur);
-        const float4 lo = node.a;
-        const float4 hi = node.b;
-        const int nbPrimitives = uniform(asint(lo.w));
-        const int skip = uniform(asint(hi.w));
-        const bool here = (cursor == cur);
-        countAdd<COUNT>(cnt.wNodes, 1);
-        if (here)
-            countAdd<COUNT>(cnt.boxes, 1);
-        /* evaluated by every lane: pure arithmetic, no exec-mask bookkeeping */
-        bool inBox;
-        if (fastBoxes)
-            inBox = boxIntersectionFast(lo, hi, r, 0.f, minDistance);
-        else
-            inBox = boxIntersectionExact(lo, hi, r, 0.f, minDistance);
-        const bool entered = here & inBox;
-        cursor = entered ? cur + 1 : (here ? cur + skip : cursor);
-        const bool anyEntered = ballot(entered) != 0ull;
-        if (anyEntered)
+        int leaf = cur, nbPrimitives;
+        bool entered;
+        if (tidy)
         {
-            if ((FEAT & F_FULL) && si.renderBoxes != 0)
+            leaf = advanceTidy(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
+            if (leaf < 0)
+                break;
+        }
+        else
+        {
+            if (!stepGeneral<COUNT>(S, r, fastBoxes, minDistance, cursor, cur, node, nbPrimitives, entered, cnt))
+                continue;
+            if (showBoxes)
             {
                 if (entered)
                 {
-                    const int start = boxStart(S, cur);
+                    const int start = boxStart(S, leaf);
                     const float4 c = loadMaterialHot(S, (int)((unsigned)start % (unsigned)NB_MAX_MATERIALS)).color;
                     colorBox.x += c.x / 200.f;
                     colorBox.y += c.y / 200.f;
                     colorBox.z += c.z / 200.f;
                 }
+                continue;
             }
-            else if (nbPrimitives > 0)
+            if (nbPrimitives <= 0)
+                continue;
+        }
+        const int start = uniform(boxStart(S, leaf));
+        for (int k = 0; k < nbPrimitives; ++k)
+        {
+            const int pi = start + k;
+            const Row2 head = primHead(S, pi);
+            const int tag = uniform(asint(head.a.w));
+            const int materialId = uniform(asint(head.b.w));
+            /* GI:704-705 */
+            const bool lanes = entered && ((tag & PRIM_FAST0) != 0 ||
+                                           ((tag & PRIM_FAST1) != 0 && currentMaterialId != materialId));
+            if (ballot(lanes) == 0ull)
+                continue;
+            countAdd<COUNT>(cnt.wPrims, 1);
+            if (lanes)
+                countAdd<COUNT>(cnt.prims, 1);
+            const int type = tag & PRIM_TYPE_MASK;
+            if ((FEAT & (F_SPHERE | F_PROC)) && si.extendedGeometry && (type == ptSphere || type == ptEnvironment))
             {
-                const int start = uniform(boxStart(S, cur));
-                for (int k = 0; k < nbPrimitives; ++k)
+                /* spheres: decide on the intersection point, pay for the normal only when
+                 * the hit becomes the closest one (GI:749-760 uses nothing else before) */
+                Hit h;
+                bool back;
+                const bool i = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
+                const float distance = length(h.intersection - r.o);
+                const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
+                if (ballot(keep) != 0ull)
                 {
-                    const int pi = start + k;
-                    const Row2 head = primHead(S, pi);
-                    const int tag = uniform(asint(head.a.w));
-                    const int materialId = uniform(asint(head.b.w));
-                    /* GI:704-705 */
-                    const bool lanes = entered && ((tag & PRIM_FAST0) != 0 ||
-                                                   ((tag & PRIM_FAST1) != 0 && currentMaterialId != materialId));
-                    if (ballot(lanes) == 0ull)
-                        continue;
-                    countAdd<COUNT>(cnt.wPrims, 1);
-                    if (lanes)
-                        countAdd<COUNT>(cnt.prims, 1);
-                    const int type = tag & PRIM_TYPE_MASK;
-                    if ((FEAT & (F_SPHERE | F_PROC)) && si.extendedGeometry && (type == ptSphere || type == ptEnvironment))
+                    if (keep)
                     {
-                        /* spheres: decide on the intersection point, pay for the normal only when
-                         * the hit becomes the closest one (GI:749-760 uses nothing else before) */
-                        Hit h;
-                        bool back;
-                        const bool i = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
-                        const float distance = length(h.intersection - r.o);
-                        const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
-                        if (ballot(keep) != 0ull)
-                        {
-                            if (keep)
-                            {
-                                sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b),
-                                                                   (tag & PRIM_PROCEDURAL) != 0, false, back, r, h);
-                                minDistance = distance;
-                                closestPrimitive = pi;
-                                closestIntersection = h.intersection;
-                                closestNormal = h.normal;
-                                closestAreas = V(0.f, 0.f, 0.f);
-                                intersections = true;
-                            }
-                        }
-                    }
-                    else if (lanes)
-                    {
-                        Hit h;
-                        h.intersection = V(0.f, 0.f, 0.f);
-                        h.normal = V(0.f, 0.f, 0.f);
-                        h.areas = V(0.f, 0.f, 0.f);
-                        h.shadowIntensity = 0.f;
-                        const bool i = testPrimitive<false, FEAT>(S, si, pi, head, tag, r, h);
-                        const float distance = length(h.intersection - r.o);
-                        if (i && distance > si.geometryEpsilon && distance < minDistance)
-                        {
-                            minDistance = distance;
-                            closestPrimitive = pi;
-                            closestIntersection = h.intersection;
-                            closestNormal = h.normal;
-                            closestAreas = h.areas;
-                            intersections = true;
-                        }
+                        sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b), (tag & PRIM_PROCEDURAL) != 0,
+                                                           false, back, r, h);
+                        minDistance = distance;
+                        closestPrimitive = pi;
+                        closestIntersection = h.intersection;
+                        closestNormal = h.normal;
+                        closestAreas = V(0.f, 0.f, 0.f);
+                        intersections = true;
                     }
                 }
             }
+            else if (lanes)
+            {
+                Hit h;
+                h.intersection = V(0.f, 0.f, 0.f);
+                h.normal = V(0.f, 0.f, 0.f);
+                h.areas = V(0.f, 0.f, 0.f);
+                h.shadowIntensity = 0.f;
+                const bool i = testPrimitive<false, FEAT>(S, si, pi, head, tag, r, h);
+                const float distance = length(h.intersection - r.o);
+                if (i && distance > si.geometryEpsilon && distance < minDistance)
+                {
+                    minDistance = distance;
+                    closestPrimitive = pi;
+                    closestIntersection = h.intersection;
+                    closestNormal = h.normal;
+                    closestAreas = h.areas;
+                    intersections = true;
+                }
+            }
         }
-        const int next = nextNode(S, cur, skip, anyEntered, cursor);
-        node = (next == cur + 1) ? ahead : boxNode(S, next < nbBoxes ? next : cur);
-        cur = next;
     }
     return intersections;
 }
@@ -1046,102 +1193,92 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     countAdd<COUNT>(cnt.wShadow, 1);
 
     const int nbBoxes = S.nbBoxes;
-    const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteInverse(r)) == 0ull);
+    const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteRay(r)) == 0ull);
+    const bool tidy = !COUNT && fastBoxes && S.nested;
+    const PackedRay pr = packRay(r);
     int cursor = (active && result < si.shadowIntensity) ? 0 : SOLR_CURSOR_DONE;
     int cur = 0;
-    Row2 node = boxNode(S, 0);
+    Row2 node;
+    node.a = node.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!tidy)
+        node = boxNode(S, 0);
     while (cur < nbBoxes)
     {
         if (ballot(cursor != SOLR_CURSOR_DONE) == 0ull)
             break;
-        const Row2 ahead = boxNode(S, (cur + 1 < nbBoxes) ? cur + 1 : cur);
-        const float4 lo = node.a;
-        const float4 hi = node.b;
-        const int nbPrimitives = uniform(asint(lo.w));
-        const int skip = uniform(asint(hi.w));
-        const bool here = (cursor == cur);
-        countAdd<COUNT>(cnt.wNodes, 1);
-        if (here)
-            countAdd<COUNT>(cnt.boxes, 1);
-        /* evaluated by every lane: pure arithmetic, no exec-mask bookkeeping */
-        bool inBox;
-        if (fastBoxes)
-            inBox = boxIntersectionFast(lo, hi, r, 0.f, minDistance);
-        else
-            inBox = boxIntersectionExact(lo, hi, r, 0.f, minDistance);
-        const bool entered = here & inBox;
-        cursor = entered ? cur + 1 : (here ? cur + skip : cursor);
-        const bool anyEntered = ballot(entered) != 0ull;
-        if (anyEntered && nbPrimitives > 0)
+        int leaf = cur, nbPrimitives;
+        bool entered;
+        if (tidy)
         {
-            const int start = uniform(boxStart(S, cur));
-            for (int k = 0; k < nbPrimitives; ++k)
+            leaf = advanceTidy(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
+            if (leaf < 0)
+                break;
+        }
+        else if (!stepGeneral<COUNT>(S, r, fastBoxes, minDistance, cursor, cur, node, nbPrimitives, entered, cnt) ||
+                 nbPrimitives <= 0)
+            continue;
+        const int start = uniform(boxStart(S, leaf));
+        for (int k = 0; k < nbPrimitives; ++k)
+        {
+            const int pi = start + k;
+            const Row2 head = primHead(S, pi);
+            const int tag = uniform(asint(head.a.w));
+            const int index = uniform(asint(primRow(S, pi, ROW_P1_INDEX).w));
+            /* GI:829-830 */
+            const bool lanes = entered && result < si.shadowIntensity && index != lightId && index != objectId &&
+                               (tag & PRIM_FAST0) != 0;
+            if (ballot(lanes) == 0ull)
+                continue;
+            countAdd<COUNT>(cnt.wPrims, 1);
+            if (lanes)
+                countAdd<COUNT>(cnt.prims, 1);
+            const int type = tag & PRIM_TYPE_MASK;
+            Hit h;
+            h.intersection = V(0.f, 0.f, 0.f);
+            h.normal = V(0.f, 0.f, 0.f);
+            h.areas = V(0.f, 0.f, 0.f);
+            h.shadowIntensity = 0.f;
+            bool hit = false;
+            if ((FEAT & (F_SPHERE | F_PROC)) && si.extendedGeometry && type == ptSphere)
             {
-                const int pi = start + k;
-                const Row2 head = primHead(S, pi);
-                const int tag = uniform(asint(head.a.w));
-                const int index = uniform(asint(primRow(S, pi, ROW_P1_INDEX).w));
-                /* GI:829-830 */
-                const bool lanes = entered && result < si.shadowIntensity && index != lightId && index != objectId &&
-                                   (tag & PRIM_FAST0) != 0;
-                if (ballot(lanes) == 0ull)
-                    continue;
-                countAdd<COUNT>(cnt.wPrims, 1);
-                if (lanes)
-                    countAdd<COUNT>(cnt.prims, 1);
-                const int type = tag & PRIM_TYPE_MASK;
-                Hit h;
-                h.intersection = V(0.f, 0.f, 0.f);
-                h.normal = V(0.f, 0.f, 0.f);
-                h.areas = V(0.f, 0.f, 0.f);
-                h.shadowIntensity = 0.f;
-                bool hit = false;
-                if ((FEAT & (F_SPHERE | F_PROC)) && si.extendedGeometry && type == ptSphere)
-                {
-                    /* opaque spheres shadow with intensity 1 and need no normal (GI:281, 880) */
-                    bool back;
-                    hit = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
-                    h.shadowIntensity = 1.f;
-                    if ((tag & PRIM_TRANSPARENT) || ((FEAT & F_PROC) && (tag & PRIM_PROCEDURAL)))
-                    {
-                        if (hit)
-                            sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b), (tag & PRIM_PROCEDURAL) != 0,
-                                                               (tag & PRIM_TRANSPARENT) != 0, back, r, h);
-                    }
-                }
-                else if (lanes)
-                    hit = testPrimitive<true, FEAT>(S, si, pi, head, tag, r, h);
+                /* opaque spheres shadow with intensity 1 and need no normal (GI:281, 880) */
+                bool back;
+                hit = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
+                h.shadowIntensity = 1.f;
+                if ((tag & PRIM_TRANSPARENT) || ((FEAT & F_PROC) && (tag & PRIM_PROCEDURAL)))
                 {
                     if (hit)
+                        sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b), (tag & PRIM_PROCEDURAL) != 0,
+                                                           (tag & PRIM_TRANSPARENT) != 0, back, r, h);
+                }
+            }
+            else if (lanes)
+                hit = testPrimitive<true, FEAT>(S, si, pi, head, tag, r, h);
+            if (hit)
+            {
+                const float l = length(h.intersection - r.o);
+                if (l > si.geometryEpsilon && l < lengthOL)
+                {
+                    float ratio = h.shadowIntensity * si.shadowIntensity;
+                    if (tag & PRIM_TRANSPARENT)
                     {
-                        const float l = length(h.intersection - r.o);
-                        if (l > si.geometryEpsilon && l < lengthOL)
-                        {
-                            float ratio = h.shadowIntensity * si.shadowIntensity;
-                            if (tag & PRIM_TRANSPARENT)
-                            {
-                                /* coloured shadow through a transparent primitive, GI:880-892 */
-                                const MaterialHot mh = loadMaterialHot(S, uniform(asint(head.b.w)));
-                                v3 O_L = r.dn;
-                                float a = fabsf(dot(O_L, h.normal));
-                                float rr = (mh.transparency == 0.f) ? 1.f : (1.f - mh.transparency);
-                                ratio *= rr * a;
-                                color.x += ratio * (0.3f - 0.3f * mh.color.x);
-                                color.y += ratio * (0.3f - 0.3f * mh.color.y);
-                                color.z += ratio * (0.3f - 0.3f * mh.color.z);
-                            }
-                            result += ratio;
-                        }
+                        /* coloured shadow through a transparent primitive, GI:880-892 */
+                        const MaterialHot mh = loadMaterialHot(S, uniform(asint(head.b.w)));
+                        v3 O_L = r.dn;
+                        float a = fabsf(dot(O_L, h.normal));
+                        float rr = (mh.transparency == 0.f) ? 1.f : (1.f - mh.transparency);
+                        ratio *= rr * a;
+                        color.x += ratio * (0.3f - 0.3f * mh.color.x);
+                        color.y += ratio * (0.3f - 0.3f * mh.color.y);
+                        color.z += ratio * (0.3f - 0.3f * mh.color.z);
                     }
+                    result += ratio;
                 }
             }
         }
         /* the reference re-tests `result < shadowIntensity` before every node */
         if (cursor != SOLR_CURSOR_DONE && !(result < si.shadowIntensity))
             cursor = SOLR_CURSOR_DONE;
-        const int next = nextNode(S, cur, skip, anyEntered, cursor);
-        node = (next == cur + 1) ? ahead : boxNode(S, next < nbBoxes ? next : cur);
-        cur = next;
     }
     result = fmaxf(0.f, fminf(result, si.shadowIntensity));
     return result;

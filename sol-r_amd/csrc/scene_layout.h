@@ -8,8 +8,8 @@
  * that reads them together:
  *
  *   geometry arena
- *     box node i        row 2i   = { min.x, min.y, min.z, bits(nbPrimitives) }
- *                       row 2i+1 = { max.x, max.y, max.z, bits(skip) }
+ *     box node i        row 2i   = { min.x, min.y, min.z, max.z }        (x,y) (z,z) (x,y) pairs feed the
+ *                       row 2i+1 = { max.x, max.y, bits(nbPrimitives), bits(skip) }   packed slab test
  *     boxStart[i]       int plane: first primitive of a leaf
  *     primitive i       row 8i   = { p0.xyz,   bits(tag) }         \ sphere / ellipsoid / plane tests
  *                       row 8i+1 = { size.xyz, bits(materialId) }  / read these 32 bytes only
@@ -211,8 +211,10 @@ __device__ __forceinline__ int4 asint4(const float4 &v)
 
 __device__ __forceinline__ Row2 boxNode(const Scene &s, int i) { return ld8(s.geo, s.offBoxes + 2u * (unsigned)i); }
 __device__ __forceinline__ Row2 primHead(const Scene &s, int i) { return ld8(s.geo, s.offPrims + 8u * (unsigned)i); }
-__device__ __forceinline__ float4 boxLo(const Scene &s, int i) { return ld4(s.geo, s.offBoxes + 2u * (unsigned)i); }
-__device__ __forceinline__ float4 boxHi(const Scene &s, int i) { return ld4(s.geo, s.offBoxes + 2u * (unsigned)i + 1u); }
+__device__ __forceinline__ float4 nodeLo(const Row2 &n) { return make_float4(n.a.x, n.a.y, n.a.z, 0.f); }
+__device__ __forceinline__ float4 nodeHi(const Row2 &n) { return make_float4(n.b.x, n.b.y, n.a.w, 0.f); }
+__device__ __forceinline__ int nodeCount(const Row2 &n) { return __float_as_int(n.b.z); }
+__device__ __forceinline__ int nodeSkip(const Row2 &n) { return __float_as_int(n.b.w); }
 __device__ __forceinline__ int boxStart(const Scene &s, int i) { return ((cip)s.geo)[s.offBoxStart + (unsigned)i]; }
 __device__ __forceinline__ float4 primRow(const Scene &s, int i, int row)
 {

@@ -1068,9 +1068,10 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
         ARGCHECK(b.nbPrimitives >= 0 && (b.nbPrimitives == 0 || (b.startIndex >= 0 &&
                                                                   (long)b.startIndex + b.nbPrimitives <= nbPrimitives)),
                  "h2d_scene: box primitive range outside the primitive array");
-        boxes[2 * i] = make_float4(b.parameters[0].x, b.parameters[0].y, b.parameters[0].z, bitsf(b.nbPrimitives));
+        /* node record, scene_layout.h: { min.xyz, max.z } { max.xy, nbPrimitives, skip } */
+        boxes[2 * i] = make_float4(b.parameters[0].x, b.parameters[0].y, b.parameters[0].z, b.parameters[1].z);
         boxes[2 * i + 1] =
-            make_float4(b.parameters[1].x, b.parameters[1].y, b.parameters[1].z, bitsf(b.indexForNextBox.x));
+            make_float4(b.parameters[1].x, b.parameters[1].y, bitsf(b.nbPrimitives), bitsf(b.indexForNextBox.x));
         start[i] = b.startIndex;
     }
     if (!ok())
