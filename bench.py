@@ -65,9 +65,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
 
     torch = dist = None
-    if world > 1:
+    # SOLR_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, strip binding, pipelined gather)
+    # with a single rank: a 1-GPU box can then exercise it against RCCL
+    distributed = world > 1 or os.environ.get("SOLR_BENCH_FORCE_DIST") == "1"
+    if distributed:
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -84,13 +91,17 @@ def main():
     if args.graphics_level != 4:
         k.set_scene_info(graphicsLevel=args.graphics_level)
     hip.solr_hip_set_variant(args.variant)
-    if world > 1:
+    sg = None
+    if distributed:
+        if os.environ.get("SOLR_BENCH_NULL_STREAM") != "1":
+            # a stream of our own: the legacy default stream synchronises implicitly with others
+            torch.cuda.set_stream(torch.cuda.Stream())
         hip.solr_hip_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
         hip.solr_hip_set_strip(first_row, nb_rows)
-        strip = torch.zeros((nb_rows * W * 3,), dtype=torch.uint8, device="cuda")
-        hip.solr_hip_bind_device_bitmap(C.c_void_p(strip.data_ptr()))
-        slots = ([torch.zeros((rows_per_rank * W * 3,), dtype=torch.uint8, device="cuda") for _ in range(world)]
-                 if rank == 0 else None)
+        # in-order gather on the render stream unless SOLR_BENCH_PIPELINED=1 (see StripGather)
+        sg = solr.StripGather(dist, torch, W, H, rank, world, device="cuda",
+                              pipelined=os.environ.get("SOLR_BENCH_PIPELINED") == "1")
+        hip.solr_hip_bind_device_bitmap(C.c_void_p(sg.buffer(0).data_ptr()))
 
     # first frame through the full host protocol: uploads scene, materials, randoms
     k.L.SolRx_Render(0.0)
@@ -100,20 +111,36 @@ def main():
     objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
 
+    frame_no = [0]
+    rendered = [None, None]
+
     def frame():
+        if sg is None:
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+            return
+        # the renderer writes RGB8 straight into the strip buffer; then the single collective of the
+        # path: strips -> rank 0 (RCCL over xGMI), stream-ordered behind the kernel
+        i = frame_no[0]
+        frame_no[0] += 1
+        if i % 4 == 0:  # the host stays at most eight frames ahead of the GPU
+            j = (i // 4) % 2
+            if rendered[j] is not None:
+                rendered[j].synchronize()
+            rendered[j] = torch.cuda.Event()
+            rendered[j].record()
+        hip.solr_hip_bind_device_bitmap(C.c_void_p(sg.buffer(i).data_ptr()))
         hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
-        if world > 1:
-            # the single collective of the path: RGB8 strips to rank 0 (RCCL over xGMI)
-            solr.gather_strips(dist, torch, strip, rows_per_rank, W, H, rank, world, slots=slots, assemble=False)
+        sg.submit(i)
 
     def sync():
-        if world > 1:
+        if distributed:
+            sg.drain()
             torch.cuda.synchronize()
         else:
             hip.solr_hip_synchronize()
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
 
     # ---- ray census of this rank's strip (untimed; input-determined)
@@ -127,12 +154,14 @@ def main():
         frame()
     sync()
     hip.solr_hip_kernel_time(None, 1)
-    hip.solr_hip_enable_timing(1)
+    # event pairs cost launch gaps: every launch at N = 1, every fourth when frames are short (N > 1)
+    hip.solr_hip_enable_timing(4 if distributed else 1)
     barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
+    t_issued = time.perf_counter()
     sync()
     barrier()
     t1 = time.perf_counter()
@@ -143,7 +172,7 @@ def main():
     kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
 
     rays_total = rays_local
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed, float(rays_local), kernel_ms / max(launches.value, 1)], dtype=torch.float64,
                          device="cuda")
         tmax = t.clone()
@@ -157,8 +186,7 @@ def main():
         kernel_avg_ms = kernel_ms / max(launches.value, 1)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     mrays = rays_total * args.steps / elapsed / 1e6
@@ -184,6 +212,7 @@ def main():
                    "rays_per_frame": rays_total, "closest_hit_walks_rank0": int(counts[0]),
                    "shadow_walks_rank0": int(counts[1]), "lane_nodes": int(counts[2]), "lane_prim_tests": int(counts[3]),
                    "wave_nodes": int(counts[4]), "wave_prim_tests": int(counts[5]), "wave_walks": int(counts[6]) + int(counts[7]), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 2),
+                   "host_issue_ms_per_step_rank0": round((t_issued - t0) / args.steps * 1e3, 4),
                    "parallelism": "tile%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
@@ -194,7 +223,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(flat, si, ppi, eye, direction, angles, args.cpu_seconds)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -128,12 +128,19 @@ void solr_hip_render(const SceneInfo *sceneInfo, const vec4i *objects, const Pos
                      const float origin[3], const float direction[3], const float angles[4]);
 void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds);
 
-/* Kernel timing: when enabled every cudaRender/solr_hip_render brackets its
- * launches with HIP events on the engine's stream.  solr_hip_kernel_time
+/* Kernel timing: enable = n > 0 makes every n-th cudaRender/solr_hip_render bracket its
+ * launch with HIP events on the engine's stream (1: every launch; 0: off).  solr_hip_kernel_time
  * synchronises, returns the summed milliseconds of the renderer kernel and
  * writes the number of timed launches; reset != 0 clears both afterwards. */
 void solr_hip_enable_timing(int enable);
 double solr_hip_kernel_time(int *nbLaunches, int reset);
+
+/* Load-balance diagnostics: when enabled every render records, per 8x8 tile
+ * (one wavefront), the 100 MHz timestamps at which its wave started and ended.
+ * solr_hip_tile_clocks synchronises and copies {start, end} pairs of the last
+ * render in launch order (tile = ty * tilesX + tx); returns the number of tiles. */
+void solr_hip_enable_tile_clocks(int enable);
+int solr_hip_tile_clocks(unsigned long long *clocks, int capacityTiles);
 
 /* Renders the frame once with the counting variant of the kernel and returns
  * the number of box-tree traversals: counts[0] = closest-hit walks

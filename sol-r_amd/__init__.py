@@ -162,6 +162,9 @@ def _declare_hip(L):
     L.solr_hip_enable_timing.argtypes = [C.c_int]
     L.solr_hip_kernel_time.argtypes = [P(C.c_int), C.c_int]
     L.solr_hip_kernel_time.restype = C.c_double
+    L.solr_hip_enable_tile_clocks.argtypes = [C.c_int]
+    L.solr_hip_tile_clocks.argtypes = [C.c_void_p, C.c_int]
+    L.solr_hip_tile_clocks.restype = C.c_int
     L.solr_hip_set_variant.argtypes = [C.c_int]
     L.solr_hip_get_variant.restype = C.c_int
     L.solr_hip_memory_usage.argtypes = [P(C.c_ulonglong)]
@@ -433,6 +436,71 @@ def gather_strips(dist, torch, strip, rows_per_rank, width, height, rank, world,
     if rank != dst or not assemble:
         return None
     return torch.cat(slots)[: height * width * 3].reshape(height, width, 3)
+
+
+class StripGather:
+    """Pipelined assembly of the frame from the ranks' row strips.
+
+    ONE collective per frame - a gather of the RGB8 strips to `dst` (RCCL over xGMI with the nccl
+    backend, gloo on CPU) - issued asynchronously, so that it overlaps the rendering of the next
+    frame.  `depth` strip buffers alternate; buffer(i) hands out the buffer of frame i only after
+    the gather that last read it has completed (for nccl that wait is stream-ordered, the host
+    does not block).  On `dst` the receive slots are consecutive views of one (rows, width, 3)
+    tensor, so the assembled image needs no further copy.  Strips are padded to the common slot
+    size (strip_rows): the engine writes its rows at the start of the buffer.
+
+    pipelined=False issues the gather with blocking semantics on one buffer instead.  With the nccl
+    backend of this PyTorch that runs the collective in order on the CURRENT stream - no event hop
+    between streams - which on MI355X / ROCm 7 costs about 6 us of launch gaps per frame against two
+    hops of about 16 us each for the pipelined form (profiles/r1/dist_overhead.txt): the better
+    choice whenever a strip renders in less time than the hops cost, i.e. for the frames bench.py times."""
+
+    def __init__(self, dist, torch, width, height, rank, world, device="cpu", dst=0, depth=2, pipelined=True):
+        self.dist, self.torch = dist, torch
+        self.pipelined = pipelined
+        if not pipelined:
+            depth = 1
+        self.width, self.height, self.rank, self.world, self.dst, self.depth = width, height, rank, world, dst, depth
+        self.first_row, self.nb_rows, self.rows_per_rank = strip_rows(rank, world, height)
+        self.slot = self.rows_per_rank * width * 3
+        self.strips = [torch.zeros((self.slot,), dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.frames = self.lists = None
+        if rank == dst:
+            self.frames = [torch.zeros((world * self.slot,), dtype=torch.uint8, device=device) for _ in range(depth)]
+            self.lists = [[f[r * self.slot:(r + 1) * self.slot] for r in range(world)] for f in self.frames]
+        self.works = [None] * depth
+
+    def _wait(self, b):
+        if self.works[b] is not None:
+            self.works[b].wait()
+            self.works[b] = None
+
+    def buffer(self, i):
+        """strip buffer of frame i (flat uint8, slot bytes); safe to overwrite when this returns"""
+        b = i % self.depth
+        self._wait(b)
+        return self.strips[b]
+
+    def submit(self, i):
+        """start the gather of frame i's strip; returns immediately"""
+        b = i % self.depth
+        gather_list = self.lists[b] if self.rank == self.dst else None
+        if not self.pipelined:
+            self.dist.gather(self.strips[b], gather_list, dst=self.dst)
+            return
+        self.works[b] = self.dist.gather(self.strips[b], gather_list, dst=self.dst, async_op=True)
+
+    def image(self, i):
+        """the assembled (height, width, 3) image of frame i on `dst` (a view), None elsewhere"""
+        b = i % self.depth
+        self._wait(b)
+        if self.rank != self.dst:
+            return None
+        return self.frames[b][: self.height * self.width * 3].reshape(self.height, self.width, 3)
+
+    def drain(self):
+        for b in range(self.depth):
+            self._wait(b)
 
 
 from . import scenes  # noqa: E402,F401

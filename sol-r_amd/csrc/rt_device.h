@@ -946,7 +946,7 @@ SOLR_DEV bool stepGeneral(const Scene &S, const WalkRay &r, bool fastBoxes, floa
  *   - the wave's next node is one s_cselect on "mask != 0".
  * Hazards (gfx950): every SGPR a vector instruction reads here is written by the
  * scalar unit; v_cmpx results are only read back through s_mov from exec.
- * Fixed registers: s[64:87], v[122:127] (sub-registers of pairs cannot be named
+ * Fixed registers: s[64:87], v[58:63] (sub-registers of pairs cannot be named
  * through operands).  All scalar loads are drained before the statement ends.
  *
  * Returns the leaf (>= 0) with `entered` lanes and its primitive count, cur
@@ -974,25 +974,25 @@ SOLR_DEV PackedRay packRay(const WalkRay &r)
     "s_lshl_b32 s84, s84, 5\n"                                                                                         \
     "s_load_dwordx8 " OTHER_REGS ", %[base], s84\n"                                                                    \
     "s_add_i32 s86, %[cur], " SKIP "\n"                                                                                \
-    "v_pk_add_f32 v[122:123], " LOXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
-    "v_pk_add_f32 v[124:125], " HIXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
-    "v_pk_add_f32 v[126:127], " ZZ ", %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"                                              \
-    "v_pk_mul_f32 v[122:123], %[ixy], v[122:123]\n"                                                                    \
-    "v_pk_mul_f32 v[124:125], %[ixy], v[124:125]\n"                                                                    \
-    "v_pk_mul_f32 v[126:127], %[izz], v[126:127]\n"                                                                    \
-    "v_min_f32 %[t], v122, v124\n"                                                                                     \
-    "v_max_f32 v122, v122, v124\n"                                                                                     \
-    "v_min_f32 v124, v123, v125\n"                                                                                     \
-    "v_max_f32 v123, v123, v125\n"                                                                                     \
-    "v_min_f32 v125, v126, v127\n"                                                                                     \
-    "v_max_f32 v126, v126, v127\n"                                                                                     \
-    "v_max3_f32 %[t], %[t], v124, v125\n"                                                                              \
-    "v_min3_f32 v122, v122, v123, v126\n"                                                                              \
+    "v_pk_add_f32 v[58:59], " LOXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
+    "v_pk_add_f32 v[60:61], " HIXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
+    "v_pk_add_f32 v[62:63], " ZZ ", %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"                                              \
+    "v_pk_mul_f32 v[58:59], %[ixy], v[58:59]\n"                                                                    \
+    "v_pk_mul_f32 v[60:61], %[ixy], v[60:61]\n"                                                                    \
+    "v_pk_mul_f32 v[62:63], %[izz], v[62:63]\n"                                                                    \
+    "v_min_f32 %[t], v58, v60\n"                                                                                     \
+    "v_max_f32 v58, v58, v60\n"                                                                                     \
+    "v_min_f32 v60, v59, v61\n"                                                                                     \
+    "v_max_f32 v59, v59, v61\n"                                                                                     \
+    "v_min_f32 v61, v62, v63\n"                                                                                     \
+    "v_max_f32 v62, v62, v63\n"                                                                                     \
+    "v_max3_f32 %[t], %[t], v60, v61\n"                                                                              \
+    "v_min3_f32 v58, v58, v59, v62\n"                                                                              \
     "v_cmpx_eq_u32_e32 vcc, %[cur], %[cursor]\n"                                                                       \
     "v_mov_b32 %[cursor], s86\n"                                                                                       \
-    "v_cmpx_le_f32_e32 vcc, %[t], v122\n"                                                                              \
+    "v_cmpx_le_f32_e32 vcc, %[t], v58\n"                                                                              \
     "v_cmpx_lt_f32_e32 vcc, %[t], %[far]\n"                                                                            \
-    "v_cmpx_lt_f32_e32 vcc, 0, v122\n"                                                                                 \
+    "v_cmpx_lt_f32_e32 vcc, 0, v58\n"                                                                                 \
     "v_mov_b32 %[cursor], s85\n"                                                                                       \
     "s_mov_b64 s[82:83], exec\n"                                                                                       \
     "s_mov_b64 exec, s[80:81]\n"                                                                                       \
@@ -1039,8 +1039,8 @@ SOLR_DEV int advanceTidy(const Scene &S, const PackedRay &p, float farDistance, 
                  : [oxy] "v"(p.oxy), [ozz] "v"(p.ozz), [ixy] "v"(p.ixy), [izz] "v"(p.izz), [far] "v"(farDistance),
                    [base] "s"(base), [n] "s"(S.nbBoxes)
                  : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
-                   "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v122", "v123",
-                   "v124", "v125", "v126", "v127");
+                   "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v58", "v59",
+                   "v60", "v61", "v62", "v63");
     nbPrimitives = nb;
     entered = flag != 0;
     return leaf;

@@ -45,6 +45,7 @@ struct FrameArgs
     int tilesX;
     int fuseDefault;      /* 1: write the RGB bitmap from the renderer */
     int stackSlots;       /* colour-stack slots per lane in LDS */
+    unsigned long long *tileClock; /* diagnostics: {start, end} of every tile in 100 MHz ticks, or null */
 };
 
 #define TILE 8
@@ -72,6 +73,9 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     const SceneInfo &si = F.si;
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
+    unsigned long long clock0 = 0ull;
+    if (F.tileClock)
+        clock0 = __builtin_amdgcn_s_memrealtime();
     const int tx = tile % F.tilesX;
     const int ty = tile / F.tilesX;
     const int x = tx * TILE + (lane & (TILE - 1));
@@ -239,6 +243,11 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
         }
     }
 
+    if (F.tileClock && lane == 0)
+    {
+        F.tileClock[2 * tile] = clock0;
+        F.tileClock[2 * tile + 1] = __builtin_amdgcn_s_memrealtime();
+    }
     if (COUNT)
     {
         unsigned int vals[4] = {cnt.closest, cnt.shadow, cnt.boxes, cnt.prims};
@@ -434,14 +443,17 @@ struct Engine
     long nbRandoms = 0;
 
     /* per-pixel buffers of the strip */
-    DeviceBuffer pp, ids, bitmap, counters;
+    DeviceBuffer pp, ids, bitmap, counters, tileClock;
+    bool tileClocks = false; /* diagnostics, solr_hip_enable_tile_clocks */
+    int nbTilesTimed = 0;
     void *boundBitmap = nullptr;
     int width = 0, height = 0;       /* full image */
     int firstRow = 0, nbRows = 0;    /* strip; nbRows == 0 -> full frame */
     int allocW = 0, allocRows = 0;
 
     /* timing */
-    bool timing = false;
+    int timing = 0; /* 0 off, n: every n-th launch is bracketed with events */
+    unsigned timingTick = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double timedMs = 0.0;
     int timedLaunches = 0;
@@ -789,8 +801,16 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     const size_t ldsBytes = (size_t)F.stackSlots * 4 * WAVE * sizeof(float);
 
     const dim3 grid(F.tilesX * tilesY), block(WAVE);
+    if (g.tileClocks)
+    {
+        reserve(g.tileClock, (size_t)grid.x * 2 * sizeof(unsigned long long));
+        if (!ok())
+            return;
+        F.tileClock = (unsigned long long *)g.tileClock.ptr;
+        g.nbTilesTimed = (int)grid.x;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g.timing && !counting)
+    if (g.timing > 0 && !counting && (g.timingTick++ % (unsigned)g.timing) == 0)
     {
         HIPCHECK(hipEventCreate(&e0));
         HIPCHECK(hipEventCreate(&e1));
@@ -1010,7 +1030,7 @@ void finalize_scene(vec2i)
         (void)hipStreamSynchronize(g.stream);
     collectEvents();
     DeviceBuffer *all[] = {&g.geometry, &g.materials, &g.textures, &g.randoms, &g.lamps,
-                           &g.pp,       &g.ids,       &g.bitmap,   &g.counters};
+                           &g.pp,       &g.ids,       &g.bitmap,   &g.counters, &g.tileClock};
     for (DeviceBuffer *b : all)
         release(*b);
     if (g.ownStream && g.stream)
@@ -1379,7 +1399,25 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
 
 void solr_hip_enable_timing(int enable)
 {
-    g.timing = enable != 0;
+    g.timing = enable > 0 ? enable : 0;
+    g.timingTick = 0;
+}
+
+void solr_hip_enable_tile_clocks(int enable)
+{
+    g.tileClocks = enable != 0;
+}
+
+int solr_hip_tile_clocks(unsigned long long *clocks, int capacityTiles)
+{
+    if (!g.initialized || !g.tileClock.ptr || !clocks || capacityTiles <= 0)
+        return 0;
+    const int n = g.nbTilesTimed < capacityTiles ? g.nbTilesTimed : capacityTiles;
+    if (hipStreamSynchronize(g.stream) != hipSuccess ||
+        hipMemcpy(clocks, g.tileClock.ptr, (size_t)n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) !=
+            hipSuccess)
+        return 0;
+    return n;
 }
 
 double solr_hip_kernel_time(int *nbLaunches, int reset)
