@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py.  Never imported by the sol-r_amd package.
-PARITY UNPINNED - see solr_oracle.h.
+Parity status (pinned at image level against the reference's OpenCL renderer, not bit for bit): solr_oracle.h.
 """
 import ctypes as C
 import os
@@ -102,3 +102,51 @@ def render(flat, scene_info, pp_info, eye, direction, angles, first_row=0, nb_ro
 
 def max_threads():
     return lib().oracle_max_threads()
+
+
+# ---- oracle/_ref: the reference's OpenCL renderer (built by `make -C oracle ref` where /root/reference exists)
+REF_DIR = os.path.join(_HERE, "_ref")
+REF_LIB = os.path.join(REF_DIR, "libsolr_ref_opencl.so")
+REF_CODE_OBJECT = os.path.join(REF_DIR, "RayTracer_gfx950.co")
+
+
+def build_ref(reference="/root/reference"):
+    """Compiles the reference's RayTracer.cl for gfx950 and the OpenCL host runner into oracle/_ref/.
+    Returns False (and builds nothing) where the reference tree is absent, e.g. on the GPU box."""
+    if not os.path.exists(os.path.join(reference, "solr/engines/opencl/RayTracer.cl")):
+        return False
+    res = subprocess.run(["make", "-C", _HERE, "ref", "REFERENCE=" + reference], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("oracle/_ref build failed:\n" + res.stdout + res.stderr)
+    return True
+
+
+def have_ref():
+    return os.path.exists(REF_LIB) and os.path.exists(REF_CODE_OBJECT)
+
+
+def ref_render(flat, scene_info, pp_info, eye, direction, angles):
+    """One frame of the reference's OpenCL k_standardRenderer + k_default on the GPU (ref_opencl_runner.c).
+    Returns (pp (H, W, 8) float32, ids (H, W, 4) int32, bitmap (H, W, 3) uint8)."""
+    R = C.CDLL(REF_LIB)
+    R.solr_ref_opencl_render.restype = C.c_int
+    s = Scene(flat)
+    boxes, prims, lights, mats, rnd, _ = s.keep
+    w, h = scene_info.size_x, scene_info.size_y
+    pp = np.zeros((h, w, 8), np.float32)
+    ids = np.zeros((h, w, 4), np.int32)
+    rgb = np.zeros((h, w, 3), np.uint8)
+    if len(rnd) == 0:
+        rnd = np.zeros(16, np.float32)
+    eye, direction, angles = _f(eye), _f(direction), _f(angles)
+    log = C.create_string_buffer(4096)
+    vp = C.c_void_p
+    status = R.solr_ref_opencl_render(
+        REF_CODE_OBJECT.encode(), vp(boxes.ctypes.data), C.c_int(len(boxes)), vp(prims.ctypes.data),
+        C.c_int(len(prims)), vp(lights.ctypes.data), C.c_int(len(lights)), C.c_int(flat.nb_lamps),
+        vp(mats.ctypes.data), C.c_int(len(mats)), vp(rnd.ctypes.data), C.c_int(len(rnd)),
+        vp(C.addressof(scene_info)), vp(C.addressof(pp_info)), vp(eye.ctypes.data), vp(direction.ctypes.data),
+        vp(angles.ctypes.data), vp(pp.ctypes.data), vp(ids.ctypes.data), vp(rgb.ctypes.data), log, C.c_int(4096))
+    if status != 0:
+        raise RuntimeError("reference OpenCL renderer failed (%d): %s" % (status, log.value.decode(errors="replace")))
+    return pp, ids, rgb

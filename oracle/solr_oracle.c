@@ -1,8 +1,11 @@
 /*
  * solr_oracle.c - CPU restatement of Sol-R's per-pixel rendering path.
  *
- * TEST INFRASTRUCTURE ONLY (see solr_oracle.h).  PARITY UNPINNED: checked
- * against hand-derived known answers, not against reference outputs.
+ * TEST INFRASTRUCTURE ONLY (see solr_oracle.h).  Parity status: pinned at
+ * image level against the reference's OpenCL renderer run on the GPU
+ * (tests/test_reference_opencl.py) and, per function, against hand-derived
+ * known answers; not bit for bit against the CUDA engine it restates, which
+ * cannot be built here (solr_oracle.h).
  *
  * Every function cites the reference file:line it restates.  "ref:" paths are
  * relative to the reference tree, with

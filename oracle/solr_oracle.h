@@ -5,15 +5,23 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library, and only as the checker / the timed CPU baseline.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
- * for this path, its CPU engine does not compile
- *  and its CUDA engine cannot be built in this image without
- * writing stand-ins for the CUDA SDK headers and the cmake-generated
- * defines.h, which the build rules forbid.  This oracle is therefore a
- * line-by-line restatement of the reference's device code with IEEE fp32
- * semantics (no FMA contraction, correctly rounded / and sqrt, glibc libm for
- * pow/sin/cos/atan2/asin) that is checked against hand-derived known-answer
- * cases in tests/, not against outputs of the reference itself.
+ * PARITY STATUS - pinned at image level, not bit for bit.  The reference ships
+ * no tests, golden vectors or fixtures for this path; its
+ * CPU engine does not compile and its CUDA engine cannot be built
+ * in this image without writing stand-ins for the CUDA SDK headers and the
+ * cmake-generated defines.h, which the build rules forbid.  Its OpenCL engine
+ * keeps the same path in one self-contained file, and ROCm's clang compiles that
+ * file for gfx950 as it lies (oracle/Makefile, target `ref` -> oracle/_ref/):
+ * tests/test_reference_opencl.py runs the reference's own k_standardRenderer on
+ * the MI355X and checks this oracle against its output - same primitive on
+ * >= 99.95 % of the pixels, identical RGB8 on 94-100 %, float colour within 1e-5
+ * on 88-100 % depending on the scene; the rest is drift between the reference's
+ * two engines (listed in that test).  The CUDA engine, which is what this file
+ * restates line by line (IEEE fp32, no FMA contraction, correctly rounded / and
+ * sqrt, glibc libm for pow/sin/cos/atan2/asin), has no runnable form here, so
+ * the <= 1 ULP bar of the parity tests is a bar against this restatement; the
+ * unit behaviour of each function is additionally checked against hand-derived
+ * known answers (tests/test_oracle_known_answers.py).
  */
 #ifndef SOLR_ORACLE_H
 #define SOLR_ORACLE_H

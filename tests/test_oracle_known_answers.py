@@ -1,9 +1,10 @@
 """The oracle against hand-derived known answers.
 
-The reference ships no tests or golden vectors for this path, so the
-oracle's parity with the reference is UNPINNED; what can be pinned is that each restated
-function reproduces results that follow from the reference's formulas by hand.  Every
-expected value below is derived in the comment next to it from the cited reference lines.
+The reference ships no tests or golden vectors for this path.  Whole frames
+of the oracle are pinned against the reference's own OpenCL renderer in test_reference_opencl.py
+(GPU, image level); here each restated function is pinned, on CPU, to results that follow from the
+reference's formulas by hand.  Every expected value below is derived in the comment next to it from
+the cited reference lines.
 """
 import ctypes as C
 import importlib
