@@ -125,9 +125,11 @@ def have_ref():
     return os.path.exists(REF_LIB) and os.path.exists(REF_CODE_OBJECT)
 
 
-def ref_render(flat, scene_info, pp_info, eye, direction, angles):
+def ref_render(flat, scene_info, pp_info, eye, direction, angles, repeats=1, timing=None):
     """One frame of the reference's OpenCL k_standardRenderer + k_default on the GPU (ref_opencl_runner.c).
-    Returns (pp (H, W, 8) float32, ids (H, W, 4) int32, bitmap (H, W, 3) uint8)."""
+    Returns (pp (H, W, 8) float32, ids (H, W, 4) int32, bitmap (H, W, 3) uint8).  repeats > 1 launches the
+    renderer that many times and stores the mean kernel milliseconds (OpenCL events, first launch
+    excluded) in timing["renderer_ms"]."""
     R = C.CDLL(REF_LIB)
     R.solr_ref_opencl_render.restype = C.c_int
     s = Scene(flat)
@@ -140,13 +142,17 @@ def ref_render(flat, scene_info, pp_info, eye, direction, angles):
         rnd = np.zeros(16, np.float32)
     eye, direction, angles = _f(eye), _f(direction), _f(angles)
     log = C.create_string_buffer(4096)
+    ms = C.c_double(0.0)
     vp = C.c_void_p
     status = R.solr_ref_opencl_render(
         REF_CODE_OBJECT.encode(), vp(boxes.ctypes.data), C.c_int(len(boxes)), vp(prims.ctypes.data),
         C.c_int(len(prims)), vp(lights.ctypes.data), C.c_int(len(lights)), C.c_int(flat.nb_lamps),
         vp(mats.ctypes.data), C.c_int(len(mats)), vp(rnd.ctypes.data), C.c_int(len(rnd)),
         vp(C.addressof(scene_info)), vp(C.addressof(pp_info)), vp(eye.ctypes.data), vp(direction.ctypes.data),
-        vp(angles.ctypes.data), vp(pp.ctypes.data), vp(ids.ctypes.data), vp(rgb.ctypes.data), log, C.c_int(4096))
+        vp(angles.ctypes.data), vp(pp.ctypes.data), vp(ids.ctypes.data), vp(rgb.ctypes.data), C.c_int(repeats),
+        C.byref(ms), log, C.c_int(4096))
+    if timing is not None:
+        timing["renderer_ms"] = ms.value
     if status != 0:
         raise RuntimeError("reference OpenCL renderer failed (%d): %s" % (status, log.value.decode(errors="replace")))
     return pp, ids, rgb

@@ -93,7 +93,7 @@ int solr_ref_opencl_render(const char *codeObjectPath, const BoundingBox *boxes,
                            const Material *materials, int nbMaterials, const float *randoms, int nbRandoms,
                            const SceneInfo *sceneInfo, const PostProcessingInfo *ppInfo, const float eye[3],
                            const float direction[3], const float angles[4], float *ppOut, int *idsOut,
-                           unsigned char *rgbOut, char *log, int logCapacity)
+                           unsigned char *rgbOut, int repeats, double *rendererMs, char *log, int logCapacity)
 {
     int status = 0;
     cl_platform_id platforms[8];
@@ -140,7 +140,7 @@ int solr_ref_opencl_render(const char *codeObjectPath, const BoundingBox *boxes,
         FAIL(-4, "no OpenCL GPU device");
     ctx = clCreateContext(NULL, 1, &device, NULL, NULL, &err);
     CHECK(err, "clCreateContext");
-    queue = clCreateCommandQueue(ctx, device, 0, &err);
+    queue = clCreateCommandQueue(ctx, device, CL_QUEUE_PROFILING_ENABLE, &err);
     CHECK(err, "clCreateCommandQueue");
     {
         const unsigned char *bins[1] = {binary};
@@ -265,8 +265,23 @@ int solr_ref_opencl_render(const char *codeObjectPath, const BoundingBox *boxes,
         ARG(kRender, dPp);
         ARG(kRender, dIds);
         const size_t global[2] = {(size_t)W, (size_t)H}, local[2] = {8, 8};
-        CHECK(clEnqueueNDRangeKernel(queue, kRender, 2, NULL, global, local, 0, NULL, NULL),
-              "clEnqueueNDRangeKernel(k_standardRenderer)");
+        /* repeats > 1: the same pass again (pass 0 overwrites its outputs), timed with OpenCL events */
+        double ms = 0.0;
+        for (int rep = 0; rep < (repeats > 1 ? repeats : 1); ++rep)
+        {
+            cl_event ev = NULL;
+            CHECK(clEnqueueNDRangeKernel(queue, kRender, 2, NULL, global, local, 0, NULL, &ev),
+                  "clEnqueueNDRangeKernel(k_standardRenderer)");
+            CHECK(clWaitForEvents(1, &ev), "clWaitForEvents");
+            cl_ulong t0 = 0, t1 = 0;
+            clGetEventProfilingInfo(ev, CL_PROFILING_COMMAND_START, sizeof(t0), &t0, NULL);
+            clGetEventProfilingInfo(ev, CL_PROFILING_COMMAND_END, sizeof(t1), &t1, NULL);
+            clReleaseEvent(ev);
+            if (rep > 0 || repeats <= 1)
+                ms += (double)(t1 - t0) * 1e-6;
+        }
+        if (rendererMs)
+            *rendererMs = ms / (repeats > 1 ? repeats - 1 : 1);
         /* OpenCLKernel.cpp:884-889 */
         a = 0;
         ARG(kDefault, occupancy);
