@@ -153,6 +153,9 @@ def ref_render(flat, scene_info, pp_info, eye, direction, angles, repeats=1, tim
         C.byref(ms), log, C.c_int(4096))
     if timing is not None:
         timing["renderer_ms"] = ms.value
+        timing["log"] = log.value.decode(errors="replace")
+    if log.value and status == 0 and os.environ.get("SOLR_REF_VERBOSE"):
+        print("reference runner:", log.value.decode(errors="replace"))
     if status != 0:
         raise RuntimeError("reference OpenCL renderer failed (%d): %s" % (status, log.value.decode(errors="replace")))
     return pp, ids, rgb

@@ -1582,10 +1582,36 @@ SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 tar
 }
 
 /* per-lane column of the LDS colour stack: slot s, component c */
+/* Per-lane record kept in LDS behind the colour stack: path state that is touched once per
+ * bounce (or once per pixel) but would otherwise sit in VGPRs through both walks of every
+ * bounce.  At four waves per SIMD the kernel has 128 VGPRs; what does not fit goes to scratch,
+ * and scratch of 4096 resident waves does not fit the L2 either (measured: 0.3 GB read + 0.8 GB
+ * written per 1080p Cornell frame against 0.1 GB of framebuffer) - LDS is the cheaper home. */
+enum ColdField
+{
+    C_RRO = 0,        /* deferred reflection ray: origin, target (CRT:262-269) */
+    C_RRD = 3,
+    C_RRATIO = 6,
+    C_RRAYS = 7,      /* int */
+    C_RBLINN = 8,     /* recursiveBlinn */
+    C_LATEST = 11,    /* latestIntersection */
+    C_RAYLENGTH = 14,
+    C_REFRACTION = 15, /* initialRefraction */
+    C_LASTIT = 16,    /* int */
+    C_ID_X = 17,      /* primitiveXYId.x .z .w (int) */
+    C_ID_Z = 18,
+    C_ID_W = 19,
+    C_DOF = 20,
+    COLD_FIELDS = 22
+};
+
 struct ColorStack
 {
     float *base;  /* &lds[lane] */
     int stride;   /* floats between consecutive (slot, component) cells = block size */
+    int cold;     /* first cell of the cold record = 4 * stack slots */
+    SOLR_DEV float &coldf(int field) const { return base[(cold + field) * stride]; }
+    SOLR_DEV int &coldi(int field) const { return *(int *)&base[(cold + field) * stride]; }
     SOLR_DEV float &at(int slot, int c) const { return base[(slot * 4 + c) * stride]; }
     SOLR_DEV void set(int slot, v3 v) const
     {
@@ -1594,6 +1620,21 @@ struct ColorStack
         at(slot, 2) = v.z;
     }
     SOLR_DEV v3 get(int slot) const { return V(at(slot, 0), at(slot, 1), at(slot, 2)); }
+};
+
+/* three consecutive cold fields used like a v3 */
+struct V3Ref
+{
+    float &x, &y, &z;
+    SOLR_DEV V3Ref(const ColorStack &cs, int field) : x(cs.coldf(field)), y(cs.coldf(field + 1)), z(cs.coldf(field + 2)) {}
+    SOLR_DEV operator v3() const { return V(x, y, z); }
+    SOLR_DEV const V3Ref &operator=(const v3 &v) const
+    {
+        x = v.x;
+        y = v.y;
+        z = v.z;
+        return *this;
+    }
 };
 
 /* CRT:69-408.  Called by the whole wave; `active` lanes own a pixel.
@@ -1614,12 +1655,15 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
     int closestPrimitive = -1;
     bool carryon = true;
     v3 roO = rayO, roD = rayD;
-    float initialRefraction = 1.f;
+    float &initialRefraction = cs.coldf(C_REFRACTION);
+    initialRefraction = 1.f;
     int iteration = 0;     /* loop trip counter of phase 0, identical in every running lane */
-    int lastIteration = 0; /* per lane: trips it took part in = the reference's final `iteration` */
-    primitiveXYId.x = -1;
-    primitiveXYId.z = 0;
-    primitiveXYId.w = 0;
+    int &lastIteration = cs.coldi(C_LASTIT); /* per lane: trips it took part in = the reference's final `iteration` */
+    lastIteration = 0;
+    int &idX = cs.coldi(C_ID_X), &idZ = cs.coldi(C_ID_Z), &idW = cs.coldi(C_ID_W); /* primitiveXYId.x .z .w */
+    idX = -1;
+    idZ = 0;
+    idW = 0;
     int currentMaterialId = -2;
 
     int currentMaxIteration =
@@ -1634,17 +1678,25 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
         cs.at(s, 3) = 0.f;
     }
 
-    v3 recursiveBlinn = V(0.f, 0.f, 0.f);
+    const V3Ref recursiveBlinn(cs, C_RBLINN);
+    recursiveBlinn = V(0.f, 0.f, 0.f);
     float shadowIntensity = 0.f;
     v3 closestColor = V(0.f, 0.f, 0.f);
     v3 colorBox = V(0.f, 0.f, 0.f);
-    v3 latestIntersection = rayO;
-    float rayLength = 0.f;
-    depthOfField = si.viewDistance;
+    const V3Ref latestIntersection(cs, C_LATEST);
+    latestIntersection = rayO;
+    float &rayLength = cs.coldf(C_RAYLENGTH);
+    rayLength = 0.f;
+    float &dofCold = cs.coldf(C_DOF);
+    dofCold = si.viewDistance;
 
-    int reflectedRays = -1;
-    v3 rrO = V(0.f, 0.f, 0.f), rrD = V(0.f, 0.f, 0.f);
-    float reflectedRatio = 0.f;
+    int &reflectedRays = cs.coldi(C_RRAYS);
+    reflectedRays = -1;
+    const V3Ref rrO(cs, C_RRO), rrD(cs, C_RRD);
+    rrO = V(0.f, 0.f, 0.f);
+    rrD = V(0.f, 0.f, 0.f);
+    float &reflectedRatio = cs.coldf(C_RRATIO);
+    reflectedRatio = 0.f;
 
     /* FULL = false is the lean instantiation the host selects when neither
      * global illumination nor the box-debug view is requested */
@@ -1723,7 +1775,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                     cs.set(0, V(0.f, 0.f, 0.f));
                     cs.at(0, 3) = 1.f;
                     latestIntersection = closestIntersection;
-                    depthOfField = length(closestIntersection - tO); /* tO is the primary origin in trip 0 */
+                    dofCold = length(closestIntersection - tO); /* tO is the primary origin in trip 0 */
                     if (giEnabled && cm.innerIllumination.x == 0.f)
                     {
                         int t = (index + si.pathTracingIteration * 100 + si.timestamp) % (MAX_BITMAP_SIZE - 3);
@@ -1738,7 +1790,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                         pathTracingRatio = (1.f - attributes.y) * fabsf(cos_theta);
                         useGlobalIllumination = true;
                     }
-                    primitiveXYId.x = asint(primRow(S, cp, ROW_P1_INDEX).w);
+                    idX = asint(primRow(S, cp, ROW_P1_INDEX).w);
                 }
             }
         }
@@ -1794,7 +1846,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                 v3 colorIt = shaded;
                 float contribution;
                 v3 reflectedTarget = V(0.f, 0.f, 0.f);
-                primitiveXYId.z = (int)((float)primitiveXYId.z + cm.innerIllumination.x * 256);
+                idZ = (int)((float)idZ + cm.innerIllumination.x * 256);
 
                 float segmentLength = length(closestIntersection - latestIntersection);
                 latestIntersection = closestIntersection;
@@ -1871,7 +1923,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                 {
                     c = skyboxMapping<FEAT>(S, si, roO, roD);
                     float rad = c.x + c.y + c.z;
-                    primitiveXYId.z = (int)((float)primitiveXYId.z + ((rad > 2.5f) ? rad * 256.f : 0.f));
+                    idZ = (int)((float)idZ + ((rad > 2.5f) ? rad * 256.f : 0.f));
                 }
                 else if (si.gradientBackground)
                 {
@@ -1899,7 +1951,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                 cs.at(reflectedRays, 0) += shaded.x * reflectedRatio;
                 cs.at(reflectedRays, 1) += shaded.y * reflectedRatio;
                 cs.at(reflectedRays, 2) += shaded.z * reflectedRatio;
-                primitiveXYId.w = (int)(shadowIntensity * 255);
+                idW = (int)(shadowIntensity * 255);
             }
             if (!giPass)
                 break;
@@ -1948,10 +2000,11 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
             intersectionColor = cs.get(0);
 
         float D1 = si.viewDistance * 0.95f;
-        if (si.atmosphericEffect == aeFog && depthOfField > D1)
+        const float dofNow = dofCold;
+        if (si.atmosphericEffect == aeFog && dofNow > D1)
         {
             float D2 = si.viewDistance * 0.05f;
-            float a = depthOfField - D1;
+            float a = dofNow - D1;
             float b = 1.f - (a / D2);
             intersectionColor.x = intersectionColor.x * b + si.backgroundColor.x * (1.f - b);
             intersectionColor.y = intersectionColor.y * b + si.backgroundColor.y * (1.f - b);
@@ -1962,6 +2015,10 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
         intersectionColor.y -= colorBox.y;
         intersectionColor.z -= colorBox.z;
     }
+    depthOfField = dofCold;
+    primitiveXYId.x = idX;
+    primitiveXYId.z = idZ;
+    primitiveXYId.w = idW;
     return intersectionColor;
 }
 

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     ColorStack cs;
     cs.base = ldsStack + lane;
     cs.stride = WAVE;
+    cs.cold = 4 * F.stackSlots;
 
     Counters cnt = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 
@@ -798,7 +799,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     maxIt = maxIt > NB_MAX_ITERATIONS ? NB_MAX_ITERATIONS : maxIt;
     maxIt = maxIt < 1 ? 1 : maxIt;
     F.stackSlots = maxIt + 1;
-    const size_t ldsBytes = (size_t)F.stackSlots * 4 * WAVE * sizeof(float);
+    const size_t ldsBytes = ((size_t)F.stackSlots * 4 + COLD_FIELDS) * WAVE * sizeof(float);
 
     const dim3 grid(F.tilesX * tilesY), block(WAVE);
     if (g.tileClocks)

@@ -55,7 +55,7 @@ def add_room(k, rng, center=(0.0, 15000.0, 0.0), half=(20000.0, 20000.0, 20000.0
     return ids
 
 
-def cornell(k, width=512, height=512, iterations=1, extra_spheres=16, glass=2, seed=2017, **scene_info):
+def cornell(k, width=512, height=512, iterations=1, extra_spheres=16, glass=2, seed=2017, room=True, **scene_info):
     """BASELINE configs[0]/[1]: Cornell box, about 30 primitives (spheres + planes).
 
     Four reflective spheres of radius 2000 at (+-2200, 0, 0), (0, +-2200, 0)
@@ -79,7 +79,8 @@ def cornell(k, width=512, height=512, iterations=1, extra_spheres=16, glass=2, s
         m = k.add_material(0.9, 0.95, 1.0, reflection=1.0, refraction=1.1, transparency=0.7, specValue=1.0,
                            specPower=200.0)
         k.add_primitive(ptSphere, (-5000.0 + 10000.0 * i, 3500.0, -6000.0), size=(1200.0, 0, 0), material=m)
-    add_room(k, rng)
+    if room:
+        add_room(k, rng)
     add_light(k)
     k.compact_boxes(True)
     k.set_camera((0.0, 0.0, -15000.0))

@@ -10,9 +10,14 @@ is at image level, with the tolerances written below, not bit for bit.  Known dr
 compensated here: it jitters the primary ray on every pass (RayTracer.cl:2526-2527; undone by moving
 the look-at point, exact only for an unrotated camera), it computes in float4 with fused dot products
 (1-ULP noise everywhere, and different outcomes where a hit sits on an epsilon: silhouettes), it
-handles a zero direction component differently (off-axis camera), and its transparent-shadow term is
-weaker by 1-3 % (scenes without glass).  What the figures below pin: which primitive every pixel
-sees, the depth, and the shaded colour through diffuse/specular/shadow/reflection passes.
+handles a zero direction component differently (off-axis camera), its transparent-shadow term is
+weaker by 1-3 % (scenes without glass), and its plane test leaves the .w lanes of the float4 normal
+and hit point unwritten (RayTracer.cl:1151-1290 assigns .x .y .z only) while its float4 dot products
+read them: the shading of planes depends on what the register held before and changes from run to
+run, in whole 8x8 work-groups at a time.  Colour is therefore compared on plane-free scenes; the
+full Cornell room is compared, loosely, on the primitive every pixel sees.  What the
+figures below pin: visibility (box walk + every intersection routine, planes included), first-hit
+depth, and the shaded colour through diffuse/specular/shadow/reflection passes.
 """
 import importlib
 import os
@@ -58,8 +63,12 @@ def _agreement(pp, ids, rgb, rpp, rids, rrgb):
 
 # scene, minimum fraction of pixels: same primitive, identical RGB8, RGB8 within 8 levels, float colour within 1e-5
 CASES = [
-    (("cornell", dict(width=256, height=192, iterations=1, glass=0)), 0.9995, 0.985, 0.993, 0.96),
-    (("cornell", dict(width=256, height=192, iterations=3, glass=0)), 0.9995, 0.94, 0.955, 0.90),
+    (("cornell", dict(width=256, height=192, iterations=1, glass=0, room=False)), 0.9995, 0.985, 0.99, 0.96),
+    (("cornell", dict(width=256, height=192, iterations=3, glass=0, room=False)), 0.9995, 0.975, 0.99, 0.95),
+    # with the room: visibility only, and loosely - the garbage .w of a plane hit also enters the hit
+    # distance (float4 length), so a few per cent of the wall pixels can lose to a farther primitive
+    # (99.998 % equal on a clean device, 97.5 % measured after other kernels have run)
+    (("cornell", dict(width=256, height=192, iterations=1, glass=0)), 0.95, 0.0, 0.0, 0.0),
     (("height_field", dict(n=24, width=128, height=96)), 0.9995, 0.985, 0.99, 0.985),
     (("triangles_only", dict(width=80, height=64)), 0.999, 0.999, 0.999, 0.999),
     (("sticks", dict(width=80, height=64)), 0.99, 0.96, 0.965, 0.85),
@@ -87,7 +96,8 @@ def test_oracle_reproduces_the_reference_renderer(solr, ref, case):
     assert res["rgb_identical"] >= min_rgb, res
     assert res["rgb_within_8"] >= min_rgb8, res
     assert res["colour_within_1e-5"] >= min_colour, res
-    assert res["colour_median_rel"] <= 1e-5, res
+    if min_colour > 0.0:
+        assert res["colour_median_rel"] <= 1e-5, res
     # first-hit depth: the OpenCL engine measures it from the LAST ray origin of the path and for every
     # pixel (RayTracer.cl:2411-2417), the CUDA engine from the eye and only where something was hit
     # (CudaRayTracer.cu:107,155): comparable on single-bounce frames only
@@ -99,10 +109,10 @@ def test_engine_reproduces_the_reference_renderer(solr, ref, have_gpu):
     """The shipped HIP path against the reference renderer directly, no oracle in between."""
     assert have_gpu
     from helpers import gpu_frame
-    spec = ("cornell", dict(width=256, height=192, iterations=3, glass=0))
+    spec = ("cornell", dict(width=256, height=192, iterations=3, glass=0, room=False))
     k = _build(solr, spec, "hip")
     rpp, rids, rrgb = _reference_frame(ref, k)   # before the engine advances its pass counter
     gpp, gids, grgb = gpu_frame(k)
     k.check(0, "render")
     res = _agreement(gpp, gids, grgb, rpp, rids, rrgb)
-    assert res["ids_equal"] >= 0.9995 and res["rgb_identical"] >= 0.94 and res["colour_median_rel"] <= 1e-5, res
+    assert res["ids_equal"] >= 0.9995 and res["rgb_identical"] >= 0.975 and res["colour_median_rel"] <= 1e-5, res

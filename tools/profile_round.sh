@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collects the measurements a round commits under profiles/<tag>/ (run on the GPU box from the repo root):
+#   bash tools/profile_round.sh r1 [scene]
+# 1. bench.py with its defaults (incl. cpu_baseline)        -> bench.json
+# 2. rocprofv3 --kernel-trace --stats of the same command    -> kernel_stats.csv
+# 3. rocprofv3 --pmc, separate passes (SQ counters; FETCH_SIZE; WRITE_SIZE) -> pmc_*.csv
+TAG=${1:-r1}; SCENE=${2:-cornell}
+ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+python bench.py --scene $SCENE > $OUT/bench_$SCENE.json 2> $OUT/bench_$SCENE.err; tail -1 $OUT/bench_$SCENE.json | cut -c1-400
+CMD="python3 $ROOT/bench.py --scene $SCENE --steps 10 --warmup 2 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$SCENE -o trace -- $CMD > $OUT/trace_$SCENE.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_BUSY_CYCLES \
+    --output-format csv -d $OUT/pmc_sq_$SCENE -o pmc -- $CMD > $OUT/pmc_sq_$SCENE.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$SCENE -o pmc -- $CMD > $OUT/pmc_fetch_$SCENE.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$SCENE -o pmc -- $CMD > $OUT/pmc_write_$SCENE.log 2>&1
+cd $ROOT
+find $OUT -name "*.csv" | head -20
