@@ -1602,7 +1602,9 @@ enum ColdField
     C_ID_Z = 18,
     C_ID_W = 19,
     C_DOF = 20,
-    COLD_FIELDS = 22
+    C_ROO = 21,       /* the bounce loop's current ray: origin, target */
+    C_ROD = 24,
+    COLD_FIELDS = 27
 };
 
 struct ColorStack
@@ -1654,7 +1656,9 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
     v3 normal = V(0.f, 0.f, 0.f);
     int closestPrimitive = -1;
     bool carryon = true;
-    v3 roO = rayO, roD = rayD;
+    const V3Ref roO(cs, C_ROO), roD(cs, C_ROD);
+    roO = rayO;
+    roD = rayD;
     float &initialRefraction = cs.coldf(C_REFRACTION);
     initialRefraction = 1.f;
     int iteration = 0;     /* loop trip counter of phase 0, identical in every running lane */
@@ -1670,7 +1674,9 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
         (si.graphicsLevel < glReflectionsAndRefractions) ? 1 : si.nbRayIterations + si.pathTracingIteration;
     currentMaxIteration = (currentMaxIteration > NB_MAX_ITERATIONS) ? NB_MAX_ITERATIONS : currentMaxIteration;
 
-    for (int s = 0; s <= currentMaxIteration; ++s)
+    /* slots 0 .. currentMaxIteration-1 are the ones ever written or read (the reference's array
+     * has one more, CRT:92) */
+    for (int s = 0; s < (currentMaxIteration > 1 ? currentMaxIteration : 1); ++s)
     {
         cs.at(s, 0) = 0.f;
         cs.at(s, 1) = 0.f;

@@ -798,7 +798,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                     : sceneInfo.nbRayIterations + sceneInfo.pathTracingIteration;
     maxIt = maxIt > NB_MAX_ITERATIONS ? NB_MAX_ITERATIONS : maxIt;
     maxIt = maxIt < 1 ? 1 : maxIt;
-    F.stackSlots = maxIt + 1;
+    F.stackSlots = maxIt;
     const size_t ldsBytes = ((size_t)F.stackSlots * 4 + COLD_FIELDS) * WAVE * sizeof(float);
 
     const dim3 grid(F.tilesX * tilesY), block(WAVE);
