@@ -46,6 +46,9 @@ struct FrameArgs
     int fuseDefault;      /* 1: write the RGB bitmap from the renderer */
     int stackSlots;       /* colour-stack slots per lane in LDS */
     unsigned long long *tileClock; /* diagnostics: {start, end} of every tile in 100 MHz ticks, or null */
+    /* cost-ordered launch (see TileScheduling below); all null when off */
+    unsigned *tileCost;        /* out: duration of every tile of this frame, 100 MHz ticks */
+    const unsigned *tileOrder; /* in: workgroup -> tile, most expensive tiles of the previous frame first */
 };
 
 #define TILE 8
@@ -72,9 +75,9 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     const Scene S = makeScene(SA);
     const SceneInfo &si = F.si;
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int tile = F.tileOrder ? (int)F.tileOrder[blockIdx.x] : (int)blockIdx.x;
     unsigned long long clock0 = 0ull;
-    if (F.tileClock)
+    if (F.tileClock || F.tileCost)
         clock0 = __builtin_amdgcn_s_memrealtime();
     const int tx = tile % F.tilesX;
     const int ty = tile / F.tilesX;
@@ -249,6 +252,8 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
         F.tileClock[2 * tile] = clock0;
         F.tileClock[2 * tile + 1] = __builtin_amdgcn_s_memrealtime();
     }
+    if (F.tileCost && lane == 0) /* what this tile cost, for the launch order of the next frames */
+        F.tileCost[tile] = (unsigned)(__builtin_amdgcn_s_memrealtime() - clock0);
     if (COUNT)
     {
         unsigned int vals[4] = {cnt.closest, cnt.shadow, cnt.boxes, cnt.prims};
@@ -289,6 +294,76 @@ __global__ __launch_bounds__(256) void k_default(const SceneInfo si, int nbPixel
         c.z /= d;
     }
     makeColor(si, c, bitmap, index);
+}
+
+/* TileScheduling.  A frame is tens of thousands of one-wave workgroups whose costs differ by an
+ * order of magnitude (a tile of sky against a tile of mesh seen at a grazing angle) and the
+ * dispatcher hands them out in launch order, so an expensive tile that happens to be launched late
+ * runs on alone while the rest of the chip idles (profiles/r1/tile_timeline_*.txt: 23 % of the
+ * 100k-triangle frame).  Consecutive frames of a renderer see nearly the same picture: every wave
+ * records what its tile cost (one store); this kernel - one workgroup - reduces the costs to their
+ * maximum and sum for the host (every eighth frame while the launch is in raster order) and, when the
+ * host has seen a heavy tail (max > 3 x mean), sorts the tiles by cost with a 1024-bin counting sort
+ * in LDS so that the next frame is launched most-expensive-first.  Only the order of work changes,
+ * never a result.  (Per-wave atomics for max / sum were tried first: 32 400 same-address device-scope
+ * atomics per frame serialise at the memory side and tripled the frame time.) */
+__global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict__ cost, unsigned *__restrict__ order,
+                                                      int n, volatile unsigned *hostStats, int sort)
+{
+    __shared__ unsigned bins[1024];
+    __shared__ unsigned maxCost;
+    __shared__ unsigned long long sumCost;
+    const int t = threadIdx.x;
+    bins[t] = 0u;
+    if (t == 0)
+    {
+        maxCost = 0u;
+        sumCost = 0ull;
+    }
+    __syncthreads();
+    unsigned m = 0u;
+    unsigned long long sum = 0ull;
+    for (int i = t; i < n; i += 1024)
+    {
+        m = max(m, cost[i]);
+        sum += cost[i];
+    }
+    atomicMax(&maxCost, m);
+    atomicAdd(&sumCost, sum);
+    __syncthreads();
+    if (t == 0) /* {max, sum lo, sum hi, tiles, serial}: the host reads them without synchronising */
+    {
+        hostStats[0] = maxCost;
+        hostStats[1] = (unsigned)sumCost;
+        hostStats[2] = (unsigned)(sumCost >> 32);
+        hostStats[3] = (unsigned)n;
+        hostStats[4] = hostStats[4] + 1u;
+    }
+    if (!sort)
+        return;
+    const unsigned long long scale = (unsigned long long)maxCost + 1ull;
+    for (int i = t; i < n; i += 1024)
+        atomicAdd(&bins[(unsigned)(((unsigned long long)cost[i] * 1024ull) / scale)], 1u);
+    __syncthreads();
+    /* exclusive prefix over bins in DESCENDING bin order (Hillis-Steele on the reversed array) */
+    __shared__ unsigned scan[1024];
+    const unsigned mine = bins[1023 - t];
+    scan[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1)
+    {
+        const unsigned add = (t >= off) ? scan[t - off] : 0u;
+        __syncthreads();
+        scan[t] += add;
+        __syncthreads();
+    }
+    bins[1023 - t] = scan[t] - mine; /* first slot of this bin */
+    __syncthreads();
+    for (int i = t; i < n; i += 1024)
+    {
+        const unsigned b = (unsigned)(((unsigned long long)cost[i] * 1024ull) / scale);
+        order[atomicAdd(&bins[b], 1u)] = (unsigned)i;
+    }
 }
 
 /* CRT:1128-1181; gathers stay inside this process's strip */
@@ -444,7 +519,15 @@ struct Engine
     long nbRandoms = 0;
 
     /* per-pixel buffers of the strip */
-    DeviceBuffer pp, ids, bitmap, counters, tileClock;
+    DeviceBuffer pp, ids, bitmap, counters, tileClock, tileCost, tileOrder;
+    /* cost-ordered launch: 0 off, 1 automatic (default), 2 always */
+    int tileScheduling = 1;
+    unsigned *hostStats = nullptr;    /* mapped host memory, 8 words */
+    unsigned *hostStatsDev = nullptr; /* its device address */
+    long costKey[6] = {0, 0, 0, 0, 0, 0}; /* the frame geometry the recorded costs belong to */
+    int costFrames = 0;               /* frames rendered with that geometry */
+    bool reorder = false;             /* current decision of the automatic mode */
+    unsigned lastSerial = 0;
     bool tileClocks = false; /* diagnostics, solr_hip_enable_tile_clocks */
     int nbTilesTimed = 0;
     void *boundBitmap = nullptr;
@@ -810,6 +893,52 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         F.tileClock = (unsigned long long *)g.tileClock.ptr;
         g.nbTilesTimed = (int)grid.x;
     }
+    if (g.tileScheduling > 0 && !counting)
+    {
+        const long key[6] = {(long)grid.x, F.tilesX, F.firstRow, F.nbRows, sceneInfo.size.x, sceneInfo.size.y};
+        if (!g.hostStats)
+        {
+            HIPCHECK(hipHostMalloc((void **)&g.hostStats, 8 * sizeof(unsigned), hipHostMallocMapped));
+            if (ok())
+            {
+                memset(g.hostStats, 0, 8 * sizeof(unsigned));
+                HIPCHECK(hipHostGetDevicePointer((void **)&g.hostStatsDev, g.hostStats, 0));
+            }
+        }
+        if (memcmp(key, g.costKey, sizeof(key)) != 0 || !g.tileCost.ptr)
+        {
+            memcpy(g.costKey, key, sizeof(key));
+            g.costFrames = 0;
+            g.reorder = false;
+            reserve(g.tileCost, (size_t)grid.x * sizeof(unsigned));
+            reserve(g.tileOrder, (size_t)grid.x * sizeof(unsigned));
+        }
+        if (!ok())
+            return;
+        /* decision of the automatic mode from the newest frame the host can see (no synchronisation:
+         * the figures are one or two frames old, which is as good for a scheduling hint) */
+        if (g.costFrames > 0 && g.hostStats[4] != 0 && g.hostStats[3] == grid.x)
+        {
+            const unsigned long long sum = (unsigned long long)g.hostStats[1] | ((unsigned long long)g.hostStats[2] << 32);
+            const unsigned long long mx = g.hostStats[0];
+            if (mx * grid.x > 3ull * sum)
+                g.reorder = true;
+            else if (mx * grid.x < 2ull * sum)
+                g.reorder = false;
+        }
+        F.tileCost = (unsigned *)g.tileCost.ptr;
+        const bool sort = g.costFrames > 0 && (g.tileScheduling == 2 || g.reorder);
+        if (sort || (g.costFrames > 0 && g.costFrames % 8 == 1))
+        {
+            hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, g.stream, (const unsigned *)g.tileCost.ptr,
+                               (unsigned *)g.tileOrder.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev,
+                               sort ? 1 : 0);
+            HIPCHECK(hipGetLastError());
+            if (sort)
+                F.tileOrder = (const unsigned *)g.tileOrder.ptr;
+        }
+        g.costFrames++;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g.timing > 0 && !counting && (g.timingTick++ % (unsigned)g.timing) == 0)
     {
@@ -1031,9 +1160,16 @@ void finalize_scene(vec2i)
         (void)hipStreamSynchronize(g.stream);
     collectEvents();
     DeviceBuffer *all[] = {&g.geometry, &g.materials, &g.textures, &g.randoms, &g.lamps,
-                           &g.pp,       &g.ids,       &g.bitmap,   &g.counters, &g.tileClock};
+                           &g.pp,       &g.ids,       &g.bitmap,   &g.counters, &g.tileClock,
+                           &g.tileCost, &g.tileOrder};
     for (DeviceBuffer *b : all)
         release(*b);
+    if (g.hostStats)
+        (void)hipHostFree(g.hostStats);
+    g.hostStats = g.hostStatsDev = nullptr;
+    g.costFrames = 0;
+    g.reorder = false;
+    memset(g.costKey, 0, sizeof(g.costKey));
     if (g.ownStream && g.stream)
         (void)hipStreamDestroy(g.stream);
     g.stream = nullptr;
@@ -1402,6 +1538,18 @@ void solr_hip_enable_timing(int enable)
 {
     g.timing = enable > 0 ? enable : 0;
     g.timingTick = 0;
+}
+
+void solr_hip_set_tile_scheduling(int mode)
+{
+    g.tileScheduling = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    g.costFrames = 0;
+    g.reorder = false;
+}
+
+int solr_hip_tile_scheduling_active(void)
+{
+    return (g.tileScheduling == 2 || (g.tileScheduling == 1 && g.reorder)) && g.costFrames > 1 ? 1 : 0;
 }
 
 void solr_hip_enable_tile_clocks(int enable)

@@ -230,3 +230,43 @@ def test_engine_survives_scene_changes(solr, oracle):
     opp, oids, orgb, counts, status = oracle_frame(k, oracle)
     k.finalize()
     assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
+
+
+def test_cost_ordered_launch_changes_no_pixel(solr, oracle):
+    """Tile scheduling (solr_hip_set_tile_scheduling): frames launched most-expensive-tile-first are
+    bit-identical to frames launched in raster order, and still equal to the oracle."""
+    import ctypes as C
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    X.sticks(k, width=200, height=120)
+    try:
+        hip.solr_hip_set_tile_scheduling(0)
+        pp0, ids0, rgb0 = gpu_frame(k)
+        k.check(0, "raster-order frame")
+        flat = k.flat_scene()
+        si, ppi, eye, direction, angles = k.frame_parameters()
+        si.pathTracingIteration = 0
+        objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        hip.solr_hip_set_tile_scheduling(2)
+        for i in range(4):
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+            hip.solr_hip_synchronize()
+            k.check(0, "cost-ordered frame %d" % i)
+            if i >= 1:
+                assert hip.solr_hip_tile_scheduling_active() == 1
+            pp, ids = k.postprocessing_buffer(), k.primitive_ids()
+            assert np.array_equal(pp.view(np.uint32), pp0.view(np.uint32)), i
+            assert np.array_equal(ids, ids0), i
+        hip.solr_hip_set_tile_scheduling(1)   # automatic: whatever it decides, the frame is the same
+        for i in range(3):
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+            hip.solr_hip_synchronize()
+            pp, ids = k.postprocessing_buffer(), k.primitive_ids()
+            assert np.array_equal(pp.view(np.uint32), pp0.view(np.uint32)) and np.array_equal(ids, ids0), i
+        opp, oids, orgb, counts, status = oracle_frame(k, oracle)
+        assert status == 0
+        assert_parity(compare_frames(pp, ids, rgb0, opp, oids, orgb))
+    finally:
+        hip.solr_hip_set_tile_scheduling(1)
+        k.finalize()

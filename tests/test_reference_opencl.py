@@ -14,8 +14,10 @@ handles a zero direction component differently (off-axis camera), its transparen
 weaker by 1-3 % (scenes without glass), and its plane test leaves the .w lanes of the float4 normal
 and hit point unwritten (RayTracer.cl:1151-1290 assigns .x .y .z only) while its float4 dot products
 read them: the shading of planes depends on what the register held before and changes from run to
-run, in whole 8x8 work-groups at a time.  Colour is therefore compared on plane-free scenes; the
-full Cornell room is compared, loosely, on the primitive every pixel sees.  What the
+run, in whole 8x8 work-groups at a time, and through the float4 length of the hit distance even
+which primitive wins (a clean device gives 99.998 % equal ids and 98.9 % identical RGB8 on the full
+Cornell room, a device other kernels have run on 94-98 % and 74-95 %).  The pin is therefore taken
+on plane-free scenes.  What the
 figures below pin: visibility (box walk + every intersection routine, planes included), first-hit
 depth, and the shaded colour through diffuse/specular/shadow/reflection passes.
 """
@@ -65,10 +67,6 @@ def _agreement(pp, ids, rgb, rpp, rids, rrgb):
 CASES = [
     (("cornell", dict(width=256, height=192, iterations=1, glass=0, room=False)), 0.9995, 0.985, 0.99, 0.96),
     (("cornell", dict(width=256, height=192, iterations=3, glass=0, room=False)), 0.9995, 0.975, 0.99, 0.95),
-    # with the room: visibility only, and loosely - the garbage .w of a plane hit also enters the hit
-    # distance (float4 length), so a few per cent of the wall pixels can lose to a farther primitive
-    # (99.998 % equal on a clean device, 97.5 % measured after other kernels have run)
-    (("cornell", dict(width=256, height=192, iterations=1, glass=0)), 0.95, 0.0, 0.0, 0.0),
     (("height_field", dict(n=24, width=128, height=96)), 0.9995, 0.985, 0.99, 0.985),
     (("triangles_only", dict(width=80, height=64)), 0.999, 0.999, 0.999, 0.999),
     (("sticks", dict(width=80, height=64)), 0.99, 0.96, 0.965, 0.85),
@@ -96,8 +94,7 @@ def test_oracle_reproduces_the_reference_renderer(solr, ref, case):
     assert res["rgb_identical"] >= min_rgb, res
     assert res["rgb_within_8"] >= min_rgb8, res
     assert res["colour_within_1e-5"] >= min_colour, res
-    if min_colour > 0.0:
-        assert res["colour_median_rel"] <= 1e-5, res
+    assert res["colour_median_rel"] <= 1e-5, res
     # first-hit depth: the OpenCL engine measures it from the LAST ray origin of the path and for every
     # pixel (RayTracer.cl:2411-2417), the CUDA engine from the eye and only where something was hit
     # (CudaRayTracer.cu:107,155): comparable on single-bounce frames only
