@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--scene", default="cornell", choices=["cornell", "height_field", "molecule"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--graphics-level", type=int, default=4, help="experiments only; the metric is quoted at 4 (glFull)")
+    ap.add_argument("--tile-scheduling", type=int, default=1, help="0 raster order, 1 automatic (default), 2 cost order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -91,6 +92,7 @@ def main():
     if args.graphics_level != 4:
         k.set_scene_info(graphicsLevel=args.graphics_level)
     hip.solr_hip_set_variant(args.variant)
+    hip.solr_hip_set_tile_scheduling(args.tile_scheduling)
     sg = None
     if distributed:
         if os.environ.get("SOLR_BENCH_NULL_STREAM") != "1":
@@ -213,6 +215,7 @@ def main():
                    "shadow_walks_rank0": int(counts[1]), "lane_nodes": int(counts[2]), "lane_prim_tests": int(counts[3]),
                    "wave_nodes": int(counts[4]), "wave_prim_tests": int(counts[5]), "wave_walks": int(counts[6]) + int(counts[7]), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 2),
                    "host_issue_ms_per_step_rank0": round((t_issued - t0) / args.steps * 1e3, 4),
+                   "cost_ordered_launch_rank0": bool(hip.solr_hip_tile_scheduling_active()),
                    "parallelism": "tile%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,

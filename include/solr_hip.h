@@ -135,9 +135,9 @@ void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYI
 void solr_hip_enable_timing(int enable);
 double solr_hip_kernel_time(int *nbLaunches, int reset);
 
-/* Cost-ordered launch.  Every wave records what its 8x8 tile cost; when the previous frame of the same
- * geometry had a heavy tail (its most expensive tile > 3 x the mean) the next frame is launched
- * most-expensive-first (one small sorting kernel ahead of the renderer).  Changes the order of work
+/* Cost-ordered launch.  Every wave records what its 8x8 tile cost; when recent frames of the same
+ * geometry had a heavy tail (the most expensive tile > 2 x the mean) the following frames are launched
+ * most-expensive-first (a one-workgroup sorting kernel every eighth frame).  Changes the order of work
  * only.  mode 0: off, 1: automatic (default), 2: always.  solr_hip_tile_scheduling_active() tells
  * whether the last render was launched in cost order. */
 void solr_hip_set_tile_scheduling(int mode);

@@ -303,8 +303,9 @@ __global__ __launch_bounds__(256) void k_default(const SceneInfo si, int nbPixel
  * 100k-triangle frame).  Consecutive frames of a renderer see nearly the same picture: every wave
  * records what its tile cost (one store); this kernel - one workgroup - reduces the costs to their
  * maximum and sum for the host (every eighth frame while the launch is in raster order) and, when the
- * host has seen a heavy tail (max > 3 x mean), sorts the tiles by cost with a 1024-bin counting sort
- * in LDS so that the next frame is launched most-expensive-first.  Only the order of work changes,
+ * host has seen a heavy tail (max > 2 x mean), sorts the tiles by cost with a counting sort in LDS
+ * (64 cost classes) so that the following frames are launched most-expensive-first; the order is
+ * refreshed every eighth frame.  Only the order of work changes,
  * never a result.  (Per-wave atomics for max / sum were tried first: 32 400 same-address device-scope
  * atomics per frame serialise at the memory side and tripled the frame time.) */
 __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict__ cost, unsigned *__restrict__ order,
@@ -341,9 +342,11 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict_
     }
     if (!sort)
         return;
+    /* 64 cost classes x 16 sub-bins picked by the tile index: tiles of similar cost are the common
+     * case and would otherwise all contend for one LDS counter */
     const unsigned long long scale = (unsigned long long)maxCost + 1ull;
     for (int i = t; i < n; i += 1024)
-        atomicAdd(&bins[(unsigned)(((unsigned long long)cost[i] * 1024ull) / scale)], 1u);
+        atomicAdd(&bins[((unsigned)(((unsigned long long)cost[i] * 64ull) / scale) << 4) | ((unsigned)i & 15u)], 1u);
     __syncthreads();
     /* exclusive prefix over bins in DESCENDING bin order (Hillis-Steele on the reversed array) */
     __shared__ unsigned scan[1024];
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict_
     __syncthreads();
     for (int i = t; i < n; i += 1024)
     {
-        const unsigned b = (unsigned)(((unsigned long long)cost[i] * 1024ull) / scale);
+        const unsigned b = ((unsigned)(((unsigned long long)cost[i] * 64ull) / scale) << 4) | ((unsigned)i & 15u);
         order[atomicAdd(&bins[b], 1u)] = (unsigned)i;
     }
 }
@@ -527,6 +530,7 @@ struct Engine
     long costKey[6] = {0, 0, 0, 0, 0, 0}; /* the frame geometry the recorded costs belong to */
     int costFrames = 0;               /* frames rendered with that geometry */
     bool reorder = false;             /* current decision of the automatic mode */
+    bool orderValid = false;          /* tileOrder holds an order for the current geometry */
     unsigned lastSerial = 0;
     bool tileClocks = false; /* diagnostics, solr_hip_enable_tile_clocks */
     int nbTilesTimed = 0;
@@ -910,6 +914,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             memcpy(g.costKey, key, sizeof(key));
             g.costFrames = 0;
             g.reorder = false;
+            g.orderValid = false;
             reserve(g.tileCost, (size_t)grid.x * sizeof(unsigned));
             reserve(g.tileOrder, (size_t)grid.x * sizeof(unsigned));
         }
@@ -921,22 +926,30 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         {
             const unsigned long long sum = (unsigned long long)g.hostStats[1] | ((unsigned long long)g.hostStats[2] << 32);
             const unsigned long long mx = g.hostStats[0];
-            if (mx * grid.x > 3ull * sum)
+            if (mx * grid.x > 2ull * sum)
                 g.reorder = true;
-            else if (mx * grid.x < 2ull * sum)
+            else if (2ull * mx * grid.x < 3ull * sum)
                 g.reorder = false;
         }
         F.tileCost = (unsigned *)g.tileCost.ptr;
-        const bool sort = g.costFrames > 0 && (g.tileScheduling == 2 || g.reorder);
-        if (sort || (g.costFrames > 0 && g.costFrames % 8 == 1))
+        /* statistics (and, in cost order, a fresh order) every eighth frame, and at once when the
+         * decision has just changed; in between the last order is reused */
+        const bool ordered = g.costFrames > 0 && (g.tileScheduling == 2 || g.reorder);
+        const bool refresh = g.costFrames > 0 && (g.costFrames % 8 == 1 || (ordered && !g.orderValid));
+        const bool sort = ordered && refresh;
+        if (!ordered)
+            g.orderValid = false;
+        if (refresh)
         {
             hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, g.stream, (const unsigned *)g.tileCost.ptr,
                                (unsigned *)g.tileOrder.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev,
                                sort ? 1 : 0);
             HIPCHECK(hipGetLastError());
             if (sort)
-                F.tileOrder = (const unsigned *)g.tileOrder.ptr;
+                g.orderValid = true;
         }
+        if (ordered && g.orderValid)
+            F.tileOrder = (const unsigned *)g.tileOrder.ptr;
         g.costFrames++;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1169,6 +1182,7 @@ void finalize_scene(vec2i)
     g.hostStats = g.hostStatsDev = nullptr;
     g.costFrames = 0;
     g.reorder = false;
+    g.orderValid = false;
     memset(g.costKey, 0, sizeof(g.costKey));
     if (g.ownStream && g.stream)
         (void)hipStreamDestroy(g.stream);
@@ -1545,11 +1559,12 @@ void solr_hip_set_tile_scheduling(int mode)
     g.tileScheduling = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
     g.costFrames = 0;
     g.reorder = false;
+    g.orderValid = false;
 }
 
 int solr_hip_tile_scheduling_active(void)
 {
-    return (g.tileScheduling == 2 || (g.tileScheduling == 1 && g.reorder)) && g.costFrames > 1 ? 1 : 0;
+    return (g.tileScheduling == 2 || (g.tileScheduling == 1 && g.reorder)) && g.orderValid ? 1 : 0;
 }
 
 void solr_hip_enable_tile_clocks(int enable)

@@ -11,6 +11,7 @@ ap.add_argument("--scene", default="cornell")
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--iterations", type=int, default=None)
+ap.add_argument("--tile-scheduling", type=int, default=1)
 ap.add_argument("--strip", type=int, nargs=2, default=None, help="rank world")
 a = ap.parse_args()
 k = solr.Kernel("hip", deterministic_seed=1)
@@ -24,11 +25,21 @@ if a.strip:
     first, count, per = solr.strip_rows(a.strip[0], a.strip[1], a.height)
     hip.solr_hip_set_strip(first, count)
     a.height = count
-for _ in range(3):
-    k.render()
-hip.solr_hip_enable_tile_clocks(1)
+hip.solr_hip_set_tile_scheduling(a.tile_scheduling)
+import ctypes as C
 k.render()
+flat = k.flat_scene(); si, ppi, eye, direction, angles = k.frame_parameters(); si.pathTracingIteration = 0
+objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+fp = lambda v: v.ctypes.data_as(C.POINTER(C.c_float))
+def frame():
+    hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+for _ in range(12):
+    frame()
+    hip.solr_hip_synchronize()
+hip.solr_hip_enable_tile_clocks(1)
+frame()
 hip.solr_hip_synchronize()
+print("scene %s %dx%d, tile scheduling mode %d, cost-ordered launch active: %d" % (a.scene, a.width, a.height, a.tile_scheduling, hip.solr_hip_tile_scheduling_active()))
 tx, ty = (a.width + 7) // 8, (a.height + 7) // 8
 clk = np.zeros((tx * ty, 2), dtype=np.uint64)
 n = hip.solr_hip_tile_clocks(clk.ctypes.data, tx * ty)
