@@ -163,9 +163,9 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
                               const PostProcessingInfo *postProcessingInfo, const float origin[3],
                               const float direction[3], const float angles[4], unsigned long long counts[8]);
 
-/* Kernel variant selection (A/B measurements): 0 = automatic, 1 = scene read
- * through the scalar cache from HBM, 2 = scene staged in LDS (small scenes
- * only; falls back to 1 when it does not fit). */
+/* A/B measurements: 0 = automatic; 3 = walk the node list exactly as uploaded (no collapsed chains, no
+ * grouping nodes); 4 = always the all-features kernel; 5 = no grouping nodes (takes effect at the next
+ * h2d_scene).  Every setting renders the same frame. */
 void solr_hip_set_variant(int variant);
 int solr_hip_get_variant(void);
 

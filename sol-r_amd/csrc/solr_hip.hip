@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/solr_hip.h"
@@ -547,6 +548,7 @@ struct Engine
     int timedLaunches = 0;
 
     int variant = 0;
+    bool grouping = true; /* groupSiblings(); variant 5 turns it off for A/B measurements */
 };
 
 Engine g;
@@ -633,6 +635,12 @@ void upload(DeviceBuffer &b, const std::vector<T> &host)
     }
 }
 
+inline int bitsi(float v)
+{
+    int i;
+    memcpy(&i, &v, sizeof(i));
+    return i;
+}
 inline float bitsf(int v)
 {
     float f;
@@ -1221,6 +1229,172 @@ void solr_hip_reshape(const SceneInfo *sceneInfo)
     reshape_scene(occ, *sceneInfo);
 }
 
+/* Grouping nodes.  The reference's grid builder produces wide levels - 31 sibling leaves under the root of
+ * the Cornell scene, 134 top-level cells for the 100k-primitive molecule - and a walk tests every sibling
+ * of every node it enters.  Here runs of CONSECUTIVE siblings are wrapped in nodes of our own whose bounds
+ * are the union of the siblings' bounds (up to four parts per level, split points by the surface-area
+ * heuristic, recursively while a part has more than four members; members about as large as their whole
+ * run are left out).  No result can change:
+ *   - the depth-first order of the original nodes, hence of every primitive test, is untouched (only
+ *     consecutive runs are wrapped), so ties and the shadow accumulation resolve as before;
+ *   - a walk reaches an original node only through nodes whose tests it passed, and a group passes
+ *     whenever one of its members does: the slab values (b - o) * inv are monotonic in b under IEEE
+ *     rounding, so the union's near values are <= and its far values >= the member's on every axis, and
+ *     the member's three conditions tnear <= tfar, tnear < far, tfar > 0 carry over (for the sign-selected
+ *     form with an infinite reciprocal as well: a member can only pass an axis whose slab contains the
+ *     origin coordinate, and then so does the union); the closest-distance cut-off a group is tested
+ *     with is never smaller than the one its members will see;
+ *   - groups hold no primitives and have no side effects.
+ * Requires nested skip pointers and ordered finite bounds (checked by the caller).  Rewrites the node
+ * rows and the first-primitive plane in place; returns the new node count. */
+static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start)
+{
+    const int n = (int)start.size();
+    auto skipOf = [&](int i) { return bitsi(rows[2 * i + 1].w); };
+    struct Bounds
+    {
+        float lo[3], hi[3];
+    };
+    auto boundsOf = [&](int i) {
+        Bounds b;
+        b.lo[0] = rows[2 * i].x, b.lo[1] = rows[2 * i].y, b.lo[2] = rows[2 * i].z;
+        b.hi[0] = rows[2 * i + 1].x, b.hi[1] = rows[2 * i + 1].y, b.hi[2] = rows[2 * i].w;
+        return b;
+    };
+    auto merge = [](Bounds a, const Bounds &b) {
+        for (int k = 0; k < 3; ++k)
+        {
+            a.lo[k] = std::min(a.lo[k], b.lo[k]);
+            a.hi[k] = std::max(a.hi[k], b.hi[k]);
+        }
+        return a;
+    };
+    auto area = [](const Bounds &b) {
+        const double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2];
+        return x * y + y * z + z * x;
+    };
+    std::vector<float4> outRows;
+    std::vector<int> outStart;
+    outRows.reserve(rows.size() + rows.size() / 2);
+    outStart.reserve(start.size() + start.size() / 2);
+
+    /* best split of sib[from, to) into two consecutive parts */
+    std::vector<Bounds> suffix;
+    auto splitPoint = [&](const std::vector<int> &sib, int from, int to) {
+        const int count = to - from;
+        suffix.resize((size_t)count);
+        Bounds acc = boundsOf(sib[to - 1]);
+        suffix[count - 1] = acc;
+        for (int k = count - 2; k >= 0; --k)
+        {
+            acc = merge(acc, boundsOf(sib[from + k]));
+            suffix[k] = acc;
+        }
+        Bounds left = boundsOf(sib[from]);
+        double best = 1e300;
+        int bestAt = from + count / 2;
+        for (int k = 1; k < count; ++k)
+        {
+            const double cost = area(left) * k + area(suffix[k]) * (count - k);
+            if (cost < best)
+            {
+                best = cost;
+                bestAt = from + k;
+            }
+            left = merge(left, boundsOf(sib[from + k]));
+        }
+        return bestAt;
+    };
+
+    struct Emit
+    {
+        std::function<void(const std::vector<int> &, int, int)> siblings;
+        std::function<void(int)> node;
+    } emit;
+    emit.node = [&](int i) {
+        const size_t at = outStart.size();
+        outRows.push_back(rows[2 * i]);
+        outRows.push_back(rows[2 * i + 1]);
+        outStart.push_back(start[i]);
+        std::vector<int> children;
+        for (int j = i + 1; j < i + skipOf(i) && j < n; j += std::max(skipOf(j), 1))
+            children.push_back(j);
+        if (!children.empty())
+            emit.siblings(children, 0, (int)children.size());
+        outRows[2 * at + 1].w = bitsf((int)(outStart.size() - at));
+    };
+    emit.siblings = [&](const std::vector<int> &sib, int from, int to) {
+        if (to - from <= 4)
+        {
+            for (int k = from; k < to; ++k)
+                emit.node(sib[k]);
+            return;
+        }
+        /* a member about as large as the whole run (a wall of the room, the light cell that spans the
+         * view distance) would make every group around it as large as itself and never culled: such
+         * members stay where they are, ungrouped, and the runs between them are grouped on their own */
+        {
+            Bounds u = boundsOf(sib[from]);
+            for (int k = from + 1; k < to; ++k)
+                u = merge(u, boundsOf(sib[k]));
+            const double limit = 0.5 * area(u);
+            bool dominant = false;
+            for (int k = from; k < to && !dominant; ++k)
+                dominant = area(boundsOf(sib[k])) > limit;
+            if (dominant)
+            {
+                int runStart = from;
+                for (int k = from; k <= to; ++k)
+                    if (k == to || area(boundsOf(sib[k])) > limit)
+                    {
+                        if (k > runStart)
+                            emit.siblings(sib, runStart, k);
+                        if (k < to)
+                            emit.node(sib[k]);
+                        runStart = k + 1;
+                    }
+                return;
+            }
+        }
+        const int mid = splitPoint(sib, from, to);
+        /* second level of the split, without an intermediate node: up to four parts */
+        int parts[5];
+        int np = 0;
+        parts[np++] = from;
+        if (mid - from > 2)
+            parts[np++] = splitPoint(sib, from, mid);
+        parts[np++] = mid;
+        if (to - mid > 2)
+            parts[np++] = splitPoint(sib, mid, to);
+        parts[np] = to;
+        for (int q = 0; q < np; ++q)
+        {
+            const int a = parts[q], b = parts[q + 1];
+            if (b - a == 1)
+            {
+                emit.node(sib[a]);
+                continue;
+            }
+            Bounds u = boundsOf(sib[a]);
+            for (int k = a + 1; k < b; ++k)
+                u = merge(u, boundsOf(sib[k]));
+            const size_t at = outStart.size();
+            outRows.push_back(make_float4(u.lo[0], u.lo[1], u.lo[2], u.hi[2]));
+            outRows.push_back(make_float4(u.hi[0], u.hi[1], bitsf(0), bitsf(1)));
+            outStart.push_back(0);
+            emit.siblings(sib, a, b);
+            outRows[2 * at + 1].w = bitsf((int)(outStart.size() - at));
+        }
+    };
+    std::vector<int> top;
+    for (int j = 0; j < n; j += std::max(skipOf(j), 1))
+        top.push_back(j);
+    emit.siblings(top, 0, (int)top.size());
+    rows.swap(outRows);
+    start.swap(outStart);
+    return (int)start.size();
+}
+
 void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *primitives, int nbPrimitives,
                Lamp *lamps, int nbLamps)
 {
@@ -1319,6 +1493,20 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
             startC[j] = start[i];
         }
 
+    int nbWalkNodes = nc;
+    if (g.nested && g.orderedCompact && nc > 0 && g.grouping)
+        nbWalkNodes = groupSiblings(boxesC, startC);
+    if (getenv("SOLR_HIP_DEBUG_TREE"))
+    {
+        fprintf(stderr, "solr_hip: %d nodes uploaded, %d after collapsing chains, %d with grouping nodes\n",
+                nbActiveBoxes, nc, nbWalkNodes);
+        if (nbWalkNodes <= 80)
+            for (int i = 0; i < nbWalkNodes; ++i)
+                fprintf(stderr, "  node %2d: prims %d skip %d  [%g %g %g .. %g %g %g]\n", i, bitsi(boxesC[2 * i + 1].z),
+                        bitsi(boxesC[2 * i + 1].w), boxesC[2 * i].x, boxesC[2 * i].y, boxesC[2 * i].z,
+                        boxesC[2 * i + 1].x, boxesC[2 * i + 1].y, boxesC[2 * i].w);
+    }
+
     std::vector<float4> prims(8 * (size_t)nbPrimitives);
     for (int i = 0; i < nbPrimitives; ++i)
     {
@@ -1347,7 +1535,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     if (ok())
     {
         g.nbBoxes = nbActiveBoxes;
-        g.nbBoxesCompact = nc;
+        g.nbBoxesCompact = nbWalkNodes;
         g.nbPrimitives = nbPrimitives;
         g.nbLamps = nbLamps;
     }
@@ -1603,6 +1791,7 @@ double solr_hip_kernel_time(int *nbLaunches, int reset)
 void solr_hip_set_variant(int variant)
 {
     g.variant = variant;
+    g.grouping = (variant != 5); /* takes effect at the next h2d_scene */
 }
 
 int solr_hip_get_variant(void)
