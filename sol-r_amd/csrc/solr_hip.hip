@@ -1323,8 +1323,10 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start)
             emit.siblings(children, 0, (int)children.size());
         outRows[2 * at + 1].w = bitsf((int)(outStart.size() - at));
     };
+    const int flatMax = getenv("SOLR_HIP_GROUP_FLAT") ? atoi(getenv("SOLR_HIP_GROUP_FLAT")) : 4;
+    const int levels = getenv("SOLR_HIP_GROUP_LEVELS") ? atoi(getenv("SOLR_HIP_GROUP_LEVELS")) : 2;
     emit.siblings = [&](const std::vector<int> &sib, int from, int to) {
-        if (to - from <= 4)
+        if (to - from <= flatMax)
         {
             for (int k = from; k < to; ++k)
                 emit.node(sib[k]);
@@ -1356,17 +1358,26 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start)
                 return;
             }
         }
-        const int mid = splitPoint(sib, from, to);
-        /* second level of the split, without an intermediate node: up to four parts */
-        int parts[5];
-        int np = 0;
-        parts[np++] = from;
-        if (mid - from > 2)
-            parts[np++] = splitPoint(sib, from, mid);
-        parts[np++] = mid;
-        if (to - mid > 2)
-            parts[np++] = splitPoint(sib, mid, to);
-        parts[np] = to;
+        /* `levels` rounds of binary splits without intermediate nodes: up to 2^levels parts */
+        int parts[17];
+        int np = 1;
+        parts[0] = from;
+        parts[1] = to;
+        for (int level = 0; level < levels; ++level)
+        {
+            int next[17];
+            int nn = 0;
+            for (int q = 0; q < np; ++q)
+            {
+                next[nn++] = parts[q];
+                if (parts[q + 1] - parts[q] > 2)
+                    next[nn++] = splitPoint(sib, parts[q], parts[q + 1]);
+            }
+            next[nn] = to;
+            np = nn;
+            for (int q = 0; q <= np; ++q)
+                parts[q] = next[q];
+        }
         for (int q = 0; q < np; ++q)
         {
             const int a = parts[q], b = parts[q + 1];
