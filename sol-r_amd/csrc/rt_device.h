@@ -712,6 +712,69 @@ SOLR_DEV bool planeIntersection(const SceneInfo &si, int type, v3 p0, v3 size, v
 }
 
 /* GI:575-659 */
+/* GI:575-626: does the ray hit the triangle, and where.  Nothing below this point of the reference's
+ * function can turn a hit into a miss except the double-sided shadow case handled by the caller. */
+SOLR_DEV bool triangleHit(const SceneInfo &si, v3 p0, v3 p1, v3 p2, const WalkRay &ray, v3 &intersection)
+{
+    v3 E01 = p1 - p0;
+    v3 E03 = p2 - p0;
+    v3 P = cross(ray.d, E03);
+    float det = dot(E01, P);
+    if (fabsf(det) < si.geometryEpsilon)
+        return false;
+    v3 T = ray.o - p0;
+    float a = dot(T, P) / det;
+    if (a < 0.f || a > 1.f)
+        return false;
+    v3 Q = cross(T, E01);
+    float b = dot(ray.d, Q) / det;
+    if (b < 0.f || b > 1.f)
+        return false;
+    if ((a + b) > 1.f)
+    {
+        /* GI:603-616 with E21 = p1 - p1 (sic) */
+        v3 E23 = p0 - p1;
+        v3 E21 = p1 - p1;
+        v3 P_ = cross(ray.d, E21);
+        float det_ = dot(E23, P_);
+        if (fabsf(det_) < si.geometryEpsilon)
+            return false;
+        v3 T_ = ray.o - p2;
+        float a_ = dot(T_, P_) / det_;
+        if (a_ < 0.f)
+            return false;
+        v3 Q_ = cross(T_, E23);
+        float b_ = dot(ray.d, Q_) / det_;
+        if (b_ < 0.f)
+            return false;
+    }
+    float t = dot(E03, Q) / det;
+    if (t < 0)
+        return false;
+    intersection = ray.o + ray.d * t;
+    return true;
+}
+
+/* GI:627-655: barycentric areas and the interpolated, ray-facing normal at the hit point.  The walks
+ * call it only for hits they keep (closest-hit walk) or whose normal they use (shadows through a
+ * transparent triangle): about two thirds of the arithmetic of a triangle test. */
+SOLR_DEV void triangleNormal(v3 p0, v3 p1, v3 p2, v3 n0, v3 n1, v3 n2, const WalkRay &ray, Hit &h)
+{
+    v3 v0 = p0 - h.intersection;
+    v3 v1 = p1 - h.intersection;
+    v3 v2 = p2 - h.intersection;
+    h.areas.x = 0.5f * length(cross(v1, v2));
+    h.areas.y = 0.5f * length(cross(v0, v2));
+    h.areas.z = 0.5f * length(cross(v0, v1));
+    v3 wn = (n0 * h.areas.x + n1 * h.areas.y) + n2 * h.areas.z;
+    h.normal = normalize(vdivs(wn, h.areas.x + h.areas.y + h.areas.z));
+    v3 dir = ray.dn;
+    float r = dot(dir, h.normal);
+    if (r > 0.f)
+        h.normal = h.normal * -1.f;
+    h.shadowIntensity = 1.f;
+}
+
 SOLR_DEV bool triangleIntersection(const SceneInfo &si, v3 p0, v3 p1, v3 p2, v3 n0, v3 n1, v3 n2,
                                    const WalkRay &ray, Hit &h, bool processingShadows)
 {
@@ -1150,6 +1213,37 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     }
                 }
             }
+            else if ((FEAT & F_TRI) && (type == ptTriangle || !si.extendedGeometry))
+            {
+                /* triangles (every primitive, without extended geometry, GI:743-747): areas and the
+                 * interpolated normal only for hits that become the closest one */
+                Hit h;
+                h.intersection = V(0.f, 0.f, 0.f);
+                bool i = false;
+                const v3 p0 = V4(head.a);
+                const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
+                const v3 p2 = V4(primRow(S, pi, ROW_P2));
+                if (lanes)
+                    i = triangleHit(si, p0, p1, p2, r, h.intersection);
+                const float distance = length(h.intersection - r.o);
+                const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
+                if (ballot(keep) != 0ull)
+                {
+                    const v3 n0 = V4(primRow(S, pi, ROW_N0));
+                    const v3 n1 = V4(primRow(S, pi, ROW_N1));
+                    const v3 n2 = V4(primRow(S, pi, ROW_N2));
+                    if (keep)
+                    {
+                        triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
+                        minDistance = distance;
+                        closestPrimitive = pi;
+                        closestIntersection = h.intersection;
+                        closestNormal = h.normal;
+                        closestAreas = h.areas;
+                        intersections = true;
+                    }
+                }
+            }
             else if (lanes)
             {
                 Hit h;
@@ -1250,6 +1344,25 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                     if (hit)
                         sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b), (tag & PRIM_PROCEDURAL) != 0,
                                                            (tag & PRIM_TRANSPARENT) != 0, back, r, h);
+                }
+            }
+            else if ((FEAT & F_TRI) && !si.doubleSidedTriangles && (type == ptTriangle || !si.extendedGeometry))
+            {
+                /* an opaque triangle shadows with intensity 1 whatever its normal (GI:880); with
+                 * double-sided triangles the normal decides (GI:643-647) and the full test is used */
+                const v3 p0 = V4(head.a);
+                const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
+                const v3 p2 = V4(primRow(S, pi, ROW_P2));
+                if (lanes)
+                    hit = triangleHit(si, p0, p1, p2, r, h.intersection);
+                h.shadowIntensity = 1.f;
+                if (tag & PRIM_TRANSPARENT)
+                {
+                    const v3 n0 = V4(primRow(S, pi, ROW_N0));
+                    const v3 n1 = V4(primRow(S, pi, ROW_N1));
+                    const v3 n2 = V4(primRow(S, pi, ROW_N2));
+                    if (hit)
+                        triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
                 }
             }
             else if (lanes)
