@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+PREROLL_FRAMES = 48    # untimed setup frames before the W warmup steps
 BYTES_PER_PIXEL = 67    # 16 (ids write) + 32 (float framebuffer write) + 16 (ids read, refinement passes) + 3 (RGB)
 
 
@@ -152,6 +153,11 @@ def main():
     k.check(0, "ray census")
     rays_local = int(counts[0]) + int(counts[1])
 
+    # setup, untimed: let the clocks and the tile-cost feedback of the engine settle before the W
+    # warmup steps (a frame is 0.4 ms; W = 3 alone is 1.2 ms of GPU work, shorter than the power ramp)
+    for _ in range(PREROLL_FRAMES):
+        frame()
+    sync()
     for _ in range(args.warmup):
         frame()
     sync()

@@ -303,19 +303,23 @@ __global__ __launch_bounds__(256) void k_default(const SceneInfo si, int nbPixel
  * runs on alone while the rest of the chip idles (profiles/r1/tile_timeline_*.txt: 23 % of the
  * 100k-triangle frame).  Consecutive frames of a renderer see nearly the same picture: every wave
  * records what its tile cost (one store); this kernel - one workgroup - reduces the costs to their
- * maximum and sum for the host (every eighth frame while the launch is in raster order) and, when the
+ * maximum and sum for the host (every sixteenth frame) and, when the
  * host has seen a heavy tail (max > 2 x mean), sorts the tiles by cost with a counting sort in LDS
  * (64 cost classes) so that the following frames are launched most-expensive-first; the order is
- * refreshed every eighth frame.  Only the order of work changes,
+ * refreshed every sixteenth frame.  Only the order of work changes,
  * never a result.  (Per-wave atomics for max / sum were tried first: 32 400 same-address device-scope
  * atomics per frame serialise at the memory side and tripled the frame time.) */
+__device__ unsigned orderSerial = 0u;
+
 __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict__ cost, unsigned *__restrict__ order,
                                                       int n, volatile unsigned *hostStats, int sort)
 {
     __shared__ unsigned bins[1024];
+    __shared__ unsigned scan[1024];
     __shared__ unsigned maxCost;
     __shared__ unsigned long long sumCost;
     const int t = threadIdx.x;
+    const int BATCH = 8; /* independent loads in flight per thread: the passes are latency bound */
     bins[t] = 0u;
     if (t == 0)
     {
@@ -325,10 +329,21 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict_
     __syncthreads();
     unsigned m = 0u;
     unsigned long long sum = 0ull;
-    for (int i = t; i < n; i += 1024)
+    for (int base = 0; base < n; base += BATCH * 1024)
     {
-        m = max(m, cost[i]);
-        sum += cost[i];
+        unsigned c[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+        {
+            const int i = base + k * 1024 + t;
+            c[k] = (i < n) ? cost[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+        {
+            m = max(m, c[k]);
+            sum += c[k];
+        }
     }
     atomicMax(&maxCost, m);
     atomicAdd(&sumCost, sum);
@@ -339,18 +354,32 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict_
         hostStats[1] = (unsigned)sumCost;
         hostStats[2] = (unsigned)(sumCost >> 32);
         hostStats[3] = (unsigned)n;
-        hostStats[4] = hostStats[4] + 1u;
+        hostStats[4] = ++orderSerial;
     }
     if (!sort)
         return;
     /* 64 cost classes x 16 sub-bins picked by the tile index: tiles of similar cost are the common
      * case and would otherwise all contend for one LDS counter */
-    const unsigned long long scale = (unsigned long long)maxCost + 1ull;
-    for (int i = t; i < n; i += 1024)
-        atomicAdd(&bins[((unsigned)(((unsigned long long)cost[i] * 64ull) / scale) << 4) | ((unsigned)i & 15u)], 1u);
+    const float toClass = 64.f / ((float)maxCost + 1.f); /* the same expression in both passes */
+    for (int base = 0; base < n; base += BATCH * 1024)
+    {
+        unsigned c[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+        {
+            const int i = base + k * 1024 + t;
+            c[k] = (i < n) ? cost[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+        {
+            const int i = base + k * 1024 + t;
+            if (i < n)
+                atomicAdd(&bins[(min(63u, (unsigned)((float)c[k] * toClass)) << 4) | ((unsigned)i & 15u)], 1u);
+        }
+    }
     __syncthreads();
     /* exclusive prefix over bins in DESCENDING bin order (Hillis-Steele on the reversed array) */
-    __shared__ unsigned scan[1024];
     const unsigned mine = bins[1023 - t];
     scan[t] = mine;
     __syncthreads();
@@ -363,10 +392,25 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict_
     }
     bins[1023 - t] = scan[t] - mine; /* first slot of this bin */
     __syncthreads();
-    for (int i = t; i < n; i += 1024)
+    for (int base = 0; base < n; base += BATCH * 1024)
     {
-        const unsigned b = ((unsigned)(((unsigned long long)cost[i] * 64ull) / scale) << 4) | ((unsigned)i & 15u);
-        order[atomicAdd(&bins[b], 1u)] = (unsigned)i;
+        unsigned c[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+        {
+            const int i = base + k * 1024 + t;
+            c[k] = (i < n) ? cost[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+        {
+            const int i = base + k * 1024 + t;
+            if (i < n)
+            {
+                const unsigned b = (min(63u, (unsigned)((float)c[k] * toClass)) << 4) | ((unsigned)i & 15u);
+                order[atomicAdd(&bins[b], 1u)] = (unsigned)i;
+            }
+        }
     }
 }
 
@@ -940,10 +984,10 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                 g.reorder = false;
         }
         F.tileCost = (unsigned *)g.tileCost.ptr;
-        /* statistics (and, in cost order, a fresh order) every eighth frame, and at once when the
+        /* statistics (and, in cost order, a fresh order) every sixteenth frame, and at once when the
          * decision has just changed; in between the last order is reused */
         const bool ordered = g.costFrames > 0 && (g.tileScheduling == 2 || g.reorder);
-        const bool refresh = g.costFrames > 0 && (g.costFrames % 8 == 1 || (ordered && !g.orderValid));
+        const bool refresh = g.costFrames > 0 && (g.costFrames % 16 == 1 || (ordered && !g.orderValid));
         const bool sort = ordered && refresh;
         if (!ordered)
             g.orderValid = false;

@@ -1,0 +1,35 @@
+"""Copies the summaries of tools/profile_round.sh from gpurun_out/<tag>/ into profiles/<tag>/ (tracked)."""
+import sys, os, glob, shutil, csv, collections, json
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src, dst = "gpurun_out/" + tag, "profiles/" + tag
+os.makedirs(dst, exist_ok=True)
+for scene in ("cornell", "height_field", "molecule"):
+    b = os.path.join(src, "bench_%s.json" % scene)
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(dst, "bench_%s.json" % scene))
+    st = os.path.join(src, "trace_%s" % scene, "trace_kernel_stats.csv")
+    if os.path.exists(st):
+        shutil.copy(st, os.path.join(dst, "kernel_stats_%s.csv" % scene))
+    out = []
+    for p in ("sq", "fetch", "write"):
+        agg = collections.defaultdict(list)
+        meta = None
+        for f in glob.glob(os.path.join(src, "pmc_%s_%s" % (p, scene), "*counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if "k_standardRenderer<false" in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"])); meta = r
+        for k in sorted(agg):
+            out.append("%-22s %16.0f   (mean of %d launches)" % (k, sum(agg[k]) / len(agg[k]), len(agg[k])))
+        if meta and p == "sq":
+            out.append("kernel %s  grid %s  workgroup %s  scratch %s B/lane  LDS %s B/workgroup" % (
+                meta["Kernel_Name"][:60], meta["Grid_Size"], meta["Workgroup_Size"], meta["Scratch_Size"], meta["LDS_Block_Size"]))
+    if out:
+        hdr = ("# rocprofv3 --pmc, three separate passes (SQ counters; FETCH_SIZE; WRITE_SIZE) of\n"
+               "#   python3 bench.py --scene %s --steps 24 --warmup 12 --no-cpu-baseline\n"
+               "# per launch of the renderer kernel.  FETCH_SIZE / WRITE_SIZE are in KB (L2 <-> fabric requests x 64 B;\n"
+               "# MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, WRITE_SIZE is exact).\n" % scene)
+        open(os.path.join(dst, "pmc_%s.txt" % scene), "w").write(hdr + "\n".join(out) + "\n")
+for f in glob.glob(os.path.join(src, "tile_timeline_*.txt")) + glob.glob(os.path.join(src, "strip_times_*.txt")) + \
+        glob.glob(os.path.join(src, "reference_opencl_speed.txt")):
+    shutil.copy(f, dst)
+print(sorted(os.listdir(dst)))
