@@ -202,6 +202,7 @@ def main():
                    176 * len(set(int(m) for m in flat.primitives["materialId"])))
     algo_bytes = nb_rows * W * BYTES_PER_PIXEL + scene_bytes  # per launch, rank 0's strip
     achieved = algo_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+    traffic, traffic_source = measured_traffic(args, world)
     out = {
         "metric": "Mrays/s @1920x1080, 3-bounce Cornell",
         "value": round(mrays, 3),
@@ -224,7 +225,7 @@ def main():
                    "cost_ordered_launch_rank0": bool(hip.solr_hip_tile_scheduling_active()),
                    "parallelism": "tile%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "k_standardRenderer", "kernel_ms": round(kernel_avg_ms, 5),
                      "algorithmic_bytes": algo_bytes},
     }
@@ -234,6 +235,25 @@ def main():
     print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
+
+
+def measured_traffic(args, world):
+    """HBM-side bytes per launch of the renderer from the committed rocprofv3 --pmc passes of this same
+    command (profiles/rNN/hbm_traffic.json, written by tools/collect_profiles.py); None when the workload
+    differs from the profiled one.  bench.py cannot run the profiler on itself."""
+    import glob
+    if world != 1 or (args.width, args.height) != (1920, 1080) or args.graphics_level != 4:
+        return None, None
+    if args.scene == "cornell" and args.iterations != 3:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
+        try:
+            entry = json.load(open(path)).get(args.scene)
+        except (OSError, ValueError):
+            continue
+        if entry:
+            return entry["bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def usable_cpus():

@@ -29,6 +29,26 @@ for scene in ("cornell", "height_field", "molecule"):
                "# per launch of the renderer kernel.  FETCH_SIZE / WRITE_SIZE are in KB (L2 <-> fabric requests x 64 B;\n"
                "# MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, WRITE_SIZE is exact).\n" % scene)
         open(os.path.join(dst, "pmc_%s.txt" % scene), "w").write(hdr + "\n".join(out) + "\n")
+traffic = {}
+for scene in ("cornell", "height_field", "molecule"):
+    vals = {}
+    for p, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        v = []
+        for f in glob.glob(os.path.join(src, "pmc_%s_%s" % (p, scene), "*counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if "k_standardRenderer<false" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                    v.append(float(r["Counter_Value"]))
+        if v:
+            vals[name] = sum(v) / len(v)
+    if len(vals) == 2:
+        traffic[scene] = {"workload": "%s 1920x1080" % scene, "FETCH_SIZE_KB": round(vals["FETCH_SIZE"], 1),
+                          "WRITE_SIZE_KB": round(vals["WRITE_SIZE"], 1),
+                          "bytes_per_launch": int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
+                          "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB -> bytes; "
+                                  "FETCH_SIZE taken at face value (the gfx950 2x under-count is calibrated for 16 B/lane "
+                                  "streaming reads only; the reads here are dword scratch reloads and scalar loads)"}
+if traffic:
+    json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "tile_timeline_*.txt")) + glob.glob(os.path.join(src, "strip_times_*.txt")) + \
         glob.glob(os.path.join(src, "reference_opencl_speed.txt")):
     shutil.copy(f, dst)
