@@ -217,7 +217,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, row strips of %d" %
-                   (args.scene, W, H, args.iterations, len(flat.boxes), len(flat.primitives), rows_per_rank),
+                   (args.scene, W, H, si.nbRayIterations, len(flat.boxes), len(flat.primitives), rows_per_rank),
                    "rays_per_frame": rays_total, "closest_hit_walks_rank0": int(counts[0]),
                    "shadow_walks_rank0": int(counts[1]), "lane_nodes": int(counts[2]), "lane_prim_tests": int(counts[3]),
                    "wave_nodes": int(counts[4]), "wave_prim_tests": int(counts[5]), "wave_walks": int(counts[6]) + int(counts[7]), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 2),
