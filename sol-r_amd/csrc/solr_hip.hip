@@ -112,7 +112,9 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     v3 rotationCenter = V(0.f, 0.f, 0.f);
     if (si.cameraType == ctVR)
         rotationCenter = rayO;
-    const bool antialiasingActivated = (si.cameraType == ctAntialiazed);
+    /* the five-ray camera keeps the primary ray and a colour sum alive across the whole path trace:
+     * only the instantiations with F_FULL carry it (the host selects one of them for that camera) */
+    const bool antialiasingActivated = (FEAT & F_FULL) && (si.cameraType == ctAntialiazed);
 
     /* first-hit distance of the previous pass, only needed for the natural
      * depth-of-field jitter of the accumulation passes (CRT:470-479) */
@@ -891,7 +893,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
 
     /* the box-debug view and the census count every node of the original tree */
     const bool full = sceneInfo.renderBoxes != 0 || sceneInfo.advancedIllumination == aiBasic ||
-                      sceneInfo.advancedIllumination == aiFull;
+                      sceneInfo.advancedIllumination == aiFull || sceneInfo.cameraType == ctAntialiazed;
     const bool exactNodes = counting || sceneInfo.renderBoxes != 0 || objects.x != g.nbBoxes || g.variant == 3;
     flushGeometry();
     if (!ok())
