@@ -270,3 +270,23 @@ def test_cost_ordered_launch_changes_no_pixel(solr, oracle):
     finally:
         hip.solr_hip_set_tile_scheduling(1)
         k.finalize()
+
+
+def test_blinn_exponents_outside_the_lean_pow_domain(solr, oracle):
+    """pow_f (rt_device.h) has a lean path for exponents in (0, 4096] and sends everything else to the
+    library routine: specular powers 0 and 10 000 take that road."""
+    def build(k, **kw):
+        k.initialize(width=96, height=64, nbRayIterations=2, **kw)
+        a = k.add_material(0.8, 0.3, 0.2, reflection=0.3, specValue=1.0, specPower=0.0)
+        b = k.add_material(0.2, 0.7, 0.9, specValue=0.8, specPower=10000.0)
+        c = k.add_material(0.5, 0.5, 0.5, specValue=0.6, specPower=60.0)
+        k.add_primitive(solr.ptSphere, (-2500.0, 0.0, 0.0), size=(2000.0, 0, 0), material=a)
+        k.add_primitive(solr.ptSphere, (2500.0, 0.0, 0.0), size=(2000.0, 0, 0), material=b)
+        k.add_primitive(solr.ptXZPlane, (0.0, -2500.0, 0.0), size=(9000.0, 0.0, 9000.0), material=c)
+        solr.scenes.add_light(k, position=(3000.0, 8000.0, -8000.0))
+        k.compact_boxes(True)
+        k.set_camera((100.0, 500.0, -12000.0))
+        return k
+    k, res, _ = both(solr, oracle, build)
+    k.finalize()
+    assert_parity(res, rgb_max_diff=1)
