@@ -497,6 +497,7 @@ int GPUKernel::processBoxes(const int boxSize, bool simulate)
         return 0;
 
     BoxContainer &level0 = f.boundingBoxes[0];
+    level0.reserve(f.primitives.size());
     const float vd = m_sceneInfo.viewDistance;
     size_t maxPrimitivesPerBox = 0;
     unsigned int p = 0;
@@ -510,7 +511,7 @@ int GPUKernel::processBoxes(const int boxSize, bool simulate)
         unsigned int B = 1 + 1000 * (X * boxSize * boxSize + Y * boxSize + Z);
 
         /* the cell is created for every primitive, lights included */
-        if (level0.find(B) == level0.end())
+        if (!level0.contains(B))
         {
             CPUBoundingBox box;
             box.parameters[0] = make_vec3f(vd, vd, vd);
@@ -549,6 +550,7 @@ int GPUKernel::processOutterBoxes(const int boxSize, const int boundingBoxesDept
 
     const float vd = m_sceneInfo.viewDistance;
     BoxContainer &level = f.boundingBoxes[boundingBoxesDepth];
+    level.reserve(f.boundingBoxes[boundingBoxesDepth - 1].size() + 1);
     size_t maxPrimitivesPerBox = 0;
     for (const auto &box : f.boundingBoxes[boundingBoxesDepth - 1])
     {
@@ -675,6 +677,13 @@ void GPUKernel::streamDataToGPU()
     m_hBoundingBoxes.clear();
     m_hPrimitives.clear();
     m_hLamps.clear();
+    {
+        size_t nodes = 0;
+        for (int level = 0; level < BOUNDING_BOXES_TREE_DEPTH; ++level)
+            nodes += f.boundingBoxes[level].size();
+        m_hBoundingBoxes.reserve(nodes);
+        m_hPrimitives.reserve(f.primitives.size());
+    }
     if (m_lightInformation.size() < NB_MAX_LIGHTINFORMATIONS)
         m_lightInformation.assign(NB_MAX_LIGHTINFORMATIONS, LightInformation());
 

@@ -231,3 +231,28 @@ def test_textures_are_packed_into_one_atlas(solr, kernel):
     assert bytes(flat.textures[:24]) == t0.tobytes() and bytes(flat.textures[24:36]) == t1.tobytes()
     mat = flat.materials[m]                                            # GPUKernel.cpp:1865-1889 / 2280-2300
     assert tuple(mat["textureMapping"]) == (2, 2, -1, 3) and int(mat["textureOffset"][0]) == 24
+
+
+def _flat_digest(flat):
+    import hashlib
+    h = hashlib.sha256()
+    for a in (flat.boxes, flat.primitives, flat.lights):
+        for name in a.dtype.names:   # field by field: the records have padding bytes
+            h.update(np.ascontiguousarray(a[name]).tobytes())
+    return h.hexdigest()[:16]
+
+
+@pytest.mark.parametrize("name,kw,boxes,prims,digest", [
+    ("cornell", dict(width=64, height=64, iterations=2), 75, 29, "bb2bfdce9fac275a"),
+    ("molecule", dict(width=64, height=64, atoms=20000), 184169, 39999, "a83ea5ee46fd3f99"),
+    ("height_field", dict(width=64, height=64, n=96), 55117, 18433, "8b8f8939456a1dd0"),
+])
+def test_flattened_tree_is_what_the_map_based_builder_produced(solr, name, kw, boxes, prims, digest):
+    """The builder's per-level std::map (as in the reference) was replaced by OrderedMap (hash index +
+    one sort per level).  These digests were taken from the std::map build: node order, skip pointers,
+    bounds, primitive order and light records are unchanged, bit for bit."""
+    k = solr.Kernel(engine="host-only")
+    getattr(solr.scenes, name)(k, **kw)
+    flat = k.flat_scene()
+    assert (len(flat.boxes), len(flat.primitives)) == (boxes, prims)
+    assert _flat_digest(flat) == digest
