@@ -51,6 +51,10 @@ def parse():
 
 def main():
     args = parse()
+    if os.environ.get("SOLR_BENCH_DEBUG"):
+        import faulthandler
+        import signal
+        faulthandler.register(signal.SIGUSR1, all_threads=True)  # `timeout -s USR1` prints where it hangs
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -13,7 +13,8 @@
  * keeps the same path in one self-contained file, and ROCm's clang compiles that
  * file for gfx950 as it lies (oracle/Makefile, target `ref` -> oracle/_ref/):
  * tests/test_reference_opencl.py runs the reference's own k_standardRenderer on
- * the MI355X and checks this oracle against its output - same primitive on
+ * the MI355X and checks this oracle against its output (tests/test_golden_reference.py
+ * does the same on CPU against frames of that renderer committed under tests/golden/) - same primitive on
  * >= 99.95 % of the pixels, identical RGB8 on 94-100 %, float colour within 1e-5
  * on 88-100 % depending on the scene; the rest is drift between the reference's
  * two engines (listed in that test).  The CUDA engine, which is what this file
