@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--graphics-level", type=int, default=4, help="experiments only; the metric is quoted at 4 (glFull)")
     ap.add_argument("--tile-scheduling", type=int, default=1, help="0 raster order, 1 automatic (default), 2 cost order")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="2 (default): consecutive frames alternate between two streams and buffer sets of the engine, "
+                         "so a frame's tail overlaps the next frame's start; 1: the reference's one frame at a time. "
+                         "Ignored at N > 1 (the engine runs on torch's stream there)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -98,6 +102,8 @@ def main():
         k.set_scene_info(graphicsLevel=args.graphics_level)
     hip.solr_hip_set_variant(args.variant)
     hip.solr_hip_set_tile_scheduling(args.tile_scheduling)
+    if not distributed:
+        hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
     sg = None
     if distributed:
         if os.environ.get("SOLR_BENCH_NULL_STREAM") != "1":
@@ -182,6 +188,23 @@ def main():
     elapsed = t1 - t0
     launches = C.c_int(0)
     kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
+    kernel_basis = "HIP events around every launch of the timed region"
+    if not distributed and hip.solr_hip_get_frames_in_flight() == 2:
+        # with two frames in flight consecutive launches overlap and an event pair around one of them
+        # spans parts of two frames; the kernel's own duration is taken from a short one-at-a-time
+        # segment after the timed region (same frame, same buffers)
+        hip.solr_hip_set_frames_in_flight(1)
+        for _ in range(8):
+            frame()
+        sync()
+        hip.solr_hip_enable_timing(1)
+        for _ in range(16):
+            frame()
+        sync()
+        hip.solr_hip_enable_timing(0)
+        kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
+        hip.solr_hip_set_frames_in_flight(2)
+        kernel_basis = "HIP events around each of 16 launches issued one at a time after the timed region"
 
     rays_total = rays_local
     if distributed:
@@ -227,10 +250,11 @@ def main():
                    "wave_nodes": int(counts[4]), "wave_prim_tests": int(counts[5]), "wave_walks": int(counts[6]) + int(counts[7]), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 2),
                    "host_issue_ms_per_step_rank0": round((t_issued - t0) / args.steps * 1e3, 4),
                    "cost_ordered_launch_rank0": bool(hip.solr_hip_tile_scheduling_active()),
+                   "frames_in_flight": int(hip.solr_hip_get_frames_in_flight()),
                    "parallelism": "tile%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "k_standardRenderer", "kernel_ms": round(kernel_avg_ms, 5),
+                     "kernel": "k_standardRenderer", "kernel_ms": round(kernel_avg_ms, 5), "kernel_ms_basis": kernel_basis,
                      "algorithmic_bytes": algo_bytes},
     }
 

@@ -135,6 +135,16 @@ void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYI
 void solr_hip_enable_timing(int enable);
 double solr_hip_kernel_time(int *nbLaunches, int reset);
 
+/* Frames in flight.  n = 2: consecutive first-pass frames (pathTracingIteration == 0) alternate between
+ * two streams and two sets of per-pixel buffers owned by the engine, so that the tail of a frame - a
+ * few long waves on an otherwise idle chip - overlaps the start of the next one (the 100k-triangle
+ * frame: 0.76 -> 0.60 ms).  Refinement and accumulation passes stay on the set of the pass before them.
+ * d2h_bitmap and the device-pointer accessors refer to the frame rendered last; every upload waits for
+ * both streams.  Ignored (one frame in flight) while the engine runs on a caller's stream.  Default 1,
+ * the reference's behaviour. */
+void solr_hip_set_frames_in_flight(int n);
+int solr_hip_get_frames_in_flight(void);
+
 /* Cost-ordered launch.  Every wave records what its 8x8 tile cost; when recent frames of the same
  * geometry had a heavy tail (the most expensive tile > 2 x the mean) the following frames are launched
  * most-expensive-first (a one-workgroup sorting kernel every sixteenth frame).  Changes the order of work

@@ -162,6 +162,8 @@ def _declare_hip(L):
     L.solr_hip_enable_timing.argtypes = [C.c_int]
     L.solr_hip_kernel_time.argtypes = [P(C.c_int), C.c_int]
     L.solr_hip_kernel_time.restype = C.c_double
+    L.solr_hip_set_frames_in_flight.argtypes = [C.c_int]
+    L.solr_hip_get_frames_in_flight.restype = C.c_int
     L.solr_hip_set_tile_scheduling.argtypes = [C.c_int]
     L.solr_hip_tile_scheduling_active.restype = C.c_int
     L.solr_hip_enable_tile_clocks.argtypes = [C.c_int]

@@ -570,6 +570,17 @@ struct Engine
 
     /* per-pixel buffers of the strip */
     DeviceBuffer pp, ids, bitmap, counters, tileClock, tileCost, tileOrder;
+    /* Frames in flight (solr_hip_set_frames_in_flight): with 2, consecutive first-pass frames alternate
+     * between two streams and two sets of per-pixel buffers, so that the tail of one frame - a few long
+     * waves on an otherwise idle chip - overlaps the start of the next.  Set 0 is the members above. */
+    int flights = 1;
+    hipStream_t stream2 = nullptr;
+    DeviceBuffer pp2, ids2, bitmap2, tileOrder2;
+    int current = 0;           /* set / stream of the last render */
+    unsigned frameSerial = 0;
+    hipEvent_t orderEvent = nullptr; /* completion of the last tile sort */
+    bool orderWait[2] = {false, false}; /* that stream has not yet waited for it */
+    int orderBuffer = 0;       /* which of tileOrder / tileOrder2 holds the valid order */
     /* cost-ordered launch: 0 off, 1 automatic (default), 2 always */
     int tileScheduling = 1;
     unsigned *hostStats = nullptr;    /* mapped host memory, 8 words */
@@ -598,6 +609,20 @@ struct Engine
 };
 
 Engine g;
+
+bool twoFlights() { return g.flights == 2 && g.ownStream && g.stream2 != nullptr; }
+hipStream_t flightStream(int f) { return f ? g.stream2 : g.stream; }
+DeviceBuffer &flightPp(int f) { return f ? g.pp2 : g.pp; }
+DeviceBuffer &flightIds(int f) { return f ? g.ids2 : g.ids; }
+DeviceBuffer &flightBitmap(int f) { return f ? g.bitmap2 : g.bitmap; }
+/* nothing may touch scene or frame buffers while a frame is still in flight on the other stream */
+void quiesce()
+{
+    if (g.stream2)
+        (void)hipStreamSynchronize(g.stream2);
+    if (g.stream && g.ownStream)
+        (void)hipStreamSynchronize(g.stream);
+}
 
 void setError(int code, const char *what, const char *file, int line)
 {
@@ -708,11 +733,27 @@ void allocateFrame()
     reserve(g.ids, pixels * sizeof(PrimitiveXYIdBuffer));
     reserve(g.bitmap, pixels * SOLR_COLOR_DEPTH);
     reserve(g.counters, 8 * sizeof(unsigned long long));
-    if (ok() && (grow || g.allocW != g.width || g.allocRows != rows))
+    const bool fresh = grow || g.allocW != g.width || g.allocRows != rows;
+    if (ok() && fresh)
     {
         HIPCHECK(hipMemsetAsync(g.pp.ptr, 0, g.pp.bytes, g.stream));
         HIPCHECK(hipMemsetAsync(g.ids.ptr, 0, g.ids.bytes, g.stream));
         HIPCHECK(hipMemsetAsync(g.bitmap.ptr, 0, g.bitmap.bytes, g.stream));
+    }
+    if (ok() && g.flights == 2 && g.ownStream)
+    {
+        if (!g.stream2)
+            HIPCHECK(hipStreamCreate(&g.stream2));
+        const bool grow2 = pixels * sizeof(PostProcessingBuffer) > g.pp2.bytes;
+        reserve(g.pp2, pixels * sizeof(PostProcessingBuffer));
+        reserve(g.ids2, pixels * sizeof(PrimitiveXYIdBuffer));
+        reserve(g.bitmap2, pixels * SOLR_COLOR_DEPTH);
+        if (ok() && (fresh || grow2))
+        {
+            HIPCHECK(hipMemsetAsync(g.pp2.ptr, 0, g.pp2.bytes, g.stream2));
+            HIPCHECK(hipMemsetAsync(g.ids2.ptr, 0, g.ids2.bytes, g.stream2));
+            HIPCHECK(hipMemsetAsync(g.bitmap2.ptr, 0, g.bitmap2.bytes, g.stream2));
+        }
     }
     g.allocW = g.width;
     g.allocRows = rows;
@@ -890,6 +931,15 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     allocateFrame();
     if (!ok())
         return;
+    /* which stream / buffer set: first-pass frames alternate when two frames may be in flight; a
+     * refinement or accumulation pass reads what the previous pass wrote and stays where that is */
+    int flight = g.current;
+    if (twoFlights() && !counting && sceneInfo.pathTracingIteration == 0)
+        flight = (int)(g.frameSerial++ & 1u);
+    else if (!twoFlights())
+        flight = 0;
+    const hipStream_t stream = flightStream(flight);
+    g.current = flight;
 
     /* the box-debug view and the census count every node of the original tree */
     const bool full = sceneInfo.renderBoxes != 0 || sceneInfo.advancedIllumination == aiBasic ||
@@ -931,7 +981,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     F.tilesX = (sceneInfo.size.x + TILE - 1) / TILE;
     const int tilesY = (F.nbRows + TILE - 1) / TILE;
     const bool neighbourhood = (ppInfo.type == ppe_ambientOcclusion || ppInfo.type == ppe_depthOfField);
-    unsigned char *bitmap = (unsigned char *)(g.boundBitmap ? g.boundBitmap : g.bitmap.ptr);
+    unsigned char *bitmap = (unsigned char *)(g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr);
     F.fuseDefault = neighbourhood ? 0 : 1;
 
     int maxIt = (sceneInfo.graphicsLevel < glReflectionsAndRefractions)
@@ -971,6 +1021,9 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             g.orderValid = false;
             reserve(g.tileCost, (size_t)grid.x * sizeof(unsigned));
             reserve(g.tileOrder, (size_t)grid.x * sizeof(unsigned));
+            reserve(g.tileOrder2, (size_t)grid.x * sizeof(unsigned));
+            g.orderBuffer = 0;
+            g.orderWait[0] = g.orderWait[1] = false;
         }
         if (!ok())
             return;
@@ -995,15 +1048,36 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             g.orderValid = false;
         if (refresh)
         {
-            hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, g.stream, (const unsigned *)g.tileCost.ptr,
-                               (unsigned *)g.tileOrder.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev,
+            /* a new order goes to the buffer no frame in flight is reading; the other stream waits for
+             * the sort before its next frame picks that buffer up */
+            const int target = sort ? (g.orderBuffer ^ 1) : g.orderBuffer;
+            DeviceBuffer &orderOut = target ? g.tileOrder2 : g.tileOrder;
+            hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, stream, (const unsigned *)g.tileCost.ptr,
+                               (unsigned *)orderOut.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev,
                                sort ? 1 : 0);
             HIPCHECK(hipGetLastError());
             if (sort)
+            {
                 g.orderValid = true;
+                g.orderBuffer = target;
+                if (twoFlights())
+                {
+                    if (!g.orderEvent)
+                        HIPCHECK(hipEventCreateWithFlags(&g.orderEvent, hipEventDisableTiming));
+                    if (ok())
+                        HIPCHECK(hipEventRecord(g.orderEvent, stream));
+                    g.orderWait[flight ^ 1] = true;
+                    g.orderWait[flight] = false;
+                }
+            }
+        }
+        if (g.orderWait[flight] && g.orderEvent)
+        {
+            HIPCHECK(hipStreamWaitEvent(stream, g.orderEvent, 0));
+            g.orderWait[flight] = false;
         }
         if (ordered && g.orderValid)
-            F.tileOrder = (const unsigned *)g.tileOrder.ptr;
+            F.tileOrder = (const unsigned *)(g.orderBuffer ? g.tileOrder2.ptr : g.tileOrder.ptr);
         g.costFrames++;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1011,10 +1085,10 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     {
         HIPCHECK(hipEventCreate(&e0));
         HIPCHECK(hipEventCreate(&e1));
-        HIPCHECK(hipEventRecord(e0, g.stream));
+        HIPCHECK(hipEventRecord(e0, stream));
     }
-    PixelRecord *ppPtr = (PixelRecord *)g.pp.ptr;
-    int4 *idPtr = (int4 *)g.ids.ptr;
+    PixelRecord *ppPtr = (PixelRecord *)flightPp(flight).ptr;
+    int4 *idPtr = (int4 *)flightIds(flight).ptr;
     unsigned long long *cntPtr = (unsigned long long *)g.counters.ptr;
     /* smallest instantiation that covers the scene (rt_device.h, enum Feature) */
     int need = g.sceneFeatures;
@@ -1051,12 +1125,12 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             }
     }
     else
-        HIPCHECK(hipMemsetAsync(g.counters.ptr, 0, 8 * sizeof(unsigned long long), g.stream));
-    hipLaunchKernelGGL(fn, grid, block, ldsBytes, g.stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
+        HIPCHECK(hipMemsetAsync(g.counters.ptr, 0, 8 * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(fn, grid, block, ldsBytes, stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
     HIPCHECK(hipGetLastError());
     if (e0)
     {
-        HIPCHECK(hipEventRecord(e1, g.stream));
+        HIPCHECK(hipEventRecord(e1, stream));
         g.events.push_back(std::make_pair(e0, e1));
     }
 
@@ -1065,12 +1139,12 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         const int nbPixels = sceneInfo.size.x * F.nbRows;
         const dim3 pgrid((nbPixels + 255) / 256), pblock(256);
         if (ppInfo.type == ppe_ambientOcclusion)
-            hipLaunchKernelGGL(k_ambientOcclusion, pgrid, pblock, 0, g.stream, sceneInfo, ppInfo, F.nbRows,
-                               (const PixelRecord *)g.pp.ptr, (const float *)g.randoms.ptr,
+            hipLaunchKernelGGL(k_ambientOcclusion, pgrid, pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
+                               (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
                                g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
         else
-            hipLaunchKernelGGL(k_depthOfField, pgrid, pblock, 0, g.stream, sceneInfo, ppInfo, F.nbRows,
-                               (const PixelRecord *)g.pp.ptr, (const float *)g.randoms.ptr,
+            hipLaunchKernelGGL(k_depthOfField, pgrid, pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
+                               (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
                                g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
         HIPCHECK(hipGetLastError());
     }
@@ -1078,8 +1152,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     if (counting && counts)
     {
         HIPCHECK(hipMemcpyAsync(counts, g.counters.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                                g.stream));
-        HIPCHECK(hipStreamSynchronize(g.stream));
+                                stream));
+        HIPCHECK(hipStreamSynchronize(stream));
     }
 }
 
@@ -1137,6 +1211,8 @@ void solr_hip_set_device(int device)
 
 void solr_hip_set_stream(void *stream)
 {
+    quiesce();
+    g.current = 0; /* a caller's stream is the only stream: one frame in flight */
     if (g.ownStream && g.stream)
     {
         (void)hipStreamSynchronize(g.stream);
@@ -1156,10 +1232,13 @@ void solr_hip_synchronize(void)
     if (!ready("solr_hip_synchronize"))
         return;
     HIPCHECK(hipStreamSynchronize(g.stream));
+    if (g.stream2)
+        HIPCHECK(hipStreamSynchronize(g.stream2));
 }
 
 void solr_hip_set_strip(int firstRow, int nbRows)
 {
+    quiesce();
     g.firstRow = nbRows > 0 ? firstRow : 0;
     g.nbRows = nbRows > 0 ? nbRows : 0;
     if (g.initialized && g.width > 0)
@@ -1168,15 +1247,15 @@ void solr_hip_set_strip(int firstRow, int nbRows)
 
 void *solr_hip_device_bitmap(void)
 {
-    return g.boundBitmap ? g.boundBitmap : g.bitmap.ptr;
+    return g.boundBitmap ? g.boundBitmap : flightBitmap(g.current).ptr;
 }
 void *solr_hip_device_primitive_ids(void)
 {
-    return g.ids.ptr;
+    return flightIds(g.current).ptr;
 }
 void *solr_hip_device_postprocessing(void)
 {
-    return g.pp.ptr;
+    return flightPp(g.current).ptr;
 }
 void solr_hip_bind_device_bitmap(void *deviceBitmap)
 {
@@ -1225,12 +1304,24 @@ void finalize_scene(vec2i)
     (void)hipSetDevice(g.device);
     if (g.stream)
         (void)hipStreamSynchronize(g.stream);
+    if (g.stream2)
+        (void)hipStreamSynchronize(g.stream2);
     collectEvents();
     DeviceBuffer *all[] = {&g.geometry, &g.materials, &g.textures, &g.randoms, &g.lamps,
                            &g.pp,       &g.ids,       &g.bitmap,   &g.counters, &g.tileClock,
-                           &g.tileCost, &g.tileOrder};
+                           &g.tileCost, &g.tileOrder, &g.pp2,      &g.ids2,      &g.bitmap2,
+                           &g.tileOrder2};
     for (DeviceBuffer *b : all)
         release(*b);
+    if (g.stream2)
+        (void)hipStreamDestroy(g.stream2);
+    g.stream2 = nullptr;
+    if (g.orderEvent)
+        (void)hipEventDestroy(g.orderEvent);
+    g.orderEvent = nullptr;
+    g.current = 0;
+    g.orderBuffer = 0;
+    g.orderWait[0] = g.orderWait[1] = false;
     if (g.hostStats)
         (void)hipHostFree(g.hostStats);
     g.hostStats = g.hostStatsDev = nullptr;
@@ -1262,6 +1353,7 @@ void reshape_scene(vec2i, SceneInfo sceneInfo)
 {
     if (!ready("reshape_scene"))
         return;
+    quiesce();
     g.width = sceneInfo.size.x;
     g.height = sceneInfo.size.y;
     allocateFrame();
@@ -1457,6 +1549,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
 {
     if (!ready("h2d_scene"))
         return;
+    quiesce();
     ARGCHECK(nbActiveBoxes >= 0 && nbPrimitives >= 0 && nbLamps >= 0, "h2d_scene: negative count");
     ARGCHECK(nbActiveBoxes == 0 || boundingBoxes, "h2d_scene: null boxes");
     ARGCHECK(nbPrimitives == 0 || primitives, "h2d_scene: null primitives");
@@ -1602,6 +1695,7 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
 {
     if (!ready("h2d_materials"))
         return;
+    quiesce();
     ARGCHECK(nbActiveMaterials >= 0 && (nbActiveMaterials == 0 || materials), "h2d_materials: bad arguments");
     if (!ok())
         return;
@@ -1659,6 +1753,7 @@ void h2d_randoms(vec2i, float *randoms)
 {
     if (!ready("h2d_randoms"))
         return;
+    quiesce();
     ARGCHECK(randoms != nullptr, "h2d_randoms: null buffer");
     if (!ok())
         return;
@@ -1673,6 +1768,7 @@ void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
 {
     if (!ready("h2d_textures"))
         return;
+    quiesce();
     size_t total = 0;
     for (int i = 0; i < activeTextures; ++i)
         if (textureInfos[i].buffer)
@@ -1697,6 +1793,7 @@ void h2d_lightInformation(vec2i, LightInformation *lightInformation, int lightIn
 {
     if (!ready("h2d_lightInformation"))
         return;
+    quiesce();
     ARGCHECK(lightInformationSize >= 0 && (lightInformationSize == 0 || lightInformation),
              "h2d_lightInformation: bad arguments");
     if (!ok())
@@ -1723,14 +1820,16 @@ void d2h_bitmap(vec2i, SceneInfo sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdB
     const int first = g.nbRows > 0 ? g.firstRow : 0;
     const size_t pixels = (size_t)sceneInfo.size.x * rows;
     const size_t offset = (size_t)sceneInfo.size.x * first;
-    const void *src = g.boundBitmap ? g.boundBitmap : g.bitmap.ptr;
+    /* the frame rendered last: its buffer set, on its stream */
+    const hipStream_t stream = flightStream(g.current);
+    const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(g.current).ptr;
     if (bitmap && src)
         HIPCHECK(hipMemcpyAsync(bitmap + offset * SOLR_COLOR_DEPTH, src, pixels * SOLR_COLOR_DEPTH,
-                                hipMemcpyDeviceToHost, g.stream));
-    if (primitivesXYIds && g.ids.ptr)
-        HIPCHECK(hipMemcpyAsync(primitivesXYIds + offset, g.ids.ptr, pixels * sizeof(PrimitiveXYIdBuffer),
-                                hipMemcpyDeviceToHost, g.stream));
-    HIPCHECK(hipStreamSynchronize(g.stream));
+                                hipMemcpyDeviceToHost, stream));
+    if (primitivesXYIds && flightIds(g.current).ptr)
+        HIPCHECK(hipMemcpyAsync(primitivesXYIds + offset, flightIds(g.current).ptr,
+                                pixels * sizeof(PrimitiveXYIdBuffer), hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
 }
 
 void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds)
@@ -1745,30 +1844,33 @@ void solr_hip_d2h_postprocessing(PostProcessingBuffer *hostBuffer)
 {
     if (!ready("solr_hip_d2h_postprocessing"))
         return;
-    ARGCHECK(hostBuffer != nullptr && g.pp.ptr != nullptr, "solr_hip_d2h_postprocessing: no buffer");
+    ARGCHECK(hostBuffer != nullptr && flightPp(g.current).ptr != nullptr, "solr_hip_d2h_postprocessing: no buffer");
     if (!ok())
         return;
     const size_t pixels = (size_t)g.width * stripRows();
-    HIPCHECK(hipMemcpyAsync(hostBuffer, g.pp.ptr, pixels * sizeof(PostProcessingBuffer), hipMemcpyDeviceToHost,
-                            g.stream));
-    HIPCHECK(hipStreamSynchronize(g.stream));
+    HIPCHECK(hipMemcpyAsync(hostBuffer, flightPp(g.current).ptr, pixels * sizeof(PostProcessingBuffer),
+                            hipMemcpyDeviceToHost, flightStream(g.current)));
+    HIPCHECK(hipStreamSynchronize(flightStream(g.current)));
 }
 
 void solr_hip_h2d_postprocessing(const PostProcessingBuffer *hostBuffer, const PrimitiveXYIdBuffer *ids)
 {
     if (!ready("solr_hip_h2d_postprocessing"))
         return;
+    quiesce();
     allocateFrame();
     if (!ok())
         return;
+    /* into the set the next refinement / accumulation pass will read: the current one */
     const size_t pixels = (size_t)g.width * stripRows();
+    const hipStream_t stream = flightStream(g.current);
     if (hostBuffer)
-        HIPCHECK(hipMemcpyAsync(g.pp.ptr, hostBuffer, pixels * sizeof(PostProcessingBuffer), hipMemcpyHostToDevice,
-                                g.stream));
+        HIPCHECK(hipMemcpyAsync(flightPp(g.current).ptr, hostBuffer, pixels * sizeof(PostProcessingBuffer),
+                                hipMemcpyHostToDevice, stream));
     if (ids)
-        HIPCHECK(hipMemcpyAsync(g.ids.ptr, ids, pixels * sizeof(PrimitiveXYIdBuffer), hipMemcpyHostToDevice,
-                                g.stream));
-    HIPCHECK(hipStreamSynchronize(g.stream));
+        HIPCHECK(hipMemcpyAsync(flightIds(g.current).ptr, ids, pixels * sizeof(PrimitiveXYIdBuffer),
+                                hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
 }
 
 void cudaRender(vec2i, vec4i, SceneInfo sceneInfo, vec4i objects, PostProcessingInfo postProcessingInfo,
@@ -1797,6 +1899,20 @@ void solr_hip_enable_timing(int enable)
 {
     g.timing = enable > 0 ? enable : 0;
     g.timingTick = 0;
+}
+
+void solr_hip_set_frames_in_flight(int n)
+{
+    quiesce();
+    g.flights = n >= 2 ? 2 : 1;
+    g.current = 0;
+    if (g.initialized && g.width > 0)
+        allocateFrame();
+}
+
+int solr_hip_get_frames_in_flight(void)
+{
+    return twoFlights() ? 2 : 1;
 }
 
 void solr_hip_set_tile_scheduling(int mode)
@@ -1861,6 +1977,6 @@ void solr_hip_memory_usage(unsigned long long bytes[4])
     bytes[0] = g.geometry.bytes + g.lamps.bytes;
     bytes[1] = g.materials.bytes;
     bytes[2] = g.textures.bytes;
-    bytes[3] = g.pp.bytes + g.ids.bytes + g.bitmap.bytes + g.randoms.bytes;
+    bytes[3] = g.pp.bytes + g.ids.bytes + g.bitmap.bytes + g.pp2.bytes + g.ids2.bytes + g.bitmap2.bytes + g.randoms.bytes;
 }
 }

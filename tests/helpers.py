@@ -61,3 +61,16 @@ def oracle_frame(k, oracle, pp=None, ids=None, first_row=0, nb_rows=None, nthrea
 
 def f3(*v):
     return (C.c_float * 3)(*v)
+
+
+def device_frame(solr, si):
+    """Float framebuffer, primitive ids and RGB8 of the frame the engine rendered last, straight from
+    the C-ABI (for tests that render through solr_hip_render instead of the host protocol)."""
+    hip = solr.hip_lib()
+    w, h = si.size_x, si.size_y
+    pp = np.zeros((h, w, 8), np.float32)
+    ids = np.zeros((h, w, 4), np.int32)
+    rgb = np.zeros((h, w, 3), np.uint8)
+    hip.solr_hip_d2h_postprocessing(C.c_void_p(pp.ctypes.data))
+    hip.solr_hip_d2h(C.byref(si), C.c_void_p(rgb.ctypes.data), C.c_void_p(ids.ctypes.data))
+    return pp, ids, rgb

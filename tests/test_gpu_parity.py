@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import scenes_extra as X
-from helpers import assert_parity, compare_frames, gpu_frame, oracle_frame
+from helpers import assert_parity, compare_frames, device_frame, gpu_frame, oracle_frame
 
 pytestmark = pytest.mark.gpu
 solr_mod = importlib.import_module("sol-r_amd")
@@ -255,14 +255,14 @@ def test_cost_ordered_launch_changes_no_pixel(solr, oracle):
             k.check(0, "cost-ordered frame %d" % i)
             if i >= 1:
                 assert hip.solr_hip_tile_scheduling_active() == 1
-            pp, ids = k.postprocessing_buffer(), k.primitive_ids()
+            pp, ids, rgb = device_frame(solr, si)
             assert np.array_equal(pp.view(np.uint32), pp0.view(np.uint32)), i
-            assert np.array_equal(ids, ids0), i
+            assert np.array_equal(ids, ids0) and np.array_equal(rgb, rgb0), i
         hip.solr_hip_set_tile_scheduling(1)   # automatic: whatever it decides, the frame is the same
         for i in range(3):
             hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
             hip.solr_hip_synchronize()
-            pp, ids = k.postprocessing_buffer(), k.primitive_ids()
+            pp, ids, rgb = device_frame(solr, si)
             assert np.array_equal(pp.view(np.uint32), pp0.view(np.uint32)) and np.array_equal(ids, ids0), i
         opp, oids, orgb, counts, status = oracle_frame(k, oracle)
         assert status == 0
@@ -290,3 +290,56 @@ def test_blinn_exponents_outside_the_lean_pow_domain(solr, oracle):
     k, res, _ = both(solr, oracle, build)
     k.finalize()
     assert_parity(res, rgb_max_diff=1)
+
+
+def test_two_frames_in_flight(solr, oracle):
+    """solr_hip_set_frames_in_flight(2): first-pass frames alternate between two streams and buffer sets;
+    every frame read back is the frame just rendered, and refinement passes continue on the set of
+    the pass before them."""
+    import ctypes as C
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    X.sticks(k, width=136, height=72)
+    try:
+        hip.solr_hip_set_frames_in_flight(2)
+        assert hip.solr_hip_get_frames_in_flight() == 2
+        pp0, ids0, rgb0 = gpu_frame(k)
+        k.check(0, "first frame")
+        opp, oids, orgb, counts, status = oracle_frame(k, oracle)
+        assert status == 0
+        assert_parity(compare_frames(pp0, ids0, rgb0, opp, oids, orgb))
+        flat = k.flat_scene()
+        si, ppi, eye, direction, angles = k.frame_parameters()
+        objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        # a burst of first-pass frames, no synchronisation in between, from two camera positions
+        eye2 = eye.copy()
+        eye2[0] += 700.0
+        si.pathTracingIteration = 0
+        for i in range(7):
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye if i % 2 == 0 else eye2),
+                                fp(direction), fp(angles))
+        k.check(0, "burst")
+        pp, ids, rgb = device_frame(solr, si)   # frame 6: camera 1
+        assert np.array_equal(pp.view(np.uint32), pp0.view(np.uint32)) and np.array_equal(ids, ids0)
+        assert np.array_equal(rgb, rgb0)
+        hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye2), fp(direction), fp(angles))
+        pp2, ids2, _ = device_frame(solr, si)  # frame 7: camera 2, the other buffer set
+        opp2, oids2, _, _, status = oracle.render(flat, si, ppi, eye2, direction, angles, nthreads=4)
+        assert status == 0
+        assert np.array_equal(ids2, oids2) and not np.array_equal(ids2, ids0)
+        # refinement passes 1..3 continue where pass 0 of camera 2 left off
+        pp_ref, ids_ref = opp2, oids2
+        for it in (1, 2, 3):
+            si.pathTracingIteration = it
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye2), fp(direction), fp(angles))
+            pp_ref, ids_ref, _, _, status = oracle.render(flat, si, ppi, eye2, direction, angles, pp=pp_ref,
+                                                          ids=ids_ref, nthreads=4)
+            assert status == 0
+        ppn, idsn, _ = device_frame(solr, si)
+        assert np.array_equal(idsn, ids_ref)
+        from helpers import ulp_distance
+        assert int(ulp_distance(ppn[..., :3], pp_ref[..., :3]).max()) <= 1
+    finally:
+        hip.solr_hip_set_frames_in_flight(1)
+        k.finalize()

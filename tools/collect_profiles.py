@@ -25,7 +25,7 @@ for scene in ("cornell", "height_field", "molecule"):
                 meta["Kernel_Name"][:60], meta["Grid_Size"], meta["Workgroup_Size"], meta["Scratch_Size"], meta["LDS_Block_Size"]))
     if out:
         hdr = ("# rocprofv3 --pmc, three separate passes (SQ counters; FETCH_SIZE; WRITE_SIZE) of\n"
-               "#   python3 bench.py --scene %s --steps 24 --warmup 12 --no-cpu-baseline\n"
+               "#   python3 bench.py --scene %s --steps 24 --warmup 12 --no-cpu-baseline --frames-in-flight 1\n"
                "# per launch of the renderer kernel.  FETCH_SIZE / WRITE_SIZE are in KB (L2 <-> fabric requests x 64 B;\n"
                "# MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, WRITE_SIZE is exact).\n" % scene)
         open(os.path.join(dst, "pmc_%s.txt" % scene), "w").write(hdr + "\n".join(out) + "\n")
