@@ -69,16 +69,13 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
 
-    solr = importlib.import_module("sol-r_amd")
-    hip = solr.hip_lib()
-    if hip.solr_hip_device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-
     torch = dist = None
-    # SOLR_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, strip binding, pipelined gather)
-    # with a single rank: a 1-GPU box can then exercise it against RCCL
+    # SOLR_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, strip binding, gather) with a
+    # single rank: a 1-GPU box can then exercise it against RCCL
     distributed = world > 1 or os.environ.get("SOLR_BENCH_FORCE_DIST") == "1"
     if distributed:
+        # torch BEFORE the engine library: torch brings its own copy of the HIP runtime and importing it
+        # into a process in which another copy is already initialised hangs
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -87,6 +84,11 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    solr = importlib.import_module("sol-r_amd")
+    hip = solr.hip_lib()
+    if hip.solr_hip_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
 
     W, H = args.width, args.height
     first_row, nb_rows, rows_per_rank = solr.strip_rows(rank, world, H)
@@ -104,17 +106,13 @@ def main():
     hip.solr_hip_set_tile_scheduling(args.tile_scheduling)
     if not distributed:
         hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
-    sg = None
+    pipe = None
     if distributed:
-        if os.environ.get("SOLR_BENCH_NULL_STREAM") != "1":
-            # a stream of our own: the legacy default stream synchronises implicitly with others
-            torch.cuda.set_stream(torch.cuda.Stream())
-        hip.solr_hip_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        hip.solr_hip_set_strip(first_row, nb_rows)
-        # in-order gather on the render stream unless SOLR_BENCH_PIPELINED=1 (see StripGather)
-        sg = solr.StripGather(dist, torch, W, H, rank, world, device="cuda",
-                              pipelined=os.environ.get("SOLR_BENCH_PIPELINED") == "1")
-        hip.solr_hip_bind_device_bitmap(C.c_void_p(sg.buffer(0).data_ptr()))
+        # SOLR_BENCH_PIPELINED=1 is gone: two frames in flight (default) chain the gather behind the
+        # render with events while the next frame renders; --frames-in-flight 1 runs both in order on
+        # one stream
+        pipe = solr.StripPipeline(dist, torch, hip, W, H, rank, world, local_rank=local_rank,
+                                  frames_in_flight=args.frames_in_flight)
 
     # first frame through the full host protocol: uploads scene, materials, randoms
     k.L.SolRx_Render(0.0)
@@ -124,31 +122,20 @@ def main():
     objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
 
-    frame_no = [0]
-    rendered = [None, None]
+    def render():
+        hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
 
     def frame():
-        if sg is None:
-            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
-            return
-        # the renderer writes RGB8 straight into the strip buffer; then the single collective of the
-        # path: strips -> rank 0 (RCCL over xGMI), stream-ordered behind the kernel
-        i = frame_no[0]
-        frame_no[0] += 1
-        if i % 4 == 0:  # the host stays at most eight frames ahead of the GPU
-            j = (i // 4) % 2
-            if rendered[j] is not None:
-                rendered[j].synchronize()
-            rendered[j] = torch.cuda.Event()
-            rendered[j].record()
-        hip.solr_hip_bind_device_bitmap(C.c_void_p(sg.buffer(i).data_ptr()))
-        hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
-        sg.submit(i)
+        # N = 1: the renderer alone.  N > 1: the renderer writes RGB8 straight into a strip buffer and the
+        # single collective of the path - strips -> rank 0, RCCL over xGMI - follows (StripPipeline)
+        if pipe is None:
+            render()
+        else:
+            pipe.frame(render)
 
     def sync():
         if distributed:
-            sg.drain()
-            torch.cuda.synchronize()
+            pipe.drain()
         else:
             hip.solr_hip_synchronize()
 

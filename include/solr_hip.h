@@ -144,6 +144,13 @@ double solr_hip_kernel_time(int *nbLaunches, int reset);
  * the reference's behaviour. */
 void solr_hip_set_frames_in_flight(int n);
 int solr_hip_get_frames_in_flight(void);
+/* For callers that chain their own work (a collective, a copy) behind a frame without blocking the host:
+ * the HIP stream of buffer set 0 / 1, and the set the next first-pass frame will be issued on. */
+void *solr_hip_flight_stream(int flight);
+int solr_hip_next_flight(void);
+/* Two streams of the caller for the two buffer sets (e.g. two streams of a framework's pool, which the
+ * framework has already spread over the hardware queues); both stay the caller's. */
+void solr_hip_set_flight_streams(void *stream0, void *stream1);
 
 /* Cost-ordered launch.  Every wave records what its 8x8 tile cost; when recent frames of the same
  * geometry had a heavy tail (the most expensive tile > 2 x the mean) the following frames are launched

@@ -575,6 +575,7 @@ struct Engine
      * waves on an otherwise idle chip - overlaps the start of the next.  Set 0 is the members above. */
     int flights = 1;
     hipStream_t stream2 = nullptr;
+    bool callerStream2 = false; /* stream2 belongs to the caller (solr_hip_set_flight_streams) */
     DeviceBuffer pp2, ids2, bitmap2, tileOrder2;
     int current = 0;           /* set / stream of the last render */
     unsigned frameSerial = 0;
@@ -610,7 +611,7 @@ struct Engine
 
 Engine g;
 
-bool twoFlights() { return g.flights == 2 && g.ownStream && g.stream2 != nullptr; }
+bool twoFlights() { return g.flights == 2 && (g.ownStream || g.callerStream2) && g.stream2 != nullptr; }
 hipStream_t flightStream(int f) { return f ? g.stream2 : g.stream; }
 DeviceBuffer &flightPp(int f) { return f ? g.pp2 : g.pp; }
 DeviceBuffer &flightIds(int f) { return f ? g.ids2 : g.ids; }
@@ -620,7 +621,7 @@ void quiesce()
 {
     if (g.stream2)
         (void)hipStreamSynchronize(g.stream2);
-    if (g.stream && g.ownStream)
+    if (g.stream)
         (void)hipStreamSynchronize(g.stream);
 }
 
@@ -740,7 +741,7 @@ void allocateFrame()
         HIPCHECK(hipMemsetAsync(g.ids.ptr, 0, g.ids.bytes, g.stream));
         HIPCHECK(hipMemsetAsync(g.bitmap.ptr, 0, g.bitmap.bytes, g.stream));
     }
-    if (ok() && g.flights == 2 && g.ownStream)
+    if (ok() && g.flights == 2 && (g.ownStream || g.callerStream2))
     {
         if (!g.stream2)
             HIPCHECK(hipStreamCreate(&g.stream2));
@@ -1209,10 +1210,31 @@ void solr_hip_set_device(int device)
     g.device = device;
 }
 
+void solr_hip_set_flight_streams(void *stream0, void *stream1)
+{
+    quiesce();
+    g.current = 0;
+    if (g.ownStream && g.stream)
+        (void)hipStreamDestroy(g.stream);
+    if (g.stream2 && !g.callerStream2)
+        (void)hipStreamDestroy(g.stream2);
+    g.ownStream = false;
+    g.stream = (hipStream_t)stream0;
+    g.stream2 = (hipStream_t)stream1;
+    g.callerStream2 = stream1 != nullptr;
+    if (g.initialized && g.width > 0)
+        allocateFrame();
+}
+
 void solr_hip_set_stream(void *stream)
 {
     quiesce();
     g.current = 0; /* a caller's stream is the only stream: one frame in flight */
+    if (g.callerStream2)
+    {
+        g.stream2 = nullptr;
+        g.callerStream2 = false;
+    }
     if (g.ownStream && g.stream)
     {
         (void)hipStreamSynchronize(g.stream);
@@ -1283,6 +1305,11 @@ void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, 
     {
         HIPCHECK(hipStreamCreate(&g.stream));
         g.ownStream = ok();
+        /* the second stream right away: streams are dealt to the hardware queues in creation order, and two
+         * streams that share a hardware queue do not overlap (measured: created after a framework had
+         * made its pool of 32, both engine streams sat on one queue and frames in flight gained nothing) */
+        if (ok() && !g.stream2)
+            HIPCHECK(hipStreamCreate(&g.stream2));
     }
     g.initialized = ok();
     g.width = sceneInfo.size.x;
@@ -1313,9 +1340,10 @@ void finalize_scene(vec2i)
                            &g.tileOrder2};
     for (DeviceBuffer *b : all)
         release(*b);
-    if (g.stream2)
+    if (g.stream2 && !g.callerStream2)
         (void)hipStreamDestroy(g.stream2);
     g.stream2 = nullptr;
+    g.callerStream2 = false;
     if (g.orderEvent)
         (void)hipEventDestroy(g.orderEvent);
     g.orderEvent = nullptr;
@@ -1913,6 +1941,16 @@ void solr_hip_set_frames_in_flight(int n)
 int solr_hip_get_frames_in_flight(void)
 {
     return twoFlights() ? 2 : 1;
+}
+
+void *solr_hip_flight_stream(int flight)
+{
+    return (void *)flightStream(flight ? 1 : 0);
+}
+
+int solr_hip_next_flight(void)
+{
+    return twoFlights() ? (int)(g.frameSerial & 1u) : 0;
 }
 
 void solr_hip_set_tile_scheduling(int mode)
