@@ -1976,9 +1976,9 @@ int solr_hip_tile_clocks(unsigned long long *clocks, int capacityTiles)
     if (!g.initialized || !g.tileClock.ptr || !clocks || capacityTiles <= 0)
         return 0;
     const int n = g.nbTilesTimed < capacityTiles ? g.nbTilesTimed : capacityTiles;
-    if (hipStreamSynchronize(g.stream) != hipSuccess ||
-        hipMemcpy(clocks, g.tileClock.ptr, (size_t)n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) !=
-            hipSuccess)
+    quiesce();
+    if (hipMemcpy(clocks, g.tileClock.ptr, (size_t)n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) !=
+        hipSuccess)
         return 0;
     return n;
 }

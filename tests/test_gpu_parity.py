@@ -343,3 +343,40 @@ def test_two_frames_in_flight(solr, oracle):
     finally:
         hip.solr_hip_set_frames_in_flight(1)
         k.finalize()
+
+
+def test_post_processing_and_strips_with_two_frames_in_flight(solr, oracle):
+    """The neighbourhood post-process and a row strip on both buffer sets of the two-frame mode."""
+    import ctypes as C
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    k.set_post_processing(type=solr_mod.ppe_ambientOcclusion, param1=0.0, param2=10.0, param3=0)
+    solr.scenes.cornell(k, width=96, height=64, iterations=2)
+    try:
+        hip.solr_hip_set_frames_in_flight(2)
+        pp0, ids0, rgb0 = gpu_frame(k)
+        opp, oids, orgb, counts, status = oracle_frame(k, oracle)
+        assert status == 0
+        assert_parity(compare_frames(pp0, ids0, rgb0, opp, oids, orgb))
+        flat = k.flat_scene()
+        si, ppi, eye, direction, angles = k.frame_parameters()
+        si.pathTracingIteration = 0
+        objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        for i in range(3):   # sets 1, 0, 1
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+            pp, ids, rgb = device_frame(solr, si)
+            assert np.array_equal(rgb, rgb0) and np.array_equal(ids, ids0), i
+            assert np.array_equal(pp.view(np.uint32), pp0.view(np.uint32)), i
+        # a strip of rows 16..47 on each set
+        hip.solr_hip_set_strip(16, 32)
+        for i in range(2):
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+            k.check(0, "strip frame")
+            spp = np.zeros((32, 96, 8), np.float32)
+            hip.solr_hip_d2h_postprocessing(C.c_void_p(spp.ctypes.data))
+            assert np.array_equal(spp.view(np.uint32), pp0[16:48].view(np.uint32)), i
+    finally:
+        hip.solr_hip_set_strip(0, 0)
+        hip.solr_hip_set_frames_in_flight(1)
+        k.finalize()
