@@ -44,10 +44,10 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--graphics-level", type=int, default=4, help="experiments only; the metric is quoted at 4 (glFull)")
     ap.add_argument("--tile-scheduling", type=int, default=1, help="0 raster order, 1 automatic (default), 2 cost order")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="2 (default): consecutive frames alternate between two streams and buffer sets of the engine, "
-                         "so a frame's tail overlaps the next frame's start; 1: the reference's one frame at a time. "
-                         "Ignored at N > 1 (the engine runs on torch's stream there)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="consecutive frames rotate over this many streams and buffer sets of the engine, so a "
+                         "frame's tail overlaps the next frame's start; 1: the reference's one frame at a time. "
+                         "Default: 2 at N = 1, 3 at N > 1 (strips are one round of waves with a long tail)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -104,13 +104,14 @@ def main():
         k.set_scene_info(graphicsLevel=args.graphics_level)
     hip.solr_hip_set_variant(args.variant)
     hip.solr_hip_set_tile_scheduling(args.tile_scheduling)
+    if args.frames_in_flight <= 0:
+        args.frames_in_flight = 3 if distributed else 2
     if not distributed:
         hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
     pipe = None
     if distributed:
-        # SOLR_BENCH_PIPELINED=1 is gone: two frames in flight (default) chain the gather behind the
-        # render with events while the next frame renders; --frames-in-flight 1 runs both in order on
-        # one stream
+        # every frame: render on one of the engine's streams, then the gather in order on that same
+        # stream, while the next frames render on the other streams (StripPipeline)
         pipe = solr.StripPipeline(dist, torch, hip, W, H, rank, world, local_rank=local_rank,
                                   frames_in_flight=args.frames_in_flight)
 
@@ -176,7 +177,7 @@ def main():
     launches = C.c_int(0)
     kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
     kernel_basis = "HIP events around every launch of the timed region"
-    if not distributed and hip.solr_hip_get_frames_in_flight() == 2:
+    if not distributed and hip.solr_hip_get_frames_in_flight() > 1:
         # with two frames in flight consecutive launches overlap and an event pair around one of them
         # spans parts of two frames; the kernel's own duration is taken from a short one-at-a-time
         # segment after the timed region (same frame, same buffers)
@@ -190,7 +191,7 @@ def main():
         sync()
         hip.solr_hip_enable_timing(0)
         kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
-        hip.solr_hip_set_frames_in_flight(2)
+        hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
         kernel_basis = "HIP events around each of 16 launches issued one at a time after the timed region"
 
     rays_total = rays_local

@@ -135,10 +135,10 @@ void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYI
 void solr_hip_enable_timing(int enable);
 double solr_hip_kernel_time(int *nbLaunches, int reset);
 
-/* Frames in flight.  n = 2: consecutive first-pass frames (pathTracingIteration == 0) alternate between
- * two streams and two sets of per-pixel buffers owned by the engine, so that the tail of a frame - a
- * few long waves on an otherwise idle chip - overlaps the start of the next one (the 100k-triangle
- * frame: 0.76 -> 0.60 ms).  Refinement and accumulation passes stay on the set of the pass before them.
+/* Frames in flight.  n = 2..4: consecutive first-pass frames (pathTracingIteration == 0) rotate over n
+ * streams and n sets of per-pixel buffers owned by the engine, so that the tail of a frame - a few long
+ * waves on an otherwise idle chip - overlaps the start of the next one (the 100k-triangle frame:
+ * 0.76 -> 0.60 ms with two).  Refinement and accumulation passes stay on the set of the pass before them.
  * d2h_bitmap and the device-pointer accessors refer to the frame rendered last; every upload waits for
  * both streams.  Ignored (one frame in flight) while the engine runs on a caller's stream.  Default 1,
  * the reference's behaviour. */
@@ -148,9 +148,9 @@ int solr_hip_get_frames_in_flight(void);
  * the HIP stream of buffer set 0 / 1, and the set the next first-pass frame will be issued on. */
 void *solr_hip_flight_stream(int flight);
 int solr_hip_next_flight(void);
-/* Two streams of the caller for the two buffer sets (e.g. two streams of a framework's pool, which the
- * framework has already spread over the hardware queues); both stay the caller's. */
-void solr_hip_set_flight_streams(void *stream0, void *stream1);
+/* n streams of the caller for the buffer sets (e.g. streams of a framework's pool, which the framework
+ * has already spread over the hardware queues); they stay the caller's. */
+void solr_hip_set_flight_streams(void *const *streams, int n);
 
 /* Cost-ordered launch.  Every wave records what its 8x8 tile cost; when recent frames of the same
  * geometry had a heavy tail (the most expensive tile > 2 x the mean) the following frames are launched

@@ -167,7 +167,7 @@ def _declare_hip(L):
     L.solr_hip_flight_stream.argtypes = [C.c_int]
     L.solr_hip_flight_stream.restype = C.c_void_p
     L.solr_hip_next_flight.restype = C.c_int
-    L.solr_hip_set_flight_streams.argtypes = [C.c_void_p, C.c_void_p]
+    L.solr_hip_set_flight_streams.argtypes = [P(C.c_void_p), C.c_int]
     L.solr_hip_set_tile_scheduling.argtypes = [C.c_int]
     L.solr_hip_tile_scheduling_active.restype = C.c_int
     L.solr_hip_enable_tile_clocks.argtypes = [C.c_int]
@@ -512,80 +512,61 @@ class StripGather:
 class StripPipeline:
     """One rank of the N-GPU frame loop: render this rank's strip, gather the strips on `dst`.
 
-    Two frames in flight: the engine renders on its own two streams (solr_hip_set_frames_in_flight(2)),
-    alternating two strip buffers, and the gather of frame i - in order on torch's current stream - is
-    chained behind render i with an event, while render i+1 already runs on the engine's other stream.
-    A strip of a 1080p frame is one round of waves whose tail leaves most of the chip idle (DESIGN.md
-    section 6): overlapping consecutive frames is what fills it.  The host never blocks except to stay
-    at most eight frames ahead.  frames_in_flight=1: the engine renders on torch's current stream and
-    the gather follows in order on that same stream (no events at all)."""
+    frames_in_flight = K > 1: the engine renders consecutive frames on K streams of torch's pool
+    (solr_hip_set_flight_streams; torch has spread its pool over the hardware queues), each with a strip
+    buffer of its own, and the gather of a frame is issued IN ORDER ON THE STREAM THAT RENDERED IT, right
+    behind the kernel: no event between streams anywhere, a strip buffer is reused only by the next frame
+    of the same stream, and while stream f waits for its gather the other streams render.  A strip of a
+    1080p frame is one round of waves whose tail leaves most of the chip idle:
+    overlapping consecutive frames is what fills it.  Collectives are still issued in frame order, the
+    same on every rank.  The host never blocks except to stay at most eight frames ahead.
+    frames_in_flight = 1: one stream, render and gather in order on it."""
 
-    def __init__(self, dist, torch, hip, width, height, rank, world, local_rank=0, dst=0, frames_in_flight=2):
+    def __init__(self, dist, torch, hip, width, height, rank, world, local_rank=0, dst=0, frames_in_flight=3):
         self.dist, self.torch, self.hip = dist, torch, hip
-        self.two = frames_in_flight == 2
+        self.flights = max(1, min(int(frames_in_flight), 4))
         self.device = local_rank
-        self.stream = torch.cuda.Stream(device=local_rank)   # the gathers run here
-        torch.cuda.set_stream(self.stream)
-        if self.two:
-            # two streams of torch's pool for the engine: torch has spread its pool over the hardware
-            # queues, whereas two streams the engine creates itself this late end up on one queue and
-            # then do not overlap (measured with rocprofv3)
-            self.render_streams = [torch.cuda.Stream(device=local_rank), torch.cuda.Stream(device=local_rank)]
-            hip.solr_hip_set_flight_streams(C.c_void_p(self.render_streams[0].cuda_stream),
-                                            C.c_void_p(self.render_streams[1].cuda_stream))
-            hip.solr_hip_set_frames_in_flight(2)
+        self.streams = [torch.cuda.Stream(device=local_rank) for _ in range(self.flights)]
+        torch.cuda.set_stream(self.streams[0])
+        if self.flights > 1:
+            pointers = (C.c_void_p * self.flights)(*[s.cuda_stream for s in self.streams])
+            hip.solr_hip_set_flight_streams(pointers, self.flights)
+            hip.solr_hip_set_frames_in_flight(self.flights)
         else:
             hip.solr_hip_set_frames_in_flight(1)
-            hip.solr_hip_set_stream(C.c_void_p(self.stream.cuda_stream))
-        # four strip buffers for two frames in flight: a frame then never waits for the gather of the
-        # frame two before it (two event hops, about 40 us), only for that of the frame four before it
-        self.depth = 4 if self.two else 2
+            hip.solr_hip_set_stream(C.c_void_p(self.streams[0].cuda_stream))
         self.sg = StripGather(dist, torch, width, height, rank, world, device="cuda:%d" % local_rank, dst=dst,
-                              depth=self.depth, pipelined=False)
+                              depth=self.flights, pipelined=False)
         hip.solr_hip_set_strip(self.sg.first_row, self.sg.nb_rows)
         hip.solr_hip_bind_device_bitmap(C.c_void_p(self.sg.strips[0].data_ptr()))
-        self.gathered = [None] * self.depth
         self.throttle = [None, None]
+        self.slot = {}
         self.frame_no = 0
 
-    def _engine_stream(self, flight):
-        return self.render_streams[flight]
-
     def frame(self, render):
-        """render() issues one solr_hip_render / cudaRender; returns the frame number"""
+        """render() issues one solr_hip_render / cudaRender of a first-pass frame; returns the frame number"""
         i = self.frame_no
         self.frame_no += 1
-        b = i % self.depth
         torch = self.torch
+        f = self.hip.solr_hip_next_flight() if self.flights > 1 else 0   # the stream / buffer set of this frame
+        stream = self.streams[f]
         if i % 4 == 0:   # the host stays at most eight frames ahead of the GPU
             j = (i // 4) % 2
             if self.throttle[j] is not None:
                 self.throttle[j].synchronize()
             self.throttle[j] = torch.cuda.Event()
-            self.throttle[j].record(self.stream)
-        self.hip.solr_hip_bind_device_bitmap(C.c_void_p(self.sg.strips[b].data_ptr()))
-        if not self.two:
-            render()
-            self.sg.submit(i)
-            return i
-        # a fresh event for every record: an event that is recorded again while a wait on its previous
-        # record is still queued is exactly how two streams end up waiting for each other
-        es = self._engine_stream(self.hip.solr_hip_next_flight())
-        if self.gathered[b] is not None:
-            es.wait_event(self.gathered[b])      # strip buffer b: its last gather has read it
+            self.throttle[j].record(stream)
+        self.hip.solr_hip_bind_device_bitmap(C.c_void_p(self.sg.strips[f].data_ptr()))
         render()
-        rendered = torch.cuda.Event()
-        rendered.record(es)
-        self.stream.wait_event(rendered)
-        self.sg.submit(i)                        # in order on self.stream
-        self.gathered[b] = torch.cuda.Event()
-        self.gathered[b].record(self.stream)
+        torch.cuda.set_stream(stream)
+        self.sg.submit(f)            # blocking-semantics gather: in order on `stream`, behind the kernel
+        self.slot[i % 64] = f
         return i
 
     def image(self, i):
-        """assembled frame i on dst (a view, valid until frame i + depth is gathered); synchronises"""
+        """assembled frame i on dst (a view, valid until `flights` more frames are gathered); synchronises"""
         self.torch.cuda.synchronize(self.device)
-        return self.sg.image(i)
+        return self.sg.image(self.slot[i % 64])
 
     def drain(self):
         self.sg.drain()

@@ -570,17 +570,17 @@ struct Engine
 
     /* per-pixel buffers of the strip */
     DeviceBuffer pp, ids, bitmap, counters, tileClock, tileCost, tileOrder;
-    /* Frames in flight (solr_hip_set_frames_in_flight): with 2, consecutive first-pass frames alternate
-     * between two streams and two sets of per-pixel buffers, so that the tail of one frame - a few long
-     * waves on an otherwise idle chip - overlaps the start of the next.  Set 0 is the members above. */
+    /* Frames in flight (solr_hip_set_frames_in_flight): with n > 1, consecutive first-pass frames rotate
+     * over n streams and n sets of per-pixel buffers, so that the tail of one frame - a few long waves
+     * on an otherwise idle chip - overlaps the start of the next.  Set 0 is the members above. */
     int flights = 1;
-    hipStream_t stream2 = nullptr;
-    bool callerStream2 = false; /* stream2 belongs to the caller (solr_hip_set_flight_streams) */
-    DeviceBuffer pp2, ids2, bitmap2, tileOrder2;
+    hipStream_t extraStream[3] = {nullptr, nullptr, nullptr}; /* streams of sets 1..3 */
+    bool callerStreams = false; /* the streams belong to the caller (solr_hip_set_flight_streams) */
+    DeviceBuffer ppX[3], idsX[3], bitmapX[3], tileOrder2;
     int current = 0;           /* set / stream of the last render */
     unsigned frameSerial = 0;
     hipEvent_t orderEvent = nullptr; /* completion of the last tile sort */
-    bool orderWait[2] = {false, false}; /* that stream has not yet waited for it */
+    bool orderWait[4] = {false, false, false, false}; /* that stream has not yet waited for it */
     int orderBuffer = 0;       /* which of tileOrder / tileOrder2 holds the valid order */
     /* cost-ordered launch: 0 off, 1 automatic (default), 2 always */
     int tileScheduling = 1;
@@ -611,16 +611,28 @@ struct Engine
 
 Engine g;
 
-bool twoFlights() { return g.flights == 2 && (g.ownStream || g.callerStream2) && g.stream2 != nullptr; }
-hipStream_t flightStream(int f) { return f ? g.stream2 : g.stream; }
-DeviceBuffer &flightPp(int f) { return f ? g.pp2 : g.pp; }
-DeviceBuffer &flightIds(int f) { return f ? g.ids2 : g.ids; }
-DeviceBuffer &flightBitmap(int f) { return f ? g.bitmap2 : g.bitmap; }
+const int MAX_FLIGHTS = 4;
+/* how many frames may really be in flight: what was asked for, as far as streams exist */
+int activeFlights()
+{
+    if (g.flights < 2 || !(g.ownStream || g.callerStreams))
+        return 1;
+    int n = 1;
+    while (n < g.flights && n < MAX_FLIGHTS && g.extraStream[n - 1])
+        ++n;
+    return n;
+}
+bool twoFlights() { return activeFlights() > 1; }
+hipStream_t flightStream(int f) { return f ? g.extraStream[f - 1] : g.stream; }
+DeviceBuffer &flightPp(int f) { return f ? g.ppX[f - 1] : g.pp; }
+DeviceBuffer &flightIds(int f) { return f ? g.idsX[f - 1] : g.ids; }
+DeviceBuffer &flightBitmap(int f) { return f ? g.bitmapX[f - 1] : g.bitmap; }
 /* nothing may touch scene or frame buffers while a frame is still in flight on the other stream */
 void quiesce()
 {
-    if (g.stream2)
-        (void)hipStreamSynchronize(g.stream2);
+    for (hipStream_t extra : g.extraStream)
+        if (extra)
+            (void)hipStreamSynchronize(extra);
     if (g.stream)
         (void)hipStreamSynchronize(g.stream);
 }
@@ -741,21 +753,26 @@ void allocateFrame()
         HIPCHECK(hipMemsetAsync(g.ids.ptr, 0, g.ids.bytes, g.stream));
         HIPCHECK(hipMemsetAsync(g.bitmap.ptr, 0, g.bitmap.bytes, g.stream));
     }
-    if (ok() && g.flights == 2 && (g.ownStream || g.callerStream2))
-    {
-        if (!g.stream2)
-            HIPCHECK(hipStreamCreate(&g.stream2));
-        const bool grow2 = pixels * sizeof(PostProcessingBuffer) > g.pp2.bytes;
-        reserve(g.pp2, pixels * sizeof(PostProcessingBuffer));
-        reserve(g.ids2, pixels * sizeof(PrimitiveXYIdBuffer));
-        reserve(g.bitmap2, pixels * SOLR_COLOR_DEPTH);
-        if (ok() && (fresh || grow2))
+    if (ok() && g.flights >= 2 && (g.ownStream || g.callerStreams))
+        for (int f = 1; f < g.flights && f < MAX_FLIGHTS; ++f)
         {
-            HIPCHECK(hipMemsetAsync(g.pp2.ptr, 0, g.pp2.bytes, g.stream2));
-            HIPCHECK(hipMemsetAsync(g.ids2.ptr, 0, g.ids2.bytes, g.stream2));
-            HIPCHECK(hipMemsetAsync(g.bitmap2.ptr, 0, g.bitmap2.bytes, g.stream2));
+            if (!g.extraStream[f - 1])
+            {
+                if (g.callerStreams)
+                    break; /* the caller gave fewer streams */
+                HIPCHECK(hipStreamCreate(&g.extraStream[f - 1]));
+            }
+            const bool growX = pixels * sizeof(PostProcessingBuffer) > g.ppX[f - 1].bytes;
+            reserve(g.ppX[f - 1], pixels * sizeof(PostProcessingBuffer));
+            reserve(g.idsX[f - 1], pixels * sizeof(PrimitiveXYIdBuffer));
+            reserve(g.bitmapX[f - 1], pixels * SOLR_COLOR_DEPTH);
+            if (ok() && (fresh || growX))
+            {
+                HIPCHECK(hipMemsetAsync(g.ppX[f - 1].ptr, 0, g.ppX[f - 1].bytes, g.extraStream[f - 1]));
+                HIPCHECK(hipMemsetAsync(g.idsX[f - 1].ptr, 0, g.idsX[f - 1].bytes, g.extraStream[f - 1]));
+                HIPCHECK(hipMemsetAsync(g.bitmapX[f - 1].ptr, 0, g.bitmapX[f - 1].bytes, g.extraStream[f - 1]));
+            }
         }
-    }
     g.allocW = g.width;
     g.allocRows = rows;
 }
@@ -936,7 +953,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
      * refinement or accumulation pass reads what the previous pass wrote and stays where that is */
     int flight = g.current;
     if (twoFlights() && !counting && sceneInfo.pathTracingIteration == 0)
-        flight = (int)(g.frameSerial++ & 1u);
+        flight = (int)(g.frameSerial++ % (unsigned)activeFlights());
     else if (!twoFlights())
         flight = 0;
     const hipStream_t stream = flightStream(flight);
@@ -1024,7 +1041,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             reserve(g.tileOrder, (size_t)grid.x * sizeof(unsigned));
             reserve(g.tileOrder2, (size_t)grid.x * sizeof(unsigned));
             g.orderBuffer = 0;
-            g.orderWait[0] = g.orderWait[1] = false;
+            for (bool &w : g.orderWait)
+                w = false;
         }
         if (!ok())
             return;
@@ -1067,8 +1085,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                         HIPCHECK(hipEventCreateWithFlags(&g.orderEvent, hipEventDisableTiming));
                     if (ok())
                         HIPCHECK(hipEventRecord(g.orderEvent, stream));
-                    g.orderWait[flight ^ 1] = true;
-                    g.orderWait[flight] = false;
+                    for (int f = 0; f < MAX_FLIGHTS; ++f)
+                        g.orderWait[f] = (f != flight);
                 }
             }
         }
@@ -1210,18 +1228,31 @@ void solr_hip_set_device(int device)
     g.device = device;
 }
 
-void solr_hip_set_flight_streams(void *stream0, void *stream1)
+void dropExtraStreams()
+{
+    for (hipStream_t &extra : g.extraStream)
+    {
+        if (extra && !g.callerStreams)
+            (void)hipStreamDestroy(extra);
+        extra = nullptr;
+    }
+    g.callerStreams = false;
+}
+
+void solr_hip_set_flight_streams(void *const *streams, int n)
 {
     quiesce();
     g.current = 0;
+    if (!streams || n < 1 || !streams[0])
+        return;
     if (g.ownStream && g.stream)
         (void)hipStreamDestroy(g.stream);
-    if (g.stream2 && !g.callerStream2)
-        (void)hipStreamDestroy(g.stream2);
+    dropExtraStreams();
     g.ownStream = false;
-    g.stream = (hipStream_t)stream0;
-    g.stream2 = (hipStream_t)stream1;
-    g.callerStream2 = stream1 != nullptr;
+    g.stream = (hipStream_t)streams[0];
+    for (int f = 1; f < n && f < MAX_FLIGHTS; ++f)
+        g.extraStream[f - 1] = (hipStream_t)streams[f];
+    g.callerStreams = n > 1;
     if (g.initialized && g.width > 0)
         allocateFrame();
 }
@@ -1230,11 +1261,8 @@ void solr_hip_set_stream(void *stream)
 {
     quiesce();
     g.current = 0; /* a caller's stream is the only stream: one frame in flight */
-    if (g.callerStream2)
-    {
-        g.stream2 = nullptr;
-        g.callerStream2 = false;
-    }
+    if (g.callerStreams)
+        dropExtraStreams();
     if (g.ownStream && g.stream)
     {
         (void)hipStreamSynchronize(g.stream);
@@ -1254,8 +1282,9 @@ void solr_hip_synchronize(void)
     if (!ready("solr_hip_synchronize"))
         return;
     HIPCHECK(hipStreamSynchronize(g.stream));
-    if (g.stream2)
-        HIPCHECK(hipStreamSynchronize(g.stream2));
+    for (hipStream_t extra : g.extraStream)
+        if (extra)
+            HIPCHECK(hipStreamSynchronize(extra));
 }
 
 void solr_hip_set_strip(int firstRow, int nbRows)
@@ -1305,11 +1334,12 @@ void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, 
     {
         HIPCHECK(hipStreamCreate(&g.stream));
         g.ownStream = ok();
-        /* the second stream right away: streams are dealt to the hardware queues in creation order, and two
+        /* the other streams right away: streams are dealt to the hardware queues in creation order, and
          * streams that share a hardware queue do not overlap (measured: created after a framework had
          * made its pool of 32, both engine streams sat on one queue and frames in flight gained nothing) */
-        if (ok() && !g.stream2)
-            HIPCHECK(hipStreamCreate(&g.stream2));
+        for (int f = 1; f < MAX_FLIGHTS && ok(); ++f)
+            if (!g.extraStream[f - 1])
+                HIPCHECK(hipStreamCreate(&g.extraStream[f - 1]));
     }
     g.initialized = ok();
     g.width = sceneInfo.size.x;
@@ -1331,25 +1361,29 @@ void finalize_scene(vec2i)
     (void)hipSetDevice(g.device);
     if (g.stream)
         (void)hipStreamSynchronize(g.stream);
-    if (g.stream2)
-        (void)hipStreamSynchronize(g.stream2);
+    for (hipStream_t extra : g.extraStream)
+        if (extra)
+            (void)hipStreamSynchronize(extra);
     collectEvents();
     DeviceBuffer *all[] = {&g.geometry, &g.materials, &g.textures, &g.randoms, &g.lamps,
                            &g.pp,       &g.ids,       &g.bitmap,   &g.counters, &g.tileClock,
-                           &g.tileCost, &g.tileOrder, &g.pp2,      &g.ids2,      &g.bitmap2,
-                           &g.tileOrder2};
+                           &g.tileCost, &g.tileOrder, &g.tileOrder2};
     for (DeviceBuffer *b : all)
         release(*b);
-    if (g.stream2 && !g.callerStream2)
-        (void)hipStreamDestroy(g.stream2);
-    g.stream2 = nullptr;
-    g.callerStream2 = false;
+    for (int f = 0; f < MAX_FLIGHTS - 1; ++f)
+    {
+        release(g.ppX[f]);
+        release(g.idsX[f]);
+        release(g.bitmapX[f]);
+    }
+    dropExtraStreams();
     if (g.orderEvent)
         (void)hipEventDestroy(g.orderEvent);
     g.orderEvent = nullptr;
     g.current = 0;
     g.orderBuffer = 0;
-    g.orderWait[0] = g.orderWait[1] = false;
+    for (bool &w : g.orderWait)
+        w = false;
     if (g.hostStats)
         (void)hipHostFree(g.hostStats);
     g.hostStats = g.hostStatsDev = nullptr;
@@ -1932,7 +1966,7 @@ void solr_hip_enable_timing(int enable)
 void solr_hip_set_frames_in_flight(int n)
 {
     quiesce();
-    g.flights = n >= 2 ? 2 : 1;
+    g.flights = n < 1 ? 1 : (n > MAX_FLIGHTS ? MAX_FLIGHTS : n);
     g.current = 0;
     if (g.initialized && g.width > 0)
         allocateFrame();
@@ -1940,17 +1974,17 @@ void solr_hip_set_frames_in_flight(int n)
 
 int solr_hip_get_frames_in_flight(void)
 {
-    return twoFlights() ? 2 : 1;
+    return activeFlights();
 }
 
 void *solr_hip_flight_stream(int flight)
 {
-    return (void *)flightStream(flight ? 1 : 0);
+    return (flight >= 0 && flight < MAX_FLIGHTS) ? (void *)flightStream(flight) : nullptr;
 }
 
 int solr_hip_next_flight(void)
 {
-    return twoFlights() ? (int)(g.frameSerial & 1u) : 0;
+    return twoFlights() ? (int)(g.frameSerial % (unsigned)activeFlights()) : 0;
 }
 
 void solr_hip_set_tile_scheduling(int mode)
@@ -2015,6 +2049,8 @@ void solr_hip_memory_usage(unsigned long long bytes[4])
     bytes[0] = g.geometry.bytes + g.lamps.bytes;
     bytes[1] = g.materials.bytes;
     bytes[2] = g.textures.bytes;
-    bytes[3] = g.pp.bytes + g.ids.bytes + g.bitmap.bytes + g.pp2.bytes + g.ids2.bytes + g.bitmap2.bytes + g.randoms.bytes;
+    bytes[3] = g.pp.bytes + g.ids.bytes + g.bitmap.bytes + g.randoms.bytes;
+    for (int f = 0; f < MAX_FLIGHTS - 1; ++f)
+        bytes[3] += g.ppX[f].bytes + g.idsX[f].bytes + g.bitmapX[f].bytes;
 }
 }

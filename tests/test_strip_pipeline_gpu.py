@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("flights", [2, 1])
+@pytest.mark.parametrize("flights", [3, 2, 1])
 def test_gathered_frames_are_the_rendered_frames(flights):
     res = subprocess.run([sys.executable, os.path.join(HERE, "strip_pipeline_worker.py"), str(flights)],
                          capture_output=True, text=True, timeout=600)
