@@ -177,6 +177,9 @@ def main():
     launches = C.c_int(0)
     kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
     kernel_basis = "HIP events around every launch of the timed region"
+    if distributed and args.frames_in_flight > 1:
+        kernel_basis = ("HIP events around every fourth launch of the timed region; with %d frames in flight the launches "
+                        "overlap, so this is the latency of a launch, not its share of the GPU" % args.frames_in_flight)
     if not distributed and hip.solr_hip_get_frames_in_flight() > 1:
         # with two frames in flight consecutive launches overlap and an event pair around one of them
         # spans parts of two frames; the kernel's own duration is taken from a short one-at-a-time
