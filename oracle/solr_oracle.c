@@ -1875,6 +1875,101 @@ static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, cons
     makeColor(si, localColor, bitmap, index);
 }
 
+/* ref CRT:1189-1228.  Random gathers over the frame, weighted by the emissive word of the pixel
+ * they land on.  randoms is indexed with the reference's expressions (rnd() returns 0 out of range). */
+static void postRadiosity(const OracleScene *s, const SceneInfo *si, const PostProcessingInfo *ppi,
+                          const PostProcessingBuffer *pp, const PrimitiveXYIdBuffer *ids, BitmapBuffer *bitmap, int x,
+                          int y, int rows, Stats *st)
+{
+    int index = y * si->size.x + x;
+    int wh = si->size.x * rows;
+    int div = (si->pathTracingIteration > NB_MAX_ITERATIONS) ? (si->pathTracingIteration - NB_MAX_ITERATIONS + 1) : 1;
+    c3 localColor = {0.f, 0.f, 0.f};
+    for (int i = 0; i < ppi->param3; ++i)
+    {
+        int ix = (i + si->pathTracingIteration) % wh;
+        int iy = (i + 100 + si->pathTracingIteration) % wh;
+        int xx = (int)((float)x + rnd(s, ix, st) * ppi->param2);
+        int yy = (int)((float)y + rnd(s, iy, st) * ppi->param2);
+        localColor.x += pp[index].colorInfo.x;
+        localColor.y += pp[index].colorInfo.y;
+        localColor.z += pp[index].colorInfo.z;
+        if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
+        {
+            int localIndex = yy * si->size.x + xx;
+            float w = (float)ids[localIndex].z;
+            localColor.x += pp[localIndex].colorInfo.x * w / 256.f;
+            localColor.y += pp[localIndex].colorInfo.y * w / 256.f;
+            localColor.z += pp[localIndex].colorInfo.z * w / 256.f;
+        }
+    }
+    localColor.x /= (float)ppi->param3;
+    localColor.y /= (float)ppi->param3;
+    localColor.z /= (float)ppi->param3;
+    localColor.x /= (float)div;
+    localColor.y /= (float)div;
+    localColor.z /= (float)div;
+    saturate3(&localColor);
+    makeColor(si, localColor, bitmap, index);
+}
+
+/* ref CRT:1236-1333: six convolution filters selected by param3, wrapping around the frame */
+static void postFilter(const SceneInfo *si, const PostProcessingInfo *ppi, const PostProcessingBuffer *pp,
+                       BitmapBuffer *bitmap, int x, int y, int rows)
+{
+    enum { NB_FILTERS = 6 };
+    static const int filterSize[NB_FILTERS][2] = {{3, 3}, {5, 5}, {3, 3}, {3, 3}, {5, 5}, {5, 5}};
+    static const float filterFactors[NB_FILTERS][2] = {{1.f, 128.f}, {1.f, 0.f}, {1.f, 0.f},
+                                                       {1.f, 0.f},   {0.2f, 0.f}, {0.125f, 0.f}};
+    static const float filterInfo[NB_FILTERS][5][5] = {
+        {{-1.f, -1.f, 0.f, 0.f, 0.f}, {-1.f, 0.f, 1.f, 0.f, 0.f}, {0.f, 1.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
+        {{0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {-1.f, -1.f, 2.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
+        {{-1.f, -1.f, -1.f, 0.f, 0.f}, {-1.f, 9.f, -1.f, 0.f, 0.f}, {-1.f, -1.f, -1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
+        {{0.f, 0.2f, 0.f, 0.f, 0.f}, {0.2f, 0.2f, 0.2f, 0.f, 0.f}, {0.f, 0.2f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
+        {{1.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 1.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 1.f}},
+        {{-1.f, -1.f, -1.f, -1.f, -1.f}, {-1.f, 2.f, 2.f, 2.f, -1.f}, {-1.f, 2.f, 8.f, 2.f, -1.f}, {-1.f, 2.f, 2.f, 2.f, -1.f}, {-1.f, -1.f, -1.f, -1.f, -1.f}}};
+    int index = y * si->size.x + x;
+    c3 localColor = {0.f, 0.f, 0.f};
+    c3 color = {0.f, 0.f, 0.f};
+    const int f = ppi->param3;
+    if (f >= 0 && f < NB_FILTERS) /* the reference compares as unsigned: negative values select nothing either */
+    {
+        for (int filterX = 0; filterX < filterSize[f][0]; filterX++)
+            for (int filterY = 0; filterY < filterSize[f][1]; filterY++)
+            {
+                int imageX = (x - filterSize[f][0] / 2 + filterX + si->size.x) % si->size.x;
+                int imageY = (y - filterSize[f][1] / 2 + filterY + rows) % rows;
+                int localIndex = imageY * si->size.x + imageX;
+                c3 c = {pp[localIndex].colorInfo.x, pp[localIndex].colorInfo.y, pp[localIndex].colorInfo.z};
+                if (si->pathTracingIteration > NB_MAX_ITERATIONS)
+                {
+                    float d = (float)(si->pathTracingIteration - NB_MAX_ITERATIONS + 1);
+                    c.x /= d;
+                    c.y /= d;
+                    c.z /= d;
+                }
+                localColor.x += c.x * filterInfo[f][filterX][filterY];
+                localColor.y += c.y * filterInfo[f][filterX][filterY];
+                localColor.z += c.z * filterInfo[f][filterX][filterY];
+            }
+        color.x += fminf(fmaxf(filterFactors[f][0] * localColor.x + filterFactors[f][1] / 255.f, 0.f), 1.f);
+        color.y += fminf(fmaxf(filterFactors[f][0] * localColor.y + filterFactors[f][1] / 255.f, 0.f), 1.f);
+        color.z += fminf(fmaxf(filterFactors[f][0] * localColor.z + filterFactors[f][1] / 255.f, 0.f), 1.f);
+    }
+    saturate3(&color);
+    makeColor(si, color, bitmap, index);
+}
+
+/* ref CRT:1341-1358: depth shown as grey */
+static void postCartoon(const SceneInfo *si, const PostProcessingInfo *ppi, const PostProcessingBuffer *pp,
+                        BitmapBuffer *bitmap, int index)
+{
+    float depth = si->viewDistance / fabsf(pp[index].colorInfo.w - ppi->param1);
+    c3 color = {depth, depth, depth};
+    saturate3(&color);
+    makeColor(si, color, bitmap, index);
+}
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP
@@ -1922,6 +2017,15 @@ int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const Po
                     break;
                 case ppe_ambientOcclusion:
                     postAmbientOcclusion(scene, sceneInfo, ppInfo, pp, bitmap, x, y, nbRows, &st);
+                    break;
+                case ppe_radiosity:
+                    postRadiosity(scene, sceneInfo, ppInfo, pp, ids, bitmap, x, y, nbRows, &st);
+                    break;
+                case ppe_filter:
+                    postFilter(sceneInfo, ppInfo, pp, bitmap, x, y, nbRows);
+                    break;
+                case ppe_cartoon:
+                    postCartoon(sceneInfo, ppInfo, pp, bitmap, index);
                     break;
                 default:
                     postDefault(sceneInfo, pp, bitmap, index);

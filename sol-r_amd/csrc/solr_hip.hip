@@ -299,6 +299,117 @@ __global__ __launch_bounds__(256) void k_default(const SceneInfo si, int nbPixel
     makeColor(si, c, bitmap, index);
 }
 
+/* CRT:1189-1228; gathers stay inside this process's strip */
+__global__ __launch_bounds__(256) void k_radiosity(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
+                                                   const PixelRecord *__restrict__ pp, const int4 *__restrict__ ids,
+                                                   const float *__restrict__ randoms, long nbRandoms,
+                                                   unsigned char *__restrict__ bitmap)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = si.size.x;
+    const int wh = W * nbRows;
+    if (index >= wh)
+        return;
+    const int x = index % W;
+    const int y = index / W;
+    const int div = (si.pathTracingIteration > NB_MAX_ITERATIONS) ? (si.pathTracingIteration - NB_MAX_ITERATIONS + 1) : 1;
+    const float4 own = pp[index].colorInfo;
+    v3 local = V(0.f, 0.f, 0.f);
+    for (int i = 0; i < ppi.param3; ++i)
+    {
+        const int ix = (i + si.pathTracingIteration) % wh;
+        const int iy = (i + 100 + si.pathTracingIteration) % wh;
+        const float rx = (ix >= 0 && ix < nbRandoms) ? randoms[ix] : 0.f;
+        const float ry = (iy >= 0 && iy < nbRandoms) ? randoms[iy] : 0.f;
+        const int xx = (int)((float)x + rx * ppi.param2);
+        const int yy = (int)((float)y + ry * ppi.param2);
+        local.x += own.x;
+        local.y += own.y;
+        local.z += own.z;
+        if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
+        {
+            const int localIndex = yy * W + xx;
+            const float4 light = pp[localIndex].colorInfo;
+            const float w = (float)ids[localIndex].z;
+            local.x += light.x * w / 256.f;
+            local.y += light.y * w / 256.f;
+            local.z += light.z * w / 256.f;
+        }
+    }
+    local.x /= (float)ppi.param3;
+    local.y /= (float)ppi.param3;
+    local.z /= (float)ppi.param3;
+    local.x /= (float)div;
+    local.y /= (float)div;
+    local.z /= (float)div;
+    saturate3(local);
+    makeColor(si, local, bitmap, index);
+}
+
+/* CRT:1236-1333: six convolution filters selected by param3, wrapping around the strip */
+__device__ const int FILTER_SIZE[6][2] = {{3, 3}, {5, 5}, {3, 3}, {3, 3}, {5, 5}, {5, 5}};
+__device__ const float FILTER_FACTORS[6][2] = {{1.f, 128.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {0.2f, 0.f}, {0.125f, 0.f}};
+__device__ const float FILTER_INFO[6][5][5] = {
+    {{-1.f, -1.f, 0.f, 0.f, 0.f}, {-1.f, 0.f, 1.f, 0.f, 0.f}, {0.f, 1.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
+    {{0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {-1.f, -1.f, 2.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
+    {{-1.f, -1.f, -1.f, 0.f, 0.f}, {-1.f, 9.f, -1.f, 0.f, 0.f}, {-1.f, -1.f, -1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
+    {{0.f, 0.2f, 0.f, 0.f, 0.f}, {0.2f, 0.2f, 0.2f, 0.f, 0.f}, {0.f, 0.2f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
+    {{1.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 1.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 1.f}},
+    {{-1.f, -1.f, -1.f, -1.f, -1.f}, {-1.f, 2.f, 2.f, 2.f, -1.f}, {-1.f, 2.f, 8.f, 2.f, -1.f}, {-1.f, 2.f, 2.f, 2.f, -1.f}, {-1.f, -1.f, -1.f, -1.f, -1.f}}};
+
+__global__ __launch_bounds__(256) void k_filter(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
+                                                const PixelRecord *__restrict__ pp, unsigned char *__restrict__ bitmap)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = si.size.x;
+    if (index >= W * nbRows)
+        return;
+    const int x = index % W;
+    const int y = index / W;
+    v3 local = V(0.f, 0.f, 0.f);
+    v3 color = V(0.f, 0.f, 0.f);
+    const int f = ppi.param3;
+    if (f >= 0 && f < 6)
+    {
+        for (int filterX = 0; filterX < FILTER_SIZE[f][0]; filterX++)
+            for (int filterY = 0; filterY < FILTER_SIZE[f][1]; filterY++)
+            {
+                const int imageX = (x - FILTER_SIZE[f][0] / 2 + filterX + W) % W;
+                const int imageY = (y - FILTER_SIZE[f][1] / 2 + filterY + nbRows) % nbRows;
+                const float4 p = pp[imageY * W + imageX].colorInfo;
+                v3 c = V(p.x, p.y, p.z);
+                if (si.pathTracingIteration > NB_MAX_ITERATIONS)
+                {
+                    const float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
+                    c.x /= d;
+                    c.y /= d;
+                    c.z /= d;
+                }
+                local.x += c.x * FILTER_INFO[f][filterX][filterY];
+                local.y += c.y * FILTER_INFO[f][filterX][filterY];
+                local.z += c.z * FILTER_INFO[f][filterX][filterY];
+            }
+        color.x += fminf(fmaxf(FILTER_FACTORS[f][0] * local.x + FILTER_FACTORS[f][1] / 255.f, 0.f), 1.f);
+        color.y += fminf(fmaxf(FILTER_FACTORS[f][0] * local.y + FILTER_FACTORS[f][1] / 255.f, 0.f), 1.f);
+        color.z += fminf(fmaxf(FILTER_FACTORS[f][0] * local.z + FILTER_FACTORS[f][1] / 255.f, 0.f), 1.f);
+    }
+    saturate3(color);
+    makeColor(si, color, bitmap, index);
+}
+
+/* CRT:1341-1358: depth shown as grey */
+__global__ __launch_bounds__(256) void k_cartoon(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
+                                                 const PixelRecord *__restrict__ pp, unsigned char *__restrict__ bitmap)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= si.size.x * nbRows)
+        return;
+    const float depth = si.viewDistance / fabsf(pp[index].colorInfo.w - ppi.param1);
+    v3 color = V(depth, depth, depth);
+    saturate3(color);
+    makeColor(si, color, bitmap, index);
+}
+
 /* TileScheduling.  A frame is tens of thousands of one-wave workgroups whose costs differ by an
  * order of magnitude (a tile of sky against a tile of mesh seen at a grazing angle) and the
  * dispatcher hands them out in launch order, so an expensive tile that happens to be launched late
@@ -998,7 +1109,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     F.nbRows = stripRows();
     F.tilesX = (sceneInfo.size.x + TILE - 1) / TILE;
     const int tilesY = (F.nbRows + TILE - 1) / TILE;
-    const bool neighbourhood = (ppInfo.type == ppe_ambientOcclusion || ppInfo.type == ppe_depthOfField);
+    const bool neighbourhood = (ppInfo.type == ppe_ambientOcclusion || ppInfo.type == ppe_depthOfField ||
+                                ppInfo.type == ppe_radiosity || ppInfo.type == ppe_filter || ppInfo.type == ppe_cartoon);
     unsigned char *bitmap = (unsigned char *)(g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr);
     F.fuseDefault = neighbourhood ? 0 : 1;
 
@@ -1161,10 +1273,20 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             hipLaunchKernelGGL(k_ambientOcclusion, pgrid, pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
                                (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
                                g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
-        else
+        else if (ppInfo.type == ppe_depthOfField)
             hipLaunchKernelGGL(k_depthOfField, pgrid, pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
                                (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
                                g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
+        else if (ppInfo.type == ppe_radiosity)
+            hipLaunchKernelGGL(k_radiosity, pgrid, pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
+                               (const PixelRecord *)flightPp(flight).ptr, (const int4 *)flightIds(flight).ptr,
+                               (const float *)g.randoms.ptr, g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
+        else if (ppInfo.type == ppe_filter)
+            hipLaunchKernelGGL(k_filter, pgrid, pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
+                               (const PixelRecord *)flightPp(flight).ptr, bitmap);
+        else
+            hipLaunchKernelGGL(k_cartoon, pgrid, pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
+                               (const PixelRecord *)flightPp(flight).ptr, bitmap);
         HIPCHECK(hipGetLastError());
     }
 

@@ -166,7 +166,11 @@ def test_advanced_illumination(solr, oracle, mode):
 
 
 @pytest.mark.parametrize("pp", [dict(type=solr_mod.ppe_ambientOcclusion, param1=0.0, param2=10.0, param3=0),
-                                dict(type=solr_mod.ppe_depthOfField, param1=12000.0, param2=20.0, param3=16)])
+                                dict(type=solr_mod.ppe_depthOfField, param1=12000.0, param2=20.0, param3=16),
+                                dict(type=solr_mod.ppe_radiosity, param1=0.0, param2=4000.0, param3=12),
+                                dict(type=solr_mod.ppe_cartoon, param1=9000.0, param2=0.0, param3=0)] +
+                               [dict(type=solr_mod.ppe_filter, param1=0.0, param2=0.0, param3=f) for f in range(7)],
+                         ids=lambda pp: "type%d-%d" % (pp["type"], pp["param3"]))
 def test_post_processing(solr, oracle, pp):
     k = solr.Kernel(engine="hip")
     k.set_post_processing(**pp)
