@@ -1764,6 +1764,58 @@ static void standardRendererPixel(const OracleScene *s, const SceneInfo *si, con
     }
 }
 
+/* ref CRT:840-950, k_anaglyphRenderer for one pixel: one trace per eye (origin.x -+ eyeSeparation), red from
+ * the left eye's luminance, green and blue from the right eye.  No jitter, no random-illumination term,
+ * plain store / accumulate.  The row is the global one (the reference's kernel has no split argument). */
+static void anaglyphRendererPixel(const OracleScene *s, const SceneInfo *si, v3 origin, v3 direction,
+                                  const float angles[4], const Trig *trig, int x, int yLocal, int firstRow,
+                                  PostProcessingBuffer *pp, PrimitiveXYIdBuffer *ids, Stats *st)
+{
+    int index = yLocal * si->size.x + x;
+    int gindex = (firstRow + yLocal) * si->size.x + x;
+    int yGlobal = firstRow + yLocal;
+    if (si->pathTracingIteration > ids[index].y && ids[index].w == 0 && si->pathTracingIteration > 0 &&
+        si->pathTracingIteration <= NB_MAX_ITERATIONS)
+        return;
+    v3 rotationCenter = {0.f, 0.f, 0.f};
+    float dof = 0.f;
+    float ratio = (float)si->size.x / (float)si->size.y;
+    float stepx = ratio * angles[3] / (float)si->size.x;
+    float stepy = angles[3] / (float)si->size.y;
+    c3 eye[2];
+    for (int e = 0; e < 2; ++e)
+    {
+        Ray r;
+        memset(&r, 0, sizeof(r));
+        r.origin.x = (e == 0) ? origin.x - si->eyeSeparation : origin.x + si->eyeSeparation;
+        r.origin.y = origin.y;
+        r.origin.z = origin.z;
+        r.direction.x = direction.x - stepx * (float)(x - (si->size.x / 2));
+        r.direction.y = direction.y + stepy * (float)(yGlobal - (si->size.y / 2));
+        r.direction.z = direction.z;
+        r.origin = vectorRotation(r.origin, rotationCenter, trig);
+        r.direction = vectorRotation(r.direction, rotationCenter, trig);
+        eye[e] = launchRayTracing(s, gindex, &r, si, &dof, &ids[index], st);
+    }
+    float r1 = eye[0].x * 0.299f + eye[0].y * 0.587f + eye[0].z * 0.114f;
+    float g2 = eye[1].y;
+    float b2 = eye[1].z;
+    if (si->pathTracingIteration == 0)
+        pp[index].colorInfo.w = dof;
+    if (si->pathTracingIteration <= NB_MAX_ITERATIONS)
+    {
+        pp[index].colorInfo.x = r1 + 0.f;
+        pp[index].colorInfo.y = 0.f + g2;
+        pp[index].colorInfo.z = 0.f + b2;
+    }
+    else
+    {
+        pp[index].colorInfo.x += r1 + 0.f;
+        pp[index].colorInfo.y += 0.f + g2;
+        pp[index].colorInfo.z += 0.f + b2;
+    }
+}
+
 /* ---- post-processing stage --------------------------------------------- */
 
 /* ref CRT:1057-1073 */
@@ -2004,7 +2056,13 @@ int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const Po
 #pragma omp for schedule(dynamic, 2)
         for (int y = 0; y < nbRows; ++y)
             for (int x = 0; x < W; ++x)
-                standardRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
+            {
+                /* the camera types the engine renders with a kernel of their own (CRT:1714-1836) */
+                if (sceneInfo->cameraType == ctAnaglyph)
+                    anaglyphRendererPixel(scene, sceneInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
+                else
+                    standardRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
+            }
 #pragma omp for schedule(dynamic, 2)
         for (int y = 0; y < nbRows; ++y)
             for (int x = 0; x < W; ++x)

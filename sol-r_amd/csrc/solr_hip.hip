@@ -159,11 +159,26 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
      * starts from the same origin as the fourth (CRT:504-514, 523-525);
      * otherwise the centre ray only.  The offsets are re-applied from the
      * unjittered origin with the reference's order of additions. */
-    const int nbRays = antialiasingActivated ? 5 : 1;
+    /* ctAnaglyph (k_anaglyphRenderer, CRT:840-950): one trace per eye from origin.x -+ eyeSeparation, no
+     * jitter; like the five-ray camera it lives in the F_FULL instantiations only */
+    const bool anaglyph = (FEAT & F_FULL) && (si.cameraType == ctAnaglyph);
+    v3 leftEye = V(0.f, 0.f, 0.f);
+    const int nbRays = antialiasingActivated ? 5 : (anaglyph ? 2 : 1);
 #pragma unroll 1
     for (int I = 0; I < nbRays; ++I)
     {
         v3 rO = rayO;
+        v3 rD = rayD;
+        if (anaglyph)
+        {
+            const float ratio = (float)si.size.x / (float)si.size.y;
+            const float stepx = ratio * F.aw / (float)si.size.x;
+            const float stepy = F.aw / (float)si.size.y;
+            rO = V((I == 0) ? F.ox - si.eyeSeparation : F.ox + si.eyeSeparation, F.oy, F.oz);
+            rD = V(F.dx - stepx * (float)(x - (si.size.x / 2)), F.dy + stepy * (float)(yGlobal - (si.size.y / 2)), F.dz);
+            rO = vectorRotation(rO, V(0.f, 0.f, 0.f), F.trig);
+            rD = vectorRotation(rD, V(0.f, 0.f, 0.f), F.trig);
+        }
         if (antialiasingActivated)
         {
             rO.x += 3.f;
@@ -184,11 +199,19 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
                 rO.y += 3.f;
             }
         }
-        v3 c = launchRayTracing<COUNT, FEAT>(S, active, gindex, rO, rayD, si, dof, id, cs, cnt);
-        color = color + c;
+        v3 c = launchRayTracing<COUNT, FEAT>(S, active, gindex, rO, rD, si, dof, id, cs, cnt);
+        if (anaglyph)
+        {
+            if (I == 0)
+                leftEye = c;
+            else
+                color = V((leftEye.x * 0.299f + leftEye.y * 0.587f + leftEye.z * 0.114f) + 0.f, 0.f + c.y, 0.f + c.z);
+        }
+        else
+            color = color + c;
     }
 
-    if (si.advancedIllumination == aiRandomIllumination)
+    if (!anaglyph && si.advancedIllumination == aiRandomIllumination)
     {
         int rindex = (gindex + si.timestamp) % MAX_BITMAP_SIZE;
         float rv = rnd(S, rindex);
@@ -214,7 +237,22 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
         }
         if (si.pathTracingIteration == 0)
             ppColor.w = dof;
-        if (si.pathTracingIteration <= NB_MAX_ITERATIONS)
+        if (anaglyph) /* plain store / accumulate, the last-sample record is not touched (CRT:936-947) */
+        {
+            if (si.pathTracingIteration <= NB_MAX_ITERATIONS)
+            {
+                ppColor.x = color.x;
+                ppColor.y = color.y;
+                ppColor.z = color.z;
+            }
+            else
+            {
+                ppColor.x += color.x;
+                ppColor.y += color.y;
+                ppColor.z += color.z;
+            }
+        }
+        else if (si.pathTracingIteration <= NB_MAX_ITERATIONS)
         {
             ppColor.x = color.x;
             ppColor.y = color.y;
@@ -1072,7 +1110,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
 
     /* the box-debug view and the census count every node of the original tree */
     const bool full = sceneInfo.renderBoxes != 0 || sceneInfo.advancedIllumination == aiBasic ||
-                      sceneInfo.advancedIllumination == aiFull || sceneInfo.cameraType == ctAntialiazed;
+                      sceneInfo.advancedIllumination == aiFull || sceneInfo.cameraType == ctAntialiazed ||
+                      sceneInfo.cameraType == ctAnaglyph;
     const bool exactNodes = counting || sceneInfo.renderBoxes != 0 || objects.x != g.nbBoxes || g.variant == 3;
     flushGeometry();
     if (!ok())

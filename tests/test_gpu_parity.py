@@ -87,7 +87,8 @@ def test_double_sided_triangles(solr, oracle):
     dict(graphicsLevel=solr_mod.glPhongAndBlinn), dict(graphicsLevel=solr_mod.glReflectionsAndRefractions),
     dict(gradientBackground=1), dict(atmosphericEffect=solr_mod.aeFog, viewDistance=30000.0),
     dict(cameraType=solr_mod.ctOrthographic), dict(cameraType=solr_mod.ctAntialiazed),
-    dict(cameraType=solr_mod.ctVR), dict(shadowIntensity=0.4), dict(renderBoxes=1),
+    dict(cameraType=solr_mod.ctVR), dict(cameraType=solr_mod.ctAnaglyph, eyeSeparation=350.0),
+    dict(shadowIntensity=0.4), dict(renderBoxes=1),
     dict(frameBufferType=solr_mod.ftBGR), dict(bgColor=(0.2, 0.3, 0.4, 0.1)), dict(draftMode=1),
 ])
 def test_scene_info_modes(solr, oracle, info):
@@ -384,3 +385,10 @@ def test_post_processing_and_strips_with_two_frames_in_flight(solr, oracle):
         hip.solr_hip_set_strip(0, 0)
         hip.solr_hip_set_frames_in_flight(1)
         k.finalize()
+
+
+def test_anaglyph_camera_through_refinement_and_accumulation_passes(solr, oracle):
+    # k_anaglyphRenderer, CRT:840-950: two traces per pixel, plain store then plain accumulation
+    res = progressive(solr, oracle, solr.scenes.cornell, range(0, 14), width=64, height=48, iterations=2,
+                      cameraType=solr_mod.ctAnaglyph, eyeSeparation=420.0)
+    assert_parity(res, max_ulp=2)
