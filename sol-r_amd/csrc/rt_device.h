@@ -135,6 +135,9 @@ __device__ __attribute__((noinline)) float pow_general(float a, float b) { retur
 
 SOLR_DEV float pow_f(float a, float b)
 {
+#ifdef SOLR_LIBRARY_POW /* A/B builds: the library routine everywhere */
+    return pow_general(a, b);
+#endif
     const int ix = __float_as_int(a);
     const bool lean = (a >= 1.17549435e-38f) && (a < 3.0e38f) && (b > 0.f) && (b <= 4096.f);
     const bool zero = (ix == 0) && (b > 0.f) && (b <= 4096.f);

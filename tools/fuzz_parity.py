@@ -1,0 +1,73 @@
+"""Development aid: random scenes, HIP engine vs CPU oracle.  Prints every scene whose frame is not within the
+parity bar (ids exact, colour <= 1 ULP, RGB8 within 1)."""
+import os, sys, importlib, math
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+solr = importlib.import_module("sol-r_amd")
+from oracle import loader
+from helpers import compare_frames, gpu_frame, oracle_frame
+S = solr.scenes
+
+def build(k, seed, width=72, height=48):
+    rng = S.LCG(seed)
+    u = lambda a, b: rng.uniform(a, b)
+    pick = lambda seq: seq[rng.next() % len(seq)]
+    iterations = 1 + rng.next() % 4
+    k.initialize(width=width, height=height, nbRayIterations=iterations, graphicsLevel=pick([4, 4, 4, 3, 2]),
+                 shadowIntensity=pick([1.0, 0.6]), gradientBackground=rng.next() % 2,
+                 doubleSidedTriangles=(rng.next() % 5 == 0))
+    mats = []
+    for _ in range(6):
+        kind = rng.next() % 5
+        mats.append(k.add_material(u(0.1, 1.0), u(0.1, 1.0), u(0.1, 1.0),
+                                   reflection=u(0.1, 0.9) if kind == 1 else 0.0,
+                                   transparency=u(0.2, 0.9) if kind == 2 else 0.0,
+                                   refraction=pick([1.0, 1.1, 1.33]) if kind == 2 else 0.0,
+                                   opacity=u(0.0, 0.5) if kind == 2 else 0.0,
+                                   specValue=u(0.0, 1.0), specPower=pick([10.0, 50.0, 200.0, 1000.0]),
+                                   fastTransparency=(kind == 3), noise=0.0))
+    n = 20 + rng.next() % 200
+    span = 9000.0
+    for _ in range(n):
+        t = pick([solr.ptSphere, solr.ptSphere, solr.ptCylinder, solr.ptTriangle, solr.ptTriangle, solr.ptEllipsoid,
+                  solr.ptCone, solr.ptXYPlane, solr.ptYZPlane, solr.ptXZPlane])
+        p0 = (u(-span, span), u(-span, span), u(-span, span))
+        m = pick(mats)
+        if t in (solr.ptSphere,):
+            k.add_primitive(t, p0, size=(u(200, 1500), 0, 0), material=m)
+        elif t == solr.ptEllipsoid:
+            k.add_primitive(t, p0, size=(u(300, 1500), u(300, 1500), u(300, 1500)), material=m)
+        elif t in (solr.ptCylinder, solr.ptCone):
+            p1 = (p0[0] + u(-3000, 3000), p0[1] + u(-3000, 3000), p0[2] + u(-3000, 3000))
+            k.add_primitive(t, p0, p1, size=(u(100, 600), 0, 0), material=m)
+        elif t == solr.ptTriangle:
+            p1 = (p0[0] + u(-2500, 2500), p0[1] + u(-2500, 2500), p0[2] + u(-2500, 2500))
+            p2 = (p0[0] + u(-2500, 2500), p0[1] + u(-2500, 2500), p0[2] + u(-2500, 2500))
+            i = k.add_primitive(t, p0, p1, p2, material=m)
+            k.set_normals(i, (u(-1, 1), u(-1, 1), u(-1, 1)), (u(-1, 1), u(-1, 1), u(-1, 1)), (u(-1, 1), u(-1, 1), u(-1, 1)))
+        else:
+            k.add_primitive(t, p0, size=(u(500, 4000), u(500, 4000), u(500, 4000)), material=m)
+    for _ in range(1 + rng.next() % 2):
+        S.add_light(k, position=(u(-span, span), u(3000, 12000), u(-12000, -3000)), intensity=u(0.8, 2.0))
+    k.compact_boxes(True)
+    k.set_camera((u(-2000, 2000), u(-2000, 2000), -16000.0 + u(-2000, 2000)), look_at=(u(-1500, 1500), u(-1500, 1500), 0.0),
+                 angles=(u(-0.2, 0.2), u(-0.2, 0.2), u(-0.1, 0.1)))
+    return k
+
+if __name__ == "__main__":
+    first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1, 40)
+    bad = 0
+    for seed in range(first, first + count):
+        k = solr.Kernel(engine="hip")
+        build(k, seed)
+        pp, ids, rgb = gpu_frame(k)
+        opp, oids, orgb, counts, status = oracle_frame(k, loader)
+        res = compare_frames(pp, ids, rgb, opp, oids, orgb)
+        flat = k.flat_scene()
+        k.finalize()
+        ok = res["ids_all_equal"] and res["max_ulp"] <= 1 and res["rgb_max_diff"] <= 1 and res["depth_max_ulp"] == 0 and status == 0
+        if not ok:
+            bad += 1
+            print("seed %d: %d boxes %d prims: %s" % (seed, len(flat.boxes), len(flat.primitives), res))
+    print("fuzz: %d scenes, %d outside the bar" % (count, bad))
