@@ -151,6 +151,19 @@ def main():
     k.check(0, "ray census")
     rays_local = int(counts[0]) + int(counts[1])
 
+    # a frame loop that does not come back is reported, not sat out: the multi-GPU loop chains work
+    # across streams and ranks, and a stuck collective would otherwise hang the whole launch
+    import threading
+
+    def stuck():
+        print("bench.py: rank %d made no progress for 600 s (frames in flight %d, distributed %s): giving up"
+              % (rank, args.frames_in_flight, distributed), file=sys.stderr, flush=True)
+        os._exit(3)
+
+    watchdog = threading.Timer(600.0, stuck)
+    watchdog.daemon = True
+    watchdog.start()
+
     # setup, untimed: let the clocks and the tile-cost feedback of the engine settle before the W
     # warmup steps (a frame is 0.4 ms; W = 3 alone is 1.2 ms of GPU work, shorter than the power ramp)
     for _ in range(PREROLL_FRAMES):
@@ -172,6 +185,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     hip.solr_hip_enable_timing(0)
+    watchdog.cancel()
     k.check(0, "timed frames")
     elapsed = t1 - t0
     launches = C.c_int(0)

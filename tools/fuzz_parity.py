@@ -27,7 +27,7 @@ def build(k, seed, width=72, height=48):
                                    opacity=u(0.0, 0.5) if kind == 2 else 0.0,
                                    specValue=u(0.0, 1.0), specPower=pick([10.0, 50.0, 200.0, 1000.0]),
                                    fastTransparency=(kind == 3), noise=0.0))
-    n = 20 + rng.next() % 200
+    n = 20 + rng.next() % int(os.environ.get("FUZZ_MAX_PRIMS", "200"))
     span = 9000.0
     for _ in range(n):
         t = pick([solr.ptSphere, solr.ptSphere, solr.ptCylinder, solr.ptTriangle, solr.ptTriangle, solr.ptEllipsoid,
