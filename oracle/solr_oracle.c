@@ -1816,6 +1816,59 @@ static void anaglyphRendererPixel(const OracleScene *s, const SceneInfo *si, v3 
     }
 }
 
+/* ref CRT:741-815, k_fishEyeRenderer for one pixel: 360 degrees around the Y axis across the image width -
+ * the look-at point is rotated about the eye by angles.y + 2 pi x / W - plain store / accumulate.  The
+ * rotation's cos / sin are per pixel.  cosf / sinf are only specified to an error bound (CUDA's: 2 ULP, glibc's: <1 ULP),
+ * so no two conforming libraries agree bit for bit on 2048 different angles per row; the restatement takes the
+ * correctly rounded value (binary64 libm rounded once), which every such bound admits, and so does the engine. */
+static void fishEyeRendererPixel(const OracleScene *s, const SceneInfo *si, const PostProcessingInfo *ppi, v3 origin,
+                                 v3 direction, const float angles[4], int x, int yLocal, int firstRow,
+                                 PostProcessingBuffer *pp, PrimitiveXYIdBuffer *ids, Stats *st)
+{
+    int index = yLocal * si->size.x + x;
+    int gindex = (firstRow + yLocal) * si->size.x + x;
+    int yGlobal = firstRow + yLocal;
+    if (si->pathTracingIteration > ids[index].y && ids[index].w == 0 && si->pathTracingIteration > 0 &&
+        si->pathTracingIteration <= NB_MAX_ITERATIONS)
+        return;
+    Ray ray;
+    memset(&ray, 0, sizeof(ray));
+    ray.origin = origin;
+    ray.direction = direction;
+    if (si->pathTracingIteration >= NB_MAX_ITERATIONS)
+    {
+        int rindex = (gindex + si->timestamp) % (MAX_BITMAP_SIZE - 3);
+        float a = (float)si->pathTracingIteration / (float)si->maxPathTracingIterations;
+        ray.direction.x += rnd(s, rindex, st) * pp[index].colorInfo.w * ppi->param2 * a;
+        ray.direction.y += rnd(s, rindex + 1, st) * pp[index].colorInfo.w * ppi->param2 * a;
+        ray.direction.z += rnd(s, rindex + 2, st) * pp[index].colorInfo.w * ppi->param2 * a;
+    }
+    float dof = 0.f;
+    float stepy = angles[3] / (float)si->size.y;
+    ray.direction.y = ray.direction.y + stepy * (float)(yGlobal - (si->size.y / 2));
+    float stepx = 2.f * 3.14159265358979323846f / (float)si->size.x;
+    float fishEyeAngles[3] = {0.f, angles[1] + stepx * (float)x, 0.f};
+    Trig t = makeTrig(fishEyeAngles); /* x and z: cos(0) = 1, sin(0) = 0 exactly */
+    t.cy = (float)cos((double)fishEyeAngles[1]);
+    t.sy = (float)sin((double)fishEyeAngles[1]);
+    ray.direction = vectorRotation(ray.direction, ray.origin, &t);
+    c3 color = launchRayTracing(s, gindex, &ray, si, &dof, &ids[index], st);
+    if (si->pathTracingIteration == 0)
+        pp[index].colorInfo.w = dof;
+    if (si->pathTracingIteration <= NB_MAX_ITERATIONS)
+    {
+        pp[index].colorInfo.x = color.x;
+        pp[index].colorInfo.y = color.y;
+        pp[index].colorInfo.z = color.z;
+    }
+    else
+    {
+        pp[index].colorInfo.x += color.x;
+        pp[index].colorInfo.y += color.y;
+        pp[index].colorInfo.z += color.z;
+    }
+}
+
 /* ---- post-processing stage --------------------------------------------- */
 
 /* ref CRT:1057-1073 */
@@ -2060,6 +2113,8 @@ int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const Po
                 /* the camera types the engine renders with a kernel of their own (CRT:1714-1836) */
                 if (sceneInfo->cameraType == ctAnaglyph)
                     anaglyphRendererPixel(scene, sceneInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
+                else if (sceneInfo->cameraType == ctPanoramic)
+                    fishEyeRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, x, y, firstRow, pp, ids, &st);
                 else
                     standardRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
             }

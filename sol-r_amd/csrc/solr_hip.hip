@@ -162,6 +162,10 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     /* ctAnaglyph (k_anaglyphRenderer, CRT:840-950): one trace per eye from origin.x -+ eyeSeparation, no
      * jitter; like the five-ray camera it lives in the F_FULL instantiations only */
     const bool anaglyph = (FEAT & F_FULL) && (si.cameraType == ctAnaglyph);
+    /* ctPanoramic (k_fishEyeRenderer, CRT:741-815): the look-at point turns about the eye by
+     * angles.y + 2 pi x / W; plain store like the anaglyph camera */
+    const bool fishEye = (FEAT & F_FULL) && (si.cameraType == ctPanoramic);
+    const bool plainStore = anaglyph || fishEye;
     v3 leftEye = V(0.f, 0.f, 0.f);
     const int nbRays = antialiasingActivated ? 5 : (anaglyph ? 2 : 1);
 #pragma unroll 1
@@ -178,6 +182,32 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
             rD = V(F.dx - stepx * (float)(x - (si.size.x / 2)), F.dy + stepy * (float)(yGlobal - (si.size.y / 2)), F.dz);
             rO = vectorRotation(rO, V(0.f, 0.f, 0.f), F.trig);
             rD = vectorRotation(rD, V(0.f, 0.f, 0.f), F.trig);
+        }
+        if (fishEye)
+        {
+            rO = V(F.ox, F.oy, F.oz);
+            rD = V(F.dx, F.dy, F.dz);
+            if (si.pathTracingIteration >= NB_MAX_ITERATIONS)
+            {
+                const int rindex = (gindex + si.timestamp) % (MAX_BITMAP_SIZE - 3);
+                const float a = (float)si.pathTracingIteration / (float)si.maxPathTracingIterations;
+                const float depth = active ? pp[index].colorInfo.w : 0.f;
+                rD.x += rnd(S, rindex) * depth * F.ppi.param2 * a;
+                rD.y += rnd(S, rindex + 1) * depth * F.ppi.param2 * a;
+                rD.z += rnd(S, rindex + 2) * depth * F.ppi.param2 * a;
+            }
+            const float stepy = F.aw / (float)si.size.y;
+            rD.y = rD.y + stepy * (float)(yGlobal - (si.size.y / 2));
+            const float stepx = 2.f * 3.14159265358979323846f / (float)si.size.x;
+            const float turn = F.ay + stepx * (float)x;
+            Trig t;
+            t.cx = 1.f; /* cos(0), sin(0): exact in every libm */
+            t.sx = 0.f;
+            t.cy = cos_f(turn);
+            t.sy = sin_f(turn);
+            t.cz = 1.f;
+            t.sz = 0.f;
+            rD = vectorRotation(rD, rO, t);
         }
         if (antialiasingActivated)
         {
@@ -211,7 +241,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
             color = color + c;
     }
 
-    if (!anaglyph && si.advancedIllumination == aiRandomIllumination)
+    if (!plainStore && si.advancedIllumination == aiRandomIllumination)
     {
         int rindex = (gindex + si.timestamp) % MAX_BITMAP_SIZE;
         float rv = rnd(S, rindex);
@@ -237,7 +267,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
         }
         if (si.pathTracingIteration == 0)
             ppColor.w = dof;
-        if (anaglyph) /* plain store / accumulate, the last-sample record is not touched (CRT:936-947) */
+        if (plainStore) /* plain store / accumulate, the last-sample record is not touched (CRT:801-812, 936-947) */
         {
             if (si.pathTracingIteration <= NB_MAX_ITERATIONS)
             {
@@ -1111,7 +1141,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     /* the box-debug view and the census count every node of the original tree */
     const bool full = sceneInfo.renderBoxes != 0 || sceneInfo.advancedIllumination == aiBasic ||
                       sceneInfo.advancedIllumination == aiFull || sceneInfo.cameraType == ctAntialiazed ||
-                      sceneInfo.cameraType == ctAnaglyph;
+                      sceneInfo.cameraType == ctAnaglyph || sceneInfo.cameraType == ctPanoramic;
     const bool exactNodes = counting || sceneInfo.renderBoxes != 0 || objects.x != g.nbBoxes || g.variant == 3;
     flushGeometry();
     if (!ok())

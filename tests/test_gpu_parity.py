@@ -88,6 +88,7 @@ def test_double_sided_triangles(solr, oracle):
     dict(gradientBackground=1), dict(atmosphericEffect=solr_mod.aeFog, viewDistance=30000.0),
     dict(cameraType=solr_mod.ctOrthographic), dict(cameraType=solr_mod.ctAntialiazed),
     dict(cameraType=solr_mod.ctVR), dict(cameraType=solr_mod.ctAnaglyph, eyeSeparation=350.0),
+    dict(cameraType=solr_mod.ctPanoramic),
     dict(shadowIntensity=0.4), dict(renderBoxes=1),
     dict(frameBufferType=solr_mod.ftBGR), dict(bgColor=(0.2, 0.3, 0.4, 0.1)), dict(draftMode=1),
 ])
@@ -391,4 +392,20 @@ def test_anaglyph_camera_through_refinement_and_accumulation_passes(solr, oracle
     # k_anaglyphRenderer, CRT:840-950: two traces per pixel, plain store then plain accumulation
     res = progressive(solr, oracle, solr.scenes.cornell, range(0, 14), width=64, height=48, iterations=2,
                       cameraType=solr_mod.ctAnaglyph, eyeSeparation=420.0)
+    assert_parity(res, max_ulp=2)
+
+
+def _panorama_inside_the_room(k, **info):
+    solr_mod.scenes.cornell(k, **info)
+    k.set_camera((150.0, -300.0, -1200.0), look_at=(150.0, -300.0, 2800.0))
+    k.set_post_processing(type=solr_mod.ppe_none, param2=0.002)   # strength of the depth-of-field jitter
+
+
+def test_fisheye_camera_through_refinement_and_accumulation_passes(solr, oracle):
+    # k_fishEyeRenderer, CRT:741-815: 360 degrees across the image width from inside the room, the
+    # depth-of-field jitter of the accumulation passes reads the depth the first pass stored.  The per-pixel
+    # cos / sin of the turn are libm binary32 in the oracle and binary64-rounded-once in the engine.
+    res = progressive(solr, oracle, _panorama_inside_the_room, range(0, 14), width=128, height=48, iterations=2,
+                      cameraType=solr_mod.ctPanoramic)
+    print(res)
     assert_parity(res, max_ulp=2)
