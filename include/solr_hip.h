@@ -186,6 +186,32 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
 void solr_hip_set_variant(int variant);
 int solr_hip_get_variant(void);
 
+/* Animated scenes.  The reference re-runs GPUKernel::rotatePrimitives (GPUKernel.cpp:1378-1460: rotate
+ * the primitives of the level-0 boxes, refit every level) and compactBoxes(false) (:1151-1281: flatten
+ * again) on the host and uploads the whole scene for every frame of a rotating model
+ * (apps/scenes/science/MoleculeScene.cpp:75-81).  The flattened tree keeps its shape under that, so the
+ * engine can do the same arithmetic on the resident scene:
+ *   solr_hip_set_movable        after h2d_scene: per flattened primitive, 1 if rotatePrimitives moves it
+ *                               (in a level-0 box, movable, not the camera primitive);
+ *   solr_hip_rotate_primitives  rotation centre, cos and sin of angles.x/.y/.z as the host computes them
+ *                               (cosf / sinf), sceneInfo.viewDistance (the seed of the outer boxes).
+ *                               Returns 1 when the resident scene now holds, bit for bit, what the host
+ *                               rotation + a fresh h2d_scene would have produced for the reference's node
+ *                               list and primitives (the engine's own walk-order list is refitted from it),
+ *                               0 when it cannot serve the request (no flags, a tree the engine did not
+ *                               validate as nested, viewDistance > 1e6): nothing changed, take the host
+ *                               route;
+ *   solr_hip_device_rotations   how many requests were served since initialize_scene;
+ *   solr_hip_read_nodes / _primitives   the resident records, for tests (float4 rows: 2 per node in the
+ *                               layout of sol-r_amd/csrc/scene_layout.h, 8 per primitive); they return the
+ *                               number of rows, with rows == NULL only that. */
+void solr_hip_set_movable(const unsigned char *flags, int nbPrimitives);
+int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], const float sinAngles[3],
+                               float viewDistance);
+int solr_hip_device_rotations(void);
+int solr_hip_read_nodes(int exact, float *rows, int capacityRows);
+int solr_hip_read_primitives(float *rows, int capacityRows);
+
 /* Bytes of HBM this engine currently holds for {scene planes, materials,
  * textures, per-pixel buffers}; for DESIGN.md's layout table and tests. */
 void solr_hip_memory_usage(unsigned long long bytes[4]);

@@ -176,6 +176,14 @@ def _declare_hip(L):
     L.solr_hip_set_variant.argtypes = [C.c_int]
     L.solr_hip_get_variant.restype = C.c_int
     L.solr_hip_memory_usage.argtypes = [P(C.c_ulonglong)]
+    L.solr_hip_set_movable.argtypes = [C.c_void_p, C.c_int]
+    L.solr_hip_rotate_primitives.argtypes = [P(C.c_float), P(C.c_float), P(C.c_float), C.c_float]
+    L.solr_hip_rotate_primitives.restype = C.c_int
+    L.solr_hip_device_rotations.restype = C.c_int
+    L.solr_hip_read_nodes.argtypes = [C.c_int, C.c_void_p, C.c_int]
+    L.solr_hip_read_nodes.restype = C.c_int
+    L.solr_hip_read_primitives.argtypes = [C.c_void_p, C.c_int]
+    L.solr_hip_read_primitives.restype = C.c_int
     # the by-value reference entry points are exercised from C++ (host/HipKernel.cpp);
     # ctypes cannot 16-byte align a by-value struct, so they get no argtypes here
     L.h2d_scene.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -226,6 +234,7 @@ def _declare_host(L):
     L.SolRx_GetPostProcessingBuffer.argtypes = [C.c_void_p]
     L.SolRx_AddRectangle.argtypes = [d] * 6 + [i]
     L.SolRx_SetSceneInfoExtras.argtypes = [i, i]
+    L.SolRx_GetMovable.argtypes = [P(C.c_void_p), P(i)]
 
 
 def _np_from_ptr(ptr, count, dtype):
@@ -355,6 +364,37 @@ class Kernel:
 
     def compact_boxes(self, reconstruct=True):
         return self.L.SolR_CompactBoxes(reconstruct)
+
+    def rotate_primitives(self, center=(0.0, 0.0, 0.0), angles=(0.0, 0.0, 0.0)):
+        """One step of an animated scene: GPUKernel::rotatePrimitives + compactBoxes(false), as the
+        reference's scenes do per frame (SolR_RotatePrimitives).  With the HIP engine and an unchanged
+        scene the rotation runs on the resident scene and the host copy follows lazily."""
+        return self.L.SolR_RotatePrimitives(0, 0, center[0], center[1], center[2], angles[0], angles[1], angles[2])
+
+    def pending_rotations(self):
+        return self.L.SolRx_PendingRotations()
+
+    def sync_host(self):
+        self.L.SolRx_SyncHost()
+
+    def device_nodes(self, exact=True):
+        """The resident node records (n, 2, 4) float32 as the device holds them now: the reference's
+        node list (exact) or the engine's walk-order list."""
+        hip = hip_lib()
+        cap = hip.solr_hip_read_nodes(1 if exact else 0, None, 0)
+        buf = np.zeros((max(cap, 1), 4), np.float32)
+        if cap < 0 or hip.solr_hip_read_nodes(1 if exact else 0, buf.ctypes.data, cap) != cap:
+            raise SolrError("solr_hip_read_nodes failed")
+        return buf[:cap].reshape(-1, 2, 4)
+
+    def device_primitives(self):
+        """The resident primitive records (n, 8, 4) float32."""
+        hip = hip_lib()
+        cap = hip.solr_hip_read_primitives(None, 0)
+        buf = np.zeros((max(cap, 1), 4), np.float32)
+        if cap < 0 or hip.solr_hip_read_primitives(buf.ctypes.data, cap) != cap:
+            raise SolrError("solr_hip_read_primitives failed")
+        return buf[:cap].reshape(-1, 8, 4)
 
     def set_camera(self, eye, look_at=(0, 0, 0), angles=(0, 0, 0), w=6400.0):
         self.L.SolRx_SetCameraW(eye[0], eye[1], eye[2], look_at[0], look_at[1], look_at[2], angles[0], angles[1],

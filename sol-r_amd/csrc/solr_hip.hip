@@ -715,6 +715,185 @@ __global__ __launch_bounds__(256) void k_depthOfField(const SceneInfo si, const 
 
 namespace
 {
+/* ---- animated scenes: rotate + refit on the device ---------------------------------------------------
+ * The reference animates a scene by GPUKernel::rotatePrimitives + compactBoxes(false) on the host and a
+ * full upload, every frame (MoleculeScene.cpp:75-81; GPUKernel.cpp:1378-1460 rotates the primitives of
+ * the level-0 boxes and refits every level, :1151-1281 flattens again).  The flattened tree keeps its
+ * shape under that - only primitive coordinates and node bounds change - so the same arithmetic runs
+ * here on the resident arena instead: the primitive rows in place, then the nodes bottom-up.  Every
+ * expression below is the host builder's (sol-r_amd/host/GPUKernel.cpp rotateVector, updateBoundingBox,
+ * updateOutterBoundingBox), in its order and with its comparisons, so that the arena afterwards holds
+ * bit for bit what a host rotation followed by a fresh upload would have put there. */
+struct RotationArgs
+{
+    float cx, cy, cz;
+    float cosx, cosy, cosz;
+    float sinx, siny, sinz;
+};
+
+__device__ inline void rotateRow(float4 &v, float cx, float cy, float cz, const RotationArgs &R)
+{
+    float vx = v.x - cx, vy = v.y - cy, vz = v.z - cz;
+    float ry = vy * R.cosx - vz * R.sinx;
+    float rz = vy * R.sinx + vz * R.cosx;
+    vy = ry;
+    vz = rz;
+    rz = vz * R.cosy - vx * R.siny;
+    float rx = vz * R.siny + vx * R.cosy;
+    vz = rz;
+    vx = rx;
+    rx = vx * R.cosz - vy * R.sinz;
+    ry = vx * R.sinz + vy * R.cosz;
+    v.x = rx + cx;
+    v.y = ry + cy;
+    v.z = rz + cz;
+}
+
+__global__ __launch_bounds__(256) void k_rotatePrimitives(float4 *__restrict__ arena, unsigned offPrims, int nbPrimitives,
+                                                          const unsigned char *__restrict__ movable,
+                                                          const RotationArgs R)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbPrimitives || !movable[i])
+        return;
+    float4 *r = arena + offPrims + (size_t)PRIM_ROWS * i;
+    float4 p0 = r[ROW_P0_TYPE];
+    const int type = __float_as_int(p0.w) & PRIM_TYPE_MASK;
+    rotateRow(p0, R.cx, R.cy, R.cz, R);
+    r[ROW_P0_TYPE] = p0;
+    if (type == ptCylinder || type == ptTriangle)
+    {
+        float4 p1 = r[ROW_P1_INDEX], p2 = r[ROW_P2], n0 = r[ROW_N0], n1 = r[ROW_N1], n2 = r[ROW_N2];
+        rotateRow(p1, R.cx, R.cy, R.cz, R);
+        rotateRow(p2, R.cx, R.cy, R.cz, R);
+        rotateRow(n0, 0.f, 0.f, 0.f, R);
+        rotateRow(n1, 0.f, 0.f, 0.f, R);
+        rotateRow(n2, 0.f, 0.f, 0.f, R);
+        if (type == ptCylinder)
+        {
+            float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z;
+            const float len = __builtin_sqrtf(ax * ax + ay * ay + az * az);
+            if (len != 0)
+            {
+                ax /= len;
+                ay /= len;
+                az /= len;
+            }
+            n1.x = ax;
+            n1.y = ay;
+            n1.z = az;
+        }
+        r[ROW_P1_INDEX] = p1;
+        r[ROW_P2] = p2;
+        r[ROW_N0] = n0;
+        r[ROW_N1] = n1;
+        r[ROW_N2] = n2;
+    }
+}
+
+/* One node per thread, the nodes of one height of the tree per launch (children first).  A node with
+ * primitives is a level-0 box: updateBoundingBox; one without is the union of its children:
+ * updateOutterBoundingBox, seeded like it (+-viewDistance; +-infinity for our own grouping nodes). */
+__global__ __launch_bounds__(256) void k_refitNodes(float4 *__restrict__ arena, unsigned offNodes, unsigned offStart,
+                                                    unsigned offPrims, const int *__restrict__ list, int count,
+                                                    float seed)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count)
+        return;
+    const int node = list[t];
+    float4 *rows = arena + offNodes;
+    const float4 row1 = rows[2 * node + 1];
+    const int nb = __float_as_int(row1.z);
+    const int skip = __float_as_int(row1.w);
+    float lx, ly, lz, hx, hy, hz;
+    if (nb > 0)
+    {
+        const int first = ((const int *)arena)[offStart + node];
+        lx = ly = lz = 1000000.f;
+        hx = hy = hz = -1000000.f;
+        for (int k = 0; k < nb; ++k)
+        {
+            const float4 *r = arena + offPrims + (size_t)PRIM_ROWS * (first + k);
+            const float4 p0 = r[ROW_P0_TYPE];
+            const float4 size = r[ROW_SIZE_MAT];
+            const int type = __float_as_int(p0.w) & PRIM_TYPE_MASK;
+            /* std::min(a, b) is (b < a) ? b : a and std::max(a, b) is (a < b) ? b : a: kept as such, the
+             * sign of a zero that ties depends on it */
+            float c0x = p0.x, c0y = p0.y, c0z = p0.z, c1x = p0.x, c1y = p0.y, c1z = p0.z;
+            if (type == ptTriangle || type == ptCylinder)
+            {
+                const float4 p1 = r[ROW_P1_INDEX];
+                c0x = (p1.x < p0.x) ? p1.x : p0.x;
+                c0y = (p1.y < p0.y) ? p1.y : p0.y;
+                c0z = (p1.z < p0.z) ? p1.z : p0.z;
+                c1x = (p0.x < p1.x) ? p1.x : p0.x;
+                c1y = (p0.y < p1.y) ? p1.y : p0.y;
+                c1z = (p0.z < p1.z) ? p1.z : p0.z;
+                if (type == ptTriangle)
+                {
+                    const float4 p2 = r[ROW_P2];
+                    c0x = (p2.x < c0x) ? p2.x : c0x;
+                    c0y = (p2.y < c0y) ? p2.y : c0y;
+                    c0z = (p2.z < c0z) ? p2.z : c0z;
+                    c1x = (c1x < p2.x) ? p2.x : c1x;
+                    c1y = (c1y < p2.y) ? p2.y : c1y;
+                    c1z = (c1z < p2.z) ? p2.z : c1z;
+                }
+            }
+            float ax = (c1x < c0x) ? c1x : c0x, ay = (c1y < c0y) ? c1y : c0y, az = (c1z < c0z) ? c1z : c0z;
+            float bx = (c0x > c1x) ? c0x : c1x, by = (c0y > c1y) ? c0y : c1y, bz = (c0z > c1z) ? c0z : c1z;
+            const bool round = type == ptCylinder || type == ptSphere || type == ptCone;
+            const float sy = round ? size.x : size.y, sz = round ? size.x : size.z;
+            ax -= size.x;
+            ay -= sy;
+            az -= sz;
+            bx += size.x;
+            by += sy;
+            bz += sz;
+            if (ax < lx) lx = ax;
+            if (ay < ly) ly = ay;
+            if (az < lz) lz = az;
+            if (bx > hx) hx = bx;
+            if (by > hy) hy = by;
+            if (bz > hz) hz = bz;
+        }
+    }
+    else
+    {
+        lx = ly = lz = seed;
+        hx = hy = hz = -seed;
+        for (int c = node + 1; c < node + skip;)
+        {
+            const float4 a = rows[2 * c], b = rows[2 * c + 1];
+            if (lx > a.x) lx = a.x;
+            if (ly > a.y) ly = a.y;
+            if (lz > a.z) lz = a.z;
+            if (hx < b.x) hx = b.x;
+            if (hy < b.y) hy = b.y;
+            if (hz < a.w) hz = a.w;
+            const int s = __float_as_int(b.w);
+            c += (s > 1) ? s : 1;
+        }
+    }
+    rows[2 * node] = make_float4(lx, ly, lz, hz);
+    rows[2 * node + 1] = make_float4(hx, hy, row1.z, row1.w);
+}
+
+/* walk-order nodes that are copies of nodes of the reference's tree take their refitted bounds */
+__global__ __launch_bounds__(256) void k_copyBounds(float4 *__restrict__ arena, unsigned offFrom, unsigned offTo,
+                                                    const int2 *__restrict__ pairs, int count)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count)
+        return;
+    const int2 p = pairs[t]; /* x: node of the walk-order list, y: the node it was copied from */
+    const float4 a = arena[offFrom + 2 * p.y], b = arena[offFrom + 2 * p.y + 1];
+    const float4 old = arena[offTo + 2 * p.x + 1];
+    arena[offTo + 2 * p.x] = a;
+    arena[offTo + 2 * p.x + 1] = make_float4(b.x, b.y, old.z, old.w);
+}
+
 struct DeviceBuffer
 {
     void *ptr = nullptr;
@@ -783,6 +962,16 @@ struct Engine
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double timedMs = 0.0;
     int timedLaunches = 0;
+
+    /* device-side rotation (solr_hip_rotate_primitives): what to refit, in which order */
+    DeviceBuffer movable, refitPlan;
+    int nbMovable = -1;                 /* flags uploaded for that many primitives, -1: none */
+    std::vector<int> refitLevels;       /* exact list: [offset, count] per height, offsets into refitPlan (ints) */
+    std::vector<int> refitGroupLevels;  /* grouping nodes of the walk-order list, same form */
+    int refitCopyOffset = 0, refitCopyCount = 0;
+    bool refitReady = false;
+    bool deviceAhead = false;           /* the arena has moved on from the host images */
+    int nbDeviceRotations = 0;
 
     int variant = 0;
     bool grouping = true; /* groupSiblings(); variant 5 turns it off for A/B measurements */
@@ -1001,8 +1190,95 @@ int materialTag(const Material &m)
     return tag;
 }
 
+/* What solr_hip_rotate_primitives refits and in which order: the nodes of the reference's list by
+ * height (children before parents; node 0, the light cell, keeps its +-viewDistance, GPUKernel.cpp:1189),
+ * then the walk-order list: copies take the bounds of the node they came from, grouping nodes the union
+ * of their children. */
+static void buildRefitPlan(const std::vector<float4> &exact, const std::vector<float4> &walk, const std::vector<int> &origin)
+{
+    g.refitReady = false;
+    g.refitLevels.clear();
+    g.refitGroupLevels.clear();
+    g.refitCopyOffset = g.refitCopyCount = 0;
+    if (!g.nested)
+        return;
+    auto heights = [](const std::vector<float4> &rows, std::vector<int> &height) {
+        const int n = (int)(rows.size() / 2);
+        height.assign(n, 0);
+        /* nested skip pointers: a node's subtree is the nodes after it up to its skip; going backwards
+         * every child is finished before its parent reads it */
+        std::vector<int> parent(n, -1), stack;
+        for (int i = 0; i < n; ++i)
+        {
+            while (!stack.empty() && i >= stack.back() + std::max(bitsi(rows[2 * stack.back() + 1].w), 1))
+                stack.pop_back();
+            parent[i] = stack.empty() ? -1 : stack.back();
+            stack.push_back(i);
+        }
+        int top = 0;
+        for (int i = n - 1; i >= 0; --i)
+        {
+            if (parent[i] >= 0)
+                height[parent[i]] = std::max(height[parent[i]], height[i] + 1);
+            top = std::max(top, height[i]);
+        }
+        return n ? top + 1 : 0;
+    };
+    std::vector<int> plan;
+    auto byHeight = [&](const std::vector<int> &height, int nbHeights, std::vector<int> &levels, auto wanted) {
+        for (int h = 0; h < nbHeights; ++h)
+        {
+            const int offset = (int)plan.size();
+            for (int i = 0; i < (int)height.size(); ++i)
+                if (height[i] == h && wanted(i))
+                    plan.push_back(i);
+            if ((int)plan.size() > offset)
+            {
+                levels.push_back(offset);
+                levels.push_back((int)plan.size() - offset);
+            }
+        }
+    };
+    std::vector<int> height;
+    int nbHeights = heights(exact, height);
+    byHeight(height, nbHeights, g.refitLevels, [](int i) { return i != 0; });
+    if (plan.size() & 1)
+        plan.push_back(0); /* the pairs below start on 8 bytes */
+    g.refitCopyOffset = (int)plan.size();
+    for (int j = 0; j < (int)origin.size(); ++j)
+        if (origin[j] > 0)
+        {
+            plan.push_back(j);
+            plan.push_back(origin[j]);
+            ++g.refitCopyCount;
+        }
+    nbHeights = heights(walk, height);
+    byHeight(height, nbHeights, g.refitGroupLevels, [&](int j) { return origin[j] < 0; });
+    if (plan.empty())
+        plan.push_back(0);
+    upload(g.refitPlan, plan);
+    g.refitReady = ok();
+}
+
+/* the arena moved on (device-side rotations): bring the host images up to date before anything reads them */
+static void pullGeometry()
+{
+    if (!g.deviceAhead || !g.geometry.ptr)
+        return;
+    quiesce();
+    auto get = [&](unsigned at, void *dst, size_t bytes) {
+        if (bytes)
+            HIPCHECK(hipMemcpy(dst, (const char *)g.geometry.ptr + (size_t)at * 16, bytes, hipMemcpyDeviceToHost));
+    };
+    get(g.offBoxes, g.hostBoxes.data(), g.hostBoxes.size() * 16);
+    get(g.offBoxesCompact, g.hostBoxesCompact.data(), g.hostBoxesCompact.size() * 16);
+    get(g.offPrims, g.hostPrims.data(), g.hostPrims.size() * 16);
+    g.deviceAhead = false;
+}
+
 void retagPrimitives()
 {
+    pullGeometry();
     const size_t n = g.hostPrims.size() / PRIM_ROWS;
     int features = 0;
     for (size_t i = 0; i < n; ++i)
@@ -1051,6 +1327,7 @@ void flushGeometry()
 {
     if (!g.geometryDirty)
         return;
+    pullGeometry();
     auto rowsOfInts = [](size_t n) { return (unsigned)((n + 3) / 4); };
     unsigned row = 0;
     g.offBoxes = row;
@@ -1558,7 +1835,7 @@ void finalize_scene(vec2i)
     collectEvents();
     DeviceBuffer *all[] = {&g.geometry, &g.materials, &g.textures, &g.randoms, &g.lamps,
                            &g.pp,       &g.ids,       &g.bitmap,   &g.counters, &g.tileClock,
-                           &g.tileCost, &g.tileOrder, &g.tileOrder2};
+                           &g.tileCost, &g.tileOrder, &g.tileOrder2, &g.movable,  &g.refitPlan};
     for (DeviceBuffer *b : all)
         release(*b);
     for (int f = 0; f < MAX_FLIGHTS - 1; ++f)
@@ -1587,6 +1864,10 @@ void finalize_scene(vec2i)
     g.stream = nullptr;
     g.ownStream = false;
     g.initialized = false;
+    g.refitReady = false;
+    g.deviceAhead = false;
+    g.nbMovable = -1;
+    g.nbDeviceRotations = 0;
     g.nbBoxes = g.nbPrimitives = g.nbLights = g.nbLamps = g.nbMaterials = 0;
     g.allocW = g.allocRows = 0;
     g.boundBitmap = nullptr;
@@ -1638,7 +1919,7 @@ void solr_hip_reshape(const SceneInfo *sceneInfo)
  *   - groups hold no primitives and have no side effects.
  * Requires nested skip pointers and ordered finite bounds (checked by the caller).  Rewrites the node
  * rows and the first-primitive plane in place; returns the new node count. */
-static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start)
+static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start, std::vector<int> &origin)
 {
     const int n = (int)start.size();
     auto skipOf = [&](int i) { return bitsi(rows[2 * i + 1].w); };
@@ -1665,9 +1946,10 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start)
         return x * y + y * z + z * x;
     };
     std::vector<float4> outRows;
-    std::vector<int> outStart;
+    std::vector<int> outStart, outOrigin; /* origin: the caller's tag of each node, -1 for the nodes made here */
     outRows.reserve(rows.size() + rows.size() / 2);
     outStart.reserve(start.size() + start.size() / 2);
+    outOrigin.reserve(start.size() + start.size() / 2);
 
     /* best split of sib[from, to) into two consecutive parts */
     std::vector<Bounds> suffix;
@@ -1707,6 +1989,7 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start)
         outRows.push_back(rows[2 * i]);
         outRows.push_back(rows[2 * i + 1]);
         outStart.push_back(start[i]);
+        outOrigin.push_back(origin[i]);
         std::vector<int> children;
         for (int j = i + 1; j < i + skipOf(i) && j < n; j += std::max(skipOf(j), 1))
             children.push_back(j);
@@ -1784,6 +2067,7 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start)
             outRows.push_back(make_float4(u.lo[0], u.lo[1], u.lo[2], u.hi[2]));
             outRows.push_back(make_float4(u.hi[0], u.hi[1], bitsf(0), bitsf(1)));
             outStart.push_back(0);
+            outOrigin.push_back(-1);
             emit.siblings(sib, a, b);
             outRows[2 * at + 1].w = bitsf((int)(outStart.size() - at));
         }
@@ -1794,6 +2078,7 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start)
     emit.siblings(top, 0, (int)top.size());
     rows.swap(outRows);
     start.swap(outStart);
+    origin.swap(outOrigin);
     return (int)start.size();
 }
 
@@ -1884,11 +2169,12 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
         newIndex[i + 1] = newIndex[i] + (keep[i] ? 1 : 0);
     const int nc = newIndex[nbActiveBoxes];
     std::vector<float4> boxesC(2 * (size_t)nc);
-    std::vector<int> startC(nc);
+    std::vector<int> startC(nc), originC(nc);
     for (int i = 0; i < nbActiveBoxes; ++i)
         if (keep[i])
         {
             const int j = newIndex[i];
+            originC[j] = i;
             const int end = std::min(i + boundingBoxes[i].indexForNextBox.x, nbActiveBoxes);
             boxesC[2 * j] = boxes[2 * i];
             boxesC[2 * j + 1] = boxes[2 * i + 1];
@@ -1898,7 +2184,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
 
     int nbWalkNodes = nc;
     if (g.nested && g.orderedCompact && nc > 0 && g.grouping)
-        nbWalkNodes = groupSiblings(boxesC, startC);
+        nbWalkNodes = groupSiblings(boxesC, startC, originC);
     if (getenv("SOLR_HIP_DEBUG_TREE"))
     {
         fprintf(stderr, "solr_hip: %d nodes uploaded, %d after collapsing chains, %d with grouping nodes\n",
@@ -1926,6 +2212,9 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     }
     if (prims.empty())
         prims.assign(8, make_float4(0.f, 0.f, 0.f, 0.f)); /* inactive lanes read record 0 */
+    buildRefitPlan(boxes, boxesC, originC);
+    g.deviceAhead = false;
+    g.nbMovable = -1;
     g.hostBoxes.swap(boxes);
     g.hostBoxesCompact.swap(boxesC);
     g.hostBoxStart.swap(start);
@@ -1942,6 +2231,123 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
         g.nbPrimitives = nbPrimitives;
         g.nbLamps = nbLamps;
     }
+}
+
+/* Extension: per flattened primitive, whether GPUKernel::rotatePrimitives would move it (it sits in a
+ * level-0 box, is movable and is not the camera primitive).  Valid until the next h2d_scene. */
+void solr_hip_set_movable(const unsigned char *flags, int nbPrimitives)
+{
+    if (!ready("solr_hip_set_movable"))
+        return;
+    ARGCHECK(nbPrimitives >= 0 && (nbPrimitives == 0 || flags), "solr_hip_set_movable: null flags");
+    if (!ok())
+        return;
+    g.nbMovable = -1;
+    if (nbPrimitives != g.nbPrimitives)
+        return;
+    quiesce();
+    HIPCHECK(hipSetDevice(g.device));
+    std::vector<unsigned char> f(flags, flags + nbPrimitives);
+    if (f.empty())
+        f.push_back(0);
+    upload(g.movable, f);
+    if (ok())
+        g.nbMovable = nbPrimitives;
+}
+
+/* Extension: GPUKernel::rotatePrimitives + compactBoxes(false) + h2d_scene on the resident scene
+ * (GPUKernel.cpp:1378-1460, 1151-1281 of the reference), see k_rotatePrimitives.  Returns 1 when the
+ * arena now holds the rotated scene, 0 when the request cannot be served here and the caller has to
+ * take the host route (nothing was changed). */
+int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], const float sinAngles[3],
+                               float viewDistance)
+{
+    if (!ready("solr_hip_rotate_primitives") || !ok())
+        return 0;
+    /* the seeds of the two box updates only commute with the unions while viewDistance <= 1e6, and a
+     * tree cut off at NB_MAX_BOXES has host-side children the flattened list does not show */
+    if (!g.refitReady || g.nbMovable != g.nbPrimitives || g.nbPrimitives <= 0 || !(viewDistance <= 1000000.f) ||
+        !(viewDistance > 0.f) || g.nbBoxes >= NB_MAX_BOXES || !center || !cosAngles || !sinAngles)
+    {
+        if (getenv("SOLR_HIP_DEBUG_TREE"))
+            fprintf(stderr, "solr_hip_rotate_primitives refused: plan %d, flags for %d of %d primitives, viewDistance %g, %d nodes\n",
+                    (int)g.refitReady, g.nbMovable, g.nbPrimitives, viewDistance, g.nbBoxes);
+        return 0;
+    }
+    HIPCHECK(hipSetDevice(g.device));
+    flushGeometry();
+    if (!ok())
+        return 0;
+    quiesce();
+    RotationArgs R;
+    R.cx = center[0], R.cy = center[1], R.cz = center[2];
+    R.cosx = cosAngles[0], R.cosy = cosAngles[1], R.cosz = cosAngles[2];
+    R.sinx = sinAngles[0], R.siny = sinAngles[1], R.sinz = sinAngles[2];
+    float4 *arena = (float4 *)g.geometry.ptr;
+    const int *plan = (const int *)g.refitPlan.ptr;
+    auto blocks = [](int n) { return dim3((unsigned)((n + 255) / 256)); };
+    hipLaunchKernelGGL(k_rotatePrimitives, blocks(g.nbPrimitives), dim3(256), 0, g.stream, arena, g.offPrims,
+                       g.nbPrimitives, (const unsigned char *)g.movable.ptr, R);
+    for (size_t l = 0; l + 1 < g.refitLevels.size(); l += 2)
+        hipLaunchKernelGGL(k_refitNodes, blocks(g.refitLevels[l + 1]), dim3(256), 0, g.stream, arena, g.offBoxes,
+                           g.offBoxStart, g.offPrims, plan + g.refitLevels[l], g.refitLevels[l + 1], viewDistance);
+    if (g.refitCopyCount)
+        hipLaunchKernelGGL(k_copyBounds, blocks(g.refitCopyCount), dim3(256), 0, g.stream, arena, g.offBoxes,
+                           g.offBoxesCompact, (const int2 *)(plan + g.refitCopyOffset), g.refitCopyCount);
+    for (size_t l = 0; l + 1 < g.refitGroupLevels.size(); l += 2)
+        hipLaunchKernelGGL(k_refitNodes, blocks(g.refitGroupLevels[l + 1]), dim3(256), 0, g.stream, arena,
+                           g.offBoxesCompact, g.offBoxStartCompact, g.offPrims, plan + g.refitGroupLevels[l],
+                           g.refitGroupLevels[l + 1], INFINITY);
+    HIPCHECK(hipGetLastError());
+    /* the other flights' streams start their next frame only after this */
+    HIPCHECK(hipStreamSynchronize(g.stream));
+    if (!ok())
+        return 0;
+    g.deviceAhead = true;
+    ++g.nbDeviceRotations;
+    return 1;
+}
+
+int solr_hip_device_rotations(void)
+{
+    return g.nbDeviceRotations;
+}
+
+/* Diagnostics / tests: the resident arena's node lists and primitive records as the device holds them
+ * now.  exact != 0: the reference's list, else the walk-order list.  Returns the number of float4 rows
+ * written (2 per node, 8 per primitive), -1 if the capacity is too small. */
+int solr_hip_read_nodes(int exact, float *rows, int capacityRows)
+{
+    if (!ready("solr_hip_read_nodes") || !g.geometry.ptr)
+        return -1;
+    flushGeometry();
+    quiesce();
+    const int n = 2 * (exact ? g.nbBoxes : g.nbBoxesCompact);
+    if (!rows)
+        return n; /* size query */
+    if (n > capacityRows)
+        return -1;
+    if (n)
+        HIPCHECK(hipMemcpy(rows, (const char *)g.geometry.ptr + (size_t)(exact ? g.offBoxes : g.offBoxesCompact) * 16,
+                           (size_t)n * 16, hipMemcpyDeviceToHost));
+    return ok() ? n : -1;
+}
+
+int solr_hip_read_primitives(float *rows, int capacityRows)
+{
+    if (!ready("solr_hip_read_primitives") || !g.geometry.ptr)
+        return -1;
+    flushGeometry();
+    quiesce();
+    const int n = PRIM_ROWS * g.nbPrimitives;
+    if (!rows)
+        return n;
+    if (n > capacityRows)
+        return -1;
+    if (n)
+        HIPCHECK(hipMemcpy(rows, (const char *)g.geometry.ptr + (size_t)g.offPrims * 16, (size_t)n * 16,
+                           hipMemcpyDeviceToHost));
+    return ok() ? n : -1;
 }
 
 void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)

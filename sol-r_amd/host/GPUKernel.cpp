@@ -113,6 +113,7 @@ void GPUKernel::initBuffers()
     memset(m_hMaterials.data(), 0, m_hMaterials.size() * sizeof(Material));
     m_hBoundingBoxes.clear();
     m_hPrimitives.clear();
+    m_hMovable.clear();
     m_hLamps.clear();
     for (int i = 0; i < NB_MAX_TEXTURES; ++i)
         delete[] m_hTextures[i].buffer;
@@ -574,6 +575,10 @@ int GPUKernel::processOutterBoxes(const int boxSize, const int boundingBoxesDept
 /* reference: GPUKernel.cpp:1041-1083 */
 int GPUKernel::compactBoxes(bool reconstructBoxes)
 {
+    /* rotations applied on the device: the flattened scene over there is already what the lines below
+     * would produce and upload */
+    if (!reconstructBoxes && !m_pendingRotations.empty())
+        return frameAsIs().nbActiveBoxes;
     m_primitivesTransfered = false;
     if (reconstructBoxes)
     {
@@ -609,7 +614,7 @@ int GPUKernel::compactBoxes(bool reconstructBoxes)
     return frame().nbActiveBoxes;
 }
 
-void GPUKernel::appendPrimitive(long id)
+void GPUKernel::appendPrimitive(long id, bool inLevel0Box)
 {
     CPUPrimitive &primitive = frame().primitives[(unsigned int)id];
     Primitive out;
@@ -628,6 +633,7 @@ void GPUKernel::appendPrimitive(long id)
     out.vt1 = primitive.vt1;
     out.vt2 = primitive.vt2;
     m_hPrimitives.push_back(out);
+    m_hMovable.push_back(inLevel0Box && primitive.movable && primitive.type != ptCamera);
     ++frame().nbActivePrimitives;
 }
 
@@ -656,7 +662,7 @@ void GPUKernel::recursiveDataStreamToGPU(const int depth, std::vector<long> &ele
                 m_maxPrimitivesPerBox = std::max(m_maxPrimitivesPerBox, box.primitives.size());
                 for (long id : box.primitives)
                     if (id < NB_MAX_PRIMITIVES)
-                        appendPrimitive(id);
+                        appendPrimitive(id, true);
             }
             else
                 recursiveDataStreamToGPU(depth - 1, box.primitives);
@@ -676,6 +682,7 @@ void GPUKernel::streamDataToGPU()
     m_maxPrimitivesPerBox = 0;
     m_hBoundingBoxes.clear();
     m_hPrimitives.clear();
+    m_hMovable.clear();
     m_hLamps.clear();
     {
         size_t nodes = 0;
@@ -683,6 +690,7 @@ void GPUKernel::streamDataToGPU()
             nodes += f.boundingBoxes[level].size();
         m_hBoundingBoxes.reserve(nodes);
         m_hPrimitives.reserve(f.primitives.size());
+        m_hMovable.reserve(f.primitives.size());
     }
     if (m_lightInformation.size() < NB_MAX_LIGHTINFORMATIONS)
         m_lightInformation.assign(NB_MAX_LIGHTINFORMATIONS, LightInformation());
@@ -710,7 +718,7 @@ void GPUKernel::streamDataToGPU()
             out.startIndex = 0;
             for (long id : box.primitives)
             {
-                appendPrimitive(id);
+                appendPrimitive(id, false);
                 CPUPrimitive &primitive = f.primitives[(unsigned int)id];
                 Material &material = m_hMaterials[primitive.materialId];
                 LightInformation li;
@@ -792,15 +800,31 @@ void GPUKernel::rotateVector(vec3f &v, const vec3f &c, const vec3f &cosA, const 
  * refits every level without re-hashing. */
 void GPUKernel::rotatePrimitives(const vec3f &rotationCenter, const vec4f &angles)
 {
-    m_primitivesTransfered = false;
     vec3f cosA = make_vec3f(cosf(angles.x), cosf(angles.y), cosf(angles.z));
     vec3f sinA = make_vec3f(sinf(angles.x), sinf(angles.y), sinf(angles.z));
+    /* the scene the device holds is the one the host holds (plus the rotations already pending): the
+     * engine may turn it in place, and the host copy follows when somebody looks (syncHost) */
+    if (m_primitivesTransfered && !m_hostTouched && deviceRotatePrimitives(rotationCenter, cosA, sinA))
+    {
+        PendingRotation r;
+        r.center = rotationCenter;
+        r.cosA = cosA;
+        r.sinA = sinA;
+        m_pendingRotations.push_back(r);
+        return;
+    }
     Frame &f = frame();
+    m_primitivesTransfered = false;
+    rotatePrimitivesOnly(f, rotationCenter, cosA, sinA);
+    refitBoxes(f);
+}
+
+void GPUKernel::rotatePrimitivesOnly(Frame &f, const vec3f &rotationCenter, const vec3f &cosA, const vec3f &sinA)
+{
     const vec3f zero = make_vec3f();
     for (auto &entry : f.boundingBoxes[0])
     {
         CPUBoundingBox &box = entry.second;
-        resetBox(box, false);
         for (long id : box.primitives)
         {
             CPUPrimitive &p = f.primitives[(unsigned int)id];
@@ -829,11 +853,39 @@ void GPUKernel::rotatePrimitives(const vec3f &rotationCenter, const vec4f &angle
                 }
             }
         }
-        updateBoundingBox(box);
+    }
+}
+
+/* the box updates of the reference's rotatePrimitives: they read the primitives only, so one pass after
+ * several rotations leaves what one pass after each would */
+void GPUKernel::refitBoxes(Frame &f)
+{
+    for (auto &entry : f.boundingBoxes[0])
+    {
+        resetBox(entry.second, false);
+        updateBoundingBox(entry.second);
     }
     for (int b = 1; b < BOUNDING_BOXES_TREE_DEPTH; ++b)
         for (auto &entry : f.boundingBoxes[b])
             updateOutterBoundingBox(entry.second, b - 1);
+}
+
+void GPUKernel::syncHost()
+{
+    if (m_pendingRotations.empty())
+        return;
+    std::vector<PendingRotation> pending;
+    pending.swap(m_pendingRotations);
+    Frame &f = m_frames[m_frame];
+    for (const PendingRotation &r : pending)
+        rotatePrimitivesOnly(f, r.center, r.cosA, r.sinA);
+    refitBoxes(f);
+    /* the flattened arrays follow.  What they now hold is what the device holds (the same arithmetic
+     * ran there), so neither an upload is due nor has the scene been "touched" by this */
+    const bool transfered = m_primitivesTransfered, touched = m_hostTouched;
+    streamDataToGPU();
+    m_primitivesTransfered = transfered;
+    m_hostTouched = touched;
 }
 
 /* reference: GPUKernel.cpp:1462-1511 */
@@ -1140,9 +1192,9 @@ void GPUKernel::setPostProcessingInfo(const PostProcessingInfo &postProcessingIn
     m_postProcessingInfo = postProcessingInfo;
 }
 
-unsigned int GPUKernel::getNbActiveBoxes() { return frame().nbActiveBoxes; }
-unsigned int GPUKernel::getNbActivePrimitives() { return frame().nbActivePrimitives; }
-unsigned int GPUKernel::getNbActiveLamps() { return frame().nbActiveLamps; }
+unsigned int GPUKernel::getNbActiveBoxes() { return frameAsIs().nbActiveBoxes; }
+unsigned int GPUKernel::getNbActivePrimitives() { return frameAsIs().nbActivePrimitives; }
+unsigned int GPUKernel::getNbActiveLamps() { return frameAsIs().nbActiveLamps; }
 unsigned int GPUKernel::getNbActiveMaterials() { return m_nbActiveMaterials; }
 unsigned int GPUKernel::getNbActiveTextures() { return m_nbActiveTextures; }
 

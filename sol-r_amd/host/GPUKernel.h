@@ -288,7 +288,12 @@ public:
     void resetFrame();
     void resetAll();
     void setNbFrames(const int nbFrames) { m_nbFrames = nbFrames; }
-    void setFrame(const int frame) { m_frame = frame; }
+    void setFrame(const int frame)
+    {
+        if ((unsigned int)frame != m_frame)
+            syncHost();
+        m_frame = frame;
+    }
     int getNbFrames() { return m_nbFrames; }
     int getFrame() { return m_frame; }
 
@@ -310,10 +315,18 @@ public:
      * distribution 5e-6 * (k % 2000 - 1000); -1 restores rand(). */
     void setDeterministic(long seed);
     /* flattened arrays of the current frame, as handed to the device layer */
-    const std::vector<BoundingBox> &hostBoxes() const { return m_hBoundingBoxes; }
-    const std::vector<Primitive> &hostPrimitives() const { return m_hPrimitives; }
-    const std::vector<Lamp> &hostLamps() const { return m_hLamps; }
-    const std::vector<LightInformation> &hostLights() const { return m_lightInformation; }
+    const std::vector<BoundingBox> &hostBoxes() { syncHost(); return m_hBoundingBoxes; }
+    const std::vector<Primitive> &hostPrimitives() { syncHost(); return m_hPrimitives; }
+    const std::vector<Lamp> &hostLamps() { syncHost(); return m_hLamps; }
+    const std::vector<LightInformation> &hostLights() { syncHost(); return m_lightInformation; }
+    /* per flattened primitive: would rotatePrimitives move it (level-0 box, movable, not the camera) */
+    const std::vector<unsigned char> &hostMovable() { syncHost(); return m_hMovable; }
+    /* Animated scenes: rotatePrimitives + compactBoxes(false) per frame (MoleculeScene.cpp:75-81).  An
+     * engine that keeps the scene resident may apply the rotation there (deviceRotatePrimitives); the
+     * host copy then lags behind by the rotations listed in m_pendingRotations and is caught up - the same
+     * arithmetic, replayed in order - by syncHost() before anything reads or changes it. */
+    void syncHost();
+    size_t nbPendingRotations() const { return m_pendingRotations.size(); }
     int lightInformationSize() const { return m_lightInformationSize; }
     const Material *hostMaterials() const { return m_hMaterials.data(); }
     const std::vector<RandomBuffer> &hostRandoms() const { return m_hRandoms; }
@@ -332,7 +345,21 @@ protected:
         vec3f minPos = {0.f, 0.f, 0.f};
         vec3f maxPos = {0.f, 0.f, 0.f};
     };
-    Frame &frame() { return m_frames[m_frame]; }
+    /* every access to the scene store: catches the host copy up and ends the device-side fast path until
+     * the next upload (the caller may be about to change what the device holds) */
+    Frame &frame()
+    {
+        m_hostTouched = true;
+        if (!m_pendingRotations.empty())
+            syncHost();
+        return m_frames[m_frame];
+    }
+    /* counters and the frame protocol: reads that stay valid while rotations are pending */
+    Frame &frameAsIs() { return m_frames[m_frame]; }
+    /* engine hook: apply the rotation to the resident scene; false = not done, nothing changed */
+    virtual bool deviceRotatePrimitives(const vec3f &, const vec3f &, const vec3f &) { return false; }
+    void rotatePrimitivesOnly(Frame &f, const vec3f &rotationCenter, const vec3f &cosA, const vec3f &sinA);
+    void refitBoxes(Frame &f);
 
     /* box-tree build (GPUKernel.h:318-324) */
     int processBoxes(const int boxSize, bool simulate);
@@ -341,7 +368,7 @@ protected:
     bool updateOutterBoundingBox(CPUBoundingBox &box, const int depth);
     void resetBox(CPUBoundingBox &box, bool resetPrimitives);
     void recursiveDataStreamToGPU(const int depth, std::vector<long> &elements);
-    void appendPrimitive(long id);
+    void appendPrimitive(long id, bool inLevel0Box);
     void fillRandoms();
 
     float vectorLength(const vec3f &v);
@@ -354,6 +381,7 @@ protected:
     std::vector<BoundingBox> m_hBoundingBoxes;
     std::vector<Primitive> m_hPrimitives;
     std::vector<Lamp> m_hLamps;
+    std::vector<unsigned char> m_hMovable;
     std::vector<Material> m_hMaterials;
     TextureInfo m_hTextures[NB_MAX_TEXTURES];
     std::vector<BitmapBuffer> m_textureAtlas;
@@ -382,6 +410,12 @@ protected:
     bool m_materialsTransfered;
     bool m_texturesTransfered;
     bool m_randomsTransfered;
+    bool m_hostTouched = true; /* scene store accessed since the last upload */
+    struct PendingRotation
+    {
+        vec3f center, cosA, sinA;
+    };
+    std::vector<PendingRotation> m_pendingRotations;
 
     SceneInfo m_sceneInfo;
     PostProcessingInfo m_postProcessingInfo;

@@ -58,6 +58,7 @@ void HipKernel::initializeDevice()
 
 void HipKernel::releaseDevice()
 {
+    syncHost(); /* rotations that only the device has seen would be lost with it */
     if (m_deviceInitialized)
         finalize_scene(m_occupancyParameters);
     m_deviceInitialized = false;
@@ -85,7 +86,9 @@ void HipKernel::render_begin(const float timer)
     GPUKernel::render_begin(timer);
     if (m_refresh)
     {
-        Frame &f = frame();
+        if (!m_primitivesTransfered)
+            syncHost(); /* somebody asked for a fresh upload while rotations were pending on the device */
+        Frame &f = frameAsIs();
         int nbBoxes = f.nbActiveBoxes;
         int nbPrimitives = f.nbActivePrimitives;
         int nbLamps = f.nbActiveLamps;
@@ -96,7 +99,9 @@ void HipKernel::render_begin(const float timer)
             h2d_scene(m_occupancyParameters, m_hBoundingBoxes.data(), nbBoxes, m_hPrimitives.data(), nbPrimitives,
                       m_hLamps.data(), nbLamps);
             h2d_lightInformation(m_occupancyParameters, m_lightInformation.data(), m_lightInformationSize);
+            solr_hip_set_movable(m_hMovable.data(), (int)m_hMovable.size());
             m_primitivesTransfered = true;
+            m_hostTouched = false; /* device and host hold the same scene from here on */
         }
         if (!m_randomsTransfered)
         {
@@ -127,6 +132,16 @@ void HipKernel::render_begin(const float timer)
                    m_angles);
     }
     m_refresh = (m_sceneInfo.pathTracingIteration < m_sceneInfo.maxPathTracingIterations);
+}
+
+bool HipKernel::deviceRotatePrimitives(const vec3f &center, const vec3f &cosA, const vec3f &sinA)
+{
+    if (!m_deviceInitialized)
+        return false;
+    const float c[3] = {center.x, center.y, center.z};
+    const float co[3] = {cosA.x, cosA.y, cosA.z};
+    const float si[3] = {sinA.x, sinA.y, sinA.z};
+    return solr_hip_rotate_primitives(c, co, si, m_sceneInfo.viewDistance) == 1;
 }
 
 void HipKernel::render_end()

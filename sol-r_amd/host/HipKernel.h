@@ -47,6 +47,10 @@ public:
     }
     void setSharedMemSize(int sharedMemSize) { m_sharedMemSize = sharedMemSize; }
 
+protected:
+    /* rotatePrimitives on the resident scene, solr_hip_rotate_primitives (include/solr_hip.h) */
+    bool deviceRotatePrimitives(const vec3f &center, const vec3f &cosA, const vec3f &sinA) override;
+
 private:
     vec4i m_blockSize;
     int m_sharedMemSize;

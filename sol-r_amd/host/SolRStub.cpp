@@ -199,6 +199,25 @@ int SolR_RotatePrimitives(int, int, double rx, double ry, double rz, double ax, 
     return 0;
 }
 
+int SolRx_PendingRotations()
+{
+    return (int)SingletonKernel::kernel()->nbPendingRotations();
+}
+
+int SolRx_SyncHost()
+{
+    SingletonKernel::kernel()->syncHost();
+    return 0;
+}
+
+int SolRx_GetMovable(const unsigned char **flags, int *nbPrimitives)
+{
+    const std::vector<unsigned char> &v = SingletonKernel::kernel()->hostMovable();
+    *flags = v.data();
+    *nbPrimitives = (int)v.size();
+    return 0;
+}
+
 int SolR_SetPrimitiveMaterial(int index, int materialId)
 {
     SingletonKernel::kernel()->setPrimitiveMaterial(index, materialId);

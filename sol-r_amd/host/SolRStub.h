@@ -102,6 +102,10 @@ int SolRx_GetPrimitiveIds(const PrimitiveXYIdBuffer **ids, int *nbPixels);
 int SolRx_GetSceneInfo(SceneInfo *sceneInfo, PostProcessingInfo *postProcessingInfo, float eye[3], float dir[3],
                        float angles[4]);
 int SolRx_GetTreeDepth();
+/* rotations applied on the device that the host scene store has not replayed yet; SolRx_SyncHost replays them */
+int SolRx_PendingRotations();
+int SolRx_SyncHost();
+int SolRx_GetMovable(const unsigned char **flags, int *nbPrimitives);
 /* float framebuffer of the last frame, W*H records */
 int SolRx_GetPostProcessingBuffer(PostProcessingBuffer *buffer);
 /* camera with an explicit angles.w (SolR_SetCamera forces 6400) */

@@ -1,0 +1,165 @@
+"""Animated scenes: GPUKernel::rotatePrimitives + compactBoxes(false) per frame (reference:
+apps/scenes/science/MoleculeScene.cpp:75-81, GPUKernel.cpp:1378-1460 and :1151-1281).
+
+With the HIP engine the rotation runs on the resident scene (solr_hip_rotate_primitives) and the host
+scene store follows lazily.  The bar: after any number of such steps the device holds, bit for bit, the
+primitives and the node list the host route (rotate on the host, flatten, upload) produces; the frames
+rendered on the way match the oracle on the host-route scene; and the host store, once it catches up,
+equals the host route's."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import scenes_extra  # noqa: E402
+from helpers import assert_parity, compare_frames, gpu_frame, oracle_frame  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+STEPS = [((0.0, 0.0, 0.0), (0.0, 0.02, 0.0)), ((10.0, -20.0, 30.0), (0.11, -0.07, 0.05)),
+         ((0.0, 0.0, 0.0), (0.0, 0.0, 0.3)), ((-500.0, 100.0, 0.0), (-0.2, 0.4, 0.0)),
+         ((0.0, 0.0, 0.0), (1.5, 0.02, -0.6))]
+
+SCENES = [
+    ("molecule", dict(atoms=400, width=96, height=64, iterations=2)),
+    ("height_field", dict(n=20, width=96, height=64)),
+    ("cornell", dict(width=96, height=64, iterations=3)),
+    ("primitives_mix", dict()),
+    ("sticks", dict()),
+]
+
+
+def _build(solr, spec, engine):
+    name, kw = spec
+    k = solr.Kernel(engine=engine, deterministic_seed=1)
+    (getattr(solr.scenes, name, None) or getattr(scenes_extra, name))(k, **kw)
+    return k
+
+
+def _node_rows(flat):
+    """the reference's flattened boxes in the engine's node-record layout (scene_layout.h)"""
+    b = flat.boxes
+    rows = np.zeros((len(b), 2, 4), np.float32)
+    rows[:, 0, :3] = b["min"]
+    rows[:, 0, 3] = b["max"][:, 2]
+    rows[:, 1, :2] = b["max"][:, :2]
+    rows[:, 1, 2] = b["nbPrimitives"].view(np.float32)
+    rows[:, 1, 3] = b["indexForNextBox"][:, 0].copy().view(np.float32)
+    return rows
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def _same_records(a, b):
+    """field by field: the structs carry padding that no one initialises"""
+    return len(a) == len(b) and all(_same_bits(a[f], b[f]) for f in a.dtype.names)
+
+
+def _primitive_geometry(rows):
+    """p0 p1 p2 n0 n1 n2 of the device's primitive records (rows 0, 2, 3, 4, 5, 6; .xyz)"""
+    return rows[:, [0, 2, 3, 4, 5, 6], :3]
+
+
+@pytest.mark.parametrize("spec", SCENES, ids=[s[0] for s in SCENES])
+def test_device_rotation_equals_host_rotation(solr, oracle, spec):
+    hip = solr.hip_lib()
+    k = _build(solr, spec, "hip")
+    gpu_frame(k)                                   # uploads the scene
+    frames = []
+    for n, (center, angles) in enumerate(STEPS):
+        k.rotate_primitives(center, angles)
+        assert k.pending_rotations() == n + 1, "the rotation took the host route"
+        frames.append(gpu_frame(k))
+    assert hip.solr_hip_device_rotations() == len(STEPS)
+    nodes = k.device_nodes(exact=True)
+    prims = k.device_primitives()
+    walk = k.device_nodes(exact=False)
+    assert k.pending_rotations() == len(STEPS)     # reading the device does not wake the host store
+    caught_up = k.flat_scene()                     # this does
+    assert k.pending_rotations() == 0
+    pp2, ids2, rgb2 = gpu_frame(k)                 # fresh upload of the replayed host scene
+    walk_fresh = k.device_nodes(exact=False)
+    k.finalize()
+
+    h = _build(solr, spec, "host-only")
+    for n, (center, angles) in enumerate(STEPS):
+        h.rotate_primitives(center, angles)
+        assert h.pending_rotations() == 0
+        if n in (0, len(STEPS) - 1):
+            pp, ids, rgb = frames[n]
+            flat = h.flat_scene()
+            flat.randoms = caught_up.randoms       # a store that never rendered has not drawn its random buffer
+            si, ppi, eye, direction, view_angles = h.frame_parameters()
+            opp, oids, orgb, _, status = oracle.render(flat, si, ppi, eye, direction, view_angles)
+            assert status == 0
+            assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
+    flat = h.flat_scene()
+    # the host store after its lazy replay == the host route
+    assert _same_records(caught_up.boxes, flat.boxes)
+    assert _same_records(caught_up.primitives, flat.primitives)
+    # the resident scene == what the host route would upload
+    assert nodes.shape[0] == len(flat.boxes)
+    assert _same_bits(nodes, _node_rows(flat))
+    fp = flat.primitives
+    want = np.stack([fp["p0"], fp["p1"], fp["p2"], fp["n0"], fp["n1"], fp["n2"]], axis=1)
+    assert _same_bits(_primitive_geometry(prims), want)
+    # the engine's own walk-order list keeps the shape it was given at upload; refitted, every node still
+    # holds its children (a fresh upload may group differently, the frames are the same either way)
+    assert walk.shape[0] > 0 and np.isfinite(walk[:, 0, :3]).all()
+    pp, ids, rgb = frames[-1]
+    res = compare_frames(pp, ids, rgb, pp2, ids2, rgb2)
+    assert res["ids_all_equal"] and res["max_ulp"] == 0 and res["rgb_max_diff"] == 0, res
+    assert walk_fresh.shape[0] > 0
+    h.finalize()
+
+
+def test_touching_the_scene_store_ends_the_fast_path(solr, oracle):
+    k = _build(solr, SCENES[0], "hip")
+    gpu_frame(k)
+    k.rotate_primitives((0.0, 0.0, 0.0), (0.0, 0.1, 0.0))
+    assert k.pending_rotations() == 1
+    gpu_frame(k)
+    # a change of the scene store: the next rotation has to see it, so it runs on the host and is uploaded
+    k.L.SolR_SetPrimitiveMaterial(3, 5)
+    assert k.pending_rotations() == 0
+    k.rotate_primitives((0.0, 0.0, 0.0), (0.0, 0.1, 0.0))
+    assert k.pending_rotations() == 0
+    pp, ids, rgb = gpu_frame(k)
+    opp, oids, orgb, _, status = oracle_frame(k, oracle)
+    assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
+    # ... after which the scene is resident and unchanged again (reading the flattened arrays is no change)
+    k.rotate_primitives((0.0, 0.0, 0.0), (0.0, 0.1, 0.0))
+    assert k.pending_rotations() == 1
+    pp, ids, rgb = gpu_frame(k)
+    opp, oids, orgb, _, status = oracle_frame(k, oracle)   # catches the host store up
+    assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
+    k.finalize()
+
+
+def test_rotation_with_frames_in_flight_and_materials_update(solr, oracle):
+    """a retag of the primitives (materials change) rebuilds the arena from the host images: they must
+    have been brought up to date from the device first"""
+    hip = solr.hip_lib()
+    k = _build(solr, SCENES[0], "hip")
+    hip.solr_hip_set_frames_in_flight(2)
+    try:
+        gpu_frame(k)
+        for _ in range(3):
+            k.rotate_primitives((0.0, 0.0, 0.0), (0.03, 0.1, 0.0))
+            gpu_frame(k)
+        assert k.pending_rotations() == 3
+        k.L.SolR_SetMaterial(5, 0.9, 0.1, 0.1, 0.0, 0.0, 0.0, 0, 0, 0, 0.0, 0.0, -1, -1, -1, -1, -1, -1, -1, 1.0, 200.0,
+                             0.0, 0.0, 0.0, 0.0, 0)
+        still_pending = k.pending_rotations()
+        pp, ids, rgb = gpu_frame(k)
+        opp, oids, orgb, _, status = oracle_frame(k, oracle)
+        assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
+        assert still_pending in (0, 3)
+    finally:
+        hip.solr_hip_set_frames_in_flight(1)
+        k.finalize()
