@@ -40,7 +40,10 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iterations", type=int, default=3)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "height_field", "molecule"])
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "height_field", "molecule", "irt_model"])
+    ap.add_argument("--scene-file", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden",
+                                                         "model_subset.irt"),
+                    help="--scene irt_model: the .irt file (reference: medias/irt/test.irt)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--graphics-level", type=int, default=4, help="experiments only; the metric is quoted at 4 (glFull)")
     ap.add_argument("--tile-scheduling", type=int, default=1, help="0 raster order, 1 automatic (default), 2 cost order")
@@ -97,9 +100,12 @@ def main():
     k = solr.Kernel(engine="hip", device=local_rank)
     builder = getattr(solr.scenes, args.scene)
     kw = dict(width=W, height=H, iterations=args.iterations)
-    if args.scene != "cornell":
+    if args.scene not in ("cornell", "irt_model"):
         kw.pop("iterations")
-    builder(k, **kw)
+    if args.scene == "irt_model":
+        builder(k, args.scene_file, **kw)
+    else:
+        builder(k, **kw)
     if args.graphics_level != 4:
         k.set_scene_info(graphicsLevel=args.graphics_level)
     hip.solr_hip_set_variant(args.variant)

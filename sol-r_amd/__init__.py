@@ -235,6 +235,8 @@ def _declare_host(L):
     L.SolRx_AddRectangle.argtypes = [d] * 6 + [i]
     L.SolRx_SetSceneInfoExtras.argtypes = [i, i]
     L.SolRx_GetMovable.argtypes = [P(C.c_void_p), P(i)]
+    L.SolR_LoadFromFile.argtypes = [C.c_char_p, d]
+    L.SolR_SaveToFile.argtypes = [C.c_char_p]
 
 
 def _np_from_ptr(ptr, count, dtype):
@@ -364,6 +366,15 @@ class Kernel:
 
     def compact_boxes(self, reconstruct=True):
         return self.L.SolR_CompactBoxes(reconstruct)
+
+    def load_from_file(self, path, scale):
+        """Append an .irt scene dump (reference: FileMarshaller::loadFromFile via SolR_LoadFromFile): its
+        primitives, textures and materials; every primitive of the kernel is then rescaled so that the
+        loaded model is `scale` high."""
+        return self.L.SolR_LoadFromFile(os.fsencode(path), scale)
+
+    def save_to_file(self, path):
+        return self.L.SolR_SaveToFile(os.fsencode(path))
 
     def rotate_primitives(self, center=(0.0, 0.0, 0.0), angles=(0.0, 0.0, 0.0)):
         """One step of an animated scene: GPUKernel::rotatePrimitives + compactBoxes(false), as the

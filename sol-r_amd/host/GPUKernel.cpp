@@ -874,6 +874,7 @@ void GPUKernel::syncHost()
 {
     if (m_pendingRotations.empty())
         return;
+    const bool transfered = m_primitivesTransfered, touched = m_hostTouched;
     std::vector<PendingRotation> pending;
     pending.swap(m_pendingRotations);
     Frame &f = m_frames[m_frame];
@@ -882,7 +883,6 @@ void GPUKernel::syncHost()
     refitBoxes(f);
     /* the flattened arrays follow.  What they now hold is what the device holds (the same arithmetic
      * ran there), so neither an upload is due nor has the scene been "touched" by this */
-    const bool transfered = m_primitivesTransfered, touched = m_hostTouched;
     streamDataToGPU();
     m_primitivesTransfered = transfered;
     m_hostTouched = touched;

@@ -169,6 +169,21 @@ int HostOnlyKernel::lastError(std::string *message)
     return m_failed ? -1 : 0;
 }
 
+void ReplayKernel::render_begin(const float timer)
+{
+    HostOnlyKernel::render_begin(timer);
+    if (!m_primitivesTransfered)
+        syncHost();
+    m_primitivesTransfered = true; /* the upload a real engine does here */
+    m_hostTouched = false;
+}
+
+bool ReplayKernel::deviceRotatePrimitives(const vec3f &, const vec3f &, const vec3f &)
+{
+    ++m_claimed;
+    return true;
+}
+
 /* reference: GPUKernel.cpp:115-128 (compile-time there, run-time here) */
 static std::string gEngineName = "hip";
 
@@ -190,6 +205,8 @@ GPUKernel *SingletonKernel::kernel()
     {
         if (gEngineName == "host-only")
             m_kernel = new HostOnlyKernel();
+        else if (gEngineName == "host-replay")
+            m_kernel = new ReplayKernel();
         else
             m_kernel = new HipKernel();
     }

@@ -67,7 +67,24 @@ public:
     void render_end() override;
     int lastError(std::string *message = nullptr) override;
 
-private:
+protected:
     bool m_failed = false;
+};
+
+/* Test double for the animated-scene protocol (GPUKernel::rotatePrimitives / syncHost): a host-only
+ * store that claims, like an engine with a resident scene would, to have uploaded the scene at the first
+ * frame and to apply every rotation "over there" - so that the lazy replay of the pending rotations can be
+ * checked against the eager host route without a GPU.  Renders nothing. */
+class ReplayKernel : public HostOnlyKernel
+{
+public:
+    void render_begin(const float timer) override;
+    int nbClaimedRotations() const { return m_claimed; }
+
+protected:
+    bool deviceRotatePrimitives(const vec3f &, const vec3f &, const vec3f &) override;
+
+private:
+    int m_claimed = 0;
 };
 }

@@ -10,6 +10,7 @@
 #include <string>
 
 #include "../../include/solr_hip.h"
+#include "FileMarshaller.h"
 #include "GPUKernel.h"
 
 using solr::SingletonKernel;
@@ -197,6 +198,21 @@ int SolR_RotatePrimitives(int, int, double rx, double ry, double rz, double ax, 
     SingletonKernel::kernel()->rotatePrimitives(rotationCenter, angles);
     SingletonKernel::kernel()->compactBoxes(false);
     return 0;
+}
+
+int SolR_SaveToFile(char *filename)
+{
+    solr::FileMarshaller fm;
+    fm.saveToFile(*SingletonKernel::kernel(), filename ? filename : "");
+    return (int)SingletonKernel::kernel()->getNbActivePrimitives();
+}
+
+int SolR_LoadFromFile(char *filename, double scale)
+{
+    solr::FileMarshaller fm;
+    fm.loadFromFile(*SingletonKernel::kernel(), filename ? filename : "", solr::make_vec4f(0.f, 0.f, 0.f),
+                    static_cast<float>(scale));
+    return (int)SingletonKernel::kernel()->getNbActivePrimitives();
 }
 
 int SolRx_PendingRotations()

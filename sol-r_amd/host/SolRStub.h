@@ -70,6 +70,12 @@ int SolR_SetMaterial(int index, double color_r, double color_g, double color_b, 
                      double innerIllumination, double illuminationDiffusion, double illuminationPropagation,
                      int fastTransparency);
 
+/* ---------- Scene files (SolRStub.h:145-146) ---------- */
+/* .irt scene dumps, host/FileMarshaller.h; both return the number of active (flattened) primitives,
+ * which is what the reference returns: 0 until the next SolR_CompactBoxes */
+int SolR_SaveToFile(char *filename);
+int SolR_LoadFromFile(char *filename, double scale);
+
 /* ---------- Boxes / lights (SolRStub.h:128-131) ---------- */
 int SolR_CompactBoxes(bool update);
 int SolR_GetLight(int index);

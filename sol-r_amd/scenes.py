@@ -164,3 +164,22 @@ def molecule(k, atoms=50000, width=1920, height=1080, iterations=3, seed=4321, *
     k.compact_boxes(True)
     k.set_camera((0.0, 0.0, -15000.0))
     return k
+
+
+def irt_model(k, path, width=1920, height=1080, iterations=3, scale=5000.0, floor=True, **scene_info):
+    """A scene around an .irt model file (reference: FileMarshaller::loadFromFile, the viewer's
+    "load scene"): material slots for the file's ids first - the loader overwrites them - then the
+    model scaled to `scale` units of height, a floor and the default light.  medias/irt/test.irt of the
+    reference is the sample of the format."""
+    k.initialize(width=width, height=height, nbRayIterations=iterations, graphicsLevel=glFull, **scene_info)
+    for _ in range(64):                      # the ids a file may carry; test.irt uses 0..15
+        k.add_material(0.5, 0.5, 0.5)
+    ground = k.add_material(0.55, 0.5, 0.45, reflection=0.2, specValue=0.5, specPower=100.0)
+    n = k.load_from_file(path, scale)
+    if floor:
+        k.add_primitive(ptXZPlane, (0.0, -0.5 * scale - 50.0, 0.0), size=(20000.0, 0.0, 20000.0), material=ground,
+                        movable=0)
+    add_light(k, position=(-6000.0, 9000.0, -9000.0))
+    k.compact_boxes(True)
+    k.set_camera((0.0, 0.3 * scale, -3.2 * scale), look_at=(0.0, 0.0, 0.0))
+    return k

@@ -1,0 +1,150 @@
+"""Scene files: the .irt container (reference: solr/io/FileMarshaller.cpp; sol-r_amd/host/FileMarshaller.*).
+
+Golden vector: the reference's own sample medias/irt/test.irt - in full where /root/reference exists
+(here), and as tests/golden/model_subset.irt (every 10th triangle, made by
+tests/golden/make_irt_fixture.py) everywhere.  The expectations below are derived from the file's bytes
+with numpy, independently of the loader."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import assert_parity, compare_frames, gpu_frame, oracle_frame  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SUBSET = os.path.join(HERE, "golden", "model_subset.irt")
+FULL = "/root/reference/medias/irt/test.irt"
+
+f4, i4 = np.float32, np.int32
+RECORD = np.dtype({"names": ["belongs", "movable", "p0", "p1", "p2", "n0", "n1", "n2", "size", "type", "materialId",
+                             "vt0", "vt1", "vt2"],
+                   "formats": ["u1", "u1"] + [(f4, 3)] * 7 + [i4, i4] + [(f4, 2)] * 3,
+                   "offsets": [0, 1, 4, 16, 28, 40, 52, 64, 76, 88, 92, 96, 104, 112], "itemsize": 160})
+
+
+def parse(path):
+    d = open(path, "rb").read()
+    version, = struct.unpack("<Q", d[:8])
+    n, = struct.unpack("<Q", d[120:128])
+    records = np.frombuffer(d, RECORD, count=n, offset=128)
+    at = 128 + 160 * n
+    nb_textures, = struct.unpack("<Q", d[at:at + 8])
+    assert nb_textures == 0
+    nb_materials, = struct.unpack("<Q", d[at + 8:at + 16])
+    at += 16
+    materials = {}
+    for _ in range(nb_materials):
+        mid, = struct.unpack("<Q", d[at:at + 8])
+        materials[mid] = d[at + 8:at + 8 + 176]
+        at += 184
+    assert at == len(d)
+    return version, records, materials
+
+
+def expected_geometry(records, scale):
+    """loadFromFile: setPrimitive(center + p), then every primitive times scale / height, all binary32"""
+    pts = np.stack([records["p0"], records["p1"], records["p2"]])
+    height = np.float32(abs(pts[..., 1].max() - pts[..., 1].min()))
+    ratio = np.float32(scale) / height
+    zero = np.float32(0.0)
+    return [((zero + records[f]) * ratio).astype(f4) for f in ("p0", "p1", "p2")], ratio
+
+
+def load(solr, path, engine="host-only", scale=5000.0, **kw):
+    k = solr.Kernel(engine=engine, deterministic_seed=1)
+    solr.scenes.irt_model(k, path, scale=scale, **kw)
+    return k
+
+
+FILES = [SUBSET] + ([FULL] if os.path.exists(FULL) else [])
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p) for p in FILES])
+def test_irt_loader_against_the_files_bytes(solr, path):
+    version, records, materials = parse(path)
+    assert version == 2 and (records["type"] == solr.ptTriangle).all()
+    k = load(solr, path, width=64, height=48)
+    flat = k.flat_scene()
+    prims = flat.primitives
+    model = prims[prims["index"] < len(records)]
+    assert len(model) == len(records) and len(prims) == len(records) + 2       # + floor + light
+    order = np.argsort(model["index"])
+    model = model[order]
+    (p0, p1, p2), ratio = expected_geometry(records, 5000.0)
+    for got, want in ((model["p0"], p0), (model["p1"], p1), (model["p2"], p2)):
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(model["materialId"], records["materialId"])
+    assert np.array_equal(model["vt0"], records["vt0"]) and np.array_equal(model["vt2"], records["vt2"])
+    # setPrimitiveNormals normalises what the file holds
+    n0 = records["n0"] / np.maximum(np.linalg.norm(records["n0"], axis=1, keepdims=True), 1e-30)
+    assert np.abs(model["n0"] - n0).max() < 1e-6
+    # materials: the file's ids overwritten with the file's bytes (no textures in this file: no id shift)
+    for mid, raw in materials.items():
+        assert flat.materials[mid].tobytes()[:168] == raw[:168], mid   # 8 bytes of padding follow
+    k.finalize()
+
+
+def test_irt_save_and_load_round_trip(solr, tmp_path):
+    _, records, materials = parse(SUBSET)
+    k = load(solr, SUBSET, width=64, height=48)
+    out = str(tmp_path / "saved.irt")
+    assert k.save_to_file(out) == len(records) + 2
+    version, saved, saved_materials = parse(out)
+    assert version == 2 and len(saved) == len(records)       # the floor and the light are not of the model
+    (p0, p1, p2), _ = expected_geometry(records, 5000.0)
+    assert np.array_equal(saved["p0"].view(np.uint32), p0.view(np.uint32))
+    assert np.array_equal(saved["p2"].view(np.uint32), p2.view(np.uint32))
+    assert (saved["belongs"] == 1).all() and (saved["movable"] == 0).all()
+    assert set(saved_materials) == set(int(m) for m in np.unique(records["materialId"]))
+    for mid, raw in saved_materials.items():
+        assert raw[:168] == materials[mid][:168]
+    first = k.flat_scene()
+    k.finalize()
+    # a second generation, loaded at the height the first one has: ratio exactly 1
+    height = float(np.float32(abs(max(saved["p0"][:, 1].max(), saved["p1"][:, 1].max(), saved["p2"][:, 1].max()) -
+                                  min(saved["p0"][:, 1].min(), saved["p1"][:, 1].min(), saved["p2"][:, 1].min()))))
+    k2 = load(solr, out, scale=height, width=64, height=48)
+    second = k2.flat_scene()
+    a = first.primitives[first.primitives["index"] < len(records)]
+    b = second.primitives[second.primitives["index"] < len(records)]
+    a, b = a[np.argsort(a["index"])], b[np.argsort(b["index"])]
+    for f in ("p0", "p1", "p2", "materialId", "vt0", "vt1", "vt2"):
+        assert np.array_equal(np.ascontiguousarray(a[f]).view(np.uint8), np.ascontiguousarray(b[f]).view(np.uint8)), f
+    for f in ("n0", "n1", "n2"):     # normalised once more on the way in: the last bit may move
+        assert np.abs(a[f] - b[f]).max() < 2e-7, f
+    k2.finalize()
+
+
+def test_irt_loader_refuses_other_versions_and_survives_truncation(solr, tmp_path):
+    d = bytearray(open(SUBSET, "rb").read())
+    other = str(tmp_path / "v1.irt")
+    open(other, "wb").write(struct.pack("<Q", 1) + bytes(d[8:]))     # the OpenCL engine's format
+    k = solr.Kernel(engine="host-only", deterministic_seed=1)
+    solr.scenes.cornell(k, width=32, height=32)
+    before = k.flat_scene().primitives
+    assert k.load_from_file(other, 1000.0) == len(before)
+    k.compact_boxes(True)
+    after = k.flat_scene().primitives
+    assert len(after) == len(before) and np.array_equal(after["p0"], before["p0"])          # untouched
+    cut = str(tmp_path / "cut.irt")
+    open(cut, "wb").write(bytes(d[:128 + 160 * 10 + 77]))
+    k.load_from_file(cut, 1000.0)
+    k.compact_boxes(True)
+    ids = np.unique(k.flat_scene().primitives["index"])
+    assert set(range(len(before) + 10)) <= set(ids.tolist()) and len(before) + 10 not in ids   # the ten whole records
+    k.finalize()
+
+
+@pytest.mark.gpu
+def test_irt_model_renders_like_the_oracle(solr, oracle):
+    k = load(solr, SUBSET, engine="hip", width=160, height=120, iterations=3)
+    pp, ids, rgb = gpu_frame(k)
+    opp, oids, orgb, _, status = oracle_frame(k, oracle)
+    assert status == 0
+    model_pixels = (ids[..., 0] >= 0) & (ids[..., 0] < 2096)
+    assert model_pixels.mean() > 0.05, "the model is not in view"
+    assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
+    k.finalize()
