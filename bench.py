@@ -40,10 +40,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iterations", type=int, default=3)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "height_field", "molecule", "irt_model"])
-    ap.add_argument("--scene-file", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden",
-                                                         "model_subset.irt"),
-                    help="--scene irt_model: the .irt file (reference: medias/irt/test.irt)")
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "height_field", "molecule", "irt_model", "obj_model"])
+    ap.add_argument("--scene-file", default="",
+                    help="--scene irt_model / obj_model: the file (default: the reference's samples under tests/golden)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--graphics-level", type=int, default=4, help="experiments only; the metric is quoted at 4 (glFull)")
     ap.add_argument("--tile-scheduling", type=int, default=1, help="0 raster order, 1 automatic (default), 2 cost order")
@@ -100,10 +99,12 @@ def main():
     k = solr.Kernel(engine="hip", device=local_rank)
     builder = getattr(solr.scenes, args.scene)
     kw = dict(width=W, height=H, iterations=args.iterations)
-    if args.scene not in ("cornell", "irt_model"):
+    if args.scene not in ("cornell", "irt_model", "obj_model"):
         kw.pop("iterations")
-    if args.scene == "irt_model":
-        builder(k, args.scene_file, **kw)
+    if args.scene in ("irt_model", "obj_model"):
+        default = "model_subset.irt" if args.scene == "irt_model" else "cornell.obj"
+        path = args.scene_file or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", default)
+        builder(k, path, **kw)
     else:
         builder(k, **kw)
     if args.graphics_level != 4:
@@ -253,7 +254,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if args.scene not in ("irt_model", "obj_model") else "the reference's sample scene file",
         "config": {"workload": "%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, row strips of %d" %
                    (args.scene, W, H, si.nbRayIterations, len(flat.boxes), len(flat.primitives), rows_per_rank),
                    "rays_per_frame": rays_total, "closest_hit_walks_rank0": int(counts[0]),

@@ -237,6 +237,7 @@ def _declare_host(L):
     L.SolRx_GetMovable.argtypes = [P(C.c_void_p), P(i)]
     L.SolR_LoadFromFile.argtypes = [C.c_char_p, d]
     L.SolR_SaveToFile.argtypes = [C.c_char_p]
+    L.SolR_LoadOBJModel.argtypes = [C.c_char_p, i, i, d, i, P(d)]
 
 
 def _np_from_ptr(ptr, count, dtype):
@@ -372,6 +373,14 @@ class Kernel:
         primitives, textures and materials; every primitive of the kernel is then rescaled so that the
         loaded model is `scale` high."""
         return self.L.SolR_LoadFromFile(os.fsencode(path), scale)
+
+    def load_obj_model(self, path, material_id=0, auto_scale=True, scale=5000.0, auto_center=True):
+        """Append a Wavefront OBJ model and its MTL materials (reference: OBJReader::loadModelFromFile via
+        SolR_LoadOBJModel).  Returns -(scaled height) / 2, the ground level the reference's scenes use."""
+        height = C.c_double()
+        self.L.SolR_LoadOBJModel(os.fsencode(path), material_id, 1 if auto_scale else 0, scale,
+                                 1 if auto_center else 0, C.byref(height))
+        return height.value
 
     def save_to_file(self, path):
         return self.L.SolR_SaveToFile(os.fsencode(path))

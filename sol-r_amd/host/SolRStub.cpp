@@ -12,6 +12,7 @@
 #include "../../include/solr_hip.h"
 #include "FileMarshaller.h"
 #include "GPUKernel.h"
+#include "OBJReader.h"
 
 using solr::SingletonKernel;
 
@@ -198,6 +199,20 @@ int SolR_RotatePrimitives(int, int, double rx, double ry, double rz, double ax, 
     SingletonKernel::kernel()->rotatePrimitives(rotationCenter, angles);
     SingletonKernel::kernel()->compactBoxes(false);
     return 0;
+}
+
+int SolR_LoadOBJModel(char *filename, int materialId, int autoScale, double scale, int autoCenter, double *height)
+{
+    solr::OBJReader reader;
+    const float s = static_cast<float>(scale);
+    solr::CPUBoundingBox aabb, inAABB;
+    const vec4f size = reader.loadModelFromFile(filename ? filename : "", *SingletonKernel::kernel(),
+                                                solr::make_vec4f(0.f, 0.f, 0.f), autoScale == 1,
+                                                solr::make_vec4f(s, s, s), true, materialId, false, autoCenter == 1, aabb,
+                                                false, inAABB);
+    if (height)
+        *height = -size.y / 2.f;
+    return (int)SingletonKernel::kernel()->getNbActivePrimitives();
 }
 
 int SolR_SaveToFile(char *filename)

@@ -73,6 +73,10 @@ int SolR_SetMaterial(int index, double color_r, double color_g, double color_b, 
 /* ---------- Scene files (SolRStub.h:145-146) ---------- */
 /* .irt scene dumps, host/FileMarshaller.h; both return the number of active (flattened) primitives,
  * which is what the reference returns: 0 until the next SolR_CompactBoxes */
+/* Wavefront OBJ + MTL, host/OBJReader.h (SolRStub.h:141-143; the reference passes `double &height`, the
+ * same ABI).  The model's materials take the ids materialId, materialId + 1, ... in the order of the MTL
+ * file; *height receives -(scaled model height) / 2. */
+int SolR_LoadOBJModel(char *filename, int materialId, int autoScale, double scale, int autoCenter, double *height);
 int SolR_SaveToFile(char *filename);
 int SolR_LoadFromFile(char *filename, double scale);
 

@@ -183,3 +183,17 @@ def irt_model(k, path, width=1920, height=1080, iterations=3, scale=5000.0, floo
     k.compact_boxes(True)
     k.set_camera((0.0, 0.3 * scale, -3.2 * scale), look_at=(0.0, 0.0, 0.0))
     return k
+
+
+def obj_model(k, path, width=1920, height=1080, iterations=3, scale=5000.0, **scene_info):
+    """A scene around a Wavefront OBJ model (reference: OBJReader::loadModelFromFile; the viewer's
+    Cornell-box scene loads medias/obj/cornell.obj this way): the model auto-scaled to `scale` and
+    centred, its MTL materials from id 0, one light inside."""
+    k.initialize(width=width, height=height, nbRayIterations=iterations, graphicsLevel=glFull, **scene_info)
+    for _ in range(64):                      # ids for the MTL file's materials, overwritten by the loader
+        k.add_material(0.5, 0.5, 0.5)
+    ground = k.load_obj_model(path, material_id=0, auto_scale=True, scale=scale, auto_center=True)
+    add_light(k, position=(0.0, 0.35 * scale, -0.1 * scale), radius=0.02 * scale)
+    k.compact_boxes(True)
+    k.set_camera((0.0, 0.0, -1.6 * scale), look_at=(0.0, 0.0, 0.0))
+    return ground

@@ -148,3 +148,120 @@ def test_irt_model_renders_like_the_oracle(solr, oracle):
     assert model_pixels.mean() > 0.05, "the model is not in view"
     assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
     k.finalize()
+
+
+# ---- Wavefront OBJ / MTL (reference: solr/io/OBJReader.cpp; sol-r_amd/host/OBJReader.*) --------------
+# Golden vector: the reference's medias/obj/cornell.obj + cornell.mtl (the model its Cornell-box scene
+# loads), kept as data under tests/golden/.  Expectations come from an independent reading of the file.
+OBJ = os.path.join(HERE, "golden", "cornell.obj")
+
+
+def parse_obj(path):
+    v, vt, vn, faces, material = [None], [None], [None], [], None
+    for line in open(path):
+        w = line.split()
+        if not w:
+            continue
+        if w[0] == "v":
+            v.append((f4(w[1]), f4(w[2]), -f4(w[3])))
+        elif w[0] == "vn":
+            vn.append((f4(w[1]), f4(w[2]), -f4(w[3])))
+        elif w[0] == "vt":
+            t = [f4(w[1]), f4(w[2])]
+            t = [f4(abs(c) - int(abs(c))) if c < 0 else c for c in t]
+            vt.append(tuple(t))
+        elif w[0] == "usemtl":
+            material = w[1]
+        elif w[0] == "f":
+            corners = [tuple(int(x) if x else 0 for x in (c.split("/") + ["", ""])[:3]) for c in w[1:]]
+            faces.append((corners[:3], material))
+            if len(corners) == 4:
+                faces.append(([corners[3], corners[2], corners[0]], material))
+    return v, vt, vn, faces
+
+
+def parse_mtl(path):
+    order, kd = [], {}
+    for line in open(path):
+        w = line.split()
+        if w and w[0] == "newmtl":
+            order.append(w[1])
+        if w and w[0] == "Kd":
+            kd[order[-1]] = tuple(f4(x) for x in w[1:4])
+    return order, kd
+
+
+def test_obj_reader_against_the_files_text(solr):
+    v, vt, vn, faces = parse_obj(OBJ)
+    order, kd = parse_mtl(OBJ[:-4] + ".mtl")
+    k = solr.Kernel(engine="host-only", deterministic_seed=1)
+    ground = solr.scenes.obj_model(k, OBJ, width=64, height=48, scale=5000.0)
+    flat = k.flat_scene()
+    prims = flat.primitives
+    model = prims[prims["index"] < len(faces)]
+    model = model[np.argsort(model["index"])]
+    assert len(model) == len(faces) == 38 and (model["type"] == solr.ptTriangle).all()
+
+    pts = np.array(v[1:], f4)
+    lo, hi = pts.min(0), pts.max(0)
+    os_ = max(hi[0] - lo[0], max(hi[1] - lo[1], hi[2] - lo[2]))
+    s = f4(5000.0) / f4(os_)
+    centre = ((lo + hi) / f4(2.0)).astype(f4)
+    assert abs(ground - float(-(s * (hi[1] - lo[1])) / f4(2.0))) < 1e-3
+
+    def place(p):                                       # position + scale * (-centre + p), binary32
+        return (f4(0.0) + s * (-centre + np.array(p, f4))).astype(f4)
+
+    ids = {name: n for n, name in enumerate(order)}     # material ids in MTL order from materialId = 0
+    for n, (corners, material) in enumerate(faces):
+        for field, (vi, ti, ni) in zip(("p0", "p1", "p2"), corners):
+            assert np.array_equal(model[field][n].view(np.uint32), place(v[vi]).view(np.uint32)), (n, field)
+        for field, (vi, ti, ni) in zip(("vt0", "vt1", "vt2"), corners):
+            assert tuple(model[field][n]) == tuple(vt[ti]), (n, field)
+        for field, (vi, ti, ni) in zip(("n0", "n1", "n2"), corners):
+            want = np.array(vn[ni], f4)
+            assert np.abs(model[field][n] - want / np.linalg.norm(want)).max() < 1e-6, (n, field)
+        assert model["materialId"][n] == ids[material]
+    for name, n in ids.items():
+        assert tuple(flat.materials["color"][n][:3]) == kd[name]
+        # Ks 0.33 0.33 0.33 -> specular value, 100 x power, coefficient (OBJReader.cpp:188-190)
+        assert np.allclose(flat.materials["specular"][n], (0.33, 33.0, 0.0, 0.33))
+    k.finalize()
+
+
+def test_obj_reader_quads_missing_indices_and_absent_files(solr, tmp_path):
+    path = str(tmp_path / "quad.obj")
+    open(path, "w").write("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt -1.25 0.5\nf 1/1 2 3 4\nf 1 2 9 5 6\n")
+    k = solr.Kernel(engine="host-only", deterministic_seed=1)
+    solr.scenes.cornell(k, width=32, height=32)
+    before = len(k.flat_scene().primitives)
+    k.load_obj_model(path, material_id=3, auto_scale=False, scale=10.0, auto_center=False)
+    k.load_obj_model(str(tmp_path / "absent.obj"), material_id=3)      # nothing is added, as in the reference
+    k.compact_boxes(True)
+    prims = k.flat_scene().primitives
+    new = prims[(prims["index"] >= before) & (prims["index"] < before + 3)]
+    new = new[np.argsort(new["index"])]
+    assert len(new) == 3 and before + 3 not in prims["index"]
+    # the quad: corners 0 1 2, then 3 2 0 (OBJReader.cpp:735-752); z is negated, scale 10, no centring
+    assert new["p0"][0].tolist() == [0.0, 0.0, 0.0] and new["p1"][0].tolist() == [10.0, 0.0, 0.0]
+    assert new["p2"][0].tolist() == [10.0, 10.0, 0.0]
+    assert new["p0"][1].tolist() == [0.0, 10.0, 0.0] and new["p1"][1].tolist() == [10.0, 10.0, 0.0]
+    assert new["p2"][1].tolist() == [0.0, 0.0, 0.0]
+    assert new["vt0"][0].tolist() == [0.25, 0.5]          # -1.25 -> the fraction of its magnitude
+    assert new["vt1"][0].tolist() == [0.0, 0.0]           # no texture coordinate given: number 0, zeros
+    # five corners: the first three only; vertex 9 does not exist and reads as the origin
+    assert new["p2"][2].tolist() == [0.0, 0.0, 0.0] and new["p1"][2].tolist() == [10.0, 0.0, 0.0]
+    assert (new["materialId"] == 3).all()
+    k.finalize()
+
+
+@pytest.mark.gpu
+def test_obj_model_renders_like_the_oracle(solr, oracle):
+    k = solr.Kernel(engine="hip", deterministic_seed=1)
+    solr.scenes.obj_model(k, OBJ, width=160, height=120, iterations=3)
+    pp, ids, rgb = gpu_frame(k)
+    opp, oids, orgb, _, status = oracle_frame(k, oracle)
+    assert status == 0
+    assert ((ids[..., 0] >= 0) & (ids[..., 0] < 38)).mean() > 0.5, "the model is not in view"
+    assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
+    k.finalize()
