@@ -238,6 +238,7 @@ def _declare_host(L):
     L.SolR_LoadFromFile.argtypes = [C.c_char_p, d]
     L.SolR_SaveToFile.argtypes = [C.c_char_p]
     L.SolR_LoadOBJModel.argtypes = [C.c_char_p, i, i, d, i, P(d)]
+    L.SolRx_LoadSWCMorphology.argtypes = [C.c_char_p] + [d] * 7 + [i]
 
 
 def _np_from_ptr(ptr, count, dtype):
@@ -381,6 +382,11 @@ class Kernel:
         self.L.SolR_LoadOBJModel(os.fsencode(path), material_id, 1 if auto_scale else 0, scale,
                                  1 if auto_center else 0, C.byref(height))
         return height.value
+
+    def load_swc_morphology(self, path, position=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0, 1.0), material_id=0):
+        """Append a neuron morphology (reference: SWCReader::loadMorphologyFromFile): spheres and
+        cylinders along the sample points.  Returns the number of samples read."""
+        return self.L.SolRx_LoadSWCMorphology(os.fsencode(path), *position, *scale, material_id)
 
     def save_to_file(self, path):
         return self.L.SolR_SaveToFile(os.fsencode(path))

@@ -13,6 +13,7 @@
 #include "FileMarshaller.h"
 #include "GPUKernel.h"
 #include "OBJReader.h"
+#include "SWCReader.h"
 
 using solr::SingletonKernel;
 
@@ -213,6 +214,16 @@ int SolR_LoadOBJModel(char *filename, int materialId, int autoScale, double scal
     if (height)
         *height = -size.y / 2.f;
     return (int)SingletonKernel::kernel()->getNbActivePrimitives();
+}
+
+int SolRx_LoadSWCMorphology(const char *filename, double px, double py, double pz, double sx, double sy, double sz,
+                            double sw, int materialId)
+{
+    solr::SWCReader reader;
+    reader.loadMorphologyFromFile(filename ? filename : "", *SingletonKernel::kernel(),
+                                  solr::make_vec4f((float)px, (float)py, (float)pz),
+                                  solr::make_vec4f((float)sx, (float)sy, (float)sz, (float)sw), materialId);
+    return (int)reader.getMorphologies().size();
 }
 
 int SolR_SaveToFile(char *filename)

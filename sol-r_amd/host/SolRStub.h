@@ -77,6 +77,11 @@ int SolR_SetMaterial(int index, double color_r, double color_g, double color_b, 
  * same ABI).  The model's materials take the ids materialId, materialId + 1, ... in the order of the MTL
  * file; *height receives -(scaled model height) / 2. */
 int SolR_LoadOBJModel(char *filename, int materialId, int autoScale, double scale, int autoCenter, double *height);
+/* SWC neuron morphology, host/SWCReader.h.  The reference has the reader (solr/io/SWCReader.cpp, used by
+ * its SwcScene) but no stub entry for it; this one passes loadMorphologyFromFile's arguments through and
+ * returns the number of samples read. */
+int SolRx_LoadSWCMorphology(const char *filename, double px, double py, double pz, double sx, double sy, double sz,
+                            double sw, int materialId);
 int SolR_SaveToFile(char *filename);
 int SolR_LoadFromFile(char *filename, double scale);
 

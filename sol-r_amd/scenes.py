@@ -197,3 +197,15 @@ def obj_model(k, path, width=1920, height=1080, iterations=3, scale=5000.0, **sc
     k.compact_boxes(True)
     k.set_camera((0.0, 0.0, -1.6 * scale), look_at=(0.0, 0.0, 0.0))
     return ground
+
+
+def swc_morphology(k, path, width=1920, height=1080, iterations=3, scale=40.0, **scene_info):
+    """A scene around an SWC neuron morphology (reference: SWCReader::loadMorphologyFromFile, its SwcScene):
+    spheres and cylinders along the sample points, one material, a light."""
+    k.initialize(width=width, height=height, nbRayIterations=iterations, graphicsLevel=glFull, **scene_info)
+    m = k.add_material(0.85, 0.75, 0.35, specValue=0.6, specPower=80.0)
+    n = k.load_swc_morphology(path, scale=(scale, scale, scale, scale), material_id=m)
+    add_light(k, position=(-6000.0, 9000.0, -12000.0))
+    k.compact_boxes(True)
+    k.set_camera((0.0, 2000.0, -16000.0), look_at=(0.0, 2000.0, 0.0))
+    return n

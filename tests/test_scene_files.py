@@ -265,3 +265,97 @@ def test_obj_model_renders_like_the_oracle(solr, oracle):
     assert ((ids[..., 0] >= 0) & (ids[..., 0] < 38)).mean() > 0.5, "the model is not in view"
     assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
     k.finalize()
+
+
+# ---- SWC neuron morphologies (reference: solr/io/SWCReader.cpp; sol-r_amd/host/SWCReader.*) -----------
+# Golden vector: the reference's medias/swc/02a_pyramidal2aFI.CNG.swc, kept as data (pyramidal.swc).
+SWC = os.path.join(HERE, "golden", "pyramidal.swc")
+
+
+def read_swc_like_the_reference(path):
+    """drop a line, take seven blank-separated words (across line ends), repeat while the stream is good"""
+    text = open(path, "rb").read().decode("latin-1")
+    pos, good, records = 0, True, []
+    while good:
+        nl = text.find("\n", pos)
+        if nl < 0:
+            good = False            # getline ran into the end
+            pos = len(text)
+        else:
+            pos = nl + 1
+        words = []
+        for _ in range(7):
+            while pos < len(text) and text[pos] in " \t\r\n\v\f":
+                pos += 1
+            if pos >= len(text):
+                good = False
+                words.append("")
+                continue
+            end = pos
+            while end < len(text) and text[end] not in " \t\r\n\v\f":
+                end += 1
+            words.append(text[pos:end])
+            pos = end
+        if words[0] != "#":
+            records.append(words)
+    return records
+
+
+def _atoi(s):
+    import re
+    m = re.match(r"\s*[+-]?\d+", s)
+    return int(m.group(0)) if m else 0
+
+
+def _atof(s):
+    import re
+    m = re.match(r"\s*[+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?)", s)
+    return float(m.group(0)) if m else 0.0
+
+
+def test_swc_reader_against_the_files_text(solr):
+    scale = 40.0
+    samples = {}
+    for w in read_swc_like_the_reference(SWC):
+        samples[_atoi(w[0])] = dict(x=f4(scale * _atof(w[2])), y=f4(scale * _atof(w[3])), z=f4(scale * _atof(w[4])),
+                                    r=f4(scale * _atof(w[5])), parent=_atoi(w[6]))
+    nb_samples = len(samples)
+    expected = []                                        # (type, p0, p1, size.x) in the order they are added
+    for sid in sorted(samples):
+        a = samples[sid]
+        if a["parent"] == -1:
+            expected.append((solr.ptSphere, (a["x"], a["y"], a["z"]), (0, 0, 0), f4(a["r"] * f4(1.5))))
+            continue
+        b = samples.setdefault(a["parent"], dict(x=f4(0), y=f4(0), z=f4(0), r=f4(0), parent=0))
+        if b["parent"] == -1:
+            continue
+        expected.append((solr.ptCylinder, (a["x"], a["y"], a["z"]), (b["x"], b["y"], b["z"]), a["r"]))
+        expected.append((solr.ptSphere, (b["x"], b["y"], b["z"]), (0, 0, 0), b["r"]))
+
+    k = solr.Kernel(engine="host-only", deterministic_seed=1)
+    n = solr.scenes.swc_morphology(k, SWC, width=64, height=48, scale=scale)
+    assert n == len(samples)         # the reader's map, parents that came into being included
+    assert nb_samples in (n, n - 1)
+    prims = k.flat_scene().primitives
+    model = prims[prims["index"] < len(expected)]
+    model = model[np.argsort(model["index"])]
+    assert len(model) == len(expected) > 3000
+    for got, (ptype, p0, p1, radius) in zip(model, expected):
+        assert got["type"] == ptype
+        assert tuple(got["p0"]) == tuple(f4(c) for c in p0)
+        if ptype == solr.ptCylinder:
+            assert tuple(got["p1"]) == tuple(f4(c) for c in p1)
+        assert got["size"][0] == radius
+    k.finalize()
+
+
+@pytest.mark.gpu
+def test_swc_morphology_renders_like_the_oracle(solr, oracle):
+    k = solr.Kernel(engine="hip", deterministic_seed=1)
+    solr.scenes.swc_morphology(k, SWC, width=160, height=120, iterations=2)
+    pp, ids, rgb = gpu_frame(k)
+    opp, oids, orgb, _, status = oracle_frame(k, oracle)
+    assert status == 0
+    assert (ids[..., 0] >= 0).mean() > 0.02, "the neuron is not in view"
+    assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
+    k.finalize()
