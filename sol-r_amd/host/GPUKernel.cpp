@@ -319,6 +319,7 @@ void GPUKernel::setPrimitiveNormals(unsigned int index, vec3f n0, vec3f n1, vec3
 unsigned int GPUKernel::getPrimitiveAt(int x, int y)
 {
     unsigned int returnValue = -1;
+    fetchPrimitiveIds();
     unsigned int index = y * m_sceneInfo.size.x + x;
     if (index < static_cast<unsigned int>(m_sceneInfo.size.x * m_sceneInfo.size.y) &&
         index < m_hPrimitivesXYIds.size())

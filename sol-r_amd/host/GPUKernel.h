@@ -331,7 +331,7 @@ public:
     const Material *hostMaterials() const { return m_hMaterials.data(); }
     const std::vector<RandomBuffer> &hostRandoms() const { return m_hRandoms; }
     const std::vector<BitmapBuffer> &hostTextureAtlas();
-    PrimitiveXYIdBuffer *hostPrimitiveIds() { return m_hPrimitivesXYIds.data(); }
+    PrimitiveXYIdBuffer *hostPrimitiveIds() { fetchPrimitiveIds(); return m_hPrimitivesXYIds.data(); }
     unsigned int treeDepth() const { return m_treeDepth; }
 
 protected:
@@ -356,6 +356,11 @@ protected:
     }
     /* counters and the frame protocol: reads that stay valid while rotations are pending */
     Frame &frameAsIs() { return m_frames[m_frame]; }
+    /* engine hook: the per-pixel primitive ids of the last frame are wanted on the host (getPrimitiveAt).
+     * The reference copies all of them back after every frame (CudaKernel.cpp:304-312 via d2h_bitmap) -
+     * 16 bytes per pixel, five times the image - although only picking ever looks at them; an engine may
+     * leave them on the device until then */
+    virtual void fetchPrimitiveIds() {}
     /* engine hook: apply the rotation to the resident scene; false = not done, nothing changed */
     virtual bool deviceRotatePrimitives(const vec3f &, const vec3f &, const vec3f &) { return false; }
     void rotatePrimitivesOnly(Frame &f, const vec3f &rotationCenter, const vec3f &cosA, const vec3f &sinA);

@@ -59,6 +59,7 @@ void HipKernel::initializeDevice()
 void HipKernel::releaseDevice()
 {
     syncHost(); /* rotations that only the device has seen would be lost with it */
+    fetchPrimitiveIds(); /* and so would the last frame's ids */
     if (m_deviceInitialized)
         finalize_scene(m_occupancyParameters);
     m_deviceInitialized = false;
@@ -67,6 +68,7 @@ void HipKernel::releaseDevice()
 void HipKernel::reshape()
 {
     GPUKernel::reshape();
+    m_idsOnDevice = false; /* the buffers are re-made for the new size */
     if (m_deviceInitialized)
         reshape_scene(m_occupancyParameters, m_sceneInfo);
 }
@@ -146,7 +148,18 @@ bool HipKernel::deviceRotatePrimitives(const vec3f &center, const vec3f &cosA, c
 
 void HipKernel::render_end()
 {
-    d2h_bitmap(m_occupancyParameters, m_sceneInfo, m_bitmap.data(), m_hPrimitivesXYIds.data());
+    /* the image now, the ids when somebody asks (fetchPrimitiveIds): they stay valid on the device until
+     * the next frame is rendered into the same buffers */
+    d2h_bitmap(m_occupancyParameters, m_sceneInfo, m_bitmap.data(), nullptr);
+    m_idsOnDevice = true;
+}
+
+void HipKernel::fetchPrimitiveIds()
+{
+    if (!m_idsOnDevice || !m_deviceInitialized)
+        return;
+    d2h_bitmap(m_occupancyParameters, m_sceneInfo, nullptr, m_hPrimitivesXYIds.data());
+    m_idsOnDevice = false;
 }
 
 void HostOnlyKernel::render_begin(const float timer)

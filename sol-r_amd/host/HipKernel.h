@@ -50,11 +50,13 @@ public:
 protected:
     /* rotatePrimitives on the resident scene, solr_hip_rotate_primitives (include/solr_hip.h) */
     bool deviceRotatePrimitives(const vec3f &center, const vec3f &cosA, const vec3f &sinA) override;
+    void fetchPrimitiveIds() override;
 
 private:
     vec4i m_blockSize;
     int m_sharedMemSize;
     bool m_deviceInitialized;
+    bool m_idsOnDevice = false;
 };
 
 /* Scene store without a device: everything up to compactBoxes works, any
