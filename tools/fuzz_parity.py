@@ -65,8 +65,26 @@ if __name__ == "__main__":
         opp, oids, orgb, counts, status = oracle_frame(k, loader)
         res = compare_frames(pp, ids, rgb, opp, oids, orgb)
         flat = k.flat_scene()
+        good = lambda r: r["ids_all_equal"] and r["max_ulp"] <= 1 and r["rgb_max_diff"] <= 1 and r["depth_max_ulp"] == 0
+        ok = good(res) and status == 0
+        if os.environ.get("FUZZ_ROTATE"):
+            # animated-scene route: rotations on the resident scene, then the frame against the oracle on the
+            # host store's replay of them
+            rng = S.LCG(seed * 7919 + 1)
+            for step in range(3):
+                k.rotate_primitives((rng.uniform(-800, 800), rng.uniform(-800, 800), rng.uniform(-800, 800)),
+                                    (rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5)))
+                if k.pending_rotations() != step + 1:
+                    print("seed %d: rotation %d took the host route" % (seed, step))
+                    ok = False
+                    break
+            pp, ids, rgb = gpu_frame(k)
+            opp, oids, orgb, counts, status = oracle_frame(k, loader)
+            r2 = compare_frames(pp, ids, rgb, opp, oids, orgb)
+            if not (good(r2) and status == 0):
+                ok = False
+                res = dict(r2, after="3 device rotations")
         k.finalize()
-        ok = res["ids_all_equal"] and res["max_ulp"] <= 1 and res["rgb_max_diff"] <= 1 and res["depth_max_ulp"] == 0 and status == 0
         if not ok:
             bad += 1
             print("seed %d: %d boxes %d prims: %s" % (seed, len(flat.boxes), len(flat.primitives), res))
