@@ -236,6 +236,10 @@ def _declare_host(L):
     L.SolRx_SetSceneInfoExtras.argtypes = [i, i]
     L.SolRx_GetMovable.argtypes = [P(C.c_void_p), P(i)]
     L.SolR_LoadFromFile.argtypes = [C.c_char_p, d]
+    L.SolR_GetMaterial.argtypes = [i] + [P(d)] * 6 + [P(i)] * 3 + [P(d)] * 2 + [P(i)] * 7 + [P(d)] * 6 + [P(i)]
+    L.SolR_GetTexture.argtypes = [i, C.c_void_p]
+    L.SolR_RotatePrimitive.argtypes = [i] + [d] * 6
+    L.SolR_RecompileKernels.argtypes = [C.c_char_p]
     L.SolR_SaveToFile.argtypes = [C.c_char_p]
     L.SolR_LoadOBJModel.argtypes = [C.c_char_p, i, i, d, i, P(d)]
     L.SolRx_LoadSWCMorphology.argtypes = [C.c_char_p] + [d] * 7 + [i]

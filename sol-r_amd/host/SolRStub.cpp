@@ -353,6 +353,66 @@ int SolR_GetNbTextures(int *nbTextures)
     return 0;
 }
 
+int SolR_GetMaterial(int index, double *color_r, double *color_g, double *color_b, double *noise, double *reflection,
+                     double *refraction, int *procedural, int *wireframe, int *wireframeDepth, double *transparency,
+                     double *opacity, int *diffuseTextureId, int *normalTextureId, int *bumpTextureId,
+                     int *specularTextureId, int *reflectionTextureId, int *transparencyTextureId,
+                     int *ambientOcclusionTextureId, double *specValue, double *specPower, double *specCoef,
+                     double *innerIllumination, double *illuminationDiffusion, double *illuminationPropagation,
+                     int *fastTransparency)
+{
+    /* where GPUKernel::setMaterial put each attribute (GPUKernel.cpp:1780-1909 of the reference) */
+    const Material *m = SingletonKernel::kernel()->getMaterial(index);
+    if (!m)
+        return -1;
+    auto d = [](double *out, float v) { if (out) *out = static_cast<double>(v); };
+    auto n = [](int *out, int v) { if (out) *out = v; };
+    d(color_r, m->color.x), d(color_g, m->color.y), d(color_b, m->color.z);
+    d(noise, m->innerIllumination.w);
+    d(reflection, m->reflection), d(refraction, m->refraction);
+    d(transparency, m->transparency), d(opacity, m->opacity);
+    n(fastTransparency, m->attributes.x == 1), n(procedural, m->attributes.y == 1);
+    n(wireframe, m->attributes.z == 1), n(wireframeDepth, m->attributes.w);
+    n(diffuseTextureId, m->textureIds.x), n(normalTextureId, m->textureIds.y);
+    n(bumpTextureId, m->textureIds.z), n(specularTextureId, m->textureIds.w);
+    n(reflectionTextureId, m->advancedTextureIds.x), n(transparencyTextureId, m->advancedTextureIds.y);
+    n(ambientOcclusionTextureId, m->advancedTextureIds.z);
+    d(specValue, m->specular.x), d(specPower, m->specular.y), d(specCoef, m->specular.w);
+    d(innerIllumination, m->innerIllumination.x), d(illuminationDiffusion, m->innerIllumination.y);
+    d(illuminationPropagation, m->innerIllumination.z);
+    return 0;
+}
+
+int SolR_GetTexture(int index, BitmapBuffer *image)
+{
+    if (index < 0 || index >= (int)SingletonKernel::kernel()->getNbActiveTextures() || !image)
+        return 1;
+    TextureInfo info;
+    memset(&info, 0, sizeof(info));
+    SingletonKernel::kernel()->getTexture(index, info);
+    if (info.buffer && info.size.z >= 3)
+    {
+        const int len = info.size.x * info.size.y * info.size.z;
+        for (int i = 0; i + 2 < len; i += info.size.z)
+        {
+            image[i] = info.buffer[i + 2];
+            image[i + 1] = info.buffer[i + 1];
+            image[i + 2] = info.buffer[i];
+        }
+    }
+    return 0;
+}
+
+int SolR_RotatePrimitive(int, double, double, double, double, double, double)
+{
+    return 0;
+}
+
+int SolR_RecompileKernels(char *)
+{
+    return 0;
+}
+
 /* ---------------------------------------------------------------- extensions */
 
 int SolRx_SelectEngine(const char *name)

@@ -70,6 +70,24 @@ int SolR_SetMaterial(int index, double color_r, double color_g, double color_b, 
                      double innerIllumination, double illuminationDiffusion, double illuminationPropagation,
                      int fastTransparency);
 
+/* ---------- Read-back of materials and textures (SolRStub.h:114-122,133) ---------- */
+/* the reference's `type &out` parameters are pointers here: the same ABI.  -1 (outputs untouched) for an
+ * index beyond the active materials */
+int SolR_GetMaterial(int index, double *color_r, double *color_g, double *color_b, double *noise, double *reflection,
+                     double *refraction, int *procedural, int *wireframe, int *wireframeDepth, double *transparency,
+                     double *opacity, int *diffuseTextureId, int *normalTextureId, int *bumpTextureId,
+                     int *specularTextureId, int *reflectionTextureId, int *transparencyTextureId,
+                     int *ambientOcclusionTextureId, double *specValue, double *specPower, double *specCoef,
+                     double *innerIllumination, double *illuminationDiffusion, double *illuminationPropagation,
+                     int *fastTransparency);
+/* the texture's pixels with the first and third channel swapped (SolRStub.cpp:351-373); 0 = done, 1 = no
+ * such texture */
+int SolR_GetTexture(int index, BitmapBuffer *image);
+/* accepted for compatibility: the reference's SolR_RotatePrimitive is an empty TODO (SolRStub.cpp:232-240),
+ * and there is nothing to recompile at run time - the kernels are built ahead of time for gfx950 */
+int SolR_RotatePrimitive(int index, double rx, double ry, double rz, double ax, double ay, double az);
+int SolR_RecompileKernels(char *filename);
+
 /* ---------- Scene files (SolRStub.h:145-146) ---------- */
 /* .irt scene dumps, host/FileMarshaller.h; both return the number of active (flattened) primitives,
  * which is what the reference returns: 0 until the next SolR_CompactBoxes */

@@ -87,6 +87,18 @@ def test_material_record(solr, kernel):
     assert tuple(m["attributes"]) == (1, 1, 2, 3)                      # wireframe with width != 0 -> 2
     assert tuple(m["textureIds"]) == (-1, -1, -1, -1)
     assert tuple(m["textureMapping"]) == (40000, 40000, -1, 3)         # "computed texture" defaults (:1893-1896)
+    # and back out through SolR_GetMaterial (SolRStub.cpp:427-476)
+    import ctypes as C
+    d = [C.c_double() for _ in range(14)]
+    n = [C.c_int() for _ in range(11)]
+    r = C.byref
+    status = k.L.SolR_GetMaterial(idx, r(d[0]), r(d[1]), r(d[2]), r(d[3]), r(d[4]), r(d[5]), r(n[0]), r(n[1]), r(n[2]),
+                                  r(d[6]), r(d[7]), r(n[3]), r(n[4]), r(n[5]), r(n[6]), r(n[7]), r(n[8]), r(n[9]),
+                                  r(d[8]), r(d[9]), r(d[10]), r(d[11]), r(d[12]), r(d[13]), r(n[10]))
+    assert status == 0
+    assert np.allclose([x.value for x in d], (0.1, 0.2, 0.3, 0.4, 0.5, 1.33, 0.6, 0.7, 0.8, 90.0, 0.25, 1.5, 11.0, 12.0))
+    assert [x.value for x in n] == [1, 0, 3, -1, -1, -1, -1, -1, -1, -1, 1]   # wireframe reads 0: the stored code is 2
+    assert k.L.SolR_GetMaterial(5000, *([None] * 25)) == -1
 
 
 def test_lights_box_comes_first_and_spans_the_view_distance(solr, kernel):
@@ -231,6 +243,11 @@ def test_textures_are_packed_into_one_atlas(solr, kernel):
     assert bytes(flat.textures[:24]) == t0.tobytes() and bytes(flat.textures[24:36]) == t1.tobytes()
     mat = flat.materials[m]                                            # GPUKernel.cpp:1865-1889 / 2280-2300
     assert tuple(mat["textureMapping"]) == (2, 2, -1, 3) and int(mat["textureOffset"][0]) == 24
+    # SolR_GetTexture hands the pixels back with the first and third channel swapped (SolRStub.cpp:351-373)
+    back = np.zeros_like(t1)
+    assert k.L.SolR_GetTexture(1, back.ctypes.data) == 0 and np.array_equal(back, t1[..., ::-1])
+    assert k.L.SolR_GetTexture(7, back.ctypes.data) == 1
+    assert k.L.SolR_RotatePrimitive(0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0) == 0 and k.L.SolR_RecompileKernels(None) == 0
 
 
 def _flat_digest(flat):
