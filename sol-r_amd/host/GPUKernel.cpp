@@ -749,6 +749,64 @@ void GPUKernel::streamDataToGPU()
                   << "!=" << f.primitives.size() << std::endl;
 }
 
+/* reference: GPUKernel.cpp:2764-2775 */
+void GPUKernel::nextFrame()
+{
+    syncHost();
+    ++m_frame;
+    if (m_frame >= m_nbFrames)
+        m_frame = m_nbFrames ? m_nbFrames - 1 : 0;
+}
+
+void GPUKernel::previousFrame()
+{
+    syncHost();
+    if (m_frame > 0)
+        --m_frame;
+}
+
+/* reference: GPUKernel.cpp:1686-1690 */
+void GPUKernel::getPrimitiveOtherCenter(unsigned int index, vec3f &center)
+{
+    if (CPUPrimitive *p = getPrimitive(index))
+        center = p->p1;
+}
+
+/* reference: GPUKernel.cpp:1513-1572: the frames between the first and the last key frame are rebuilt as
+ * blends of the two, primitive by primitive in id order, with weight frame / nbFrames; each gets its own
+ * box tree */
+void GPUKernel::morphPrimitives()
+{
+    if (m_nbFrames < 3)
+        return;
+    syncHost();
+    const float nbFrames = static_cast<float>(m_nbFrames);
+    for (unsigned int frame = 1; frame < m_nbFrames - 1; ++frame)
+    {
+        setFrame((int)frame);
+        resetFrame();
+        PrimitiveContainer &first = m_frames[0].primitives;
+        PrimitiveContainer &last = m_frames[m_nbFrames - 1].primitives;
+        const float r = static_cast<float>(m_frame) / nbFrames;
+        auto mix = [r](const vec3f &a, const vec3f &b) {
+            return make_vec3f(a.x + r * (b.x - a.x), a.y + r * (b.y - a.y), a.z + r * (b.z - a.z));
+        };
+        PrimitiveContainer::iterator it2 = last.begin();
+        for (PrimitiveContainer::iterator it1 = first.begin(); it1 != first.end() && it2 != last.end(); ++it1, ++it2)
+        {
+            const CPUPrimitive a = it1->second, b = it2->second; /* copies: adding below may move the store */
+            const vec3f p0 = mix(a.p0, b.p0), p1 = mix(a.p1, b.p1), p2 = mix(a.p2, b.p2);
+            const vec3f size = mix(a.size, b.size);
+            const int i = addPrimitive(PrimitiveType(a.type));
+            setPrimitive(i, p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, size.x, size.y, size.z, a.materialId);
+            setPrimitiveNormals(i, mix(a.n0, b.n0), mix(a.n1, b.n1), mix(a.n2, b.n2));
+            setPrimitiveTextureCoordinates(i, a.vt0, a.vt1, a.vt2);
+            setPrimitiveIsMovable(i, a.movable);
+        }
+        compactBoxes(true);
+    }
+}
+
 /* reference: GPUKernel.cpp:1283-1305 */
 void GPUKernel::resetFrame()
 {
@@ -1032,6 +1090,25 @@ Material *GPUKernel::getMaterial(const int index)
     if (index >= 0 && index <= m_nbActiveMaterials && index < (int)m_hMaterials.size())
         return &m_hMaterials[index];
     return nullptr;
+}
+
+/* reference: GPUKernel.cpp:1932-1953: the current material becomes a plain textured one */
+void GPUKernel::setMaterialTextureId(unsigned int textureId)
+{
+    if (m_currentMaterial < 0 || (size_t)m_currentMaterial >= m_hMaterials.size() || textureId >= NB_MAX_TEXTURES)
+        return;
+    Material &m = m_hMaterials[m_currentMaterial];
+    if ((int)textureId != m.textureIds.x)
+    {
+        m.reflection = 0.3f;
+        m.refraction = 0.f;
+        m.transparency = 0.f;
+        m.opacity = 0.f;
+        m.textureMapping = make_vec4i(m_hTextures[textureId].size.x, m_hTextures[textureId].size.y, TEXTURE_NONE,
+                                      m_hTextures[textureId].size.z);
+        m.textureIds = make_vec4i((int)textureId, TEXTURE_NONE, TEXTURE_NONE, TEXTURE_NONE);
+        m_materialsTransfered = false;
+    }
 }
 
 /* reference: GPUKernel.cpp:2017-2033 */

@@ -296,6 +296,16 @@ public:
     }
     int getNbFrames() { return m_nbFrames; }
     int getFrame() { return m_frame; }
+    /* key-frame animation (GPUKernel.h:275-298 of the reference) */
+    void nextFrame();
+    void previousFrame();
+    void morphPrimitives();
+    void resetAddingIndex() { m_addingIndex = 0; }
+    void doneWithAdding(const bool &done) { m_doneWithAdding = done; }
+    void getPrimitiveOtherCenter(unsigned int index, vec3f &center);
+    int getCurrentMaterial() { return m_currentMaterial; }
+    void setCurrentMaterial(const int currentMaterial) { m_currentMaterial = currentMaterial; }
+    void setMaterialTextureId(unsigned int textureId);
 
     /* ---------- Box tree (GPUKernel.h:304-309) ---------- */
     int compactBoxes(bool reconstructBoxes);
@@ -401,6 +411,7 @@ protected:
     int m_lightInformationSize;
     size_t m_maxPrimitivesPerBox;
     bool m_doneWithAdding;
+    int m_currentMaterial = 0;
     int m_addingIndex;
 
     vec3f m_viewPos;

@@ -241,6 +241,24 @@ int SolR_LoadFromFile(char *filename, double scale)
     return (int)SingletonKernel::kernel()->getNbActivePrimitives();
 }
 
+int SolRx_SetNbFrames(int nbFrames)
+{
+    SingletonKernel::kernel()->setNbFrames(nbFrames);
+    return 0;
+}
+
+int SolRx_SetFrame(int frame)
+{
+    SingletonKernel::kernel()->setFrame(frame);
+    return SingletonKernel::kernel()->getFrame();
+}
+
+int SolRx_MorphPrimitives()
+{
+    SingletonKernel::kernel()->morphPrimitives();
+    return SingletonKernel::kernel()->getFrame();
+}
+
 int SolRx_PendingRotations()
 {
     return (int)SingletonKernel::kernel()->nbPendingRotations();

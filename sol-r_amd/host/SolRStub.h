@@ -136,6 +136,10 @@ int SolRx_GetSceneInfo(SceneInfo *sceneInfo, PostProcessingInfo *postProcessingI
                        float angles[4]);
 int SolRx_GetTreeDepth();
 /* rotations applied on the device that the host scene store has not replayed yet; SolRx_SyncHost replays them */
+/* key frames (GPUKernel::setNbFrames / setFrame / morphPrimitives; the reference's scenes call them directly) */
+int SolRx_SetNbFrames(int nbFrames);
+int SolRx_SetFrame(int frame);
+int SolRx_MorphPrimitives();
 int SolRx_PendingRotations();
 int SolRx_SyncHost();
 int SolRx_GetMovable(const unsigned char **flags, int *nbPrimitives);

@@ -250,6 +250,32 @@ def test_textures_are_packed_into_one_atlas(solr, kernel):
     assert k.L.SolR_RotatePrimitive(0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0) == 0 and k.L.SolR_RecompileKernels(None) == 0
 
 
+def test_key_frames_are_blended_primitive_by_primitive(solr, kernel):
+    # GPUKernel::morphPrimitives (reference GPUKernel.cpp:1513-1572): frames 1 .. n-2 = first + frame / n * (last - first)
+    k = kernel
+    light = k.add_material(innerIllumination=1.0)
+    m = k.add_material(0.5, 0.5, 0.5)
+    k.L.SolRx_SetNbFrames(4)
+    for frame, x in ((0, 0.0), (3, 400.0)):
+        k.L.SolRx_SetFrame(frame)
+        for i in range(40):
+            k.add_primitive(solr.ptSphere, (x + 100.0 * i, 10.0 * i, 0.0), size=(20.0 + frame, 0, 0), material=m)
+        k.add_primitive(solr.ptSphere, (0.0, 5000.0, 0.0), size=(10.0, 0, 0), material=light, movable=0)
+        k.compact_boxes(True)
+    k.L.SolRx_MorphPrimitives()
+    for frame in (1, 2):
+        k.L.SolRx_SetFrame(frame)
+        k.compact_boxes(False)              # the flattened arrays are shared: stream this frame's
+        prims = k.flat_scene().primitives
+        spheres = prims[prims["index"] < 40]
+        spheres = spheres[np.argsort(spheres["index"])]
+        r = np.float32(frame) / np.float32(4)
+        want_x = (np.float32(100.0) * np.arange(40, dtype=np.float32)) + r * np.float32(400.0)
+        assert np.allclose(spheres["p0"][:, 0], want_x, rtol=0, atol=1e-3)
+        assert np.allclose(spheres["size"][:, 0], 20.0 + r * 3.0)
+    k.L.SolRx_SetFrame(0)
+
+
 def _flat_digest(flat):
     import hashlib
     h = hashlib.sha256()
