@@ -88,4 +88,5 @@ if __name__ == "__main__":
         if not ok:
             bad += 1
             print("seed %d: %d boxes %d prims: %s" % (seed, len(flat.boxes), len(flat.primitives), res))
-    print("fuzz: %d scenes, %d outside the bar" % (count, bad))
+    print("fuzz: %d scenes, %d outside the bar%s" % (count, bad, "" if not os.environ.get("SOLR_ORACLE_CORRECTLY_ROUNDED_POW")
+                                                       else " (oracle with the correctly rounded specular power)"))
