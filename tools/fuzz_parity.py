@@ -84,6 +84,31 @@ if __name__ == "__main__":
             if not (good(r2) and status == 0):
                 ok = False
                 res = dict(r2, after="3 device rotations")
+        if os.environ.get("FUZZ_MODES") and ok:
+            # another camera, a post-processing effect, and a few refinement / accumulation passes, the oracle
+            # being handed its own previous frame
+            rng = S.LCG(seed * 104729 + 3)
+            camera = [solr.ctPerspective, solr.ctOrthographic, solr.ctVR, solr.ctAntialiazed, solr.ctAnaglyph,
+                      solr.ctPanoramic][rng.next() % 6]
+            effect = [solr.ppe_none, solr.ppe_depthOfField, solr.ppe_ambientOcclusion, solr.ppe_radiosity,
+                      solr.ppe_filter, solr.ppe_cartoon][rng.next() % 6]
+            k.set_post_processing(type=effect, param1=rng.uniform(1000.0, 9000.0), param2=rng.uniform(0.001, 20.0),
+                                  param3=1 + rng.next() % 8)
+            k.set_scene_info(cameraType=camera, eyeSeparation=300.0,
+                             advancedIllumination=[solr.aiNone, solr.aiBasic, solr.aiFull][rng.next() % 3])
+            opp = oids = None
+            passes = [0, 1, 2, 10, 11, 12, 13]
+            for it in passes:
+                k.set_scene_info(pathTracingIteration=it, maxPathTracingIterations=max(passes) + 1)
+                pp, ids, rgb = gpu_frame(k)
+                opp, oids, orgb, counts, status = oracle_frame(k, loader, pp=opp, ids=oids)
+                r3 = compare_frames(pp, ids, rgb, opp, oids, orgb)
+                # the running sums add one rounding per accumulated sample
+                if not (r3["ids_all_equal"] and r3["max_ulp"] <= 2 + (it > 10) * (it - 10) and r3["rgb_max_diff"] <= 1
+                        and status == 0):
+                    ok = False
+                    res = dict(r3, after="camera %d, effect %d, pass %d" % (camera, effect, it))
+                    break
         k.finalize()
         if not ok:
             bad += 1
