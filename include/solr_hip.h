@@ -197,7 +197,8 @@ int solr_hip_get_variant(void);
  *                               (cosf / sinf), sceneInfo.viewDistance (the seed of the outer boxes).
  *                               Returns 1 when the resident scene now holds, bit for bit, what the host
  *                               rotation + a fresh h2d_scene would have produced for the reference's node
- *                               list and primitives (the engine's own walk-order list is refitted from it),
+ *                               list and primitives (the engine's own walk-order list is refitted the same way;
+ *                               the reference's list itself only when a frame or a read-back needs it),
  *                               0 when it cannot serve the request (no flags, a tree the engine did not
  *                               validate as nested, viewDistance > 1e6): nothing changed, take the host
  *                               route;

@@ -793,7 +793,8 @@ __global__ __launch_bounds__(256) void k_rotatePrimitives(float4 *__restrict__ a
 
 /* One node per thread, the nodes of one height of the tree per launch (children first).  A node with
  * primitives is a level-0 box: updateBoundingBox; one without is the union of its children:
- * updateOutterBoundingBox, seeded like it (+-viewDistance; +-infinity for our own grouping nodes). */
+ * updateOutterBoundingBox, seeded like it (+-viewDistance; +-infinity for our own grouping nodes, which
+ * the list marks with the sign bit). */
 __global__ __launch_bounds__(256) void k_refitNodes(float4 *__restrict__ arena, unsigned offNodes, unsigned offStart,
                                                     unsigned offPrims, const int *__restrict__ list, int count,
                                                     float seed)
@@ -801,7 +802,10 @@ __global__ __launch_bounds__(256) void k_refitNodes(float4 *__restrict__ arena, 
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count)
         return;
-    const int node = list[t];
+    const int entry = list[t];
+    const int node = entry & 0x7fffffff;
+    if (entry < 0)
+        seed = INFINITY; /* one of our own grouping nodes: the plain union */
     float4 *rows = arena + offNodes;
     const float4 row1 = rows[2 * node + 1];
     const int nb = __float_as_int(row1.z);
@@ -880,20 +884,6 @@ __global__ __launch_bounds__(256) void k_refitNodes(float4 *__restrict__ arena, 
     rows[2 * node + 1] = make_float4(hx, hy, row1.z, row1.w);
 }
 
-/* walk-order nodes that are copies of nodes of the reference's tree take their refitted bounds */
-__global__ __launch_bounds__(256) void k_copyBounds(float4 *__restrict__ arena, unsigned offFrom, unsigned offTo,
-                                                    const int2 *__restrict__ pairs, int count)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count)
-        return;
-    const int2 p = pairs[t]; /* x: node of the walk-order list, y: the node it was copied from */
-    const float4 a = arena[offFrom + 2 * p.y], b = arena[offFrom + 2 * p.y + 1];
-    const float4 old = arena[offTo + 2 * p.x + 1];
-    arena[offTo + 2 * p.x] = a;
-    arena[offTo + 2 * p.x + 1] = make_float4(b.x, b.y, old.z, old.w);
-}
-
 struct DeviceBuffer
 {
     void *ptr = nullptr;
@@ -967,9 +957,10 @@ struct Engine
     DeviceBuffer movable, refitPlan;
     int nbMovable = -1;                 /* flags uploaded for that many primitives, -1: none */
     std::vector<int> refitLevels;       /* exact list: [offset, count] per height, offsets into refitPlan (ints) */
-    std::vector<int> refitGroupLevels;  /* grouping nodes of the walk-order list, same form */
-    int refitCopyOffset = 0, refitCopyCount = 0;
+    std::vector<int> refitWalkLevels;   /* walk-order list, same form */
     bool refitReady = false;
+    bool exactStale = false;            /* the exact list has not been refitted since the last rotation */
+    float exactStaleViewDistance = 0.f;
     bool deviceAhead = false;           /* the arena has moved on from the host images */
     int nbDeviceRotations = 0;
 
@@ -1190,16 +1181,19 @@ int materialTag(const Material &m)
     return tag;
 }
 
-/* What solr_hip_rotate_primitives refits and in which order: the nodes of the reference's list by
- * height (children before parents; node 0, the light cell, keeps its +-viewDistance, GPUKernel.cpp:1189),
- * then the walk-order list: copies take the bounds of the node they came from, grouping nodes the union
- * of their children. */
+/* What solr_hip_rotate_primitives refits and in which order: the nodes of a list by height, children
+ * before parents.  A frame walks the walk-order list, so that is the one refitted with every rotation; the
+ * reference's own list (box-debug view, census, variant 3, read-back) follows when somebody needs it
+ * (refreshExactList) - node bounds are a function of the primitives alone, so late is as good as at once.
+ * Both give a node of the reference's tree the same bounds: min / max over the level-0 boxes below it,
+ * clamped once or several times by the same +-viewDistance seed, first occurrence winning a tie in either
+ * nesting.  Node 0, the light cell, keeps its +-viewDistance (GPUKernel.cpp:1189). */
 static void buildRefitPlan(const std::vector<float4> &exact, const std::vector<float4> &walk, const std::vector<int> &origin)
 {
     g.refitReady = false;
+    g.exactStale = false;
     g.refitLevels.clear();
-    g.refitGroupLevels.clear();
-    g.refitCopyOffset = g.refitCopyCount = 0;
+    g.refitWalkLevels.clear();
     if (!g.nested)
         return;
     auto heights = [](const std::vector<float4> &rows, std::vector<int> &height) {
@@ -1225,39 +1219,56 @@ static void buildRefitPlan(const std::vector<float4> &exact, const std::vector<f
         return n ? top + 1 : 0;
     };
     std::vector<int> plan;
-    auto byHeight = [&](const std::vector<int> &height, int nbHeights, std::vector<int> &levels, auto wanted) {
-        for (int h = 0; h < nbHeights; ++h)
+    auto byHeight = [&](const std::vector<int> &height, int nbHeights, std::vector<int> &levels, auto entry) {
+        std::vector<std::vector<int>> bucket((size_t)nbHeights);
+        for (int i = 0; i < (int)height.size(); ++i)
         {
-            const int offset = (int)plan.size();
-            for (int i = 0; i < (int)height.size(); ++i)
-                if (height[i] == h && wanted(i))
-                    plan.push_back(i);
-            if ((int)plan.size() > offset)
-            {
-                levels.push_back(offset);
-                levels.push_back((int)plan.size() - offset);
-            }
+            const long e = entry(i);
+            if (e != -1)
+                bucket[(size_t)height[i]].push_back((int)e);
         }
+        for (const std::vector<int> &b : bucket)
+            if (!b.empty())
+            {
+                levels.push_back((int)plan.size());
+                levels.push_back((int)b.size());
+                plan.insert(plan.end(), b.begin(), b.end());
+            }
     };
     std::vector<int> height;
     int nbHeights = heights(exact, height);
-    byHeight(height, nbHeights, g.refitLevels, [](int i) { return i != 0; });
-    if (plan.size() & 1)
-        plan.push_back(0); /* the pairs below start on 8 bytes */
-    g.refitCopyOffset = (int)plan.size();
-    for (int j = 0; j < (int)origin.size(); ++j)
-        if (origin[j] > 0)
-        {
-            plan.push_back(j);
-            plan.push_back(origin[j]);
-            ++g.refitCopyCount;
-        }
+    byHeight(height, nbHeights, g.refitLevels, [](int i) { return i != 0 ? (long)i : -1L; });
     nbHeights = heights(walk, height);
-    byHeight(height, nbHeights, g.refitGroupLevels, [&](int j) { return origin[j] < 0; });
+    byHeight(height, nbHeights, g.refitWalkLevels, [&](int j) {
+        if (origin[j] == 0)
+            return -1L;                                   /* the light cell */
+        return origin[j] < 0 ? (long)(j | (int)0x80000000) : (long)j; /* sign bit: a grouping node */
+    });
     if (plan.empty())
         plan.push_back(0);
     upload(g.refitPlan, plan);
     g.refitReady = ok();
+}
+
+static void refitList(const std::vector<int> &levels, unsigned offNodes, unsigned offStart, float viewDistance)
+{
+    float4 *arena = (float4 *)g.geometry.ptr;
+    const int *plan = (const int *)g.refitPlan.ptr;
+    for (size_t l = 0; l + 1 < levels.size(); l += 2)
+        hipLaunchKernelGGL(k_refitNodes, dim3((unsigned)((levels[l + 1] + 255) / 256)), dim3(256), 0, g.stream, arena,
+                           offNodes, offStart, g.offPrims, plan + levels[l], levels[l + 1], viewDistance);
+}
+
+/* the reference's node list is wanted: refit it from the primitives as they are now */
+static void refreshExactList()
+{
+    if (!g.exactStale || !g.geometry.ptr)
+        return;
+    quiesce();
+    refitList(g.refitLevels, g.offBoxes, g.offBoxStart, g.exactStaleViewDistance);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(g.stream));
+    g.exactStale = false;
 }
 
 /* the arena moved on (device-side rotations): bring the host images up to date before anything reads them */
@@ -1265,6 +1276,7 @@ static void pullGeometry()
 {
     if (!g.deviceAhead || !g.geometry.ptr)
         return;
+    refreshExactList();
     quiesce();
     auto get = [&](unsigned at, void *dst, size_t bytes) {
         if (bytes)
@@ -1421,6 +1433,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                       sceneInfo.cameraType == ctAnaglyph || sceneInfo.cameraType == ctPanoramic;
     const bool exactNodes = counting || sceneInfo.renderBoxes != 0 || objects.x != g.nbBoxes || g.variant == 3;
     flushGeometry();
+    if (exactNodes)
+        refreshExactList();
     if (!ok())
         return;
     SceneArgs S = makeScene(exactNodes);
@@ -1865,6 +1879,7 @@ void finalize_scene(vec2i)
     g.ownStream = false;
     g.initialized = false;
     g.refitReady = false;
+    g.exactStale = false;
     g.deviceAhead = false;
     g.nbMovable = -1;
     g.nbDeviceRotations = 0;
@@ -2283,21 +2298,11 @@ int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], 
     R.cx = center[0], R.cy = center[1], R.cz = center[2];
     R.cosx = cosAngles[0], R.cosy = cosAngles[1], R.cosz = cosAngles[2];
     R.sinx = sinAngles[0], R.siny = sinAngles[1], R.sinz = sinAngles[2];
-    float4 *arena = (float4 *)g.geometry.ptr;
-    const int *plan = (const int *)g.refitPlan.ptr;
-    auto blocks = [](int n) { return dim3((unsigned)((n + 255) / 256)); };
-    hipLaunchKernelGGL(k_rotatePrimitives, blocks(g.nbPrimitives), dim3(256), 0, g.stream, arena, g.offPrims,
-                       g.nbPrimitives, (const unsigned char *)g.movable.ptr, R);
-    for (size_t l = 0; l + 1 < g.refitLevels.size(); l += 2)
-        hipLaunchKernelGGL(k_refitNodes, blocks(g.refitLevels[l + 1]), dim3(256), 0, g.stream, arena, g.offBoxes,
-                           g.offBoxStart, g.offPrims, plan + g.refitLevels[l], g.refitLevels[l + 1], viewDistance);
-    if (g.refitCopyCount)
-        hipLaunchKernelGGL(k_copyBounds, blocks(g.refitCopyCount), dim3(256), 0, g.stream, arena, g.offBoxes,
-                           g.offBoxesCompact, (const int2 *)(plan + g.refitCopyOffset), g.refitCopyCount);
-    for (size_t l = 0; l + 1 < g.refitGroupLevels.size(); l += 2)
-        hipLaunchKernelGGL(k_refitNodes, blocks(g.refitGroupLevels[l + 1]), dim3(256), 0, g.stream, arena,
-                           g.offBoxesCompact, g.offBoxStartCompact, g.offPrims, plan + g.refitGroupLevels[l],
-                           g.refitGroupLevels[l + 1], INFINITY);
+    hipLaunchKernelGGL(k_rotatePrimitives, dim3((unsigned)((g.nbPrimitives + 255) / 256)), dim3(256), 0, g.stream,
+                       (float4 *)g.geometry.ptr, g.offPrims, g.nbPrimitives, (const unsigned char *)g.movable.ptr, R);
+    refitList(g.refitWalkLevels, g.offBoxesCompact, g.offBoxStartCompact, viewDistance);
+    g.exactStale = true;
+    g.exactStaleViewDistance = viewDistance;
     HIPCHECK(hipGetLastError());
     /* the other flights' streams start their next frame only after this */
     HIPCHECK(hipStreamSynchronize(g.stream));
@@ -2321,6 +2326,8 @@ int solr_hip_read_nodes(int exact, float *rows, int capacityRows)
     if (!ready("solr_hip_read_nodes") || !g.geometry.ptr)
         return -1;
     flushGeometry();
+    if (exact)
+        refreshExactList();
     quiesce();
     const int n = 2 * (exact ? g.nbBoxes : g.nbBoxesCompact);
     if (!rows)

@@ -65,8 +65,18 @@ def _primitive_geometry(rows):
     return rows[:, [0, 2, 3, 4, 5, 6], :3]
 
 
+@pytest.mark.parametrize("grouping", [True, False], ids=["grouped", "ungrouped"])
 @pytest.mark.parametrize("spec", SCENES, ids=[s[0] for s in SCENES])
-def test_device_rotation_equals_host_rotation(solr, oracle, spec):
+def test_device_rotation_equals_host_rotation(solr, oracle, spec, grouping):
+    hip = solr.hip_lib()
+    hip.solr_hip_set_variant(0 if grouping else 5)      # 5: no grouping nodes, from the next upload on
+    try:
+        _device_rotation_equals_host_rotation(solr, oracle, spec, grouping)
+    finally:
+        hip.solr_hip_set_variant(0)
+
+
+def _device_rotation_equals_host_rotation(solr, oracle, spec, grouping):
     hip = solr.hip_lib()
     k = _build(solr, spec, "hip")
     gpu_frame(k)                                   # uploads the scene
@@ -115,6 +125,10 @@ def test_device_rotation_equals_host_rotation(solr, oracle, spec):
     res = compare_frames(pp, ids, rgb, pp2, ids2, rgb2)
     assert res["ids_all_equal"] and res["max_ulp"] == 0 and res["rgb_max_diff"] == 0, res
     assert walk_fresh.shape[0] > 0
+    if not grouping:
+        # without grouping nodes the walk-order list is the reference's list minus its single-child chains:
+        # the same nodes whether refitted in place or uploaded afresh, and then the same bits
+        assert walk.shape == walk_fresh.shape and _same_bits(walk, walk_fresh)
     h.finalize()
 
 
