@@ -66,6 +66,14 @@ class Scene:
         self.keep = [np.ascontiguousarray(a) for a in (flat.boxes, flat.primitives, flat.lights, flat.materials,
                                                         flat.randoms, flat.textures)]
         boxes, prims, lights, mats, rnd, tex = self.keep
+        # the reference's material array always has NB_MAX_MATERIALS + 1 records, zeros beyond the active ones,
+        # and the box-debug view indexes it with box.startIndex % NB_MAX_MATERIALS (GI:695): give the
+        # restatement the same array, not just the active records
+        capacity = 65506 + 30 + 1
+        if len(mats) < capacity:
+            full = np.zeros(capacity, dtype=mats.dtype)
+            full[: len(mats)] = mats
+            mats = self.keep[3] = full
         # numpy silently re-packs padded structured dtypes in some operations (concatenate): insist on the C layout
         assert boxes.dtype.itemsize == 48 and prims.dtype.itemsize == 128 and mats.dtype.itemsize == 176
         assert lights.dtype.itemsize == 48 and rnd.dtype == np.float32 and tex.dtype == np.uint8

@@ -177,3 +177,27 @@ def test_rotation_with_frames_in_flight_and_materials_update(solr, oracle):
     finally:
         hip.solr_hip_set_frames_in_flight(1)
         k.finalize()
+
+
+def test_exact_node_list_follows_when_a_frame_walks_it(solr, oracle):
+    """rotations refit the walk-order list; the reference's own list is refitted when a frame walks it
+    (variant 3: walk the list exactly as uploaded; the box-debug view does the same)"""
+    hip = solr.hip_lib()
+    k = _build(solr, SCENES[0], "hip")
+    try:
+        gpu_frame(k)
+        for center, angles in STEPS[:3]:
+            k.rotate_primitives(center, angles)
+        fast = gpu_frame(k)
+        hip.solr_hip_set_variant(3)
+        exact = gpu_frame(k)
+        assert k.pending_rotations() == 3
+        res = compare_frames(*exact, *fast)
+        assert res["ids_all_equal"] and res["max_ulp"] == 0 and res["rgb_max_diff"] == 0, res
+        k.set_scene_info(renderBoxes=1)
+        boxes = gpu_frame(k)
+        opp, oids, orgb, _, status = oracle_frame(k, oracle)      # the host store catches up here
+        assert_parity(compare_frames(*boxes, opp, oids, orgb))
+    finally:
+        hip.solr_hip_set_variant(0)
+        k.finalize()

@@ -94,7 +94,7 @@ if __name__ == "__main__":
                       solr.ppe_filter, solr.ppe_cartoon][rng.next() % 6]
             k.set_post_processing(type=effect, param1=rng.uniform(1000.0, 9000.0), param2=rng.uniform(0.001, 20.0),
                                   param3=1 + rng.next() % 8)
-            k.set_scene_info(cameraType=camera, eyeSeparation=300.0,
+            k.set_scene_info(cameraType=camera, eyeSeparation=300.0, renderBoxes=int(rng.next() % 5 == 0),
                              advancedIllumination=[solr.aiNone, solr.aiBasic, solr.aiFull][rng.next() % 3])
             opp = oids = None
             passes = [0, 1, 2, 10, 11, 12, 13]
