@@ -242,6 +242,7 @@ def main():
     algo_bytes = nb_rows * W * BYTES_PER_PIXEL + scene_bytes  # per launch, rank 0's strip
     achieved = algo_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
     traffic, traffic_source = measured_traffic(args, world)
+    valu = measured_valu(args, world)
     out = {
         "metric": "Mrays/s @1920x1080, 3-bounce Cornell",
         "value": round(mrays, 3),
@@ -269,6 +270,14 @@ def main():
                      "kernel": "k_standardRenderer", "kernel_ms": round(kernel_avg_ms, 5), "kernel_ms_basis": kernel_basis,
                      "algorithmic_bytes": algo_bytes},
     }
+    if valu and kernel_avg_ms > 0:
+        # what actually bounds this kernel: a wave64 vector instruction occupies one of a
+        # CU's four SIMD16 units for four cycles -> 256 CUs x 4 SIMDs x 2.4 GHz / 4 wave-instructions per second
+        peak = 256 * 4 * 2.4e9 / 4
+        out["roofline"]["valu_issue"] = {
+            "insts_per_launch": valu[0], "source": valu[1], "peak_wave_insts_per_s": peak,
+            "frac": round(valu[0] / (kernel_avg_ms * 1e-3) / peak, 4),
+            "note": "informative: the contract's roofline is the HBM one above; this kernel is vector-issue bound"}
 
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(flat, si, ppi, eye, direction, angles, args.cpu_seconds)
@@ -294,6 +303,24 @@ def measured_traffic(args, world):
         if entry:
             return entry["bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None
+
+
+def measured_valu(args, world):
+    """SQ_INSTS_VALU per launch of the renderer from the committed PMC pass of this same command
+    (profiles/rNN/pmc_<scene>.txt), or None."""
+    import glob
+    if world != 1 or (args.width, args.height) != (1920, 1080) or args.graphics_level != 4:
+        return None
+    if args.scene == "cornell" and args.iterations != 3:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_%s.txt" % args.scene)), reverse=True):
+        try:
+            for line in open(path):
+                if line.startswith("SQ_INSTS_VALU"):
+                    return int(float(line.split()[1])), os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def usable_cpus():
