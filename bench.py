@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iterations", type=int, default=3)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "height_field", "molecule", "irt_model", "obj_model", "swc_morphology"])
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "height_field", "molecule", "irt_model", "obj_model", "swc_morphology", "pdb_molecule"])
     ap.add_argument("--scene-file", default="",
                     help="--scene irt_model / obj_model: the file (default: the reference's samples under tests/golden)")
     ap.add_argument("--variant", type=int, default=0)
@@ -99,10 +99,11 @@ def main():
     k = solr.Kernel(engine="hip", device=local_rank)
     builder = getattr(solr.scenes, args.scene)
     kw = dict(width=W, height=H, iterations=args.iterations)
-    if args.scene not in ("cornell", "irt_model", "obj_model", "swc_morphology"):
+    if args.scene not in ("cornell", "irt_model", "obj_model", "swc_morphology", "pdb_molecule"):
         kw.pop("iterations")
-    if args.scene in ("irt_model", "obj_model", "swc_morphology"):
-        default = {"irt_model": "model_subset.irt", "obj_model": "cornell.obj", "swc_morphology": "pyramidal.swc"}[args.scene]
+    if args.scene in ("irt_model", "obj_model", "swc_morphology", "pdb_molecule"):
+        default = {"irt_model": "model_subset.irt", "obj_model": "cornell.obj", "swc_morphology": "pyramidal.swc",
+                   "pdb_molecule": "1BNA.pdb"}[args.scene]
         path = args.scene_file or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", default)
         builder(k, path, **kw)
     else:
@@ -255,7 +256,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic" if args.scene not in ("irt_model", "obj_model", "swc_morphology") else "the reference's sample scene file",
+        "data": "synthetic" if args.scene not in ("irt_model", "obj_model", "swc_morphology", "pdb_molecule") else "the reference's sample scene file",
         "config": {"workload": "%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, row strips of %d" %
                    (args.scene, W, H, si.nbRayIterations, len(flat.boxes), len(flat.primitives), rows_per_rank),
                    "rays_per_frame": rays_total, "closest_hit_walks_rank0": int(counts[0]),

@@ -241,6 +241,7 @@ def _declare_host(L):
     L.SolR_RotatePrimitive.argtypes = [i] + [d] * 6
     L.SolR_RecompileKernels.argtypes = [C.c_char_p]
     L.SolR_SaveToFile.argtypes = [C.c_char_p]
+    L.SolR_LoadMolecule.argtypes = [C.c_char_p, i, d, d, i, d]
     L.SolR_LoadOBJModel.argtypes = [C.c_char_p, i, i, d, i, P(d)]
     L.SolRx_LoadSWCMorphology.argtypes = [C.c_char_p] + [d] * 7 + [i]
 
@@ -386,6 +387,11 @@ class Kernel:
         self.L.SolR_LoadOBJModel(os.fsencode(path), material_id, 1 if auto_scale else 0, scale,
                                  1 if auto_center else 0, C.byref(height))
         return height.value
+
+    def load_molecule(self, path, geometry_type=0, atom_size=100.0, stick_size=10.0, material_type=0, scale=100.0):
+        """Append a molecule from a PDB file (reference: PDBReader::loadAtomsFromFile via SolR_LoadMolecule);
+        overwrites materials 0..118 with the element colours."""
+        return self.L.SolR_LoadMolecule(os.fsencode(path), geometry_type, atom_size, stick_size, material_type, scale)
 
     def load_swc_morphology(self, path, position=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0, 1.0), material_id=0):
         """Append a neuron morphology (reference: SWCReader::loadMorphologyFromFile): spheres and

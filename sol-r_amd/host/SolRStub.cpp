@@ -13,6 +13,7 @@
 #include "FileMarshaller.h"
 #include "GPUKernel.h"
 #include "OBJReader.h"
+#include "PDBReader.h"
 #include "SWCReader.h"
 
 using solr::SingletonKernel;
@@ -200,6 +201,17 @@ int SolR_RotatePrimitives(int, int, double rx, double ry, double rz, double ax, 
     SingletonKernel::kernel()->rotatePrimitives(rotationCenter, angles);
     SingletonKernel::kernel()->compactBoxes(false);
     return 0;
+}
+
+int SolR_LoadMolecule(char *filename, int geometryType, double defaultAtomSize, double defaultStickSize,
+                      int atomMaterialType, double scale)
+{
+    solr::PDBReader reader;
+    const float s = static_cast<float>(scale);
+    reader.loadAtomsFromFile(filename ? filename : "", *SingletonKernel::kernel(),
+                             static_cast<solr::GeometryType>(geometryType), static_cast<float>(defaultAtomSize),
+                             static_cast<float>(defaultStickSize), atomMaterialType, solr::make_vec4f(s, s, s));
+    return (int)SingletonKernel::kernel()->getNbActivePrimitives();
 }
 
 int SolR_LoadOBJModel(char *filename, int materialId, int autoScale, double scale, int autoCenter, double *height)

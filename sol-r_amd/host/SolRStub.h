@@ -91,6 +91,11 @@ int SolR_RecompileKernels(char *filename);
 /* ---------- Scene files (SolRStub.h:145-146) ---------- */
 /* .irt scene dumps, host/FileMarshaller.h; both return the number of active (flattened) primitives,
  * which is what the reference returns: 0 until the next SolR_CompactBoxes */
+/* Molecules from PDB files, host/PDBReader.h (SolRStub.h:137-138): geometryType 0 atoms, 1 fixed-size atoms,
+ * 2 sticks, 3 atoms and sticks, 4 iso-surface, 5 backbone; atomMaterialType 0 by element, 1 by chain,
+ * 2 by residue.  Materials 0..118 are overwritten with the element colours. */
+int SolR_LoadMolecule(char *filename, int geometryType, double defaultAtomSize, double defaultStickSize,
+                      int atomMaterialType, double scale);
 /* Wavefront OBJ + MTL, host/OBJReader.h (SolRStub.h:141-143; the reference passes `double &height`, the
  * same ABI).  The model's materials take the ids materialId, materialId + 1, ... in the order of the MTL
  * file; *height receives -(scaled model height) / 2. */

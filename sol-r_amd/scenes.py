@@ -209,3 +209,16 @@ def swc_morphology(k, path, width=1920, height=1080, iterations=3, scale=40.0, *
     k.compact_boxes(True)
     k.set_camera((0.0, 2000.0, -16000.0), look_at=(0.0, 2000.0, 0.0))
     return n
+
+
+def pdb_molecule(k, path, width=1920, height=1080, iterations=3, geometry_type=3, scale=200.0, **scene_info):
+    """A scene around a PDB molecule (reference: PDBReader::loadAtomsFromFile as its MoleculeScene calls it:
+    atom size 100, stick size 10, scale 200, materials by element; light at (-5000, 5000, -15000))."""
+    k.initialize(width=width, height=height, nbRayIterations=iterations, graphicsLevel=glFull, **scene_info)
+    for _ in range(1100):                    # ids the reader writes or refers to (0..118, 1000, 1010)
+        k.add_material(0.5, 0.5, 0.5, specValue=1.0, specPower=100.0)
+    k.load_molecule(path, geometry_type=geometry_type, atom_size=100.0, stick_size=10.0, material_type=0, scale=scale)
+    add_light(k, position=(-5000.0, 5000.0, -15000.0), radius=1.0)
+    k.compact_boxes(True)
+    k.set_camera((0.0, 0.0, -15000.0), look_at=(0.0, 0.0, 0.0))
+    return k

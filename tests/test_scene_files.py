@@ -359,3 +359,116 @@ def test_swc_morphology_renders_like_the_oracle(solr, oracle):
     assert (ids[..., 0] >= 0).mean() > 0.02, "the neuron is not in view"
     assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
     k.finalize()
+
+
+# ---- PDB molecules (reference: solr/io/PDBReader.cpp; sol-r_amd/host/PDBReader.*) ---------------------
+# Golden vector: the reference's medias/pdb/1BNA.pdb (a B-DNA dodecamer, 486 atoms), kept as data.  The
+# expectations restate the reader with plain column slices and numpy binary32 arithmetic.
+PDB = os.path.join(HERE, "golden", "1BNA.pdb")
+ELEMENTS = os.path.join(os.path.dirname(HERE), "sol-r_amd", "host", "pdb_elements.txt")
+
+
+def _element_tables():
+    colours, radii = [], []
+    for line in open(ELEMENTS):
+        w = line.split()
+        if w and w[0] == "colour":
+            colours.append((w[1].upper(), int(w[2]), int(w[3]), int(w[4])))
+        elif w and w[0] == "radius":
+            radii.append((w[1], f4(w[2])))
+    return colours, radii
+
+
+def _squeeze(s):
+    return s.replace(" ", "")
+
+
+def parse_pdb(path):
+    atoms = []
+    for raw in open(path, newline=""):
+        line = raw.rstrip("\n")
+        if not line.startswith("ATOM"):
+            continue
+        assert len(line) >= 80
+        atoms.append(dict(id=_atoi(_squeeze(line[7:11])), code=_squeeze(line[13:17]), chain=ord(line[21]) - 64,
+                          residue=_atoi(_squeeze(line[23:26])), x=f4(_atof(_squeeze(line[31:37]))),
+                          y=f4(_atof(_squeeze(line[39:45]))), z=f4(-f4(_atof(_squeeze(line[47:53])))),
+                          element=_squeeze(line[77:79])))
+    return atoms
+
+
+def expected_molecule(solr, geometry_type, scale=200.0, atom_size=100.0, stick_size=10.0):
+    colours, radii = _element_tables()
+    atoms = parse_pdb(PDB)
+    for n, a in enumerate(atoms):
+        a["material"] = next(i for i, c in enumerate(colours) if c[0] == a["element"])
+        a["w"] = next(r for name, r in radii if name == a["element"])
+        a["backbone"] = len(a["code"]) == 1 or geometry_type in (4, 5)
+        a["key"] = a["id"] if (geometry_type == 2 or (geometry_type == 3 and a["residue"] % 2 == 0)) else n + 1
+    by_key = {}
+    for a in atoms:
+        by_key[a["key"]] = a                      # a later atom with the same key replaces the earlier one
+    order = [by_key[k_] for k_ in sorted(by_key)]
+    pos = np.array([[a["x"], a["y"], a["z"]] for a in atoms], f4)   # the extent is taken over every atom read
+    mn, mx = pos.min(0), pos.max(0)
+    centre = ((mn + mx) / f4(2)).astype(f4)
+    s = (f4(scale) / (mx - mn)).astype(f4)
+    spread = ((s * f4(2)) * f4(30)).astype(f4)
+
+    def place(p):
+        return (spread * (np.array(p, f4) - centre)).astype(f4)
+
+    out = []
+    for a in order:
+        radius, stick = a["w"], a["w"]
+        if geometry_type == 2:
+            radius = stick = f4(stick_size)
+        elif geometry_type == 3:
+            radius, stick = f4(a["w"] / f4(2)), f4(f4(stick_size) / f4(2))
+        if geometry_type in (2, 3):
+            for b in order:
+                if b is a or b["backbone"] != a["backbone"]:
+                    continue
+                d = np.array([a["x"] - b["x"], a["y"] - b["y"], a["z"] - b["z"]], f4)
+                dist = np.sqrt(f4(f4(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]))
+                if dist < f4(1.7):
+                    half = [f4((a[c] + b[c]) / f4(2)) for c in "xyz"]
+                    out.append((solr.ptCylinder, place([a["x"], a["y"], a["z"]]), place(half), f4(s[0] * stick),
+                                a["material"] if geometry_type == 2 else 1010))
+        material = 11 if geometry_type == 3 else a["material"]
+        out.append((solr.ptSphere, place([a["x"], a["y"], a["z"]]), None, f4(s[0] * stick), material))
+    return out, colours
+
+
+@pytest.mark.parametrize("geometry_type", [0, 2, 3], ids=["atoms", "sticks", "atoms-and-sticks"])
+def test_pdb_reader_against_the_files_text(solr, geometry_type):
+    expected, colours = expected_molecule(solr, geometry_type)
+    k = solr.Kernel(engine="host-only", deterministic_seed=1)
+    solr.scenes.pdb_molecule(k, PDB, width=64, height=48, geometry_type=geometry_type)
+    flat = k.flat_scene()
+    prims = flat.primitives
+    model = prims[prims["index"] < len(expected)]
+    model = model[np.argsort(model["index"])]
+    assert len(model) == len(expected) and len(np.unique(prims["index"])) == len(expected) + 1     # + the light
+    assert len(expected) == 486 if geometry_type == 0 else len(expected) > 486 + 800      # half-bonds on top
+    for got, (ptype, p0, p1, size, material) in zip(model, expected):
+        assert got["type"] == ptype and got["materialId"] == material
+        assert np.array_equal(got["p0"].view(np.uint32), p0.view(np.uint32))
+        if p1 is not None:
+            assert np.array_equal(got["p1"].view(np.uint32), p1.view(np.uint32))
+        assert got["size"][0] == size
+    for i, (_, r, g, b) in enumerate(colours):          # materials 0.. take the element colours
+        assert np.array_equal(flat.materials["color"][i][:3], np.array([r, g, b], f4) / f4(255))
+    k.finalize()
+
+
+@pytest.mark.gpu
+def test_pdb_molecule_renders_like_the_oracle(solr, oracle):
+    k = solr.Kernel(engine="hip", deterministic_seed=1)
+    solr.scenes.pdb_molecule(k, PDB, width=160, height=120, iterations=3)
+    pp, ids, rgb = gpu_frame(k)
+    opp, oids, orgb, _, status = oracle_frame(k, oracle)
+    assert status == 0
+    assert (ids[..., 0] >= 0).mean() > 0.05, "the molecule is not in view"
+    assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
+    k.finalize()
