@@ -6,7 +6,6 @@ scene store follows lazily.  The bar: after any number of such steps the device 
 primitives and the node list the host route (rotate on the host, flatten, upload) produces; the frames
 rendered on the way match the oracle on the host-route scene; and the host store, once it catches up,
 equals the host route's."""
-import importlib
 import os
 import sys
 
