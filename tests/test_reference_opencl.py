@@ -34,11 +34,18 @@ import scenes_extra  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
 def _build(solr, spec, engine):
     name, kw = spec
     k = solr.Kernel(engine=engine, deterministic_seed=1)
     fn = getattr(solr.scenes, name, None) or getattr(scenes_extra, name)
-    fn(k, **kw)
+    if "file" in kw:        # a scene loaded from one of the reference's sample files (tests/test_scene_files.py)
+        kw = dict(kw)
+        fn(k, os.path.join(GOLDEN, kw.pop("file")), **kw)
+    else:
+        fn(k, **kw)
     # off-axis: no pixel gets an exactly zero direction component
     k.set_camera((131.0, 77.0, -15000.0), look_at=(57.0, 23.0, 0.0))
     return k
@@ -70,6 +77,11 @@ CASES = [
     (("height_field", dict(n=24, width=128, height=96)), 0.9995, 0.985, 0.99, 0.985),
     (("triangles_only", dict(width=80, height=64)), 0.999, 0.999, 0.999, 0.999),
     (("sticks", dict(width=80, height=64)), 0.99, 0.96, 0.965, 0.85),
+    # the reference's own sample files, loaded by the readers of sol-r_amd/host (tests/test_scene_files.py)
+    (("obj_model", dict(file="cornell.obj", width=256, height=192, iterations=3)), 0.9995, 0.995, 0.995, 0.65),
+    (("irt_model", dict(file="model_subset.irt", width=256, height=192, iterations=2, floor=False)), 0.9995, 0.98, 0.985, 0.97),
+    (("pdb_molecule", dict(file="1BNA.pdb", width=256, height=192, iterations=2, geometry_type=3)), 0.998, 0.985, 0.988, 0.90),
+    (("swc_morphology", dict(file="pyramidal.swc", width=256, height=192, iterations=2)), 0.997, 0.985, 0.988, 0.96),
 ]
 
 
@@ -80,7 +92,7 @@ def ref(oracle):
     return oracle
 
 
-@pytest.mark.parametrize("case", CASES, ids=[c[0][0] + "-" + "-".join("%s%s" % kv for kv in c[0][1].items()) for c in CASES])
+@pytest.mark.parametrize("case", CASES, ids=[c[0][0] + "-" + "-".join("%s%s" % kv for kv in c[0][1].items() if kv[0] != "file") for c in CASES])
 def test_oracle_reproduces_the_reference_renderer(solr, ref, case):
     spec, min_ids, min_rgb, min_rgb8, min_colour = case
     k = _build(solr, spec, "host-only")
