@@ -443,9 +443,12 @@ bool GPUKernel::updateOutterBoundingBox(CPUBoundingBox &outterBox, const int dep
     outterBox.parameters[0] = make_vec3f(vd, vd, vd);
     outterBox.parameters[1] = make_vec3f(-vd, -vd, -vd);
     BoxContainer &level = frame().boundingBoxes[depth];
-    for (long key : outterBox.primitives)
+    const bool direct = outterBox.childAt.size() == outterBox.primitives.size();
+    for (size_t c = 0; c < outterBox.primitives.size(); ++c)
     {
-        CPUBoundingBox &box = level[(unsigned int)key];
+        const unsigned int key = (unsigned int)outterBox.primitives[c];
+        CPUBoundingBox *known = direct ? level.atIfKey(outterBox.childAt[c], key) : nullptr;
+        CPUBoundingBox &box = known ? *known : level[key];
         if (outterBox.parameters[0].x > box.parameters[0].x) outterBox.parameters[0].x = box.parameters[0].x;
         if (outterBox.parameters[0].y > box.parameters[0].y) outterBox.parameters[0].y = box.parameters[0].y;
         if (outterBox.parameters[0].z > box.parameters[0].z) outterBox.parameters[0].z = box.parameters[0].z;
@@ -475,6 +478,7 @@ void GPUKernel::resetBox(CPUBoundingBox &box, bool resetPrimitives)
     if (resetPrimitives)
     {
         box.primitives.clear();
+        box.childAt.clear();
         box.indexForNextBox = 1;
     }
     const float vd = m_sceneInfo.viewDistance;
@@ -554,9 +558,10 @@ int GPUKernel::processOutterBoxes(const int boxSize, const int boundingBoxesDept
     BoxContainer &level = f.boundingBoxes[boundingBoxesDepth];
     level.reserve(f.boundingBoxes[boundingBoxesDepth - 1].size() + 1);
     size_t maxPrimitivesPerBox = 0;
-    for (const auto &box : f.boundingBoxes[boundingBoxesDepth - 1])
+    BoxContainer &below = f.boundingBoxes[boundingBoxesDepth - 1];
+    for (BoxContainer::iterator it = below.begin(); it != below.end(); ++it)
     {
-        const vec3f &center = box.second.center;
+        const vec3f &center = it->second.center;
         int X = static_cast<int>((center.x - f.minPos.x) / boxSteps.x);
         int Y = static_cast<int>((center.y - f.minPos.y) / boxSteps.y);
         int Z = static_cast<int>((center.z - f.minPos.z) / boxSteps.z);
@@ -565,7 +570,8 @@ int GPUKernel::processOutterBoxes(const int boxSize, const int boundingBoxesDept
         CPUBoundingBox &outer = level[(unsigned int)B];
         outer.parameters[0] = make_vec3f(vd, vd, vd);
         outer.parameters[1] = make_vec3f(-vd, -vd, -vd);
-        outer.primitives.push_back(box.first);
+        outer.primitives.push_back(it->first);
+        outer.childAt.push_back(it.position());
         maxPrimitivesPerBox = std::max(maxPrimitivesPerBox, outer.primitives.size());
     }
     for (auto &box : level)
@@ -640,13 +646,18 @@ void GPUKernel::appendPrimitive(long id, bool inLevel0Box)
 
 /* reference: GPUKernel.cpp:1085-1149: depth-first emission; a node's skip
  * pointer is the number of nodes emitted for its subtree. */
-void GPUKernel::recursiveDataStreamToGPU(const int depth, std::vector<long> &elements)
+void GPUKernel::recursiveDataStreamToGPU(const int depth, CPUBoundingBox &parent)
 {
-    Frame &f = frame();
-    for (long element : elements)
+    Frame &f = frameAsIs();
+    BoxContainer &level = f.boundingBoxes[depth];
+    const bool direct = parent.childAt.size() == parent.primitives.size();
+    for (size_t c = 0; c < parent.primitives.size(); ++c)
     {
-        /* operator[] semantics: a missing key yields an empty box (skipped) */
-        CPUBoundingBox &box = f.boundingBoxes[depth][(unsigned int)element];
+        /* operator[] semantics: a missing key yields an empty box (skipped).  It may also grow the level
+         * and move its boxes: `parent` lives one level up and stays put */
+        const unsigned int key = (unsigned int)parent.primitives[c];
+        CPUBoundingBox *known = direct ? level.atIfKey(parent.childAt[c], key) : nullptr;
+        CPUBoundingBox &box = known ? *known : level[key];
         if (box.primitives.size() != 0 && f.nbActiveBoxes < NB_MAX_BOXES)
         {
             int boxIndex = f.nbActiveBoxes;
@@ -666,7 +677,7 @@ void GPUKernel::recursiveDataStreamToGPU(const int depth, std::vector<long> &ele
                         appendPrimitive(id, true);
             }
             else
-                recursiveDataStreamToGPU(depth - 1, box.primitives);
+                recursiveDataStreamToGPU(depth - 1, box);
             m_hBoundingBoxes[boxIndex].indexForNextBox.x = (depth == 0) ? 1 : f.nbActiveBoxes - boxIndex;
         }
     }
@@ -741,7 +752,7 @@ void GPUKernel::streamDataToGPU()
         m_hBoundingBoxes.push_back(out);
         ++f.nbActiveBoxes;
         if (maxDepth > 0)
-            recursiveDataStreamToGPU(maxDepth - 1, box.primitives);
+            recursiveDataStreamToGPU(maxDepth - 1, box);
         m_hBoundingBoxes[boxIndex].indexForNextBox.x = f.nbActiveBoxes - boxIndex;
     }
     if (f.nbActivePrimitives != (int)f.primitives.size())

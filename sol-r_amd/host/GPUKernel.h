@@ -51,6 +51,11 @@ struct CPUBoundingBox
     vec3f parameters[2];
     vec3f center;
     std::vector<long> primitives; /* primitive ids (level 0) or child box keys (level > 0) */
+    /* level > 0: where each child box sits in the level below (OrderedMap::at), filled next to `primitives`
+     * by processOutterBoxes so that the refit and the flattening need not hash 500 k keys per pass.  Only
+     * trusted while it has one entry per key: the light cell also lists light ids (GPUKernel.cpp:1189-1215)
+     * and goes the hashed way. */
+    std::vector<unsigned int> childAt;
     long indexForNextBox;
 };
 
@@ -73,6 +78,8 @@ public:
         iterator(OrderedMap *owner, size_t rank) : m_owner(owner), m_rank(rank) {}
         value_type &operator*() const { return m_owner->m_items[m_owner->m_order[m_rank]]; }
         value_type *operator->() const { return &m_owner->m_items[m_owner->m_order[m_rank]]; }
+        /* where the element lives: stable until clear(), see OrderedMap::at */
+        unsigned int position() const { return m_owner->m_order[m_rank]; }
         iterator &operator++()
         {
             ++m_rank;
@@ -122,6 +129,13 @@ public:
         return iterator(const_cast<OrderedMap *>(this), lo);
     }
     bool contains(unsigned int key) const { return m_index.find(key) != m_index.end(); }
+    /* the element at a position an iterator reported: no hashing (positions survive insertions) */
+    V &at(unsigned int position) { return m_items[position].second; }
+    /* ... provided it still is the element with that key (a level may have been cleared and refilled since) */
+    V *atIfKey(unsigned int position, unsigned int key)
+    {
+        return (position < m_items.size() && m_items[position].first == key) ? &m_items[position].second : nullptr;
+    }
     V *lookup(unsigned int key)
     {
         if (key < m_items.size() && m_items[key].first == key) /* dense ids: position == key */
@@ -382,7 +396,7 @@ protected:
     bool updateBoundingBox(CPUBoundingBox &box);
     bool updateOutterBoundingBox(CPUBoundingBox &box, const int depth);
     void resetBox(CPUBoundingBox &box, bool resetPrimitives);
-    void recursiveDataStreamToGPU(const int depth, std::vector<long> &elements);
+    void recursiveDataStreamToGPU(const int depth, CPUBoundingBox &parent);
     void appendPrimitive(long id, bool inLevel0Box);
     void fillRandoms();
 
