@@ -200,3 +200,37 @@ def test_exact_node_list_follows_when_a_frame_walks_it(solr, oracle):
     finally:
         hip.solr_hip_set_variant(0)
         k.finalize()
+
+
+def test_rotation_requests_the_engine_cannot_serve_change_nothing(solr):
+    import ctypes as C
+    hip = solr.hip_lib()
+    k = _build(solr, SCENES[0], "hip")
+    try:
+        gpu_frame(k)
+        before = k.device_primitives().copy()
+        f3 = C.c_float * 3
+        zero, one = f3(0, 0, 0), f3(1, 1, 1)
+        turn_c, turn_s = f3(1.0, float(np.cos(0.3)), 1.0), f3(0.0, float(np.sin(0.3)), 0.0)
+        served = hip.solr_hip_device_rotations()
+        assert hip.solr_hip_rotate_primitives(None, one, zero, 50000.0) == 0          # no centre
+        assert hip.solr_hip_rotate_primitives(zero, turn_c, turn_s, 2.0e6) == 0       # seeds would not commute
+        assert hip.solr_hip_rotate_primitives(zero, turn_c, turn_s, -1.0) == 0
+        hip.solr_hip_set_movable(None, 0)                                             # flags for another scene size
+        assert hip.solr_hip_rotate_primitives(zero, turn_c, turn_s, 50000.0) == 0
+        assert hip.solr_hip_device_rotations() == served
+        assert _same_bits(k.device_primitives(), before)
+        k.check(0, "refused rotations are not errors")
+        # too small a buffer for the read-back
+        small = np.zeros((4, 4), np.float32)
+        assert hip.solr_hip_read_primitives(small.ctypes.data, 4) == -1
+        assert hip.solr_hip_read_nodes(1, small.ctypes.data, 4) == -1
+        # the host store notices nothing of all this: its own rotation still goes through (by the host route,
+        # the flags being gone) and the frame is right
+        k.rotate_primitives((0.0, 0.0, 0.0), (0.0, 0.3, 0.0))
+        assert k.pending_rotations() == 0
+        gpu_frame(k)
+        k.rotate_primitives((0.0, 0.0, 0.0), (0.0, 0.3, 0.0))     # uploaded again, flags and all
+        assert k.pending_rotations() == 1
+    finally:
+        k.finalize()
