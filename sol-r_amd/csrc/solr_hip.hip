@@ -2650,7 +2650,7 @@ int solr_hip_get_variant(void)
 
 void solr_hip_memory_usage(unsigned long long bytes[4])
 {
-    bytes[0] = g.geometry.bytes + g.lamps.bytes;
+    bytes[0] = g.geometry.bytes + g.lamps.bytes + g.movable.bytes + g.refitPlan.bytes;
     bytes[1] = g.materials.bytes;
     bytes[2] = g.textures.bytes;
     bytes[3] = g.pp.bytes + g.ids.bytes + g.bitmap.bytes + g.randoms.bytes;
