@@ -335,14 +335,14 @@ void GPUKernel::setPrimitiveMaterial(unsigned int index, int materialId)
 
 int GPUKernel::getPrimitiveMaterial(unsigned int index)
 {
-    CPUPrimitive *p = getPrimitive(index);
+    const CPUPrimitive *p = peekPrimitive(index);
     return p ? p->materialId : -1;
 }
 
 vec4f GPUKernel::getPrimitiveCenter(unsigned int index)
 {
     vec4f center = make_vec4f();
-    if (CPUPrimitive *p = getPrimitive(index))
+    if (const CPUPrimitive *p = peekPrimitive(index))
     {
         center.x = p->p0.x;
         center.y = p->p0.y;
@@ -361,7 +361,8 @@ void GPUKernel::setPrimitiveCenter(unsigned int index, const vec3f &center)
 /* reference: GPUKernel.cpp:2482-2495 */
 int GPUKernel::getLight(int index)
 {
-    if (index >= 0 && index < frame().nbActiveLamps && index < (int)m_hLamps.size())
+    syncHost();
+    if (index >= 0 && index < frameAsIs().nbActiveLamps && index < (int)m_hLamps.size())
         return m_hLamps[index];
     return -1;
 }
@@ -779,7 +780,7 @@ void GPUKernel::previousFrame()
 /* reference: GPUKernel.cpp:1686-1690 */
 void GPUKernel::getPrimitiveOtherCenter(unsigned int index, vec3f &center)
 {
-    if (CPUPrimitive *p = getPrimitive(index))
+    if (const CPUPrimitive *p = peekPrimitive(index))
         center = p->p1;
 }
 

@@ -450,6 +450,12 @@ protected:
             syncHost();
         return m_frames[m_frame];
     }
+    /* a look that changes nothing (getPrimitiveCenter, getLight ...): up to date, fast path kept */
+    const CPUPrimitive *peekPrimitive(unsigned int index)
+    {
+        syncHost();
+        return m_frames[m_frame].primitives.lookup(index);
+    }
     /* counters and the frame protocol: reads that stay valid while rotations are pending */
     Frame &frameAsIs() { return m_frames[m_frame]; }
     /* engine hook: the per-pixel primitive ids of the last frame are wanted on the host (getPrimitiveAt).

@@ -73,6 +73,10 @@ def test_device_route_needs_an_uploaded_untouched_scene(solr):
     _frame(k)
     k.rotate_primitives(*STEPS[1])
     assert k.pending_rotations() == 1
+    assert k.L.SolR_GetPrimitiveMaterial(2) >= 0 # a look: replayed, fast path kept
+    assert k.pending_rotations() == 0
+    k.rotate_primitives(*STEPS[1])
+    assert k.pending_rotations() == 1
     k.L.SolR_SetPrimitiveMaterial(2, 3)          # a change: replayed first, then applied, fast path off
     assert k.pending_rotations() == 0
     k.rotate_primitives(*STEPS[2])
@@ -87,6 +91,7 @@ def test_device_route_needs_an_uploaded_untouched_scene(solr):
 
     h = _build(solr, "host-only", SCENES[0])
     h.rotate_primitives(*STEPS[0])
+    h.rotate_primitives(*STEPS[1])
     h.rotate_primitives(*STEPS[1])
     h.L.SolR_SetPrimitiveMaterial(2, 3)
     h.rotate_primitives(*STEPS[2])

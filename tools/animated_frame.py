@@ -32,7 +32,7 @@ step = ((0.0, 0.0, 0.0), (0.0, 0.02, 0.0))
 # host route: a touch of the scene store before every rotation keeps it off the device
 t = []
 for _ in range(a.host_frames):
-    k.L.SolR_GetPrimitiveMaterial(0)
+    k.L.SolR_SetPrimitiveMaterial(0, k.L.SolR_GetPrimitiveMaterial(0))
     t0 = time.perf_counter()
     k.rotate_primitives(*step)
     t1 = time.perf_counter()
