@@ -1831,6 +1831,73 @@ static void anaglyphRendererPixel(const OracleScene *s, const SceneInfo *si, v3 
     }
 }
 
+/* ref CRT:953-1043, k_3DVisionRenderer for one pixel - what cudaRender dispatches for cameraType == ctVR
+ * (CRT:1737-1755): the left half of the image is the left eye's view, the right half the right eye's, the
+ * eyes' distance scaled by the look-at depth over the depth of the frame's focus pixel.  That depth is read
+ * from postProcessingBuffer[size.x / 2 * size.y / 2].colorInfo.w while, on pass 0, the thread of that pixel
+ * writes it: a race in the reference.  `focusDepth` is the value before the frame - the outcome in which the
+ * focus pixel is written last - and on later passes the only one. */
+static void visionRendererPixel(const OracleScene *s, const SceneInfo *si, const PostProcessingInfo *ppi, v3 origin,
+                                v3 direction, const float angles[4], const Trig *trig, float focusDepth, int x,
+                                int yLocal, int firstRow, PostProcessingBuffer *pp, PrimitiveXYIdBuffer *ids, Stats *st)
+{
+    int index = yLocal * si->size.x + x;
+    int gindex = (firstRow + yLocal) * si->size.x + x;
+    int yGlobal = firstRow + yLocal;
+    if (si->pathTracingIteration > ids[index].y && ids[index].w == 0 && si->pathTracingIteration > 0 &&
+        si->pathTracingIteration <= NB_MAX_ITERATIONS)
+        return;
+    float focus = fabsf(focusDepth - origin.z);
+    float eyeSeparation = si->eyeSeparation * (direction.z / focus);
+    v3 rotationCenter = origin; /* cameraType is ctVR here */
+    float dof = ppi->param1;
+    int halfWidth = si->size.x / 2;
+    float ratio = (float)si->size.x / (float)si->size.y;
+    float stepx = ratio * angles[3] / (float)si->size.x;
+    float stepy = angles[3] / (float)si->size.y;
+    Ray r;
+    memset(&r, 0, sizeof(r));
+    if (x < halfWidth)
+    {
+        r.origin.x = origin.x + eyeSeparation;
+        r.direction.x = direction.x - stepx * (float)(x - (si->size.x / 2) + halfWidth / 2) + si->eyeSeparation;
+    }
+    else
+    {
+        r.origin.x = origin.x - eyeSeparation;
+        r.direction.x = direction.x - stepx * (float)(x - (si->size.x / 2) - halfWidth / 2) - si->eyeSeparation;
+    }
+    r.origin.y = origin.y;
+    r.origin.z = origin.z;
+    r.direction.y = direction.y + stepy * (float)(yGlobal - (si->size.y / 2));
+    r.direction.z = direction.z;
+    r.origin = vectorRotation(r.origin, rotationCenter, trig);
+    r.direction = vectorRotation(r.direction, rotationCenter, trig);
+    c3 color = launchRayTracing(s, gindex, &r, si, &dof, &ids[index], st);
+    if (si->advancedIllumination == aiRandomIllumination)
+    {
+        int rindex = (gindex + si->timestamp) % MAX_BITMAP_SIZE;
+        float rv = rnd(s, rindex, st);
+        color.x += si->backgroundColor.x * rv * 5.f;
+        color.y += si->backgroundColor.y * rv * 5.f;
+        color.z += si->backgroundColor.z * rv * 5.f;
+    }
+    if (si->pathTracingIteration == 0)
+        pp[index].colorInfo.w = dof;
+    if (si->pathTracingIteration <= NB_MAX_ITERATIONS)
+    {
+        pp[index].colorInfo.x = color.x;
+        pp[index].colorInfo.y = color.y;
+        pp[index].colorInfo.z = color.z;
+    }
+    else
+    {
+        pp[index].colorInfo.x += color.x;
+        pp[index].colorInfo.y += color.y;
+        pp[index].colorInfo.z += color.z;
+    }
+}
+
 /* ref CRT:741-815, k_fishEyeRenderer for one pixel: 360 degrees around the Y axis across the image width -
  * the look-at point is rotated about the eye by angles.y + 2 pi x / W - plain store / accumulate.  The
  * rotation's cos / sin are per pixel.  cosf / sinf are only specified to an error bound (CUDA's: 2 ULP, glibc's: <1 ULP),
@@ -2117,6 +2184,17 @@ int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const Po
     nthreads = 1;
 #endif
 
+    /* k_3DVisionRenderer's focus pixel, CRT:973 (integer expression as written there), as it is before the
+     * frame; a strip that does not hold it reads 0 */
+    float focusDepth = 0.f;
+    if (sceneInfo->cameraType == ctVR)
+    {
+        const int focusIndex = sceneInfo->size.x / 2 * sceneInfo->size.y / 2;
+        const int focusRow = focusIndex / W - firstRow;
+        if (focusRow >= 0 && focusRow < nbRows)
+            focusDepth = pp[focusRow * W + focusIndex % W].colorInfo.w;
+    }
+
 #pragma omp parallel num_threads(nthreads)
     {
         Stats st;
@@ -2126,7 +2204,10 @@ int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const Po
             for (int x = 0; x < W; ++x)
             {
                 /* the camera types the engine renders with a kernel of their own (CRT:1714-1836) */
-                if (sceneInfo->cameraType == ctAnaglyph)
+                if (sceneInfo->cameraType == ctVR)
+                    visionRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, &trig, focusDepth, x, y, firstRow, pp,
+                                        ids, &st);
+                else if (sceneInfo->cameraType == ctAnaglyph)
                     anaglyphRendererPixel(scene, sceneInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
                 else if (sceneInfo->cameraType == ctPanoramic)
                     fishEyeRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, x, y, firstRow, pp, ids, &st);

@@ -46,6 +46,7 @@ struct FrameArgs
     int tilesX;
     int fuseDefault;      /* 1: write the RGB bitmap from the renderer */
     int stackSlots;       /* colour-stack slots per lane in LDS */
+    float focusDepth;     /* ctVR: depth of the focus pixel before this frame (k_3DVisionRenderer) */
     unsigned long long *tileClock; /* diagnostics: {start, end} of every tile in 100 MHz ticks, or null */
     /* cost-ordered launch (see TileScheduling below); all null when off */
     unsigned *tileCost;        /* out: duration of every tile of this frame, 100 MHz ticks */
@@ -165,7 +166,11 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     /* ctPanoramic (k_fishEyeRenderer, CRT:741-815): the look-at point turns about the eye by
      * angles.y + 2 pi x / W; plain store like the anaglyph camera */
     const bool fishEye = (FEAT & F_FULL) && (si.cameraType == ctPanoramic);
-    const bool plainStore = anaglyph || fishEye;
+    /* ctVR is dispatched to k_3DVisionRenderer (CRT:1737-1755, 953-1043): side-by-side views of the two
+     * eyes, their distance scaled by look-at depth / depth of the focus pixel (F.focusDepth: the value
+     * before this frame, see the oracle's visionRendererPixel for the race it stands for) */
+    const bool vision = (FEAT & F_FULL) && (si.cameraType == ctVR);
+    const bool plainStore = anaglyph || fishEye || vision;
     v3 leftEye = V(0.f, 0.f, 0.f);
     const int nbRays = antialiasingActivated ? 5 : (anaglyph ? 2 : 1);
 #pragma unroll 1
@@ -182,6 +187,31 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
             rD = V(F.dx - stepx * (float)(x - (si.size.x / 2)), F.dy + stepy * (float)(yGlobal - (si.size.y / 2)), F.dz);
             rO = vectorRotation(rO, V(0.f, 0.f, 0.f), F.trig);
             rD = vectorRotation(rD, V(0.f, 0.f, 0.f), F.trig);
+        }
+        if (vision)
+        {
+            const float focus = fabsf(F.focusDepth - F.oz);
+            const float eyeSeparation = si.eyeSeparation * (F.dz / focus);
+            const int halfWidth = si.size.x / 2;
+            const float ratio = (float)si.size.x / (float)si.size.y;
+            const float stepx = ratio * F.aw / (float)si.size.x;
+            const float stepy = F.aw / (float)si.size.y;
+            const v3 eye = V(F.ox, F.oy, F.oz);
+            if (x < halfWidth)
+            {
+                rO = V(F.ox + eyeSeparation, F.oy, F.oz);
+                rD.x = F.dx - stepx * (float)(x - (si.size.x / 2) + halfWidth / 2) + si.eyeSeparation;
+            }
+            else
+            {
+                rO = V(F.ox - eyeSeparation, F.oy, F.oz);
+                rD.x = F.dx - stepx * (float)(x - (si.size.x / 2) - halfWidth / 2) - si.eyeSeparation;
+            }
+            rD.y = F.dy + stepy * (float)(yGlobal - (si.size.y / 2));
+            rD.z = F.dz;
+            rO = vectorRotation(rO, eye, F.trig);
+            rD = vectorRotation(rD, eye, F.trig);
+            dof = F.ppi.param1;
         }
         if (fishEye)
         {
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
             color = color + c;
     }
 
-    if (!plainStore && si.advancedIllumination == aiRandomIllumination)
+    if ((!plainStore || vision) && si.advancedIllumination == aiRandomIllumination)
     {
         int rindex = (gindex + si.timestamp) % MAX_BITMAP_SIZE;
         float rv = rnd(S, rindex);
@@ -1420,7 +1450,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     /* which stream / buffer set: first-pass frames alternate when two frames may be in flight; a
      * refinement or accumulation pass reads what the previous pass wrote and stays where that is */
     int flight = g.current;
-    if (twoFlights() && !counting && sceneInfo.pathTracingIteration == 0)
+    /* (the 3D-vision camera reads a depth of the frame before: it stays on one buffer set) */
+    if (twoFlights() && !counting && sceneInfo.pathTracingIteration == 0 && sceneInfo.cameraType != ctVR)
         flight = (int)(g.frameSerial++ % (unsigned)activeFlights());
     else if (!twoFlights())
         flight = 0;
@@ -1430,7 +1461,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     /* the box-debug view and the census count every node of the original tree */
     const bool full = sceneInfo.renderBoxes != 0 || sceneInfo.advancedIllumination == aiBasic ||
                       sceneInfo.advancedIllumination == aiFull || sceneInfo.cameraType == ctAntialiazed ||
-                      sceneInfo.cameraType == ctAnaglyph || sceneInfo.cameraType == ctPanoramic;
+                      sceneInfo.cameraType == ctAnaglyph || sceneInfo.cameraType == ctPanoramic ||
+                      sceneInfo.cameraType == ctVR;
     const bool exactNodes = counting || sceneInfo.renderBoxes != 0 || objects.x != g.nbBoxes || g.variant == 3;
     flushGeometry();
     if (exactNodes)
@@ -1480,6 +1512,20 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     maxIt = maxIt > NB_MAX_ITERATIONS ? NB_MAX_ITERATIONS : maxIt;
     maxIt = maxIt < 1 ? 1 : maxIt;
     F.stackSlots = maxIt;
+    if (sceneInfo.cameraType == ctVR)
+    {
+        /* the focus pixel of k_3DVisionRenderer (CRT:973, integer expression as written there) as the frame
+         * before left it; a strip that does not hold it reads 0 */
+        const long focusIndex = (long)(sceneInfo.size.x / 2 * sceneInfo.size.y / 2);
+        const long focusRow = focusIndex / sceneInfo.size.x - F.firstRow;
+        if (focusRow >= 0 && focusRow < F.nbRows && flightPp(flight).ptr)
+        {
+            const PostProcessingBuffer *at = (const PostProcessingBuffer *)flightPp(flight).ptr +
+                                             focusRow * sceneInfo.size.x + focusIndex % sceneInfo.size.x;
+            HIPCHECK(hipMemcpyAsync(&F.focusDepth, &at->colorInfo.w, sizeof(float), hipMemcpyDeviceToHost, stream));
+            HIPCHECK(hipStreamSynchronize(stream));
+        }
+    }
     const size_t ldsBytes = ((size_t)F.stackSlots * 4 + COLD_FIELDS) * WAVE * sizeof(float);
 
     const dim3 grid(F.tilesX * tilesY), block(WAVE);

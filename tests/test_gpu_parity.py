@@ -395,6 +395,34 @@ def test_anaglyph_camera_through_refinement_and_accumulation_passes(solr, oracle
     assert_parity(res, max_ulp=2)
 
 
+def _stereo_scene(k, **info):
+    solr_mod.scenes.cornell(k, **info)
+    # a look-at point off the z = 0 plane: the eyes' distance is eyeSeparation x look-at depth / focus depth
+    k.set_camera((200.0, 100.0, -15000.0), look_at=(0.0, 0.0, 4000.0))
+
+
+def test_3d_vision_camera_through_refinement_and_accumulation_passes(solr, oracle):
+    # cameraType ctVR is dispatched to k_3DVisionRenderer (CRT:1737-1755, 953-1043): side-by-side eyes whose
+    # distance follows the depth the frame before stored for the focus pixel; plain store, then accumulation
+    res = progressive(solr, oracle, _stereo_scene, range(0, 14), width=96, height=64, iterations=2,
+                      cameraType=solr_mod.ctVR, eyeSeparation=380.0)
+    print(res)
+    assert_parity(res, max_ulp=2)
+
+
+def test_3d_vision_camera_reads_the_focus_depth_of_the_frame_before(solr, oracle):
+    k = solr.Kernel(engine="hip")
+    _stereo_scene(k, width=96, height=64, iterations=2, cameraType=solr_mod.ctVR, eyeSeparation=380.0)
+    first = gpu_frame(k)            # focus depth 0: nothing has been rendered yet
+    opp, oids, orgb, _, status = oracle_frame(k, oracle)
+    assert_parity(compare_frames(*first, opp, oids, orgb))
+    second = gpu_frame(k)           # now the depth the first frame left behind
+    opp2, oids2, orgb2, _, status = oracle_frame(k, oracle, pp=opp, ids=oids)
+    assert_parity(compare_frames(*second, opp2, oids2, orgb2))
+    assert not np.array_equal(first[2], second[2]), "the eyes did not move with the focus depth"
+    k.finalize()
+
+
 def _panorama_inside_the_room(k, **info):
     solr_mod.scenes.cornell(k, **info)
     k.set_camera((150.0, -300.0, -1200.0), look_at=(150.0, -300.0, 2800.0))
