@@ -230,11 +230,17 @@ def main():
         elapsed = float(tmax[0])
         rays_total = int(tsum[1])
         kernel_avg_ms = float(tmax[2])
+        # every rank empties its C stdout buffer (RCCL's version banner sits there until exit) before rank 0
+        # may print: the JSON line is then the last thing the job writes to stdout
+        C.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        dist.barrier()
     else:
         kernel_avg_ms = kernel_ms / max(launches.value, 1)
 
     if rank != 0:
         dist.destroy_process_group()
+        C.CDLL(None).fflush(None)
         return
 
     mrays = rays_total * args.steps / elapsed / 1e6
@@ -282,9 +288,13 @@ def main():
 
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(flat, si, ppi, eye, direction, angles, args.cpu_seconds)
-    print(json.dumps(out), flush=True)
     if distributed:
+        # RCCL writes its version banner to the C library's stdout buffer when the communicator comes up; on a
+        # pipe that buffer is only flushed at exit, after our line.  Tear the group down and flush it first:
+        # the JSON line is the last thing on stdout
         dist.destroy_process_group()
+    C.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
 
 
 def measured_traffic(args, world):
