@@ -26,7 +26,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HIP_LIB = os.environ.get("SOLR_HIP_LIB") or os.path.join(_HERE, "csrc", "libsolr_hip.so")
-HOST_LIB = os.path.join(_HERE, "host", "libsolr.so")
+HOST_LIB = os.environ.get("SOLR_HOST_LIB") or os.path.join(_HERE, "host", "libsolr.so")  # sanitizer builds
 
 # ---- constants (include/solr_types.h) ---------------------------------------
 NB_MAX_ITERATIONS = 10
