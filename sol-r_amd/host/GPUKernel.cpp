@@ -949,8 +949,10 @@ void GPUKernel::syncHost()
     std::vector<PendingRotation> pending;
     pending.swap(m_pendingRotations);
     Frame &f = m_frames[m_frame];
-    for (const PendingRotation &r : pending)
-        rotatePrimitivesOnly(f, r.center, r.cosA, r.sinA);
+    /* a handful of rotations is replayed (4 ms each for 100 k primitives); a long animation is fetched */
+    if (pending.size() <= 8 || !primitivesFromDevice(f))
+        for (const PendingRotation &r : pending)
+            rotatePrimitivesOnly(f, r.center, r.cosA, r.sinA);
     refitBoxes(f);
     /* the flattened arrays follow.  What they now hold is what the device holds (the same arithmetic
      * ran there), so neither an upload is due nor has the scene been "touched" by this */

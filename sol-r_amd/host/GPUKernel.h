@@ -463,6 +463,10 @@ protected:
      * 16 bytes per pixel, five times the image - although only picking ever looks at them; an engine may
      * leave them on the device until then */
     virtual void fetchPrimitiveIds() {}
+    /* engine hook: the primitives as the resident scene holds them now, written into the store (the same
+     * bits a replay of the pending rotations produces - tests/test_animation_gpu.py - at a cost that does not
+     * grow with their number); false = not available, replay */
+    virtual bool primitivesFromDevice(Frame &) { return false; }
     /* engine hook: apply the rotation to the resident scene; false = not done, nothing changed */
     virtual bool deviceRotatePrimitives(const vec3f &, const vec3f &, const vec3f &) { return false; }
     void rotatePrimitivesOnly(Frame &f, const vec3f &rotationCenter, const vec3f &cosA, const vec3f &sinA);

@@ -6,6 +6,7 @@
 #include "HipKernel.h"
 
 #include <cstring>
+#include <vector>
 #include <iostream>
 
 #include "../../include/solr_hip.h"
@@ -144,6 +145,39 @@ bool HipKernel::deviceRotatePrimitives(const vec3f &center, const vec3f &cosA, c
     const float co[3] = {cosA.x, cosA.y, cosA.z};
     const float si[3] = {sinA.x, sinA.y, sinA.z};
     return solr_hip_rotate_primitives(c, co, si, m_sceneInfo.viewDistance) == 1;
+}
+
+bool HipKernel::primitivesFromDevice(Frame &f)
+{
+    if (!m_deviceInitialized)
+        return false;
+    /* 8 rows of 4 floats per flattened primitive, sol-r_amd/csrc/scene_layout.h: p0 | size | p1 | p2 | n0 | n1 | n2 | uv */
+    const int rows = solr_hip_read_primitives(nullptr, 0);
+    if (rows <= 0 || (size_t)rows != 8 * m_hPrimitives.size())
+        return false; /* not the scene the flattened arrays describe */
+    std::vector<float> data((size_t)rows * 4);
+    if (solr_hip_read_primitives(data.data(), rows) != rows)
+        return false;
+    /* nothing is written before everything is known to be writable: a half-updated store could not fall back
+     * to the replay */
+    std::vector<CPUPrimitive *> target(m_hPrimitives.size(), nullptr);
+    for (size_t i = 0; i < m_hPrimitives.size(); ++i)
+        if (m_hMovable[i] && !(target[i] = f.primitives.lookup((unsigned int)m_hPrimitives[i].index)))
+            return false;
+    for (size_t i = 0; i < m_hPrimitives.size(); ++i)
+    {
+        CPUPrimitive *p = target[i];
+        if (!p)
+            continue;
+        const float *r = &data[i * 32];
+        p->p0 = make_vec3f(r[0], r[1], r[2]);
+        p->p1 = make_vec3f(r[8], r[9], r[10]);
+        p->p2 = make_vec3f(r[12], r[13], r[14]);
+        p->n0 = make_vec3f(r[16], r[17], r[18]);
+        p->n1 = make_vec3f(r[20], r[21], r[22]);
+        p->n2 = make_vec3f(r[24], r[25], r[26]);
+    }
+    return true;
 }
 
 void HipKernel::render_end()

@@ -51,6 +51,7 @@ protected:
     /* rotatePrimitives on the resident scene, solr_hip_rotate_primitives (include/solr_hip.h) */
     bool deviceRotatePrimitives(const vec3f &center, const vec3f &cosA, const vec3f &sinA) override;
     void fetchPrimitiveIds() override;
+    bool primitivesFromDevice(Frame &f) override;
 
 private:
     vec4i m_blockSize;

@@ -234,3 +234,27 @@ def test_rotation_requests_the_engine_cannot_serve_change_nothing(solr):
         assert k.pending_rotations() == 1
     finally:
         k.finalize()
+
+
+@pytest.mark.parametrize("spec", [SCENES[0], SCENES[3]], ids=[SCENES[0][0], SCENES[3][0]])
+def test_long_animation_is_fetched_not_replayed(solr, spec):
+    """beyond a handful of pending rotations the host store takes the primitives from the device instead of
+    replaying them one by one: same bits, constant cost"""
+    k = _build(solr, spec, "hip")
+    gpu_frame(k)
+    n = 0
+    for lap in range(5):
+        for center, angles in STEPS:
+            k.rotate_primitives(center, angles)
+            n += 1
+    assert k.pending_rotations() == n == 25
+    fetched = k.flat_scene()
+    assert k.pending_rotations() == 0
+    k.finalize()
+    h = _build(solr, spec, "host-only")
+    for lap in range(5):
+        for center, angles in STEPS:
+            h.rotate_primitives(center, angles)
+    eager = h.flat_scene()
+    h.finalize()
+    assert _same_records(fetched.boxes, eager.boxes) and _same_records(fetched.primitives, eager.primitives)
