@@ -585,7 +585,7 @@ int GPUKernel::compactBoxes(bool reconstructBoxes)
 {
     /* rotations applied on the device: the flattened scene over there is already what the lines below
      * would produce and upload */
-    if (!reconstructBoxes && !m_pendingRotations.empty())
+    if (!reconstructBoxes && (!m_pendingRotations.empty() || m_unrecordedRotations))
         return frameAsIs().nbActiveBoxes;
     m_primitivesTransfered = false;
     if (reconstructBoxes)
@@ -877,6 +877,11 @@ void GPUKernel::rotatePrimitives(const vec3f &rotationCenter, const vec4f &angle
      * engine may turn it in place, and the host copy follows when somebody looks (syncHost) */
     if (m_primitivesTransfered && !m_hostTouched && deviceRotatePrimitives(rotationCenter, cosA, sinA))
     {
+        if (m_pendingRotations.size() >= MAX_RECORDED_ROTATIONS)
+        {
+            ++m_unrecordedRotations;
+            return;
+        }
         PendingRotation r;
         r.center = rotationCenter;
         r.cosA = cosA;
@@ -943,16 +948,23 @@ void GPUKernel::refitBoxes(Frame &f)
 
 void GPUKernel::syncHost()
 {
-    if (m_pendingRotations.empty())
+    if (m_pendingRotations.empty() && !m_unrecordedRotations)
         return;
     const bool transfered = m_primitivesTransfered, touched = m_hostTouched;
     std::vector<PendingRotation> pending;
     pending.swap(m_pendingRotations);
+    const size_t unrecorded = m_unrecordedRotations;
+    m_unrecordedRotations = 0;
     Frame &f = m_frames[m_frame];
     /* a handful of rotations is replayed (4 ms each for 100 k primitives); a long animation is fetched */
     if (pending.size() <= 8 || !primitivesFromDevice(f))
+    {
+        if (unrecorded)
+            std::cerr << "GPUKernel::syncHost: the engine did not hand back its primitives and " << unrecorded
+                      << " of the rotations it applied were not recorded: the scene store lags behind" << std::endl;
         for (const PendingRotation &r : pending)
             rotatePrimitivesOnly(f, r.center, r.cosA, r.sinA);
+    }
     refitBoxes(f);
     /* the flattened arrays follow.  What they now hold is what the device holds (the same arithmetic
      * ran there), so neither an upload is due nor has the scene been "touched" by this */

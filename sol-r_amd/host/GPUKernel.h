@@ -422,7 +422,7 @@ public:
      * host copy then lags behind by the rotations listed in m_pendingRotations and is caught up - the same
      * arithmetic, replayed in order - by syncHost() before anything reads or changes it. */
     void syncHost();
-    size_t nbPendingRotations() const { return m_pendingRotations.size(); }
+    size_t nbPendingRotations() const { return m_pendingRotations.size() + m_unrecordedRotations; }
     int lightInformationSize() const { return m_lightInformationSize; }
     const Material *hostMaterials() const { return m_hMaterials.data(); }
     const std::vector<RandomBuffer> &hostRandoms() const { return m_hRandoms; }
@@ -446,7 +446,7 @@ protected:
     Frame &frame()
     {
         m_hostTouched = true;
-        if (!m_pendingRotations.empty())
+        if (!m_pendingRotations.empty() || m_unrecordedRotations)
             syncHost();
         return m_frames[m_frame];
     }
@@ -528,6 +528,10 @@ protected:
         vec3f center, cosA, sinA;
     };
     std::vector<PendingRotation> m_pendingRotations;
+    /* an animation that runs for hours: past this many the rotations are only counted - the store then
+     * catches up from the device's primitives, which it does for more than a handful anyway */
+    static constexpr size_t MAX_RECORDED_ROTATIONS = 100000;
+    size_t m_unrecordedRotations = 0;
 
     SceneInfo m_sceneInfo;
     PostProcessingInfo m_postProcessingInfo;
