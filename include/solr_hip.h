@@ -71,7 +71,10 @@ void h2d_lightInformation(vec2i occupancyParameters, LightInformation *lightInfo
 
 /* CudaRayTracer.h:55 / CudaRayTracer.cu:1647-1672: waits for the frame and
  * copies the RGB bitmap (W*H*3 bytes) and the primitive-id buffer (W*H*16
- * bytes) of this process's strip to the strip's position in the host arrays */
+ * bytes) of this process's strip to the strip's position in the host arrays.
+ * Extension: either pointer may be NULL and is then skipped - the ids, five times the image, can be left
+ * on the device until picking needs them and fetched with a second call (they stay valid until the next
+ * frame is rendered into the same buffers; HipKernel::render_end / fetchPrimitiveIds do that) */
 void d2h_bitmap(vec2i occupancyParameters, SceneInfo sceneInfo, BitmapBuffer *bitmap,
                 PrimitiveXYIdBuffer *primitivesXYIds);
 
