@@ -69,6 +69,11 @@ class Scene:
         # the reference's material array always has NB_MAX_MATERIALS + 1 records, zeros beyond the active ones,
         # and the box-debug view indexes it with box.startIndex % NB_MAX_MATERIALS (GI:695): give the
         # restatement the same array, not just the active records
+        # the texture atlas is followed by zeros, like the engine's (h2d_textures): a material's secondary maps
+        # are read at its diffuse texture's texel index, past the end of a smaller map and, for the last
+        # textures, past the atlas (undefined in the reference)
+        if len(tex):
+            tex = self.keep[5] = np.concatenate([tex, np.zeros(len(tex) + 4, np.uint8)])
         capacity = 65506 + 30 + 1
         if len(mats) < capacity:
             full = np.zeros(capacity, dtype=mats.dtype)

@@ -2481,16 +2481,21 @@ void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
     if (!ready("h2d_textures"))
         return;
     quiesce();
-    size_t total = 0;
+    size_t total = 0, largest = 0;
     for (int i = 0; i < activeTextures; ++i)
         if (textureInfos[i].buffer)
         {
             size_t sz = (size_t)textureInfos[i].size.x * textureInfos[i].size.y * textureInfos[i].size.z;
             size_t end = (size_t)textureInfos[i].offset + sz;
             total = end > total ? end : total;
+            largest = sz > largest ? sz : largest;
         }
-    /* 4 bytes of slack: texel fetches read index .. index+2 */
-    std::vector<unsigned char> atlas(total + 4, 0);
+    /* Slack: a texel fetch reads index .. index+2, and the secondary maps of a material (normal, bump,
+     * specular ...) are read at the texel index of its DIFFUSE texture (TextureMapping.cuh:30-116): a map
+     * smaller than the diffuse texture is read up to `largest` bytes past its own end.  Inside the atlas that
+     * is the next texture, as in the reference; past the atlas the reference reads whatever follows its
+     * buffer - here zeros, always. */
+    std::vector<unsigned char> atlas(total + largest + 4, 0);
     for (int i = 0; i < activeTextures; ++i)
         if (textureInfos[i].buffer)
         {

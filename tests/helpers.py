@@ -6,7 +6,8 @@ import numpy as np
 
 def ulp_distance(a, b):
     """Element-wise distance in units in the last place between two float32 arrays
-    (sign-magnitude aware; NaN never equal)."""
+    (sign-magnitude aware; a NaN only equals a NaN: where the reference's arithmetic ends in 0/0 - a
+    normal map that flattens the normal to zero length, TextureMapping.cuh:30-40 - both sides must)."""
     a = np.ascontiguousarray(a, np.float32)
     b = np.ascontiguousarray(b, np.float32)
     ia = a.view(np.int32).astype(np.int64)
@@ -15,6 +16,7 @@ def ulp_distance(a, b):
     ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
     d = np.abs(ia - ib)
     d[np.isnan(a) | np.isnan(b)] = 1 << 40
+    d[np.isnan(a) & np.isnan(b)] = 0
     return d
 
 

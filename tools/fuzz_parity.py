@@ -17,6 +17,21 @@ def build(k, seed, width=72, height=48):
                  shadowIntensity=pick([1.0, 0.6]), gradientBackground=rng.next() % 2,
                  doubleSidedTriangles=(rng.next() % 5 == 0))
     mats = []
+    textures = 0
+    if os.environ.get("FUZZ_TEXTURES"):
+        # a few random images for the texture tier (diffuse / normal / bump / specular / reflection /
+        # transparency / ambient-occlusion maps on random materials)
+        import numpy as np
+        textures = 4
+        # one size for all: the secondary maps are read at the DIFFUSE texture's texel index (TM:30-116), so a
+        # smaller normal / specular / ... map is read past its end - into the next texture of the atlas or,
+        # for the last ones, past the atlas (undefined in the reference, nothing to compare)
+        w, h = 8 + rng.next() % 56, 8 + rng.next() % 40
+        for i in range(textures):
+            if os.environ["FUZZ_TEXTURES"] == "2":   # mixed sizes: reads past the atlas see zeros on both sides
+                w, h = 8 + rng.next() % 56, 8 + rng.next() % 40
+            k.set_texture(i, np.random.RandomState(seed * 31 + i).randint(0, 256, size=(h, w, 3)).astype(np.uint8),
+                          texture_type=rng.next() % 7)
     for _ in range(6):
         kind = rng.next() % 5
         mats.append(k.add_material(u(0.1, 1.0), u(0.1, 1.0), u(0.1, 1.0),
@@ -25,7 +40,15 @@ def build(k, seed, width=72, height=48):
                                    refraction=pick([1.0, 1.1, 1.33]) if kind == 2 else 0.0,
                                    opacity=u(0.0, 0.5) if kind == 2 else 0.0,
                                    specValue=u(0.0, 1.0), specPower=pick([10.0, 50.0, 200.0, 1000.0]),
-                                   fastTransparency=(kind == 3), noise=0.0))
+                                   fastTransparency=(kind == 3), noise=0.0,
+                                   **({} if not textures or rng.next() % 2 else dict(
+                                       diffuseTextureId=rng.next() % textures,
+                                       normalTextureId=pick([solr.TEXTURE_NONE, rng.next() % textures]),
+                                       bumpTextureId=pick([solr.TEXTURE_NONE, rng.next() % textures]),
+                                       specularTextureId=pick([solr.TEXTURE_NONE, rng.next() % textures]),
+                                       reflectionTextureId=pick([solr.TEXTURE_NONE, rng.next() % textures]),
+                                       transparencyTextureId=pick([solr.TEXTURE_NONE, rng.next() % textures]),
+                                       ambientOcclusionTextureId=pick([solr.TEXTURE_NONE, rng.next() % textures])))))
     n = 20 + rng.next() % int(os.environ.get("FUZZ_MAX_PRIMS", "200"))
     span = 9000.0
     for _ in range(n):
@@ -45,6 +68,8 @@ def build(k, seed, width=72, height=48):
             p2 = (p0[0] + u(-2500, 2500), p0[1] + u(-2500, 2500), p0[2] + u(-2500, 2500))
             i = k.add_primitive(t, p0, p1, p2, material=m)
             k.set_normals(i, (u(-1, 1), u(-1, 1), u(-1, 1)), (u(-1, 1), u(-1, 1), u(-1, 1)), (u(-1, 1), u(-1, 1), u(-1, 1)))
+            if textures:
+                k.set_texture_coordinates(i, (u(0, 1), u(0, 1)), (u(0, 1), u(0, 1)), (u(0, 1), u(0, 1)))
         else:
             k.add_primitive(t, p0, size=(u(500, 4000), u(500, 4000), u(500, 4000)), material=m)
     for _ in range(1 + rng.next() % 2):
