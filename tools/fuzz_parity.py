@@ -13,9 +13,18 @@ def build(k, seed, width=72, height=48):
     u = lambda a, b: rng.uniform(a, b)
     pick = lambda seq: seq[rng.next() % len(seq)]
     iterations = 1 + rng.next() % 4
+    misc = {}
+    wild = bool(os.environ.get("FUZZ_MISC"))
+    if wild:
+        # odd image sizes, the all-triangle mode, fog, a shorter view distance, a time stamp for the
+        # procedural materials
+        width, height = 17 + rng.next() % 90, 9 + rng.next() % 60
+        misc = dict(extendedGeometry=int(rng.next() % 4 != 0), atmosphericEffect=pick([solr.aeNone, solr.aeFog]),
+                    viewDistance=pick([50000.0, 30000.0, 22000.0]), timestamp=rng.next() % 5000,
+                    bgColor=(u(0, 1), u(0, 1), u(0, 1), u(0, 0.5)))
     k.initialize(width=width, height=height, nbRayIterations=iterations, graphicsLevel=pick([4, 4, 4, 3, 2]),
                  shadowIntensity=pick([1.0, 0.6]), gradientBackground=rng.next() % 2,
-                 doubleSidedTriangles=(rng.next() % 5 == 0))
+                 doubleSidedTriangles=(rng.next() % 5 == 0), **misc)
     mats = []
     textures = 0
     if os.environ.get("FUZZ_TEXTURES"):
@@ -40,7 +49,11 @@ def build(k, seed, width=72, height=48):
                                    refraction=pick([1.0, 1.1, 1.33]) if kind == 2 else 0.0,
                                    opacity=u(0.0, 0.5) if kind == 2 else 0.0,
                                    specValue=u(0.0, 1.0), specPower=pick([10.0, 50.0, 200.0, 1000.0]),
-                                   fastTransparency=(kind == 3), noise=0.0,
+                                   fastTransparency=(kind == 3), noise=(pick([0.0, 0.0, 0.02]) if wild else 0.0),
+                                   procedural=bool(wild and rng.next() % 6 == 0),
+                                   wireframe=bool(wild and rng.next() % 6 == 0),
+                                   wireframeWidth=(pick([0, 30, 80]) if wild else 0),
+                                   innerIllumination=(pick([0.0, 0.0, 0.0, 0.3]) if wild and kind == 0 else 0.0),
                                    **({} if not textures or rng.next() % 2 else dict(
                                        diffuseTextureId=rng.next() % textures,
                                        normalTextureId=pick([solr.TEXTURE_NONE, rng.next() % textures]),
