@@ -36,6 +36,21 @@
  * the correctly rounded value, CUDA's within 2 ULP; the engine evaluates it in binary64 and rounds once.
  * SOLR_ORACLE_CORRECTLY_ROUNDED_POW=1 makes the restatement do the same, which tells a powf rounding
  * difference (gone with it) from a real one when a frame is 2 ULP off (tools/fuzz_parity.py). */
+/* float -> int as the reference's device code converts (cvt.rzi.s32.f32 on its GPU, v_cvt_i32_f32 on this
+ * one): truncation, saturating at the ends of the range, NaN -> 0.  A C cast of such a value is undefined
+ * (x86 yields INT_MIN for all of them), and the texture mappers do reach them: a grazing triangle's
+ * barycentric sum is 0. */
+static int f2i(float v)
+{
+    if (v != v)
+        return 0;
+    if (v >= 2147483648.f)
+        return 2147483647;
+    if (v <= -2147483648.f)
+        return (-2147483647 - 1);
+    return (int)v;
+}
+
 static int correctlyRoundedPow = -1;
 static float specularPower(float base, float exponent)
 {
@@ -406,8 +421,8 @@ static f4 triangleUVMapping(const SceneInfo *si, const Primitive *primitive, con
         mox = material->mappingOffset.x * si->timestamp;
         moy = material->mappingOffset.y * si->timestamp;
     }
-    int u = (int)(Tx * material->textureMapping.x + mox);
-    int v = (int)(Ty * material->textureMapping.y + moy);
+    int u = f2i(Tx * material->textureMapping.x + mox);
+    int v = f2i(Ty * material->textureMapping.y + moy);
     u = u % material->textureMapping.x;
     v = v % material->textureMapping.y;
     if (u >= 0 && u < material->textureMapping.x && v >= 0 && v < material->textureMapping.y)
@@ -436,8 +451,8 @@ static f4 sphereUVMapping(const Primitive *primitive, const Material *materials,
     v3 I = vnormalize(vsub(intersection, primitive->p0));
     float U = ((atan2f(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
     float V_ = (asinf(I.y) / SOLR_PI) + .5f;
-    int u = (int)(material->textureMapping.x * (U * primitive->vt1.x));
-    int v = (int)(material->textureMapping.y * (V_ * primitive->vt1.y));
+    int u = f2i(material->textureMapping.x * (U * primitive->vt1.x));
+    int v = f2i(material->textureMapping.y * (V_ * primitive->vt1.y));
     if (material->textureMapping.x != 0)
         u = u % material->textureMapping.x;
     if (material->textureMapping.y != 0)
@@ -454,11 +469,11 @@ static f4 cubeMapping(const SceneInfo *si, const Primitive *primitive, const Mat
 {
     const Material *material = &materials[primitive->materialId];
     f4 result = colorOf(material);
-    int u = (int)(((primitive->type == ptCheckboard) || (primitive->type == ptXZPlane) ||
+    int u = f2i(((primitive->type == ptCheckboard) || (primitive->type == ptXZPlane) ||
                    (primitive->type == ptXYPlane))
                       ? (intersection.x - primitive->p0.x + primitive->size.x)
                       : (intersection.z - primitive->p0.z + primitive->size.z));
-    int v = (int)(((primitive->type == ptCheckboard) || (primitive->type == ptXZPlane))
+    int v = f2i(((primitive->type == ptCheckboard) || (primitive->type == ptXZPlane))
                       ? (intersection.z + primitive->p0.z + primitive->size.z)
                       : (intersection.y - primitive->p0.y + primitive->size.y));
     if (material->textureMapping.x != 0)
@@ -486,8 +501,8 @@ static f4 cubeMapping(const SceneInfo *si, const Primitive *primitive, const Mat
 /* ref TM:449-456 */
 static inline int wireFrameMapping(float x, float y, int width)
 {
-    int X = (int)fabsf(x);
-    int Y = (int)fabsf(y);
+    int X = f2i(fabsf(x));
+    int Y = f2i(fabsf(y));
     int A = 100;
     int B = 100;
     return (X % A <= width) || (Y % B <= width);
@@ -523,8 +538,8 @@ static c3 skyboxMapping(const SceneInfo *si, const Material *materials, const Bi
     v3 intersection = vnormalize(vadd(ray->origin, vscale(dir, t)));
     float U = ((atan2f(intersection.x, intersection.z) / SOLR_PI) + 1.f) * .5f;
     float V_ = (asinf(intersection.y) / SOLR_PI) + .5f;
-    int u = (int)(material->textureMapping.x * U);
-    int v = (int)(material->textureMapping.y * V_);
+    int u = f2i(material->textureMapping.x * U);
+    int v = f2i(material->textureMapping.y * V_);
     if (material->textureMapping.x != 0)
         u %= material->textureMapping.x;
     if (material->textureMapping.y != 0)
@@ -738,7 +753,7 @@ static int planeIntersection(const SceneInfo *si, const Primitive *primitive, co
         {
             PLANE_HIT(y, z, x);
             if (mat->innerIllumination.x != 0.f)
-                collision &= (int)fabsf(intersection->z) % 4000 < 2000 && (int)fabsf(intersection->y) % 4000 < 2000;
+                collision &= f2i(fabsf(intersection->z)) % 4000 < 2000 && f2i(fabsf(intersection->y)) % 4000 < 2000;
             if (mat->attributes.z == 2)
                 collision &= wireFrameMapping(intersection->y, intersection->z, mat->attributes.w);
         }
@@ -747,7 +762,7 @@ static int planeIntersection(const SceneInfo *si, const Primitive *primitive, co
             *normal = vneg(*normal);
             PLANE_HIT(y, z, x);
             if (mat->innerIllumination.x != 0.f)
-                collision &= (int)fabsf(intersection->z) % 4000 < 2000 && (int)fabsf(intersection->y) % 4000 < 2000;
+                collision &= f2i(fabsf(intersection->z)) % 4000 < 2000 && f2i(fabsf(intersection->y)) % 4000 < 2000;
             if (mat->attributes.z == 2)
                 collision &= wireFrameMapping(intersection->y, intersection->z, mat->attributes.w);
         }
@@ -1151,8 +1166,8 @@ static f4 intersectionShader(const SceneInfo *si, const Primitive *primitive, co
                                 advancedAttributes);
             else
             {
-                int x = (int)(si->viewDistance + ((intersection.x - primitive->p0.x) / primitive->size.x));
-                int z = (int)(si->viewDistance + ((intersection.z - primitive->p0.z) / primitive->size.x));
+                int x = f2i(si->viewDistance + ((intersection.x - primitive->p0.x) / primitive->size.x));
+                int z = f2i(si->viewDistance + ((intersection.z - primitive->p0.z) / primitive->size.x));
                 if (x % 2 == 0)
                 {
                     if (z % 2 == 0)
@@ -1413,7 +1428,7 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
                                                 &shadowIntensity, &rBlinn, &attributes, st);
 
             /* CRT:190: int += float*int, evaluated in float then truncated */
-            primitiveXYId->z = (int)((float)primitiveXYId->z + cm->innerIllumination.x * 256);
+            primitiveXYId->z = f2i((float)primitiveXYId->z + cm->innerIllumination.x * 256);
 
             float segmentLength = vlength(vsub(closestIntersection, latestIntersection));
             latestIntersection = closestIntersection;
@@ -1486,7 +1501,7 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
             {
                 colors[iteration] = skyboxMapping(si, s->materials, s->textures, &rayOrigin);
                 float rad = colors[iteration].x + colors[iteration].y + colors[iteration].z;
-                primitiveXYId->z = (int)((float)primitiveXYId->z + ((rad > 2.5f) ? rad * 256.f : 0.f));
+                primitiveXYId->z = f2i((float)primitiveXYId->z + ((rad > 2.5f) ? rad * 256.f : 0.f));
             }
             else if (si->gradientBackground)
             {
@@ -1522,7 +1537,7 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
             colors[reflectedRays].x += color.x * reflectedRatio;
             colors[reflectedRays].y += color.y * reflectedRatio;
             colors[reflectedRays].z += color.z * reflectedRatio;
-            primitiveXYId->w = (int)(shadowIntensity * 255);
+            primitiveXYId->w = f2i(shadowIntensity * 255);
         }
 
     int test = 1;
@@ -1980,8 +1995,8 @@ static void postDepthOfField(const OracleScene *s, const SceneInfo *si, const Po
     {
         int ix = i % wh;
         int iy = (i + 1000) % wh;
-        int xx = (int)(x + depth * rnd(s, ix, st) * ppi->param2);
-        int yy = (int)(y + depth * rnd(s, iy, st) * ppi->param2);
+        int xx = f2i(x + depth * rnd(s, ix, st) * ppi->param2);
+        int yy = f2i(y + depth * rnd(s, iy, st) * ppi->param2);
         if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
         {
             int localIndex = yy * si->size.x + xx;
@@ -2032,8 +2047,8 @@ static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, cons
             int iy = (i + 100) % wh;
             ++i;
             c += 1.f;
-            int xx = (int)(x + (X * ppi->param2 * rnd(s, ix, st) / 10.f));
-            int yy = (int)(y + (Y * ppi->param2 * rnd(s, iy, st) / 10.f));
+            int xx = f2i(x + (X * ppi->param2 * rnd(s, ix, st) / 10.f));
+            int yy = f2i(y + (Y * ppi->param2 * rnd(s, iy, st) / 10.f));
             if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
             {
                 int localIndex = yy * si->size.x + xx;
@@ -2076,8 +2091,8 @@ static void postRadiosity(const OracleScene *s, const SceneInfo *si, const PostP
     {
         int ix = (i + si->pathTracingIteration) % wh;
         int iy = (i + 100 + si->pathTracingIteration) % wh;
-        int xx = (int)((float)x + rnd(s, ix, st) * ppi->param2);
-        int yy = (int)((float)y + rnd(s, iy, st) * ppi->param2);
+        int xx = f2i((float)x + rnd(s, ix, st) * ppi->param2);
+        int yy = f2i((float)y + rnd(s, iy, st) * ppi->param2);
         localColor.x += pp[index].colorInfo.x;
         localColor.y += pp[index].colorInfo.y;
         localColor.z += pp[index].colorInfo.z;

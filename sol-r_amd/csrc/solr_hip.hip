@@ -1630,7 +1630,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     /* smallest instantiation that covers the scene (rt_device.h, enum Feature) */
     int need = g.sceneFeatures;
     if (!sceneInfo.extendedGeometry)
-        need = F_TRI; /* every primitive is tested as a triangle, GI:743-747 */
+        /* every primitive is tested as a triangle, GI:743-747 - and textured as one (GI:916-931) */
+        need = F_TRI | (g.sceneFeatures & F_TEX);
     if (full)
         need |= F_FULL;
     if (sceneInfo.skyboxMaterialId >= 0 && sceneInfo.skyboxMaterialId < (int)g.materialTags.size() &&

@@ -395,6 +395,20 @@ def test_anaglyph_camera_through_refinement_and_accumulation_passes(solr, oracle
     assert_parity(res, max_ulp=2)
 
 
+def test_textures_in_the_all_triangle_mode(solr, oracle):
+    # extendedGeometry == 0 tests every primitive as a triangle (GI:743-747) and textures it as one
+    # (intersectionShader's else branch): the kernel chosen for that mode has to carry the texture tier
+    k = solr.Kernel(engine="hip")
+    X.textured(k, width=96, height=64, skybox=False, extendedGeometry=0)
+    pp, ids, rgb = gpu_frame(k)
+    opp, oids, orgb, counts, status = oracle_frame(k, oracle)
+    assert status == 0
+    res = compare_frames(pp, ids, rgb, opp, oids, orgb)
+    assert (ids[..., 0] >= 0).mean() > 0.02, "no triangle in view"
+    assert_parity(res)
+    k.finalize()
+
+
 def _stereo_scene(k, **info):
     solr_mod.scenes.cornell(k, **info)
     # a look-at point off the z = 0 plane: the eyes' distance is eyeSeparation x look-at depth / focus depth
