@@ -121,6 +121,30 @@ if __name__ == "__main__":
             if not (good(r2) and status == 0):
                 ok = False
                 res = dict(r2, after="3 device rotations")
+        if os.environ.get("FUZZ_STRIPS") and ok:
+            # what the ranks of a multi-GPU run render: the frame in 2..4 row strips, each against the oracle's
+            # strip, assembled against the full frame
+            import numpy as np
+            hip = solr.hip_lib()
+            H = k.info["height"]
+            world = 2 + seed % 3
+            full = k.render()
+            assembled = np.zeros_like(full)
+            for rank in range(world):
+                row0, rows, _ = solr.strip_rows(rank, world, H)
+                if rows <= 0:
+                    continue
+                hip.solr_hip_set_strip(row0, rows)
+                img = k.render()
+                assembled[row0:row0 + rows] = img[row0:row0 + rows]
+                o = oracle_frame(k, loader, first_row=row0, nb_rows=rows)
+                if not np.array_equal(img[row0:row0 + rows], o[2]):
+                    ok = False
+                    res = dict(res, after="strip %d of %d differs from the oracle's" % (rank, world))
+            hip.solr_hip_set_strip(0, 0)
+            if ok and not np.array_equal(assembled, full):
+                ok = False
+                res = dict(res, after="%d strips do not add up to the full frame" % world)
         if os.environ.get("FUZZ_MODES") and ok:
             # another camera, a post-processing effect, and a few refinement / accumulation passes, the oracle
             # being handed its own previous frame
