@@ -521,6 +521,11 @@ static c3 skyboxMapping(const SceneInfo *si, const Material *materials, const Bi
     float d = b * b - 2.f * a * c;
     if (d <= 0.f || a == 0.f)
         return result;
+    /* GI:87-151 fetches a texel whatever the material: without a diffuse texture the "computed texture"
+     * mapping (40000 x 40000, GPUKernel.cpp:1893-1896) indexes gigabytes past the atlas.  Here, as in the
+     * engine, such a skybox shows the material's colour. */
+    if (material->textureIds.x < 0)
+        return result;
     float r = sqrtf(d);
     float t1 = (-b - r) / a;
     float t2 = (-b + r) / a;

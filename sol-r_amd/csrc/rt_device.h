@@ -1712,6 +1712,12 @@ SOLR_DEV v3 skyboxMapping(const Scene &S, const SceneInfo &si, v3 origin, v3 tar
         return result;
     if (!(FEAT & F_TEX))
         return result; /* the host selects a F_TEX instantiation whenever the skybox material has a texture */
+    /* GI:87-151 fetches a texel whatever the material: without a diffuse texture the "computed texture"
+     * mapping (40000 x 40000) indexes gigabytes past the atlas - a fault here.  Such a skybox shows the
+     * material's colour, wherever the test falls in the reference's order of operations: nothing that
+     * follows has a side effect */
+    if (mh.ids.x < 0)
+        return result;
     v3 I = normalize(origin + dir * t);
     float U = ((atan2_f(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
     float Vv = (asin_f(I.y) / SOLR_PI) + .5f;

@@ -88,6 +88,10 @@ def build(k, seed, width=72, height=48):
     for _ in range(1 + rng.next() % 2):
         S.add_light(k, position=(u(-span, span), u(3000, 12000), u(-12000, -3000)), intensity=u(0.8, 2.0))
     k.compact_boxes(True)
+    if textures and rng.next() % 3 == 0:
+        # a textured skybox (the viewer's default has one) and a colour key for the texture transparency
+        k.set_scene_info(skyboxMaterialId=pick(mats), skyboxSize=int(u(20000, 45000)),
+                         transparentColor=pick([0.0, 0.95, 0.5]))
     k.set_camera((u(-2000, 2000), u(-2000, 2000), -16000.0 + u(-2000, 2000)), look_at=(u(-1500, 1500), u(-1500, 1500), 0.0),
                  angles=(u(-0.2, 0.2), u(-0.2, 0.2), u(-0.1, 0.1)))
     return k
