@@ -1436,6 +1436,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     ARGCHECK(objects.x <= g.nbBoxes && objects.y <= g.nbPrimitives, "cudaRender: more objects than were uploaded");
     ARGCHECK(objects.w <= g.nbLights, "cudaRender: more lights than were uploaded");
     ARGCHECK(g.materials.ptr != nullptr, "cudaRender: no materials uploaded");
+    ARGCHECK(sceneInfo.skyboxMaterialId <= NB_MAX_MATERIALS, "cudaRender: skybox material beyond the material table");
     if (!ok())
         return;
     HIPCHECK(hipSetDevice(g.device));
