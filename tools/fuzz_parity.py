@@ -125,6 +125,24 @@ if __name__ == "__main__":
             if not (good(r2) and status == 0):
                 ok = False
                 res = dict(r2, after="3 device rotations")
+        if os.environ.get("FUZZ_FLIGHTS") and ok:
+            # what bench.py runs: two frames in flight and the cost-ordered tile launch (forced), through two
+            # refreshes of the order - every frame must be the first one again
+            import numpy as np
+            hip = solr.hip_lib()
+            hip.solr_hip_set_frames_in_flight(2)
+            hip.solr_hip_set_tile_scheduling(2)
+            try:
+                for n in range(36):
+                    again = gpu_frame(k)
+                    if not (np.array_equal(again[0].view(np.uint32), pp.view(np.uint32)) and np.array_equal(again[1], ids) and
+                            np.array_equal(again[2], rgb)):   # bit patterns: a NaN pixel is a NaN pixel again
+                        ok = False
+                        res = dict(res, after="frame %d with two frames in flight and cost-ordered tiles differs" % n)
+                        break
+            finally:
+                hip.solr_hip_set_frames_in_flight(1)
+                hip.solr_hip_set_tile_scheduling(1)
         if os.environ.get("FUZZ_STRIPS") and ok:
             # what the ranks of a multi-GPU run render: the frame in 2..4 row strips, each against the oracle's
             # strip, assembled against the full frame
