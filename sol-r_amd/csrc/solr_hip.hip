@@ -2425,7 +2425,13 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
     g.materialAverage.assign(capacity, 0.f);
     for (int i = 0; i < nbActiveMaterials && i < capacity; ++i)
     {
-        const Material &m = materials[i];
+        Material m = materials[i];
+        /* A diffuse texture id that was never loaded: GPUKernel::setMaterial then leaves the "computed texture"
+         * mapping (40000 x 40000 at offset 0, GPUKernel.cpp:1893-1896) next to the id, and the mappers would
+         * index gigabytes past the atlas (the reference reads whatever is there; a memory fault here).  Such a
+         * material is untextured on the device. */
+        if (m.textureIds.x >= 0 && m.textureMapping.x == 40000 && m.textureMapping.y == 40000 && m.textureOffset.x == 0)
+            m.textureIds.x = TEXTURE_NONE;
         g.materialTags[i] = materialTag(m);
         g.materialAverage[i] = (m.color.x + m.color.y + m.color.z) / 3.f; /* same expression, same rounding */
         MaterialHot &h = hot[i];

@@ -1080,7 +1080,7 @@ void GPUKernel::setMaterial(unsigned int index, float r, float g, float b, float
         make_vec4i(reflectionTextureId, transparentTextureId, ambientOcclusionTextureId, TEXTURE_NONE);
     m.advancedTextureOffset = make_vec4i();
     m.mappingOffset = make_vec2f(1.f, 1.f);
-    auto off = [this](int id) { return (id == TEXTURE_NONE) ? 0 : m_hTextures[id].offset; };
+    auto off = [this](int id) { return (id < 0 || id >= NB_MAX_TEXTURES) ? 0 : m_hTextures[id].offset; };
     if (diffuseTextureId >= 0 && diffuseTextureId < m_nbActiveTextures)
     {
         const TextureInfo &t = m_hTextures[diffuseTextureId];
@@ -1198,7 +1198,7 @@ const std::vector<BitmapBuffer> &GPUKernel::hostTextureAtlas()
 void GPUKernel::realignTexturesAndMaterials()
 {
     processTextureOffsets();
-    auto off = [this](int id) { return (id == TEXTURE_NONE) ? 0 : m_hTextures[id].offset; };
+    auto off = [this](int id) { return (id < 0 || id >= NB_MAX_TEXTURES) ? 0 : m_hTextures[id].offset; };
     for (int i = 0; i < m_nbActiveMaterials && i < (int)m_hMaterials.size(); ++i)
     {
         Material &m = m_hMaterials[i];

@@ -409,6 +409,33 @@ def test_textures_in_the_all_triangle_mode(solr, oracle):
     k.finalize()
 
 
+def test_a_texture_id_that_was_never_loaded_does_not_fault(solr):
+    # A material that names a texture nobody loaded.  Through the host protocol realignTexturesAndMaterials
+    # gives it a 0 x 0 mapping (no texel is fetched; `x % 0` is guarded on the device); uploaded as
+    # GPUKernel::setMaterial leaves it - the id next to the 40000 x 40000 "computed texture" mapping - the
+    # reference's mappers would read gigabytes past the atlas, and h2d_materials drops the id instead.
+    k = solr.Kernel(engine="hip")
+    k.initialize(width=64, height=48, nbRayIterations=2)
+    k.set_texture(0, np.full((8, 8, 3), 200, np.uint8))
+    wall = k.add_material(0.8, 0.4, 0.2, diffuseTextureId=7)
+    ball = k.add_material(0.2, 0.6, 0.9, diffuseTextureId=7, normalTextureId=300, reflection=0.3)
+    k.add_primitive(solr_mod.ptXYPlane, (0, 0, 4000), size=(9000, 6000, 0), material=wall)
+    k.add_primitive(solr_mod.ptSphere, (0, 0, 0), size=(1500, 0, 0), material=ball)
+    t = k.add_primitive(solr_mod.ptTriangle, (-3000, -2000, 500), (-1000, -2000, 0), (-2000, 1500, 300), material=ball)
+    k.set_texture_coordinates(t, (0.1, 0.1), (0.9, 0.2), (0.4, 0.9))
+    solr_mod.scenes.add_light(k)
+    k.compact_boxes(True)
+    k.set_scene_info(skyboxMaterialId=wall, skyboxSize=30000)
+    k.set_camera((0.0, 0.0, -12000.0))
+    first = gpu_frame(k)
+    k.check(0, "render")
+    second = gpu_frame(k)
+    k.check(0, "render")
+    assert (first[1][..., 0] >= 0).mean() > 0.2
+    assert np.array_equal(first[0].view(np.uint32), second[0].view(np.uint32))
+    k.finalize()
+
+
 def _stereo_scene(k, **info):
     solr_mod.scenes.cornell(k, **info)
     # a look-at point off the z = 0 plane: the eyes' distance is eyeSeparation x look-at depth / focus depth
