@@ -105,9 +105,11 @@ void solr_hip_set_stream(void *stream);
 void solr_hip_synchronize(void);
 
 /* Row strip rendered by this process: rows [firstRow, firstRow + nbRows) of
- * the full sceneInfo.size image.  nbRows <= 0 restores the full frame.  The
- * device buffers then hold only the strip (row 0 of the buffer = firstRow);
- * d2h_bitmap places it at its position in a full-size host image. */
+ * the full sceneInfo.size image.  nbRows < 0 restores the full frame; nbRows
+ * == 0 is an EMPTY strip (a process left without rows when there are more
+ * processes than rows to share out): cudaRender and d2h_bitmap then do
+ * nothing.  The device buffers hold only the strip (row 0 of the buffer =
+ * firstRow); d2h_bitmap places it at its position in a full-size host image. */
 void solr_hip_set_strip(int firstRow, int nbRows);
 
 /* Device pointers of the current per-pixel buffers (strip-sized), for

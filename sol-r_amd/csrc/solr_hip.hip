@@ -77,7 +77,8 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     const Scene S = makeScene(SA);
     const SceneInfo &si = F.si;
     const int lane = threadIdx.x;
-    const int tile = F.tileOrder ? (int)F.tileOrder[blockIdx.x] : (int)blockIdx.x;
+    /* the order is a permutation by construction (k_orderTiles); the clamp keeps a damaged one inside the frame */
+    const int tile = F.tileOrder ? (int)min(F.tileOrder[blockIdx.x], gridDim.x - 1u) : (int)blockIdx.x;
     unsigned long long clock0 = 0ull;
     if (F.tileClock || F.tileCost)
         clock0 = __builtin_amdgcn_s_memrealtime();
@@ -522,8 +523,13 @@ __global__ __launch_bounds__(256) void k_cartoon(const SceneInfo si, const PostP
  * atomics per frame serialise at the memory side and tripled the frame time.) */
 __device__ unsigned orderSerial = 0u;
 
-__global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict__ cost, unsigned *__restrict__ order,
-                                                      int n, volatile unsigned *hostStats, int sort)
+/* Frames in flight: the frame on the other stream may still be storing its tiles' costs while this kernel
+ * runs.  Every cost is therefore read from `cost` exactly ONCE, into `snapshot` (private to the sort, written
+ * and read by this workgroup only); maximum, histogram and scatter all work on that one stable copy, so the
+ * histogram and the scatter agree and `order` is a permutation of 0..n-1 whatever is being stored meanwhile. */
+__global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsigned *__restrict__ snapshot,
+                                                      unsigned *__restrict__ order, int n,
+                                                      volatile unsigned *hostStats, int sort)
 {
     __shared__ unsigned bins[1024];
     __shared__ unsigned scan[1024];
@@ -547,11 +553,14 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict_
         for (int k = 0; k < BATCH; ++k)
         {
             const int i = base + k * 1024 + t;
-            c[k] = (i < n) ? cost[i] : 0u;
+            c[k] = (i < n) ? __builtin_nontemporal_load(&cost[i]) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k)
         {
+            const int i = base + k * 1024 + t;
+            if (sort && i < n)
+                snapshot[i] = c[k]; /* re-read below by the thread that wrote it */
             m = max(m, c[k]);
             sum += c[k];
         }
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict_
         for (int k = 0; k < BATCH; ++k)
         {
             const int i = base + k * 1024 + t;
-            c[k] = (i < n) ? cost[i] : 0u;
+            c[k] = (i < n) ? snapshot[i] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k)
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *__restrict_
         for (int k = 0; k < BATCH; ++k)
         {
             const int i = base + k * 1024 + t;
-            c[k] = (i < n) ? cost[i] : 0u;
+            c[k] = (i < n) ? snapshot[i] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k)
@@ -935,6 +944,17 @@ struct Engine
     std::vector<float4> hostBoxes, hostBoxesCompact, hostPrims, hostLights;
     std::vector<int> hostBoxStart, hostBoxStartCompact;
     std::vector<int> materialTags; /* PRIM_* bits per material id */
+    /* texture tables of the textured materials and the size of the uploaded atlas: checked against each other
+     * before the first frame that follows either upload (checkTextureTables) */
+    struct TextureUse
+    {
+        int material;
+        long texels;      /* bytes of the diffuse map: x * y * depth */
+        long offsets[7];  /* diffuse, normal, bump, specular, reflection, transparency, ambient occlusion; -1 unused */
+    };
+    std::vector<TextureUse> textureUses;
+    size_t atlasBytes = 0;
+    bool textureTablesChecked = false;
     std::vector<float> materialAverage; /* (r + g + b) / 3.f per material id (plane colour key, GI:561) */
     int sceneFeatures = F_ALL & ~F_FULL; /* rt_device.h enum Feature, recomputed with the tags */
     unsigned offBoxes = 0, offBoxesCompact = 0, offBoxStart = 0, offBoxStartCompact = 0, offPrims = 0, offLights = 0;
@@ -947,7 +967,7 @@ struct Engine
     long nbRandoms = 0;
 
     /* per-pixel buffers of the strip */
-    DeviceBuffer pp, ids, bitmap, counters, tileClock, tileCost, tileOrder;
+    DeviceBuffer pp, ids, bitmap, counters, tileClock, tileCost, tileCostSnapshot, tileOrder;
     /* Frames in flight (solr_hip_set_frames_in_flight): with n > 1, consecutive first-pass frames rotate
      * over n streams and n sets of per-pixel buffers, so that the tail of one frame - a few long waves
      * on an otherwise idle chip - overlaps the start of the next.  Set 0 is the members above. */
@@ -973,7 +993,7 @@ struct Engine
     int nbTilesTimed = 0;
     void *boundBitmap = nullptr;
     int width = 0, height = 0;       /* full image */
-    int firstRow = 0, nbRows = 0;    /* strip; nbRows == 0 -> full frame */
+    int firstRow = 0, nbRows = -1;   /* strip; nbRows < 0 -> full frame, 0 -> this process renders no row */
     int allocW = 0, allocRows = 0;
 
     /* timing */
@@ -1123,7 +1143,7 @@ inline float bitsf(int v)
 
 int stripRows()
 {
-    return g.nbRows > 0 ? g.nbRows : g.height;
+    return g.nbRows >= 0 ? g.nbRows : g.height;
 }
 
 void allocateFrame()
@@ -1426,6 +1446,33 @@ SceneArgs makeScene(bool exactNodes)
     return S;
 }
 
+/* The texel fetch (rt_device.h fetchTexel, skyboxMapping) indexes the atlas with textureOffset + index % texels
+ * and reads three bytes, for the diffuse map and, at the same index, for every secondary map of the
+ * material.  The reference reads whatever lies there when the tables and the atlas disagree; on this
+ * device that is a memory fault which ends the process's use of the GPU.  So the tables are checked against
+ * the atlas once after either was uploaded, and a frame with a material that points outside is refused. */
+void checkTextureTables()
+{
+    if (g.textureTablesChecked)
+        return;
+    g.textureTablesChecked = true;
+    for (const Engine::TextureUse &use : g.textureUses)
+    {
+        ARGCHECK(use.texels > 0, "cudaRender: a textured material with an empty or negative texture mapping");
+        ARGCHECK(g.textures.ptr != nullptr && g.atlasBytes > 0,
+                 "cudaRender: textured materials but no texture atlas was uploaded (h2d_textures)");
+        for (int t = 0; ok() && t < 7; ++t)
+            if (use.offsets[t] >= 0 || t == 0)
+                ARGCHECK(use.offsets[t] >= 0 && (size_t)(use.offsets[t] + use.texels + 2) <= g.atlasBytes,
+                         "cudaRender: a material's texture table points outside the uploaded atlas");
+        if (!ok())
+        {
+            g.textureTablesChecked = false; /* checked again once the caller has uploaded something else */
+            return;
+        }
+    }
+}
+
 void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProcessingInfo &ppInfo,
                 const float origin[3], const float direction[3], const float angles[4], bool counting,
                 unsigned long long counts[8])
@@ -1439,6 +1486,9 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     ARGCHECK(sceneInfo.skyboxMaterialId <= NB_MAX_MATERIALS, "cudaRender: skybox material beyond the material table");
     if (!ok())
         return;
+    checkTextureTables();
+    if (!ok())
+        return;
     HIPCHECK(hipSetDevice(g.device));
     if (sceneInfo.size.x != g.width || sceneInfo.size.y != g.height)
     {
@@ -1448,6 +1498,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     allocateFrame();
     if (!ok())
         return;
+    if (stripRows() == 0)
+        return; /* an empty strip (more processes than rows to share out): nothing to render */
     /* which stream / buffer set: first-pass frames alternate when two frames may be in flight; a
      * refinement or accumulation pass reads what the previous pass wrote and stays where that is */
     int flight = g.current;
@@ -1498,7 +1550,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     F.trig.sx = sinf(angles[0]);
     F.trig.sy = sinf(angles[1]);
     F.trig.sz = sinf(angles[2]);
-    F.firstRow = g.nbRows > 0 ? g.firstRow : 0;
+    F.firstRow = g.nbRows >= 0 ? g.firstRow : 0;
     F.nbRows = stripRows();
     F.tilesX = (sceneInfo.size.x + TILE - 1) / TILE;
     const int tilesY = (F.nbRows + TILE - 1) / TILE;
@@ -1556,9 +1608,15 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             g.costFrames = 0;
             g.reorder = false;
             g.orderValid = false;
-            reserve(g.tileCost, (size_t)grid.x * sizeof(unsigned));
-            reserve(g.tileOrder, (size_t)grid.x * sizeof(unsigned));
-            reserve(g.tileOrder2, (size_t)grid.x * sizeof(unsigned));
+            /* none of them is read before a sort has written it; a fresh allocation still gets a defined
+             * content (a buffer that is kept may be in use by a frame in flight and is left alone) */
+            for (DeviceBuffer *b : {&g.tileCost, &g.tileCostSnapshot, &g.tileOrder, &g.tileOrder2})
+            {
+                const void *before = b->ptr;
+                reserve(*b, (size_t)grid.x * sizeof(unsigned));
+                if (ok() && b->ptr != before)
+                    HIPCHECK(hipMemset(b->ptr, 0, b->bytes));
+            }
             g.orderBuffer = 0;
             for (bool &w : g.orderWait)
                 w = false;
@@ -1591,7 +1649,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             const int target = sort ? (g.orderBuffer ^ 1) : g.orderBuffer;
             DeviceBuffer &orderOut = target ? g.tileOrder2 : g.tileOrder;
             hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, stream, (const unsigned *)g.tileCost.ptr,
-                               (unsigned *)orderOut.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev,
+                               (unsigned *)g.tileCostSnapshot.ptr, (unsigned *)orderOut.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev,
                                sort ? 1 : 0);
             HIPCHECK(hipGetLastError());
             if (sort)
@@ -1820,8 +1878,8 @@ void solr_hip_synchronize(void)
 void solr_hip_set_strip(int firstRow, int nbRows)
 {
     quiesce();
-    g.firstRow = nbRows > 0 ? firstRow : 0;
-    g.nbRows = nbRows > 0 ? nbRows : 0;
+    g.firstRow = nbRows >= 0 ? firstRow : 0;
+    g.nbRows = nbRows >= 0 ? nbRows : -1;
     if (g.initialized && g.width > 0)
         allocateFrame();
 }
@@ -1897,7 +1955,7 @@ void finalize_scene(vec2i)
     collectEvents();
     DeviceBuffer *all[] = {&g.geometry, &g.materials, &g.textures, &g.randoms, &g.lamps,
                            &g.pp,       &g.ids,       &g.bitmap,   &g.counters, &g.tileClock,
-                           &g.tileCost, &g.tileOrder, &g.tileOrder2, &g.movable,  &g.refitPlan};
+                           &g.tileCost, &g.tileCostSnapshot, &g.tileOrder, &g.tileOrder2, &g.movable,  &g.refitPlan};
     for (DeviceBuffer *b : all)
         release(*b);
     for (int f = 0; f < MAX_FLIGHTS - 1; ++f)
@@ -2060,8 +2118,10 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start, std
             emit.siblings(children, 0, (int)children.size());
         outRows[2 * at + 1].w = bitsf((int)(outStart.size() - at));
     };
-    const int flatMax = getenv("SOLR_HIP_GROUP_FLAT") ? atoi(getenv("SOLR_HIP_GROUP_FLAT")) : 4;
-    const int levels = getenv("SOLR_HIP_GROUP_LEVELS") ? atoi(getenv("SOLR_HIP_GROUP_LEVELS")) : 2;
+    /* tuning knobs (tools/group_sweep.sh); parts[] / next[] below hold at most 2^4 parts */
+    const int flatMax = std::max(1, getenv("SOLR_HIP_GROUP_FLAT") ? atoi(getenv("SOLR_HIP_GROUP_FLAT")) : 4);
+    const int levels =
+        std::min(4, std::max(0, getenv("SOLR_HIP_GROUP_LEVELS") ? atoi(getenv("SOLR_HIP_GROUP_LEVELS")) : 2));
     emit.siblings = [&](const std::vector<int> &sib, int from, int to) {
         if (to - from <= flatMax)
         {
@@ -2423,6 +2483,8 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
     memset(cold.data(), 0, cold.size() * sizeof(MaterialCold));
     g.materialTags.assign(capacity, PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
     g.materialAverage.assign(capacity, 0.f);
+    g.textureUses.clear();
+    g.textureTablesChecked = false;
     for (int i = 0; i < nbActiveMaterials && i < capacity; ++i)
     {
         Material m = materials[i];
@@ -2433,6 +2495,23 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
         if (m.textureIds.x >= 0 && m.textureMapping.x == 40000 && m.textureMapping.y == 40000 && m.textureOffset.x == 0)
             m.textureIds.x = TEXTURE_NONE;
         g.materialTags[i] = materialTag(m);
+        /* the mappers fetch only for 0 <= u < mapping.x (rt_device.h): a mapping without columns - what
+         * realignTexturesAndMaterials gives a material whose texture nobody loaded - never reaches the atlas */
+        if (m.textureIds.x >= 0 && m.textureMapping.x > 0) /* procedural ids (Mandelbrot, Julia) are negative */
+        {
+            Engine::TextureUse use;
+            use.material = i;
+            use.texels = (long)m.textureMapping.x * (long)m.textureMapping.y * (long)m.textureMapping.w;
+            if (m.textureMapping.y <= 0 || m.textureMapping.w <= 0 || m.textureOffset.x < 0)
+                use.texels = 0; /* fetchTexel takes an index modulo this: refused by checkTextureTables */
+            const int ids[7] = {m.textureIds.x, m.textureIds.y, m.textureIds.z, m.textureIds.w,
+                                m.advancedTextureIds.x, m.advancedTextureIds.y, m.advancedTextureIds.z};
+            const int offs[7] = {m.textureOffset.x, m.textureOffset.y, m.textureOffset.z, m.textureOffset.w,
+                                 m.advancedTextureOffset.x, m.advancedTextureOffset.y, m.advancedTextureOffset.z};
+            for (int t = 0; t < 7; ++t)
+                use.offsets[t] = ids[t] != TEXTURE_NONE ? (long)offs[t] : -1L;
+            g.textureUses.push_back(use);
+        }
         g.materialAverage[i] = (m.color.x + m.color.y + m.color.z) / 3.f; /* same expression, same rounding */
         MaterialHot &h = hot[i];
         h.innerIllumination = make_float4(m.innerIllumination.x, m.innerIllumination.y, m.innerIllumination.z,
@@ -2489,6 +2568,15 @@ void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
     if (!ready("h2d_textures"))
         return;
     quiesce();
+    ARGCHECK(activeTextures >= 0 && (activeTextures == 0 || textureInfos), "h2d_textures: bad arguments");
+    for (int i = 0; ok() && i < activeTextures; ++i)
+        if (textureInfos[i].buffer)
+            ARGCHECK(textureInfos[i].offset >= 0 && textureInfos[i].size.x >= 0 && textureInfos[i].size.y >= 0 &&
+                         textureInfos[i].size.z >= 0 &&
+                         (double)textureInfos[i].size.x * textureInfos[i].size.y * textureInfos[i].size.z < 2147483648.0,
+                     "h2d_textures: a texture with a negative offset or size, or larger than 2 GB");
+    if (!ok())
+        return;
     size_t total = 0, largest = 0;
     for (int i = 0; i < activeTextures; ++i)
         if (textureInfos[i].buffer)
@@ -2512,6 +2600,8 @@ void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
         }
     HIPCHECK(hipSetDevice(g.device));
     upload(g.textures, atlas);
+    g.atlasBytes = ok() ? atlas.size() : 0;
+    g.textureTablesChecked = false;
 }
 
 void h2d_lightInformation(vec2i, LightInformation *lightInformation, int lightInformationSize)
@@ -2542,7 +2632,7 @@ void d2h_bitmap(vec2i, SceneInfo sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdB
         return;
     HIPCHECK(hipSetDevice(g.device));
     const int rows = stripRows();
-    const int first = g.nbRows > 0 ? g.firstRow : 0;
+    const int first = g.nbRows >= 0 ? g.firstRow : 0;
     const size_t pixels = (size_t)sceneInfo.size.x * rows;
     const size_t offset = (size_t)sceneInfo.size.x * first;
     /* the frame rendered last: its buffer set, on its stream */

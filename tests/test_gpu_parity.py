@@ -199,9 +199,99 @@ def test_row_strips_equal_the_full_frame(solr, oracle):
         assembled[first:first + count] = img[first:first + count]
         opp, oids, orgb, _, _ = oracle_frame(k, oracle, first_row=first, nb_rows=count)
         assert np.array_equal(img[first:first + count], orgb)
-    hip.solr_hip_set_strip(0, 0)
+    hip.solr_hip_set_strip(0, -1)
     k.finalize()
     assert np.array_equal(assembled, full)
+
+
+def test_an_empty_strip_renders_nothing(solr):
+    """more processes than rows to share out (strip_rows gives the trailing ranks no row): such a rank
+    must not render the whole frame into its strip-sized buffer"""
+    import ctypes as C
+    W, H = 64, 17
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=2)
+    full = k.render()
+    hip = solr.hip_lib()
+    try:
+        first, count, per = solr.strip_rows(7, 8, H)
+        assert count == 0 and per == 3
+        hip.solr_hip_set_strip(first, count)
+        guard = np.full((per + 2, W, 3), 0xAB, np.uint8)   # what a strip-sized send buffer of the gather holds
+        image = guard.copy()
+        si, ppi, eye, direction, angles = k.frame_parameters()
+        flat = k.flat_scene()
+        objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+        k.check(0, "empty strip")
+        # d2h places `count` rows at row `first` of a full-size image: nothing may be written
+        hip.solr_hip_d2h(C.byref(si), C.c_void_p(image.ctypes.data), None)
+        k.check(0, "empty strip read-back")
+        assert np.array_equal(image, guard)
+    finally:
+        hip.solr_hip_set_strip(0, -1)
+    again = k.render()
+    k.finalize()
+    assert np.array_equal(again, full)
+
+
+def test_frames_in_flight_with_a_moving_camera_render_every_tile(solr):
+    """The cost-ordered launch sorts the tiles while the frame on the other stream is still storing its
+    costs (k_orderTiles): the order must stay a permutation, or a tile is skipped and shows the picture of
+    two frames earlier.  Frames are issued back to back, no host synchronisation between them, with the
+    camera moving so that a stale tile differs; the last frames are compared with the same views rendered
+    in raster order one at a time."""
+    import ctypes as C
+    W, H = 512, 384     # 3072 tiles: the sort runs over several batches per thread
+    k = solr.Kernel(engine="hip")
+    X.primitives_mix(k)
+    solr.scenes.cornell(k, width=W, height=H, iterations=2)
+    k.render()
+    hip = solr.hip_lib()
+    flat = k.flat_scene()
+    si, ppi, eye, direction, angles = k.frame_parameters()
+    si.pathTracingIteration = 0
+    objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+
+    def view(i):
+        e = eye.copy()
+        e[0] += 90.0 * i
+        e[1] += 40.0 * (i % 7)
+        return e
+
+    def render(i):
+        e = view(i)
+        hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(e), fp(direction), fp(angles))
+
+    nb = 70   # the order is refreshed every sixteenth frame: several sorts overlap a running frame
+    try:
+        hip.solr_hip_set_tile_scheduling(0)
+        hip.solr_hip_set_frames_in_flight(1)
+        expected = {}
+        for i in (nb - 2, nb - 1):
+            render(i)
+            expected[i] = device_frame(solr, si)
+        for flights in (2, 3):
+            hip.solr_hip_set_tile_scheduling(2)     # cost order forced
+            hip.solr_hip_set_frames_in_flight(flights)
+            for i in range(nb - 1):
+                render(i)
+            # frame nb-2 is the newest on its buffer set: read it, then issue the last one
+            k.check(0, "frames in flight")
+            pp, ids, rgb = device_frame(solr, si)
+            assert np.array_equal(ids, expected[nb - 2][1]), flights
+            assert np.array_equal(pp.view(np.uint32), expected[nb - 2][0].view(np.uint32)), flights
+            render(nb - 1)
+            pp, ids, rgb = device_frame(solr, si)
+            assert np.array_equal(rgb, expected[nb - 1][2]), flights
+            assert np.array_equal(ids, expected[nb - 1][1]), flights
+            assert np.array_equal(pp.view(np.uint32), expected[nb - 1][0].view(np.uint32)), flights
+    finally:
+        hip.solr_hip_set_tile_scheduling(1)
+        hip.solr_hip_set_frames_in_flight(1)
+        k.finalize()
 
 
 def test_ray_census_matches_the_oracle(solr, oracle):
@@ -383,7 +473,7 @@ def test_post_processing_and_strips_with_two_frames_in_flight(solr, oracle):
             hip.solr_hip_d2h_postprocessing(C.c_void_p(spp.ctypes.data))
             assert np.array_equal(spp.view(np.uint32), pp0[16:48].view(np.uint32)), i
     finally:
-        hip.solr_hip_set_strip(0, 0)
+        hip.solr_hip_set_strip(0, -1)
         hip.solr_hip_set_frames_in_flight(1)
         k.finalize()
 
@@ -434,6 +524,44 @@ def test_a_texture_id_that_was_never_loaded_does_not_fault(solr):
     assert (first[1][..., 0] >= 0).mean() > 0.2
     assert np.array_equal(first[0].view(np.uint32), second[0].view(np.uint32))
     k.finalize()
+
+
+def test_texture_tables_that_point_outside_the_atlas_are_refused(solr):
+    """fetchTexel indexes the atlas with textureOffset + texel index, unchecked (as the reference does, which
+    reads whatever is there): an offset beyond the uploaded atlas, or a textured material with no atlas at all,
+    must end in an error the caller can read, not in a GPU memory fault."""
+    import ctypes as C
+    k = solr.Kernel(engine="hip")
+    X.textured(k, width=64, height=48, skybox=False)
+    good = k.render()
+    k.check(0, "textured frame")
+    hip = solr.hip_lib()
+    flat = k.flat_scene()
+    si, ppi, eye, direction, angles = k.frame_parameters()
+    objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    occ = 1 | (1 << 32)   # vec2i {1, 1} by value
+    mats = np.array(flat.materials, copy=True)
+    textured = [i for i in range(len(mats)) if mats["textureIds"][i][0] >= 0 and mats["textureMapping"][i][0] > 0]
+    assert textured, "the scene has no textured material"
+    bad = mats.copy()
+    bad["textureOffset"][textured[0]][0] = 1 << 30
+    try:
+        hip.h2d_materials(occ, C.c_void_p(bad.ctypes.data), len(bad))
+        hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+        text = C.create_string_buffer(512)
+        assert hip.solr_hip_last_error(text, 512) != 0
+        assert b"outside the uploaded atlas" in text.value, text.value
+        hip.solr_hip_clear_error()
+        # the tables as they were: renders again, same picture
+        hip.h2d_materials(occ, C.c_void_p(mats.ctypes.data), len(mats))
+        hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+        assert hip.solr_hip_last_error(None, 0) == 0
+        pp, ids, rgb = device_frame(solr, si)
+        assert np.array_equal(rgb, good)
+    finally:
+        hip.solr_hip_clear_error()
+        k.finalize()
 
 
 def _stereo_scene(k, **info):

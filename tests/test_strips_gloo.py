@@ -39,10 +39,11 @@ def _worker(rank, world, port, width, height, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("height", [48, 45])   # 45: the last strip is one row shorter
-def test_two_strips_equal_the_full_frame(solr, oracle, tmp_path, height):
+# 45: the last strip is one row shorter; (4, 3): strips of 2 rows leave the third process without a row
+@pytest.mark.parametrize("height,world", [(48, 2), (45, 2), (4, 3)])
+def test_strips_equal_the_full_frame(solr, oracle, tmp_path, height, world):
     import torch.multiprocessing as mp
-    width, world = 64, 2
+    width = 64
     out = str(tmp_path / "gathered.npz")
     port = 29500 + (os.getpid() % 2000) + height
     mp.spawn(_worker, args=(world, port, width, height, out), nprocs=world, join=True)

@@ -163,7 +163,7 @@ if __name__ == "__main__":
                 if not np.array_equal(img[row0:row0 + rows], o[2]):
                     ok = False
                     res = dict(res, after="strip %d of %d differs from the oracle's" % (rank, world))
-            hip.solr_hip_set_strip(0, 0)
+            hip.solr_hip_set_strip(0, -1)
             if ok and not np.array_equal(assembled, full):
                 ok = False
                 res = dict(res, after="%d strips do not add up to the full frame" % world)
