@@ -320,3 +320,129 @@ done:
     free(cl);
     return status;
 }
+
+/* ---- generic launcher for the probe kernels of oracle/ref_probes.cl (and for the reference's own
+ * post-processing kernels): one kernel of a code object over a 1-D or 2-D range with a list of
+ * arguments - a value passed as it is, or a buffer that is uploaded before and/or read back after. */
+typedef struct
+{
+    int kind;     /* 0 value, 1 buffer in, 2 buffer out (starts zeroed), 3 buffer in/out */
+    void *data;   /* value bytes or host buffer */
+    size_t bytes;
+} RefArg;
+
+int solr_ref_opencl_run(const char *codeObjectPath, const char *kernelName, int nbArgs, RefArg *args, int dims,
+                        const size_t *global, const size_t *local, char *log, int logCapacity)
+{
+    int status = 0;
+    cl_platform_id platforms[8];
+    cl_uint nbPlatforms = 0;
+    cl_device_id device = NULL;
+    cl_context ctx = NULL;
+    cl_command_queue queue = NULL;
+    cl_program program = NULL;
+    cl_kernel kernel = NULL;
+    cl_mem *buffers = NULL;
+    unsigned char *binary = NULL;
+    cl_int err = 0;
+
+    FILE *f = fopen(codeObjectPath, "rb");
+    if (!f)
+        FAIL(-3, "cannot open %s (run `make -C oracle ref` where /root/reference exists)", codeObjectPath);
+    fseek(f, 0, SEEK_END);
+    size_t binarySize = (size_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    binary = (unsigned char *)malloc(binarySize);
+    if (!binary || fread(binary, 1, binarySize, f) != binarySize)
+    {
+        fclose(f);
+        FAIL(-3, "cannot read %s", codeObjectPath);
+    }
+    fclose(f);
+    buffers = (cl_mem *)calloc((size_t)(nbArgs > 0 ? nbArgs : 1), sizeof(cl_mem));
+    if (!buffers)
+        FAIL(-5, "out of memory");
+
+    CHECK(clGetPlatformIDs(8, platforms, &nbPlatforms), "clGetPlatformIDs");
+    for (cl_uint p = 0; p < nbPlatforms && !device; ++p)
+    {
+        cl_uint n = 0;
+        if (clGetDeviceIDs(platforms[p], CL_DEVICE_TYPE_GPU, 1, &device, &n) != CL_SUCCESS || n == 0)
+            device = NULL;
+    }
+    if (!device)
+        FAIL(-4, "no OpenCL GPU device");
+    ctx = clCreateContext(NULL, 1, &device, NULL, NULL, &err);
+    CHECK(err, "clCreateContext");
+    queue = clCreateCommandQueue(ctx, device, 0, &err);
+    CHECK(err, "clCreateCommandQueue");
+    {
+        const unsigned char *bins[1] = {binary};
+        cl_int binStatus = 0;
+        program = clCreateProgramWithBinary(ctx, 1, &device, &binarySize, bins, &binStatus, &err);
+        CHECK(err, "clCreateProgramWithBinary");
+        err = clBuildProgram(program, 1, &device, "", NULL, NULL);
+        if (err != CL_SUCCESS)
+        {
+            char buildLog[2048] = "";
+            clGetProgramBuildInfo(program, device, CL_PROGRAM_BUILD_LOG, sizeof(buildLog) - 1, buildLog, NULL);
+            FAIL(err, "clBuildProgram failed: %d: %.1800s", (int)err, buildLog);
+        }
+    }
+    kernel = clCreateKernel(program, kernelName, &err);
+    if (err != CL_SUCCESS)
+        FAIL(err, "clCreateKernel(%s) failed: %d", kernelName, (int)err);
+    for (int a = 0; a < nbArgs; ++a)
+    {
+        if (args[a].kind == 0)
+        {
+            err = clSetKernelArg(kernel, (cl_uint)a, args[a].bytes, args[a].data);
+            if (err != CL_SUCCESS)
+                FAIL(err, "clSetKernelArg(%s, %d, value of %zu bytes) failed: %d", kernelName, a, args[a].bytes, (int)err);
+            continue;
+        }
+        const size_t bytes = args[a].bytes > 0 ? args[a].bytes : 16;
+        buffers[a] = clCreateBuffer(ctx, CL_MEM_READ_WRITE, bytes, NULL, &err);
+        if (err != CL_SUCCESS)
+            FAIL(err, "clCreateBuffer(arg %d, %zu bytes) failed: %d", a, bytes, (int)err);
+        if (args[a].kind == 2 || args[a].bytes == 0)
+        {
+            void *zero = calloc(bytes, 1);
+            if (!zero)
+                FAIL(-5, "out of memory");
+            err = clEnqueueWriteBuffer(queue, buffers[a], CL_TRUE, 0, bytes, zero, 0, NULL, NULL);
+            free(zero);
+        }
+        else
+            err = clEnqueueWriteBuffer(queue, buffers[a], CL_TRUE, 0, args[a].bytes, args[a].data, 0, NULL, NULL);
+        if (err != CL_SUCCESS)
+            FAIL(err, "clEnqueueWriteBuffer(arg %d) failed: %d", a, (int)err);
+        err = clSetKernelArg(kernel, (cl_uint)a, sizeof(cl_mem), &buffers[a]);
+        if (err != CL_SUCCESS)
+            FAIL(err, "clSetKernelArg(%s, %d, buffer) failed: %d", kernelName, a, (int)err);
+    }
+    err = clEnqueueNDRangeKernel(queue, kernel, (cl_uint)dims, NULL, global, local, 0, NULL, NULL);
+    if (err != CL_SUCCESS)
+        FAIL(err, "clEnqueueNDRangeKernel(%s) failed: %d", kernelName, (int)err);
+    CHECK(clFinish(queue), "clFinish");
+    for (int a = 0; a < nbArgs; ++a)
+        if ((args[a].kind == 2 || args[a].kind == 3) && args[a].bytes > 0)
+        {
+            err = clEnqueueReadBuffer(queue, buffers[a], CL_TRUE, 0, args[a].bytes, args[a].data, 0, NULL, NULL);
+            if (err != CL_SUCCESS)
+                FAIL(err, "clEnqueueReadBuffer(arg %d) failed: %d", a, (int)err);
+        }
+
+done:
+    if (buffers)
+        for (int a = 0; a < nbArgs; ++a)
+            if (buffers[a])
+                clReleaseMemObject(buffers[a]);
+    free(buffers);
+    if (kernel) clReleaseKernel(kernel);
+    if (program) clReleaseProgram(program);
+    if (queue) clReleaseCommandQueue(queue);
+    if (ctx) clReleaseContext(ctx);
+    free(binary);
+    return status;
+}

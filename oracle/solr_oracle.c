@@ -31,6 +31,7 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
 
 /* The specular power.  powf is only specified to an error bound: glibc's is within 1 ULP but not always
  * the correctly rounded value, CUDA's within 2 ULP; the engine evaluates it in binary64 and rounds once.
@@ -61,7 +62,27 @@ static float specularPower(float base, float exponent)
     }
     return correctlyRoundedPow ? (float)pow((double)base, (double)exponent) : powf(base, exponent);
 }
-#endif
+
+/* ---- dialect ------------------------------------------------------------------------------------
+ * The reference keeps the same per-pixel path twice: the CUDA engine, which this file restates and the
+ * product matches (dialect 0, the default), and an older sibling, the OpenCL engine
+ * (solr/engines/opencl/RayTracer.cl, "CL" below), which is the only form of the path that can be BUILT
+ * in this image and therefore the only source of reference-produced outputs (oracle/_ref, oracle/ref_probes.cl).
+ * The two have drifted apart in a few dozen statements.  oracle_set_dialect(1) switches exactly those
+ * statements to the OpenCL engine's form - every switch is an `if (g_cl)` next to the CUDA form, citing both
+ * files - so that the restatement can be compared with the reference's own functions BIT FOR BIT
+ * (tests/test_reference_probes.py).  Everything not under such a switch is shared by both dialects and is
+ * thereby pinned to reference output; what a switch selects in dialect 0 is the cited CUDA statement.
+ * Test infrastructure only; never set by the parity tests of the product. */
+static int g_cl = 0;
+void oracle_set_dialect(int openclEngine)
+{
+    g_cl = openclEngine ? 1 : 0;
+}
+int oracle_get_dialect(void)
+{
+    return g_cl;
+}
 
 typedef vec3f v3;
 
@@ -216,9 +237,10 @@ static inline float rnd(const OracleScene *s, long i, Stats *st)
 /* ref GI:36-44 */
 static inline void computeRayAttributes(Ray *ray)
 {
-    ray->inv_direction.x = ray->direction.x != 0.f ? 1.f / ray->direction.x : 1.f;
-    ray->inv_direction.y = ray->direction.y != 0.f ? 1.f / ray->direction.y : 1.f;
-    ray->inv_direction.z = ray->direction.z != 0.f ? 1.f / ray->direction.z : 1.f;
+    const float zero = g_cl ? 0.f : 1.f; /* CL:365-367 gives a zero component 0.f, GI:39-41 1.f */
+    ray->inv_direction.x = ray->direction.x != 0.f ? 1.f / ray->direction.x : zero;
+    ray->inv_direction.y = ray->direction.y != 0.f ? 1.f / ray->direction.y : zero;
+    ray->inv_direction.z = ray->direction.z != 0.f ? 1.f / ray->direction.z : zero;
     ray->sx = (ray->inv_direction.x < 0);
     ray->sy = (ray->inv_direction.y < 0);
     ray->sz = (ray->inv_direction.z < 0);
@@ -273,7 +295,8 @@ static inline void normalMap(int index, const Material *m, const BitmapBuffer *t
     BitmapBuffer r = tex[i], g = tex[i + 1];
     normal->x -= strength * (r / 256.f - 0.5f);
     normal->y -= strength * (g / 256.f - 0.5f);
-    normal->z = 0.f;
+    if (!g_cl) /* TM:39; CL:505-514 leaves z alone */
+        normal->z = 0.f;
 }
 /* ref TM:45-57 */
 static inline void bumpMap(int index, const Material *m, const BitmapBuffer *tex, float *value)
@@ -287,6 +310,11 @@ static inline void specularMap(int index, const Material *m, const BitmapBuffer 
 {
     int i = m->textureOffset.w + index;
     BitmapBuffer r = tex[i], g = tex[i + 1], b = tex[i + 2];
+    if (g_cl) /* CL:533-541 scales the specular value by the texel's brightness */
+    {
+        specular->x *= (r + g + b) / 768.f;
+        return;
+    }
     specular->x = r / 256.f;
     specular->y = 1000.f * g / 256.f;
     specular->z = b / 256.f;
@@ -380,7 +408,7 @@ static inline f4 colorOf(const Material *m)
 
 /* common tail of the three mappers (TM:238-279, 311-343, 410-441) */
 static inline void fetchTexel(const Material *material, const BitmapBuffer *textures, int u, int v, f4 *result,
-                              v3 *normal, f4 *specular, f4 *attributes, f4 *advancedAttributes)
+                              v3 *normal, f4 *specular, f4 *attributes, f4 *advancedAttributes, int triangleMapper)
 {
     int A = (v * material->textureMapping.x + u) * material->textureMapping.w;
     int B = material->textureMapping.x * material->textureMapping.y * material->textureMapping.w;
@@ -392,7 +420,11 @@ static inline void fetchTexel(const Material *material, const BitmapBuffer *text
     result->z = b / 256.f;
     float strength = 3.f;
     if (material->textureIds.z != TEXTURE_NONE)
+    {
         bumpMap(index, material, textures, &strength);
+        if (g_cl && triangleMapper) /* CL:815-819: the triangle mapper also scales the opacity; TM:260-264 does not */
+            attributes->w *= strength / 10.f;
+    }
     if (material->textureIds.y != TEXTURE_NONE)
         normalMap(index, material, textures, normal, strength);
     if (material->textureIds.w != TEXTURE_NONE)
@@ -436,7 +468,7 @@ static f4 triangleUVMapping(const SceneInfo *si, const Primitive *primitive, con
             juliaSet(material, si, (float)u, (float)v, &result);
             break;
         default:
-            fetchTexel(material, textures, u, v, &result, normal, specular, attributes, advancedAttributes);
+            fetchTexel(material, textures, u, v, &result, normal, specular, attributes, advancedAttributes, 1);
         }
     }
     return result;
@@ -458,7 +490,7 @@ static f4 sphereUVMapping(const Primitive *primitive, const Material *materials,
     if (material->textureMapping.y != 0)
         v = v % material->textureMapping.y;
     if (u >= 0 && u < material->textureMapping.x && v >= 0 && v < material->textureMapping.y)
-        fetchTexel(material, textures, u, v, &result, normal, specular, attributes, advancedAttributes);
+        fetchTexel(material, textures, u, v, &result, normal, specular, attributes, advancedAttributes, 0);
     return result;
 }
 
@@ -492,7 +524,7 @@ static f4 cubeMapping(const SceneInfo *si, const Primitive *primitive, const Mat
             juliaSet(material, si, (float)u, (float)v, &result);
             break;
         default:
-            fetchTexel(material, textures, u, v, &result, normal, specular, attributes, advancedAttributes);
+            fetchTexel(material, textures, u, v, &result, normal, specular, attributes, advancedAttributes, 0);
         }
     }
     return result;
@@ -710,7 +742,17 @@ static int cylinderIntersection(const SceneInfo *si, const Primitive *cyl, const
                     fabsf(intersection->V_ - primitive->p0.V_) < primitive->size.V_;                             \
     } while (0)
 
-/* ref GI:424-567 */
+/* ref GI:424-567.  OpenCL dialect (CL:1151-1305): the normal is written as the axis vector inside the branch
+ * that is taken instead of being copied from primitive.n0; no wireframe and no "chessboard light" masks;
+ * ptCamera has a front side only. */
+#define PLANE_NORMAL(NX, NY, NZ, SIGN)                                                                           \
+    do                                                                                                           \
+    {                                                                                                            \
+        if (g_cl)                                                                                                \
+            *normal = V((SIGN) * (NX), (SIGN) * (NY), (SIGN) * (NZ));                                            \
+        else if ((SIGN) < 0.f)                                                                                   \
+            *normal = vneg(*normal);                                                                             \
+    } while (0)
 static int planeIntersection(const SceneInfo *si, const Primitive *primitive, const Material *materials,
                              const BitmapBuffer *textures, const Ray *ray, v3 *intersection, v3 *normal,
                              float *shadowIntensity, int reverse)
@@ -718,7 +760,9 @@ static int planeIntersection(const SceneInfo *si, const Primitive *primitive, co
     int collision = 0;
     float reverted = reverse ? -1.f : 1.f;
     const Material *mat = &materials[primitive->materialId];
-    *normal = primitive->n0;
+    const int masks = !g_cl; /* GI:447-449, 463-471 ... : wireframe / chessboard-light masks, absent from CL */
+    if (!g_cl)
+        *normal = primitive->n0;
     switch (primitive->type)
     {
     case ptMagicCarpet:
@@ -728,6 +772,7 @@ static int planeIntersection(const SceneInfo *si, const Primitive *primitive, co
         float y = ray->origin.y - primitive->p0.y;
         if (reverted * ray->direction.y < 0.f && reverted * ray->origin.y > reverted * primitive->p0.y)
         {
+            PLANE_NORMAL(0.f, 1.f, 0.f, 1.f);
             intersection->x = ray->origin.x + y * ray->direction.x / -ray->direction.y;
             intersection->z = ray->origin.z + y * ray->direction.z / -ray->direction.y;
             collision = fabsf(intersection->x - primitive->p0.x) < primitive->size.x &&
@@ -739,15 +784,16 @@ static int planeIntersection(const SceneInfo *si, const Primitive *primitive, co
     {
         if (reverted * ray->direction.y < 0.f && reverted * ray->origin.y > reverted * primitive->p0.y)
         {
+            PLANE_NORMAL(0.f, 1.f, 0.f, 1.f);
             PLANE_HIT(x, z, y);
-            if (mat->attributes.z == 2)
+            if (masks && mat->attributes.z == 2)
                 collision &= wireFrameMapping(intersection->x, intersection->z, mat->attributes.w);
         }
         if (!collision && reverted * ray->direction.y > 0.f && reverted * ray->origin.y < reverted * primitive->p0.y)
         {
-            *normal = vneg(*normal);
+            PLANE_NORMAL(0.f, 1.f, 0.f, -1.f);
             PLANE_HIT(x, z, y);
-            if (mat->attributes.z == 2)
+            if (masks && mat->attributes.z == 2)
                 collision &= wireFrameMapping(intersection->x, intersection->z, mat->attributes.w);
         }
         break;
@@ -756,19 +802,20 @@ static int planeIntersection(const SceneInfo *si, const Primitive *primitive, co
     {
         if (reverted * ray->direction.x < 0.f && reverted * ray->origin.x > reverted * primitive->p0.x)
         {
+            PLANE_NORMAL(1.f, 0.f, 0.f, 1.f);
             PLANE_HIT(y, z, x);
-            if (mat->innerIllumination.x != 0.f)
+            if (masks && mat->innerIllumination.x != 0.f)
                 collision &= f2i(fabsf(intersection->z)) % 4000 < 2000 && f2i(fabsf(intersection->y)) % 4000 < 2000;
-            if (mat->attributes.z == 2)
+            if (masks && mat->attributes.z == 2)
                 collision &= wireFrameMapping(intersection->y, intersection->z, mat->attributes.w);
         }
         if (!collision && reverted * ray->direction.x > 0.f && reverted * ray->origin.x < reverted * primitive->p0.x)
         {
-            *normal = vneg(*normal);
+            PLANE_NORMAL(1.f, 0.f, 0.f, -1.f);
             PLANE_HIT(y, z, x);
-            if (mat->innerIllumination.x != 0.f)
+            if (masks && mat->innerIllumination.x != 0.f)
                 collision &= f2i(fabsf(intersection->z)) % 4000 < 2000 && f2i(fabsf(intersection->y)) % 4000 < 2000;
-            if (mat->attributes.z == 2)
+            if (masks && mat->attributes.z == 2)
                 collision &= wireFrameMapping(intersection->y, intersection->z, mat->attributes.w);
         }
         break;
@@ -778,15 +825,17 @@ static int planeIntersection(const SceneInfo *si, const Primitive *primitive, co
     {
         if (reverted * ray->direction.z < 0.f && reverted * ray->origin.z > reverted * primitive->p0.z)
         {
+            PLANE_NORMAL(0.f, 0.f, 1.f, 1.f);
             PLANE_HIT(x, y, z);
-            if (mat->attributes.z == 2)
+            if (masks && mat->attributes.z == 2)
                 collision &= wireFrameMapping(intersection->x, intersection->y, mat->attributes.w);
         }
-        if (!collision && reverted * ray->direction.z > 0.f && reverted * ray->origin.z < reverted * primitive->p0.z)
+        if (!(g_cl && primitive->type == ptCamera) /* CL:1266-1281 */ && !collision &&
+            reverted * ray->direction.z > 0.f && reverted * ray->origin.z < reverted * primitive->p0.z)
         {
-            *normal = vneg(*normal);
+            PLANE_NORMAL(0.f, 0.f, 1.f, -1.f);
             PLANE_HIT(x, y, z);
-            if (mat->attributes.z == 2)
+            if (masks && mat->attributes.z == 2)
                 collision &= wireFrameMapping(intersection->x, intersection->y, mat->attributes.w);
         }
         break;
@@ -860,14 +909,29 @@ static int triangleIntersection(const SceneInfo *si, const Primitive *tri, const
     areas->x = 0.5f * vlength(crossProduct(v1, v2));
     areas->y = 0.5f * vlength(crossProduct(v0, v2));
     areas->z = 0.5f * vlength(crossProduct(v0, v1));
+    if (g_cl) /* CL:1374 normalises the areas; GI:626-628 keeps them */
+        *areas = vnormalize(*areas);
     v3 wn = vadd(vadd(vscale(tri->n0, areas->x), vscale(tri->n1, areas->y)), vscale(tri->n2, areas->z));
-    *normal = vnormalize(vdivs(wn, areas->x + areas->y + areas->z));
+    *normal = vdivs(wn, areas->x + areas->y + areas->z);
+    if (!g_cl) /* GI:630-631 normalises the interpolated normal; CL:1376-1377 does not */
+        *normal = vnormalize(*normal);
     if (si->doubleSidedTriangles)
     {
-        /* GI:643-647: the else binds to the inner if */
         v3 N = vnormalize(ray->direction);
-        if (processingShadows)
+        if (g_cl)
         {
+            /* CL:1379-1394: shadow rays keep the faces turned away from the lamp, view rays those turned to the eye */
+            if (processingShadows)
+            {
+                if (vdot(N, *normal) <= 0.f)
+                    return 0;
+            }
+            else if (vdot(N, *normal) >= 0.f)
+                return 0;
+        }
+        else if (processingShadows)
+        {
+            /* GI:643-647: the else binds to the inner if */
             if (vdot(N, *normal) <= 0.f)
                 return 0;
             else if (vdot(N, *normal) >= 0.f)
@@ -894,8 +958,12 @@ static inline int testPrimitive(const SceneInfo *si, const Primitive *primitive,
         case ptEnvironment:
         case ptSphere:
             return sphereIntersection(si, primitive, materials, r, intersection, normal, shadowIntensity);
-        case ptCylinder:
         case ptCone:
+            if (g_cl) /* CL:1846-1869 has no cone: the type falls through to the plane test, which ignores it */
+                return planeIntersection(si, primitive, materials, textures, r, intersection, normal, shadowIntensity,
+                                         0);
+            /* fall through */
+        case ptCylinder:
             return cylinderIntersection(si, primitive, r, intersection, normal, shadowIntensity);
         case ptEllipsoid:
             return ellipsoidIntersection(si, primitive, r, intersection, normal, shadowIntensity);
@@ -922,8 +990,12 @@ static inline int testPrimitiveShadow(const SceneInfo *si, const Primitive *prim
             return sphereIntersection(si, primitive, materials, r, intersection, normal, shadowIntensity);
         case ptEllipsoid:
             return ellipsoidIntersection(si, primitive, r, intersection, normal, shadowIntensity);
-        case ptCylinder:
         case ptCone:
+            if (g_cl) /* CL:1544-1569: no cone */
+                return planeIntersection(si, primitive, materials, textures, r, intersection, normal, shadowIntensity,
+                                         0);
+            /* fall through */
+        case ptCylinder:
             return cylinderIntersection(si, primitive, r, intersection, normal, shadowIntensity);
         case ptTriangle:
             return triangleIntersection(si, primitive, r, intersection, normal, areas, shadowIntensity, 1);
@@ -993,9 +1065,10 @@ static int intersectionWithPrimitives(const OracleScene *s, const SceneInfo *si,
             {
                 /* GI:695: NB_MAX_MATERIALS is unsigned in the reference */
                 const Material *m = &s->materials[(unsigned)box->startIndex % (unsigned)NB_MAX_MATERIALS];
-                colorBox->x += m->color.x / 200.f;
-                colorBox->y += m->color.y / 200.f;
-                colorBox->z += m->color.z / 200.f;
+                const float share = g_cl ? 50.f : 200.f; /* GI:695; CL:1894 */
+                colorBox->x += m->color.x / share;
+                colorBox->y += m->color.y / share;
+                colorBox->z += m->color.z / share;
             }
             else
             {
@@ -1080,7 +1153,8 @@ static float processShadows(const OracleScene *s, const SceneInfo *si, v3 lampCe
     {
         const BoundingBox *box = &s->boxes[cptBoxes];
         st->boxes++;
-        if (boxIntersection(box, &r, 0.f, minDistance))
+        /* GI:817 tests the node against [0, minDistance]; CL:1528 against [0.05, minDistance] */
+        if (boxIntersection(box, &r, g_cl ? 0.05f : 0.f, minDistance))
         {
             int cptPrimitives = 0;
             while (result < si->shadowIntensity && cptPrimitives < box->nbPrimitives)
@@ -1091,7 +1165,9 @@ static float processShadows(const OracleScene *s, const SceneInfo *si, v3 lampCe
                 float shadowIntensity = 0.f;
                 const Primitive *primitive = &s->primitives[box->startIndex + cptPrimitives];
                 const Material *pm = &s->materials[primitive->materialId];
-                if (primitive->index != lightId && primitive->index != objectId && pm->attributes.x == 0)
+                /* GI:829 leaves out the lamp and the shaded primitive; CL:1539 only what its caller passes as
+                 * objectId, which is the lamp's primitive (CL:1709-1711) */
+                if (primitive->index != lightId && (g_cl || primitive->index != objectId) && pm->attributes.x == 0)
                 {
                     st->prims++;
                     int hit = testPrimitiveShadow(si, primitive, s->materials, s->textures, &r, &intersection,
@@ -1108,7 +1184,10 @@ static float processShadows(const OracleScene *s, const SceneInfo *si, v3 lampCe
                             {
                                 O_L = vnormalize(O_L);
                                 float a = fabsf(vdot(O_L, normal));
-                                float rr = (pm->transparency == 0.f) ? 1.f : (1.f - pm->transparency);
+                                /* GI:885-886; CL:1589-1591 lets 20 % more through */
+                                float rr = (pm->transparency == 0.f)
+                                               ? 1.f
+                                               : (g_cl ? (1.f - 0.8f * pm->transparency) : (1.f - pm->transparency));
                                 ratio *= rr * a;
                                 color->x += ratio * (0.3f - 0.3f * pm->color.x);
                                 color->y += ratio * (0.3f - 0.3f * pm->color.y);
@@ -1157,6 +1236,9 @@ static f4 intersectionShader(const SceneInfo *si, const Primitive *primitive, co
         switch (primitive->type)
         {
         case ptCone:
+            if (g_cl) /* CL:1422-1487: no cone */
+                break;
+            /* fall through */
         case ptCylinder:
         case ptEnvironment:
         case ptSphere:
@@ -1243,7 +1325,13 @@ static c3 primitiveShader(const OracleScene *s, int index, const SceneInfo *si, 
     *normal = vadd(*normal, bumpNormal);
     *normal = vnormalize(*normal);
 
-    if (material->attributes.z == 1)
+    if (g_cl)
+    {
+        /* CL:1652-1659: unshaded frames, emissive and any wireframe material return the texel */
+        if (si->graphicsLevel == glNoShading || material->innerIllumination.x != 0.f || material->attributes.z != 0)
+            return intersectionColor;
+    }
+    else if (material->attributes.z == 1)
         return intersectionColor; /* wireframe: constant colour */
 
     if (si->graphicsLevel > glNoShading)
@@ -1251,7 +1339,8 @@ static c3 primitiveShader(const OracleScene *s, int index, const SceneInfo *si, 
         closestColor->x *= material->innerIllumination.x;
         closestColor->y *= material->innerIllumination.x;
         closestColor->z *= material->innerIllumination.x;
-        for (int cpt = 0; cpt < s->nbLights; ++cpt)
+        /* GI:956: once per entry of the light list; CL:1664-1665: once */
+        for (int cpt = 0; cpt < (g_cl ? 1 : s->nbLights); ++cpt)
         {
             /* GI:958-960: lamp 0 is applied nbLights times below iteration 10 */
             int cptLamp = (si->pathTracingIteration >= NB_MAX_ITERATIONS) ? (si->pathTracingIteration % s->nbLights) : 0;
@@ -1261,7 +1350,9 @@ static c3 primitiveShader(const OracleScene *s, int index, const SceneInfo *si, 
                 v3 center = li->location;
                 int t = (index + si->timestamp) % (MAX_BITMAP_SIZE - 3);
                 const Material *m = &s->materials[li->materialId];
-                if (si->pathTracingIteration >= NB_MAX_ITERATIONS)
+                /* CL:1678-1682 jitters only lamps that are primitives of the scene */
+                if (si->pathTracingIteration >= NB_MAX_ITERATIONS &&
+                    (!g_cl || (li->primitiveId >= 0 && li->primitiveId < s->nbPrimitives)))
                 {
                     float a = m->innerIllumination.y * 10.f * si->pathTracingIteration / si->maxPathTracingIterations;
                     center.x += rnd(s, t, st) * a;
@@ -1274,7 +1365,9 @@ static c3 primitiveShader(const OracleScene *s, int index, const SceneInfo *si, 
                 {
                     c3 shadowColor = {0.f, 0.f, 0.f};
                     lightRay = vnormalize(lightRay);
-                    float lambert = material->innerIllumination.x + vdot(*normal, lightRay);
+                    /* GI:985; CL:1701 has the bare cosine */
+                    float lambert = g_cl ? vdot(*normal, lightRay)
+                                         : material->innerIllumination.x + vdot(*normal, lightRay);
                     if (lambert > 0.f && si->graphicsLevel > 3 && iteration < 4 && material->innerIllumination.x == 0.f)
                         *shadowIntensity = processShadows(s, si, center, intersection, li->primitiveId, iteration,
                                                           &shadowColor, objectId, st);
@@ -1342,14 +1435,15 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
     v3 closestIntersection = {0.f, 0.f, 0.f};
     v3 firstIntersection = {0.f, 0.f, 0.f};
     v3 normal = {0.f, 0.f, 0.f};
-    int closestPrimitive = -1;
+    int closestPrimitive = g_cl ? 0 : -1; /* CRT:76; CL:2117 */
     int carryon = 1;
     Ray rayOrigin = *ray;
     float initialRefraction = 1.f;
     int iteration = 0;
     primitiveXYId->x = -1;
     primitiveXYId->z = 0;
-    primitiveXYId->w = 0;
+    if (!g_cl) /* CRT:83; CL:2122-2123 leaves w as the caller's buffer holds it */
+        primitiveXYId->w = 0;
     int currentMaterialId = -2;
 
     float colorContributions[NB_MAX_ITERATIONS + 1];
@@ -1408,9 +1502,10 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
                 colorContributions[iteration] = 1.f;
                 firstIntersection = closestIntersection;
                 latestIntersection = closestIntersection;
-                *depthOfField = vlength(vsub(firstIntersection, ray->origin));
+                if (!g_cl) /* CRT:139; CL:2411-2412 takes the length after the loop, hit or not */
+                    *depthOfField = vlength(vsub(firstIntersection, ray->origin));
 
-                if (cm->innerIllumination.x == 0.f &&
+                if (!g_cl && cm->innerIllumination.x == 0.f && /* the CL global-illumination ray is not restated */
                     (si->advancedIllumination == aiBasic || si->advancedIllumination == aiFull))
                 {
                     int t = (index + si->pathTracingIteration * 100 + si->timestamp) % (MAX_BITMAP_SIZE - 3);
@@ -1432,8 +1527,15 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
                                                 closestIntersection, areas, &closestColor, iteration,
                                                 &shadowIntensity, &rBlinn, &attributes, st);
 
-            /* CRT:190: int += float*int, evaluated in float then truncated */
-            primitiveXYId->z = f2i((float)primitiveXYId->z + cm->innerIllumination.x * 256);
+            if (g_cl)
+            {
+                /* CL:2226-2227: sixteen per bounce whose shaded colour is brighter than the colour key */
+                float colorLight = colors[iteration].x + colors[iteration].y + colors[iteration].z;
+                primitiveXYId->z += (colorLight > si->transparentColor) ? 16 : 0;
+            }
+            else
+                /* CRT:190: int += float*int, evaluated in float then truncated */
+                primitiveXYId->z = f2i((float)primitiveXYId->z + cm->innerIllumination.x * 256);
 
             float segmentLength = vlength(vsub(closestIntersection, latestIntersection));
             latestIntersection = closestIntersection;
@@ -1505,10 +1607,13 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
             if (si->skyboxMaterialId != MATERIAL_NONE)
             {
                 colors[iteration] = skyboxMapping(si, s->materials, s->textures, &rayOrigin);
-                float rad = colors[iteration].x + colors[iteration].y + colors[iteration].z;
-                primitiveXYId->z = f2i((float)primitiveXYId->z + ((rad > 2.5f) ? rad * 256.f : 0.f));
+                if (!g_cl) /* CRT:274-275; absent from CL:2314-2315 */
+                {
+                    float rad = colors[iteration].x + colors[iteration].y + colors[iteration].z;
+                    primitiveXYId->z = f2i((float)primitiveXYId->z + ((rad > 2.5f) ? rad * 256.f : 0.f));
+                }
             }
-            else if (si->gradientBackground)
+            else if (g_cl ? (si->extendedGeometry == 2) /* CL:2318 */ : si->gradientBackground)
             {
                 v3 up = {0.f, 1.f, 0.f};
                 v3 dir = vnormalize(vsub(rayOrigin.direction, rayOrigin.origin));
@@ -1536,9 +1641,10 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
         {
             f4 attributes = {0.f, 0.f, 0.f, 0.f}; /* only .x is set in the reference (CRT:305-306) */
             attributes.x = s->materials[s->primitives[closestPrimitive].materialId].reflection;
+            /* CRT:307-311 shades it as bounce `reflectedRays`, CL:2345-2349 as bounce `iteration` */
             c3 color = primitiveShader(s, index, si, reflectedRay.origin, &normal, closestPrimitive,
-                                       closestIntersection, areas, &closestColor, reflectedRays, &shadowIntensity,
-                                       &rBlinn, &attributes, st);
+                                       closestIntersection, areas, &closestColor, g_cl ? iteration : reflectedRays,
+                                       &shadowIntensity, &rBlinn, &attributes, st);
             colors[reflectedRays].x += color.x * reflectedRatio;
             colors[reflectedRays].y += color.y * reflectedRatio;
             colors[reflectedRays].z += color.z * reflectedRatio;
@@ -1624,11 +1730,21 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
     else
         intersectionColor = colors[0];
 
+    float len = *depthOfField;
+    if (g_cl)
+    {
+        /* CL:2411-2418: the depth is taken here, from the first hit or from the origin of the frame of reference
+         * when there was none; a wireframe material under the last hit pushes the fog to the horizon */
+        len = vlength(vsub(firstIntersection, ray->origin));
+        *depthOfField = len;
+        if (closestPrimitive != -1 && s->materials[s->primitives[closestPrimitive].materialId].attributes.z == 1)
+            len = si->viewDistance;
+    }
     float D1 = si->viewDistance * 0.95f;
-    if (si->atmosphericEffect == aeFog && *depthOfField > D1)
+    if (si->atmosphericEffect == aeFog && len > D1)
     {
         float D2 = si->viewDistance * 0.05f;
-        float a = *depthOfField - D1;
+        float a = len - D1;
         float b = 1.f - (a / D2);
         intersectionColor.x = intersectionColor.x * b + si->backgroundColor.x * (1.f - b);
         intersectionColor.y = intersectionColor.y * b + si->backgroundColor.y * (1.f - b);
@@ -1639,6 +1755,8 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
     intersectionColor.x -= colorBox.x;
     intersectionColor.y -= colorBox.y;
     intersectionColor.z -= colorBox.z;
+    if (g_cl) /* CL:2438; CRT:404-407 returns the colour as it is */
+        saturate3(&intersectionColor);
     return intersectionColor;
 }
 
@@ -1999,7 +2117,7 @@ static void postDepthOfField(const OracleScene *s, const SceneInfo *si, const Po
     for (int i = 0; i < ppi->param3; ++i)
     {
         int ix = i % wh;
-        int iy = (i + 1000) % wh;
+        int iy = (i + (g_cl ? 100 : 1000)) % wh; /* CRT:1101; CL:2968 */
         int xx = f2i(x + depth * rnd(s, ix, st) * ppi->param2);
         int yy = f2i(y + depth * rnd(s, iy, st) * ppi->param2);
         if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
@@ -2057,19 +2175,35 @@ static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, cons
             if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
             {
                 int localIndex = yy * si->size.x + xx;
-                if (pp[localIndex].colorInfo.w >= depth)
+                if (g_cl)
+                {
+                    /* CL:3026-3027: nearer neighbours darken, by more the nearer they are */
+                    if (pp[localIndex].colorInfo.w < depth)
+                        occ += 1.f - (pp[localIndex].colorInfo.w - depth) / si->viewDistance;
+                }
+                else if (pp[localIndex].colorInfo.w >= depth)
                     occ += 1.f;
             }
             else
                 occ += 1.f;
         }
-    occ /= (float)c;
-    occ += 0.3f;
-    if (occ < 1.f)
+    if (g_cl)
     {
-        localColor.x *= occ;
-        localColor.y *= occ;
-        localColor.z *= occ;
+        /* CL:3033-3043: the occlusion is subtracted, after the division by the number of samples */
+        occ /= 5.f * c;
+        occ = (occ > 1.f) ? 1.f : occ;
+        occ = (occ < 0.f) ? 0.f : occ;
+    }
+    else
+    {
+        occ /= (float)c;
+        occ += 0.3f;
+        if (occ < 1.f)
+        {
+            localColor.x *= occ;
+            localColor.y *= occ;
+            localColor.z *= occ;
+        }
     }
     if (si->pathTracingIteration > NB_MAX_ITERATIONS)
     {
@@ -2077,6 +2211,12 @@ static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, cons
         localColor.x /= d;
         localColor.y /= d;
         localColor.z /= d;
+    }
+    if (g_cl)
+    {
+        localColor.x -= occ;
+        localColor.y -= occ;
+        localColor.z -= occ;
     }
     saturate3(&localColor);
     makeColor(si, localColor, bitmap, index);
@@ -2278,4 +2418,238 @@ int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const Po
         counts[3] = total.prims;
     }
     return total.randomFault ? -1 : 0;
+}
+
+/* ---- batched function-level entry points ----------------------------------------------------------
+ * One call = n independent evaluations of one function of the path, on the arrays the reference probes
+ * (oracle/ref_probes.cl) are given: tests/test_reference_probes.py compares the two element for element.
+ * Vectors are packed xyz (3 floats) unless said otherwise. */
+static inline v3 at3(const float *a, int i) { return V(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+static inline void put3(float *a, int i, v3 v)
+{
+    a[3 * i] = v.x;
+    a[3 * i + 1] = v.y;
+    a[3 * i + 2] = v.z;
+}
+
+void oracle_probe_box(int n, const BoundingBox *boxes, const float *origins, const float *directions, const float *t0,
+                      const float *t1, int *hit)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        Ray r;
+        r.origin = at3(origins, i);
+        r.direction = at3(directions, i);
+        computeRayAttributes(&r);
+        hit[i] = boxIntersection(&boxes[i], &r, t0[i], t1[i]);
+    }
+}
+
+void oracle_probe_primitive(int n, const SceneInfo *si, const Primitive *prims, const Material *materials,
+                            const BitmapBuffer *textures, const float *origins, const float *directions,
+                            const int *shadows, float *intersection, float *normal, float *areas,
+                            float *shadowIntensity, int *hit)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        Ray r;
+        r.origin = at3(origins, i);
+        r.direction = at3(directions, i);
+        computeRayAttributes(&r);
+        v3 in = at3(intersection, i), no = at3(normal, i), ar = V(0.f, 0.f, 0.f);
+        float sh = 0.f;
+        hit[i] = shadows[i] ? testPrimitiveShadow(si, &prims[i], materials, textures, &r, &in, &no, &ar, &sh)
+                            : testPrimitive(si, &prims[i], materials, textures, &r, &in, &no, &ar, &sh);
+        put3(intersection, i, in);
+        put3(normal, i, no);
+        put3(areas, i, ar);
+        shadowIntensity[i] = sh;
+    }
+}
+
+void oracle_probe_closest(int n, const OracleScene *scene, const SceneInfo *si, const float *origins,
+                          const float *targets, const int *iteration, const int *currentMaterialId, int *hit,
+                          int *closestPrimitive, float *intersection, float *normal, float *areas)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        Ray ray;
+        Stats st;
+        memset(&st, 0, sizeof(st));
+        ray.origin = at3(origins, i);
+        ray.direction = at3(targets, i);
+        v3 ci = V(0.f, 0.f, 0.f), cn = V(0.f, 0.f, 0.f), ca = V(0.f, 0.f, 0.f);
+        c3 colorBox = {0.f, 0.f, 0.f};
+        int cp = -1;
+        hit[i] = intersectionWithPrimitives(scene, si, &ray, iteration[i], &cp, &ci, &cn, &ca, &colorBox,
+                                            currentMaterialId[i], &st);
+        closestPrimitive[i] = cp;
+        put3(intersection, i, ci);
+        put3(normal, i, cn);
+        put3(areas, i, ca);
+    }
+}
+
+void oracle_probe_shadow(int n, const OracleScene *scene, const SceneInfo *si, const float *lampCenters,
+                         const float *origins, const int *lightId, const int *objectId, const int *iteration,
+                         float *result, float *color)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        Stats st;
+        memset(&st, 0, sizeof(st));
+        c3 c;
+        result[i] = processShadows(scene, si, at3(lampCenters, i), at3(origins, i), lightId[i], iteration[i], &c,
+                                   objectId[i], &st);
+        color[3 * i] = c.x;
+        color[3 * i + 1] = c.y;
+        color[3 * i + 2] = c.z;
+    }
+}
+
+/* primitiveShader: normal, closestColor, totalBlinn (xyz) and attributes (xyzw) are in/out */
+int oracle_probe_shader(int n, const OracleScene *scene, const SceneInfo *si, const int *index, const float *origins,
+                        float *normal, const int *objectId, const float *intersection, const float *areas,
+                        float *closestColor, const int *iteration, float *totalBlinn, float *attributes,
+                        float *returned, float *shadowIntensity)
+{
+    int fault = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        Stats st;
+        memset(&st, 0, sizeof(st));
+        v3 no = at3(normal, i);
+        c3 cc = {closestColor[3 * i], closestColor[3 * i + 1], closestColor[3 * i + 2]};
+        c3 tb = {totalBlinn[3 * i], totalBlinn[3 * i + 1], totalBlinn[3 * i + 2]};
+        f4 at = {attributes[4 * i], attributes[4 * i + 1], attributes[4 * i + 2], attributes[4 * i + 3]};
+        float sh = 0.f;
+        c3 ret = primitiveShader(scene, index[i], si, at3(origins, i), &no, objectId[i], at3(intersection, i),
+                                 at3(areas, i), &cc, iteration[i], &sh, &tb, &at, &st);
+        put3(normal, i, no);
+        closestColor[3 * i] = cc.x, closestColor[3 * i + 1] = cc.y, closestColor[3 * i + 2] = cc.z;
+        totalBlinn[3 * i] = tb.x, totalBlinn[3 * i + 1] = tb.y, totalBlinn[3 * i + 2] = tb.z;
+        attributes[4 * i] = at.x, attributes[4 * i + 1] = at.y, attributes[4 * i + 2] = at.z, attributes[4 * i + 3] = at.w;
+        returned[3 * i] = ret.x, returned[3 * i + 1] = ret.y, returned[3 * i + 2] = ret.z;
+        shadowIntensity[i] = sh;
+        fault |= st.randomFault;
+    }
+    return fault ? -1 : 0;
+}
+
+/* intersectionShader on primitive i with its material's starting specular (as primitiveShader sets it up):
+ * colour (xyzw), the bump-normal accumulator, specular, attributes (in/out), advanced attributes */
+void oracle_probe_intersection_shader(int n, const SceneInfo *si, const Primitive *prims, const Material *materials,
+                                      const BitmapBuffer *textures, const float *intersection, const float *areas,
+                                      float *attributes, float *color, float *bumpNormal, float *specular,
+                                      float *advancedAttributes)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        const Material *m = &materials[prims[i].materialId];
+        v3 bump = V(0.f, 0.f, 0.f);
+        f4 adv = {0.f, 0.f, 0.f, 0.f};
+        f4 spec = {m->specular.x, m->specular.y, m->specular.z, 0.f};
+        f4 at = {attributes[4 * i], attributes[4 * i + 1], attributes[4 * i + 2], attributes[4 * i + 3]};
+        f4 c = intersectionShader(si, &prims[i], materials, textures, at3(intersection, i), at3(areas, i), &bump, &spec,
+                                  &at, &adv);
+        color[4 * i] = c.x, color[4 * i + 1] = c.y, color[4 * i + 2] = c.z, color[4 * i + 3] = c.w;
+        put3(bumpNormal, i, bump);
+        specular[4 * i] = spec.x, specular[4 * i + 1] = spec.y, specular[4 * i + 2] = spec.z, specular[4 * i + 3] = spec.w;
+        attributes[4 * i] = at.x, attributes[4 * i + 1] = at.y, attributes[4 * i + 2] = at.z, attributes[4 * i + 3] = at.w;
+        advancedAttributes[4 * i] = adv.x, advancedAttributes[4 * i + 1] = adv.y, advancedAttributes[4 * i + 2] = adv.z,
+                               advancedAttributes[4 * i + 3] = adv.w;
+    }
+}
+
+void oracle_probe_skybox(int n, const SceneInfo *si, const Material *materials, const BitmapBuffer *textures,
+                         const float *origins, const float *targets, float *color)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        Ray r;
+        r.origin = at3(origins, i);
+        r.direction = at3(targets, i);
+        c3 c = skyboxMapping(si, materials, textures, &r);
+        color[3 * i] = c.x, color[3 * i + 1] = c.y, color[3 * i + 2] = c.z;
+    }
+}
+
+void oracle_probe_vectors(int n, const float *incident, const float *normal, const float *n1, const float *n2,
+                          float *refracted, float *reflected)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        put3(refracted, i, vectorRefraction(at3(incident, i), n1[i], at3(normal, i), n2[i]));
+        put3(reflected, i, vectorReflection(at3(incident, i), at3(normal, i)));
+    }
+}
+
+void oracle_probe_make_color(int n, const SceneInfo *si, const float *colors, BitmapBuffer *bitmap)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        c3 c = {colors[3 * i], colors[3 * i + 1], colors[3 * i + 2]};
+        makeColor(si, c, bitmap, i);
+    }
+}
+
+/* launchRayTracing for the ray origins[i] -> targets[i] of pixel index[i]; ids is in/out (the OpenCL dialect
+ * leaves .w as it finds it) */
+int oracle_probe_launch(int n, const OracleScene *scene, const SceneInfo *si, const float *origins,
+                        const float *targets, const int *index, float *color, float *depth,
+                        PrimitiveXYIdBuffer *ids)
+{
+    int fault = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(| : fault)
+    for (int i = 0; i < n; ++i)
+    {
+        Stats st;
+        memset(&st, 0, sizeof(st));
+        Ray r;
+        memset(&r, 0, sizeof(r));
+        r.origin = at3(origins, i);
+        r.direction = at3(targets, i);
+        float dof = 0.f;
+        c3 c = launchRayTracing(scene, index[i], &r, si, &dof, &ids[i], &st);
+        color[3 * i] = c.x, color[3 * i + 1] = c.y, color[3 * i + 2] = c.z;
+        depth[i] = dof;
+        fault |= st.randomFault;
+    }
+    return fault ? -1 : 0;
+}
+
+/* the post-processing stage alone (CRT:1853-1906) on a full frame of pp / ids */
+int oracle_postprocess(const OracleScene *scene, const SceneInfo *si, const PostProcessingInfo *ppi,
+                       const PostProcessingBuffer *pp, const PrimitiveXYIdBuffer *ids, BitmapBuffer *bitmap)
+{
+    Stats st;
+    memset(&st, 0, sizeof(st));
+    const int W = si->size.x, H = si->size.y;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+        {
+            int index = y * W + x;
+            switch (ppi->type)
+            {
+            case ppe_depthOfField:
+                postDepthOfField(scene, si, ppi, pp, bitmap, x, y, H, &st);
+                break;
+            case ppe_ambientOcclusion:
+                postAmbientOcclusion(scene, si, ppi, pp, bitmap, x, y, H, &st);
+                break;
+            case ppe_radiosity:
+                postRadiosity(scene, si, ppi, pp, ids, bitmap, x, y, H, &st);
+                break;
+            case ppe_filter:
+                postFilter(si, ppi, pp, bitmap, x, y, H);
+                break;
+            case ppe_cartoon:
+                postCartoon(si, ppi, pp, bitmap, index);
+                break;
+            default:
+                postDefault(si, pp, bitmap, index);
+                break;
+            }
+        }
+    return st.randomFault ? -1 : 0;
 }
