@@ -121,6 +121,11 @@ void *solr_hip_device_postprocessing(void);
  * is the send buffer of the gather); NULL restores the engine's own buffer. */
 void solr_hip_bind_device_bitmap(void *deviceBitmap);
 
+/* h2d_randoms for frames beyond the reference's 1920 x 1080 limit: `count` >= MAX_BITMAP_SIZE values, of
+ * which the renderer's random-index expressions (CudaRayTracer.cu:475: pixel index + timestamp % (N - 2))
+ * can reach width * height + 10 000.  Reads past `count` give 0. */
+void solr_hip_h2d_randoms_sized(const float *randoms, long count);
+
 /* Float framebuffer of the strip back to the host (parity tests) */
 void solr_hip_d2h_postprocessing(PostProcessingBuffer *hostBuffer);
 /* Host float framebuffer / primitive ids into the strip (accumulation tests) */

@@ -2563,6 +2563,27 @@ void h2d_randoms(vec2i, float *randoms)
         g.nbRandoms = MAX_BITMAP_SIZE;
 }
 
+/* Frames larger than the reference's 1920 x 1080 limit: its natural depth of field indexes the buffer with
+ * `pixel index + timestamp % (MAX_BITMAP_SIZE - 2)` (CRT:475, the precedence as written), i.e. up to
+ * W * H + 9999 + 1 - beyond MAX_BITMAP_SIZE floats as soon as the frame is larger (and by up to 9 999 floats
+ * even at that size).  A host that renders such frames hands over as many values
+ * as the expression can reach; reads beyond what was handed over return 0 (rt_device.h rnd()). */
+void solr_hip_h2d_randoms_sized(const float *randoms, long count)
+{
+    if (!ready("solr_hip_h2d_randoms_sized"))
+        return;
+    quiesce();
+    ARGCHECK(randoms != nullptr && count >= MAX_BITMAP_SIZE && count <= (1L << 30),
+             "solr_hip_h2d_randoms_sized: needs at least MAX_BITMAP_SIZE values");
+    if (!ok())
+        return;
+    std::vector<float> r(randoms, randoms + count);
+    HIPCHECK(hipSetDevice(g.device));
+    upload(g.randoms, r);
+    if (ok())
+        g.nbRandoms = count;
+}
+
 void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
 {
     if (!ready("h2d_textures"))

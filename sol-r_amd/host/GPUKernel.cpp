@@ -118,7 +118,7 @@ void GPUKernel::initBuffers()
     for (int i = 0; i < NB_MAX_TEXTURES; ++i)
         delete[] m_hTextures[i].buffer;
     memset(m_hTextures, 0, sizeof(m_hTextures));
-    m_hRandoms.assign(MAX_BITMAP_SIZE, 0.f);
+    m_hRandoms.assign(randomsNeeded(), 0.f);
     size_t pixels = std::max<size_t>((size_t)m_sceneInfo.size.x * (size_t)m_sceneInfo.size.y, 1);
     m_hPrimitivesXYIds.assign(pixels, make_vec4i());
     m_bitmap.assign(pixels * SOLR_COLOR_DEPTH, 0);
@@ -1308,10 +1308,20 @@ void GPUKernel::setDeterministic(long seed)
     m_randomsTransfered = false;
 }
 
+/* The reference keeps MAX_BITMAP_SIZE values (GPUKernel.cpp:350) and its 1920 x 1080 limit; its natural depth
+ * of field reads `pixel index + timestamp % (MAX_BITMAP_SIZE - 2)` (CudaRayTracer.cu:475), so a larger frame
+ * needs width * height + 10 000 of them (W * H + 10002).  The first MAX_BITMAP_SIZE
+ * values of a seed are the same whatever the length. */
+size_t GPUKernel::randomsNeeded() const
+{
+    const size_t pixels = (size_t)std::max(m_sceneInfo.size.x, 0) * (size_t)std::max(m_sceneInfo.size.y, 0);
+    return pixels > (size_t)MAX_BITMAP_SIZE ? pixels + 10002 : (size_t)MAX_BITMAP_SIZE;
+}
+
 void GPUKernel::fillRandoms()
 {
-    if (m_hRandoms.size() < MAX_BITMAP_SIZE)
-        m_hRandoms.assign(MAX_BITMAP_SIZE, 0.f);
+    if (m_hRandoms.size() != randomsNeeded())
+        m_hRandoms.assign(randomsNeeded(), 0.f);
     if (m_deterministicSeed >= 0)
     {
         unsigned int state = (unsigned int)m_deterministicSeed;
@@ -1337,7 +1347,7 @@ void GPUKernel::render_begin(const float)
     if (m_deterministicSeed < 0)
         m_sceneInfo.timestamp = rand() % 10000;
     const bool periodic = (m_deterministicSeed < 0) && (m_sceneInfo.pathTracingIteration % 50 == 1);
-    if (!m_randomsTransfered || periodic)
+    if (!m_randomsTransfered || periodic || m_hRandoms.size() != randomsNeeded() /* the frame changed size */)
     {
         m_randomsTransfered = false;
         fillRandoms();

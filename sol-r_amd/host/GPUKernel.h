@@ -426,6 +426,7 @@ public:
     int lightInformationSize() const { return m_lightInformationSize; }
     const Material *hostMaterials() const { return m_hMaterials.data(); }
     const std::vector<RandomBuffer> &hostRandoms() const { return m_hRandoms; }
+    size_t randomsNeeded() const;
     const std::vector<BitmapBuffer> &hostTextureAtlas();
     PrimitiveXYIdBuffer *hostPrimitiveIds() { fetchPrimitiveIds(); return m_hPrimitivesXYIds.data(); }
     unsigned int treeDepth() const { return m_treeDepth; }

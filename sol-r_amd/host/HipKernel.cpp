@@ -108,7 +108,10 @@ void HipKernel::render_begin(const float timer)
         }
         if (!m_randomsTransfered)
         {
-            h2d_randoms(m_occupancyParameters, m_hRandoms.data());
+            if (m_hRandoms.size() > (size_t)MAX_BITMAP_SIZE) /* a frame beyond the reference's 1920 x 1080 */
+                solr_hip_h2d_randoms_sized(m_hRandoms.data(), (long)m_hRandoms.size());
+            else
+                h2d_randoms(m_occupancyParameters, m_hRandoms.data());
             m_randomsTransfered = true;
         }
         if (!m_materialsTransfered)

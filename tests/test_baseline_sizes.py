@@ -1,0 +1,240 @@
+"""Parity at the sizes BASELINE.json names (the other parity tests render small frames of small scenes).
+
+cfg1  Cornell box, 1920 x 1080, 3 bounces + shadow rays                           (bench.py's default workload)
+cfg2  triangle mesh, 100 352 triangles, 1920 x 1080, 2 bounces                    (scenes.height_field n=224)
+cfg3  molecule, 50 000 atoms = 100k spheres + cylinders, 1920 x 1080, 3 bounces   (scenes.molecule)
+cfg4  3840 x 2160, passes 0...73 (10 refinement + 64 accumulated samples), natural depth of field + the
+      ambient-occlusion post-process - beyond the reference's 1920 x 1080 limit
+
+The engine renders the full frame; the oracle - minutes per full frame of the large scenes on this box's CPU
+share - renders 36 full rows spread over the frame (oracle.render(first_row, nb_rows), the same strip
+interface the multi-GPU split uses) and those rows must be what the engine produced: primitive ids exact,
+first-hit depth exact, RGB8 exact, float colour within 1 ULP.  Each configuration runs in the engine's
+default form (walk-order node list with grouping nodes, automatic tile order), with the reference's own node
+list (variant 3), without grouping nodes (variant 5), and with two frames in flight under the forced
+cost-ordered launch.  cfg4 walks row strips through all 74 passes on both sides (every pass reads what the
+pass before left in the frame buffers) and ties the full-size frame to those strips.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import assert_parity, compare_frames, device_frame
+
+solr_mod = importlib.import_module("sol-r_amd")
+
+W, H = 1920, 1080
+ROWS = [15 + 30 * i for i in range(36)]      # 36 rows, every 30th, from row 15 to row 1065
+
+
+def _frame_args(solr, k):
+    flat = k.flat_scene()
+    si, ppi, eye, direction, angles = k.frame_parameters()
+    objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+    return flat, si, ppi, eye, direction, angles, objects
+
+
+def _render(solr, args):
+    flat, si, ppi, eye, direction, angles, objects = args
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    solr.hip_lib().solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+
+
+def _oracle_rows(oracle, args, rows, nthreads=0):
+    flat, si, ppi, eye, direction, angles, _ = args
+    out = {}
+    scene = None
+    for row in rows:
+        opp, oids, orgb, counts, status = oracle.render(flat, si, ppi, eye, direction, angles, first_row=row, nb_rows=1,
+                                                        nthreads=nthreads)
+        assert status == 0
+        out[row] = (opp[0], oids[0], orgb[0])
+    return out
+
+
+def _check_rows(frame, expected, what):
+    pp, ids, rgb = frame
+    rows = sorted(expected)
+    epp = np.stack([expected[r][0] for r in rows])
+    eids = np.stack([expected[r][1] for r in rows])
+    ergb = np.stack([expected[r][2] for r in rows])
+    res = compare_frames(pp[rows], ids[rows], rgb[rows], epp, eids, ergb)
+    res["what"] = what
+    assert_parity(res)
+    return res
+
+
+CONFIGS = {
+    "cfg1-cornell": (lambda solr, k: solr.scenes.cornell(k, width=W, height=H, iterations=3), 29, 3),
+    "cfg2-mesh-100k-triangles": (lambda solr, k: solr.scenes.height_field(k, n=224, width=W, height=H), 100353, 2),
+    "cfg3-molecule-50k-atoms": (lambda solr, k: solr.scenes.molecule(k, atoms=50000, width=W, height=H), 99999, 3),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", list(CONFIGS))
+def test_full_size_frames_match_the_oracle_on_rows_across_the_frame(solr, oracle, config):
+    build, nb_primitives, bounces = CONFIGS[config]
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    try:
+        hip.solr_hip_set_variant(0)
+        build(solr, k)
+        k.render()                                    # uploads through the host protocol
+        k.check(0, "first frame")
+        args = _frame_args(solr, k)
+        flat, si = args[0], args[1]
+        assert len(flat.primitives) == nb_primitives and si.nbRayIterations == bounces
+        assert (si.size_x, si.size_y) == (W, H)
+        si.pathTracingIteration = 0
+        expected = _oracle_rows(oracle, args, ROWS)
+        lit = np.mean([(e[1][:, 0] >= 0).mean() for e in expected.values()])
+        assert lit > 0.2, "the rows hardly see the scene (%.3f)" % lit
+
+        # the engine's default form
+        hip.solr_hip_set_tile_scheduling(1)
+        hip.solr_hip_set_frames_in_flight(1)
+        _render(solr, args)
+        first = device_frame(solr, si)
+        _check_rows(first, expected, config + " default")
+
+        # the reference's own node list
+        hip.solr_hip_set_variant(3)
+        _render(solr, args)
+        _check_rows(device_frame(solr, si), expected, config + " variant 3")
+
+        # two frames in flight, cost-ordered launch forced: 40 frames so that the order is sorted twice while
+        # frames are running (the camera does not move: every frame must be the first one again)
+        hip.solr_hip_set_variant(0)
+        hip.solr_hip_set_tile_scheduling(2)
+        hip.solr_hip_set_frames_in_flight(2)
+        for _ in range(40):
+            _render(solr, args)
+        k.check(0, "frames in flight")
+        for _ in range(2):                            # the newest frame of either buffer set
+            frame = device_frame(solr, si)
+            _check_rows(frame, expected, config + " two frames in flight, cost order")
+            assert np.array_equal(frame[1], first[1]) and np.array_equal(frame[2], first[2])
+            assert np.array_equal(frame[0].view(np.uint32), first[0].view(np.uint32))
+            _render(solr, args)
+        hip.solr_hip_set_frames_in_flight(1)
+        hip.solr_hip_set_tile_scheduling(1)
+
+        # without grouping nodes: takes effect with the next upload of the scene
+        hip.solr_hip_set_variant(5)
+        k.compact_boxes(False)                        # same tree, flattened and uploaded again
+        k.render()
+        k.check(0, "variant 5")
+        _render(solr, args)
+        _check_rows(device_frame(solr, si), expected, config + " variant 5")
+    finally:
+        hip.solr_hip_set_variant(0)
+        hip.solr_hip_set_frames_in_flight(1)
+        hip.solr_hip_set_tile_scheduling(1)
+        k.finalize()
+
+
+# ---- cfg4 --------------------------------------------------------------------------------------------------
+W4, H4 = 3840, 2160
+PASSES = list(range(0, 74))
+STRIPS = [(120, 8), (1001, 6), (1500, 8), (2152, 8)]      # (first row, rows): top, odd offset, middle, bottom edge
+
+
+def _cfg4_scene(solr, k):
+    k.set_post_processing(type=solr_mod.ppe_ambientOcclusion, param1=11000.0, param2=10.0, param3=0)
+    solr.scenes.cornell(k, width=W4, height=H4, iterations=1, maxPathTracingIterations=74)
+
+
+def test_cfg4_random_buffer_reaches_every_pixel(solr):
+    """the natural depth of field reads randoms[pixel index + timestamp % (MAX_BITMAP_SIZE - 2)]: at 3840 x 2160
+    the host hands over W * H + 10002 values, the first 1920 * 1080 of them the usual ones"""
+    k = solr.Kernel(engine="host-only")
+    _cfg4_scene(solr, k)
+    big = np.array(k.flat_scene().randoms, copy=True)
+    k.finalize()
+    assert len(big) == W4 * H4 + 10002
+    assert np.count_nonzero(big[-(W4 * H4) // 2:]) > 0.99 * (W4 * H4 // 2)
+    k = solr.Kernel(engine="host-only")
+    solr.scenes.cornell(k, width=64, height=48)
+    small = np.array(k.flat_scene().randoms, copy=True)
+    k.finalize()
+    assert len(small) == 1920 * 1080 and np.array_equal(small, big[: len(small)])
+
+
+@pytest.mark.gpu
+def test_cfg4_strips_through_all_74_passes(solr, oracle):
+    """3840 x 2160, passes 0...73: refinement passes 1-10 re-render with more bounces, passes 11-73 jitter the
+    ray (anti-aliasing grid, natural depth of field from the random buffer, lamp position) and accumulate; the
+    ambient-occlusion kernel turns the running sum into the bitmap after every pass.  Engine and oracle walk
+    the same row strips of the full-size frame; every pass is compared (ids exact, RGB8 exact, float colour
+    within 2 ULP of the running sum, as tests/test_gpu_parity.py::test_accumulation_passes)."""
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    _cfg4_scene(solr, k)
+    worst = {"max_ulp": 0}
+    try:
+        for first, rows in STRIPS:
+            hip.solr_hip_set_strip(first, rows)
+            opp = oids = None
+            for it in PASSES:
+                k.set_scene_info(pathTracingIteration=it, maxPathTracingIterations=74)
+                img = k.render()
+                k.check(0, "pass %d" % it)
+                flat = k.flat_scene()
+                si, ppi, eye, direction, angles = k.frame_parameters()
+                assert (si.size_x, si.size_y, si.pathTracingIteration) == (W4, H4, it)
+                spp = np.zeros((rows, W4, 8), np.float32)
+                hip.solr_hip_d2h_postprocessing(C.c_void_p(spp.ctypes.data))
+                sids = k.primitive_ids()[first:first + rows]
+                opp, oids, orgb, _, status = oracle.render(flat, si, ppi, eye, direction, angles, first_row=first,
+                                                           nb_rows=rows, pp=opp, ids=oids)
+                assert status == 0, "the oracle read outside the random buffer at pass %d" % it
+                res = compare_frames(spp, sids, img[first:first + rows], opp, oids, orgb)
+                res["pass"], res["strip"] = it, (first, rows)
+                assert_parity(res, max_ulp=2)
+                if res["max_ulp"] >= worst["max_ulp"]:
+                    worst = res
+            # the natural depth of field did move the samples: the accumulated frame is not 64 x the first sample
+            assert np.abs(spp[..., :3] - 64.0 * spp[..., 4:7]).max() > 1e-3
+    finally:
+        hip.solr_hip_set_strip(0, -1)
+        k.finalize()
+    print(worst)
+
+
+@pytest.mark.gpu
+def test_cfg4_full_frame_is_made_of_those_strips(solr):
+    """the full 3840 x 2160 frame through passes 0...13 (refinement and the first accumulated samples): its rows
+    are bit for bit the rows of the strips rendered on their own - what test_cfg4_strips_through_all_74_passes
+    holds against the oracle - and the float frame buffer stays a running sum (pass n = pass n-1 + a sample)"""
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    _cfg4_scene(solr, k)
+    passes = list(range(0, 14))
+    try:
+        for it in passes:
+            k.set_scene_info(pathTracingIteration=it, maxPathTracingIterations=74)
+            k.render()
+            k.check(0, "full frame pass %d" % it)
+        full_pp = k.postprocessing_buffer()
+        full_ids = np.array(k.primitive_ids(), copy=True)
+        assert full_pp.shape == (H4, W4, 8)
+        assert np.isfinite(full_pp[..., :3]).all()
+        # running sum: after pass 13 the buffer holds the samples of passes 10...13 (CRT:550-562), the last one in .sceneInfo
+        assert (full_pp[..., :3] >= full_pp[..., 4:7] - 1e-4).all()
+        for first, rows in STRIPS[:2]:
+            hip.solr_hip_set_strip(first, rows)
+            for it in passes:
+                k.set_scene_info(pathTracingIteration=it, maxPathTracingIterations=74)
+                k.render()
+            spp = np.zeros((rows, W4, 8), np.float32)
+            hip.solr_hip_d2h_postprocessing(C.c_void_p(spp.ctypes.data))
+            sids = k.primitive_ids()[first:first + rows]
+            assert np.array_equal(spp.view(np.uint32), full_pp[first:first + rows].view(np.uint32)), (first, rows)
+            assert np.array_equal(sids, full_ids[first:first + rows]), (first, rows)
+            hip.solr_hip_set_strip(0, -1)
+    finally:
+        hip.solr_hip_set_strip(0, -1)
+        k.finalize()
