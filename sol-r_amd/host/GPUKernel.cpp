@@ -119,6 +119,7 @@ void GPUKernel::initBuffers()
         delete[] m_hTextures[i].buffer;
     memset(m_hTextures, 0, sizeof(m_hTextures));
     m_hRandoms.assign(randomsNeeded(), 0.f);
+    m_randomsFilled = false;
     size_t pixels = std::max<size_t>((size_t)m_sceneInfo.size.x * (size_t)m_sceneInfo.size.y, 1);
     m_hPrimitivesXYIds.assign(pixels, make_vec4i());
     m_bitmap.assign(pixels * SOLR_COLOR_DEPTH, 0);
@@ -1306,6 +1307,7 @@ void GPUKernel::setDeterministic(long seed)
 {
     m_deterministicSeed = seed;
     m_randomsTransfered = false;
+    m_randomsFilled = false;
 }
 
 /* The reference keeps MAX_BITMAP_SIZE values (GPUKernel.cpp:350) and its 1920 x 1080 limit; its natural depth
@@ -1318,8 +1320,21 @@ size_t GPUKernel::randomsNeeded() const
     return pixels > (size_t)MAX_BITMAP_SIZE ? pixels + 10002 : (size_t)MAX_BITMAP_SIZE;
 }
 
+/* what render_begin would upload with the next frame, for callers that look at the buffer before a frame was
+ * rendered (the test harness hands it to the oracle) */
+const std::vector<RandomBuffer> &GPUKernel::hostRandoms()
+{
+    if (!m_randomsFilled || m_hRandoms.size() != randomsNeeded())
+    {
+        m_randomsTransfered = false;
+        fillRandoms();
+    }
+    return m_hRandoms;
+}
+
 void GPUKernel::fillRandoms()
 {
+    m_randomsFilled = true;
     if (m_hRandoms.size() != randomsNeeded())
         m_hRandoms.assign(randomsNeeded(), 0.f);
     if (m_deterministicSeed >= 0)

@@ -425,7 +425,7 @@ public:
     size_t nbPendingRotations() const { return m_pendingRotations.size() + m_unrecordedRotations; }
     int lightInformationSize() const { return m_lightInformationSize; }
     const Material *hostMaterials() const { return m_hMaterials.data(); }
-    const std::vector<RandomBuffer> &hostRandoms() const { return m_hRandoms; }
+    const std::vector<RandomBuffer> &hostRandoms();
     size_t randomsNeeded() const;
     const std::vector<BitmapBuffer> &hostTextureAtlas();
     PrimitiveXYIdBuffer *hostPrimitiveIds() { fetchPrimitiveIds(); return m_hPrimitivesXYIds.data(); }
@@ -498,6 +498,7 @@ protected:
     TextureInfo m_hTextures[NB_MAX_TEXTURES];
     std::vector<BitmapBuffer> m_textureAtlas;
     std::vector<RandomBuffer> m_hRandoms;
+    bool m_randomsFilled = false;
     std::vector<PrimitiveXYIdBuffer> m_hPrimitivesXYIds;
     std::vector<LightInformation> m_lightInformation;
     std::vector<BitmapBuffer> m_bitmap;
