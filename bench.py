@@ -12,8 +12,9 @@ the timed region) and, for N > 1, the RCCL gather of the RGB strips to rank 0.
 Rank 0 prints ONE JSON line.  `value` = (closest-hit walks + shadow walks of the whole
 frame) * steps / wall time / 1e6, summed over all ranks, max wall time over ranks.
 `roofline` prices the renderer kernel against HBM bandwidth with the algorithmic bytes
-of DESIGN.md (67 B per pixel + one read of the scene), timed with HIP events on the
-launch stream.  `cpu_baseline` times the CPU oracle (a port of the reference algorithm,
+of DESIGN.md (51 B per pixel on a first pass + one read of the scene), timed with HIP events on the
+launch stream; `config.rates_mrays_per_s` holds, next to `value`, the rates of the reference's own frame
+protocol (one frame at a time; cudaRender + d2h_bitmap).  `cpu_baseline` times the CPU oracle (a port of the reference algorithm,
 see oracle/solr_oracle.h) on the host cores of the same box on a bounded sample.
 """
 import argparse
@@ -29,7 +30,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 PREROLL_FRAMES = 48    # untimed setup frames before the W warmup steps
-BYTES_PER_PIXEL = 67    # 16 (ids write) + 32 (float framebuffer write) + 16 (ids read, refinement passes) + 3 (RGB)
+# algorithmic bytes per pixel of one launch of the renderer (SURVEY.md section 8d with k_default fused):
+FIRST_PASS_BYTES_PER_PIXEL = 51    # pass 0: 16 (ids write) + 32 (float frame buffer write) + 3 (RGB); nothing is read
+LATER_PASS_BYTES_PER_PIXEL = 99    # refinement / accumulation passes also read the ids (16) and the frame buffer (32)
+# MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 vector instruction issues over 2 cycles; one scalar unit per CU
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
+SALU_PEAK_WAVE_INSTS_PER_S = 256 * 2.4e9
 
 
 def parse():
@@ -50,6 +56,11 @@ def parse():
                     help="consecutive frames rotate over this many streams and buffer sets of the engine, so a "
                          "frame's tail overlaps the next frame's start; 1: the reference's one frame at a time. "
                          "Default: 2 at N = 1, 3 at N > 1 (strips are one round of waves with a long tail)")
+    ap.add_argument("--config", default="", choices=["", "cfg1", "cfg2", "cfg3", "cfg4"],
+                    help="a BASELINE.json configuration by name: cfg1 = the default (Cornell 1080p, 3 bounces), cfg2 = "
+                         "--scene height_field, cfg3 = --scene molecule, cfg4 = Cornell 3840x2160 through passes 0...73 "
+                         "(refinement + 64 accumulated samples, natural depth of field, ambient-occlusion kernel): a "
+                         "step is then one pass of that cycle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -57,6 +68,14 @@ def parse():
 
 def main():
     args = parse()
+    if args.config == "cfg2":
+        args.scene = "height_field"
+    elif args.config == "cfg3":
+        args.scene = "molecule"
+    elif args.config == "cfg4":
+        args.scene, args.width, args.height, args.iterations = "cornell", 3840, 2160, 1
+        args.frames_in_flight = 1          # every pass reads what the pass before left in the frame buffers
+    cfg4 = args.config == "cfg4"
     if os.environ.get("SOLR_BENCH_DEBUG"):
         import faulthandler
         import signal
@@ -99,6 +118,9 @@ def main():
     k = solr.Kernel(engine="hip", device=local_rank)
     builder = getattr(solr.scenes, args.scene)
     kw = dict(width=W, height=H, iterations=args.iterations)
+    if cfg4:
+        k.set_post_processing(type=solr.ppe_ambientOcclusion, param1=11000.0, param2=10.0, param3=0)
+        kw["maxPathTracingIterations"] = 74
     if args.scene not in ("cornell", "irt_model", "obj_model", "swc_morphology", "pdb_molecule"):
         kw.pop("iterations")
     if args.scene in ("irt_model", "obj_model", "swc_morphology", "pdb_molecule"):
@@ -131,7 +153,12 @@ def main():
     objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
 
+    pass_counter = [0]
+
     def render():
+        if cfg4:
+            si.pathTracingIteration = pass_counter[0] % 74
+            pass_counter[0] += 1
         hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
 
     def frame():
@@ -158,6 +185,19 @@ def main():
                                  counts)
     k.check(0, "ray census")
     rays_local = int(counts[0]) + int(counts[1])
+    if cfg4:
+        # the passes differ (refinement passes skip finished pixels and trace deeper, accumulation passes jitter):
+        # census of every pass of the cycle, each on the frame buffers the pass before left; a step = a pass,
+        # its rays the mean over the cycle
+        total = 0
+        for it in range(74):
+            si.pathTracingIteration = it
+            hip.solr_hip_render_counting(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles),
+                                         counts)
+            total += int(counts[0]) + int(counts[1])
+        k.check(0, "ray census of the 74 passes")
+        rays_local = total // 74
+        si.pathTracingIteration = 0
 
     # a frame loop that does not come back is reported, not sat out: the multi-GPU loop chains work
     # across streams and ranks, and a stuck collective would otherwise hang the whole launch
@@ -219,6 +259,43 @@ def main():
         hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
         kernel_basis = "HIP events around each of 16 launches issued one at a time after the timed region"
 
+    # ---- the same frame under the reference's own frame protocol (N = 1; untimed extras, reported next to
+    # `value`): one frame at a time - render, wait - and cudaRender + d2h_bitmap, the wall time SURVEY.md
+    # section 8(d) defines the metric over (kernel + read-back of the RGB image and the primitive ids)
+    rates = None
+    if not distributed:
+        import numpy as np
+        hip.solr_hip_set_frames_in_flight(1)
+        n_extra = max(8, min(args.steps, 64))
+        for _ in range(4):
+            frame()
+        sync()
+        ta = time.perf_counter()
+        for _ in range(n_extra):
+            frame()
+            sync()
+        one_at_a_time = (time.perf_counter() - ta) / n_extra
+        host_rgb = np.zeros((H, W, 3), np.uint8)
+        host_ids = np.zeros((H, W, 4), np.int32)
+        hip.solr_hip_d2h(C.byref(si), C.c_void_p(host_rgb.ctypes.data), C.c_void_p(host_ids.ctypes.data))
+        ta = time.perf_counter()
+        for _ in range(n_extra):
+            frame()
+            hip.solr_hip_d2h(C.byref(si), C.c_void_p(host_rgb.ctypes.data), C.c_void_p(host_ids.ctypes.data))
+        with_d2h = (time.perf_counter() - ta) / n_extra
+        ta = time.perf_counter()
+        for _ in range(n_extra):
+            frame()
+            hip.solr_hip_d2h(C.byref(si), C.c_void_p(host_rgb.ctypes.data), None)
+        with_image_d2h = (time.perf_counter() - ta) / n_extra
+        k.check(0, "frame protocol rates")
+        hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
+        rates = {"one_frame_at_a_time": (one_at_a_time, "render, wait for it, render the next"),
+                 "cudaRender_plus_d2h_bitmap": (with_d2h, "render + read-back of the RGB image and the primitive ids "
+                                                "(the reference's render_begin / render_end, SURVEY.md 8d)"),
+                 "cudaRender_plus_image": (with_image_d2h, "render + read-back of the RGB image alone (the ids stay on "
+                                           "the device until picking asks: HipKernel::render_end)")}
+
     rays_total = rays_local
     if distributed:
         t = torch.tensor([elapsed, float(rays_local), kernel_ms / max(launches.value, 1)], dtype=torch.float64,
@@ -246,12 +323,18 @@ def main():
     mrays = rays_total * args.steps / elapsed / 1e6
     scene_bytes = (48 * len(flat.boxes) + 128 * len(flat.primitives) + 48 * len(flat.lights) +
                    176 * len(set(int(m) for m in flat.primitives["materialId"])))
-    algo_bytes = nb_rows * W * BYTES_PER_PIXEL + scene_bytes  # per launch, rank 0's strip
+    # per launch, rank 0's strip: pass 0 writes only; cfg4 cycles through 1 first pass and 73 later ones
+    per_pixel = FIRST_PASS_BYTES_PER_PIXEL if not cfg4 else (FIRST_PASS_BYTES_PER_PIXEL + 73 * LATER_PASS_BYTES_PER_PIXEL) / 74.0
+    algo_bytes = int(nb_rows * W * per_pixel) + scene_bytes
     achieved = algo_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
-    traffic, traffic_source = measured_traffic(args, world)
-    valu = measured_valu(args, world)
+    traffic, traffic_source, traffic_commit = measured_traffic(args, world)
+    valu = measured_counters(args, world)
+    label = {"cornell": "Cornell", "height_field": "triangle mesh", "molecule": "molecule"}.get(args.scene, args.scene)
+    metric = "Mrays/s @%dx%d, %d-bounce %s" % (W, H, si.nbRayIterations, label)
+    if cfg4:
+        metric = "Mrays/s @3840x2160, Cornell, passes 0-73 (64 accumulated samples, depth of field + ambient occlusion)"
     out = {
-        "metric": "Mrays/s @1920x1080, 3-bounce Cornell",
+        "metric": metric,
         "value": round(mrays, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -263,8 +346,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if args.scene not in ("irt_model", "obj_model", "swc_morphology", "pdb_molecule") else "the reference's sample scene file",
-        "config": {"workload": "%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, row strips of %d" %
-                   (args.scene, W, H, si.nbRayIterations, len(flat.boxes), len(flat.primitives), rows_per_rank),
+        "config": {"workload": "%s%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, row strips of %d" %
+                   ((args.config + ": ") if args.config else "", args.scene, W, H, si.nbRayIterations, len(flat.boxes),
+                    len(flat.primitives), rows_per_rank),
                    "rays_per_frame": rays_total, "closest_hit_walks_rank0": int(counts[0]),
                    "shadow_walks_rank0": int(counts[1]), "lane_nodes": int(counts[2]), "lane_prim_tests": int(counts[3]),
                    "wave_nodes": int(counts[4]), "wave_prim_tests": int(counts[5]), "wave_walks": int(counts[6]) + int(counts[7]), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 2),
@@ -274,17 +358,35 @@ def main():
                    "parallelism": "tile%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_taken_at_commit": traffic_commit,
+                     "traffic_note": "read from a committed rocprofv3 --pmc profile of this same command, not measured "
+                                     "by this run (a process cannot profile itself); null when the workload differs "
+                                     "from the profiled one",
                      "kernel": "k_standardRenderer", "kernel_ms": round(kernel_avg_ms, 5), "kernel_ms_basis": kernel_basis,
-                     "algorithmic_bytes": algo_bytes},
+                     "algorithmic_bytes": algo_bytes, "algorithmic_bytes_per_pixel": round(per_pixel, 2)},
     }
+    if rates:
+        out["config"]["rates_mrays_per_s"] = {"pipelined_device_resident": round(mrays, 1)}
+        out["config"]["rates_note"] = {"pipelined_device_resident": "`value`: %d frames in flight, image left in HBM" %
+                                       int(hip.solr_hip_get_frames_in_flight())}
+        for name, (seconds, what) in rates.items():
+            out["config"]["rates_mrays_per_s"][name] = round(rays_total / seconds / 1e6, 1)
+            out["config"]["rates_note"][name] = "%s: %.4f ms per frame" % (what, seconds * 1e3)
     if valu and kernel_avg_ms > 0:
-        # what actually bounds this kernel: a wave64 vector instruction occupies one of a
-        # CU's four SIMD16 units for four cycles -> 256 CUs x 4 SIMDs x 2.4 GHz / 4 wave-instructions per second
-        peak = 256 * 4 * 2.4e9 / 4
-        out["roofline"]["valu_issue"] = {
-            "insts_per_launch": valu[0], "source": valu[1], "peak_wave_insts_per_s": peak,
-            "frac": round(valu[0] / (kernel_avg_ms * 1e-3) / peak, 4),
-            "note": "informative: the contract's roofline is the HBM one above; this kernel is vector-issue bound"}
+        # instruction-issue view of the same launch (informative; the contract's roofline is the HBM one): vector
+        # instructions against 4 SIMD-32 per CU x one wave64 instruction per 2 cycles, scalar instructions against
+        # one scalar unit per CU x one per cycle (MI355X_MICROARCH.md), and against what tools/valu_issue_bench.hip
+        # measured on this chip (profiles/r2/valu_issue_bench.txt: 0.885e12 v_fma_f32, 0.575e12 s_add_i32 per second)
+        seconds = kernel_avg_ms * 1e-3
+        out["roofline"]["issue"] = {
+            "source": valu["source"], "taken_at_commit": valu.get("commit"),
+            "vector_insts_per_launch": valu["SQ_INSTS_VALU"], "vector_peak_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
+            "vector_frac": round(valu["SQ_INSTS_VALU"] / seconds / VALU_PEAK_WAVE_INSTS_PER_S, 4),
+            "vector_frac_of_measured_peak": round(valu["SQ_INSTS_VALU"] / seconds / 0.885e12, 4),
+            "scalar_insts_per_launch": valu["SQ_INSTS_SALU"] + valu.get("SQ_INSTS_SMEM", 0),
+            "scalar_peak_per_s": SALU_PEAK_WAVE_INSTS_PER_S,
+            "scalar_frac": round((valu["SQ_INSTS_SALU"] + valu.get("SQ_INSTS_SMEM", 0)) / seconds / SALU_PEAK_WAVE_INSTS_PER_S, 4),
+            "note": "counters from a committed profile of this command; durations from this run"}
 
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(flat, si, ppi, eye, direction, angles, args.cpu_seconds)
@@ -297,40 +399,49 @@ def main():
     print(json.dumps(out), flush=True)
 
 
+def _profiled_workload(args, world):
+    if world != 1 or (args.width, args.height) != (1920, 1080) or args.graphics_level != 4 or args.config == "cfg4":
+        return False
+    return not (args.scene == "cornell" and args.iterations != 3)
+
+
 def measured_traffic(args, world):
     """HBM-side bytes per launch of the renderer from the committed rocprofv3 --pmc passes of this same
-    command (profiles/rNN/hbm_traffic.json, written by tools/collect_profiles.py); None when the workload
-    differs from the profiled one.  bench.py cannot run the profiler on itself."""
+    command (profiles/rNN/hbm_traffic.json, written by tools/collect_profiles.py), the file it came from and the
+    commit the profile was taken at; None when the workload differs from the profiled one."""
     import glob
-    if world != 1 or (args.width, args.height) != (1920, 1080) or args.graphics_level != 4:
-        return None, None
-    if args.scene == "cornell" and args.iterations != 3:
-        return None, None
+    if not _profiled_workload(args, world):
+        return None, None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
         try:
-            entry = json.load(open(path)).get(args.scene)
+            data = json.load(open(path))
         except (OSError, ValueError):
             continue
+        entry = data.get(args.scene)
         if entry:
-            return entry["bytes_per_launch"], os.path.relpath(path, ROOT)
-    return None, None
+            return entry["bytes_per_launch"], os.path.relpath(path, ROOT), entry.get("commit", data.get("commit"))
+    return None, None, None
 
 
-def measured_valu(args, world):
-    """SQ_INSTS_VALU per launch of the renderer from the committed PMC pass of this same command
+def measured_counters(args, world):
+    """SQ instruction counters per launch of the renderer from the committed PMC passes of this same command
     (profiles/rNN/pmc_<scene>.txt), or None."""
     import glob
-    if world != 1 or (args.width, args.height) != (1920, 1080) or args.graphics_level != 4:
-        return None
-    if args.scene == "cornell" and args.iterations != 3:
+    if not _profiled_workload(args, world):
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_%s.txt" % args.scene)), reverse=True):
+        found = {"source": os.path.relpath(path, ROOT)}
         try:
             for line in open(path):
-                if line.startswith("SQ_INSTS_VALU"):
-                    return int(float(line.split()[1])), os.path.relpath(path, ROOT)
+                if line.startswith("# commit"):
+                    found["commit"] = line.split()[-1]
+                parts = line.split()
+                if len(parts) >= 2 and parts[0] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM"):
+                    found[parts[0]] = int(float(parts[1]))
         except (OSError, ValueError):
             continue
+        if "SQ_INSTS_VALU" in found and "SQ_INSTS_SALU" in found:
+            return found
     return None
 
 
@@ -348,9 +459,9 @@ def usable_cpus():
 
 def cpu_baseline(flat, si, ppi, eye, direction, angles, budget_s):
     """The CPU oracle (a port of the reference algorithm) on the host cores of this box, on a bounded
-    sample of the same frame.  Thread count: the best of {quota, 2x, 4x quota, all hardware threads} in
-    a short calibration (containers here run under a CFS quota far below the hardware thread count, and
-    oversubscribing it collapses throughput), then a sustained run of about budget_s seconds."""
+    sample of the same frame.  Thread count: the best SUSTAINED rate (at least 1.5 s each, after a warm-up
+    frame: a short burst is not what a CFS-throttled container sustains) of {quota, 2x quota, 4x quota, all
+    hardware threads}; then a run of about budget_s seconds with it, and a one-thread figure."""
     import numpy as np
     from oracle import loader
     L = loader.lib()
@@ -362,33 +473,37 @@ def cpu_baseline(flat, si, ppi, eye, direction, angles, budget_s):
     counts = (C.c_ulonglong * 4)()
     eye, direction, angles = (np.ascontiguousarray(a, np.float32) for a in (eye, direction, angles))
 
-    def one_frame(threads):
-        t0 = time.perf_counter()
-        L.oracle_render(C.byref(scene.c), C.addressof(si), C.addressof(ppi), eye.ctypes.data, direction.ctypes.data,
-                        angles.ctypes.data, 0, H, pp.ctypes.data, ids.ctypes.data, rgb.ctypes.data,
-                        C.addressof(counts), threads)
-        return time.perf_counter() - t0, int(counts[0]) + int(counts[1])
+    def frames_for(threads, seconds, rows=H):
+        """(rays per second, frames, seconds) of back-to-back frames (of `rows` rows) for at least `seconds`"""
+        n, rays, t0 = 0, 0, time.perf_counter()
+        while True:
+            L.oracle_render(C.byref(scene.c), C.addressof(si), C.addressof(ppi), eye.ctypes.data, direction.ctypes.data,
+                            angles.ctypes.data, 0, rows, pp.ctypes.data, ids.ctypes.data, rgb.ctypes.data,
+                            C.addressof(counts), threads)
+            rays += int(counts[0]) + int(counts[1])
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 4000:
+                return rays / dt, n, dt
 
     hw = len(os.sched_getaffinity(0))
     quota = usable_cpus()
     candidates = sorted(set(min(hw, c) for c in (quota, 2 * quota, 4 * quota, hw)))
     calib = {}
     for c in candidates:
-        one_frame(c)
-        calib[c] = min(one_frame(c)[0] for _ in range(2))
-    threads = min(calib, key=calib.get)
-    frames, rays, t0 = 0, 0, time.perf_counter()
-    while True:
-        _, r = one_frame(threads)
-        rays += r
-        frames += 1
-        if time.perf_counter() - t0 > budget_s or frames >= 2000:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "%d full %dx%d frames of the same scene in %.1f s, OpenMP over rows with %d threads "
-                      "(affinity %d, CFS quota %d CPUs; calibration s/frame by threads: %s)" %
-                      (frames, W, H, dt, threads, hw, quota, {k: round(v, 4) for k, v in calib.items()})}
+        frames_for(c, 0.0)                       # warm-up frame: thread creation, first touch
+        calib[c] = frames_for(c, 1.5)[0]
+    threads = max(calib, key=calib.get)
+    rate, frames, dt = frames_for(threads, budget_s)
+    single = frames_for(1, 2.5)
+    return {"value": round(rate / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "threads": threads, "quota_cpus": quota, "hardware_threads": hw,
+            "single_thread_value": round(single[0] / 1e6, 3),
+            "sample": "%d full %dx%d frames of the same scene in %.1f s, OpenMP over rows with %d threads (affinity "
+                      "%d hardware threads, CFS quota %d CPUs; sustained Mrays/s by thread count over >= 1.5 s each: %s); "
+                      "one thread: %d frames in %.1f s" %
+                      (frames, W, H, dt, threads, hw, quota, {k: round(v / 1e6, 1) for k, v in calib.items()},
+                       single[1], single[2])}
 
 
 if __name__ == "__main__":

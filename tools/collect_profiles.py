@@ -1,6 +1,7 @@
 """Copies the summaries of tools/profile_round.sh from gpurun_out/<tag>/ into profiles/<tag>/ (tracked)."""
 import sys, os, glob, shutil, csv, collections, json
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+commit = sys.argv[2] if len(sys.argv) > 2 else os.environ.get("SOLR_COMMIT", "unknown")   # the tree the box ran
 src, dst = "gpurun_out/" + tag, "profiles/" + tag
 os.makedirs(dst, exist_ok=True)
 for scene in ("cornell", "height_field", "molecule"):
@@ -11,7 +12,7 @@ for scene in ("cornell", "height_field", "molecule"):
     if os.path.exists(st):
         shutil.copy(st, os.path.join(dst, "kernel_stats_%s.csv" % scene))
     out = []
-    for p in ("sq", "fetch", "write"):
+    for p in ("sq", "sq2", "fetch", "write"):
         agg = collections.defaultdict(list)
         meta = None
         for f in glob.glob(os.path.join(src, "pmc_%s_%s" % (p, scene), "*counter_collection.csv")):
@@ -24,7 +25,8 @@ for scene in ("cornell", "height_field", "molecule"):
             out.append("kernel %s  grid %s  workgroup %s  scratch %s B/lane  LDS %s B/workgroup" % (
                 meta["Kernel_Name"][:60], meta["Grid_Size"], meta["Workgroup_Size"], meta["Scratch_Size"], meta["LDS_Block_Size"]))
     if out:
-        hdr = ("# rocprofv3 --pmc, three separate passes (SQ counters; FETCH_SIZE; WRITE_SIZE) of\n"
+        hdr = ("# commit %s\n" % commit +
+               "# rocprofv3 --pmc, separate passes (two sets of SQ counters; FETCH_SIZE; WRITE_SIZE) of\n"
                "#   python3 bench.py --scene %s --steps 24 --warmup 12 --no-cpu-baseline --frames-in-flight 1\n"
                "# per launch of the renderer kernel.  FETCH_SIZE / WRITE_SIZE are in KB (L2 <-> fabric requests x 64 B;\n"
                "# MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, WRITE_SIZE is exact).\n" % scene)
@@ -41,7 +43,7 @@ for scene in ("cornell", "height_field", "molecule"):
         if v:
             vals[name] = sum(v) / len(v)
     if len(vals) == 2:
-        traffic[scene] = {"workload": "%s 1920x1080" % scene, "FETCH_SIZE_KB": round(vals["FETCH_SIZE"], 1),
+        traffic[scene] = {"workload": "%s 1920x1080" % scene, "commit": commit, "FETCH_SIZE_KB": round(vals["FETCH_SIZE"], 1),
                           "WRITE_SIZE_KB": round(vals["WRITE_SIZE"], 1),
                           "bytes_per_launch": int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
                           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB -> bytes; "
@@ -50,6 +52,6 @@ for scene in ("cornell", "height_field", "molecule"):
 if traffic:
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "tile_timeline_*.txt")) + glob.glob(os.path.join(src, "strip_times_*.txt")) + \
-        glob.glob(os.path.join(src, "reference_opencl_speed.txt")):
+        glob.glob(os.path.join(src, "reference_opencl_speed.txt")) + glob.glob(os.path.join(src, "valu_issue_bench.txt")):
     shutil.copy(f, dst)
 print(sorted(os.listdir(dst)))

@@ -15,6 +15,8 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$SCENE -o trace -- $CMD > $OUT/trace_$SCENE.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_BUSY_CYCLES \
     --output-format csv -d $OUT/pmc_sq_$SCENE -o pmc -- $CMD > $OUT/pmc_sq_$SCENE.log 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR \
+    --output-format csv -d $OUT/pmc_sq2_$SCENE -o pmc -- $CMD > $OUT/pmc_sq2_$SCENE.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$SCENE -o pmc -- $CMD > $OUT/pmc_fetch_$SCENE.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$SCENE -o pmc -- $CMD > $OUT/pmc_write_$SCENE.log 2>&1
 cd $ROOT
