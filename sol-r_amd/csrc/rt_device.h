@@ -1050,7 +1050,7 @@ SOLR_DEV bool stepGeneral(const Scene &S, const WalkRay &r, bool fastBoxes, floa
  *   - the wave's next node is one s_cselect on "mask != 0".
  * Hazards (gfx950): every SGPR a vector instruction reads here is written by the
  * scalar unit; v_cmpx results are only read back through s_mov from exec.
- * Fixed registers: s[64:87], v[58:63] (sub-registers of pairs cannot be named
+ * Fixed registers: s[64:86], v[58:63] (sub-registers of pairs cannot be named
  * through operands).  All scalar loads are drained before the statement ends.
  *
  * Returns the leaf (>= 0) with `entered` lanes and its primitive count, cur
@@ -1070,12 +1070,19 @@ SOLR_DEV PackedRay packRay(const WalkRay &r)
     return p;
 }
 
-#define SOLR_WALK_HALF(SELF, OTHER, LOXY, ZZ, HIXY, NB, SKIP, SELF_REGS, OTHER_REGS)                                  \
+/* Control flow of one half.  The common case - no lane enters the node - FALLS THROUGH: half A runs into half
+ * B, half B branches back to A, so a run of nodes nobody enters costs one taken branch per two nodes (a taken
+ * branch empties the wave's instruction buffer; the first form of this loop took two per node).  The record
+ * of cur + 1 is requested into the other bank before the test; the list is followed by a pad record so that
+ * the request of the last node's successor stays inside the arena.
+ *   LW<half>   test the node in this half's bank
+ *   LE<half>   some lane entered: a leaf with primitives leaves the loop (LL), an inner node goes on at cur + 1
+ *   LR<half>   the wave skipped to a node that is not cur + 1: fetch it into this half's bank, test it here */
+#define SOLR_WALK_HALF(SELF, OTHER, LOXY, ZZ, HIXY, NB, SKIP, SELF_REGS, OTHER_REGS, TAIL)                            \
     "LW" SELF "_%=:\n"                                                                                                 \
     "s_waitcnt lgkmcnt(0)\n"                                                                                           \
     "s_add_i32 s85, %[cur], 1\n"                                                                                       \
-    "s_min_i32 s84, s85, s87\n"                                                                                        \
-    "s_lshl_b32 s84, s84, 5\n"                                                                                         \
+    "s_lshl_b32 s84, s85, 5\n"                                                                                         \
     "s_load_dwordx8 " OTHER_REGS ", %[base], s84\n"                                                                    \
     "s_add_i32 s86, %[cur], " SKIP "\n"                                                                                \
     "v_pk_add_f32 v[58:59], " LOXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
@@ -1098,27 +1105,35 @@ SOLR_DEV PackedRay packRay(const WalkRay &r)
     "v_cmpx_lt_f32_e32 vcc, %[t], %[far]\n"                                                                            \
     "v_cmpx_lt_f32_e32 vcc, 0, v58\n"                                                                                 \
     "v_mov_b32 %[cursor], s85\n"                                                                                       \
+    "s_cmp_lg_u64 exec, 0\n"                                                                                           \
+    "s_cbranch_scc1 LE" SELF "_%=\n"                                                                                   \
+    "s_mov_b64 exec, s[80:81]\n"                                                                                       \
+    "s_mov_b32 %[cur], s86\n"                                                                                          \
+    "s_cmp_ge_i32 s86, %[n]\n"                                                                                         \
+    "s_cbranch_scc1 LD_%=\n"                                                                                           \
+    "s_cmp_lg_u32 s86, s85\n"                                                                                          \
+    "s_cbranch_scc1 LR" SELF "_%=\n"                                                                                   \
+    TAIL
+
+#define SOLR_WALK_SIDE(SELF, OTHER, NB, SELF_REGS)                                                                     \
+    "LE" SELF "_%=:\n"                                                                                                 \
     "s_mov_b64 s[82:83], exec\n"                                                                                       \
     "s_mov_b64 exec, s[80:81]\n"                                                                                       \
-    "s_cmp_lg_u64 s[82:83], 0\n"                                                                                       \
-    "s_cselect_b32 s84, s85, s86\n"                                                                                    \
-    "s_cbranch_scc0 LN" SELF "_%=\n"                                                                                   \
     "s_cmp_gt_i32 " NB ", 0\n"                                                                                         \
     "s_cbranch_scc1 LL" SELF "_%=\n"                                                                                   \
-    "LN" SELF "_%=:\n"                                                                                                 \
-    "s_mov_b32 %[cur], s84\n"                                                                                          \
-    "s_cmp_ge_i32 s84, %[n]\n"                                                                                         \
+    "s_mov_b32 %[cur], s85\n"                                                                                          \
+    "s_cmp_ge_i32 s85, %[n]\n"                                                                                         \
     "s_cbranch_scc1 LD_%=\n"                                                                                           \
-    "s_cmp_eq_u32 s84, s85\n"                                                                                          \
-    "s_cbranch_scc1 LW" OTHER "_%=\n"                                                                                  \
-    "s_lshl_b32 s84, s84, 5\n"                                                                                         \
-    "s_load_dwordx8 " SELF_REGS ", %[base], s84\n"                                                                     \
-    "s_branch LW" SELF "_%=\n"                                                                                         \
+    "s_branch LW" OTHER "_%=\n"                                                                                        \
     "LL" SELF "_%=:\n"                                                                                                 \
     "s_mov_b32 %[leaf], %[cur]\n"                                                                                      \
     "s_mov_b32 %[nb], " NB "\n"                                                                                        \
     "s_mov_b32 %[cur], s85\n"                                                                                          \
-    "s_branch LX_%=\n"
+    "s_branch LX_%=\n"                                                                                                 \
+    "LR" SELF "_%=:\n"                                                                                                 \
+    "s_lshl_b32 s84, s86, 5\n"                                                                                         \
+    "s_load_dwordx8 " SELF_REGS ", %[base], s84\n"                                                                     \
+    "s_branch LW" SELF "_%=\n"
 
 SOLR_DEV int advanceTidy(const Scene &S, const PackedRay &p, float farDistance, int &cursor, int &cur,
                          int &nbPrimitives, bool &entered)
@@ -1127,12 +1142,15 @@ SOLR_DEV int advanceTidy(const Scene &S, const PackedRay &p, float farDistance, 
     int leaf, nb, flag;
     float t;
     asm volatile("s_mov_b64 s[80:81], exec\n"
-                 "s_add_i32 s87, %[n], -1\n"
                  "s_lshl_b32 s84, %[cur], 5\n"
                  "s_load_dwordx8 s[64:71], %[base], s84\n"
-                 SOLR_WALK_HALF("A", "B", "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[64:71]", "s[72:79]")
-                 SOLR_WALK_HALF("B", "A", "s[72:73]", "s[74:75]", "s[76:77]", "s78", "s79", "s[72:79]", "s[64:71]")
+                 SOLR_WALK_HALF("A", "B", "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[64:71]", "s[72:79]", "")
+                 SOLR_WALK_HALF("B", "A", "s[72:73]", "s[74:75]", "s[76:77]", "s78", "s79", "s[72:79]", "s[64:71]",
+                                "s_branch LWA_%=\n")
+                 SOLR_WALK_SIDE("A", "B", "s70", "s[64:71]")
+                 SOLR_WALK_SIDE("B", "A", "s78", "s[72:79]")
                  "LD_%=:\n"
+                 "s_mov_b64 s[82:83], 0\n"
                  "s_mov_b32 %[leaf], -1\n"
                  "s_mov_b32 %[nb], 0\n"
                  "LX_%=:\n"
@@ -1143,7 +1161,7 @@ SOLR_DEV int advanceTidy(const Scene &S, const PackedRay &p, float farDistance, 
                  : [oxy] "v"(p.oxy), [ozz] "v"(p.ozz), [ixy] "v"(p.ixy), [izz] "v"(p.izz), [far] "v"(farDistance),
                    [base] "s"(base), [n] "s"(S.nbBoxes)
                  : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
-                   "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v58", "v59",
+                   "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "v58", "v59",
                    "v60", "v61", "v62", "v63");
     nbPrimitives = nb;
     entered = flag != 0;

@@ -50,8 +50,17 @@ struct FrameArgs
     unsigned long long *tileClock; /* diagnostics: {start, end} of every tile in 100 MHz ticks, or null */
     /* cost-ordered launch (see TileScheduling below); all null when off */
     unsigned *tileCost;        /* out: duration of every tile of this frame, 100 MHz ticks */
-    const unsigned *tileOrder; /* in: workgroup -> tile, most expensive tiles of the previous frame first */
+    const unsigned *tileOrder; /* in: workgroup -> order entry (see ORDER_* below), most expensive tiles first */
+    int nbTiles;               /* tiles of the frame; the ordered launch has 3 * SPLIT_TILES_MAX workgroups more */
 };
+
+/* An entry of the launch order: the tile in bits 0-27, and in bits 28-30 which part of it this wave renders -
+ * 0 the whole 8 x 8 tile, 1-4 one of its 4 x 4 quadrants (the few most expensive tiles are rendered by four
+ * waves, see k_orderTiles).  ORDER_NOTHING pads the list to its fixed length. */
+#define ORDER_TILE_MASK 0x0fffffffu
+#define ORDER_PART_SHIFT 28
+#define ORDER_NOTHING 0xffffffffu
+#define SPLIT_TILES_MAX 256
 
 #define TILE 8
 #define WAVE 64
@@ -78,7 +87,11 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     const SceneInfo &si = F.si;
     const int lane = threadIdx.x;
     /* the order is a permutation by construction (k_orderTiles); the clamp keeps a damaged one inside the frame */
-    const int tile = F.tileOrder ? (int)min(F.tileOrder[blockIdx.x], gridDim.x - 1u) : (int)blockIdx.x;
+    const unsigned entry = F.tileOrder ? F.tileOrder[blockIdx.x] : blockIdx.x;
+    if (entry == ORDER_NOTHING)
+        return;
+    const int tile = (int)min(entry & ORDER_TILE_MASK, (unsigned)F.nbTiles - 1u);
+    const int part = (int)((entry >> ORDER_PART_SHIFT) & 7u); /* 0: the whole tile, 1-4: one 4 x 4 quadrant */
     unsigned long long clock0 = 0ull;
     if (F.tileClock || F.tileCost)
         clock0 = __builtin_amdgcn_s_memrealtime();
@@ -87,8 +100,11 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     const int x = tx * TILE + (lane & (TILE - 1));
     const int yLocal = ty * TILE + (lane >> 3);
     const int W = si.size.x;
-    const bool inside = (x < W) && (yLocal < F.nbRows);
-    const int index = inside ? yLocal * W + x : 0;
+    /* a quadrant wave: only the lanes of its quadrant take part; every lane's path is its own (the walks are
+     * wave-synchronous, not wave-dependent), so the pixels come out the same whichever wave renders them */
+    const bool mine = part == 0 || (((lane >> 2) & 1) | ((lane >> 5) << 1)) == part - 1;
+    const bool inside = mine && (x < W) && (yLocal < F.nbRows);
+    const int index0 = inside ? yLocal * W + x : 0;
     const int yGlobal = F.firstRow + yLocal;
     const int gindex = yGlobal * W + x; /* global pixel index: random-buffer addressing */
 
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     if (inside && si.pathTracingIteration > 0 && si.pathTracingIteration <= NB_MAX_ITERATIONS)
     {
         /* progressive refinement: skip pixels whose previous pass ended early (CRT:454-458) */
-        id = ids[index];
+        id = ids[index0];
         if (si.pathTracingIteration > id.y && id.w == 0)
             active = false;
     }
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
      * depth-of-field jitter of the accumulation passes (CRT:470-479) */
     if (F.ppi.type != ppe_depthOfField && si.pathTracingIteration >= NB_MAX_ITERATIONS)
     {
-        const float previousDepth = active ? pp[index].colorInfo.w : 0.f;
+        const float previousDepth = active ? pp[index0].colorInfo.w : 0.f;
         float a = (F.ppi.param1 / 20000.f);
         long rindex = (long)gindex + si.timestamp % (MAX_BITMAP_SIZE - 2);
         rayO.x += rnd(S, rindex) * previousDepth * a;
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
             {
                 const int rindex = (gindex + si.timestamp) % (MAX_BITMAP_SIZE - 3);
                 const float a = (float)si.pathTracingIteration / (float)si.maxPathTracingIterations;
-                const float depth = active ? pp[index].colorInfo.w : 0.f;
+                const float depth = active ? pp[index0].colorInfo.w : 0.f;
                 rD.x += rnd(S, rindex) * depth * F.ppi.param2 * a;
                 rD.y += rnd(S, rindex + 1) * depth * F.ppi.param2 * a;
                 rD.z += rnd(S, rindex + 2) * depth * F.ppi.param2 * a;
@@ -272,9 +288,20 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
             color = color + c;
     }
 
+    /* The pixel's coordinates once more, from the wave's tile number and the lane's position in the wave,
+     * through values the compiler cannot identify with the ones above: what the prologue computed would
+     * otherwise stay alive - in vector registers, in practice in scratch - through the whole path trace
+     * just to address the stores below. */
+    int tileAgain = tile, partAgain = part, laneAgain = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+s"(tileAgain), "+s"(partAgain), "+v"(laneAgain));
+    const int xAgain = (tileAgain % F.tilesX) * TILE + (laneAgain & (TILE - 1));
+    const int yAgain = (tileAgain / F.tilesX) * TILE + (laneAgain >> 3);
+    const int index = ((xAgain < si.size.x) && (yAgain < F.nbRows)) ? yAgain * si.size.x + xAgain : 0;
+    const int gindexAgain = (F.firstRow + yAgain) * si.size.x + xAgain;
+
     if ((!plainStore || vision) && si.advancedIllumination == aiRandomIllumination)
     {
-        int rindex = (gindex + si.timestamp) % MAX_BITMAP_SIZE;
+        int rindex = (gindexAgain + si.timestamp) % MAX_BITMAP_SIZE;
         float rv = rnd(S, rindex);
         color.x += si.backgroundColor.x * rv * 5.f;
         color.y += si.backgroundColor.y * rv * 5.f;
@@ -349,13 +376,19 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
         }
     }
 
-    if (F.tileClock && lane == 0)
+    if (F.tileClock && laneAgain == 0)
     {
-        F.tileClock[2 * tile] = clock0;
-        F.tileClock[2 * tile + 1] = __builtin_amdgcn_s_memrealtime();
+        F.tileClock[2 * tileAgain] = clock0;
+        F.tileClock[2 * tileAgain + 1] = __builtin_amdgcn_s_memrealtime();
     }
-    if (F.tileCost && lane == 0) /* what this tile cost, for the launch order of the next frames */
-        F.tileCost[tile] = (unsigned)(__builtin_amdgcn_s_memrealtime() - clock0);
+    if (F.tileCost && laneAgain == 0) /* what this tile cost, for the launch order of the next frames */
+    {
+        /* a quadrant takes about 0.8 of what its whole tile takes (profiles/r1: DESIGN.md section 5): reported
+         * as twice its own time, a split tile stays among the expensive ones and stays split (four waves write
+         * the same word; any of them will do) */
+        const unsigned cost = (unsigned)(__builtin_amdgcn_s_memrealtime() - clock0);
+        F.tileCost[tileAgain] = partAgain ? 2u * cost : cost;
+    }
     if (COUNT)
     {
         unsigned int vals[4] = {cnt.closest, cnt.shadow, cnt.boxes, cnt.prims};
@@ -527,10 +560,17 @@ __device__ unsigned orderSerial = 0u;
  * runs.  Every cost is therefore read from `cost` exactly ONCE, into `snapshot` (private to the sort, written
  * and read by this workgroup only); maximum, histogram and scatter all work on that one stable copy, so the
  * histogram and the scatter agree and `order` is a permutation of 0..n-1 whatever is being stored meanwhile. */
+/* The tiles that are the frame's critical path (criterion below), at most SPLIT_TILES_MAX of them, are launched
+ * as four quadrant waves each, first of all: a frame is as long as its longest wave (the 100k-triangle mesh: one tile
+ * seen at a grazing angle took the whole 0.78 ms of the frame), and a 4 x 4 quadrant of such a tile takes
+ * about 0.6 of the tile's time.  `order` therefore holds n + 3 * SPLIT_TILES_MAX entries: 4 per split tile,
+ * one per other tile, ORDER_NOTHING to the end. */
 __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsigned *__restrict__ snapshot,
                                                       unsigned *__restrict__ order, int n,
                                                       volatile unsigned *hostStats, int sort)
 {
+    __shared__ unsigned nbSplit;
+    __shared__ unsigned splitClass;
     __shared__ unsigned bins[1024];
     __shared__ unsigned scan[1024];
     __shared__ unsigned maxCost;
@@ -611,7 +651,39 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
         __syncthreads();
     }
     bins[1023 - t] = scan[t] - mine; /* first slot of this bin */
+    /* which classes are split: those above the class of twice the mean cost, as far down as SPLIT_TILES_MAX
+     * tiles go (whole classes only: the split tiles are then a prefix of the order) */
+    if (t == 0)
+    {
+        nbSplit = 0u;
+        splitClass = 64u;
+    }
     __syncthreads();
+    if (t < 64)
+    {
+        /* tiles in classes >= c = inclusive scan at the end of class c in descending order: bin (c << 4) is the
+         * last of class c's sixteen sub-bins there, scan[1023 - (c << 4)] counts everything up to and including it */
+        /* worth splitting: a tile that alone takes more than 0.8 of what the whole frame would take if its
+         * work were spread evenly over the chip's 4096 wave slots (256 CUs x 16 resident waves of this
+         * kernel) - such a tile IS the frame's critical path - and more than twice the mean.  A frame whose
+         * longest tile is short against that (Cornell: 0.1 ms of 0.35; the molecule: 0.5 of 1.0) is bound by
+         * throughput, and there the 3.2 x work of four quadrant waves is a loss; so it is with several frames
+         * in flight, which hide a critical path behind the next frame (sort == 2: no split). */
+        const unsigned c = (unsigned)t;
+        const float mean = (float)sumCost / (float)max(n, 1);
+        const float critical = fmaxf(2.f * mean, (float)sumCost / 5120.f);
+        const unsigned above = min(63u, (unsigned)(critical * toClass)) + 1u;
+        const unsigned upTo = scan[1023 - (c << 4)];
+        if (sort == 1 && c >= above && c < 64u && upTo <= (unsigned)SPLIT_TILES_MAX)
+            atomicMin(&splitClass, c);
+    }
+    __syncthreads();
+    if (t == 0)
+        nbSplit = splitClass < 64u ? scan[1023 - (splitClass << 4)] : 0u;
+    __syncthreads();
+    const unsigned split = nbSplit;
+    for (int i = n + 3 * (int)split + t; i < n + 3 * SPLIT_TILES_MAX; i += 1024)
+        order[i] = ORDER_NOTHING;
     for (int base = 0; base < n; base += BATCH * 1024)
     {
         unsigned c[BATCH];
@@ -628,7 +700,12 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
             if (i < n)
             {
                 const unsigned b = (min(63u, (unsigned)((float)c[k] * toClass)) << 4) | ((unsigned)i & 15u);
-                order[atomicAdd(&bins[b], 1u)] = (unsigned)i;
+                const unsigned at = atomicAdd(&bins[b], 1u); /* position in descending order of cost */
+                if (at < split)
+                    for (unsigned q = 0; q < 4u; ++q)
+                        order[4u * at + q] = (unsigned)i | ((q + 1u) << ORDER_PART_SHIFT);
+                else
+                    order[at + 3u * split] = (unsigned)i;
             }
         }
     }
@@ -1392,10 +1469,12 @@ void flushGeometry()
     pullGeometry();
     auto rowsOfInts = [](size_t n) { return (unsigned)((n + 3) / 4); };
     unsigned row = 0;
+    /* each node list is followed by one pad record: the walk requests the record after the node it tests
+     * (rt_device.h advanceTidy), after the last node too */
     g.offBoxes = row;
-    row += (unsigned)g.hostBoxes.size();
+    row += (unsigned)g.hostBoxes.size() + 2u;
     g.offBoxesCompact = row;
-    row += (unsigned)g.hostBoxesCompact.size();
+    row += (unsigned)g.hostBoxesCompact.size() + 2u;
     row = (row + 3u) & ~3u; /* primitive records start on a 64-byte line */
     g.offPrims = row;
     row += (unsigned)g.hostPrims.size();
@@ -1613,7 +1692,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             for (DeviceBuffer *b : {&g.tileCost, &g.tileCostSnapshot, &g.tileOrder, &g.tileOrder2})
             {
                 const void *before = b->ptr;
-                reserve(*b, (size_t)grid.x * sizeof(unsigned));
+                reserve(*b, ((size_t)grid.x + 3 * SPLIT_TILES_MAX) * sizeof(unsigned));
                 if (ok() && b->ptr != before)
                     HIPCHECK(hipMemset(b->ptr, 0, b->bytes));
             }
@@ -1650,7 +1729,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             DeviceBuffer &orderOut = target ? g.tileOrder2 : g.tileOrder;
             hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, stream, (const unsigned *)g.tileCost.ptr,
                                (unsigned *)g.tileCostSnapshot.ptr, (unsigned *)orderOut.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev,
-                               sort ? 1 : 0);
+                               sort ? (twoFlights() ? 2 : 1) : 0);
             HIPCHECK(hipGetLastError());
             if (sort)
             {
@@ -1723,7 +1802,11 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     }
     else
         HIPCHECK(hipMemsetAsync(g.counters.ptr, 0, 8 * sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(fn, grid, block, ldsBytes, stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
+    /* the ordered launch has a fixed number of extra workgroups for the quadrant waves of split tiles
+     * (k_orderTiles); the ones the order does not use return at once */
+    F.nbTiles = (int)grid.x;
+    const dim3 launchGrid(F.tileOrder ? grid.x + 3u * SPLIT_TILES_MAX : grid.x);
+    hipLaunchKernelGGL(fn, launchGrid, block, ldsBytes, stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
     HIPCHECK(hipGetLastError());
     if (e0)
     {
