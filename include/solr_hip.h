@@ -112,6 +112,27 @@ void solr_hip_synchronize(void);
  * firstRow); d2h_bitmap places it at its position in a full-size host image. */
 void solr_hip_set_strip(int firstRow, int nbRows);
 
+/* Multi-GPU without any framework: one process per GPU, the frame split into row strips as the reference
+ * splits it over the devices of its one process (CudaRayTracer.cu:1694-1696, 1709-1815), the strips sent
+ * to one root with RCCL (xGMI) where the reference copies them through the host (d2h_bitmap :1647-1672).
+ *   solr_hip_strip_rows       the rows of rank r of n (contiguous strips, the last absorbs the remainder)
+ *   solr_hip_comm_unique_id   rank 0: 128 bytes to hand to every other rank (ncclGetUniqueId)
+ *   solr_hip_comm_init        every rank, after initialize_scene: joins the communicator (ncclCommInitRank)
+ *   solr_hip_gather_strips    after cudaRender, every rank, every frame: this rank's strip -> root, enqueued on
+ *                             the stream that rendered the frame (one grouped ncclSend / ncclRecv per peer);
+ *                             returns at once
+ *   solr_hip_gathered_frame   root: device pointer of the assembled height x width x 3 frame
+ *   solr_hip_d2h_gathered     root: waits for the gather and copies the assembled frame to the host
+ *   solr_hip_comm_finalize    leaves the communicator
+ * All return 0, or -1 with solr_hip_last_error set.  RCCL is loaded when the first of them is called. */
+void solr_hip_strip_rows(int rank, int world, int height, int *firstRow, int *nbRows, int *rowsPerRank);
+int solr_hip_comm_unique_id(void *id128);
+int solr_hip_comm_init(int rank, int world, const void *id128);
+int solr_hip_gather_strips(int root);
+void *solr_hip_gathered_frame(void);
+int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap);
+void solr_hip_comm_finalize(void);
+
 /* Device pointers of the current per-pixel buffers (strip-sized), for
  * collectives issued by the launcher (RCCL gather of the RGB strip). */
 void *solr_hip_device_bitmap(void);

@@ -15,6 +15,7 @@
  * Host layer: device memory, AoS -> plane re-packing, launches, timing.
  */
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -2909,5 +2910,217 @@ void solr_hip_memory_usage(unsigned long long bytes[4])
     bytes[3] = g.pp.bytes + g.ids.bytes + g.bitmap.bytes + g.randoms.bytes;
     for (int f = 0; f < MAX_FLIGHTS - 1; ++f)
         bytes[3] += g.ppX[f].bytes + g.idsX[f].bytes + g.bitmapX[f].bytes;
+}
+
+/* ---- multi-GPU from the C ABI: row strips gathered with RCCL, no torch ---------------------------------------
+ * The reference splits the frame over the GPUs of one process inside cudaRender (CudaRayTracer.cu:1709-1815)
+ * and assembles it with per-device copies in d2h_bitmap (:1647-1672).  Here it is one process per GPU: every
+ * process sets its strip (solr_hip_set_strip with the rows of solr_hip_strip_rows), renders, and
+ * solr_hip_gather_strips sends the strip to the root with RCCL - one grouped ncclSend / ncclRecv per peer over
+ * xGMI - ENQUEUED ON THE STREAM THAT RENDERED THE FRAME, right behind the kernel: no event, no host wait; with
+ * several frames in flight each flight has its own assembled-frame buffer on the root.  RCCL is loaded at run
+ * time (dlopen; the copy a framework already mapped is reused), so the library needs it only when these entry
+ * points are called.  The 128-byte id of ncclGetUniqueId travels from rank 0 to the others by whatever channel
+ * the host application has (a file, a socket, MPI, torch's store: INTEGRATION.md). */
+namespace
+{
+typedef struct ncclComm *ncclComm_t;
+typedef struct
+{
+    char internal[128];
+} ncclUniqueId;
+struct Rccl
+{
+    void *lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 0;
+    DeviceBuffer frame[MAX_FLIGHTS]; /* root: the assembled RGB8 frame of each flight */
+    int lastFlight = 0;
+} rccl;
+const int RCCL_UINT8 = 1; /* ncclUint8, rccl.h:460 */
+
+bool loadRccl()
+{
+    if (rccl.lib)
+        return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+            break;
+    if (!rccl.lib)
+    {
+        setError(-1, "RCCL (librccl.so) could not be loaded", __FILE__, __LINE__);
+        return false;
+    }
+    rccl.GetUniqueId = (decltype(rccl.GetUniqueId))dlsym(rccl.lib, "ncclGetUniqueId");
+    rccl.CommInitRank = (decltype(rccl.CommInitRank))dlsym(rccl.lib, "ncclCommInitRank");
+    rccl.CommDestroy = (decltype(rccl.CommDestroy))dlsym(rccl.lib, "ncclCommDestroy");
+    rccl.GroupStart = (decltype(rccl.GroupStart))dlsym(rccl.lib, "ncclGroupStart");
+    rccl.GroupEnd = (decltype(rccl.GroupEnd))dlsym(rccl.lib, "ncclGroupEnd");
+    rccl.Send = (decltype(rccl.Send))dlsym(rccl.lib, "ncclSend");
+    rccl.Recv = (decltype(rccl.Recv))dlsym(rccl.lib, "ncclRecv");
+    rccl.GetErrorString = (decltype(rccl.GetErrorString))dlsym(rccl.lib, "ncclGetErrorString");
+    if (!rccl.GetUniqueId || !rccl.CommInitRank || !rccl.CommDestroy || !rccl.GroupStart || !rccl.GroupEnd ||
+        !rccl.Send || !rccl.Recv)
+    {
+        setError(-1, "librccl.so lacks an entry point the strip gather needs", __FILE__, __LINE__);
+        dlclose(rccl.lib);
+        rccl.lib = nullptr;
+        return false;
+    }
+    return true;
+}
+
+bool rcclOk(int result, const char *what)
+{
+    if (result == 0)
+        return true;
+    std::string text = std::string(what) + ": " + (rccl.GetErrorString ? rccl.GetErrorString(result) : "RCCL error");
+    setError(-1, text.c_str(), __FILE__, __LINE__);
+    return false;
+}
+} // namespace
+
+/* rows [first, first + count) of a `height`-row image for rank `rank` of `world`, and the common strip height:
+ * contiguous strips like the reference's (CudaRayTracer.cu:1694-1696), the last one absorbing the remainder;
+ * trailing ranks get no row when there are more ranks than rows to share out (solr_hip_set_strip(first, 0)) */
+void solr_hip_strip_rows(int rank, int world, int height, int *first, int *count, int *rowsPerRank)
+{
+    const int per = world > 0 ? (height + world - 1) / world : height;
+    const int f = rank * per;
+    int c = height - f;
+    c = c < 0 ? 0 : (c > per ? per : c);
+    if (first)
+        *first = f;
+    if (count)
+        *count = c;
+    if (rowsPerRank)
+        *rowsPerRank = per;
+}
+
+int solr_hip_comm_unique_id(void *id128)
+{
+    if (!id128 || !loadRccl())
+        return -1;
+    ncclUniqueId id;
+    if (!rcclOk(rccl.GetUniqueId(&id), "ncclGetUniqueId"))
+        return -1;
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return 0;
+}
+
+int solr_hip_comm_init(int rank, int world, const void *id128)
+{
+    if (!ready("solr_hip_comm_init") || !loadRccl())
+        return -1;
+    ARGCHECK(id128 != nullptr && world >= 1 && rank >= 0 && rank < world, "solr_hip_comm_init: bad arguments");
+    ARGCHECK(rccl.comm == nullptr, "solr_hip_comm_init: a communicator exists already");
+    if (!ok())
+        return -1;
+    HIPCHECK(hipSetDevice(g.device));
+    ncclUniqueId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    if (!rcclOk(rccl.CommInitRank(&rccl.comm, world, id, rank), "ncclCommInitRank"))
+    {
+        rccl.comm = nullptr;
+        return -1;
+    }
+    rccl.rank = rank;
+    rccl.world = world;
+    return 0;
+}
+
+/* the strip of the frame rendered last -> `root`, on that frame's stream.  Every rank calls it once per frame,
+ * in the same order of frames.  Returns immediately. */
+int solr_hip_gather_strips(int root)
+{
+    if (!ready("solr_hip_gather_strips"))
+        return -1;
+    ARGCHECK(rccl.comm != nullptr, "solr_hip_gather_strips: no communicator (solr_hip_comm_init)");
+    ARGCHECK(root >= 0 && root < rccl.world, "solr_hip_gather_strips: no such root");
+    ARGCHECK(g.width > 0 && g.height > 0, "solr_hip_gather_strips: no frame was rendered");
+    if (!ok())
+        return -1;
+    const int flight = g.current;
+    const hipStream_t stream = flightStream(flight);
+    const size_t rowBytes = (size_t)g.width * SOLR_COLOR_DEPTH;
+    int first = 0, count = 0, per = 0;
+    solr_hip_strip_rows(rccl.rank, rccl.world, g.height, &first, &count, &per);
+    ARGCHECK(rccl.world == 1 || (g.nbRows == count && (count == 0 || g.firstRow == first)),
+             "solr_hip_gather_strips: this process's strip is not the one solr_hip_strip_rows gives its rank");
+    if (!ok())
+        return -1;
+    if (rccl.world == 1) /* one process: the strip is whatever was set, the "gather" a copy into the frame */
+    {
+        first = g.nbRows >= 0 ? g.firstRow : 0;
+        count = stripRows();
+    }
+    const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr;
+    if (rccl.rank == root)
+    {
+        reserve(rccl.frame[flight], (size_t)g.height * rowBytes);
+        if (!ok())
+            return -1;
+    }
+    bool fine = rcclOk(rccl.GroupStart(), "ncclGroupStart");
+    if (fine && rccl.rank == root)
+        for (int r = 0; r < rccl.world && fine; ++r)
+        {
+            int rf = first, rc = count;
+            if (rccl.world > 1)
+                solr_hip_strip_rows(r, rccl.world, g.height, &rf, &rc, nullptr);
+            if (rc > 0)
+                fine = rcclOk(rccl.Recv((char *)rccl.frame[flight].ptr + (size_t)rf * rowBytes, (size_t)rc * rowBytes,
+                                        RCCL_UINT8, r, rccl.comm, stream),
+                              "ncclRecv");
+        }
+    if (fine && count > 0)
+        fine = rcclOk(rccl.Send(src, (size_t)count * rowBytes, RCCL_UINT8, root, rccl.comm, stream), "ncclSend");
+    if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd"))
+        fine = false;
+    rccl.lastFlight = flight;
+    return fine ? 0 : -1;
+}
+
+/* root: the assembled frame of the gather issued last (device memory, height x width x 3; valid once the
+ * stream has run the gather - solr_hip_d2h_gathered waits for it) */
+void *solr_hip_gathered_frame(void)
+{
+    return rccl.frame[rccl.lastFlight].ptr;
+}
+
+int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap)
+{
+    if (!ready("solr_hip_d2h_gathered"))
+        return -1;
+    ARGCHECK(hostBitmap != nullptr && rccl.frame[rccl.lastFlight].ptr != nullptr,
+             "solr_hip_d2h_gathered: nothing was gathered on this rank");
+    if (!ok())
+        return -1;
+    const hipStream_t stream = flightStream(rccl.lastFlight);
+    HIPCHECK(hipMemcpyAsync(hostBitmap, rccl.frame[rccl.lastFlight].ptr, (size_t)g.height * g.width * SOLR_COLOR_DEPTH,
+                            hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    return ok() ? 0 : -1;
+}
+
+void solr_hip_comm_finalize(void)
+{
+    if (rccl.comm)
+    {
+        (void)hipDeviceSynchronize();
+        (void)rccl.CommDestroy(rccl.comm);
+        rccl.comm = nullptr;
+    }
+    for (DeviceBuffer &b : rccl.frame)
+        release(b);
+    rccl.world = 0;
 }
 }
