@@ -61,6 +61,10 @@ def parse():
                          "--scene height_field, cfg3 = --scene molecule, cfg4 = Cornell 3840x2160 through passes 0...73 "
                          "(refinement + 64 accumulated samples, natural depth of field, ambient-occlusion kernel): a "
                          "step is then one pass of that cycle")
+    ap.add_argument("--native-gather", action="store_true",
+                    help="N > 1: gather the strips with RCCL called from the engine's C ABI (solr_hip_gather_strips, on "
+                         "the stream that rendered the frame) instead of torch.distributed's gather; torch then only "
+                         "carries the rendezvous, the barrier and the timing reduction (gloo).  Also SOLR_BENCH_NATIVE_GATHER=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -94,7 +98,16 @@ def main():
     # SOLR_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, strip binding, gather) with a
     # single rank: a 1-GPU box can then exercise it against RCCL
     distributed = world > 1 or os.environ.get("SOLR_BENCH_FORCE_DIST") == "1"
-    if distributed:
+    native = distributed and (args.native_gather or os.environ.get("SOLR_BENCH_NATIVE_GATHER") == "1")
+    if native:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="gloo")       # control plane only: rendezvous, barrier, timing reduction
+    elif distributed:
         # torch BEFORE the engine library: torch brings its own copy of the HIP runtime and importing it
         # into a process in which another copy is already initialised hangs
         import torch
@@ -139,7 +152,12 @@ def main():
     if not distributed:
         hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
     pipe = None
-    if distributed:
+    if native:
+        # the data path without torch: this rank's strip, K frames in flight on the engine's own streams, and
+        # behind every frame the library's own RCCL gather on that frame's stream
+        hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
+        hip.solr_hip_set_strip(first_row, nb_rows)
+    elif distributed:
         # every frame: render on one of the engine's streams, then the gather in order on that same
         # stream, while the next frames render on the other streams (StripPipeline)
         pipe = solr.StripPipeline(dist, torch, hip, W, H, rank, world, local_rank=local_rank,
@@ -161,16 +179,32 @@ def main():
             pass_counter[0] += 1
         hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
 
+    if native:
+        # the communicator: rank 0's id to everybody over the control plane, then ncclCommInitRank in the library
+        uid = C.create_string_buffer(128)
+        if rank == 0 and hip.solr_hip_comm_unique_id(uid) != 0:
+            k.check(-1, "solr_hip_comm_unique_id")
+        box = [uid.raw]
+        dist.broadcast_object_list(box, src=0)
+        uid = C.create_string_buffer(box[0], 128)
+        if hip.solr_hip_comm_init(rank, world, uid) != 0:
+            k.check(-1, "solr_hip_comm_init")
+
     def frame():
         # N = 1: the renderer alone.  N > 1: the renderer writes RGB8 straight into a strip buffer and the
-        # single collective of the path - strips -> rank 0, RCCL over xGMI - follows (StripPipeline)
-        if pipe is None:
+        # single collective of the path - strips -> rank 0, RCCL over xGMI - follows (StripPipeline, or the
+        # library's own gather)
+        if native:
+            render()
+            if hip.solr_hip_gather_strips(0) != 0:
+                k.check(-1, "solr_hip_gather_strips")
+        elif pipe is None:
             render()
         else:
             pipe.frame(render)
 
     def sync():
-        if distributed:
+        if pipe is not None:
             pipe.drain()
         else:
             hip.solr_hip_synchronize()
@@ -299,7 +333,7 @@ def main():
     rays_total = rays_local
     if distributed:
         t = torch.tensor([elapsed, float(rays_local), kernel_ms / max(launches.value, 1)], dtype=torch.float64,
-                         device="cuda")
+                         device="cpu" if native else "cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -315,6 +349,8 @@ def main():
     else:
         kernel_avg_ms = kernel_ms / max(launches.value, 1)
 
+    if native:
+        hip.solr_hip_comm_finalize()
     if rank != 0:
         dist.destroy_process_group()
         C.CDLL(None).fflush(None)
@@ -355,6 +391,9 @@ def main():
                    "host_issue_ms_per_step_rank0": round((t_issued - t0) / args.steps * 1e3, 4),
                    "cost_ordered_launch_rank0": bool(hip.solr_hip_tile_scheduling_active()),
                    "frames_in_flight": int(hip.solr_hip_get_frames_in_flight()),
+                   "gather": ("none (one GPU)" if not distributed else
+                              "RCCL from the engine's C ABI (solr_hip_gather_strips)" if native else
+                              "torch.distributed gather (RCCL)"),
                    "parallelism": "tile%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
