@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py.  Never imported by the sol-r_amd package.
-Parity status (pinned at image level against the reference's OpenCL renderer, not bit for bit): solr_oracle.h.
+Parity status (pinned bit for bit to the reference's own functions through oracle/ref_probes.cl): solr_oracle.h.
 """
 import ctypes as C
 import os

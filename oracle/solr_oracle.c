@@ -1,11 +1,11 @@
 /*
  * solr_oracle.c - CPU restatement of Sol-R's per-pixel rendering path.
  *
- * TEST INFRASTRUCTURE ONLY (see solr_oracle.h).  Parity status: pinned at
- * image level against the reference's OpenCL renderer run on the GPU
- * (tests/test_reference_opencl.py) and, per function, against hand-derived
- * known answers; not bit for bit against the CUDA engine it restates, which
- * cannot be built here (solr_oracle.h).
+ * TEST INFRASTRUCTURE ONLY (see solr_oracle.h).  Parity status: pinned bit for
+ * bit, function by function, to outputs of the reference's own OpenCL engine
+ * (oracle/ref_probes.cl, tests/test_reference_probes.py) through the OpenCL
+ * dialect below; the statements that differ in the CUDA engine it restates by
+ * default are marked `g_cl` and cite both files (solr_oracle.h).
  *
  * Every function cites the reference file:line it restates.  "ref:" paths are
  * relative to the reference tree, with

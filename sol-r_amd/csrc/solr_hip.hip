@@ -718,9 +718,25 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
                                                           const float *__restrict__ randoms, long nbRandoms,
                                                           unsigned char *__restrict__ bitmap)
 {
+    /* The 256 taps of a pixel sit at x + X * param2 * randoms[i % wh] / 10.f, y + Y * param2 * randoms[(i + 100)
+     * % wh] / 10.f (CRT:1146-1153): the offsets depend on the tap, not on the pixel.  The workgroup's 256
+     * threads evaluate one tap's pair each - the same expressions, the two correctly rounded divisions
+     * included - and every pixel then adds them to its coordinates: 2 divisions per thread instead of 512. */
+    __shared__ float tapX[256], tapY[256];
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     const int W = si.size.x;
     const int wh = W * nbRows;
+    {
+        const int i = threadIdx.x; /* tap i: X = -16 + 2 * (i / 16), Y = -16 + 2 * (i % 16), in loop order */
+        const int X = -16 + 2 * (i >> 4), Y = -16 + 2 * (i & 15);
+        const int ix = i % wh;
+        const int iy = (i + 100) % wh;
+        const float rx = (ix < nbRandoms) ? randoms[ix] : 0.f;
+        const float ry = (iy < nbRandoms) ? randoms[iy] : 0.f;
+        tapX[i] = X * ppi.param2 * rx / 10.f;
+        tapY[i] = Y * ppi.param2 * ry / 10.f;
+    }
+    __syncthreads();
     if (index >= wh)
         return;
     const int x = index % W;
@@ -728,29 +744,21 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
     float occ = 0.f;
     float4 local = pp[index].colorInfo;
     float depth = local.w;
-    const int step = 16;
-    int i = 0;
     float c = 0.f;
-    for (int X = -step; X < step; X += 2)
-        for (int Y = -step; Y < step; Y += 2)
+    for (int i = 0; i < 256; ++i)
+    {
+        c += 1.f;
+        int xx = (int)(x + tapX[i]);
+        int yy = (int)(y + tapY[i]);
+        if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
         {
-            int ix = i % wh;
-            int iy = (i + 100) % wh;
-            ++i;
-            c += 1.f;
-            float rx = (ix < nbRandoms) ? randoms[ix] : 0.f;
-            float ry = (iy < nbRandoms) ? randoms[iy] : 0.f;
-            int xx = (int)(x + (X * ppi.param2 * rx / 10.f));
-            int yy = (int)(y + (Y * ppi.param2 * ry / 10.f));
-            if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
-            {
-                int localIndex = yy * W + xx;
-                if (pp[localIndex].colorInfo.w >= depth)
-                    occ += 1.f;
-            }
-            else
+            int localIndex = yy * W + xx;
+            if (pp[localIndex].colorInfo.w >= depth)
                 occ += 1.f;
         }
+        else
+            occ += 1.f;
+    }
     occ /= (float)c;
     occ += 0.3f;
     v3 col = V(local.x, local.y, local.z);
