@@ -916,12 +916,58 @@ SOLR_DEV int waveMinInt(int v)
 
 #define SOLR_CURSOR_DONE 0x7fffffff
 
-/* Uniform primitive test shared by both walks.  `head` holds rows 0-1 of the
- * record (p0 + tag, size + materialId); the other rows are fetched per type. */
-template <bool SHADOW, int FEAT>
-SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const Row2 &head, int tag,
-                            const WalkRay &ray, Hit &h)
+/* What a walk holds of the primitive it is testing.  The first primitive of a leaf comes with the leaf's record
+ * (scene_layout.h: one 64-byte scalar load brings head, the two rows its test reads next, and the start
+ * index); further primitives of the leaf bring their head and fetch the other rows when a test asks. */
+struct PrimRec
 {
+    Row2 head;   /* rows 0-1: p0 | tag, size | materialId */
+    float4 c, d; /* packed only: p1 | index and p2 | start - or, plane class, n0 | index and average colour */
+    int pi;
+    bool packed; /* wave-uniform */
+};
+SOLR_DEV bool planeClass(int type)
+{
+    return !(type == ptSphere || type == ptEnvironment || type == ptCylinder || type == ptCone || type == ptEllipsoid ||
+             type == ptTriangle);
+}
+SOLR_DEV v3 recP1(const Scene &S, const PrimRec &r) { return r.packed ? V4(r.c) : V4(primRow(S, r.pi, ROW_P1_INDEX)); }
+SOLR_DEV v3 recP2(const Scene &S, const PrimRec &r) { return r.packed ? V4(r.d) : V4(primRow(S, r.pi, ROW_P2)); }
+SOLR_DEV v3 recPlaneNormal(const Scene &S, const PrimRec &r) { return r.packed ? V4(r.c) : V4(primRow(S, r.pi, ROW_N0)); }
+SOLR_DEV float recPlaneAverage(const Scene &S, const PrimRec &r) { return r.packed ? r.d.x : primRow(S, r.pi, ROW_P2).w; }
+SOLR_DEV int recIndex(const Scene &S, const PrimRec &r)
+{
+    return asint(r.packed ? r.c.w : primRow(S, r.pi, ROW_P1_INDEX).w);
+}
+/* primitive k of the leaf whose record is L (k == 0) or whose first primitive is `start` */
+SOLR_DEV PrimRec leafPrimitive(const Scene &S, const SceneInfo &si, const Row4 &L, int start, int k)
+{
+    PrimRec r;
+    r.pi = start + k;
+    if (k == 0)
+    {
+        r.head.a = L.a;
+        r.head.b = L.b;
+        r.c = L.c;
+        r.d = L.d;
+    }
+    else
+    {
+        r.head = primHead(S, r.pi);
+        r.c = r.d = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    /* without extended geometry every primitive is tested as a triangle (GI:743-747): a plane-class record's
+     * packed rows hold its normal and colour, not p1 / p2 */
+    r.packed = (k == 0) && (si.extendedGeometry || !planeClass(asint(r.head.a.w) & PRIM_TYPE_MASK));
+    return r;
+}
+
+/* Uniform primitive test shared by both walks. */
+template <bool SHADOW, int FEAT>
+SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, const PrimRec &rec, int tag, const WalkRay &ray, Hit &h)
+{
+    const int pi = rec.pi;
+    const Row2 &head = rec.head;
     const int type = tag & PRIM_TYPE_MASK;
     const v3 p0 = V4(head.a);
     const v3 size = V4(head.b);
@@ -947,8 +993,8 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const R
     {
         if (!(FEAT & F_CYL))
             return false;
-        const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
-        const v3 p2 = V4(primRow(S, pi, ROW_P2));
+        const v3 p1 = recP1(S, rec);
+        const v3 p2 = recP2(S, rec);
         const v3 n1 = V4(primRow(S, pi, ROW_N1));
         return cylinderIntersection(si, p0, p1, p2, n1, size, ray, h);
     }
@@ -960,8 +1006,8 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const R
     {
         if (!(FEAT & F_TRI))
             return false;
-        const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
-        const v3 p2 = V4(primRow(S, pi, ROW_P2));
+        const v3 p1 = recP1(S, rec);
+        const v3 p2 = recP2(S, rec);
         const v3 n0 = V4(primRow(S, pi, ROW_N0));
         const v3 n1 = V4(primRow(S, pi, ROW_N1));
         const v3 n2 = V4(primRow(S, pi, ROW_N2));
@@ -971,7 +1017,7 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const R
     {
         if (!(FEAT & (F_PLANE | F_TEX)))
             return false;
-        const v3 n0 = V4(primRow(S, pi, ROW_N0));
+        const v3 n0 = recPlaneNormal(S, rec);
         const int materialId = asint(head.b.w);
         PlaneMaterial pm;
         pm.wireframe = (tag & PRIM_WIRE2) ? 2 : ((tag & PRIM_WIRE1) ? 1 : 0);
@@ -979,7 +1025,7 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, int pi, const R
         pm.emissive = (tag & PRIM_EMISSIVE) != 0;
         pm.textured = (tag & PRIM_TEXTURED) != 0;
         pm.materialId = materialId;
-        pm.averageColor = primRow(S, pi, ROW_P2).w;
+        pm.averageColor = recPlaneAverage(S, rec);
         return planeIntersection<(FEAT & F_TEX) != 0>(si, type, p0, size, n0, pm, S, materialId, ray, h);
     }
     }
@@ -1232,11 +1278,14 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             if (nbPrimitives <= 0)
                 continue;
         }
-        const int start = uniform(boxStart(S, leaf));
+        /* (readfirstlane: the compiler takes an inline-asm result for divergent and would fetch the record per lane) */
+        const Row4 L = leafRecord(S, uniform(leaf));
+        const int start = uniform(asint(L.d.w));
         for (int k = 0; k < nbPrimitives; ++k)
         {
-            const int pi = start + k;
-            const Row2 head = primHead(S, pi);
+            const PrimRec rec = leafPrimitive(S, si, L, start, k);
+            const int pi = rec.pi;
+            const Row2 &head = rec.head;
             const int tag = uniform(asint(head.a.w));
             const int materialId = uniform(asint(head.b.w));
             /* GI:704-705 */
@@ -1280,8 +1329,8 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 h.intersection = V(0.f, 0.f, 0.f);
                 bool i = false;
                 const v3 p0 = V4(head.a);
-                const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
-                const v3 p2 = V4(primRow(S, pi, ROW_P2));
+                const v3 p1 = recP1(S, rec);
+                const v3 p2 = recP2(S, rec);
                 if (lanes)
                     i = triangleHit(si, p0, p1, p2, r, h.intersection);
                 const float distance = length(h.intersection - r.o);
@@ -1310,7 +1359,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 h.normal = V(0.f, 0.f, 0.f);
                 h.areas = V(0.f, 0.f, 0.f);
                 h.shadowIntensity = 0.f;
-                const bool i = testPrimitive<false, FEAT>(S, si, pi, head, tag, r, h);
+                const bool i = testPrimitive<false, FEAT>(S, si, rec, tag, r, h);
                 const float distance = length(h.intersection - r.o);
                 if (i && distance > si.geometryEpsilon && distance < minDistance)
                 {
@@ -1370,13 +1419,16 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         else if (!stepGeneral<COUNT>(S, r, fastBoxes, minDistance, cursor, cur, node, nbPrimitives, entered, cnt) ||
                  nbPrimitives <= 0)
             continue;
-        const int start = uniform(boxStart(S, leaf));
+        /* (readfirstlane: the compiler takes an inline-asm result for divergent and would fetch the record per lane) */
+        const Row4 L = leafRecord(S, uniform(leaf));
+        const int start = uniform(asint(L.d.w));
         for (int k = 0; k < nbPrimitives; ++k)
         {
-            const int pi = start + k;
-            const Row2 head = primHead(S, pi);
+            const PrimRec rec = leafPrimitive(S, si, L, start, k);
+            const int pi = rec.pi;
+            const Row2 &head = rec.head;
             const int tag = uniform(asint(head.a.w));
-            const int index = uniform(asint(primRow(S, pi, ROW_P1_INDEX).w));
+            const int index = uniform(recIndex(S, rec));
             /* GI:829-830 */
             const bool lanes = entered && result < si.shadowIntensity && index != lightId && index != objectId &&
                                (tag & PRIM_FAST0) != 0;
@@ -1410,8 +1462,8 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                 /* an opaque triangle shadows with intensity 1 whatever its normal (GI:880); with
                  * double-sided triangles the normal decides (GI:643-647) and the full test is used */
                 const v3 p0 = V4(head.a);
-                const v3 p1 = V4(primRow(S, pi, ROW_P1_INDEX));
-                const v3 p2 = V4(primRow(S, pi, ROW_P2));
+                const v3 p1 = recP1(S, rec);
+                const v3 p2 = recP2(S, rec);
                 if (lanes)
                     hit = triangleHit(si, p0, p1, p2, r, h.intersection);
                 h.shadowIntensity = 1.f;
@@ -1425,7 +1477,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                 }
             }
             else if (lanes)
-                hit = testPrimitive<true, FEAT>(S, si, pi, head, tag, r, h);
+                hit = testPrimitive<true, FEAT>(S, si, rec, tag, r, h);
             if (hit)
             {
                 const float l = length(h.intersection - r.o);

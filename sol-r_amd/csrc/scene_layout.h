@@ -11,6 +11,15 @@
  *     box node i        row 2i   = { min.x, min.y, min.z, max.z }        (x,y) (z,z) (x,y) pairs feed the
  *                       row 2i+1 = { max.x, max.y, bits(nbPrimitives), bits(skip) }   packed slab test
  *     boxStart[i]       int plane: first primitive of a leaf
+ *     leaf record i     rows 4i..4i+3 (one 64-byte line, one s_load_dwordx16), for a leaf node i the first
+ *                       primitive's test data and its index, so that entering a leaf costs ONE scalar-load
+ *                       latency instead of a chain of three (start index -> head record -> rows behind it):
+ *                         row 0 = { p0.xyz, bits(tag) }, row 1 = { size.xyz, bits(materialId) },
+ *                         row 2 = { p1.xyz, bits(index) }, row 3 = { p2.xyz, bits(start) };
+ *                       plane-class primitives (their tests read n0 and the colour-key average, not p1 / p2):
+ *                         row 2 = { n0.xyz, bits(index) }, row 3 = { average colour, 0, 0, bits(start) }.
+ *                       Built on the device from the primitive records (k_buildLeafRecords), after every
+ *                       upload and every device-side rotation.
  *     primitive i       row 8i   = { p0.xyz,   bits(tag) }         \ sphere / ellipsoid / plane tests
  *                       row 8i+1 = { size.xyz, bits(materialId) }  / read these 32 bytes only
  *                       row 8i+2 = { p1.xyz,   bits(index) }       \ + cylinder, triangle: one 64-byte
@@ -125,6 +134,7 @@ struct SceneArgs
     int nested;
     int orderedBoxes; /* every node has finite bounds with min <= max (sign-free slab test allowed) */
     long nbRandoms;
+    unsigned offLeaf; /* leaf records of the node list in use, rows */
 };
 
 /* Device view: everything is read through the CONSTANT address space.  The
@@ -156,6 +166,7 @@ struct Scene
     int nested; /* 1: skip pointers form nested intervals (validated on upload) */
     int orderedBoxes;
     long nbRandoms;
+    unsigned offLeaf;
 };
 
 __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
@@ -177,6 +188,7 @@ __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
     s.nested = a.nested;
     s.orderedBoxes = a.orderedBoxes;
     s.nbRandoms = a.nbRandoms;
+    s.offLeaf = a.offLeaf;
     return s;
 }
 
@@ -204,6 +216,23 @@ __device__ __forceinline__ Row2 ld8(cf4p p, unsigned row)
     r.b = make_float4(v[4], v[5], v[6], v[7]);
     return r;
 }
+struct Row4
+{
+    float4 a, b, c, d;
+};
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef const SOLR_CONST_AS f16v *cf16p;
+/* four consecutive rows (64 bytes, 64-byte aligned): one s_load_dwordx16 */
+__device__ __forceinline__ Row4 ld16(cf4p p, unsigned row)
+{
+    const f16v v = *(cf16p)((ccp)p + (row << 4));
+    Row4 r;
+    r.a = make_float4(v[0], v[1], v[2], v[3]);
+    r.b = make_float4(v[4], v[5], v[6], v[7]);
+    r.c = make_float4(v[8], v[9], v[10], v[11]);
+    r.d = make_float4(v[12], v[13], v[14], v[15]);
+    return r;
+}
 __device__ __forceinline__ int4 asint4(const float4 &v)
 {
     return make_int4(__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w));
@@ -216,6 +245,7 @@ __device__ __forceinline__ float4 nodeHi(const Row2 &n) { return make_float4(n.b
 __device__ __forceinline__ int nodeCount(const Row2 &n) { return __float_as_int(n.b.z); }
 __device__ __forceinline__ int nodeSkip(const Row2 &n) { return __float_as_int(n.b.w); }
 __device__ __forceinline__ int boxStart(const Scene &s, int i) { return ((cip)s.geo)[s.offBoxStart + (unsigned)i]; }
+__device__ __forceinline__ Row4 leafRecord(const Scene &s, int i) { return ld16(s.geo, s.offLeaf + 4u * (unsigned)i); }
 __device__ __forceinline__ float4 primRow(const Scene &s, int i, int row)
 {
     return ld4(s.geo, s.offPrims + 8u * (unsigned)i + (unsigned)row);

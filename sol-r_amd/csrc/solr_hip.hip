@@ -874,6 +874,40 @@ __device__ inline void rotateRow(float4 &v, float cx, float cy, float cz, const 
     v.z = rz + cz;
 }
 
+/* Leaf records (scene_layout.h): for every leaf of a node list, the first primitive's test data and index in
+ * one 64-byte line.  A function of the primitive records and the list's start indices alone: run after every
+ * upload of the arena and after every device-side rotation of the primitives. */
+__global__ __launch_bounds__(256) void k_buildLeafRecords(float4 *__restrict__ arena, unsigned offNodes, unsigned offStart,
+                                                         unsigned offPrims, unsigned offLeaf, int nbNodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbNodes)
+        return;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+    const int nb = __float_as_int(arena[offNodes + 2u * (unsigned)i + 1u].z);
+    if (nb > 0)
+    {
+        const int start = ((const int *)arena)[offStart + (unsigned)i];
+        const float4 *prim = arena + offPrims + 8u * (unsigned)start;
+        r0 = prim[ROW_P0_TYPE];
+        r1 = prim[ROW_SIZE_MAT];
+        r2 = prim[ROW_P1_INDEX];
+        r3 = prim[ROW_P2];
+        if (planeClass(__float_as_int(r0.w) & PRIM_TYPE_MASK))
+        {
+            const float4 n0 = prim[ROW_N0];
+            r2 = make_float4(n0.x, n0.y, n0.z, r2.w);
+            r3 = make_float4(r3.w, 0.f, 0.f, 0.f);
+        }
+        r3.w = __int_as_float(start);
+    }
+    float4 *out = arena + offLeaf + 4u * (unsigned)i;
+    out[0] = r0;
+    out[1] = r1;
+    out[2] = r2;
+    out[3] = r3;
+}
+
 __global__ __launch_bounds__(256) void k_rotatePrimitives(float4 *__restrict__ arena, unsigned offPrims, int nbPrimitives,
                                                           const unsigned char *__restrict__ movable,
                                                           const RotationArgs R)
@@ -1044,6 +1078,7 @@ struct Engine
     std::vector<float> materialAverage; /* (r + g + b) / 3.f per material id (plane colour key, GI:561) */
     int sceneFeatures = F_ALL & ~F_FULL; /* rt_device.h enum Feature, recomputed with the tags */
     unsigned offBoxes = 0, offBoxesCompact = 0, offBoxStart = 0, offBoxStartCompact = 0, offPrims = 0, offLights = 0;
+    unsigned offLeaf = 0, offLeafCompact = 0; /* leaf records of the two node lists (scene_layout.h) */
     unsigned offMatCold = 0;
     bool geometryDirty = true;
     int nbBoxesCompact = 0;
@@ -1470,6 +1505,23 @@ void retagPrimitives()
     g.geometryDirty = true;
 }
 
+/* the leaf records of both node lists from the primitive records as the arena holds them now */
+void buildLeafRecords()
+{
+    if (!ok() || !g.geometry.ptr)
+        return;
+    float4 *arena = (float4 *)g.geometry.ptr;
+    const int n = (int)(g.hostBoxes.size() / 2), nc = (int)(g.hostBoxesCompact.size() / 2);
+    if (n > 0)
+        hipLaunchKernelGGL(k_buildLeafRecords, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, arena, g.offBoxes,
+                           g.offBoxStart, g.offPrims, g.offLeaf, n);
+    if (nc > 0)
+        hipLaunchKernelGGL(k_buildLeafRecords, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, g.stream, arena,
+                           g.offBoxesCompact, g.offBoxStartCompact, g.offPrims, g.offLeafCompact, nc);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(g.stream));
+}
+
 /* assemble and upload the geometry arena from its host images (scene_layout.h) */
 void flushGeometry()
 {
@@ -1495,6 +1547,11 @@ void flushGeometry()
     row += rowsOfInts(g.hostBoxStartCompact.size());
     g.offBoxStart = startRow * 4;
     g.offBoxStartCompact = startRowCompact * 4;
+    row = (row + 3u) & ~3u; /* leaf records: one 64-byte line per node */
+    g.offLeaf = row;
+    row += 2u * (unsigned)g.hostBoxes.size() + 4u;
+    g.offLeafCompact = row;
+    row += 2u * (unsigned)g.hostBoxesCompact.size() + 4u;
     std::vector<float4> arena(std::max(row, 1u), make_float4(0.f, 0.f, 0.f, 0.f));
     auto put = [&](unsigned at, const void *src, size_t bytes) {
         if (bytes)
@@ -1507,6 +1564,7 @@ void flushGeometry()
     put(startRow, g.hostBoxStart.data(), g.hostBoxStart.size() * 4);
     put(startRowCompact, g.hostBoxStartCompact.data(), g.hostBoxStartCompact.size() * 4);
     upload(g.geometry, arena);
+    buildLeafRecords();
     if (ok())
         g.geometryDirty = false;
 }
@@ -1521,6 +1579,7 @@ SceneArgs makeScene(bool exactNodes)
     S.randoms = g.randoms.ptr;
     S.offBoxes = exactNodes ? g.offBoxes : g.offBoxesCompact;
     S.offBoxStart = exactNodes ? g.offBoxStart : g.offBoxStartCompact;
+    S.offLeaf = exactNodes ? g.offLeaf : g.offLeafCompact;
     S.offPrims = g.offPrims;
     S.offLights = g.offLights;
     S.offMatCold = g.offMatCold;
@@ -2501,6 +2560,7 @@ int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], 
     hipLaunchKernelGGL(k_rotatePrimitives, dim3((unsigned)((g.nbPrimitives + 255) / 256)), dim3(256), 0, g.stream,
                        (float4 *)g.geometry.ptr, g.offPrims, g.nbPrimitives, (const unsigned char *)g.movable.ptr, R);
     refitList(g.refitWalkLevels, g.offBoxesCompact, g.offBoxStartCompact, viewDistance);
+    buildLeafRecords(); /* the leaves' copies of their first primitive follow the primitives */
     g.exactStale = true;
     g.exactStaleViewDistance = viewDistance;
     HIPCHECK(hipGetLastError());
