@@ -504,7 +504,8 @@ enum Feature
     F_PLANE = 32,   /* axis planes, checkerboards, magic carpet */
     F_TEX = 64,     /* textured materials, ptCamera planes, textured skybox */
     F_FULL = 128,   /* global illumination + box-debug view */
-    F_ALL = 255
+    F_ALL = 255,
+    F_DEEP = 256    /* not a feature of the scene but of its node list: walk it with the three-bank loop (advanceTidy) */
 };
 
 struct Hit
@@ -1096,7 +1097,7 @@ SOLR_DEV bool stepGeneral(const Scene &S, const WalkRay &r, bool fastBoxes, floa
  *   - the wave's next node is one s_cselect on "mask != 0".
  * Hazards (gfx950): every SGPR a vector instruction reads here is written by the
  * scalar unit; v_cmpx results are only read back through s_mov from exec.
- * Fixed registers: s[64:86], v[58:63] (sub-registers of pairs cannot be named
+ * Fixed registers: s[64:94], v[58:63] (sub-registers of pairs cannot be named
  * through operands).  All scalar loads are drained before the statement ends.
  *
  * Returns the leaf (>= 0) with `entered` lanes and its primitive count, cur
@@ -1124,7 +1125,7 @@ SOLR_DEV PackedRay packRay(const WalkRay &r)
  *   LW<half>   test the node in this half's bank
  *   LE<half>   some lane entered: a leaf with primitives leaves the loop (LL), an inner node goes on at cur + 1
  *   LR<half>   the wave skipped to a node that is not cur + 1: fetch it into this half's bank, test it here */
-#define SOLR_WALK_HALF(SELF, OTHER, LOXY, ZZ, HIXY, NB, SKIP, SELF_REGS, OTHER_REGS, TAIL)                            \
+#define SOLR_WALK2_HALF(SELF, OTHER, LOXY, ZZ, HIXY, NB, SKIP, SELF_REGS, OTHER_REGS, TAIL)                            \
     "LW" SELF "_%=:\n"                                                                                                 \
     "s_waitcnt lgkmcnt(0)\n"                                                                                           \
     "s_add_i32 s85, %[cur], 1\n"                                                                                       \
@@ -1161,7 +1162,7 @@ SOLR_DEV PackedRay packRay(const WalkRay &r)
     "s_cbranch_scc1 LR" SELF "_%=\n"                                                                                   \
     TAIL
 
-#define SOLR_WALK_SIDE(SELF, OTHER, NB, SELF_REGS)                                                                     \
+#define SOLR_WALK2_SIDE(SELF, OTHER, NB, SELF_REGS)                                                                     \
     "LE" SELF "_%=:\n"                                                                                                 \
     "s_mov_b64 s[82:83], exec\n"                                                                                       \
     "s_mov_b64 exec, s[80:81]\n"                                                                                       \
@@ -1181,7 +1182,7 @@ SOLR_DEV PackedRay packRay(const WalkRay &r)
     "s_load_dwordx8 " SELF_REGS ", %[base], s84\n"                                                                     \
     "s_branch LW" SELF "_%=\n"
 
-SOLR_DEV int advanceTidy(const Scene &S, const PackedRay &p, float farDistance, int &cursor, int &cur,
+SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDistance, int &cursor, int &cur,
                          int &nbPrimitives, bool &entered)
 {
     const unsigned long base = (unsigned long)S.geo + ((unsigned long)S.offBoxes << 4);
@@ -1190,11 +1191,11 @@ SOLR_DEV int advanceTidy(const Scene &S, const PackedRay &p, float farDistance, 
     asm volatile("s_mov_b64 s[80:81], exec\n"
                  "s_lshl_b32 s84, %[cur], 5\n"
                  "s_load_dwordx8 s[64:71], %[base], s84\n"
-                 SOLR_WALK_HALF("A", "B", "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[64:71]", "s[72:79]", "")
-                 SOLR_WALK_HALF("B", "A", "s[72:73]", "s[74:75]", "s[76:77]", "s78", "s79", "s[72:79]", "s[64:71]",
+                 SOLR_WALK2_HALF("A", "B", "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[64:71]", "s[72:79]", "")
+                 SOLR_WALK2_HALF("B", "A", "s[72:73]", "s[74:75]", "s[76:77]", "s78", "s79", "s[72:79]", "s[64:71]",
                                 "s_branch LWA_%=\n")
-                 SOLR_WALK_SIDE("A", "B", "s70", "s[64:71]")
-                 SOLR_WALK_SIDE("B", "A", "s78", "s[72:79]")
+                 SOLR_WALK2_SIDE("A", "B", "s70", "s[64:71]")
+                 SOLR_WALK2_SIDE("B", "A", "s78", "s[72:79]")
                  "LD_%=:\n"
                  "s_mov_b64 s[82:83], 0\n"
                  "s_mov_b32 %[leaf], -1\n"
@@ -1209,9 +1210,130 @@ SOLR_DEV int advanceTidy(const Scene &S, const PackedRay &p, float farDistance, 
                  : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
                    "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "v58", "v59",
                    "v60", "v61", "v62", "v63");
-    nbPrimitives = nb;
+    /* (readfirstlane: the compiler takes inline-asm results for divergent; where two such statements meet it would
+     * otherwise have to move a "vector" value into the scalar registers the next statement asks for) */
+    nbPrimitives = uniform(nb);
+    cur = uniform(cur);
     entered = flag != 0;
-    return leaf;
+    return uniform(leaf);
+}
+
+/* Control flow.  Three register banks take turns: while the node in one bank is tested, BOTH nodes the wave can
+ * go to next are on their way into the other two - cur + 1 (some lane entered an inner node) and cur + skip
+ * (nobody entered, or a leaf: skip = 1) - so that a skip over a subtree, which in a deep tree lands on a
+ * record far away in the list and out of the scalar cache, has had a node test's time to arrive instead of
+ * being waited for from scratch (the two-bank form requested only cur + 1; on the 100k-triangle mesh and the
+ * molecule waves sat on s_waitcnt for 45 % of their cycles).  The copies are laid out so that the common case
+ * - nobody enters, go to cur + skip - falls through: A -> C -> B -> (branch) A.  The list is followed by a pad
+ * record: cur + 1 and cur + skip are at most `n`.
+ *   LW<x>   test the node in bank x
+ *   LE<x>   some lane entered: a leaf with primitives leaves the loop (LL), an inner node goes on at cur + 1 */
+#define SOLR_WALK_BANK(SELF, NEXT1, NEXTS, LOXY, ZZ, HIXY, NB, SKIP, NEXT1_REGS, NEXTS_REGS, TAIL)                    \
+    "LW" SELF "_%=:\n"                                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                           \
+    "s_add_i32 s93, %[cur], 1\n"                                                                                       \
+    "s_add_i32 s94, %[cur], " SKIP "\n"                                                                                \
+    "s_lshl_b32 s92, s93, 5\n"                                                                                         \
+    "s_load_dwordx8 " NEXT1_REGS ", %[base], s92\n"                                                                    \
+    "s_lshl_b32 s92, s94, 5\n"                                                                                         \
+    "s_load_dwordx8 " NEXTS_REGS ", %[base], s92\n"                                                                    \
+    "v_pk_add_f32 v[58:59], " LOXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
+    "v_pk_add_f32 v[60:61], " HIXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
+    "v_pk_add_f32 v[62:63], " ZZ ", %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"                                              \
+    "v_pk_mul_f32 v[58:59], %[ixy], v[58:59]\n"                                                                    \
+    "v_pk_mul_f32 v[60:61], %[ixy], v[60:61]\n"                                                                    \
+    "v_pk_mul_f32 v[62:63], %[izz], v[62:63]\n"                                                                    \
+    "v_min_f32 %[t], v58, v60\n"                                                                                     \
+    "v_max_f32 v58, v58, v60\n"                                                                                     \
+    "v_min_f32 v60, v59, v61\n"                                                                                     \
+    "v_max_f32 v59, v59, v61\n"                                                                                     \
+    "v_min_f32 v61, v62, v63\n"                                                                                     \
+    "v_max_f32 v62, v62, v63\n"                                                                                     \
+    "v_max3_f32 %[t], %[t], v60, v61\n"                                                                              \
+    "v_min3_f32 v58, v58, v59, v62\n"                                                                              \
+    "v_cmpx_eq_u32_e32 vcc, %[cur], %[cursor]\n"                                                                       \
+    "v_mov_b32 %[cursor], s94\n"                                                                                       \
+    "v_cmpx_le_f32_e32 vcc, %[t], v58\n"                                                                              \
+    "v_cmpx_lt_f32_e32 vcc, %[t], %[far]\n"                                                                            \
+    "v_cmpx_lt_f32_e32 vcc, 0, v58\n"                                                                                 \
+    "v_mov_b32 %[cursor], s93\n"                                                                                       \
+    "s_cmp_lg_u64 exec, 0\n"                                                                                           \
+    "s_cbranch_scc1 LE" SELF "_%=\n"                                                                                   \
+    "s_mov_b64 exec, s[88:89]\n"                                                                                       \
+    "s_mov_b32 %[cur], s94\n"                                                                                          \
+    "s_cmp_ge_i32 s94, %[n]\n"                                                                                         \
+    "s_cbranch_scc1 LD_%=\n"                                                                                           \
+    TAIL
+
+#define SOLR_WALK_SIDE(SELF, NEXT1, NB)                                                                                \
+    "LE" SELF "_%=:\n"                                                                                                 \
+    "s_mov_b64 s[90:91], exec\n"                                                                                       \
+    "s_mov_b64 exec, s[88:89]\n"                                                                                       \
+    "s_cmp_gt_i32 " NB ", 0\n"                                                                                         \
+    "s_cbranch_scc1 LL" SELF "_%=\n"                                                                                   \
+    "s_mov_b32 %[cur], s93\n"                                                                                          \
+    "s_cmp_ge_i32 s93, %[n]\n"                                                                                         \
+    "s_cbranch_scc1 LD_%=\n"                                                                                           \
+    "s_branch LW" NEXT1 "_%=\n"                                                                                        \
+    "LL" SELF "_%=:\n"                                                                                                 \
+    "s_mov_b32 %[leaf], %[cur]\n"                                                                                      \
+    "s_mov_b32 %[nb], " NB "\n"                                                                                        \
+    "s_mov_b32 %[cur], s93\n"                                                                                          \
+    "s_branch LX_%=\n"
+
+SOLR_DEV int advanceTidyDeep(const Scene &S, const PackedRay &p, float farDistance, int &cursor, int &cur,
+                             int &nbPrimitives, bool &entered)
+{
+    const unsigned long base = (unsigned long)S.geo + ((unsigned long)S.offBoxes << 4);
+    int leaf, nb, flag;
+    float t;
+    /* banks: A = s[64:71], B = s[72:79], C = s[80:87]; a node's successors go: A -> (cur+1: B, cur+skip: C),
+     * C -> (A, B), B -> (C, A) */
+    asm volatile("s_mov_b64 s[88:89], exec\n"
+                 "s_lshl_b32 s92, %[cur], 5\n"
+                 "s_load_dwordx8 s[64:71], %[base], s92\n"
+                 SOLR_WALK_BANK("A", "B", "C", "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[72:79]", "s[80:87]", "")
+                 SOLR_WALK_BANK("C", "A", "B", "s[80:81]", "s[82:83]", "s[84:85]", "s86", "s87", "s[64:71]", "s[72:79]", "")
+                 SOLR_WALK_BANK("B", "C", "A", "s[72:73]", "s[74:75]", "s[76:77]", "s78", "s79", "s[80:87]", "s[64:71]",
+                                "s_branch LWA_%=\n")
+                 SOLR_WALK_SIDE("A", "B", "s70")
+                 SOLR_WALK_SIDE("C", "A", "s86")
+                 SOLR_WALK_SIDE("B", "C", "s78")
+                 "LD_%=:\n"
+                 "s_mov_b64 s[90:91], 0\n"
+                 "s_mov_b32 %[leaf], -1\n"
+                 "s_mov_b32 %[nb], 0\n"
+                 "LX_%=:\n"
+                 "s_waitcnt lgkmcnt(0)\n"
+                 "v_cndmask_b32_e64 %[flag], 0, 1, s[90:91]\n"
+                 : [cursor] "+v"(cursor), [cur] "+s"(cur), [leaf] "=&s"(leaf), [nb] "=&s"(nb), [flag] "=&v"(flag),
+                   [t] "=&v"(t)
+                 : [oxy] "v"(p.oxy), [ozz] "v"(p.ozz), [ixy] "v"(p.ixy), [izz] "v"(p.izz), [far] "v"(farDistance),
+                   [base] "s"(base), [n] "s"(S.nbBoxes)
+                 : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
+                   "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
+                   "s90", "s91", "s92", "s93", "s94", "v58", "v59", "v60", "v61", "v62", "v63");
+    /* (readfirstlane: the compiler takes inline-asm results for divergent; where two such statements meet it would
+     * otherwise have to move a "vector" value into the scalar registers the next statement asks for) */
+    nbPrimitives = uniform(nb);
+    cur = uniform(cur);
+    entered = flag != 0;
+    return uniform(leaf);
+}
+
+/* Which loop: the three-bank form pays one more request and two more scalar instructions per node, and seven more
+ * reserved scalar registers, for having the skip target on its way.  That wins where skips are frequent and
+ * land far away - deep trees over megabytes of nodes (mesh 0.594 -> 0.557 ms, molecule 0.951 -> 0.921) - and
+ * loses where the list is a short run of leaves that lives in the scalar cache (Cornell's 34 nodes: 0.343 ->
+ * 0.355 ms; with both loops in one kernel 0.357: it is the register reservation that costs).  So it is a
+ * compile-time property of the instantiation (F_DEEP) and the host launches the one that fits the list. */
+template <int FEAT>
+SOLR_DEV int advanceTidy(const Scene &S, const PackedRay &p, float farDistance, int &cursor, int &cur,
+                         int &nbPrimitives, bool &entered)
+{
+    if (FEAT & F_DEEP)
+        return advanceTidyDeep(S, p, farDistance, cursor, cur, nbPrimitives, entered);
+    return advanceTidyShallow(S, p, farDistance, cursor, cur, nbPrimitives, entered);
 }
 
 /* the conditions of boxIntersectionFast that depend on the ray */
@@ -1255,7 +1377,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         bool entered;
         if (tidy)
         {
-            leaf = advanceTidy(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
+            leaf = advanceTidy<FEAT>(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
             if (leaf < 0)
                 break;
         }
@@ -1412,7 +1534,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         bool entered;
         if (tidy)
         {
-            leaf = advanceTidy(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
+            leaf = advanceTidy<FEAT>(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
             if (leaf < 0)
                 break;
         }

@@ -1848,23 +1848,26 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     static const struct
     {
         int features;
-        KernelFn fn;
+        KernelFn shallow, deep; /* two-bank / three-bank walk loop (rt_device.h advanceTidy) */
     } variants[] = {
-        {F_SPHERE | F_PLANE, k_standardRenderer<false, F_SPHERE | F_PLANE>},
-        {F_SPHERE | F_TRI, k_standardRenderer<false, F_SPHERE | F_TRI>},
-        {F_SPHERE | F_CYL, k_standardRenderer<false, F_SPHERE | F_CYL>},
-        {F_SPHERE | F_PLANE | F_TRI | F_CYL, k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL>},
-        {F_ALL & ~F_FULL, k_standardRenderer<false, F_ALL & ~F_FULL>},
-        {F_ALL, k_standardRenderer<false, F_ALL>},
+        {F_SPHERE | F_PLANE, k_standardRenderer<false, F_SPHERE | F_PLANE>, k_standardRenderer<false, F_SPHERE | F_PLANE | F_DEEP>},
+        {F_SPHERE | F_TRI, k_standardRenderer<false, F_SPHERE | F_TRI>, k_standardRenderer<false, F_SPHERE | F_TRI | F_DEEP>},
+        {F_SPHERE | F_CYL, k_standardRenderer<false, F_SPHERE | F_CYL>, k_standardRenderer<false, F_SPHERE | F_CYL | F_DEEP>},
+        {F_SPHERE | F_PLANE | F_TRI | F_CYL, k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_DEEP>,
+         k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_DEEP>},
+        {F_ALL & ~F_FULL, k_standardRenderer<false, (F_ALL & ~F_FULL) | F_DEEP>, k_standardRenderer<false, (F_ALL & ~F_FULL) | F_DEEP>},
+        {F_ALL, k_standardRenderer<false, F_ALL | F_DEEP>, k_standardRenderer<false, F_ALL | F_DEEP>},
     };
+    /* a list of more than a thousand nodes does not live in the scalar cache: skips land on cold records */
+    const bool deepList = S.nbBoxes > 1024;
     KernelFn fn = k_standardRenderer<true, F_ALL>;
     if (!counting)
     {
-        fn = k_standardRenderer<false, F_ALL>;
+        fn = k_standardRenderer<false, F_ALL | F_DEEP>;
         for (const auto &v : variants)
             if ((need & ~v.features) == 0 && g.variant != 4)
             {
-                fn = v.fn;
+                fn = deepList ? v.deep : v.shallow;
                 break;
             }
     }
