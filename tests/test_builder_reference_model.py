@@ -11,8 +11,8 @@ primitive order, the lamps and the light list.  What the model spells out, becau
   * level 0: cell of p0 in a 6400^3 grid over the scene extent, key 1 + 1000 (X 6400^2 + Y 6400 + Z) in
     UNSIGNED 32-bit arithmetic - it wraps (:938-941);
   * level d >= 1: cell of the child's centre in a grid of `nbBoxes`^3 (the primitive count, divided by 4 per
-    level), key X n^2 + Y n + Z + 1 in SIGNED 32-bit arithmetic - it wraps too, to negative keys, which sort
-    FIRST in the std::map (:1011-1017);
+    level), key X n^2 + Y n + Z + 1 in SIGNED 32-bit arithmetic - it wraps too, to negative values, and the
+    std::map is keyed by unsigned int (GPUKernel.h:75): those sort LAST (:1011-1017);
   * emissive primitives: a level-0 cell is still created for them (empty, bounds left at the +-1e6 seed,
     centre 0) but they are listed in box 0 of the top level (:954-975);
   * the flattening treats the FIRST entry of the top level as the lamp box: bounds forced to +-viewDistance, its
@@ -71,6 +71,7 @@ class ReferenceBuilder:
                 self.min[a] = min(F(p["p0"][a]), self.min[a])
                 self.max[a] = max(F(p["p0"][a]), self.max[a])
         self.levels = {}                   # depth -> {key: Box}
+        self.wrapped = False
 
     def level(self, d):
         return self.levels.setdefault(d, {})
@@ -159,6 +160,8 @@ class ReferenceBuilder:
             X, Y, Z = self.cell(below[key].center, s)
             B = i32(i32(i32(X * box_size) * box_size) + i32(Y * box_size) + Z)   # int arithmetic: it wraps
             B = i32(B + 1)
+            self.wrapped = self.wrapped or B < 0
+            B = u32(B)                                                           # std::map<unsigned int, ...>
             box = self.level(depth).setdefault(B, Box(self.vd))
             box.lo, box.hi = [self.vd] * 3, [-self.vd] * 3
             box.entries.append(key)
@@ -231,6 +234,13 @@ def _spheres(n, seed, lights):
         rng = np.random.default_rng(seed)
         out = [(solr.ptSphere, tuple(float(v) for v in rng.uniform(-20000, 20000, 3)), 0, 0,
                 (float(rng.uniform(20, 300)), 0, 0), False) for _ in range(n)]
+        if n >= 1500:
+            # the level-1 key X n^2 + ... passes 2^31 between X = 536 and 537 for n = 2001 (537 * 2001^2 > 2^31):
+            # a row of spheres across those cells (a cell is 40000 / 2001 wide), four level-1 cells per level-2 cell
+            cell = 40000.0 / (n + lights)
+            for X in range(530, 545):
+                out.append((solr.ptSphere, (-20000.0 + (X + 0.5) * cell, 100.0, 200.0), 0, 0, (5.0, 0, 0), False))
+            out = out[15:]
         for k in range(lights):
             out.insert(int(rng.integers(0, len(out))),
                        (solr.ptSphere, tuple(float(v) for v in rng.uniform(-20000, 20000, 3)), 0, 0, (10, 0, 0), True))
@@ -287,7 +297,12 @@ def test_the_flattened_tree_is_the_reference_builders(solr, name):
         want = (tuple(float(v) for v in n["lo"]), tuple(float(v) for v in n["hi"]), n["nb"], n["start"], n["skip"])
         assert got == want, "node %d: builder %s, reference model %s" % (i, got, want)
     if "negative" in name:
-        assert min(min(model.level(d)) for d in range(1, model.tree_depth + 1)) < 0, "meant to wrap the outer keys"
+        assert model.wrapped, "the scene was meant to wrap the outer keys"
+        # ... and to have a parent whose children sit on both sides of the wrap: their order shows whether the
+        # keys are compared as the unsigned values the reference's map holds
+        mixed = [b for b in model.level(2).values()
+                 if any(k >= 2 ** 31 for k in b.entries) and any(k < 2 ** 31 for k in b.entries)]
+        assert mixed, "no level-2 box with children on both sides of the key wrap"
     if "four outer levels" in name:
         assert model.tree_depth == 4
     if "two outer levels" in name:
