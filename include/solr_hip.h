@@ -133,6 +133,23 @@ void *solr_hip_gathered_frame(void);
 int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap);
 void solr_hip_comm_finalize(void);
 
+/* GPUKernel::compactBoxes(true) on the device (sol-r_amd/csrc/solr_tree.hip): the reference's box grid -
+ * processBoxes, processOutterBoxes, streamDataToGPU, GPUKernel.cpp:917-1281 - built from the scene's
+ * primitives and flattened, bit for bit the tree the host builder makes.
+ *   primitives   the scene's primitives in index order as Primitive records (what setPrimitive stored)
+ *   emissive     one byte per primitive: 1 if its material's innerIllumination.x != 0
+ *   minPos, maxPos, viewDistance   the scene extent the host keeps (GPUKernel.cpp:671-678) and SceneInfo's
+ *   boxes        out: the flattened node list (capacity boxCapacity); *nbBoxes receives its length
+ *   order        out: nbPrimitives ints: order[k] = index of the primitive streamed k-th; the first *nbLamps
+ *                are the lamps (the host fills its Primitive records, lamp and light lists from it)
+ * Returns the tree depth (>= 1); -2 when the scene is one of the few cases left to the host builder (no
+ * emissive primitive, key collisions with the lamp box, more than NB_MAX_BOXES nodes: solr_tree.hip lists
+ * them); -1 on an error, text in solr_hip_build_tree_message(). */
+int solr_hip_build_tree(const Primitive *primitives, const unsigned char *emissive, int nbPrimitives,
+                        const float minPos[3], const float maxPos[3], float viewDistance, BoundingBox *boxes,
+                        int boxCapacity, int *order, int *nbBoxes, int *nbLamps);
+const char *solr_hip_build_tree_message(void);
+
 /* Device pointers of the current per-pixel buffers (strip-sized), for
  * collectives issued by the launcher (RCCL gather of the RGB strip). */
 void *solr_hip_device_bitmap(void);

@@ -467,6 +467,7 @@ bool GPUKernel::updateOutterBoundingBox(CPUBoundingBox &outterBox, const int dep
 /* reference: GPUKernel.cpp:892-915 */
 void GPUKernel::resetBoxes(bool resetPrimitives)
 {
+    ensureLevels();
     BoxContainer &level0 = frame().boundingBoxes[0];
     if (resetPrimitives)
         for (unsigned int i = 0; i < level0.size(); ++i)
@@ -591,36 +592,145 @@ int GPUKernel::compactBoxes(bool reconstructBoxes)
     m_primitivesTransfered = false;
     if (reconstructBoxes)
     {
-        Frame &f = frame();
-        /* The reference resets only the lights box here
-         * (GPUKernel.cpp:1049) and relies on resetFrame() having emptied the
-         * levels; a second compactBoxes(true) on the same frame would hash
-         * every primitive into its cell twice.  Rebuild from empty levels. */
-        for (int level = 0; level < BOUNDING_BOXES_TREE_DEPTH; ++level)
-            f.boundingBoxes[level].clear();
-        const int gridGranularity = 2;
-        const int gridDivider = 4;
-
-        m_treeDepth = 0;
-        int nbBoxes = static_cast<int>(f.primitives.size());
-        while (nbBoxes > gridGranularity)
-        {
-            ++m_treeDepth;
-            nbBoxes /= gridDivider;
-        }
-        processBoxes(AABB_MAGIC_NUMBER, false);
-
-        m_treeDepth = 0;
-        nbBoxes = static_cast<int>(f.primitives.size());
-        do
-        {
-            ++m_treeDepth;
-            processOutterBoxes(nbBoxes, m_treeDepth);
-            nbBoxes /= gridDivider;
-        } while (nbBoxes > gridGranularity);
+        /* the engine builds the same tree on the device (0.2 s of maps and hashing for 100 k primitives on the
+         * host, 1.4-1.6 s in the reference; a few milliseconds there): the flattened arrays come back, the
+         * per-level maps are left for whoever needs them (ensureLevels) */
+        if (buildTreeOnDevice())
+            return frame().nbActiveBoxes;
+        buildLevelsOnHost();
     }
+    else
+        ensureLevels();
     streamDataToGPU();
     return frame().nbActiveBoxes;
+}
+
+/* reference: GPUKernel.cpp:1047-1076, the levels without the flattening */
+void GPUKernel::buildLevelsOnHost()
+{
+    Frame &f = frame();
+    /* The reference resets only the lights box here
+     * (GPUKernel.cpp:1049) and relies on resetFrame() having emptied the
+     * levels; a second compactBoxes(true) on the same frame would hash
+     * every primitive into its cell twice.  Rebuild from empty levels. */
+    for (int level = 0; level < BOUNDING_BOXES_TREE_DEPTH; ++level)
+        f.boundingBoxes[level].clear();
+    const int gridGranularity = 2;
+    const int gridDivider = 4;
+
+    m_treeDepth = 0;
+    int nbBoxes = static_cast<int>(f.primitives.size());
+    while (nbBoxes > gridGranularity)
+    {
+        ++m_treeDepth;
+        nbBoxes /= gridDivider;
+    }
+    processBoxes(AABB_MAGIC_NUMBER, false);
+
+    m_treeDepth = 0;
+    nbBoxes = static_cast<int>(f.primitives.size());
+    do
+    {
+        ++m_treeDepth;
+        processOutterBoxes(nbBoxes, m_treeDepth);
+        nbBoxes /= gridDivider;
+    } while (nbBoxes > gridGranularity);
+    m_levelsBuilt = true;
+}
+
+void GPUKernel::ensureLevels()
+{
+    if (!m_levelsBuilt)
+        buildLevelsOnHost();
+}
+
+/* compactBoxes(true) through the engine: true when the flattened arrays, lamps and light list are in place */
+bool GPUKernel::buildTreeOnDevice()
+{
+    if (m_hostBuildOnly || getenv("SOLR_HOST_BUILD"))
+        return false;
+    Frame &f = frame();
+    const int n = static_cast<int>(f.primitives.size());
+    if (n < 1 || n >= NB_MAX_PRIMITIVES)
+        return false;
+    /* the builder numbers the primitives by their rank in the map (GPUKernel.cpp:932-990: `p`) and looks them
+     * up by that number when it streams them: the two agree when the ids are 0..n-1 */
+    std::vector<Primitive> prims(n);
+    std::vector<unsigned char> emissive(n);
+    int rank = 0;
+    for (auto &entry : f.primitives)
+    {
+        if ((int)entry.first != rank)
+            return false;
+        const CPUPrimitive &p = entry.second;
+        Primitive &out = prims[rank];
+        memset(&out, 0, sizeof(out));
+        out.index = rank;
+        out.type = p.type;
+        out.p0 = p.p0;
+        out.p1 = p.p1;
+        out.p2 = p.p2;
+        out.size = p.size;
+        out.materialId = p.materialId;
+        if (p.materialId < 0 || p.materialId > NB_MAX_MATERIALS)
+            return false;
+        emissive[rank] = m_hMaterials[p.materialId].innerIllumination.x != 0.f;
+        ++rank;
+    }
+    std::vector<BoundingBox> boxes;
+    std::vector<int> order;
+    int nbLamps = 0;
+    const int depth = deviceBuildTree(prims, emissive, f.minPos, f.maxPos, m_sceneInfo.viewDistance, boxes, order, nbLamps);
+    if (depth < 1 || (int)order.size() != n || boxes.empty() || boxes.size() >= (size_t)NB_MAX_BOXES)
+        return false;
+
+    /* what streamDataToGPU leaves behind (GPUKernel.cpp:1151-1281), from the device's node list and order */
+    for (int level = 0; level < BOUNDING_BOXES_TREE_DEPTH; ++level)
+        f.boundingBoxes[level].clear();
+    m_levelsBuilt = false;
+    m_treeDepth = depth;
+    m_primitivesTransfered = false;
+    f.nbActiveBoxes = 0;
+    f.nbActivePrimitives = 0;
+    f.nbActiveLamps = 0;
+    m_maxPrimitivesPerBox = 0;
+    m_hBoundingBoxes.swap(boxes);
+    f.nbActiveBoxes = (int)m_hBoundingBoxes.size();
+    m_hPrimitives.clear();
+    m_hMovable.clear();
+    m_hLamps.clear();
+    m_hPrimitives.reserve(n);
+    m_hMovable.reserve(n);
+    if (m_lightInformation.size() < NB_MAX_LIGHTINFORMATIONS)
+        m_lightInformation.assign(NB_MAX_LIGHTINFORMATIONS, LightInformation());
+    m_lightInformationSize = 0;
+    for (int k = 0; k < n; ++k)
+    {
+        const long id = order[k];
+        appendPrimitive(id, k >= nbLamps);
+        if (k < nbLamps)
+        {
+            CPUPrimitive &primitive = f.primitives[(unsigned int)id];
+            Material &material = m_hMaterials[primitive.materialId];
+            LightInformation li;
+            memset(&li, 0, sizeof(li));
+            li.primitiveId = (int)id;
+            li.materialId = primitive.materialId;
+            li.location = primitive.p0;
+            li.color.x = material.color.x;
+            li.color.y = material.color.y;
+            li.color.z = material.color.z;
+            li.color.w = material.innerIllumination.x;
+            if (m_lightInformationSize < NB_MAX_LIGHTINFORMATIONS)
+                m_lightInformation[m_lightInformationSize] = li;
+            m_hLamps.push_back((Lamp)id);
+            ++f.nbActiveLamps;
+            ++m_lightInformationSize;
+        }
+    }
+    for (const BoundingBox &b : m_hBoundingBoxes)
+        m_maxPrimitivesPerBox = std::max(m_maxPrimitivesPerBox, (size_t)std::max(b.nbPrimitives, 0));
+    return true;
 }
 
 void GPUKernel::appendPrimitive(long id, bool inLevel0Box)
@@ -898,6 +1008,7 @@ void GPUKernel::rotatePrimitives(const vec3f &rotationCenter, const vec4f &angle
 
 void GPUKernel::rotatePrimitivesOnly(Frame &f, const vec3f &rotationCenter, const vec3f &cosA, const vec3f &sinA)
 {
+    ensureLevels();
     const vec3f zero = make_vec3f();
     for (auto &entry : f.boundingBoxes[0])
     {
@@ -937,6 +1048,7 @@ void GPUKernel::rotatePrimitivesOnly(Frame &f, const vec3f &rotationCenter, cons
  * several rotations leaves what one pass after each would */
 void GPUKernel::refitBoxes(Frame &f)
 {
+    ensureLevels();
     for (auto &entry : f.boundingBoxes[0])
     {
         resetBox(entry.second, false);
@@ -978,6 +1090,7 @@ void GPUKernel::syncHost()
 void GPUKernel::translatePrimitives(const vec3f &t)
 {
     m_primitivesTransfered = false;
+    ensureLevels();
     Frame &f = frame();
     for (auto &entry : f.boundingBoxes[0])
     {

@@ -427,6 +427,7 @@ public:
     const Material *hostMaterials() const { return m_hMaterials.data(); }
     const std::vector<RandomBuffer> &hostRandoms();
     size_t randomsNeeded() const;
+    void setHostBuildOnly(bool on) { m_hostBuildOnly = on; }
     const std::vector<BitmapBuffer> &hostTextureAtlas();
     PrimitiveXYIdBuffer *hostPrimitiveIds() { fetchPrimitiveIds(); return m_hPrimitivesXYIds.data(); }
     unsigned int treeDepth() const { return m_treeDepth; }
@@ -468,6 +469,20 @@ protected:
      * bits a replay of the pending rotations produces - tests/test_animation_gpu.py - at a cost that does not
      * grow with their number); false = not available, replay */
     virtual bool primitivesFromDevice(Frame &) { return false; }
+    /* engine hook: GPUKernel::compactBoxes(true) on the device (include/solr_hip.h, solr_hip_build_tree): the
+     * flattened node list, the order in which the primitives are streamed and the number of lamps, from the
+     * frame's primitives in index order.  Returns the tree depth, or a negative value when the engine has no
+     * such thing or leaves this scene to the host builder */
+    virtual int deviceBuildTree(const std::vector<Primitive> &, const std::vector<unsigned char> &, const vec3f &,
+                                const vec3f &, float, std::vector<BoundingBox> &, std::vector<int> &, int &)
+    {
+        return -2;
+    }
+    /* the per-level maps of the host builder, built when something needs them after a device-side build
+     * (host-side rotations and translations, compactBoxes(false)) */
+    void ensureLevels();
+    bool buildTreeOnDevice();
+    void buildLevelsOnHost();
     /* engine hook: apply the rotation to the resident scene; false = not done, nothing changed */
     virtual bool deviceRotatePrimitives(const vec3f &, const vec3f &, const vec3f &) { return false; }
     void rotatePrimitivesOnly(Frame &f, const vec3f &rotationCenter, const vec3f &cosA, const vec3f &sinA);
@@ -499,6 +514,8 @@ protected:
     std::vector<BitmapBuffer> m_textureAtlas;
     std::vector<RandomBuffer> m_hRandoms;
     bool m_randomsFilled = false;
+    bool m_levelsBuilt = true;  /* false: the flattened arrays came from the device build, the level maps are empty */
+    bool m_hostBuildOnly = false; /* SolRx_HostBuild(1) / SOLR_HOST_BUILD=1: never ask the engine for the tree */
     std::vector<PrimitiveXYIdBuffer> m_hPrimitivesXYIds;
     std::vector<LightInformation> m_lightInformation;
     std::vector<BitmapBuffer> m_bitmap;

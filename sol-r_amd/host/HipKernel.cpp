@@ -150,6 +150,30 @@ bool HipKernel::deviceRotatePrimitives(const vec3f &center, const vec3f &cosA, c
     return solr_hip_rotate_primitives(c, co, si, m_sceneInfo.viewDistance) == 1;
 }
 
+int HipKernel::deviceBuildTree(const std::vector<Primitive> &primitives, const std::vector<unsigned char> &emissive,
+                               const vec3f &minPos, const vec3f &maxPos, float viewDistance,
+                               std::vector<BoundingBox> &boxes, std::vector<int> &order, int &nbLamps)
+{
+    if (solr_hip_device_count() < 1)
+        return -2;
+    const int n = (int)primitives.size();
+    /* every level has at most as many boxes as the one below, the top one box more: (depth + 1) n + 1 at most */
+    boxes.resize((size_t)n * 12 + 16);
+    order.resize((size_t)n);
+    const float mn[3] = {minPos.x, minPos.y, minPos.z}, mx[3] = {maxPos.x, maxPos.y, maxPos.z};
+    int nbBoxes = 0;
+    const int depth = solr_hip_build_tree(primitives.data(), emissive.data(), n, mn, mx, viewDistance, boxes.data(),
+                                          (int)boxes.size(), order.data(), &nbBoxes, &nbLamps);
+    if (depth < 1)
+    {
+        boxes.clear();
+        order.clear();
+        return depth;
+    }
+    boxes.resize((size_t)nbBoxes);
+    return depth;
+}
+
 bool HipKernel::primitivesFromDevice(Frame &f)
 {
     if (!m_deviceInitialized)

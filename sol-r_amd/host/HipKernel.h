@@ -52,6 +52,9 @@ protected:
     bool deviceRotatePrimitives(const vec3f &center, const vec3f &cosA, const vec3f &sinA) override;
     void fetchPrimitiveIds() override;
     bool primitivesFromDevice(Frame &f) override;
+    int deviceBuildTree(const std::vector<Primitive> &primitives, const std::vector<unsigned char> &emissive,
+                        const vec3f &minPos, const vec3f &maxPos, float viewDistance, std::vector<BoundingBox> &boxes,
+                        std::vector<int> &order, int &nbLamps) override;
 
 private:
     vec4i m_blockSize;

@@ -451,6 +451,12 @@ int SolRx_SelectEngine(const char *name)
     return 0;
 }
 
+int SolRx_HostBuild(int hostOnly)
+{
+    SingletonKernel::kernel()->setHostBuildOnly(hostOnly != 0);
+    return 0;
+}
+
 int SolRx_SetDeterministic(long seed)
 {
     SingletonKernel::kernel()->setDeterministic(seed);

@@ -124,6 +124,9 @@ int SolRx_SelectEngine(const char *name);
 /* seed >= 0: keep SceneInfo.timestamp and fill the random buffer from a seeded
  * LCG; seed < 0: reference behaviour (rand()/time(0)) */
 int SolRx_SetDeterministic(long seed);
+/* 1: compactBoxes(true) always builds the box tree on the host; 0 (default): on the device when the engine
+ * offers it (include/solr_hip.h solr_hip_build_tree) - the same tree either way.  Also SOLR_HOST_BUILD=1 */
+int SolRx_HostBuild(int hostOnly);
 /* pending engine error: 0 = none; copies the text into buf when non-null */
 int SolRx_LastError(char *buf, int len);
 /* render_begin + render_end without copying the bitmap */
