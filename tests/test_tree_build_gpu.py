@@ -27,7 +27,7 @@ def _device_tree(solr, flat, view_distance):
     p0 = by_index["p0"]
     lo = np.minimum(p0.min(axis=0), 0).astype(np.float32)           # a fresh kernel's extent: primitives and the origin
     hi = np.maximum(p0.max(axis=0), 0).astype(np.float32)
-    boxes = np.zeros(4 * n + 64, flat.boxes.dtype)
+    boxes = np.zeros(12 * n + 64, flat.boxes.dtype)
     order = np.zeros(n, np.int32)
     nb_boxes, nb_lamps = C.c_int(), C.c_int()
     t0 = time.perf_counter()
