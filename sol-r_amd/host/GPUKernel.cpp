@@ -608,6 +608,9 @@ int GPUKernel::compactBoxes(bool reconstructBoxes)
 /* reference: GPUKernel.cpp:1047-1076, the levels without the flattening */
 void GPUKernel::buildLevelsOnHost()
 {
+    m_levelsBuilt = true; /* first: frame() below asks */
+    const bool outer = !m_buildingLevels;
+    m_buildingLevels = true;
     Frame &f = frame();
     /* The reference resets only the lights box here
      * (GPUKernel.cpp:1049) and relies on resetFrame() having emptied the
@@ -636,6 +639,8 @@ void GPUKernel::buildLevelsOnHost()
         nbBoxes /= gridDivider;
     } while (nbBoxes > gridGranularity);
     m_levelsBuilt = true;
+    if (outer)
+        m_buildingLevels = false;
 }
 
 void GPUKernel::ensureLevels()
@@ -649,6 +654,7 @@ bool GPUKernel::buildTreeOnDevice()
 {
     if (m_hostBuildOnly || getenv("SOLR_HOST_BUILD"))
         return false;
+    m_levelsBuilt = true; /* whatever was left unbuilt is about to be replaced */
     Frame &f = frame();
     const int n = static_cast<int>(f.primitives.size());
     if (n < 1 || n >= NB_MAX_PRIMITIVES)
@@ -687,7 +693,6 @@ bool GPUKernel::buildTreeOnDevice()
     /* what streamDataToGPU leaves behind (GPUKernel.cpp:1151-1281), from the device's node list and order */
     for (int level = 0; level < BOUNDING_BOXES_TREE_DEPTH; ++level)
         f.boundingBoxes[level].clear();
-    m_levelsBuilt = false;
     m_treeDepth = depth;
     m_primitivesTransfered = false;
     f.nbActiveBoxes = 0;
@@ -730,6 +735,7 @@ bool GPUKernel::buildTreeOnDevice()
     }
     for (const BoundingBox &b : m_hBoundingBoxes)
         m_maxPrimitivesPerBox = std::max(m_maxPrimitivesPerBox, (size_t)std::max(b.nbPrimitives, 0));
+    m_levelsBuilt = false; /* the maps follow when somebody needs them (frame()) */
     return true;
 }
 
@@ -1064,6 +1070,7 @@ void GPUKernel::syncHost()
     if (m_pendingRotations.empty() && !m_unrecordedRotations)
         return;
     const bool transfered = m_primitivesTransfered, touched = m_hostTouched;
+    ensureLevels(); /* from the primitives as they were built with, before the rotations reach the store */
     std::vector<PendingRotation> pending;
     pending.swap(m_pendingRotations);
     const size_t unrecorded = m_unrecordedRotations;

@@ -448,7 +448,12 @@ protected:
     Frame &frame()
     {
         m_hostTouched = true;
-        if (!m_pendingRotations.empty() || m_unrecordedRotations)
+        /* a tree that came from the device build left the per-level maps empty: they are made now, from the
+         * primitives as they still are, before whoever asks can change one (the cells a primitive sits in are
+         * those of the last full build, GPUKernel.cpp:1378-1460 refits them, it does not re-hash) */
+        if (!m_levelsBuilt)
+            buildLevelsOnHost();
+        if ((!m_pendingRotations.empty() || m_unrecordedRotations) && !m_buildingLevels)
             syncHost();
         return m_frames[m_frame];
     }
@@ -515,6 +520,7 @@ protected:
     std::vector<RandomBuffer> m_hRandoms;
     bool m_randomsFilled = false;
     bool m_levelsBuilt = true;  /* false: the flattened arrays came from the device build, the level maps are empty */
+    bool m_buildingLevels = false; /* the lazy build reads the store as it is: pending rotations stay pending */
     bool m_hostBuildOnly = false; /* SolRx_HostBuild(1) / SOLR_HOST_BUILD=1: never ask the engine for the tree */
     std::vector<PrimitiveXYIdBuffer> m_hPrimitivesXYIds;
     std::vector<LightInformation> m_lightInformation;
