@@ -63,6 +63,34 @@ static float specularPower(float base, float exponent)
     return correctlyRoundedPow ? (float)pow((double)base, (double)exponent) : powf(base, exponent);
 }
 
+/* The same for the trigonometry of the procedural sphere, the Julia/Mandelbrot parameters and the sphere / skybox
+ * UV maps: sinf, cosf, atan2f, asinf are specified to an error bound only (CUDA: 2 ULP, glibc: < 1 ULP, not
+ * always the nearest value); the engine evaluates them in binary64 and rounds once.  With
+ * oracle_set_rounded_transcendentals(1) (or SOLR_ORACLE_CORRECTLY_ROUNDED_TRIG=1; the call also switches the
+ * power above) the restatement does the same and the frames that depend on them can be compared EXACTLY
+ * (tests/test_gpu_parity.py::test_every_primitive_type, test_textures) instead of within a handful of pixels.
+ * The camera's six values (makeTrig) are computed by the host on both sides and are not affected. */
+static int roundedTrig = -1;
+static int roundedTrigOn(void)
+{
+    if (roundedTrig < 0)
+    {
+        const char *e = getenv("SOLR_ORACLE_CORRECTLY_ROUNDED_TRIG");
+        roundedTrig = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return roundedTrig;
+}
+static float sin_o(float a) { return roundedTrigOn() ? (float)sin((double)a) : sinf(a); }
+static float cos_o(float a) { return roundedTrigOn() ? (float)cos((double)a) : cosf(a); }
+static float atan2_o(float a, float b) { return roundedTrigOn() ? (float)atan2((double)a, (double)b) : atan2f(a, b); }
+static float asin_o(float a) { return roundedTrigOn() ? (float)asin((double)a) : asinf(a); }
+void oracle_set_rounded_transcendentals(int on)
+{
+    roundedTrig = on ? 1 : 0;
+    correctlyRoundedPow = on ? 1 : 0;
+}
+int oracle_get_rounded_transcendentals(void) { return roundedTrigOn() && correctlyRoundedPow == 1; }
+
 /* ---- dialect ------------------------------------------------------------------------------------
  * The reference keeps the same per-pixel path twice: the CUDA engine, which this file restates and the
  * product matches (dialect 0, the default), and an older sibling, the OpenCL engine
@@ -346,8 +374,8 @@ static void juliaSet(const Material *material, const SceneInfo *si, float x, flo
 {
     float W = (float)material->textureMapping.x;
     float H = (float)material->textureMapping.y;
-    float cRe = -0.7f + 0.4f * sinf(si->timestamp / 1500.f);
-    float cIm = 0.27015f + 0.4f * cosf(si->timestamp / 2000.f);
+    float cRe = -0.7f + 0.4f * sin_o(si->timestamp / 1500.f);
+    float cIm = 0.27015f + 0.4f * cos_o(si->timestamp / 2000.f);
     float newRe = 1.5f * (x - W / 2.f) / (0.5f * W);
     float newIm = (y - H / 2.f) / (0.5f * H);
     int n;
@@ -481,8 +509,8 @@ static f4 sphereUVMapping(const Primitive *primitive, const Material *materials,
     const Material *material = &materials[primitive->materialId];
     f4 result = colorOf(material);
     v3 I = vnormalize(vsub(intersection, primitive->p0));
-    float U = ((atan2f(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
-    float V_ = (asinf(I.y) / SOLR_PI) + .5f;
+    float U = ((atan2_o(I.x, I.z) / SOLR_PI) + 1.f) * .5f;
+    float V_ = (asin_o(I.y) / SOLR_PI) + .5f;
     int u = f2i(material->textureMapping.x * (U * primitive->vt1.x));
     int v = f2i(material->textureMapping.y * (V_ * primitive->vt1.y));
     if (material->textureMapping.x != 0)
@@ -573,8 +601,8 @@ static c3 skyboxMapping(const SceneInfo *si, const Material *materials, const Bi
     if (t < si->geometryEpsilon)
         return result;
     v3 intersection = vnormalize(vadd(ray->origin, vscale(dir, t)));
-    float U = ((atan2f(intersection.x, intersection.z) / SOLR_PI) + 1.f) * .5f;
-    float V_ = (asinf(intersection.y) / SOLR_PI) + .5f;
+    float U = ((atan2_o(intersection.x, intersection.z) / SOLR_PI) + 1.f) * .5f;
+    float V_ = (asin_o(intersection.y) / SOLR_PI) + .5f;
     int u = f2i(material->textureMapping.x * U);
     int v = f2i(material->textureMapping.y * V_);
     if (material->textureMapping.x != 0)
@@ -673,9 +701,9 @@ static int sphereIntersection(const SceneInfo *si, const Primitive *sphere, cons
     {
         /* procedural bumps, GI:268-273: timestamp (int) + coordinate (float) in binary32 */
         v3 newCenter;
-        newCenter.x = sphere->p0.x + 0.008f * sphere->size.x * cosf(si->timestamp + intersection->x);
-        newCenter.y = sphere->p0.y + 0.008f * sphere->size.y * sinf(si->timestamp + intersection->y);
-        newCenter.z = sphere->p0.z + 0.008f * sphere->size.z * sinf(cosf(si->timestamp + intersection->z));
+        newCenter.x = sphere->p0.x + 0.008f * sphere->size.x * cos_o(si->timestamp + intersection->x);
+        newCenter.y = sphere->p0.y + 0.008f * sphere->size.y * sin_o(si->timestamp + intersection->y);
+        newCenter.z = sphere->p0.z + 0.008f * sphere->size.z * sin_o(cos_o(si->timestamp + intersection->z));
         n = vsub(*intersection, newCenter);
     }
     n = vnormalize(n);

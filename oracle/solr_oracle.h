@@ -105,6 +105,10 @@ int oracle_max_threads(void);
 
 /* 0 (default): the CUDA engine's statements; 1: the OpenCL engine's, for the comparison with oracle/ref_probes.cl */
 void oracle_set_dialect(int openclEngine);
+/* powf / sinf / cosf / atan2f / asinf evaluated in binary64 and rounded once, as the engine does (they are
+ * specified to an error bound only); off by default = libm's binary32 routines */
+void oracle_set_rounded_transcendentals(int on);
+int oracle_get_rounded_transcendentals(void);
 int oracle_get_dialect(void);
 /* batched function-level entry points (oracle_probe_*) and oracle_postprocess: see the end of solr_oracle.c
  * and oracle/probes.py */

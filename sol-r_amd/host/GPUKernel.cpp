@@ -596,7 +596,7 @@ int GPUKernel::compactBoxes(bool reconstructBoxes)
          * host, 1.4-1.6 s in the reference; a few milliseconds there): the flattened arrays come back, the
          * per-level maps are left for whoever needs them (ensureLevels) */
         if (buildTreeOnDevice())
-            return frame().nbActiveBoxes;
+            return frameAsIs().nbActiveBoxes; /* frame() would make the level maps at once */
         buildLevelsOnHost();
     }
     else
@@ -608,7 +608,7 @@ int GPUKernel::compactBoxes(bool reconstructBoxes)
 /* reference: GPUKernel.cpp:1047-1076, the levels without the flattening */
 void GPUKernel::buildLevelsOnHost()
 {
-    m_levelsBuilt = true; /* first: frame() below asks */
+    m_frames[m_frame].levelsBuilt = true; /* first: frame() below asks */
     const bool outer = !m_buildingLevels;
     m_buildingLevels = true;
     Frame &f = frame();
@@ -638,14 +638,14 @@ void GPUKernel::buildLevelsOnHost()
         processOutterBoxes(nbBoxes, m_treeDepth);
         nbBoxes /= gridDivider;
     } while (nbBoxes > gridGranularity);
-    m_levelsBuilt = true;
+    m_frames[m_frame].levelsBuilt = true;
     if (outer)
         m_buildingLevels = false;
 }
 
 void GPUKernel::ensureLevels()
 {
-    if (!m_levelsBuilt)
+    if (!m_frames[m_frame].levelsBuilt)
         buildLevelsOnHost();
 }
 
@@ -654,7 +654,7 @@ bool GPUKernel::buildTreeOnDevice()
 {
     if (m_hostBuildOnly || getenv("SOLR_HOST_BUILD"))
         return false;
-    m_levelsBuilt = true; /* whatever was left unbuilt is about to be replaced */
+    m_frames[m_frame].levelsBuilt = true; /* whatever was left unbuilt is about to be replaced */
     Frame &f = frame();
     const int n = static_cast<int>(f.primitives.size());
     if (n < 1 || n >= NB_MAX_PRIMITIVES)
@@ -735,7 +735,7 @@ bool GPUKernel::buildTreeOnDevice()
     }
     for (const BoundingBox &b : m_hBoundingBoxes)
         m_maxPrimitivesPerBox = std::max(m_maxPrimitivesPerBox, (size_t)std::max(b.nbPrimitives, 0));
-    m_levelsBuilt = false; /* the maps follow when somebody needs them (frame()) */
+    m_frames[m_frame].levelsBuilt = false; /* the maps follow when somebody needs them (frame()) */
     return true;
 }
 
@@ -939,6 +939,7 @@ void GPUKernel::morphPrimitives()
 /* reference: GPUKernel.cpp:1283-1305 */
 void GPUKernel::resetFrame()
 {
+    m_frames[m_frame].levelsBuilt = true; /* nothing to make them for any more */
     Frame &f = frame();
     vec3f mn = f.minPos, mx = f.maxPos; /* the reference keeps the extent across resets */
     f = Frame();

@@ -442,6 +442,7 @@ protected:
         int nbActiveLamps = 0;
         vec3f minPos = {0.f, 0.f, 0.f};
         vec3f maxPos = {0.f, 0.f, 0.f};
+        bool levelsBuilt = true; /* false: the flattened arrays came from the device build, the level maps are empty */
     };
     /* every access to the scene store: catches the host copy up and ends the device-side fast path until
      * the next upload (the caller may be about to change what the device holds) */
@@ -451,7 +452,7 @@ protected:
         /* a tree that came from the device build left the per-level maps empty: they are made now, from the
          * primitives as they still are, before whoever asks can change one (the cells a primitive sits in are
          * those of the last full build, GPUKernel.cpp:1378-1460 refits them, it does not re-hash) */
-        if (!m_levelsBuilt)
+        if (!m_frames[m_frame].levelsBuilt)
             buildLevelsOnHost();
         if ((!m_pendingRotations.empty() || m_unrecordedRotations) && !m_buildingLevels)
             syncHost();
@@ -519,7 +520,6 @@ protected:
     std::vector<BitmapBuffer> m_textureAtlas;
     std::vector<RandomBuffer> m_hRandoms;
     bool m_randomsFilled = false;
-    bool m_levelsBuilt = true;  /* false: the flattened arrays came from the device build, the level maps are empty */
     bool m_buildingLevels = false; /* the lazy build reads the store as it is: pending rotations stay pending */
     bool m_hostBuildOnly = false; /* SolRx_HostBuild(1) / SOLR_HOST_BUILD=1: never ask the engine for the tree */
     std::vector<PrimitiveXYIdBuffer> m_hPrimitivesXYIds;

@@ -4,10 +4,10 @@
  * Same names, argument order and return conventions as the reference's
  * solr/SolRStub.h:36-135 (0 / -1 ints, doubles converted to floats, no C++
  * exceptions across the boundary) for every call that feeds or runs the
- * rendering path.  Not provided (out of scope): the
- * OpenCL queries, file loaders (SolR_LoadMolecule, SolR_LoadOBJModel,
- * SolR_LoadTextureFromFile, SolR_SaveToFile, SolR_LoadFromFile),
- * SolR_GenerateScreenshot and the Kinect call.
+ * rendering path, including the scene-file loaders (SolR_LoadMolecule,
+ * SolR_LoadOBJModel, SolR_SaveToFile, SolR_LoadFromFile).  Not provided (out
+ * of scope): the OpenCL queries, SolR_LoadTextureFromFile
+ * and SolR_GenerateScreenshot (image codecs) and the Kinect call.
  *
  * SolRx_* are extensions used by the test-suite and bench.py: engine
  * selection, deterministic timestamps/randoms, access to the flattened arrays

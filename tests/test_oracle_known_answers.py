@@ -370,3 +370,28 @@ def test_shadow_through_transparent_sphere(oracle):
     # shadowIntensity .4 < 1: the walk stops after the first opaque hit contributes 1 * .4 and clamps (GI:906)
     v, _ = shadow(oracle, s, scene_info(shadowIntensity=0.4), (0, 0, 20), (0, 0, 0), light_id=7)
     assert v == pytest.approx(0.4)
+
+
+def test_rounded_transcendentals_switch(oracle):
+    """oracle_set_rounded_transcendentals: off by default (libm's binary32 routines, what the reference's host
+    code calls), on = evaluated in binary64 and rounded once (what the engine does, so that frames with
+    procedural spheres or sphere / skybox UV maps compare exactly).  A frame without transcendentals but the
+    Blinn power may move by an ULP where powf is not the correctly rounded value, never more."""
+    lib = oracle.lib()
+    assert lib.oracle_get_rounded_transcendentals() == 0
+    k = solr.Kernel(engine="host-only")
+    solr.scenes.cornell(k, width=48, height=32, iterations=2)
+    flat = k.flat_scene()
+    si, ppi, eye, direction, angles = k.frame_parameters()
+    a = oracle.render(flat, si, ppi, eye, direction, angles)
+    try:
+        lib.oracle_set_rounded_transcendentals(1)
+        assert lib.oracle_get_rounded_transcendentals() == 1
+        b = oracle.render(flat, si, ppi, eye, direction, angles)
+    finally:
+        lib.oracle_set_rounded_transcendentals(0)
+    k.finalize()
+    assert lib.oracle_get_rounded_transcendentals() == 0
+    assert np.array_equal(a[1], b[1])
+    ulp = np.abs(a[0][..., :3].view(np.int32).astype(np.int64) - b[0][..., :3].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 4 and (ulp > 0).mean() < 0.05
