@@ -895,7 +895,19 @@ struct Counters
 {
     unsigned int closest, shadow, boxes, prims; /* per lane */
     unsigned int wNodes, wPrims, wClosest, wShadow; /* per wave (only lane 0's copy is reported) */
+#ifdef SOLR_TIMING
+    /* development build (make EXTRA_HIPFLAGS=-DSOLR_TIMING, tools/wave_time_split.py): shader-clock cycles a wave
+     * spends in the node loop, at leaves, in either walk as a whole, and how often */
+    unsigned long long tNode, tLeaf, tClosest, tShadow;
+    unsigned int nAdvance, nLeaf;
+#endif
 };
+#ifdef SOLR_TIMING
+#define SOLR_T(...) __VA_ARGS__
+#define SOLR_NOW() __builtin_readcyclecounter()
+#else
+#define SOLR_T(...)
+#endif
 
 template <bool COUNT>
 SOLR_DEV void countAdd(unsigned int &c, unsigned int v)
@@ -920,6 +932,8 @@ SOLR_DEV int waveMinInt(int v)
 /* What a walk holds of the primitive it is testing.  The first primitive of a leaf comes with the leaf's record
  * (scene_layout.h: one 64-byte scalar load brings head, the two rows its test reads next, and the start
  * index); further primitives of the leaf bring their head and fetch the other rows when a test asks. */
+template <int FEAT>
+SOLR_DEV bool extendedGeometry(const SceneInfo &si);
 struct PrimRec
 {
     Row2 head;   /* rows 0-1: p0 | tag, size | materialId */
@@ -941,6 +955,7 @@ SOLR_DEV int recIndex(const Scene &S, const PrimRec &r)
     return asint(r.packed ? r.c.w : primRow(S, r.pi, ROW_P1_INDEX).w);
 }
 /* primitive k of the leaf whose record is L (k == 0) or whose first primitive is `start` */
+template <int FEAT>
 SOLR_DEV PrimRec leafPrimitive(const Scene &S, const SceneInfo &si, const Row4 &L, int start, int k)
 {
     PrimRec r;
@@ -959,8 +974,41 @@ SOLR_DEV PrimRec leafPrimitive(const Scene &S, const SceneInfo &si, const Row4 &
     }
     /* without extended geometry every primitive is tested as a triangle (GI:743-747): a plane-class record's
      * packed rows hold its normal and colour, not p1 / p2 */
-    r.packed = (k == 0) && (si.extendedGeometry || !planeClass(asint(r.head.a.w) & PRIM_TYPE_MASK));
+    r.packed = (k == 0) && (extendedGeometry<FEAT>(si) || !planeClass(asint(r.head.a.w) & PRIM_TYPE_MASK));
     return r;
+}
+
+/* Instantiations without F_TRI are only launched with extended geometry (solr_hip.hip, the choice of the
+ * instantiation): there the flag is a compile-time fact. */
+template <int FEAT>
+SOLR_DEV bool extendedGeometry(const SceneInfo &si)
+{
+    return (FEAT & F_TRI) ? si.extendedGeometry != 0 : true;
+}
+/* PrimKind of the tag (scene_layout.h), KIND_GENERAL whenever the short paths do not apply */
+template <int FEAT>
+SOLR_DEV int primKind(const SceneInfo &si, int tag)
+{
+    const int kind = (int)((unsigned)tag >> PRIM_KIND_SHIFT);
+    return extendedGeometry<FEAT>(si) ? kind : (int)KIND_GENERAL;
+}
+/* the plane test of a KIND_PLANE_* primitive: planeIntersection with the type and the material facts it branches
+ * on as constants (no texture, no wireframe pattern, no chessboard light) */
+SOLR_DEV bool planePlain(const Scene &S, const SceneInfo &si, int kind, v3 p0, v3 size, v3 n0, float averageColor,
+                         const WalkRay &ray, Hit &h)
+{
+    PlaneMaterial pm;
+    pm.wireframe = 0;
+    pm.wireframeWidth = 0;
+    pm.emissive = false;
+    pm.textured = false;
+    pm.materialId = 0;
+    pm.averageColor = averageColor;
+    if (kind == KIND_PLANE_XY)
+        return planeIntersection<false>(si, ptXYPlane, p0, size, n0, pm, S, 0, ray, h);
+    if (kind == KIND_PLANE_YZ)
+        return planeIntersection<false>(si, ptYZPlane, p0, size, n0, pm, S, 0, ray, h);
+    return planeIntersection<false>(si, ptXZPlane, p0, size, n0, pm, S, 0, ray, h);
 }
 
 /* Uniform primitive test shared by both walks. */
@@ -972,13 +1020,14 @@ SOLR_DEV bool testPrimitive(const Scene &S, const SceneInfo &si, const PrimRec &
     const int type = tag & PRIM_TYPE_MASK;
     const v3 p0 = V4(head.a);
     const v3 size = V4(head.b);
-    int t = si.extendedGeometry ? type : (int)ptTriangle;
+    const bool extended = extendedGeometry<FEAT>(si);
+    int t = extended ? type : (int)ptTriangle;
     if (SHADOW)
     {
         /* GI:835-864: ptEnvironment is not a sphere here; ptCamera never shadows */
-        if (si.extendedGeometry && type == ptCamera)
+        if (extended && type == ptCamera)
             return false;
-        if (si.extendedGeometry && type == ptEnvironment)
+        if (extended && type == ptEnvironment)
             t = ptQuad; /* falls to planeIntersection, which has no case for it */
     }
     switch (t)
@@ -1353,6 +1402,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     bool intersections = false;
     if (ballot(active) == 0ull)
         return false;
+    SOLR_T(const unsigned long long tw0 = SOLR_NOW();)
     float minDistance = (iteration < 2) ? si.viewDistance : si.viewDistance / (iteration + 1);
     const WalkRay r = makeWalkRay(origin, target - origin);
     if (active)
@@ -1375,9 +1425,11 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     {
         int leaf = cur, nbPrimitives;
         bool entered;
+        SOLR_T(unsigned long long ta = SOLR_NOW();)
         if (tidy)
         {
             leaf = advanceTidy<FEAT>(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
+            SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)
             if (leaf < 0)
                 break;
         }
@@ -1405,7 +1457,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         const int start = uniform(asint(L.d.w));
         for (int k = 0; k < nbPrimitives; ++k)
         {
-            const PrimRec rec = leafPrimitive(S, si, L, start, k);
+            const PrimRec rec = leafPrimitive<FEAT>(S, si, L, start, k);
             const int pi = rec.pi;
             const Row2 &head = rec.head;
             const int tag = uniform(asint(head.a.w));
@@ -1419,7 +1471,31 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             if (lanes)
                 countAdd<COUNT>(cnt.prims, 1);
             const int type = tag & PRIM_TYPE_MASK;
-            if ((FEAT & (F_SPHERE | F_PROC)) && si.extendedGeometry && (type == ptSphere || type == ptEnvironment))
+            const int kind = primKind<FEAT>(si, tag);
+            if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY)
+            {
+                /* plain axis planes: the general test with its type and material switches settled at upload */
+                if (lanes)
+                {
+                    Hit h;
+                    h.intersection = V(0.f, 0.f, 0.f);
+                    h.normal = V(0.f, 0.f, 0.f);
+                    h.shadowIntensity = 0.f;
+                    const bool i = planePlain(S, si, kind, V4(head.a), V4(head.b), recPlaneNormal(S, rec),
+                                              recPlaneAverage(S, rec), r, h);
+                    const float distance = length(h.intersection - r.o);
+                    if (i && distance > si.geometryEpsilon && distance < minDistance)
+                    {
+                        minDistance = distance;
+                        closestPrimitive = pi;
+                        closestIntersection = h.intersection;
+                        closestNormal = h.normal;
+                        closestAreas = V(0.f, 0.f, 0.f);
+                        intersections = true;
+                    }
+                }
+            }
+            else if ((FEAT & (F_SPHERE | F_PROC)) && extendedGeometry<FEAT>(si) && (type == ptSphere || type == ptEnvironment))
             {
                 /* spheres: decide on the intersection point, pay for the normal only when
                  * the hit becomes the closest one (GI:749-760 uses nothing else before) */
@@ -1443,7 +1519,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     }
                 }
             }
-            else if ((FEAT & F_TRI) && (type == ptTriangle || !si.extendedGeometry))
+            else if ((FEAT & F_TRI) && (type == ptTriangle || !extendedGeometry<FEAT>(si)))
             {
                 /* triangles (every primitive, without extended geometry, GI:743-747): areas and the
                  * interpolated normal only for hits that become the closest one */
@@ -1494,7 +1570,9 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 }
             }
         }
+        SOLR_T(cnt.tLeaf += SOLR_NOW() - ta; ++cnt.nLeaf;)
     }
+    SOLR_T(cnt.tClosest += SOLR_NOW() - tw0;)
     return intersections;
 }
 
@@ -1508,6 +1586,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     color = V(0.f, 0.f, 0.f);
     if (ballot(active) == 0ull)
         return 0.f;
+    SOLR_T(const unsigned long long tw0 = SOLR_NOW();)
     WalkRay r = makeWalkRay(origin, lampCenter - origin);
     r.o = origin + r.dn * si.rayEpsilon; /* GI:810-811 */
     const float minDistance = (iteration < 2) ? si.viewDistance : si.viewDistance / (iteration + 1);
@@ -1532,9 +1611,11 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
             break;
         int leaf = cur, nbPrimitives;
         bool entered;
+        SOLR_T(unsigned long long ta = SOLR_NOW();)
         if (tidy)
         {
             leaf = advanceTidy<FEAT>(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
+            SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)
             if (leaf < 0)
                 break;
         }
@@ -1546,7 +1627,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         const int start = uniform(asint(L.d.w));
         for (int k = 0; k < nbPrimitives; ++k)
         {
-            const PrimRec rec = leafPrimitive(S, si, L, start, k);
+            const PrimRec rec = leafPrimitive<FEAT>(S, si, L, start, k);
             const int pi = rec.pi;
             const Row2 &head = rec.head;
             const int tag = uniform(asint(head.a.w));
@@ -1566,7 +1647,14 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
             h.areas = V(0.f, 0.f, 0.f);
             h.shadowIntensity = 0.f;
             bool hit = false;
-            if ((FEAT & (F_SPHERE | F_PROC)) && si.extendedGeometry && type == ptSphere)
+            const int kind = primKind<FEAT>(si, tag);
+            if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY)
+            {
+                if (lanes)
+                    hit = planePlain(S, si, kind, V4(head.a), V4(head.b), recPlaneNormal(S, rec), recPlaneAverage(S, rec),
+                                     r, h);
+            }
+            else if ((FEAT & (F_SPHERE | F_PROC)) && extendedGeometry<FEAT>(si) && type == ptSphere)
             {
                 /* opaque spheres shadow with intensity 1 and need no normal (GI:281, 880) */
                 bool back;
@@ -1579,7 +1667,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                                                            (tag & PRIM_TRANSPARENT) != 0, back, r, h);
                 }
             }
-            else if ((FEAT & F_TRI) && !si.doubleSidedTriangles && (type == ptTriangle || !si.extendedGeometry))
+            else if ((FEAT & F_TRI) && !si.doubleSidedTriangles && (type == ptTriangle || !extendedGeometry<FEAT>(si)))
             {
                 /* an opaque triangle shadows with intensity 1 whatever its normal (GI:880); with
                  * double-sided triangles the normal decides (GI:643-647) and the full test is used */
@@ -1625,8 +1713,10 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         /* the reference re-tests `result < shadowIntensity` before every node */
         if (cursor != SOLR_CURSOR_DONE && !(result < si.shadowIntensity))
             cursor = SOLR_CURSOR_DONE;
+        SOLR_T(cnt.tLeaf += SOLR_NOW() - ta; ++cnt.nLeaf;)
     }
     result = fmaxf(0.f, fminf(result, si.shadowIntensity));
+    SOLR_T(cnt.tShadow += SOLR_NOW() - tw0;)
     return result;
 }
 

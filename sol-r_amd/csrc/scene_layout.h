@@ -102,7 +102,21 @@ enum PrimTag
     PRIM_WIRE2 = 1 << 13,       /* material.attributes.z == 2 */
     PRIM_EMISSIVE = 1 << 14,    /* material.innerIllumination.x != 0 */
     PRIM_TEXTURED = 1 << 15,    /* material.textureIds.x != TEXTURE_NONE */
-    PRIM_WIDTH_SHIFT = 16       /* clamp(material.attributes.w, -1, 100) + 1 */
+    PRIM_WIDTH_SHIFT = 16,      /* clamp(material.attributes.w, -1, 100) + 1: bits 16-22 */
+    PRIM_KIND_SHIFT = 24        /* PrimKind: what the walks may assume about the primitive and its material */
+};
+
+/* The common primitives in their plain form get a short path through the walks (rt_device.h): the type and the
+ * material facts the tests branch on are settled at upload, the tests themselves are the general ones with
+ * those facts as compile-time constants.  Only meaningful with extended geometry (without it every primitive is
+ * tested as a triangle). */
+enum PrimKind
+{
+    KIND_GENERAL = 0,
+    KIND_SPHERE = 1,   /* ptSphere, not procedural */
+    KIND_PLANE_XY = 2, /* ptXYPlane / ptYZPlane / ptXZPlane: not textured, no wireframe mode 2, */
+    KIND_PLANE_YZ = 3, /* (YZ) not emissive */
+    KIND_PLANE_XZ = 4
 };
 
 enum PrimRow

@@ -61,6 +61,7 @@ struct FrameArgs
 #define ORDER_TILE_MASK 0x0fffffffu
 #define ORDER_PART_SHIFT 28
 #define ORDER_NOTHING 0xffffffffu
+#define SOLR_TIMING_SLOTS (160000ul) /* timing build: workgroups of the largest frame it is used on (3840 x 2160 + split tiles) */
 #define SPLIT_TILES_MAX 256
 
 #define TILE 8
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     cs.stride = WAVE;
     cs.cold = 4 * F.stackSlots;
 
-    Counters cnt = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    Counters cnt = {};
+    SOLR_T(const unsigned long long tKernel0 = SOLR_NOW();)
 
     v3 rayO = V(F.ox, F.oy, F.oz);
     v3 rayD = V(F.dx, F.dy, F.dz);
@@ -390,6 +392,21 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
         const unsigned cost = (unsigned)(__builtin_amdgcn_s_memrealtime() - clock0);
         F.tileCost[tileAgain] = partAgain ? 2u * cost : cost;
     }
+#ifdef SOLR_TIMING
+    if (!COUNT && laneAgain == 0 && counters)
+    {
+        /* one record per workgroup, summed by the host (atomics on one address would serialise the frame) */
+        unsigned long long *slot = counters + 16 + 8ull * blockIdx.x;
+        slot[0] += SOLR_NOW() - tKernel0;
+        slot[1] += cnt.tClosest;
+        slot[2] += cnt.tShadow;
+        slot[3] += cnt.tNode;
+        slot[4] += cnt.tLeaf;
+        slot[5] += (unsigned long long)cnt.nAdvance;
+        slot[6] += (unsigned long long)cnt.nLeaf;
+        slot[7] += 1ull;
+    }
+#endif
     if (COUNT)
     {
         unsigned int vals[4] = {cnt.closest, cnt.shadow, cnt.boxes, cnt.prims};
@@ -1275,7 +1292,16 @@ void allocateFrame()
     reserve(g.pp, pixels * sizeof(PostProcessingBuffer));
     reserve(g.ids, pixels * sizeof(PrimitiveXYIdBuffer));
     reserve(g.bitmap, pixels * SOLR_COLOR_DEPTH);
-    reserve(g.counters, 8 * sizeof(unsigned long long));
+#ifdef SOLR_TIMING
+    if (!g.counters.ptr)
+    {
+        reserve(g.counters, (16 + 8 * SOLR_TIMING_SLOTS) * sizeof(unsigned long long));
+        if (ok())
+            HIPCHECK(hipMemset(g.counters.ptr, 0, g.counters.bytes));
+    }
+#else
+    reserve(g.counters, 16 * sizeof(unsigned long long));
+#endif
     const bool fresh = grow || g.allocW != g.width || g.allocRows != rows;
     if (ok() && fresh)
     {
@@ -1473,7 +1499,13 @@ void retagPrimitives()
         const int type = tag & PRIM_TYPE_MASK;
         /* a material that was never uploaded reads as all zeros on the device */
         const int facts = (mat >= 0 && (size_t)mat < g.materialTags.size()) ? g.materialTags[mat] : (PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
-        r[ROW_P0_TYPE].w = bitsf(type | facts);
+        int kind = KIND_GENERAL;
+        if (type == ptSphere && !(facts & PRIM_PROCEDURAL))
+            kind = KIND_SPHERE;
+        else if ((type == ptXYPlane || type == ptYZPlane || type == ptXZPlane) && !(facts & (PRIM_TEXTURED | PRIM_WIRE2)) &&
+                 !(type == ptYZPlane && (facts & PRIM_EMISSIVE)))
+            kind = type == ptXYPlane ? KIND_PLANE_XY : (type == ptYZPlane ? KIND_PLANE_YZ : KIND_PLANE_XZ);
+        r[ROW_P0_TYPE].w = bitsf(type | facts | (kind << PRIM_KIND_SHIFT));
         r[ROW_P2].w = (mat >= 0 && (size_t)mat < g.materialAverage.size()) ? g.materialAverage[mat] : 0.f;
         switch (type)
         {
@@ -3194,4 +3226,26 @@ void solr_hip_comm_finalize(void)
         release(b);
     rccl.world = 0;
 }
+
+#ifdef SOLR_TIMING
+/* development build only (tools/wave_time_split.py): shader-clock cycles summed over the waves of every frame
+ * since the last reset - [0] whole kernel, [1] closest-hit walks, [2] shadow walks, [3] node loop, [4] leaves,
+ * [5] calls of the node loop, [6] leaf visits, [7] waves */
+void solr_hip_wave_cycles(unsigned long long out[8], int reset)
+{
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> slots(8 * SOLR_TIMING_SLOTS);
+    (void)hipMemcpy(slots.data(), (unsigned long long *)g.counters.ptr + 16, slots.size() * sizeof(unsigned long long),
+                    hipMemcpyDeviceToHost);
+    if (out)
+        for (int k = 0; k < 8; ++k)
+        {
+            out[k] = 0;
+            for (size_t w = 0; w < SOLR_TIMING_SLOTS; ++w)
+                out[k] += slots[8 * w + k];
+        }
+    if (reset)
+        (void)hipMemset((unsigned long long *)g.counters.ptr + 16, 0, slots.size() * sizeof(unsigned long long));
+}
+#endif
 }
