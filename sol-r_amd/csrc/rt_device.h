@@ -1462,21 +1462,40 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             const Row2 &head = rec.head;
             const int tag = uniform(asint(head.a.w));
             const int materialId = uniform(asint(head.b.w));
-            /* GI:704-705 */
-            const bool lanes = entered && ((tag & PRIM_FAST0) != 0 ||
-                                           ((tag & PRIM_FAST1) != 0 && currentMaterialId != materialId));
-            if (ballot(lanes) == 0ull)
-                continue;
-            countAdd<COUNT>(cnt.wPrims, 1);
-            if (lanes)
-                countAdd<COUNT>(cnt.prims, 1);
-            const int type = tag & PRIM_TYPE_MASK;
             const int kind = primKind<FEAT>(si, tag);
+            /* Short paths.  A primitive with a kind has a FAST0 material (GI:704-705: every lane that entered the
+             * leaf tests it) and its type and material facts are settled: the general tests with constants. */
+            if ((FEAT & F_SPHERE) && kind == KIND_SPHERE)
+            {
+                countAdd<COUNT>(cnt.wPrims, 1);
+                if (entered)
+                    countAdd<COUNT>(cnt.prims, 1);
+                Hit h;
+                bool back;
+                const bool i = sphereHit(si, V4(head.a), head.b.x, r, entered, h.intersection, back);
+                const float distance = length(h.intersection - r.o);
+                const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
+                if (ballot(keep) != 0ull)
+                {
+                    if (keep)
+                    {
+                        sphereNormal<false>(si, V4(head.a), V4(head.b), false, false, back, r, h);
+                        minDistance = distance;
+                        closestPrimitive = pi;
+                        closestIntersection = h.intersection;
+                        closestNormal = h.normal;
+                        closestAreas = V(0.f, 0.f, 0.f);
+                        intersections = true;
+                    }
+                }
+                continue;
+            }
             if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY)
             {
-                /* plain axis planes: the general test with its type and material switches settled at upload */
-                if (lanes)
+                countAdd<COUNT>(cnt.wPrims, 1);
+                if (entered)
                 {
+                    countAdd<COUNT>(cnt.prims, 1);
                     Hit h;
                     h.intersection = V(0.f, 0.f, 0.f);
                     h.normal = V(0.f, 0.f, 0.f);
@@ -1494,8 +1513,18 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                         intersections = true;
                     }
                 }
+                continue;
             }
-            else if ((FEAT & (F_SPHERE | F_PROC)) && extendedGeometry<FEAT>(si) && (type == ptSphere || type == ptEnvironment))
+            /* GI:704-705 */
+            const bool lanes = entered && ((tag & PRIM_FAST0) != 0 ||
+                                           ((tag & PRIM_FAST1) != 0 && currentMaterialId != materialId));
+            if (ballot(lanes) == 0ull)
+                continue;
+            countAdd<COUNT>(cnt.wPrims, 1);
+            if (lanes)
+                countAdd<COUNT>(cnt.prims, 1);
+            const int type = tag & PRIM_TYPE_MASK;
+            if ((FEAT & (F_SPHERE | F_PROC)) && extendedGeometry<FEAT>(si) && (type == ptSphere || type == ptEnvironment))
             {
                 /* spheres: decide on the intersection point, pay for the normal only when
                  * the hit becomes the closest one (GI:749-760 uses nothing else before) */
@@ -1648,7 +1677,19 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
             h.shadowIntensity = 0.f;
             bool hit = false;
             const int kind = primKind<FEAT>(si, tag);
-            if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY)
+            if ((FEAT & F_SPHERE) && kind == KIND_SPHERE)
+            {
+                /* plain spheres: intensity 1 and no normal when opaque (GI:281, 880) */
+                bool back;
+                hit = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
+                h.shadowIntensity = 1.f;
+                if (tag & PRIM_TRANSPARENT)
+                {
+                    if (hit)
+                        sphereNormal<false>(si, V4(head.a), V4(head.b), false, true, back, r, h);
+                }
+            }
+            else if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY)
             {
                 if (lanes)
                     hit = planePlain(S, si, kind, V4(head.a), V4(head.b), recPlaneNormal(S, rec), recPlaneAverage(S, rec),

@@ -109,7 +109,7 @@ enum PrimTag
 /* The common primitives in their plain form get a short path through the walks (rt_device.h): the type and the
  * material facts the tests branch on are settled at upload, the tests themselves are the general ones with
  * those facts as compile-time constants.  Only meaningful with extended geometry (without it every primitive is
- * tested as a triangle). */
+ * tested as a triangle).  Every kind but KIND_GENERAL implies a material with attributes.x == 0 (PRIM_FAST0). */
 enum PrimKind
 {
     KIND_GENERAL = 0,

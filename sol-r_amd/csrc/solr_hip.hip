@@ -730,6 +730,9 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
 }
 
 /* CRT:1128-1181; gathers stay inside this process's strip */
+#define AO_TILE_W 32
+#define AO_TILE_H 8
+#define AO_WINDOW_FLOATS 8192 /* LDS window of a tile: (AO_TILE_W + 2 rx) x (AO_TILE_H + 2 ry) depths */
 __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
                                                           const PixelRecord *__restrict__ pp,
                                                           const float *__restrict__ randoms, long nbRandoms,
@@ -738,11 +741,26 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
     /* The 256 taps of a pixel sit at x + X * param2 * randoms[i % wh] / 10.f, y + Y * param2 * randoms[(i + 100)
      * % wh] / 10.f (CRT:1146-1153): the offsets depend on the tap, not on the pixel.  The workgroup's 256
      * threads evaluate one tap's pair each - the same expressions, the two correctly rounded divisions
-     * included - and every pixel then adds them to its coordinates: 2 divisions per thread instead of 512. */
+     * included - and every pixel then adds them to its coordinates: 2 divisions per thread instead of 512.
+     *
+     * A workgroup is a 32 x 8 tile of pixels.  Every tap of every pixel of the tile lands within
+     * rx = max |tapX| + 1 columns and ry = max |tapY| + 1 rows of the tile: that window of depths (colorInfo.w
+     * of the 32-byte frame-buffer records) is read once into LDS - 2 772 four-byte reads for cfg4's taps of up to
+     * 16 pixels instead of 65 536 - and the 256 comparisons of a pixel read LDS, consecutive lanes consecutive
+     * words.  Same comparisons on the same values, counted in floats that stay exact integers: the order of the
+     * additions does not matter.  A window that does not fit (param2 beyond about 25) is gathered from memory as
+     * before. */
     __shared__ float tapX[256], tapY[256];
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int reach[2];
+    __shared__ float window[AO_WINDOW_FLOATS];
     const int W = si.size.x;
     const int wh = W * nbRows;
+    const int tilesX = (W + AO_TILE_W - 1) / AO_TILE_W;
+    const int x0 = (int)(blockIdx.x % (unsigned)tilesX) * AO_TILE_W;
+    const int y0 = (int)(blockIdx.x / (unsigned)tilesX) * AO_TILE_H;
+    if (threadIdx.x < 2)
+        reach[threadIdx.x] = 0;
+    __syncthreads();
     {
         const int i = threadIdx.x; /* tap i: X = -16 + 2 * (i / 16), Y = -16 + 2 * (i % 16), in loop order */
         const int X = -16 + 2 * (i >> 4), Y = -16 + 2 * (i & 15);
@@ -750,31 +768,85 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
         const int iy = (i + 100) % wh;
         const float rx = (ix < nbRandoms) ? randoms[ix] : 0.f;
         const float ry = (iy < nbRandoms) ? randoms[iy] : 0.f;
-        tapX[i] = X * ppi.param2 * rx / 10.f;
-        tapY[i] = Y * ppi.param2 * ry / 10.f;
+        const float tx = X * ppi.param2 * rx / 10.f;
+        const float ty = Y * ppi.param2 * ry / 10.f;
+        tapX[i] = tx;
+        tapY[i] = ty;
+        /* (int)(x + t) stays within ceil(|t|) + 1 of x for an integer x below 2^23; anything else (NaN, huge)
+         * sends the tile down the gather path */
+        const float ax = fabsf(tx), ay = fabsf(ty);
+        const int cx = (ax < 1.0e6f) ? (int)ax + 2 : (1 << 20);
+        const int cy = (ay < 1.0e6f) ? (int)ay + 2 : (1 << 20);
+        atomicMax(&reach[0], cx);
+        atomicMax(&reach[1], cy);
     }
     __syncthreads();
-    if (index >= wh)
+    const int rx = reach[0], ry = reach[1];
+    const int ww = AO_TILE_W + 2 * rx, wrows = AO_TILE_H + 2 * ry;
+    const bool tiled = rx < 4096 && ry < 4096 && ww * wrows <= AO_WINDOW_FLOATS;
+    const int wx0 = x0 - rx, wy0 = y0 - ry;
+    if (tiled)
+    {
+        for (int i = threadIdx.x; i < ww * wrows; i += 256)
+        {
+            const int gx = wx0 + i % ww, gy = wy0 + i / ww;
+            window[i] = (gx >= 0 && gx < W && gy >= 0 && gy < nbRows) ? pp[gy * W + gx].colorInfo.w : 0.f;
+        }
+        __syncthreads();
+    }
+    const int x = x0 + (int)(threadIdx.x % AO_TILE_W);
+    const int y = y0 + (int)(threadIdx.x / AO_TILE_W);
+    if (x >= W || y >= nbRows)
         return;
-    const int x = index % W;
-    const int y = index / W;
+    const int index = y * W + x;
     float occ = 0.f;
     float4 local = pp[index].colorInfo;
     float depth = local.w;
     float c = 0.f;
-    for (int i = 0; i < 256; ++i)
+    if (tiled)
     {
-        c += 1.f;
-        int xx = (int)(x + tapX[i]);
-        int yy = (int)(y + tapY[i]);
-        if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
+        /* a tile whose window lies inside the frame needs no bounds test per tap */
+        const bool inside = wx0 >= 0 && wy0 >= 0 && wx0 + ww <= W && wy0 + wrows <= nbRows;
+        if (inside)
         {
-            int localIndex = yy * W + xx;
-            if (pp[localIndex].colorInfo.w >= depth)
-                occ += 1.f;
+#pragma unroll 8
+            for (int i = 0; i < 256; ++i)
+            {
+                const int xx = (int)(x + tapX[i]);
+                const int yy = (int)(y + tapY[i]);
+                occ += (window[(yy - wy0) * ww + (xx - wx0)] >= depth) ? 1.f : 0.f;
+            }
         }
         else
-            occ += 1.f;
+        {
+            for (int i = 0; i < 256; ++i)
+            {
+                const int xx = (int)(x + tapX[i]);
+                const int yy = (int)(y + tapY[i]);
+                if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
+                    occ += (window[(yy - wy0) * ww + (xx - wx0)] >= depth) ? 1.f : 0.f;
+                else
+                    occ += 1.f;
+            }
+        }
+        c = 256.f;
+    }
+    else
+    {
+        for (int i = 0; i < 256; ++i)
+        {
+            c += 1.f;
+            int xx = (int)(x + tapX[i]);
+            int yy = (int)(y + tapY[i]);
+            if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
+            {
+                int localIndex = yy * W + xx;
+                if (pp[localIndex].colorInfo.w >= depth)
+                    occ += 1.f;
+            }
+            else
+                occ += 1.f;
+        }
     }
     occ /= (float)c;
     occ += 0.3f;
@@ -1500,7 +1572,9 @@ void retagPrimitives()
         /* a material that was never uploaded reads as all zeros on the device */
         const int facts = (mat >= 0 && (size_t)mat < g.materialTags.size()) ? g.materialTags[mat] : (PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
         int kind = KIND_GENERAL;
-        if (type == ptSphere && !(facts & PRIM_PROCEDURAL))
+        if (!(facts & PRIM_FAST0))
+            kind = KIND_GENERAL; /* the closest-hit walk lets every lane of the leaf test a primitive with a kind */
+        else if (type == ptSphere && !(facts & PRIM_PROCEDURAL))
             kind = KIND_SPHERE;
         else if ((type == ptXYPlane || type == ptYZPlane || type == ptXZPlane) && !(facts & (PRIM_TEXTURED | PRIM_WIRE2)) &&
                  !(type == ptYZPlane && (facts & PRIM_EMISSIVE)))
@@ -1922,7 +1996,9 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         const int nbPixels = sceneInfo.size.x * F.nbRows;
         const dim3 pgrid((nbPixels + 255) / 256), pblock(256);
         if (ppInfo.type == ppe_ambientOcclusion)
-            hipLaunchKernelGGL(k_ambientOcclusion, pgrid, pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
+            hipLaunchKernelGGL(k_ambientOcclusion,
+                               dim3(((sceneInfo.size.x + AO_TILE_W - 1) / AO_TILE_W) * ((F.nbRows + AO_TILE_H - 1) / AO_TILE_H)),
+                               pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
                                (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
                                g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
         else if (ppInfo.type == ppe_depthOfField)
