@@ -807,28 +807,33 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
     {
         /* a tile whose window lies inside the frame needs no bounds test per tap */
         const bool inside = wx0 >= 0 && wy0 >= 0 && wx0 + ww <= W && wy0 + wrows <= nbRows;
+        /* counted in an integer (at most 256: the float sum of the reference is the same number) */
+        const int origin = -(wy0 * ww + wx0);
+        const float fx = (float)x, fy = (float)y;
+        int count = 0;
         if (inside)
         {
 #pragma unroll 8
             for (int i = 0; i < 256; ++i)
             {
-                const int xx = (int)(x + tapX[i]);
-                const int yy = (int)(y + tapY[i]);
-                occ += (window[(yy - wy0) * ww + (xx - wx0)] >= depth) ? 1.f : 0.f;
+                const int xx = (int)(fx + tapX[i]);
+                const int yy = (int)(fy + tapY[i]);
+                count += (window[__mul24(yy, ww) + xx + origin] >= depth) ? 1 : 0;
             }
         }
         else
         {
             for (int i = 0; i < 256; ++i)
             {
-                const int xx = (int)(x + tapX[i]);
-                const int yy = (int)(y + tapY[i]);
+                const int xx = (int)(fx + tapX[i]);
+                const int yy = (int)(fy + tapY[i]);
                 if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
-                    occ += (window[(yy - wy0) * ww + (xx - wx0)] >= depth) ? 1.f : 0.f;
+                    count += (window[__mul24(yy, ww) + xx + origin] >= depth) ? 1 : 0;
                 else
-                    occ += 1.f;
+                    count += 1;
             }
         }
+        occ = (float)count;
         c = 256.f;
     }
     else
