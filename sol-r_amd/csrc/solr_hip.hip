@@ -1566,6 +1566,7 @@ void retagPrimitives()
 {
     pullGeometry();
     const size_t n = g.hostPrims.size() / PRIM_ROWS;
+    const bool noKinds = getenv("SOLR_HIP_NO_KINDS") != nullptr; /* tests: every primitive through the general tests */
     int features = 0;
     for (size_t i = 0; i < n; ++i)
     {
@@ -1577,7 +1578,7 @@ void retagPrimitives()
         /* a material that was never uploaded reads as all zeros on the device */
         const int facts = (mat >= 0 && (size_t)mat < g.materialTags.size()) ? g.materialTags[mat] : (PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
         int kind = KIND_GENERAL;
-        if (!(facts & PRIM_FAST0))
+        if (noKinds || !(facts & PRIM_FAST0))
             kind = KIND_GENERAL; /* the closest-hit walk lets every lane of the leaf test a primitive with a kind */
         else if (type == ptSphere && !(facts & PRIM_PROCEDURAL))
             kind = KIND_SPHERE;
@@ -2289,6 +2290,121 @@ void solr_hip_reshape(const SceneInfo *sceneInfo)
     reshape_scene(occ, *sceneInfo);
 }
 
+/* Inner nodes that hardly ever cull are left out of the walk list.  An inner node - one of the reference's tree
+ * whose children all lie inside it, or a grouping node, which is the union of its members - passes whenever one
+ * of its children would (the argument of groupSiblings below, read the other way: slab values are monotonic in
+ * the bounds, the cut-off only shrinks along a walk), so testing the children without it reaches the same
+ * leaves in the same order.  What the node buys is the tests of its subtree for the rays that miss it; what it
+ * costs is one test for those that do not.  A ray that is in the parent enters the node
+ *   - because it starts there: the rays of a frame start on the geometry (and at the camera, which is in the
+ *     room it looks at), so about the share of the parent's leaves whose centre lies in the node;
+ *   - otherwise with the surface-area probability area(node) / area(parent).
+ * The node stays if (1 - the larger of the two) x (nodes below it) is at least `threshold` tests.  Cornell's
+ * upper cells and the groups around its walls hold every leaf centre of the room: they go, the groups of small
+ * spheres on the floor stay.  Works on the walk-order rows in place; returns the new node count. */
+static int pruneInnerNodes(std::vector<float4> &rows, std::vector<int> &start, std::vector<int> &origin, int *nbPruned)
+{
+    const int n = (int)start.size();
+    const double threshold = getenv("SOLR_HIP_PRUNE") ? atof(getenv("SOLR_HIP_PRUNE")) : 1.0;
+    *nbPruned = 0;
+    if (n < 2 || !(threshold > 0.0))
+        return n;
+    auto skipOf = [&](int i) { return std::max(bitsi(rows[2 * i + 1].w), 1); };
+    auto countOf = [&](int i) { return bitsi(rows[2 * i + 1].z); };
+    auto lo = [&](int i, int k) { return k == 0 ? rows[2 * i].x : (k == 1 ? rows[2 * i].y : rows[2 * i].z); };
+    auto hi = [&](int i, int k) { return k == 0 ? rows[2 * i + 1].x : (k == 1 ? rows[2 * i + 1].y : rows[2 * i].w); };
+    auto areaOf = [&](int i) {
+        const double x = (double)hi(i, 0) - lo(i, 0), y = (double)hi(i, 1) - lo(i, 1), z = (double)hi(i, 2) - lo(i, 2);
+        return x * y + y * z + z * x;
+    };
+    std::vector<int> leaves; /* node indices of the leaves, in walk order */
+    std::vector<int> leavesBefore(n + 1, 0);
+    for (int i = 0; i < n; ++i)
+    {
+        leavesBefore[i + 1] = leavesBefore[i] + (countOf(i) > 0 ? 1 : 0);
+        if (countOf(i) > 0)
+            leaves.push_back(i);
+    }
+    std::vector<char> keep(n, 1);
+    struct Open
+    {
+        int node, end;
+    };
+    std::vector<Open> open; /* kept ancestors of node i */
+    double sceneLo[3] = {1e300, 1e300, 1e300}, sceneHi[3] = {-1e300, -1e300, -1e300};
+    for (int j = 0; j < n; j += skipOf(j))
+        for (int k = 0; k < 3; ++k)
+        {
+            sceneLo[k] = std::min(sceneLo[k], (double)lo(j, k));
+            sceneHi[k] = std::max(sceneHi[k], (double)hi(j, k));
+        }
+    const double sceneArea = (sceneHi[0] - sceneLo[0]) * (sceneHi[1] - sceneLo[1]) + (sceneHi[1] - sceneLo[1]) * (sceneHi[2] - sceneLo[2]) +
+                             (sceneHi[2] - sceneLo[2]) * (sceneHi[0] - sceneLo[0]);
+    for (int i = 0; i < n; ++i)
+    {
+        while (!open.empty() && open.back().end <= i)
+            open.pop_back();
+        const int end = std::min(i + skipOf(i), n);
+        if (countOf(i) == 0 && end > i + 1)
+        {
+            const int parentFrom = open.empty() ? 0 : open.back().node, parentTo = open.empty() ? n : open.back().end;
+            const double parentArea = open.empty() ? sceneArea : areaOf(open.back().node);
+            const double bySurface = parentArea > 0.0 ? std::min(1.0, areaOf(i) / parentArea) : 1.0;
+            /* share of the parent's leaves whose centre lies in the node (sampled beyond 4096 leaves) */
+            const int firstLeaf = leavesBefore[parentFrom], lastLeaf = leavesBefore[parentTo];
+            const int stride = std::max(1, (lastLeaf - firstLeaf) / 4096);
+            int sampled = 0, inside = 0;
+            for (int q = firstLeaf; q < lastLeaf; q += stride)
+            {
+                const int leaf = leaves[q];
+                bool in = true;
+                for (int k = 0; k < 3 && in; ++k)
+                {
+                    const double c = 0.5 * ((double)lo(leaf, k) + hi(leaf, k));
+                    in = c >= lo(i, k) && c <= hi(i, k);
+                }
+                ++sampled;
+                inside += in ? 1 : 0;
+            }
+            const double byOrigin = sampled ? (double)inside / sampled : 1.0;
+            bool encloses = true; /* every child within the node: what the argument above rests on */
+            for (int j = i + 1; j < end && encloses; j += skipOf(j))
+                for (int k = 0; k < 3; ++k)
+                    encloses = encloses && lo(j, k) >= lo(i, k) && hi(j, k) <= hi(i, k);
+            if (encloses && (1.0 - std::max(bySurface, byOrigin)) * (end - i - 1) < threshold)
+            {
+                keep[i] = 0;
+                ++*nbPruned;
+                continue;
+            }
+        }
+        open.push_back({i, end});
+    }
+    if (*nbPruned == 0)
+        return n;
+    std::vector<int> newIndex(n + 1, 0);
+    for (int i = 0; i < n; ++i)
+        newIndex[i + 1] = newIndex[i] + (keep[i] ? 1 : 0);
+    const int m = newIndex[n];
+    std::vector<float4> outRows(2 * (size_t)m);
+    std::vector<int> outStart(m), outOrigin(m);
+    for (int i = 0; i < n; ++i)
+        if (keep[i])
+        {
+            const int j = newIndex[i];
+            const int end = std::min(i + skipOf(i), n);
+            outRows[2 * j] = rows[2 * i];
+            outRows[2 * j + 1] = rows[2 * i + 1];
+            outRows[2 * j + 1].w = bitsf(newIndex[end] - j);
+            outStart[j] = start[i];
+            outOrigin[j] = origin[i];
+        }
+    rows.swap(outRows);
+    start.swap(outStart);
+    origin.swap(outOrigin);
+    return m;
+}
+
 /* Grouping nodes.  The reference's grid builder produces wide levels - 31 sibling leaves under the root of
  * the Cornell scene, 134 top-level cells for the 100k-primitive molecule - and a walk tests every sibling
  * of every node it enters.  Here runs of CONSECUTIVE siblings are wrapped in nodes of our own whose bounds
@@ -2572,13 +2688,17 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
             startC[j] = start[i];
         }
 
-    int nbWalkNodes = nc;
+    int nbWalkNodes = nc, prunedBefore = 0, prunedAfter = 0;
     if (g.nested && g.orderedCompact && nc > 0 && g.grouping)
-        nbWalkNodes = groupSiblings(boxesC, startC, originC);
+    {
+        pruneInnerNodes(boxesC, startC, originC, &prunedBefore); /* cells that do not cull: their children join the run above */
+        groupSiblings(boxesC, startC, originC);
+        nbWalkNodes = pruneInnerNodes(boxesC, startC, originC, &prunedAfter); /* groups that do not cull either */
+    }
     if (getenv("SOLR_HIP_DEBUG_TREE"))
     {
-        fprintf(stderr, "solr_hip: %d nodes uploaded, %d after collapsing chains, %d with grouping nodes\n",
-                nbActiveBoxes, nc, nbWalkNodes);
+        fprintf(stderr, "solr_hip: %d nodes uploaded, %d after collapsing chains, %d in the walk list (%d + %d inner nodes that hardly cull left out)\n",
+                nbActiveBoxes, nc, nbWalkNodes, prunedBefore, prunedAfter);
         if (nbWalkNodes <= 80)
             for (int i = 0; i < nbWalkNodes; ++i)
                 fprintf(stderr, "  node %2d: prims %d skip %d  [%g %g %g .. %g %g %g]\n", i, bitsi(boxesC[2 * i + 1].z),

@@ -633,3 +633,37 @@ def test_fisheye_camera_through_refinement_and_accumulation_passes(solr, oracle)
                       cameraType=solr_mod.ctPanoramic)
     print(res)
     assert_parity(res, max_ulp=2)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "primitives_mix"])
+def test_short_paths_of_plain_primitives_change_nothing(solr, oracle, scene):
+    """plain spheres and axis planes are classified at upload (PrimKind in the primitive's tag) and take a short
+    path through both walks; SOLR_HIP_NO_KINDS sends every primitive through the general tests: same frame, bit
+    for bit, and both are the oracle's"""
+    import os
+    build = solr.scenes.cornell if scene == "cornell" else X.primitives_mix
+    frames = []
+    for no_kinds in (False, True):
+        if no_kinds:
+            os.environ["SOLR_HIP_NO_KINDS"] = "1"
+        try:
+            k = solr.Kernel(engine="hip")
+            if scene == "cornell":
+                build(k, width=160, height=120, iterations=3)
+            else:
+                build(k)
+            pp, ids, rgb = gpu_frame(k)
+            if not no_kinds:
+                opp, oids, orgb, _, status = oracle_frame(k, oracle)
+                assert status == 0
+                res = compare_frames(pp, ids, rgb, opp, oids, orgb)
+                if scene == "cornell":
+                    assert_parity(res)
+                else:   # libm's binary32 sinf / cosf on the procedural sphere: test_every_primitive_type
+                    assert res["pixels_over_1ulp"] <= 12 and res["rgb_max_diff"] <= 2, res
+            frames.append((np.array(pp, copy=True), np.array(ids, copy=True), np.array(rgb, copy=True)))
+            k.finalize()
+        finally:
+            os.environ.pop("SOLR_HIP_NO_KINDS", None)
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
+    assert np.array_equal(frames[0][1], frames[1][1]) and np.array_equal(frames[0][2], frames[1][2])
