@@ -2503,8 +2503,10 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start, std
     };
     /* tuning knobs (tools/group_sweep.sh); parts[] / next[] below hold at most 2^4 parts */
     const int flatMax = std::max(1, getenv("SOLR_HIP_GROUP_FLAT") ? atoi(getenv("SOLR_HIP_GROUP_FLAT")) : 4);
-    const int levels =
-        std::min(4, std::max(0, getenv("SOLR_HIP_GROUP_LEVELS") ? atoi(getenv("SOLR_HIP_GROUP_LEVELS")) : 2));
+    /* (a list of a few dozen nodes - the Cornell room - gains 2 % from a third round of splits, lists of
+     * thousands lose 7 %: profiles/r2/group_sweep.txt) */
+    const int levels = std::min(
+        4, std::max(0, getenv("SOLR_HIP_GROUP_LEVELS") ? atoi(getenv("SOLR_HIP_GROUP_LEVELS")) : (n <= 64 ? 3 : 2)));
     emit.siblings = [&](const std::vector<int> &sib, int from, int to) {
         if (to - from <= flatMax)
         {
