@@ -1490,7 +1490,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 }
                 continue;
             }
-            if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY)
+            if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY && kind <= KIND_PLANE_XZ)
             {
                 countAdd<COUNT>(cnt.wPrims, 1);
                 if (entered)
@@ -1502,6 +1502,65 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     h.shadowIntensity = 0.f;
                     const bool i = planePlain(S, si, kind, V4(head.a), V4(head.b), recPlaneNormal(S, rec),
                                               recPlaneAverage(S, rec), r, h);
+                    const float distance = length(h.intersection - r.o);
+                    if (i && distance > si.geometryEpsilon && distance < minDistance)
+                    {
+                        minDistance = distance;
+                        closestPrimitive = pi;
+                        closestIntersection = h.intersection;
+                        closestNormal = h.normal;
+                        closestAreas = V(0.f, 0.f, 0.f);
+                        intersections = true;
+                    }
+                }
+                continue;
+            }
+            if ((FEAT & F_TRI) && kind == KIND_TRIANGLE)
+            {
+                /* as the general triangle branch below */
+                countAdd<COUNT>(cnt.wPrims, 1);
+                if (entered)
+                    countAdd<COUNT>(cnt.prims, 1);
+                Hit h;
+                h.intersection = V(0.f, 0.f, 0.f);
+                bool i = false;
+                const v3 p0 = V4(head.a);
+                const v3 p1 = recP1(S, rec);
+                const v3 p2 = recP2(S, rec);
+                if (entered)
+                    i = triangleHit(si, p0, p1, p2, r, h.intersection);
+                const float distance = length(h.intersection - r.o);
+                const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
+                if (ballot(keep) != 0ull)
+                {
+                    const v3 n0 = V4(primRow(S, pi, ROW_N0));
+                    const v3 n1 = V4(primRow(S, pi, ROW_N1));
+                    const v3 n2 = V4(primRow(S, pi, ROW_N2));
+                    if (keep)
+                    {
+                        triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
+                        minDistance = distance;
+                        closestPrimitive = pi;
+                        closestIntersection = h.intersection;
+                        closestNormal = h.normal;
+                        closestAreas = h.areas;
+                        intersections = true;
+                    }
+                }
+                continue;
+            }
+            if ((FEAT & F_CYL) && kind == KIND_CYLINDER)
+            {
+                countAdd<COUNT>(cnt.wPrims, 1);
+                if (entered)
+                {
+                    countAdd<COUNT>(cnt.prims, 1);
+                    Hit h;
+                    h.intersection = V(0.f, 0.f, 0.f);
+                    h.normal = V(0.f, 0.f, 0.f);
+                    h.shadowIntensity = 0.f;
+                    const bool i = cylinderIntersection(si, V4(head.a), recP1(S, rec), recP2(S, rec),
+                                                        V4(primRow(S, pi, ROW_N1)), V4(head.b), r, h);
                     const float distance = length(h.intersection - r.o);
                     if (i && distance > si.geometryEpsilon && distance < minDistance)
                     {
@@ -1689,7 +1748,31 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                         sphereNormal<false>(si, V4(head.a), V4(head.b), false, true, back, r, h);
                 }
             }
-            else if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY)
+            else if ((FEAT & F_TRI) && kind == KIND_TRIANGLE && !si.doubleSidedTriangles)
+            {
+                /* as the general triangle branch below */
+                const v3 p0 = V4(head.a);
+                const v3 p1 = recP1(S, rec);
+                const v3 p2 = recP2(S, rec);
+                if (lanes)
+                    hit = triangleHit(si, p0, p1, p2, r, h.intersection);
+                h.shadowIntensity = 1.f;
+                if (tag & PRIM_TRANSPARENT)
+                {
+                    const v3 n0 = V4(primRow(S, pi, ROW_N0));
+                    const v3 n1 = V4(primRow(S, pi, ROW_N1));
+                    const v3 n2 = V4(primRow(S, pi, ROW_N2));
+                    if (hit)
+                        triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
+                }
+            }
+            else if ((FEAT & F_CYL) && kind == KIND_CYLINDER)
+            {
+                if (lanes)
+                    hit = cylinderIntersection(si, V4(head.a), recP1(S, rec), recP2(S, rec), V4(primRow(S, pi, ROW_N1)),
+                                               V4(head.b), r, h);
+            }
+            else if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY && kind <= KIND_PLANE_XZ)
             {
                 if (lanes)
                     hit = planePlain(S, si, kind, V4(head.a), V4(head.b), recPlaneNormal(S, rec), recPlaneAverage(S, rec),

@@ -116,7 +116,9 @@ enum PrimKind
     KIND_SPHERE = 1,   /* ptSphere, not procedural */
     KIND_PLANE_XY = 2, /* ptXYPlane / ptYZPlane / ptXZPlane: not textured, no wireframe mode 2, */
     KIND_PLANE_YZ = 3, /* (YZ) not emissive */
-    KIND_PLANE_XZ = 4
+    KIND_PLANE_XZ = 4,
+    KIND_TRIANGLE = 5, /* ptTriangle */
+    KIND_CYLINDER = 6  /* ptCylinder, ptCone (one test, GI:293-416) */
 };
 
 enum PrimRow

@@ -1585,6 +1585,10 @@ void retagPrimitives()
         else if ((type == ptXYPlane || type == ptYZPlane || type == ptXZPlane) && !(facts & (PRIM_TEXTURED | PRIM_WIRE2)) &&
                  !(type == ptYZPlane && (facts & PRIM_EMISSIVE)))
             kind = type == ptXYPlane ? KIND_PLANE_XY : (type == ptYZPlane ? KIND_PLANE_YZ : KIND_PLANE_XZ);
+        else if (type == ptTriangle)
+            kind = KIND_TRIANGLE;
+        else if (type == ptCylinder || type == ptCone)
+            kind = KIND_CYLINDER;
         r[ROW_P0_TYPE].w = bitsf(type | facts | (kind << PRIM_KIND_SHIFT));
         r[ROW_P2].w = (mat >= 0 && (size_t)mat < g.materialAverage.size()) ? g.materialAverage[mat] : 0.f;
         switch (type)

@@ -52,6 +52,11 @@ for scene in ("cornell", "height_field", "molecule"):
 if traffic:
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "tile_timeline_*.txt")) + glob.glob(os.path.join(src, "strip_times_*.txt")) + \
-        glob.glob(os.path.join(src, "reference_opencl_speed.txt")) + glob.glob(os.path.join(src, "valu_issue_bench.txt")):
+        glob.glob(os.path.join(src, "reference_opencl_speed.txt")) + glob.glob(os.path.join(src, "valu_issue_bench.txt")) + \
+        glob.glob(os.path.join(src, "wave_time_split_*.txt")) + glob.glob(os.path.join(src, "bench_cfg4.json")) + \
+        glob.glob(os.path.join(src, "upload_time.txt")) + glob.glob(os.path.join(src, "group_sweep.txt")):
     shutil.copy(f, dst)
+st = os.path.join(src, "trace_cfg4", "trace_kernel_stats.csv")
+if os.path.exists(st):
+    shutil.copy(st, os.path.join(dst, "kernel_stats_cfg4.csv"))
 print(sorted(os.listdir(dst)))
