@@ -41,7 +41,7 @@ SALU_PEAK_WAVE_INSTS_PER_S = 256 * 2.4e9
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; --config cfg4: 74, one whole cycle of passes)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -80,6 +80,8 @@ def main():
         args.scene, args.width, args.height, args.iterations = "cornell", 3840, 2160, 1
         args.frames_in_flight = 1          # every pass reads what the pass before left in the frame buffers
     cfg4 = args.config == "cfg4"
+    if args.steps is None:
+        args.steps = 74 if cfg4 else 20    # cfg4's passes differ in cost (refinement passes re-render with more bounces)
     if os.environ.get("SOLR_BENCH_DEBUG"):
         import faulthandler
         import signal
@@ -301,6 +303,8 @@ def main():
         import numpy as np
         hip.solr_hip_set_frames_in_flight(1)
         n_extra = max(8, min(args.steps, 64))
+        if cfg4:
+            n_extra = 74  # one whole cycle of passes 0...73 (they differ in cost), wherever the timed region stopped
         for _ in range(4):
             frame()
         sync()

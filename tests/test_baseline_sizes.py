@@ -136,6 +136,30 @@ def test_full_size_frames_match_the_oracle_on_rows_across_the_frame(solr, oracle
         k.finalize()
 
 
+@pytest.mark.gpu
+def test_cfg0_whole_frame(solr, oracle):
+    """cfg0: the Cornell scene at 512 x 512, one bounce - the configuration the reference's CPU engine is quoted
+    on (BASELINE.json configs[0]).  Small enough for the oracle to render whole: every pixel is compared."""
+    k = solr.Kernel(engine="hip")
+    try:
+        solr.scenes.cornell(k, width=512, height=512, iterations=1)
+        k.render()
+        k.check(0, "cfg0")
+        args = _frame_args(solr, k)
+        flat, si, ppi, eye, direction, angles, _ = args
+        assert (si.size_x, si.size_y, si.nbRayIterations) == (512, 512, 1)
+        _render(solr, args)
+        frame = device_frame(solr, si)
+        opp, oids, orgb, _, status = oracle.render(flat, si, ppi, eye, direction, angles)
+        assert status == 0
+        res = compare_frames(frame[0], frame[1], frame[2], opp, oids, orgb)
+        res["what"] = "cfg0"
+        assert_parity(res)
+        assert (oids[..., 0] >= 0).mean() > 0.5
+    finally:
+        k.finalize()
+
+
 # ---- cfg4 --------------------------------------------------------------------------------------------------
 W4, H4 = 3840, 2160
 PASSES = list(range(0, 74))
