@@ -133,6 +133,18 @@ void *solr_hip_gathered_frame(void);
 int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap);
 void solr_hip_comm_finalize(void);
 
+/* Neighbourhood post-processing on a strip.  The ambient-occlusion kernel (CudaRayTracer.cu:1128-1181) compares a
+ * pixel's depth with 256 taps up to 16 * param2 * max|random| / 10 pixels away: rows of the ranks above and below.
+ * The reference's split post-processes each device's strip on its own, so its frames have seams there (SURVEY.md
+ * section 8e asks for a halo).  Here, with a communicator (solr_hip_comm_init) and the strips of
+ * solr_hip_strip_rows, cudaRender trades the depths of the boundary rows with the neighbouring ranks over RCCL,
+ * on the frame's stream, between the renderer and the post-processing kernel: the assembled frame is the one a
+ * single GPU renders.  A host that moves the rows itself hands them over with solr_hip_set_depth_halo:
+ * nbAbove rows of `width` floats (PostProcessingBuffer.colorInfo.w) just above its strip, nbBelow just below;
+ * they are used by the frames that follow until (NULL, 0, NULL, 0) ends it.  The other neighbourhood kernels
+ * (depth of field, radiosity: random gathers over the frame) stay inside the strip as in the reference. */
+void solr_hip_set_depth_halo(const float *above, int nbAbove, const float *below, int nbBelow);
+
 /* GPUKernel::compactBoxes(true) on the device (sol-r_amd/csrc/solr_tree.hip): the reference's box grid -
  * processBoxes, processOutterBoxes, streamDataToGPU, GPUKernel.cpp:917-1281 - built from the scene's
  * primitives and flattened, bit for bit the tree the host builder makes.

@@ -2181,10 +2181,15 @@ static void postDepthOfField(const OracleScene *s, const SceneInfo *si, const Po
 /* ref CRT:1128-1181 */
 static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, const PostProcessingInfo *ppi,
                                  const PostProcessingBuffer *pp, BitmapBuffer *bitmap, int x, int y, int rows,
-                                 Stats *st)
+                                 int firstRow, Stats *st)
 {
+    /* wh is the frame's (CRT:1140).  A strip (oracle_render's firstRow / nbRows, the multi-GPU split) is rows
+     * of the frame: a tap's row is evaluated with the frame's y, so that strips whose neighbours' rows are at
+     * hand assemble to the one-GPU frame (the engine's depth halo); here rows outside the strip read as outside
+     * the frame.  (The reference's split uses the device-local y, CRT:1133: its frames have seams.)  With
+     * firstRow == 0 - every whole frame - this is the reference's statement as written. */
     int index = y * si->size.x + x;
-    int wh = si->size.x * rows;
+    int wh = si->size.x * si->size.y;
     float occ = 0.f;
     c3 localColor = {pp[index].colorInfo.x, pp[index].colorInfo.y, pp[index].colorInfo.z};
     float depth = pp[index].colorInfo.w;
@@ -2199,7 +2204,7 @@ static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, cons
             ++i;
             c += 1.f;
             int xx = f2i(x + (X * ppi->param2 * rnd(s, ix, st) / 10.f));
-            int yy = f2i(y + (Y * ppi->param2 * rnd(s, iy, st) / 10.f));
+            int yy = f2i((y + firstRow) + (Y * ppi->param2 * rnd(s, iy, st) / 10.f)) - firstRow;
             if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
             {
                 int localIndex = yy * si->size.x + xx;
@@ -2413,7 +2418,7 @@ int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const Po
                     postDepthOfField(scene, sceneInfo, ppInfo, pp, bitmap, x, y, nbRows, &st);
                     break;
                 case ppe_ambientOcclusion:
-                    postAmbientOcclusion(scene, sceneInfo, ppInfo, pp, bitmap, x, y, nbRows, &st);
+                    postAmbientOcclusion(scene, sceneInfo, ppInfo, pp, bitmap, x, y, nbRows, firstRow, &st);
                     break;
                 case ppe_radiosity:
                     postRadiosity(scene, sceneInfo, ppInfo, pp, ids, bitmap, x, y, nbRows, &st);
@@ -2663,7 +2668,7 @@ int oracle_postprocess(const OracleScene *scene, const SceneInfo *si, const Post
                 postDepthOfField(scene, si, ppi, pp, bitmap, x, y, H, &st);
                 break;
             case ppe_ambientOcclusion:
-                postAmbientOcclusion(scene, si, ppi, pp, bitmap, x, y, H, &st);
+                postAmbientOcclusion(scene, si, ppi, pp, bitmap, x, y, H, 0, &st);
                 break;
             case ppe_radiosity:
                 postRadiosity(scene, si, ppi, pp, ids, bitmap, x, y, H, &st);

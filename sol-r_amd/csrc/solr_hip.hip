@@ -733,10 +733,34 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
 #define AO_TILE_W 32
 #define AO_TILE_H 8
 #define AO_WINDOW_FLOATS 8192 /* LDS window of a tile: (AO_TILE_W + 2 rx) x (AO_TILE_H + 2 ry) depths */
+/* depths of the rows next to a strip that belong to the ranks above and below (multi-GPU frames: §6 of
+ * DESIGN.md): `above` holds the nbAbove rows just above the strip, `below` the nbBelow rows just below it */
+struct DepthHalo
+{
+    const float *above, *below;
+    int nbAbove, nbBelow;
+};
+/* the depth a tap reads: the strip's own frame buffer, or a neighbour's row out of the halo; rows that are in
+ * neither are outside the frame (occluded, CRT:1164-1165) - or beyond the halo, which the host sizes by the reach
+ * of the taps */
+__device__ __forceinline__ bool aoDepthAt(const PixelRecord *__restrict__ pp, const DepthHalo &halo, int W, int nbRows,
+                                          int xx, int yy, float &depth)
+{
+    if (xx < 0 || xx >= W || yy < -halo.nbAbove || yy >= nbRows + halo.nbBelow)
+        return false;
+    if (yy < 0)
+        depth = halo.above[(yy + halo.nbAbove) * W + xx];
+    else if (yy >= nbRows)
+        depth = halo.below[(yy - nbRows) * W + xx];
+    else
+        depth = pp[yy * W + xx].colorInfo.w;
+    return true;
+}
 __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
                                                           const PixelRecord *__restrict__ pp,
                                                           const float *__restrict__ randoms, long nbRandoms,
-                                                          unsigned char *__restrict__ bitmap)
+                                                          unsigned char *__restrict__ bitmap, const DepthHalo halo,
+                                                          int firstRow)
 {
     /* The 256 taps of a pixel sit at x + X * param2 * randoms[i % wh] / 10.f, y + Y * param2 * randoms[(i + 100)
      * % wh] / 10.f (CRT:1146-1153): the offsets depend on the tap, not on the pixel.  The workgroup's 256
@@ -754,7 +778,7 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
     __shared__ int reach[2];
     __shared__ float window[AO_WINDOW_FLOATS];
     const int W = si.size.x;
-    const int wh = W * nbRows;
+    const int wh = W * si.size.y; /* the frame's, also when this rank renders a strip of it */
     const int tilesX = (W + AO_TILE_W - 1) / AO_TILE_W;
     const int x0 = (int)(blockIdx.x % (unsigned)tilesX) * AO_TILE_W;
     const int y0 = (int)(blockIdx.x / (unsigned)tilesX) * AO_TILE_H;
@@ -790,7 +814,9 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
         for (int i = threadIdx.x; i < ww * wrows; i += 256)
         {
             const int gx = wx0 + i % ww, gy = wy0 + i / ww;
-            window[i] = (gx >= 0 && gx < W && gy >= 0 && gy < nbRows) ? pp[gy * W + gx].colorInfo.w : 0.f;
+            float d = 0.f;
+            aoDepthAt(pp, halo, W, nbRows, gx, gy, d);
+            window[i] = d;
         }
         __syncthreads();
     }
@@ -806,10 +832,12 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
     if (tiled)
     {
         /* a tile whose window lies inside the frame needs no bounds test per tap */
-        const bool inside = wx0 >= 0 && wy0 >= 0 && wx0 + ww <= W && wy0 + wrows <= nbRows;
+        const bool inside = wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow;
         /* counted in an integer (at most 256: the float sum of the reference is the same number) */
-        const int origin = -(wy0 * ww + wx0);
-        const float fx = (float)x, fy = (float)y;
+        /* a strip is rows [firstRow, firstRow + nbRows) of the frame: the tap's row is evaluated with the frame's y
+         * (the float addition rounds, and truncates towards zero, by the row's position in the frame) */
+        const int origin = -((wy0 + firstRow) * ww + wx0);
+        const float fx = (float)x, fy = (float)(y + firstRow);
         int count = 0;
         if (inside)
         {
@@ -827,7 +855,7 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
             {
                 const int xx = (int)(fx + tapX[i]);
                 const int yy = (int)(fy + tapY[i]);
-                if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
+                if (xx >= 0 && xx < W && yy - firstRow >= -halo.nbAbove && yy - firstRow < nbRows + halo.nbBelow)
                     count += (window[__mul24(yy, ww) + xx + origin] >= depth) ? 1 : 0;
                 else
                     count += 1;
@@ -842,11 +870,11 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
         {
             c += 1.f;
             int xx = (int)(x + tapX[i]);
-            int yy = (int)(y + tapY[i]);
-            if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
+            int yy = (int)((y + firstRow) + tapY[i]) - firstRow;
+            float tap;
+            if (aoDepthAt(pp, halo, W, nbRows, xx, yy, tap))
             {
-                int localIndex = yy * W + xx;
-                if (pp[localIndex].colorInfo.w >= depth)
+                if (tap >= depth)
                     occ += 1.f;
             }
             else
@@ -874,6 +902,15 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
 }
 
 /* CRT:1081-1120 */
+/* the depths of rows [row0, row0 + n) of a strip, packed for the neighbour that needs them */
+__global__ __launch_bounds__(256) void k_packDepthRows(const PixelRecord *__restrict__ pp, int W, int row0, int n,
+                                                       float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W * n)
+        out[i] = pp[row0 * W + i].colorInfo.w;
+}
+
 __global__ __launch_bounds__(256) void k_depthOfField(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
                                                       const PixelRecord *__restrict__ pp,
                                                       const float *__restrict__ randoms, long nbRandoms,
@@ -1183,6 +1220,11 @@ struct Engine
 
     /* per-pixel buffers of the strip */
     DeviceBuffer pp, ids, bitmap, counters, tileClock, tileCost, tileCostSnapshot, tileOrder;
+    /* ambient occlusion across strips: the depths of the neighbours' rows next to this rank's strip */
+    DeviceBuffer haloAbove[4], haloBelow[4], haloSendTop[4], haloSendBottom[4]; /* per frame in flight (MAX_FLIGHTS) */
+    DeviceBuffer haloGivenAbove, haloGivenBelow; /* solr_hip_set_depth_halo */
+    int haloSuppliedAbove = 0, haloSuppliedBelow = 0; /* rows handed over by solr_hip_set_depth_halo (0: none) */
+    float randomsReach = 0.f;                          /* max |randoms[i]|, i < 356: what the 256 taps can read */
     /* Frames in flight (solr_hip_set_frames_in_flight): with n > 1, consecutive first-pass frames rotate
      * over n streams and n sets of per-pixel buffers, so that the tail of one frame - a few long waves
      * on an otherwise idle chip - overlaps the start of the next.  Set 0 is the members above. */
@@ -1736,6 +1778,10 @@ void checkTextureTables()
     }
 }
 
+/* (defined with the RCCL layer at the end of this file) */
+void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
+                       int wanted, DepthHalo *halo);
+
 void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProcessingInfo &ppInfo,
                 const float origin[3], const float direction[3], const float angles[4], bool counting,
                 unsigned long long counts[8])
@@ -2006,11 +2052,32 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         const int nbPixels = sceneInfo.size.x * F.nbRows;
         const dim3 pgrid((nbPixels + 255) / 256), pblock(256);
         if (ppInfo.type == ppe_ambientOcclusion)
-            hipLaunchKernelGGL(k_ambientOcclusion,
-                               dim3(((sceneInfo.size.x + AO_TILE_W - 1) / AO_TILE_W) * ((F.nbRows + AO_TILE_H - 1) / AO_TILE_H)),
-                               pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
-                               (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
-                               g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
+        {
+            /* a strip's taps reach into the rows of the ranks above and below: their depths come from the host
+             * (solr_hip_set_depth_halo) or, with a communicator, from the neighbours over RCCL, on this stream */
+            DepthHalo halo = {nullptr, nullptr, 0, 0};
+            if (g.nbRows >= 0 && F.nbRows > 0)
+            {
+                const float reach = 16.f * fabsf(ppInfo.param2) * g.randomsReach / 10.f;
+                const int wanted = reach < 4096.f ? (int)reach + 2 : 4096;
+                if (g.haloSuppliedAbove || g.haloSuppliedBelow)
+                {
+                    halo.above = (const float *)g.haloGivenAbove.ptr;
+                    halo.below = (const float *)g.haloGivenBelow.ptr;
+                    halo.nbAbove = g.haloSuppliedAbove;
+                    halo.nbBelow = g.haloSuppliedBelow;
+                }
+                else
+                    exchangeDepthHalo(flight, stream, (const PixelRecord *)flightPp(flight).ptr, sceneInfo.size.x, F.firstRow,
+                                      F.nbRows, sceneInfo.size.y, wanted, &halo);
+            }
+            if (ok())
+                hipLaunchKernelGGL(k_ambientOcclusion,
+                                   dim3(((sceneInfo.size.x + AO_TILE_W - 1) / AO_TILE_W) * ((F.nbRows + AO_TILE_H - 1) / AO_TILE_H)),
+                                   pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
+                                   (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
+                                   g.randoms.ptr ? g.nbRandoms : 0L, bitmap, halo, F.firstRow);
+        }
         else if (ppInfo.type == ppe_depthOfField)
             hipLaunchKernelGGL(k_depthOfField, pgrid, pblock, 0, stream, sceneInfo, ppInfo, F.nbRows,
                                (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
@@ -2230,6 +2297,16 @@ void finalize_scene(vec2i)
                            &g.tileCost, &g.tileCostSnapshot, &g.tileOrder, &g.tileOrder2, &g.movable,  &g.refitPlan};
     for (DeviceBuffer *b : all)
         release(*b);
+    for (int f = 0; f < MAX_FLIGHTS; ++f)
+    {
+        release(g.haloAbove[f]);
+        release(g.haloBelow[f]);
+        release(g.haloSendTop[f]);
+        release(g.haloSendBottom[f]);
+    }
+    release(g.haloGivenAbove);
+    release(g.haloGivenBelow);
+    g.haloSuppliedAbove = g.haloSuppliedBelow = 0;
     for (int f = 0; f < MAX_FLIGHTS - 1; ++f)
     {
         release(g.ppX[f]);
@@ -2942,6 +3019,15 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
     }
 }
 
+static void noteRandomsReach(const std::vector<float> &r)
+{
+    /* the ambient-occlusion taps read randoms[i] and randoms[i + 100], i < 256 (CRT:1146-1153) */
+    float reach = 0.f;
+    for (size_t i = 0; i < r.size() && i < 356; ++i)
+        reach = std::max(reach, fabsf(r[i]));
+    g.randomsReach = reach;
+}
+
 void h2d_randoms(vec2i, float *randoms)
 {
     if (!ready("h2d_randoms"))
@@ -2955,6 +3041,7 @@ void h2d_randoms(vec2i, float *randoms)
     upload(g.randoms, r);
     if (ok())
         g.nbRandoms = MAX_BITMAP_SIZE;
+    noteRandomsReach(r);
 }
 
 /* Frames larger than the reference's 1920 x 1080 limit: its natural depth of field indexes the buffer with
@@ -2976,6 +3063,7 @@ void solr_hip_h2d_randoms_sized(const float *randoms, long count)
     upload(g.randoms, r);
     if (ok())
         g.nbRandoms = count;
+    noteRandomsReach(r);
 }
 
 void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
@@ -3296,7 +3384,100 @@ bool rcclOk(int result, const char *what)
     setError(-1, text.c_str(), __FILE__, __LINE__);
     return false;
 }
+
+/* Ambient occlusion on a strip: the 256 taps of a pixel reach up to `wanted` rows into the strips of the ranks above
+ * and below ("exchange a 16-row halo").  Every rank packs the depths of its first and last
+ * `wanted` rows and trades them with its neighbours - one grouped ncclSend / ncclRecv pair per neighbour, on the
+ * stream that rendered the strip, between the renderer and the post-processing kernel - so that the assembled frame
+ * is the one a single GPU renders.  Only with a communicator and the strips of solr_hip_strip_rows; `wanted`
+ * follows from the post-processing parameters and the random buffer, which every rank holds alike. */
+const int RCCL_FLOAT32 = 7; /* ncclFloat32, rccl.h */
+void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
+                       int wanted, DepthHalo *halo)
+{
+    if (!rccl.comm || rccl.world < 2 || wanted < 1 || nbRows < 1)
+        return;
+    int first = 0, count = 0;
+    solr_hip_strip_rows(rccl.rank, rccl.world, frameRows, &first, &count, nullptr);
+    if (first != firstRow || count != nbRows)
+        return; /* a strip layout of the host's own: it hands the rows over itself (solr_hip_set_depth_halo) */
+    int upRows = 0, downRows = 0;
+    if (rccl.rank > 0)
+        solr_hip_strip_rows(rccl.rank - 1, rccl.world, frameRows, nullptr, &upRows, nullptr);
+    if (rccl.rank + 1 < rccl.world)
+        solr_hip_strip_rows(rccl.rank + 1, rccl.world, frameRows, nullptr, &downRows, nullptr);
+    const int mine = std::min(wanted, nbRows);
+    const int recvAbove = std::min(wanted, upRows), recvBelow = std::min(wanted, downRows);
+    const int sendUp = upRows > 0 ? mine : 0, sendDown = downRows > 0 ? mine : 0;
+    if (!(recvAbove || recvBelow || sendUp || sendDown))
+        return;
+    reserve(g.haloAbove[flight], (size_t)std::max(recvAbove, 1) * W * sizeof(float));
+    reserve(g.haloBelow[flight], (size_t)std::max(recvBelow, 1) * W * sizeof(float));
+    reserve(g.haloSendTop[flight], (size_t)mine * W * sizeof(float));
+    reserve(g.haloSendBottom[flight], (size_t)mine * W * sizeof(float));
+    if (!ok())
+        return;
+    const dim3 grid((unsigned)((mine * W + 255) / 256)), block(256);
+    if (sendUp)
+        hipLaunchKernelGGL(k_packDepthRows, grid, block, 0, stream, pp, W, 0, mine, (float *)g.haloSendTop[flight].ptr);
+    if (sendDown)
+        hipLaunchKernelGGL(k_packDepthRows, grid, block, 0, stream, pp, W, nbRows - mine, mine,
+                           (float *)g.haloSendBottom[flight].ptr);
+    HIPCHECK(hipGetLastError());
+    bool fine = ok() && rcclOk(rccl.GroupStart(), "ncclGroupStart");
+    if (fine && sendUp)
+        fine = rcclOk(rccl.Send(g.haloSendTop[flight].ptr, (size_t)mine * W, RCCL_FLOAT32, rccl.rank - 1, rccl.comm, stream),
+                      "ncclSend (depth rows, up)");
+    if (fine && sendDown)
+        fine = rcclOk(rccl.Send(g.haloSendBottom[flight].ptr, (size_t)mine * W, RCCL_FLOAT32, rccl.rank + 1, rccl.comm, stream),
+                      "ncclSend (depth rows, down)");
+    if (fine && recvAbove)
+        fine = rcclOk(rccl.Recv(g.haloAbove[flight].ptr, (size_t)recvAbove * W, RCCL_FLOAT32, rccl.rank - 1, rccl.comm, stream),
+                      "ncclRecv (depth rows, above)");
+    if (fine && recvBelow)
+        fine = rcclOk(rccl.Recv(g.haloBelow[flight].ptr, (size_t)recvBelow * W, RCCL_FLOAT32, rccl.rank + 1, rccl.comm, stream),
+                      "ncclRecv (depth rows, below)");
+    if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd") || !fine)
+        return;
+    halo->above = (const float *)g.haloAbove[flight].ptr;
+    halo->below = (const float *)g.haloBelow[flight].ptr;
+    halo->nbAbove = recvAbove;
+    halo->nbBelow = recvBelow;
+}
 } // namespace
+
+/* Extension: the depths (PostProcessingBuffer.colorInfo.w) of the rows next to this process's strip that other
+ * processes rendered - nbAbove rows of `width` floats just above it, nbBelow just below - for hosts that move them
+ * themselves (MPI, shared memory; tests/test_gpu_parity.py does it from a full frame).  Used by the ambient-occlusion
+ * kernel of the frames that follow, in place of the RCCL exchange; (NULL, 0, NULL, 0) ends it. */
+extern "C" void solr_hip_set_depth_halo(const float *above, int nbAbove, const float *below, int nbBelow)
+{
+    if (!ready("solr_hip_set_depth_halo"))
+        return;
+    ARGCHECK(nbAbove >= 0 && nbBelow >= 0 && (nbAbove == 0 || above) && (nbBelow == 0 || below) && nbAbove <= 4096 &&
+                 nbBelow <= 4096,
+             "solr_hip_set_depth_halo: bad arguments");
+    if (!ok())
+        return;
+    quiesce();
+    HIPCHECK(hipSetDevice(g.device));
+    g.haloSuppliedAbove = g.haloSuppliedBelow = 0;
+    if (nbAbove)
+    {
+        std::vector<float> rows(above, above + (size_t)nbAbove * g.width);
+        upload(g.haloGivenAbove, rows);
+    }
+    if (nbBelow)
+    {
+        std::vector<float> rows(below, below + (size_t)nbBelow * g.width);
+        upload(g.haloGivenBelow, rows);
+    }
+    if (ok())
+    {
+        g.haloSuppliedAbove = nbAbove;
+        g.haloSuppliedBelow = nbBelow;
+    }
+}
 
 /* rows [first, first + count) of a `height`-row image for rank `rank` of `world`, and the common strip height:
  * contiguous strips like the reference's (CudaRayTracer.cu:1694-1696), the last one absorbing the remainder;

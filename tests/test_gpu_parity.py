@@ -667,3 +667,44 @@ def test_short_paths_of_plain_primitives_change_nothing(solr, oracle, scene):
             os.environ.pop("SOLR_HIP_NO_KINDS", None)
     assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
     assert np.array_equal(frames[0][1], frames[1][1]) and np.array_equal(frames[0][2], frames[1][2])
+
+
+def test_ambient_occlusion_on_a_strip_reads_the_neighbours_rows(solr, oracle):
+    """Multi-GPU frames with the ambient-occlusion kernel: a strip's taps reach into the rows of the ranks above and
+    below.  With their depths handed over (solr_hip_set_depth_halo - what the RCCL exchange of cudaRender delivers
+    between ranks) the strips assemble to the frame one GPU renders, bit for bit; without them the rows next to a
+    seam differ, as they do between the devices of the reference's own split."""
+    import ctypes as C
+    W, H, reach = 192, 96, 18          # param2 = 2000: taps up to 16 * 2000 * 0.005 / 10 = 16 pixels away, + 2
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    k.set_post_processing(type=solr_mod.ppe_ambientOcclusion, param1=0.0, param2=2000.0, param3=0)
+    solr.scenes.cornell(k, width=W, height=H, iterations=2)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    try:
+        pp, ids, full = gpu_frame(k)
+        opp, oids, orgb, _, status = oracle_frame(k, oracle)
+        assert status == 0
+        assert_parity(compare_frames(pp, ids, full, opp, oids, orgb))
+        full = np.array(full, copy=True)
+        depth = np.ascontiguousarray(pp[..., 3], dtype=np.float32)
+        seams_seen = 0
+        for rank in range(3):
+            first, count, _ = solr.strip_rows(rank, 3, H)
+            hip.solr_hip_set_strip(first, count)
+            alone = np.array(k.render()[first:first + count], copy=True)
+            seams_seen += int(not np.array_equal(alone, full[first:first + count]))
+            above = np.ascontiguousarray(depth[max(0, first - reach):first])
+            below = np.ascontiguousarray(depth[first + count:first + count + reach])
+            hip.solr_hip_set_depth_halo(fp(above) if len(above) else None, len(above),
+                                        fp(below) if len(below) else None, len(below))
+            k.check(0, "solr_hip_set_depth_halo")
+            img = k.render()
+            k.check(0, "strip with halo")
+            assert np.array_equal(img[first:first + count], full[first:first + count]), rank
+            hip.solr_hip_set_depth_halo(None, 0, None, 0)
+        assert seams_seen >= 2, "the taps never crossed a seam: the test would prove nothing"
+    finally:
+        hip.solr_hip_set_depth_halo(None, 0, None, 0)
+        hip.solr_hip_set_strip(0, -1)
+        k.finalize()
