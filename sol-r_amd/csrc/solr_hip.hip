@@ -769,8 +769,8 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
      *
      * A workgroup is a 32 x 8 tile of pixels.  Every tap of every pixel of the tile lands within
      * rx = max |tapX| + 1 columns and ry = max |tapY| + 1 rows of the tile: that window of depths (colorInfo.w
-     * of the 32-byte frame-buffer records) is read once into LDS - 2 772 four-byte reads for cfg4's taps of up to
-     * 16 pixels instead of 65 536 - and the 256 comparisons of a pixel read LDS, consecutive lanes consecutive
+     * of the 32-byte frame-buffer records) is read once into LDS - 2 772 four-byte reads for taps of up to 16 pixels
+     * (432 for cfg4's, which reach one) instead of 65 536 - and the 256 comparisons of a pixel read LDS, consecutive lanes consecutive
      * words.  Same comparisons on the same values, counted in floats that stay exact integers: the order of the
      * additions does not matter.  A window that does not fit (param2 beyond about 25) is gathered from memory as
      * before. */
