@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
      * of the 32-byte frame-buffer records) is read once into LDS - 2 772 four-byte reads for taps of up to 16 pixels
      * (432 for cfg4's, which reach one) instead of 65 536 - and the 256 comparisons of a pixel read LDS, consecutive lanes consecutive
      * words.  Same comparisons on the same values, counted in floats that stay exact integers: the order of the
-     * additions does not matter.  A window that does not fit (param2 beyond about 25) is gathered from memory as
+     * additions does not matter.  A window that does not fit (taps that reach beyond about 40 pixels) is gathered from memory as
      * before. */
     __shared__ float tapX[256], tapY[256];
     __shared__ int reach[2];
