@@ -100,7 +100,9 @@ def main():
     # SOLR_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, strip binding, gather) with a
     # single rank: a 1-GPU box can then exercise it against RCCL
     distributed = world > 1 or os.environ.get("SOLR_BENCH_FORCE_DIST") == "1"
-    native = distributed and (args.native_gather or os.environ.get("SOLR_BENCH_NATIVE_GATHER") == "1")
+    # cfg4's ambient-occlusion taps cross the strips: with the library's own communicator cudaRender trades the
+    # boundary rows' depths between neighbouring ranks (no seams); the torch gather has no such leg
+    native = distributed and (args.native_gather or cfg4 or os.environ.get("SOLR_BENCH_NATIVE_GATHER") == "1")
     if native:
         import torch
         import torch.distributed as dist
