@@ -23,6 +23,7 @@
 #include <cstring>
 #include <string>
 #include <functional>
+#include <chrono>
 #include <vector>
 
 #include "../../include/solr_hip.h"
@@ -971,6 +972,21 @@ __global__ __launch_bounds__(256) void k_depthOfField(const SceneInfo si, const 
 
 namespace
 {
+/* SOLR_HIP_DEBUG_TIMING=1: where the host side of an upload spends its time (stderr) */
+struct PhaseTimer
+{
+    const bool on = getenv("SOLR_HIP_DEBUG_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char *what)
+    {
+        if (!on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "solr_hip: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
 /* ---- animated scenes: rotate + refit on the device ---------------------------------------------------
  * The reference animates a scene by GPUKernel::rotatePrimitives + compactBoxes(false) on the host and a
  * full upload, every frame (MoleculeScene.cpp:75-81; GPUKernel.cpp:1378-1460 rotates the primitives of
@@ -1710,6 +1726,7 @@ void flushGeometry()
     row += 2u * (unsigned)g.hostBoxes.size() + 4u;
     g.offLeafCompact = row;
     row += 2u * (unsigned)g.hostBoxesCompact.size() + 4u;
+    PhaseTimer phase;
     std::vector<float4> arena(std::max(row, 1u), make_float4(0.f, 0.f, 0.f, 0.f));
     auto put = [&](unsigned at, const void *src, size_t bytes) {
         if (bytes)
@@ -1721,8 +1738,11 @@ void flushGeometry()
     put(g.offLights, g.hostLights.data(), g.hostLights.size() * 16);
     put(startRow, g.hostBoxStart.data(), g.hostBoxStart.size() * 4);
     put(startRowCompact, g.hostBoxStartCompact.data(), g.hostBoxStartCompact.size() * 4);
+    phase.mark("geometry: arena on the host");
     upload(g.geometry, arena);
+    phase.mark("geometry: upload");
     buildLeafRecords();
+    phase.mark("geometry: leaf records");
     if (ok())
         g.geometryDirty = false;
 }
@@ -2682,6 +2702,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     ARGCHECK(nbPrimitives == 0 || primitives, "h2d_scene: null primitives");
     if (!ok())
         return;
+    PhaseTimer phase;
     std::vector<float4> boxes(2 * (size_t)nbActiveBoxes);
     std::vector<int> start(nbActiveBoxes);
     for (int i = 0; i < nbActiveBoxes; ++i)
@@ -2698,7 +2719,9 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     }
     if (!ok())
         return;
+    phase.mark("h2d_scene: node rows");
     g.nested = validateNesting(boundingBoxes, nbActiveBoxes);
+    phase.mark("h2d_scene: nesting check");
     if (!g.nested)
     {
         /* the general walk needs at least forward progress */
@@ -2774,9 +2797,13 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     int nbWalkNodes = nc, prunedBefore = 0, prunedAfter = 0;
     if (g.nested && g.orderedCompact && nc > 0 && g.grouping)
     {
+        phase.mark("h2d_scene: chain collapse");
         pruneInnerNodes(boxesC, startC, originC, &prunedBefore); /* cells that do not cull: their children join the run above */
+        phase.mark("h2d_scene: prune");
         groupSiblings(boxesC, startC, originC);
+        phase.mark("h2d_scene: grouping");
         nbWalkNodes = pruneInnerNodes(boxesC, startC, originC, &prunedAfter); /* groups that do not cull either */
+        phase.mark("h2d_scene: prune groups");
     }
     if (getenv("SOLR_HIP_DEBUG_TREE"))
     {
@@ -2805,7 +2832,9 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     }
     if (prims.empty())
         prims.assign(8, make_float4(0.f, 0.f, 0.f, 0.f)); /* inactive lanes read record 0 */
+    phase.mark("h2d_scene: primitive rows");
     buildRefitPlan(boxes, boxesC, originC);
+    phase.mark("h2d_scene: refit plan");
     g.deviceAhead = false;
     g.nbMovable = -1;
     g.hostBoxes.swap(boxes);
@@ -2814,6 +2843,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     g.hostBoxStartCompact.swap(startC);
     g.hostPrims.swap(prims);
     retagPrimitives();
+    phase.mark("h2d_scene: tags");
     HIPCHECK(hipSetDevice(g.device));
     std::vector<int> l(lamps, lamps + (lamps ? nbLamps : 0));
     upload(g.lamps, l);
