@@ -6,7 +6,7 @@ shadow rays, synthetic scene from sol-r_amd/scenes.py.  One "step" = one frame:
 k_standardRenderer over this rank's row strip (scene resident in HBM, uploaded before
 the timed region) and, for N > 1, the RCCL gather of the RGB strips to rank 0.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 200 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `value` = (closest-hit walks + shadow walks of the whole
@@ -41,7 +41,8 @@ SALU_PEAK_WAVE_INSTS_PER_S = 256 * 2.4e9
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; --config cfg4: 74, one whole cycle of passes)")
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 200 - a 60 ms timed region; --config cfg4: 74, one whole cycle of passes)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -81,7 +82,7 @@ def main():
         args.frames_in_flight = 1          # every pass reads what the pass before left in the frame buffers
     cfg4 = args.config == "cfg4"
     if args.steps is None:
-        args.steps = 74 if cfg4 else 20    # cfg4's passes differ in cost (refinement passes re-render with more bounces)
+        args.steps = 74 if cfg4 else 200   # cfg4's passes differ in cost (refinement passes re-render with more bounces)
     if os.environ.get("SOLR_BENCH_DEBUG"):
         import faulthandler
         import signal
