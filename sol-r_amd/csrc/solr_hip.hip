@@ -2407,10 +2407,11 @@ void solr_hip_reshape(const SceneInfo *sceneInfo)
  * The node stays if (1 - the larger of the two) x (nodes below it) is at least `threshold` tests.  Cornell's
  * upper cells and the groups around its walls hold every leaf centre of the room: they go, the groups of small
  * spheres on the floor stay.  Works on the walk-order rows in place; returns the new node count. */
-static int pruneInnerNodes(std::vector<float4> &rows, std::vector<int> &start, std::vector<int> &origin, int *nbPruned)
+static int pruneInnerNodes(std::vector<float4> &rows, std::vector<int> &start, std::vector<int> &origin, int *nbPruned,
+                           bool everyInnerNode = false)
 {
     const int n = (int)start.size();
-    const double threshold = getenv("SOLR_HIP_PRUNE") ? atof(getenv("SOLR_HIP_PRUNE")) : 1.0;
+    const double threshold = everyInnerNode ? 1e300 : (getenv("SOLR_HIP_PRUNE") ? atof(getenv("SOLR_HIP_PRUNE")) : 1.0);
     *nbPruned = 0;
     if (n < 2 || !(threshold > 0.0))
         return n;
@@ -2802,7 +2803,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     if (g.nested && g.orderedCompact && nc > 0 && g.grouping)
     {
         phase.mark("h2d_scene: chain collapse");
-        pruneInnerNodes(boxesC, startC, originC, &prunedBefore); /* cells that do not cull: their children join the run above */
+        pruneInnerNodes(boxesC, startC, originC, &prunedBefore, getenv("SOLR_HIP_REBUILD") != nullptr); /* cells that do not cull: their children join the run above */
         phase.mark("h2d_scene: prune");
         groupSiblings(boxesC, startC, originC);
         phase.mark("h2d_scene: grouping");
