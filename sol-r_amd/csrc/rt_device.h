@@ -1409,12 +1409,46 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         countAdd<COUNT>(cnt.closest, 1);
     countAdd<COUNT>(cnt.wClosest, 1);
 
-    const int nbBoxes = S.nbBoxes;
     /* sign-free slab test when it is provably identical (see boxIntersectionFast) */
     const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteRay(r)) == 0ull);
     const bool showBoxes = (FEAT & F_FULL) && si.renderBoxes != 0;
     const bool tidy = !COUNT && fastBoxes && S.nested && !showBoxes;
+    /* The order-free list (solr_hip.hip, buildFreeOrderList): the same leaves under a hierarchy of our own, in an
+     * order of our own.  The reference's result does not depend on the order in which the leaves are visited when
+     * (a) ties go to the smaller flattened index - the primitive the reference visits first - and (b) the cut-off
+     * `slab parameter < closest distance so far` never hides a nearer hit: the parameter is in units of the
+     * un-normalised direction, so for |direction| >= 2 it is at most half the Euclidean distance to anything
+     * inside the box, and every primitive of such a scene lies inside its leaf's box (checked at upload).  Primary
+     * rays qualify (|direction| is thousands); bounce rays are unit vectors and walk the reference's order. */
+    const bool freeOrder =
+        tidy && S.nbBoxesFree > 0 && ballot(active && !(dot(r.d, r.d) >= 4.f)) == 0ull;
+    Scene W = S;
+    if (freeOrder)
+    {
+        /* eight flattenings of the same hierarchy, the near child first for a direction of that sign octant: the
+         * wave takes the octant of its first active lane (any list gives the same result) */
+        const int signs = (r.d.x < 0.f ? 1 : 0) | (r.d.y < 0.f ? 2 : 0) | (r.d.z < 0.f ? 4 : 0);
+        const int lane = (int)__builtin_ctzll(ballot(active));
+        const int octant = __builtin_amdgcn_readlane(signs, lane);
+        W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
+        W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
+        W.nbBoxes = S.nbBoxesFree;
+    }
+    /* The reference's cut-off never culls for such rays (a slab parameter of order 1 against a distance of
+     * thousands).  The order-free walk may cull by the TRUE distance: a box whose entry point lies farther than the
+     * closest hit so far holds nothing that could replace it, not even on a tie.  The margins cover the rounding
+     * of both sides: 2e-4 of the distance for the computed hit distance and the products, 1e-4 of the origin's
+     * coordinates for the cancellation in (bound - origin) - a thousand times the half-ulp that subtraction can
+     * lose.  With the near child first this is what ends a walk early. */
+    const float invLength = freeOrder ? 1.f / length(r.d) : 1.f;
+    const float farScale = freeOrder ? 1.0002f * invLength : 1.f;
+    const float farOffset = freeOrder ? 1.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z)) * invLength : 0.f;
+    int tieIndex = -1; /* the primitive that holds minDistance */
+    auto closer = [&](float distance, int pi) {
+        return distance < minDistance || (freeOrder && distance == minDistance && pi < tieIndex);
+    };
     const PackedRay pr = packRay(r);
+    const int nbBoxes = W.nbBoxes;
     int cursor = active ? 0 : SOLR_CURSOR_DONE;
     int cur = 0;
     Row2 node;
@@ -1428,7 +1462,8 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         SOLR_T(unsigned long long ta = SOLR_NOW();)
         if (tidy)
         {
-            leaf = advanceTidy<FEAT>(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
+            leaf = advanceTidy<FEAT>(W, pr, freeOrder ? minDistance * farScale + farOffset : minDistance, cursor, cur,
+                                     nbPrimitives, entered);
             SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)
             if (leaf < 0)
                 break;
@@ -1453,7 +1488,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 continue;
         }
         /* (readfirstlane: the compiler takes an inline-asm result for divergent and would fetch the record per lane) */
-        const Row4 L = leafRecord(S, uniform(leaf));
+        const Row4 L = leafRecord(W, uniform(leaf));
         const int start = uniform(asint(L.d.w));
         for (int k = 0; k < nbPrimitives; ++k)
         {
@@ -1474,13 +1509,14 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 bool back;
                 const bool i = sphereHit(si, V4(head.a), head.b.x, r, entered, h.intersection, back);
                 const float distance = length(h.intersection - r.o);
-                const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
+                const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
                 if (ballot(keep) != 0ull)
                 {
                     if (keep)
                     {
                         sphereNormal<false>(si, V4(head.a), V4(head.b), false, false, back, r, h);
                         minDistance = distance;
+                        tieIndex = pi;
                         closestPrimitive = pi;
                         closestIntersection = h.intersection;
                         closestNormal = h.normal;
@@ -1503,9 +1539,10 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     const bool i = planePlain(S, si, kind, V4(head.a), V4(head.b), recPlaneNormal(S, rec),
                                               recPlaneAverage(S, rec), r, h);
                     const float distance = length(h.intersection - r.o);
-                    if (i && distance > si.geometryEpsilon && distance < minDistance)
+                    if (i && distance > si.geometryEpsilon && closer(distance, pi))
                     {
                         minDistance = distance;
+                        tieIndex = pi;
                         closestPrimitive = pi;
                         closestIntersection = h.intersection;
                         closestNormal = h.normal;
@@ -1530,7 +1567,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 if (entered)
                     i = triangleHit(si, p0, p1, p2, r, h.intersection);
                 const float distance = length(h.intersection - r.o);
-                const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
+                const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
                 if (ballot(keep) != 0ull)
                 {
                     const v3 n0 = V4(primRow(S, pi, ROW_N0));
@@ -1540,6 +1577,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     {
                         triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
                         minDistance = distance;
+                        tieIndex = pi;
                         closestPrimitive = pi;
                         closestIntersection = h.intersection;
                         closestNormal = h.normal;
@@ -1562,9 +1600,10 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     const bool i = cylinderIntersection(si, V4(head.a), recP1(S, rec), recP2(S, rec),
                                                         V4(primRow(S, pi, ROW_N1)), V4(head.b), r, h);
                     const float distance = length(h.intersection - r.o);
-                    if (i && distance > si.geometryEpsilon && distance < minDistance)
+                    if (i && distance > si.geometryEpsilon && closer(distance, pi))
                     {
                         minDistance = distance;
+                        tieIndex = pi;
                         closestPrimitive = pi;
                         closestIntersection = h.intersection;
                         closestNormal = h.normal;
@@ -1591,7 +1630,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 bool back;
                 const bool i = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
                 const float distance = length(h.intersection - r.o);
-                const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
+                const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
                 if (ballot(keep) != 0ull)
                 {
                     if (keep)
@@ -1599,6 +1638,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                         sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b), (tag & PRIM_PROCEDURAL) != 0,
                                                            false, back, r, h);
                         minDistance = distance;
+                        tieIndex = pi;
                         closestPrimitive = pi;
                         closestIntersection = h.intersection;
                         closestNormal = h.normal;
@@ -1620,7 +1660,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 if (lanes)
                     i = triangleHit(si, p0, p1, p2, r, h.intersection);
                 const float distance = length(h.intersection - r.o);
-                const bool keep = i && distance > si.geometryEpsilon && distance < minDistance;
+                const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
                 if (ballot(keep) != 0ull)
                 {
                     const v3 n0 = V4(primRow(S, pi, ROW_N0));
@@ -1630,6 +1670,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     {
                         triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
                         minDistance = distance;
+                        tieIndex = pi;
                         closestPrimitive = pi;
                         closestIntersection = h.intersection;
                         closestNormal = h.normal;
@@ -1647,9 +1688,10 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 h.shadowIntensity = 0.f;
                 const bool i = testPrimitive<false, FEAT>(S, si, rec, tag, r, h);
                 const float distance = length(h.intersection - r.o);
-                if (i && distance > si.geometryEpsilon && distance < minDistance)
+                if (i && distance > si.geometryEpsilon && closer(distance, pi))
                 {
                     minDistance = distance;
+                    tieIndex = pi;
                     closestPrimitive = pi;
                     closestIntersection = h.intersection;
                     closestNormal = h.normal;

@@ -151,6 +151,9 @@ struct SceneArgs
     int orderedBoxes; /* every node has finite bounds with min <= max (sign-free slab test allowed) */
     long nbRandoms;
     unsigned offLeaf; /* leaf records of the node list in use, rows */
+    /* the order-free list (closest-hit walks of rays longer than 2, rt_device.h): 0 nodes when there is none */
+    unsigned offBoxesFree, offLeafFree;
+    int nbBoxesFree;
 };
 
 /* Device view: everything is read through the CONSTANT address space.  The
@@ -183,6 +186,8 @@ struct Scene
     int orderedBoxes;
     long nbRandoms;
     unsigned offLeaf;
+    unsigned offBoxesFree, offLeafFree;
+    int nbBoxesFree;
 };
 
 __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
@@ -205,6 +210,9 @@ __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
     s.orderedBoxes = a.orderedBoxes;
     s.nbRandoms = a.nbRandoms;
     s.offLeaf = a.offLeaf;
+    s.offBoxesFree = a.offBoxesFree;
+    s.offLeafFree = a.offLeafFree;
+    s.nbBoxesFree = a.nbBoxesFree;
     return s;
 }
 

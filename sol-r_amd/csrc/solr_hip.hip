@@ -1210,6 +1210,13 @@ struct Engine
     DeviceBuffer geometry, materials, textures, randoms, lamps;
     std::vector<float4> hostBoxes, hostBoxesCompact, hostPrims, hostLights;
     std::vector<int> hostBoxStart, hostBoxStartCompact;
+    /* the order-free list: the leaves of the scene under a surface-area hierarchy of our own (buildFreeOrderList) */
+    std::vector<float4> hostBoxesFree;
+    std::vector<int> hostBoxStartFree;
+    unsigned offBoxesFree = 0, offBoxStartFree = 0, offLeafFree = 0;
+    int nbBoxesFree = 0;        /* nodes per list; there are eight, one per direction octant */
+    bool freeStale = false;     /* rotated on the device since it was built: not refitted, not walked */
+    bool primsContained = false; /* every primitive lies inside its leaf's box (retagPrimitives) */
     std::vector<int> materialTags; /* PRIM_* bits per material id */
     /* texture tables of the textured materials and the size of the uploaded atlas: checked against each other
      * before the first frame that follows either upload (checkTextureTables) */
@@ -1626,6 +1633,7 @@ void retagPrimitives()
     const size_t n = g.hostPrims.size() / PRIM_ROWS;
     const bool noKinds = getenv("SOLR_HIP_NO_KINDS") != nullptr; /* tests: every primitive through the general tests */
     int features = 0;
+    bool contained = true;
     for (size_t i = 0; i < n; ++i)
     {
         float4 *r = &g.hostPrims[PRIM_ROWS * i];
@@ -1648,6 +1656,12 @@ void retagPrimitives()
         else if (type == ptCylinder || type == ptCone)
             kind = KIND_CYLINDER;
         r[ROW_P0_TYPE].w = bitsf(type | facts | (kind << PRIM_KIND_SHIFT));
+        /* inside the box the reference's builder gives its leaf (GPUKernel.cpp:762-830: the vertices of a triangle,
+         * p0 +- radius of a sphere, min / max (p0, p1) +- radius of a cylinder, p0 +- size of a plane; a cone's box
+         * is built around p0 alone, a procedural sphere's surface is displaced, the others are not bounded by
+         * their size) */
+        contained = contained && (type == ptTriangle || type == ptCylinder || (type == ptSphere && !(facts & PRIM_PROCEDURAL)) ||
+                                  type == ptXYPlane || type == ptYZPlane || type == ptXZPlane);
         r[ROW_P2].w = (mat >= 0 && (size_t)mat < g.materialAverage.size()) ? g.materialAverage[mat] : 0.f;
         switch (type)
         {
@@ -1676,6 +1690,7 @@ void retagPrimitives()
             features |= F_TEX;
     }
     g.sceneFeatures = features;
+    g.primsContained = contained && n > 0;
     g.geometryDirty = true;
 }
 
@@ -1692,6 +1707,10 @@ void buildLeafRecords()
     if (nc > 0)
         hipLaunchKernelGGL(k_buildLeafRecords, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, g.stream, arena,
                            g.offBoxesCompact, g.offBoxStartCompact, g.offPrims, g.offLeafCompact, nc);
+    const int nf = (int)(g.hostBoxesFree.size() / 2);
+    if (nf > 0 && !g.freeStale)
+        hipLaunchKernelGGL(k_buildLeafRecords, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, arena,
+                           g.offBoxesFree, g.offBoxStartFree, g.offPrims, g.offLeafFree, nf);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(g.stream));
 }
@@ -1710,6 +1729,8 @@ void flushGeometry()
     row += (unsigned)g.hostBoxes.size() + 2u;
     g.offBoxesCompact = row;
     row += (unsigned)g.hostBoxesCompact.size() + 2u;
+    g.offBoxesFree = row;
+    row += (unsigned)g.hostBoxesFree.size() + 2u;
     row = (row + 3u) & ~3u; /* primitive records start on a 64-byte line */
     g.offPrims = row;
     row += (unsigned)g.hostPrims.size();
@@ -1719,13 +1740,18 @@ void flushGeometry()
     row += rowsOfInts(g.hostBoxStart.size());
     const unsigned startRowCompact = row;
     row += rowsOfInts(g.hostBoxStartCompact.size());
+    const unsigned startRowFree = row;
+    row += rowsOfInts(g.hostBoxStartFree.size());
     g.offBoxStart = startRow * 4;
     g.offBoxStartCompact = startRowCompact * 4;
+    g.offBoxStartFree = startRowFree * 4;
     row = (row + 3u) & ~3u; /* leaf records: one 64-byte line per node */
     g.offLeaf = row;
     row += 2u * (unsigned)g.hostBoxes.size() + 4u;
     g.offLeafCompact = row;
     row += 2u * (unsigned)g.hostBoxesCompact.size() + 4u;
+    g.offLeafFree = row;
+    row += 2u * (unsigned)g.hostBoxesFree.size() + 4u;
     PhaseTimer phase;
     /* the pieces go straight to their rows of the arena (a staged host copy of the whole arena, zero-filled first,
      * took 10-14 ms for 100 k primitives); pad records and the leaf-record area start as zeros */
@@ -1743,6 +1769,8 @@ void flushGeometry()
     put(g.offLights, g.hostLights.data(), g.hostLights.size() * 16);
     put(startRow, g.hostBoxStart.data(), g.hostBoxStart.size() * 4);
     put(startRowCompact, g.hostBoxStartCompact.data(), g.hostBoxStartCompact.size() * 4);
+    put(g.offBoxesFree, g.hostBoxesFree.data(), g.hostBoxesFree.size() * 16);
+    put(startRowFree, g.hostBoxStartFree.data(), g.hostBoxStartFree.size() * 4);
     HIPCHECK(hipStreamSynchronize(g.stream)); /* pageable sources: complete for the caller when this returns */
     phase.mark("geometry: upload");
     buildLeafRecords();
@@ -1772,6 +1800,13 @@ SceneArgs makeScene(bool exactNodes)
     S.nested = g.nested;
     S.orderedBoxes = exactNodes ? g.orderedExact : g.orderedCompact;
     S.nbRandoms = g.randoms.ptr ? g.nbRandoms : 0;
+    if (!exactNodes && g.nbBoxesFree > 0 && g.hostBoxesFree.size() == 16 * (size_t)g.nbBoxesFree && g.primsContained && !g.freeStale && g.nested && g.orderedCompact &&
+        g.variant != 6)
+    {
+        S.offBoxesFree = g.offBoxesFree;
+        S.offLeafFree = g.offLeafFree;
+        S.nbBoxesFree = g.nbBoxesFree; /* per list; the eight lists and their leaf records lie one behind the other */
+    }
     return S;
 }
 
@@ -2371,6 +2406,10 @@ void finalize_scene(vec2i)
     g.hostLights.clear();
     g.hostBoxStart.clear();
     g.hostBoxStartCompact.clear();
+    g.hostBoxesFree.clear();
+    g.hostBoxStartFree.clear();
+    g.nbBoxesFree = 0;
+    g.freeStale = false;
     g.materialTags.clear();
     g.materialAverage.clear();
     g.geometryDirty = true;
@@ -2509,6 +2548,248 @@ static int pruneInnerNodes(std::vector<float4> &rows, std::vector<int> &start, s
     start.swap(outStart);
     origin.swap(outOrigin);
     return m;
+}
+
+/* The order-free lists: the leaves of the scene - every node with primitives, whatever the reference put above
+ * it - under a binary surface-area hierarchy of our own (binned SAH over the leaf boxes' centres, sixteen bins),
+ * flattened depth-first with skip pointers like the other lists, EIGHT TIMES: once per sign octant of a ray's
+ * direction, the child on the near side of each split first.  Closest-hit walks whose result does not depend on
+ * the order of the leaves (rt_device.h closestHitWalk: rays longer than 2, ties to the smaller flattened index)
+ * walk the list of their octant instead of the reference's order - near boxes first, so that the first hits
+ * shrink the cut-off and the far side of the scene is culled, which no fixed order can do for every direction.
+ * Any of the eight is correct for any ray; the choice is only speed.  Inner nodes that hardly cull are left
+ * out as in the other lists (decided once, on the first flattening).  Valid only when every primitive lies
+ * inside its leaf's box and every inner node of the reference's list encloses its children (the caller checks
+ * both).  `rows` / `start`: a nested list.  Output: 8 x count nodes, list after list. */
+static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vector<int> &start, std::vector<float4> &outRows,
+                               std::vector<int> &outStart, int *nbPruned)
+{
+    struct Leaf
+    {
+        float lo[3], hi[3];
+        int node;
+    };
+    struct TreeNode
+    {
+        float lo[3], hi[3];
+        int left, right, axis, leaf; /* leaf: node of the input list, -1 for an inner node */
+        bool keep;
+    };
+    const int n = (int)start.size();
+    std::vector<Leaf> leaves;
+    for (int i = 0; i < n; ++i)
+        if (bitsi(rows[2 * i + 1].z) > 0)
+        {
+            Leaf l;
+            l.lo[0] = rows[2 * i].x, l.lo[1] = rows[2 * i].y, l.lo[2] = rows[2 * i].z;
+            l.hi[0] = rows[2 * i + 1].x, l.hi[1] = rows[2 * i + 1].y, l.hi[2] = rows[2 * i].w;
+            l.node = i;
+            leaves.push_back(l);
+        }
+    outRows.clear();
+    outStart.clear();
+    *nbPruned = 0;
+    if (leaves.size() < 2)
+        return 0;
+    auto area = [](const float *lo, const float *hi) {
+        const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+        return x * y + y * z + z * x;
+    };
+    std::vector<TreeNode> tree;
+    tree.reserve(2 * leaves.size());
+    struct Range
+    {
+        int from, to, node;
+    };
+    std::vector<Range> todo;
+    tree.push_back(TreeNode());
+    todo.push_back({0, (int)leaves.size(), 0});
+    while (!todo.empty())
+    {
+        const Range r = todo.back();
+        todo.pop_back();
+        const int count = r.to - r.from;
+        TreeNode t;
+        t.left = t.right = -1;
+        t.axis = 0;
+        t.leaf = -1;
+        t.keep = true;
+        if (count == 1)
+        {
+            for (int k = 0; k < 3; ++k)
+                t.lo[k] = leaves[r.from].lo[k], t.hi[k] = leaves[r.from].hi[k];
+            t.leaf = leaves[r.from].node;
+            tree[r.node] = t;
+            continue;
+        }
+        float clo[3] = {1e30f, 1e30f, 1e30f}, chi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int k = 0; k < 3; ++k)
+            t.lo[k] = 1e30f, t.hi[k] = -1e30f;
+        for (int q = r.from; q < r.to; ++q)
+            for (int k = 0; k < 3; ++k)
+            {
+                t.lo[k] = std::min(t.lo[k], leaves[q].lo[k]);
+                t.hi[k] = std::max(t.hi[k], leaves[q].hi[k]);
+                const float c = 0.5f * (leaves[q].lo[k] + leaves[q].hi[k]);
+                clo[k] = std::min(clo[k], c);
+                chi[k] = std::max(chi[k], c);
+            }
+        /* binned surface-area split */
+        const int BINS = 16;
+        int bestAxis = -1, bestBin = 0;
+        double bestCost = 1e300;
+        for (int axis = 0; axis < 3; ++axis)
+        {
+            const float extent = chi[axis] - clo[axis];
+            if (!(extent > 0.f))
+                continue;
+            int counts[BINS] = {0};
+            float blo[BINS][3], bhi[BINS][3];
+            for (int b = 0; b < BINS; ++b)
+                for (int k = 0; k < 3; ++k)
+                    blo[b][k] = 1e30f, bhi[b][k] = -1e30f;
+            const float scale = BINS / extent;
+            for (int q = r.from; q < r.to; ++q)
+            {
+                const float c = 0.5f * (leaves[q].lo[axis] + leaves[q].hi[axis]);
+                const int b = std::min(BINS - 1, std::max(0, (int)((c - clo[axis]) * scale)));
+                ++counts[b];
+                for (int k = 0; k < 3; ++k)
+                {
+                    blo[b][k] = std::min(blo[b][k], leaves[q].lo[k]);
+                    bhi[b][k] = std::max(bhi[b][k], leaves[q].hi[k]);
+                }
+            }
+            double rightArea[BINS];
+            int rightCount[BINS];
+            float rlo[3] = {1e30f, 1e30f, 1e30f}, rhi[3] = {-1e30f, -1e30f, -1e30f};
+            int rc = 0;
+            for (int b = BINS - 1; b > 0; --b)
+            {
+                rc += counts[b];
+                for (int k = 0; k < 3; ++k)
+                {
+                    rlo[k] = std::min(rlo[k], blo[b][k]);
+                    rhi[k] = std::max(rhi[k], bhi[b][k]);
+                }
+                rightCount[b] = rc;
+                rightArea[b] = rc ? area(rlo, rhi) : 0.0;
+            }
+            float llo[3] = {1e30f, 1e30f, 1e30f}, lhi[3] = {-1e30f, -1e30f, -1e30f};
+            int lc = 0;
+            for (int b = 0; b + 1 < BINS; ++b)
+            {
+                lc += counts[b];
+                for (int k = 0; k < 3; ++k)
+                {
+                    llo[k] = std::min(llo[k], blo[b][k]);
+                    lhi[k] = std::max(lhi[k], bhi[b][k]);
+                }
+                if (lc == 0 || rightCount[b + 1] == 0)
+                    continue;
+                const double cost = area(llo, lhi) * lc + rightArea[b + 1] * rightCount[b + 1];
+                if (cost < bestCost)
+                {
+                    bestCost = cost;
+                    bestAxis = axis;
+                    bestBin = b;
+                }
+            }
+        }
+        int mid;
+        if (bestAxis < 0)
+            mid = r.from + count / 2; /* all centres coincide */
+        else
+        {
+            const float scale = BINS / (chi[bestAxis] - clo[bestAxis]);
+            const float origin = clo[bestAxis];
+            const int axis = bestAxis, bin = bestBin;
+            mid = (int)(std::partition(leaves.begin() + r.from, leaves.begin() + r.to,
+                                       [&](const Leaf &l) {
+                                           const float c = 0.5f * (l.lo[axis] + l.hi[axis]);
+                                           return std::min(BINS - 1, std::max(0, (int)((c - origin) * scale))) <= bin;
+                                       }) -
+                        leaves.begin());
+            if (mid == r.from || mid == r.to)
+                mid = r.from + count / 2;
+            t.axis = bestAxis;
+        }
+        t.left = (int)tree.size(); /* the low side of the split */
+        t.right = t.left + 1;
+        tree.push_back(TreeNode());
+        tree.push_back(TreeNode());
+        tree[r.node] = t;
+        todo.push_back({r.from, mid, t.left});
+        todo.push_back({mid, r.to, t.right});
+    }
+
+    /* one flattening: depth-first, the child on the near side of a ray of this octant first */
+    auto flatten = [&](int octant, std::vector<float4> &fr, std::vector<int> &fs, std::vector<int> *which) {
+        struct Visit
+        {
+            int node, slot; /* slot >= 0: close the inner node written at `slot` */
+        };
+        std::vector<Visit> stack;
+        stack.push_back({0, -1});
+        while (!stack.empty())
+        {
+            const Visit v = stack.back();
+            stack.pop_back();
+            if (v.slot >= 0)
+            {
+                fr[2 * v.slot + 1].w = bitsf((int)fs.size() - v.slot);
+                continue;
+            }
+            const TreeNode &t = tree[v.node];
+            if (t.leaf >= 0)
+            {
+                fr.push_back(rows[2 * t.leaf]);
+                float4 second = rows[2 * t.leaf + 1];
+                second.w = bitsf(1);
+                fr.push_back(second);
+                fs.push_back(start[t.leaf]);
+                if (which)
+                    which->push_back(v.node);
+                continue;
+            }
+            if (t.keep)
+            {
+                const int slot = (int)fs.size();
+                fr.push_back(make_float4(t.lo[0], t.lo[1], t.lo[2], t.hi[2]));
+                fr.push_back(make_float4(t.hi[0], t.hi[1], bitsf(0), bitsf(1)));
+                fs.push_back(0);
+                if (which)
+                    which->push_back(v.node);
+                stack.push_back({0, slot});
+            }
+            const bool highFirst = (octant >> t.axis) & 1; /* direction negative along the split axis */
+            stack.push_back({highFirst ? t.left : t.right, -1});
+            stack.push_back({highFirst ? t.right : t.left, -1}); /* popped first */
+        }
+    };
+    /* which inner nodes stay: decided on the first flattening */
+    {
+        std::vector<float4> fr;
+        std::vector<int> fs, which;
+        flatten(0, fr, fs, &which);
+        std::vector<int> origin(which);
+        pruneInnerNodes(fr, fs, origin, nbPruned);
+        std::vector<char> kept(tree.size(), 0);
+        for (int t : origin)
+            kept[t] = 1;
+        for (size_t t = 0; t < tree.size(); ++t)
+            if (tree[t].leaf < 0)
+                tree[t].keep = kept[t] != 0;
+    }
+    int count = 0;
+    for (int octant = 0; octant < 8; ++octant)
+    {
+        const size_t before = outStart.size();
+        flatten(octant, outRows, outStart, nullptr);
+        /* skip pointers are relative: each list is self-contained */
+        count = (int)(outStart.size() - before);
+    }
+    return count;
 }
 
 /* Grouping nodes.  The reference's grid builder produces wide levels - 31 sibling leaves under the root of
@@ -2799,6 +3080,35 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
             startC[j] = start[i];
         }
 
+    /* the order-free list, from the leaves of the collapsed list (every inner node of which must enclose its
+     * children: the walk that uses it relies on a leaf being reachable whenever its own test passes) */
+    std::vector<float4> boxesF;
+    std::vector<int> startF;
+    int nbFreeNodes = 0;
+    if (g.nested && g.orderedCompact && nc > 1 && g.grouping && !getenv("SOLR_HIP_NO_FREE_ORDER"))
+    {
+        bool encloses = true;
+        for (int i = 0; i < nc && encloses; ++i)
+        {
+            const int end = std::min(i + std::max(bitsi(boxesC[2 * i + 1].w), 1), nc);
+            if (bitsi(boxesC[2 * i + 1].z) > 0 || end <= i + 1)
+                continue;
+            for (int j = i + 1; j < end && encloses; j += std::max(bitsi(boxesC[2 * j + 1].w), 1))
+                encloses = boxesC[2 * j].x >= boxesC[2 * i].x && boxesC[2 * j].y >= boxesC[2 * i].y &&
+                           boxesC[2 * j].z >= boxesC[2 * i].z && boxesC[2 * j + 1].x <= boxesC[2 * i + 1].x &&
+                           boxesC[2 * j + 1].y <= boxesC[2 * i + 1].y && boxesC[2 * j].w <= boxesC[2 * i].w;
+        }
+        if (encloses)
+        {
+            int prunedFree = 0;
+            nbFreeNodes = buildFreeOrderLists(boxesC, startC, boxesF, startF, &prunedFree);
+            if (getenv("SOLR_HIP_DEBUG_TREE"))
+                fprintf(stderr, "solr_hip: order-free lists: 8 x %d nodes (%d inner nodes that hardly cull left out)\n",
+                        nbFreeNodes, prunedFree);
+        }
+        phase.mark("h2d_scene: order-free list");
+    }
+
     int nbWalkNodes = nc, prunedBefore = 0, prunedAfter = 0;
     if (g.nested && g.orderedCompact && nc > 0 && g.grouping)
     {
@@ -2846,6 +3156,10 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     g.hostBoxesCompact.swap(boxesC);
     g.hostBoxStart.swap(start);
     g.hostBoxStartCompact.swap(startC);
+    g.hostBoxesFree.swap(boxesF);
+    g.hostBoxStartFree.swap(startF);
+    g.nbBoxesFree = nbFreeNodes;
+    g.freeStale = false;
     g.hostPrims.swap(prims);
     retagPrimitives();
     phase.mark("h2d_scene: tags");
@@ -2914,6 +3228,7 @@ int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], 
     hipLaunchKernelGGL(k_rotatePrimitives, dim3((unsigned)((g.nbPrimitives + 255) / 256)), dim3(256), 0, g.stream,
                        (float4 *)g.geometry.ptr, g.offPrims, g.nbPrimitives, (const unsigned char *)g.movable.ptr, R);
     refitList(g.refitWalkLevels, g.offBoxesCompact, g.offBoxStartCompact, viewDistance);
+    g.freeStale = true; /* the order-free list is not refitted: rotated scenes walk the reference's order until the next upload */
     buildLeafRecords(); /* the leaves' copies of their first primitive follow the primitives */
     g.exactStale = true;
     g.exactStaleViewDistance = viewDistance;
