@@ -242,8 +242,11 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
 
 /* A/B measurements: 0 = automatic; 3 = walk the node list exactly as uploaded (no collapsed chains, no
  * grouping nodes); 4 = always the all-features kernel; 5 = no grouping nodes (takes effect at the next
- * h2d_scene).  Every setting renders the same frame. */
+ * h2d_scene); 6 = no order-free lists (every walk in the reference's order).  Every setting renders the same
+ * frame. */
 void solr_hip_set_variant(int variant);
+/* nodes per order-free list of the resident scene when long rays' closest-hit walks use them, else 0 */
+int solr_hip_order_free_nodes(void);
 int solr_hip_get_variant(void);
 
 /* Animated scenes.  The reference re-runs GPUKernel::rotatePrimitives (GPUKernel.cpp:1378-1460: rotate

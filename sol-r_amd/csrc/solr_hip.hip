@@ -1779,6 +1779,13 @@ void flushGeometry()
         g.geometryDirty = false;
 }
 
+/* the order-free lists exist for the resident scene and every condition of their use holds (rt_device.h closestHitWalk) */
+bool orderFreeListsUsable()
+{
+    return g.nbBoxesFree > 0 && g.hostBoxesFree.size() == 16 * (size_t)g.nbBoxesFree && g.primsContained && !g.freeStale &&
+           g.nested && g.orderedCompact && g.variant != 6;
+}
+
 SceneArgs makeScene(bool exactNodes)
 {
     SceneArgs S;
@@ -1800,8 +1807,7 @@ SceneArgs makeScene(bool exactNodes)
     S.nested = g.nested;
     S.orderedBoxes = exactNodes ? g.orderedExact : g.orderedCompact;
     S.nbRandoms = g.randoms.ptr ? g.nbRandoms : 0;
-    if (!exactNodes && g.nbBoxesFree > 0 && g.hostBoxesFree.size() == 16 * (size_t)g.nbBoxesFree && g.primsContained && !g.freeStale && g.nested && g.orderedCompact &&
-        g.variant != 6)
+    if (!exactNodes && orderFreeListsUsable())
     {
         S.offBoxesFree = g.offBoxesFree;
         S.offLeafFree = g.offLeafFree;
@@ -3800,6 +3806,14 @@ void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, in
  * processes rendered - nbAbove rows of `width` floats just above it, nbBelow just below - for hosts that move them
  * themselves (MPI, shared memory; tests/test_gpu_parity.py does it from a full frame).  Used by the ambient-occlusion
  * kernel of the frames that follow, in place of the RCCL exchange; (NULL, 0, NULL, 0) ends it. */
+/* Extension: nodes per order-free list of the resident scene if closest-hit walks of long rays use them (the
+ * lists exist, every primitive lies inside its leaf's box, no rotation on the device since the upload, variant
+ * not 6), else 0. */
+extern "C" int solr_hip_order_free_nodes(void)
+{
+    return (g.initialized && orderFreeListsUsable()) ? g.nbBoxesFree : 0;
+}
+
 extern "C" void solr_hip_set_depth_halo(const float *above, int nbAbove, const float *below, int nbBelow)
 {
     if (!ready("solr_hip_set_depth_halo"))

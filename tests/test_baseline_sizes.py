@@ -10,9 +10,10 @@ The engine renders the full frame; the oracle - minutes per full frame of the la
 share - renders 36 full rows spread over the frame (oracle.render(first_row, nb_rows), the same strip
 interface the multi-GPU split uses) and those rows must be what the engine produced: primitive ids exact,
 first-hit depth exact, RGB8 exact, float colour within 1 ULP.  Each configuration runs in the engine's
-default form (walk-order node list with grouping nodes, automatic tile order), with the reference's own node
-list (variant 3), without grouping nodes (variant 5), and with two frames in flight under the forced
-cost-ordered launch.  cfg4 walks row strips through all 74 passes on both sides (every pass reads what the
+default form (order-free lists for the primary rays, walk-order node list with grouping nodes for the rest,
+automatic tile order), with every walk in the reference's order (variant 6: the whole frame must be the default
+form's bit for bit), with the reference's own node list (variant 3), without grouping nodes (variant 5), and with
+two frames in flight under the forced cost-ordered launch.  cfg4 walks row strips through all 74 passes on both sides (every pass reads what the
 pass before left in the frame buffers) and ties the full-size frame to those strips.
 """
 import ctypes as C
@@ -99,6 +100,15 @@ def test_full_size_frames_match_the_oracle_on_rows_across_the_frame(solr, oracle
         _render(solr, args)
         first = device_frame(solr, si)
         _check_rows(first, expected, config + " default")
+        assert hip.solr_hip_order_free_nodes() > 0, "primary rays did not walk the order-free lists"
+
+        # every walk in the reference's order (no order-free lists)
+        hip.solr_hip_set_variant(6)
+        _render(solr, args)
+        ordered = device_frame(solr, si)
+        _check_rows(ordered, expected, config + " variant 6")
+        assert np.array_equal(ordered[1], first[1]) and np.array_equal(ordered[2], first[2])
+        assert np.array_equal(ordered[0].view(np.uint32), first[0].view(np.uint32))
 
         # the reference's own node list
         hip.solr_hip_set_variant(3)

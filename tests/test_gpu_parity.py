@@ -708,3 +708,65 @@ def test_ambient_occlusion_on_a_strip_reads_the_neighbours_rows(solr, oracle):
         hip.solr_hip_set_depth_halo(None, 0, None, 0)
         hip.solr_hip_set_strip(0, -1)
         k.finalize()
+
+
+def _tie_scene(k, width=160, height=120, **info):
+    """Primitives that tie: every sphere, triangle and cylinder is in the scene twice (and once more with another
+    material), at the same place - equal hit distances bit for bit.  The reference keeps the one it visits
+    first; which one that is follows from its flatten order, not from the order of insertion."""
+    rng = solr_mod.scenes.LCG(11)
+    k.initialize(width=width, height=height, nbRayIterations=2, **info)
+    mats = [k.add_material(0.9, 0.2, 0.2, specValue=0.3, specPower=40.0), k.add_material(0.2, 0.9, 0.2, reflection=0.4),
+            k.add_material(0.2, 0.3, 0.9, specValue=0.8, specPower=100.0)]
+    u = rng.uniform
+    for copy in range(3):
+        rng = solr_mod.scenes.LCG(11)       # the same geometry again
+        u = rng.uniform
+        for i in range(40):
+            c = (u(-6000, 6000), u(-4000, 4000), u(-3000, 6000))
+            k.add_primitive(solr_mod.ptSphere, c, size=(u(300, 900), 0, 0), material=mats[(i + copy) % 3])
+        for i in range(60):
+            p0 = (u(-7000, 7000), u(-4500, 4500), u(0, 7000))
+            p1 = (p0[0] + u(-1500, 1500), p0[1] + u(-1500, 1500), p0[2] + u(-800, 800))
+            p2 = (p0[0] + u(-1500, 1500), p0[1] + u(-1500, 1500), p0[2] + u(-800, 800))
+            t = k.add_primitive(solr_mod.ptTriangle, p0, p1, p2, material=mats[(i + 2 * copy) % 3])
+            k.set_normals(t, (0, 0, -1), (0.1, 0, -1), (0, 0.1, -1))
+        for i in range(20):
+            a = (u(-6000, 6000), u(-4000, 4000), u(-2000, 5000))
+            b = (a[0] + u(-1200, 1200), a[1] + u(-1200, 1200), a[2] + u(-1200, 1200))
+            k.add_primitive(solr_mod.ptCylinder, a, b, size=(u(80, 250), 0, 0), material=mats[(i + copy) % 3])
+    k.add_primitive(solr_mod.ptXYPlane, (0, 0, 9000), size=(12000, 8000, 0), material=mats[0])
+    X._light(k)
+    k.compact_boxes(True)
+    k.set_camera((300.0, 200.0, -15000.0), look_at=(0.0, 0.0, 0.0), angles=(0.02, -0.03, 0.0))
+    return k
+
+
+def test_order_free_walk_resolves_ties_as_the_reference_does(solr, oracle):
+    """Primary rays walk a hierarchy of the engine's own over the scene's leaves, in an order of its own (DESIGN.md
+    section 4): equal distances must go to the primitive the reference visits first, and nothing may depend on
+    the order otherwise.  A scene in which every primitive exists three times is rendered with the order-free
+    lists (the default), without them (variant 6) and by the oracle: ids, depth and RGB8 identical, float
+    colour within 1 ULP of the oracle and bit for bit between the two engine forms."""
+    hip = solr.hip_lib()
+    frames = []
+    try:
+        for variant in (0, 6):
+            hip.solr_hip_set_variant(variant)
+            k = solr.Kernel(engine="hip")
+            _tie_scene(k)
+            pp, ids, rgb = gpu_frame(k)
+            assert (hip.solr_hip_order_free_nodes() > 0) == (variant == 0)
+            if variant == 0:
+                opp, oids, orgb, _, status = oracle_frame(k, oracle)
+                assert status == 0
+                res = compare_frames(pp, ids, rgb, opp, oids, orgb)
+                assert_parity(res)
+                hit = oids[..., 0] >= 0
+                assert hit.mean() > 0.3
+            frames.append((np.array(pp, copy=True), np.array(ids, copy=True), np.array(rgb, copy=True)))
+            k.finalize()
+    finally:
+        hip.solr_hip_set_variant(0)
+    assert np.array_equal(frames[0][1], frames[1][1]) and np.array_equal(frames[0][2], frames[1][2])
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
