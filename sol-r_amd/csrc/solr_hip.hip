@@ -1288,6 +1288,7 @@ struct Engine
     int nbMovable = -1;                 /* flags uploaded for that many primitives, -1: none */
     std::vector<int> refitLevels;       /* exact list: [offset, count] per height, offsets into refitPlan (ints) */
     std::vector<int> refitWalkLevels;   /* walk-order list, same form */
+    std::vector<int> refitFreeLevels;   /* the eight order-free lists as one forest, same form */
     bool refitReady = false;
     bool exactStale = false;            /* the exact list has not been refitted since the last rotation */
     float exactStaleViewDistance = 0.f;
@@ -1527,12 +1528,14 @@ int materialTag(const Material &m)
  * Both give a node of the reference's tree the same bounds: min / max over the level-0 boxes below it,
  * clamped once or several times by the same +-viewDistance seed, first occurrence winning a tie in either
  * nesting.  Node 0, the light cell, keeps its +-viewDistance (GPUKernel.cpp:1189). */
-static void buildRefitPlan(const std::vector<float4> &exact, const std::vector<float4> &walk, const std::vector<int> &origin)
+static void buildRefitPlan(const std::vector<float4> &exact, const std::vector<float4> &walk, const std::vector<int> &origin,
+                           const std::vector<float4> &free, const std::vector<int> &freeOrigin)
 {
     g.refitReady = false;
     g.exactStale = false;
     g.refitLevels.clear();
     g.refitWalkLevels.clear();
+    g.refitFreeLevels.clear();
     if (!g.nested)
         return;
     auto heights = [](const std::vector<float4> &rows, std::vector<int> &height) {
@@ -1583,6 +1586,17 @@ static void buildRefitPlan(const std::vector<float4> &exact, const std::vector<f
             return -1L;                                   /* the light cell */
         return origin[j] < 0 ? (long)(j | (int)0x80000000) : (long)j; /* sign bit: a grouping node */
     });
+    /* the eight order-free lists, one behind the other: a forest with the same kinds of node (leaves of the
+     * reference's tree, unions above them) */
+    if (!free.empty())
+    {
+        nbHeights = heights(free, height);
+        byHeight(height, nbHeights, g.refitFreeLevels, [&](int j) {
+            if (freeOrigin[j] == 0)
+                return -1L;
+            return freeOrigin[j] < 0 ? (long)(j | (int)0x80000000) : (long)j;
+        });
+    }
     if (plan.empty())
         plan.push_back(0);
     upload(g.refitPlan, plan);
@@ -1623,6 +1637,7 @@ static void pullGeometry()
     };
     get(g.offBoxes, g.hostBoxes.data(), g.hostBoxes.size() * 16);
     get(g.offBoxesCompact, g.hostBoxesCompact.data(), g.hostBoxesCompact.size() * 16);
+    get(g.offBoxesFree, g.hostBoxesFree.data(), g.hostBoxesFree.size() * 16);
     get(g.offPrims, g.hostPrims.data(), g.hostPrims.size() * 16);
     g.deviceAhead = false;
 }
@@ -2567,8 +2582,9 @@ static int pruneInnerNodes(std::vector<float4> &rows, std::vector<int> &start, s
  * out as in the other lists (decided once, on the first flattening).  Valid only when every primitive lies
  * inside its leaf's box and every inner node of the reference's list encloses its children (the caller checks
  * both).  `rows` / `start`: a nested list.  Output: 8 x count nodes, list after list. */
-static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vector<int> &start, std::vector<float4> &outRows,
-                               std::vector<int> &outStart, int *nbPruned)
+static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vector<int> &start, const std::vector<int> &origin,
+                               std::vector<float4> &outRows, std::vector<int> &outStart, std::vector<int> &outOrigin,
+                               int *nbPruned)
 {
     struct Leaf
     {
@@ -2594,6 +2610,7 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
         }
     outRows.clear();
     outStart.clear();
+    outOrigin.clear();
     *nbPruned = 0;
     if (leaves.size() < 2)
         return 0;
@@ -2730,7 +2747,8 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
     }
 
     /* one flattening: depth-first, the child on the near side of a ray of this octant first */
-    auto flatten = [&](int octant, std::vector<float4> &fr, std::vector<int> &fs, std::vector<int> *which) {
+    auto flatten = [&](int octant, std::vector<float4> &fr, std::vector<int> &fs, std::vector<int> *which,
+                       std::vector<int> *from) {
         struct Visit
         {
             int node, slot; /* slot >= 0: close the inner node written at `slot` */
@@ -2756,6 +2774,8 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
                 fs.push_back(start[t.leaf]);
                 if (which)
                     which->push_back(v.node);
+                if (from)
+                    from->push_back(origin[t.leaf]); /* the node of the reference's list this leaf is */
                 continue;
             }
             if (t.keep)
@@ -2766,6 +2786,8 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
                 fs.push_back(0);
                 if (which)
                     which->push_back(v.node);
+                if (from)
+                    from->push_back(-1);
                 stack.push_back({0, slot});
             }
             const bool highFirst = (octant >> t.axis) & 1; /* direction negative along the split axis */
@@ -2777,11 +2799,11 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
     {
         std::vector<float4> fr;
         std::vector<int> fs, which;
-        flatten(0, fr, fs, &which);
-        std::vector<int> origin(which);
-        pruneInnerNodes(fr, fs, origin, nbPruned);
+        flatten(0, fr, fs, &which, nullptr);
+        std::vector<int> survivors(which);
+        pruneInnerNodes(fr, fs, survivors, nbPruned);
         std::vector<char> kept(tree.size(), 0);
-        for (int t : origin)
+        for (int t : survivors)
             kept[t] = 1;
         for (size_t t = 0; t < tree.size(); ++t)
             if (tree[t].leaf < 0)
@@ -2791,7 +2813,7 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
     for (int octant = 0; octant < 8; ++octant)
     {
         const size_t before = outStart.size();
-        flatten(octant, outRows, outStart, nullptr);
+        flatten(octant, outRows, outStart, nullptr, &outOrigin);
         /* skip pointers are relative: each list is self-contained */
         count = (int)(outStart.size() - before);
     }
@@ -3089,7 +3111,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     /* the order-free list, from the leaves of the collapsed list (every inner node of which must enclose its
      * children: the walk that uses it relies on a leaf being reachable whenever its own test passes) */
     std::vector<float4> boxesF;
-    std::vector<int> startF;
+    std::vector<int> startF, originF;
     int nbFreeNodes = 0;
     if (g.nested && g.orderedCompact && nc > 1 && g.grouping && !getenv("SOLR_HIP_NO_FREE_ORDER"))
     {
@@ -3107,7 +3129,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
         if (encloses)
         {
             int prunedFree = 0;
-            nbFreeNodes = buildFreeOrderLists(boxesC, startC, boxesF, startF, &prunedFree);
+            nbFreeNodes = buildFreeOrderLists(boxesC, startC, originC, boxesF, startF, originF, &prunedFree);
             if (getenv("SOLR_HIP_DEBUG_TREE"))
                 fprintf(stderr, "solr_hip: order-free lists: 8 x %d nodes (%d inner nodes that hardly cull left out)\n",
                         nbFreeNodes, prunedFree);
@@ -3154,7 +3176,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     if (prims.empty())
         prims.assign(8, make_float4(0.f, 0.f, 0.f, 0.f)); /* inactive lanes read record 0 */
     phase.mark("h2d_scene: primitive rows");
-    buildRefitPlan(boxes, boxesC, originC);
+    buildRefitPlan(boxes, boxesC, originC, boxesF, originF);
     phase.mark("h2d_scene: refit plan");
     g.deviceAhead = false;
     g.nbMovable = -1;
@@ -3234,7 +3256,10 @@ int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], 
     hipLaunchKernelGGL(k_rotatePrimitives, dim3((unsigned)((g.nbPrimitives + 255) / 256)), dim3(256), 0, g.stream,
                        (float4 *)g.geometry.ptr, g.offPrims, g.nbPrimitives, (const unsigned char *)g.movable.ptr, R);
     refitList(g.refitWalkLevels, g.offBoxesCompact, g.offBoxStartCompact, viewDistance);
-    g.freeStale = true; /* the order-free list is not refitted: rotated scenes walk the reference's order until the next upload */
+    if (g.nbBoxesFree > 0 && !g.refitFreeLevels.empty())
+        refitList(g.refitFreeLevels, g.offBoxesFree, g.offBoxStartFree, viewDistance);
+    else
+        g.freeStale = g.nbBoxesFree > 0; /* no plan: rotated scenes walk the reference's order until the next upload */
     buildLeafRecords(); /* the leaves' copies of their first primitive follow the primitives */
     g.exactStale = true;
     g.exactStaleViewDistance = viewDistance;

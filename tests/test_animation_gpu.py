@@ -79,12 +79,14 @@ def _device_rotation_equals_host_rotation(solr, oracle, spec, grouping):
     hip = solr.hip_lib()
     k = _build(solr, spec, "hip")
     gpu_frame(k)                                   # uploads the scene
+    order_free = hip.solr_hip_order_free_nodes()   # > 0 where the primary rays walk the order-free lists
     frames = []
     for n, (center, angles) in enumerate(STEPS):
         k.rotate_primitives(center, angles)
         assert k.pending_rotations() == n + 1, "the rotation took the host route"
         frames.append(gpu_frame(k))
     assert hip.solr_hip_device_rotations() == len(STEPS)
+    assert hip.solr_hip_order_free_nodes() == order_free, "the order-free lists did not follow the rotations"
     nodes = k.device_nodes(exact=True)
     prims = k.device_primitives()
     walk = k.device_nodes(exact=False)
