@@ -3126,6 +3126,40 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
                            boxesC[2 * j].z >= boxesC[2 * i].z && boxesC[2 * j + 1].x <= boxesC[2 * i + 1].x &&
                            boxesC[2 * j + 1].y <= boxesC[2 * i + 1].y && boxesC[2 * j].w <= boxesC[2 * i].w;
         }
+        /* ... and every leaf must hold its primitives (the reference's builder makes it so, GPUKernel.cpp:741-830;
+         * another host's boxes are taken at their word only after this check).  The types whose extent is not
+         * what the builder adds around p0 - cones, ellipsoids ... - are sorted out by retagPrimitives. */
+        for (int i = 0; i < nc && encloses; ++i)
+        {
+            const int count = bitsi(boxesC[2 * i + 1].z);
+            for (int k = 0; k < count && encloses; ++k)
+            {
+                const Primitive &p = primitives[startC[i] + k];
+                float lo[3] = {p.p0.x, p.p0.y, p.p0.z}, hi[3] = {p.p0.x, p.p0.y, p.p0.z};
+                auto add = [&](const vec3f &v) {
+                    lo[0] = std::min(lo[0], v.x), lo[1] = std::min(lo[1], v.y), lo[2] = std::min(lo[2], v.z);
+                    hi[0] = std::max(hi[0], v.x), hi[1] = std::max(hi[1], v.y), hi[2] = std::max(hi[2], v.z);
+                };
+                float grow[3] = {p.size.x, p.size.y, p.size.z};
+                if (p.type == ptTriangle)
+                {
+                    add(p.p1);
+                    add(p.p2);
+                    grow[0] = grow[1] = grow[2] = 0.f;
+                }
+                else if (p.type == ptCylinder)
+                {
+                    add(p.p1);
+                    grow[1] = grow[2] = p.size.x;
+                }
+                else if (p.type == ptSphere)
+                    grow[1] = grow[2] = p.size.x;
+                const float eps = 1.0e-3f; /* the builder subtracts and adds in another order: an ulp of slack */
+                encloses = boxesC[2 * i].x <= lo[0] - fabsf(grow[0]) + eps && boxesC[2 * i].y <= lo[1] - fabsf(grow[1]) + eps &&
+                           boxesC[2 * i].z <= lo[2] - fabsf(grow[2]) + eps && boxesC[2 * i + 1].x >= hi[0] + fabsf(grow[0]) - eps &&
+                           boxesC[2 * i + 1].y >= hi[1] + fabsf(grow[1]) - eps && boxesC[2 * i].w >= hi[2] + fabsf(grow[2]) - eps;
+            }
+        }
         if (encloses)
         {
             int prunedFree = 0;
