@@ -1725,9 +1725,32 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         countAdd<COUNT>(cnt.shadow, 1);
     countAdd<COUNT>(cnt.wShadow, 1);
 
-    const int nbBoxes = S.nbBoxes;
     const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteRay(r)) == 0ull);
     const bool tidy = !COUNT && fastBoxes && S.nested;
+    /* Order-free shadows.  Where no primitive of the scene is transparent (or a textured plane) the first occluder
+     * between the point and the lamp saturates the shadow - result = 0 + 1 x shadowIntensity, exactly - and the
+     * lane is done: which occluder that was, and in which order the leaves were visited, cannot be seen in the
+     * result.  Such walks take an order-free list (closestHitWalk above; the ray reaches from the point to the
+     * lamp, thousands of units long) and leave out every box that begins beyond the lamp: an occluder must be
+     * hit before it (l < lengthOL, i.e. slab parameter < 1), which the reference's cut-off - the parameter
+     * against the view distance, hence the condition on it - never uses.  The list of the OPPOSITE octant, the
+     * lamp's side first: for an any-hit query that measured best (mesh -5 %, molecule -2 %; the near side first
+     * +10 % on the molecule: the point's own neighbourhood is where the boxes are entered and the tests miss). */
+    const bool freeOrder = tidy && S.nbBoxesFree > 0 && S.opaqueShadows &&
+                           ballot(active && !(dot(r.d, r.d) >= 4.f && minDistance >= 2.f)) == 0ull;
+    Scene W = S;
+    float farFree = 0.f;
+    if (freeOrder)
+    {
+        const int signs = ((r.d.x < 0.f ? 1 : 0) | (r.d.y < 0.f ? 2 : 0) | (r.d.z < 0.f ? 4 : 0)) ^ 7;
+        const int lane = (int)__builtin_ctzll(ballot(active));
+        const int octant = __builtin_amdgcn_readlane(signs, lane);
+        W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
+        W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
+        W.nbBoxes = S.nbBoxesFree;
+        farFree = 1.0002f + 1.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z)) / lengthOL;
+    }
+    const int nbBoxes = W.nbBoxes;
     const PackedRay pr = packRay(r);
     int cursor = (active && result < si.shadowIntensity) ? 0 : SOLR_CURSOR_DONE;
     int cur = 0;
@@ -1744,7 +1767,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         SOLR_T(unsigned long long ta = SOLR_NOW();)
         if (tidy)
         {
-            leaf = advanceTidy<FEAT>(S, pr, minDistance, cursor, cur, nbPrimitives, entered);
+            leaf = advanceTidy<FEAT>(W, pr, freeOrder ? farFree : minDistance, cursor, cur, nbPrimitives, entered);
             SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)
             if (leaf < 0)
                 break;
@@ -1753,7 +1776,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                  nbPrimitives <= 0)
             continue;
         /* (readfirstlane: the compiler takes an inline-asm result for divergent and would fetch the record per lane) */
-        const Row4 L = leafRecord(S, uniform(leaf));
+        const Row4 L = leafRecord(W, uniform(leaf));
         const int start = uniform(asint(L.d.w));
         for (int k = 0; k < nbPrimitives; ++k)
         {

@@ -154,6 +154,7 @@ struct SceneArgs
     /* the order-free list (closest-hit walks of rays longer than 2, rt_device.h): 0 nodes when there is none */
     unsigned offBoxesFree, offLeafFree;
     int nbBoxesFree;
+    int opaqueShadows; /* no primitive is transparent or a textured plane: any occluder saturates a shadow */
 };
 
 /* Device view: everything is read through the CONSTANT address space.  The
@@ -188,6 +189,7 @@ struct Scene
     unsigned offLeaf;
     unsigned offBoxesFree, offLeafFree;
     int nbBoxesFree;
+    int opaqueShadows;
 };
 
 __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
@@ -213,6 +215,7 @@ __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
     s.offBoxesFree = a.offBoxesFree;
     s.offLeafFree = a.offLeafFree;
     s.nbBoxesFree = a.nbBoxesFree;
+    s.opaqueShadows = a.opaqueShadows;
     return s;
 }
 

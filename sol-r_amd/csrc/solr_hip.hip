@@ -1217,6 +1217,7 @@ struct Engine
     int nbBoxesFree = 0;        /* nodes per list; there are eight, one per direction octant */
     bool freeStale = false;     /* rotated on the device since it was built: not refitted, not walked */
     bool primsContained = false; /* every primitive lies inside its leaf's box (retagPrimitives) */
+    bool opaqueShadows = false;  /* no transparent primitive, no textured plane (retagPrimitives) */
     std::vector<int> materialTags; /* PRIM_* bits per material id */
     /* texture tables of the textured materials and the size of the uploaded atlas: checked against each other
      * before the first frame that follows either upload (checkTextureTables) */
@@ -1648,7 +1649,7 @@ void retagPrimitives()
     const size_t n = g.hostPrims.size() / PRIM_ROWS;
     const bool noKinds = getenv("SOLR_HIP_NO_KINDS") != nullptr; /* tests: every primitive through the general tests */
     int features = 0;
-    bool contained = true;
+    bool contained = true, opaque = true;
     for (size_t i = 0; i < n; ++i)
     {
         float4 *r = &g.hostPrims[PRIM_ROWS * i];
@@ -1675,6 +1676,9 @@ void retagPrimitives()
          * p0 +- radius of a sphere, min / max (p0, p1) +- radius of a cylinder, p0 +- size of a plane; a cone's box
          * is built around p0 alone, a procedural sphere's surface is displaced, the others are not bounded by
          * their size) */
+        /* every occluder saturates a shadow (GI:880: intensity 1 x sceneInfo.shadowIntensity) unless it is transparent
+         * (GI:881-892 scales and tints) or a textured plane (its texel's alpha is the intensity, GI:553-558) */
+        opaque = opaque && !(facts & PRIM_TRANSPARENT) && !(facts & PRIM_TEXTURED) && type != ptCamera;
         contained = contained && (type == ptTriangle || type == ptCylinder || (type == ptSphere && !(facts & PRIM_PROCEDURAL)) ||
                                   type == ptXYPlane || type == ptYZPlane || type == ptXZPlane);
         r[ROW_P2].w = (mat >= 0 && (size_t)mat < g.materialAverage.size()) ? g.materialAverage[mat] : 0.f;
@@ -1706,6 +1710,7 @@ void retagPrimitives()
     }
     g.sceneFeatures = features;
     g.primsContained = contained && n > 0;
+    g.opaqueShadows = opaque && n > 0;
     g.geometryDirty = true;
 }
 
@@ -1827,6 +1832,7 @@ SceneArgs makeScene(bool exactNodes)
         S.offBoxesFree = g.offBoxesFree;
         S.offLeafFree = g.offLeafFree;
         S.nbBoxesFree = g.nbBoxesFree; /* per list; the eight lists and their leaf records lie one behind the other */
+        S.opaqueShadows = g.opaqueShadows ? 1 : 0;
     }
     return S;
 }
