@@ -2822,6 +2822,12 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
         flatten(octant, outRows, outStart, nullptr, &outOrigin);
         /* skip pointers are relative: each list is self-contained */
         count = (int)(outStart.size() - before);
+        if (octant == 0)
+        {
+            outRows.reserve(16 * (size_t)count);
+            outStart.reserve(8 * (size_t)count);
+            outOrigin.reserve(8 * (size_t)count);
+        }
     }
     return count;
 }
