@@ -1394,6 +1394,13 @@ SOLR_DEV bool finiteRay(const WalkRay &r)
 }
 
 /* GI:667-772, wave-synchronous.  `active` lanes trace origin -> target. */
+/* |direction| >= 2 (and not so long that the margins of the order-free cut-off would underflow): see closestHitWalk */
+SOLR_DEV bool longRay(v3 d)
+{
+    const float dd = dot(d, d);
+    return dd >= 4.f && dd <= 1.0e24f;
+}
+
 template <bool COUNT, int FEAT>
 SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v3 origin, v3 target, int iteration,
                              int currentMaterialId, int &closestPrimitive, v3 &closestIntersection,
@@ -1421,7 +1428,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
      * inside the box, and every primitive of such a scene lies inside its leaf's box (checked at upload).  Primary
      * rays qualify (|direction| is thousands); bounce rays are unit vectors and walk the reference's order. */
     const bool freeOrder =
-        tidy && S.nbBoxesFree > 0 && ballot(active && !(dot(r.d, r.d) >= 4.f)) == 0ull;
+        tidy && S.nbBoxesFree > 0 && ballot(active && !longRay(r.d)) == 0ull;
     Scene W = S;
     if (freeOrder)
     {
@@ -1737,7 +1744,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
      * lamp's side first: for an any-hit query that measured best (mesh -5 %, molecule -2 %; the near side first
      * +10 % on the molecule: the point's own neighbourhood is where the boxes are entered and the tests miss). */
     const bool freeOrder = tidy && S.nbBoxesFree > 0 && S.opaqueShadows &&
-                           ballot(active && !(dot(r.d, r.d) >= 4.f && minDistance >= 2.f)) == 0ull;
+                           ballot(active && !(longRay(r.d) && minDistance >= 2.f)) == 0ull;
     Scene W = S;
     float farFree = 0.f;
     if (freeOrder)
