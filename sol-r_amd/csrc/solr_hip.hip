@@ -2601,6 +2601,7 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
     {
         float lo[3], hi[3];
         int left, right, axis, leaf; /* leaf: node of the input list, -1 for an inner node */
+        int depth;
         bool keep;
     };
     const int n = (int)start.size();
@@ -2632,6 +2633,7 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
     };
     std::vector<Range> todo;
     tree.push_back(TreeNode());
+    tree[0].depth = 0;
     todo.push_back({0, (int)leaves.size(), 0});
     while (!todo.empty())
     {
@@ -2642,6 +2644,7 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
         t.left = t.right = -1;
         t.axis = 0;
         t.leaf = -1;
+        t.depth = tree[r.node].depth;
         t.keep = true;
         if (count == 1)
         {
@@ -2747,6 +2750,7 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
         t.right = t.left + 1;
         tree.push_back(TreeNode());
         tree.push_back(TreeNode());
+        tree[t.left].depth = tree[t.right].depth = t.depth + 1;
         tree[r.node] = t;
         todo.push_back({r.from, mid, t.left});
         todo.push_back({mid, r.to, t.right});
@@ -2811,9 +2815,14 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
         std::vector<char> kept(tree.size(), 0);
         for (int t : survivors)
             kept[t] = 1;
+        const int wide = getenv("SOLR_HIP_FREE_WIDE") ? atoi(getenv("SOLR_HIP_FREE_WIDE")) : 0;
         for (size_t t = 0; t < tree.size(); ++t)
             if (tree[t].leaf < 0)
+            {
                 tree[t].keep = kept[t] != 0;
+                if (wide > 1 && tree[t].depth % wide != 0) /* experiment: only every wide-th level keeps its nodes */
+                    tree[t].keep = false;
+            }
     }
     int count = 0;
     for (int octant = 0; octant < 8; ++octant)
