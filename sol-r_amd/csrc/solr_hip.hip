@@ -1209,7 +1209,8 @@ struct Engine
     /* two arenas (scene_layout.h) and their host images */
     DeviceBuffer geometry, materials, textures, randoms, lamps;
     std::vector<float4> hostBoxes, hostBoxesCompact, hostPrims, hostLights;
-    std::vector<int> hostBoxStart, hostBoxStartCompact;
+    std::vector<int> hostBoxStart, hostBoxStartCompact, hostOriginCompact;
+    int freeCountdown = 0; /* renders until the order-free lists are built (0: not scheduled) */
     /* the order-free list: the leaves of the scene under a surface-area hierarchy of our own (buildFreeOrderList) */
     std::vector<float4> hostBoxesFree;
     std::vector<int> hostBoxStartFree;
@@ -1864,6 +1865,9 @@ void checkTextureTables()
     }
 }
 
+/* (defined with the list builders further down) */
+void maybeBuildOrderFreeLists();
+
 /* (defined with the RCCL layer at the end of this file) */
 void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
                        int wanted, DepthHalo *halo);
@@ -1912,6 +1916,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                       sceneInfo.cameraType == ctAnaglyph || sceneInfo.cameraType == ctPanoramic ||
                       sceneInfo.cameraType == ctVR;
     const bool exactNodes = counting || sceneInfo.renderBoxes != 0 || objects.x != g.nbBoxes || g.variant == 3;
+    maybeBuildOrderFreeLists();
     flushGeometry();
     if (exactNodes)
         refreshExactList();
@@ -2435,7 +2440,9 @@ void finalize_scene(vec2i)
     g.hostBoxStartCompact.clear();
     g.hostBoxesFree.clear();
     g.hostBoxStartFree.clear();
+    g.hostOriginCompact.clear();
     g.nbBoxesFree = 0;
+    g.freeCountdown = 0;
     g.freeStale = false;
     g.materialTags.clear();
     g.materialAverage.clear();
@@ -2841,6 +2848,107 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
     return count;
 }
 
+/* The scene has been rendered `freeCountdown` times since its upload: build the order-free lists now, from the
+ * host images of the reference's list and the primitives as they are (brought up to date first if rotations ran
+ * on the device), after checking what their use rests on - every inner node encloses its children, every leaf
+ * holds its primitives (the reference's builder makes it so, GPUKernel.cpp:741-830; another host's boxes are
+ * taken at their word only after this check; the types whose extent is not what the builder adds around p0 -
+ * cones, ellipsoids ... - are sorted out by retagPrimitives). */
+namespace
+{
+void maybeBuildOrderFreeLists()
+{
+    if (g.freeCountdown <= 0 || --g.freeCountdown > 0)
+        return;
+    PhaseTimer phase;
+    quiesce();
+    pullGeometry();
+    if (!ok())
+        return;
+    const std::vector<float4> &rows = g.hostBoxes;
+    const std::vector<int> &start = g.hostBoxStart;
+    const int n = (int)start.size();
+    if (n < 2 || rows.size() != 2 * (size_t)n)
+        return;
+    auto skipOf = [&](int i) { return std::max(bitsi(rows[2 * i + 1].w), 1); };
+    bool encloses = true;
+    for (int i = 0; i < n && encloses; ++i)
+    {
+        const int end = std::min(i + skipOf(i), n);
+        if (bitsi(rows[2 * i + 1].z) > 0 || end <= i + 1)
+            continue;
+        for (int j = i + 1; j < end && encloses; j += skipOf(j))
+            encloses = rows[2 * j].x >= rows[2 * i].x && rows[2 * j].y >= rows[2 * i].y && rows[2 * j].z >= rows[2 * i].z &&
+                       rows[2 * j + 1].x <= rows[2 * i + 1].x && rows[2 * j + 1].y <= rows[2 * i + 1].y &&
+                       rows[2 * j].w <= rows[2 * i].w;
+    }
+    const size_t nbPrims = g.hostPrims.size() / PRIM_ROWS;
+    for (int i = 0; i < n && encloses; ++i)
+    {
+        const int count = bitsi(rows[2 * i + 1].z);
+        for (int k = 0; k < count && encloses; ++k)
+        {
+            const size_t pi = (size_t)start[i] + k;
+            if (start[i] < 0 || pi >= nbPrims)
+            {
+                encloses = false;
+                break;
+            }
+            const float4 *r = &g.hostPrims[PRIM_ROWS * pi];
+            const int type = bitsi(r[ROW_P0_TYPE].w) & PRIM_TYPE_MASK;
+            float lo[3] = {r[ROW_P0_TYPE].x, r[ROW_P0_TYPE].y, r[ROW_P0_TYPE].z};
+            float hi[3] = {lo[0], lo[1], lo[2]};
+            auto add = [&](const float4 &v) {
+                lo[0] = std::min(lo[0], v.x), lo[1] = std::min(lo[1], v.y), lo[2] = std::min(lo[2], v.z);
+                hi[0] = std::max(hi[0], v.x), hi[1] = std::max(hi[1], v.y), hi[2] = std::max(hi[2], v.z);
+            };
+            float grow[3] = {r[ROW_SIZE_MAT].x, r[ROW_SIZE_MAT].y, r[ROW_SIZE_MAT].z};
+            if (type == ptTriangle)
+            {
+                add(r[ROW_P1_INDEX]);
+                add(r[ROW_P2]);
+                grow[0] = grow[1] = grow[2] = 0.f;
+            }
+            else if (type == ptCylinder)
+            {
+                add(r[ROW_P1_INDEX]);
+                grow[1] = grow[2] = grow[0];
+            }
+            else if (type == ptSphere)
+                grow[1] = grow[2] = grow[0];
+            const float eps = 1.0e-3f; /* the builder subtracts and adds in another order: an ulp of slack */
+            encloses = rows[2 * i].x <= lo[0] - fabsf(grow[0]) + eps && rows[2 * i].y <= lo[1] - fabsf(grow[1]) + eps &&
+                       rows[2 * i].z <= lo[2] - fabsf(grow[2]) + eps && rows[2 * i + 1].x >= hi[0] + fabsf(grow[0]) - eps &&
+                       rows[2 * i + 1].y >= hi[1] + fabsf(grow[1]) - eps && rows[2 * i].w >= hi[2] + fabsf(grow[2]) - eps;
+        }
+    }
+    if (!encloses)
+    {
+        if (getenv("SOLR_HIP_DEBUG_TREE"))
+            fprintf(stderr, "solr_hip: no order-free lists: a node does not hold its children or primitives\n");
+        return;
+    }
+    std::vector<int> origin(n);
+    for (int i = 0; i < n; ++i)
+        origin[i] = i;
+    std::vector<float4> boxesF;
+    std::vector<int> startF, originF;
+    int prunedFree = 0;
+    const int count = buildFreeOrderLists(rows, start, origin, boxesF, startF, originF, &prunedFree);
+    if (getenv("SOLR_HIP_DEBUG_TREE"))
+        fprintf(stderr, "solr_hip: order-free lists: 8 x %d nodes (%d inner nodes that hardly cull left out)\n", count, prunedFree);
+    if (count <= 0)
+        return;
+    g.hostBoxesFree.swap(boxesF);
+    g.hostBoxStartFree.swap(startF);
+    g.nbBoxesFree = count;
+    g.freeStale = false;
+    buildRefitPlan(g.hostBoxes, g.hostBoxesCompact, g.hostOriginCompact, g.hostBoxesFree, originF);
+    g.geometryDirty = true; /* the arena is laid out and uploaded again with the lists in it */
+    phase.mark("order-free lists");
+}
+} // namespace
+
 /* Grouping nodes.  The reference's grid builder produces wide levels - 31 sibling leaves under the root of
  * the Cornell scene, 134 top-level cells for the 100k-primitive molecule - and a walk tests every sibling
  * of every node it enters.  Here runs of CONSECUTIVE siblings are wrapped in nodes of our own whose bounds
@@ -3129,68 +3237,14 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
             startC[j] = start[i];
         }
 
-    /* the order-free list, from the leaves of the collapsed list (every inner node of which must enclose its
-     * children: the walk that uses it relies on a leaf being reachable whenever its own test passes) */
+    /* the order-free lists are built when the scene has stayed for a frame (maybeBuildOrderFreeLists): a host that
+     * uploads the scene again for every frame - the reference's own way of animating - never pays for them */
     std::vector<float4> boxesF;
     std::vector<int> startF, originF;
-    int nbFreeNodes = 0;
+    const int nbFreeNodes = 0;
+    g.freeCountdown = 0;
     if (g.nested && g.orderedCompact && nc > 1 && g.grouping && !getenv("SOLR_HIP_NO_FREE_ORDER"))
-    {
-        bool encloses = true;
-        for (int i = 0; i < nc && encloses; ++i)
-        {
-            const int end = std::min(i + std::max(bitsi(boxesC[2 * i + 1].w), 1), nc);
-            if (bitsi(boxesC[2 * i + 1].z) > 0 || end <= i + 1)
-                continue;
-            for (int j = i + 1; j < end && encloses; j += std::max(bitsi(boxesC[2 * j + 1].w), 1))
-                encloses = boxesC[2 * j].x >= boxesC[2 * i].x && boxesC[2 * j].y >= boxesC[2 * i].y &&
-                           boxesC[2 * j].z >= boxesC[2 * i].z && boxesC[2 * j + 1].x <= boxesC[2 * i + 1].x &&
-                           boxesC[2 * j + 1].y <= boxesC[2 * i + 1].y && boxesC[2 * j].w <= boxesC[2 * i].w;
-        }
-        /* ... and every leaf must hold its primitives (the reference's builder makes it so, GPUKernel.cpp:741-830;
-         * another host's boxes are taken at their word only after this check).  The types whose extent is not
-         * what the builder adds around p0 - cones, ellipsoids ... - are sorted out by retagPrimitives. */
-        for (int i = 0; i < nc && encloses; ++i)
-        {
-            const int count = bitsi(boxesC[2 * i + 1].z);
-            for (int k = 0; k < count && encloses; ++k)
-            {
-                const Primitive &p = primitives[startC[i] + k];
-                float lo[3] = {p.p0.x, p.p0.y, p.p0.z}, hi[3] = {p.p0.x, p.p0.y, p.p0.z};
-                auto add = [&](const vec3f &v) {
-                    lo[0] = std::min(lo[0], v.x), lo[1] = std::min(lo[1], v.y), lo[2] = std::min(lo[2], v.z);
-                    hi[0] = std::max(hi[0], v.x), hi[1] = std::max(hi[1], v.y), hi[2] = std::max(hi[2], v.z);
-                };
-                float grow[3] = {p.size.x, p.size.y, p.size.z};
-                if (p.type == ptTriangle)
-                {
-                    add(p.p1);
-                    add(p.p2);
-                    grow[0] = grow[1] = grow[2] = 0.f;
-                }
-                else if (p.type == ptCylinder)
-                {
-                    add(p.p1);
-                    grow[1] = grow[2] = p.size.x;
-                }
-                else if (p.type == ptSphere)
-                    grow[1] = grow[2] = p.size.x;
-                const float eps = 1.0e-3f; /* the builder subtracts and adds in another order: an ulp of slack */
-                encloses = boxesC[2 * i].x <= lo[0] - fabsf(grow[0]) + eps && boxesC[2 * i].y <= lo[1] - fabsf(grow[1]) + eps &&
-                           boxesC[2 * i].z <= lo[2] - fabsf(grow[2]) + eps && boxesC[2 * i + 1].x >= hi[0] + fabsf(grow[0]) - eps &&
-                           boxesC[2 * i + 1].y >= hi[1] + fabsf(grow[1]) - eps && boxesC[2 * i].w >= hi[2] + fabsf(grow[2]) - eps;
-            }
-        }
-        if (encloses)
-        {
-            int prunedFree = 0;
-            nbFreeNodes = buildFreeOrderLists(boxesC, startC, originC, boxesF, startF, originF, &prunedFree);
-            if (getenv("SOLR_HIP_DEBUG_TREE"))
-                fprintf(stderr, "solr_hip: order-free lists: 8 x %d nodes (%d inner nodes that hardly cull left out)\n",
-                        nbFreeNodes, prunedFree);
-        }
-        phase.mark("h2d_scene: order-free list");
-    }
+        g.freeCountdown = std::max(1, getenv("SOLR_HIP_FREE_AFTER") ? atoi(getenv("SOLR_HIP_FREE_AFTER")) : 2);
 
     int nbWalkNodes = nc, prunedBefore = 0, prunedAfter = 0;
     if (g.nested && g.orderedCompact && nc > 0 && g.grouping)
@@ -3239,6 +3293,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     g.hostBoxesCompact.swap(boxesC);
     g.hostBoxStart.swap(start);
     g.hostBoxStartCompact.swap(startC);
+    g.hostOriginCompact = originC;
     g.hostBoxesFree.swap(boxesF);
     g.hostBoxStartFree.swap(startF);
     g.nbBoxesFree = nbFreeNodes;

@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The engine builds its order-free node lists when a scene has stayed for a frame (a host that uploads the scene
+    # again for every frame never pays for them).  Most tests render one frame of a scene: here the lists are built
+    # with the first frame, so that every parity test also holds the order-free walks to the oracle;
+    # tests/test_gpu_parity.py::test_order_free_lists_arrive_with_the_second_frame covers the default.
+    os.environ.setdefault("SOLR_HIP_FREE_AFTER", "1")
 
 
 @pytest.fixture(scope="session")

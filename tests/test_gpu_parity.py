@@ -770,3 +770,29 @@ def test_order_free_walk_resolves_ties_as_the_reference_does(solr, oracle):
         hip.solr_hip_set_variant(0)
     assert np.array_equal(frames[0][1], frames[1][1]) and np.array_equal(frames[0][2], frames[1][2])
     assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
+
+
+def test_order_free_lists_arrive_with_the_second_frame(solr, oracle):
+    """the default: the first frame after an upload walks the reference's order everywhere, the lists are built
+    before the second (SOLR_HIP_FREE_AFTER, 2 unless set) - and nobody can tell from the frames"""
+    import os
+    hip = solr.hip_lib()
+    saved = os.environ.pop("SOLR_HIP_FREE_AFTER", None)
+    try:
+        k = solr.Kernel(engine="hip")
+        solr.scenes.molecule(k, atoms=300, width=160, height=120)
+        first = gpu_frame(k)
+        assert hip.solr_hip_order_free_nodes() == 0
+        second = gpu_frame(k)
+        assert hip.solr_hip_order_free_nodes() > 0
+        third = gpu_frame(k)
+        opp, oids, orgb, _, status = oracle_frame(k, oracle)
+        assert status == 0
+        assert_parity(compare_frames(first[0], first[1], first[2], opp, oids, orgb))
+        for frame in (second, third):
+            assert np.array_equal(frame[0].view(np.uint32), first[0].view(np.uint32))
+            assert np.array_equal(frame[1], first[1]) and np.array_equal(frame[2], first[2])
+        k.finalize()
+    finally:
+        if saved is not None:
+            os.environ["SOLR_HIP_FREE_AFTER"] = saved

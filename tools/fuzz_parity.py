@@ -1,6 +1,7 @@
 """Development aid: random scenes, HIP engine vs CPU oracle.  Prints every scene whose frame is not within the
 parity bar (ids exact, colour <= 1 ULP, RGB8 within 1)."""
 import os, sys, importlib
+os.environ.setdefault("SOLR_HIP_FREE_AFTER", "1")   # one frame per scene: build the order-free lists with it
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 solr = importlib.import_module("sol-r_amd")
