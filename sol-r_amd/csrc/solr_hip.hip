@@ -821,6 +821,30 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
         }
         __syncthreads();
     }
+    /* Steady taps.  (int)(x + t) - x is the same for every x of the tile when x and all the sums x + t lie in one
+     * binade: x is a multiple of that binade's ulp U (a power of two below 1, so x / U is even and ties round the
+     * same way), hence RN(x + t) = x + RN_U(t), and the sums are positive, so the truncation is a floor.  Then a
+     * tap is ONE integer offset into the window for the whole tile - evaluated here once per tap, on the tile's
+     * first column and row, with the reference's own expression - and the 256 comparisons of a pixel are an add,
+     * a read and a compare each.  Tiles that straddle a power of two in x or in the frame's y, or whose window
+     * leaves the frame, take the per-pixel evaluation below. */
+    __shared__ int tapOffset[256];
+    bool steady = false;
+    if (tiled)
+    {
+        const int xlo = x0 - rx, xhi = x0 + AO_TILE_W - 1 + rx;
+        const int ylo = y0 + firstRow - ry, yhi = y0 + firstRow + AO_TILE_H - 1 + ry;
+        steady = wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow && xlo >= 1 &&
+                 ylo >= 1 && __clz(xlo) == __clz(xhi) && __clz(ylo) == __clz(yhi);
+        if (steady)
+        {
+            const int i = threadIdx.x;
+            const int dx = (int)((float)x0 + tapX[i]) - x0;
+            const int dy = (int)((float)(y0 + firstRow) + tapY[i]) - (y0 + firstRow);
+            tapOffset[i] = dy * ww + dx;
+            __syncthreads();
+        }
+    }
     const int x = x0 + (int)(threadIdx.x % AO_TILE_W);
     const int y = y0 + (int)(threadIdx.x / AO_TILE_W);
     if (x >= W || y >= nbRows)
@@ -840,7 +864,14 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
         const int origin = -((wy0 + firstRow) * ww + wx0);
         const float fx = (float)x, fy = (float)(y + firstRow);
         int count = 0;
-        if (inside)
+        if (steady)
+        {
+            const float *centre = window + ((y - wy0) * ww + (x - wx0));
+#pragma unroll 16
+            for (int i = 0; i < 256; ++i)
+                count += (centre[tapOffset[i]] >= depth) ? 1 : 0;
+        }
+        else if (inside)
         {
 #pragma unroll 8
             for (int i = 0; i < 256; ++i)
