@@ -2896,6 +2896,7 @@ void maybeBuildOrderFreeLists()
     pullGeometry();
     if (!ok())
         return;
+    phase.mark("order-free: host images");
     const std::vector<float4> &rows = g.hostBoxes;
     const std::vector<int> &start = g.hostBoxStart;
     const int n = (int)start.size();
@@ -2959,6 +2960,7 @@ void maybeBuildOrderFreeLists()
             fprintf(stderr, "solr_hip: no order-free lists: a node does not hold its children or primitives\n");
         return;
     }
+    phase.mark("order-free: checks");
     std::vector<int> origin(n);
     for (int i = 0; i < n; ++i)
         origin[i] = i;
@@ -2970,13 +2972,14 @@ void maybeBuildOrderFreeLists()
         fprintf(stderr, "solr_hip: order-free lists: 8 x %d nodes (%d inner nodes that hardly cull left out)\n", count, prunedFree);
     if (count <= 0)
         return;
+    phase.mark("order-free: tree, pruning, eight flattenings");
     g.hostBoxesFree.swap(boxesF);
     g.hostBoxStartFree.swap(startF);
     g.nbBoxesFree = count;
     g.freeStale = false;
     buildRefitPlan(g.hostBoxes, g.hostBoxesCompact, g.hostOriginCompact, g.hostBoxesFree, originF);
     g.geometryDirty = true; /* the arena is laid out and uploaded again with the lists in it */
-    phase.mark("order-free lists");
+    phase.mark("order-free: refit plan");
 }
 } // namespace
 
