@@ -2862,18 +2862,53 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
                     tree[t].keep = false;
             }
     }
-    int count = 0;
+    /* the eight lists: every node's place follows from the sizes of the subtrees before it (children are stored
+     * behind their parent in `tree`, so one backward pass gives the sizes); skip pointers are relative, each list
+     * is self-contained */
+    std::vector<int> size(tree.size(), 0);
+    for (int t = (int)tree.size() - 1; t >= 0; --t)
+        size[t] = tree[t].leaf >= 0 ? 1 : (tree[t].keep ? 1 : 0) + size[tree[t].left] + size[tree[t].right];
+    const int count = size[0];
+    outRows.assign(16 * (size_t)count, make_float4(0.f, 0.f, 0.f, 0.f));
+    outStart.assign(8 * (size_t)count, 0);
+    outOrigin.assign(8 * (size_t)count, -1);
+    struct Place
+    {
+        int node, at;
+    };
+    std::vector<Place> stack;
     for (int octant = 0; octant < 8; ++octant)
     {
-        const size_t before = outStart.size();
-        flatten(octant, outRows, outStart, nullptr, &outOrigin);
-        /* skip pointers are relative: each list is self-contained */
-        count = (int)(outStart.size() - before);
-        if (octant == 0)
+        float4 *fr = outRows.data() + 2 * (size_t)octant * count;
+        int *fs = outStart.data() + (size_t)octant * count, *fo = outOrigin.data() + (size_t)octant * count;
+        stack.clear();
+        stack.push_back({0, 0});
+        while (!stack.empty())
         {
-            outRows.reserve(16 * (size_t)count);
-            outStart.reserve(8 * (size_t)count);
-            outOrigin.reserve(8 * (size_t)count);
+            const Place v = stack.back();
+            stack.pop_back();
+            const TreeNode &t = tree[v.node];
+            if (t.leaf >= 0)
+            {
+                fr[2 * v.at] = rows[2 * t.leaf];
+                float4 second = rows[2 * t.leaf + 1];
+                second.w = bitsf(1);
+                fr[2 * v.at + 1] = second;
+                fs[v.at] = start[t.leaf];
+                fo[v.at] = origin[t.leaf]; /* the node of the reference's list this leaf is */
+                continue;
+            }
+            int at = v.at;
+            if (t.keep)
+            {
+                fr[2 * at] = make_float4(t.lo[0], t.lo[1], t.lo[2], t.hi[2]);
+                fr[2 * at + 1] = make_float4(t.hi[0], t.hi[1], bitsf(0), bitsf(size[v.node]));
+                ++at;
+            }
+            const bool highFirst = (octant >> t.axis) & 1; /* direction negative along the split axis */
+            const int first = highFirst ? t.right : t.left, second = highFirst ? t.left : t.right;
+            stack.push_back({second, at + size[first]});
+            stack.push_back({first, at});
         }
     }
     return count;
