@@ -268,7 +268,8 @@ int solr_hip_get_variant(void);
  *   solr_hip_device_rotations   how many requests were served since initialize_scene;
  *   solr_hip_read_nodes / _primitives   the resident records, for tests (float4 rows: 2 per node in the
  *                               layout of sol-r_amd/csrc/scene_layout.h, 8 per primitive); they return the
- *                               number of rows, with rows == NULL only that. */
+ *                               number of rows, with rows == NULL only that.  `exact`: 1 the reference's
+ *                               list, 0 the walk-order list, 2 ... 9 the order-free list of octant exact - 2. */
 void solr_hip_set_movable(const unsigned char *flags, int nbPrimitives);
 int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], const float sinAngles[3],
                                float viewDistance);

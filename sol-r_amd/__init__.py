@@ -413,13 +413,15 @@ class Kernel:
     def sync_host(self):
         self.L.SolRx_SyncHost()
 
-    def device_nodes(self, exact=True):
+    def device_nodes(self, exact=True, order_free=None):
         """The resident node records (n, 2, 4) float32 as the device holds them now: the reference's
-        node list (exact) or the engine's walk-order list."""
+        node list (exact), the engine's walk-order list, or its order-free list of octant `order_free`
+        (0 ... 7; empty when there are none)."""
         hip = hip_lib()
-        cap = hip.solr_hip_read_nodes(1 if exact else 0, None, 0)
+        which = (2 + order_free) if order_free is not None else (1 if exact else 0)
+        cap = hip.solr_hip_read_nodes(which, None, 0)
         buf = np.zeros((max(cap, 1), 4), np.float32)
-        if cap < 0 or hip.solr_hip_read_nodes(1 if exact else 0, buf.ctypes.data, cap) != cap:
+        if cap < 0 or hip.solr_hip_read_nodes(which, buf.ctypes.data, cap) != cap:
             raise SolrError("solr_hip_read_nodes failed")
         return buf[:cap].reshape(-1, 2, 4)
 

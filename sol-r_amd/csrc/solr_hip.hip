@@ -3468,14 +3468,20 @@ int solr_hip_read_nodes(int exact, float *rows, int capacityRows)
     if (exact)
         refreshExactList();
     quiesce();
-    const int n = 2 * (exact ? g.nbBoxes : g.nbBoxesCompact);
+    int n = 2 * (exact ? g.nbBoxes : g.nbBoxesCompact);
+    unsigned at = exact ? g.offBoxes : g.offBoxesCompact;
+    if (exact >= 2) /* 2 ... 9: the order-free list of octant exact - 2 (0 rows when there are none) */
+    {
+        const bool have = exact <= 9 && g.nbBoxesFree > 0 && !g.freeStale && g.hostBoxesFree.size() == 16 * (size_t)g.nbBoxesFree;
+        n = have ? 2 * g.nbBoxesFree : 0;
+        at = g.offBoxesFree + 2u * (unsigned)((exact - 2) * g.nbBoxesFree);
+    }
     if (!rows)
         return n; /* size query */
     if (n > capacityRows)
         return -1;
     if (n)
-        HIPCHECK(hipMemcpy(rows, (const char *)g.geometry.ptr + (size_t)(exact ? g.offBoxes : g.offBoxesCompact) * 16,
-                           (size_t)n * 16, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(rows, (const char *)g.geometry.ptr + (size_t)at * 16, (size_t)n * 16, hipMemcpyDeviceToHost));
     return ok() ? n : -1;
 }
 

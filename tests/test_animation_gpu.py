@@ -260,3 +260,52 @@ def test_long_animation_is_fetched_not_replayed(solr, spec):
     eager = h.flat_scene()
     h.finalize()
     assert _same_records(fetched.boxes, eager.boxes) and _same_records(fetched.primitives, eager.primitives)
+
+
+def _list_invariants(nodes):
+    """nested skip pointers; every inner node holds the nodes of its subtree; returns the leaves' rows"""
+    n = nodes.shape[0]
+    count = nodes[:, 1, 2].view(np.int32)
+    skip = nodes[:, 1, 3].view(np.int32)
+    lo = nodes[:, 0, :3]
+    hi = np.stack([nodes[:, 1, 0], nodes[:, 1, 1], nodes[:, 0, 3]], axis=1)
+    assert (skip >= 1).all() and (np.arange(n) + skip <= n).all()
+    stack = []
+    for i in range(n):
+        while stack and i >= stack[-1] + skip[stack[-1]]:
+            stack.pop()
+        if stack:
+            p = stack[-1]
+            assert i + skip[i] <= p + skip[p], "skip pointers are not nested"
+            assert (lo[i] >= lo[p]).all() and (hi[i] <= hi[p]).all(), "node %d is not inside node %d" % (i, p)
+        assert (count[i] > 0) == (skip[i] == 1) or count[i] == 0
+        stack.append(i)
+    return nodes[count > 0]
+
+
+@pytest.mark.parametrize("spec", [s for s in SCENES if s[0] in ("molecule", "height_field", "cornell")], ids=lambda s: s[0])
+def test_order_free_lists_are_eight_orders_of_one_hierarchy(solr, spec):
+    """the eight order-free lists hold the same leaves - those of the reference's list, bit for bit - under nodes
+    that hold their subtrees, before and after rotations on the device (refitted in place)"""
+    k = _build(solr, spec, "hip")
+    gpu_frame(k)
+    hip = solr.hip_lib()
+    assert hip.solr_hip_order_free_nodes() > 0
+    for round_ in range(2):
+        exact = k.device_nodes(exact=True)
+        reference_leaves = exact[exact[:, 1, 2].view(np.int32) > 0]
+        reference_leaves = reference_leaves[:, :, :].copy()
+        reference_leaves[:, 1, 3] = np.int32(1).view(np.float32)
+        want = np.sort(np.ascontiguousarray(reference_leaves).view(np.uint32).reshape(len(reference_leaves), -1), axis=0)
+        sizes = set()
+        for octant in range(8):
+            nodes = k.device_nodes(order_free=octant)
+            sizes.add(nodes.shape[0])
+            leaves = _list_invariants(nodes)
+            got = np.sort(np.ascontiguousarray(leaves).view(np.uint32).reshape(len(leaves), -1), axis=0)
+            assert got.shape == want.shape and np.array_equal(got, want), "octant %d holds other leaves" % octant
+        assert len(sizes) == 1
+        for center, angles in STEPS[:2]:
+            k.rotate_primitives(center, angles)
+        gpu_frame(k)
+    k.finalize()
