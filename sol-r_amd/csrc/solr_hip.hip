@@ -3514,8 +3514,11 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
      * active ones) so that every id a primitive or the box-debug view can
      * produce stays inside the allocation */
     const int capacity = NB_MAX_MATERIALS + 1;
-    std::vector<MaterialHot> hot(capacity);
-    std::vector<MaterialCold> cold(capacity);
+    const int active = std::min(nbActiveMaterials, capacity);
+    /* (only the active records are built and copied: the 12.6 MB of the full table took 10 ms per call, and the
+     * reference's hosts call this whenever one material changes) */
+    std::vector<MaterialHot> hot((size_t)std::max(active, 1));
+    std::vector<MaterialCold> cold((size_t)std::max(active, 1));
     memset(hot.data(), 0, hot.size() * sizeof(MaterialHot));
     memset(cold.data(), 0, cold.size() * sizeof(MaterialCold));
     g.materialTags.assign(capacity, PRIM_FAST0 | (1 << PRIM_WIDTH_SHIFT));
@@ -3573,10 +3576,31 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
         c.pad = make_float2(0.f, 0.f);
     }
     HIPCHECK(hipSetDevice(g.device));
-    std::vector<float4> arena(12 * (size_t)capacity);
-    memcpy(arena.data(), hot.data(), hot.size() * sizeof(MaterialHot));
-    memcpy(arena.data() + 6 * (size_t)capacity, cold.data(), cold.size() * sizeof(MaterialCold));
-    upload(g.materials, arena);
+    const size_t tableBytes = 12 * (size_t)capacity * sizeof(float4);
+    const bool fresh = !g.materials.ptr || g.materials.bytes < tableBytes;
+    reserve(g.materials, tableBytes);
+    if (!ok())
+        return;
+    char *table = (char *)g.materials.ptr;
+    const size_t coldAt = 6 * (size_t)capacity * sizeof(float4);
+    /* zeros beyond the active records: the whole table when it is new, else what the last call left behind */
+    const int stale = fresh ? capacity : std::min(std::max(g.nbMaterials, 0), capacity);
+    if (fresh)
+        HIPCHECK(hipMemsetAsync(table, 0, tableBytes, g.stream));
+    else if (stale > active)
+    {
+        HIPCHECK(hipMemsetAsync(table + (size_t)active * sizeof(MaterialHot), 0, (size_t)(stale - active) * sizeof(MaterialHot),
+                                g.stream));
+        HIPCHECK(hipMemsetAsync(table + coldAt + (size_t)active * sizeof(MaterialCold), 0,
+                                (size_t)(stale - active) * sizeof(MaterialCold), g.stream));
+    }
+    if (active > 0)
+    {
+        HIPCHECK(hipMemcpyAsync(table, hot.data(), (size_t)active * sizeof(MaterialHot), hipMemcpyHostToDevice, g.stream));
+        HIPCHECK(hipMemcpyAsync(table + coldAt, cold.data(), (size_t)active * sizeof(MaterialCold), hipMemcpyHostToDevice,
+                                g.stream));
+    }
+    HIPCHECK(hipStreamSynchronize(g.stream)); /* pageable sources: complete for the caller when this returns */
     if (ok())
     {
         g.offMatCold = 6u * (unsigned)capacity;
