@@ -2935,7 +2935,7 @@ void maybeBuildOrderFreeLists()
     const std::vector<float4> &rows = g.hostBoxes;
     const std::vector<int> &start = g.hostBoxStart;
     const int n = (int)start.size();
-    if (n < 2 || rows.size() != 2 * (size_t)n)
+    if (n < 2 || rows.size() != 2 * (size_t)n || n > 16000000) /* (beyond that the eight lists pass a dozen GB) */
         return;
     auto skipOf = [&](int i) { return std::max(bitsi(rows[2 * i + 1].w), 1); };
     bool encloses = true;
