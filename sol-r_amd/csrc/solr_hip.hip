@@ -2704,65 +2704,78 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
                 clo[k] = std::min(clo[k], c);
                 chi[k] = std::max(chi[k], c);
             }
-        /* binned surface-area split */
+        /* binned surface-area split: one pass over the leaves fills the bins of all three axes */
         const int BINS = 16;
         int bestAxis = -1, bestBin = 0;
         double bestCost = 1e300;
-        for (int axis = 0; axis < 3; ++axis)
         {
-            const float extent = chi[axis] - clo[axis];
-            if (!(extent > 0.f))
-                continue;
-            int counts[BINS] = {0};
-            float blo[BINS][3], bhi[BINS][3];
-            for (int b = 0; b < BINS; ++b)
-                for (int k = 0; k < 3; ++k)
-                    blo[b][k] = 1e30f, bhi[b][k] = -1e30f;
-            const float scale = BINS / extent;
+            int counts[3][BINS];
+            float blo[3][BINS][3], bhi[3][BINS][3];
+            float scale[3];
+            for (int axis = 0; axis < 3; ++axis)
+            {
+                const float extent = chi[axis] - clo[axis];
+                scale[axis] = extent > 0.f ? BINS / extent : 0.f;
+                for (int b = 0; b < BINS; ++b)
+                {
+                    counts[axis][b] = 0;
+                    for (int k = 0; k < 3; ++k)
+                        blo[axis][b][k] = 1e30f, bhi[axis][b][k] = -1e30f;
+                }
+            }
             for (int q = r.from; q < r.to; ++q)
             {
-                const float c = 0.5f * (leaves[q].lo[axis] + leaves[q].hi[axis]);
-                const int b = std::min(BINS - 1, std::max(0, (int)((c - clo[axis]) * scale)));
-                ++counts[b];
-                for (int k = 0; k < 3; ++k)
+                const Leaf &l = leaves[q];
+                for (int axis = 0; axis < 3; ++axis)
                 {
-                    blo[b][k] = std::min(blo[b][k], leaves[q].lo[k]);
-                    bhi[b][k] = std::max(bhi[b][k], leaves[q].hi[k]);
+                    if (!(scale[axis] > 0.f))
+                        continue;
+                    const float c = 0.5f * (l.lo[axis] + l.hi[axis]);
+                    const int b = std::min(BINS - 1, std::max(0, (int)((c - clo[axis]) * scale[axis])));
+                    ++counts[axis][b];
+                    float *lo3 = blo[axis][b], *hi3 = bhi[axis][b];
+                    lo3[0] = std::min(lo3[0], l.lo[0]), lo3[1] = std::min(lo3[1], l.lo[1]), lo3[2] = std::min(lo3[2], l.lo[2]);
+                    hi3[0] = std::max(hi3[0], l.hi[0]), hi3[1] = std::max(hi3[1], l.hi[1]), hi3[2] = std::max(hi3[2], l.hi[2]);
                 }
             }
-            double rightArea[BINS];
-            int rightCount[BINS];
-            float rlo[3] = {1e30f, 1e30f, 1e30f}, rhi[3] = {-1e30f, -1e30f, -1e30f};
-            int rc = 0;
-            for (int b = BINS - 1; b > 0; --b)
+            for (int axis = 0; axis < 3; ++axis)
             {
-                rc += counts[b];
-                for (int k = 0; k < 3; ++k)
-                {
-                    rlo[k] = std::min(rlo[k], blo[b][k]);
-                    rhi[k] = std::max(rhi[k], bhi[b][k]);
-                }
-                rightCount[b] = rc;
-                rightArea[b] = rc ? area(rlo, rhi) : 0.0;
-            }
-            float llo[3] = {1e30f, 1e30f, 1e30f}, lhi[3] = {-1e30f, -1e30f, -1e30f};
-            int lc = 0;
-            for (int b = 0; b + 1 < BINS; ++b)
-            {
-                lc += counts[b];
-                for (int k = 0; k < 3; ++k)
-                {
-                    llo[k] = std::min(llo[k], blo[b][k]);
-                    lhi[k] = std::max(lhi[k], bhi[b][k]);
-                }
-                if (lc == 0 || rightCount[b + 1] == 0)
+                if (!(scale[axis] > 0.f))
                     continue;
-                const double cost = area(llo, lhi) * lc + rightArea[b + 1] * rightCount[b + 1];
-                if (cost < bestCost)
+                double rightArea[BINS];
+                int rightCount[BINS];
+                float rlo[3] = {1e30f, 1e30f, 1e30f}, rhi[3] = {-1e30f, -1e30f, -1e30f};
+                int rc = 0;
+                for (int b = BINS - 1; b > 0; --b)
                 {
-                    bestCost = cost;
-                    bestAxis = axis;
-                    bestBin = b;
+                    rc += counts[axis][b];
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        rlo[k] = std::min(rlo[k], blo[axis][b][k]);
+                        rhi[k] = std::max(rhi[k], bhi[axis][b][k]);
+                    }
+                    rightCount[b] = rc;
+                    rightArea[b] = rc ? area(rlo, rhi) : 0.0;
+                }
+                float llo[3] = {1e30f, 1e30f, 1e30f}, lhi[3] = {-1e30f, -1e30f, -1e30f};
+                int lc = 0;
+                for (int b = 0; b + 1 < BINS; ++b)
+                {
+                    lc += counts[axis][b];
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        llo[k] = std::min(llo[k], blo[axis][b][k]);
+                        lhi[k] = std::max(lhi[k], bhi[axis][b][k]);
+                    }
+                    if (lc == 0 || rightCount[b + 1] == 0)
+                        continue;
+                    const double cost = area(llo, lhi) * lc + rightArea[b + 1] * rightCount[b + 1];
+                    if (cost < bestCost)
+                    {
+                        bestCost = cost;
+                        bestAxis = axis;
+                        bestBin = b;
+                    }
                 }
             }
         }
