@@ -309,3 +309,32 @@ def test_order_free_lists_are_eight_orders_of_one_hierarchy(solr, spec):
             k.rotate_primitives(center, angles)
         gpu_frame(k)
     k.finalize()
+
+
+def test_order_free_lists_built_between_rotations(solr, oracle):
+    """the default timing: the lists are built before the second frame after an upload - here after the first
+    rotation ran on the device, i.e. from host images that are fetched back first - and refitted by the next one;
+    every frame is the one a fresh upload of the rotated scene renders"""
+    hip = solr.hip_lib()
+    saved = os.environ.pop("SOLR_HIP_FREE_AFTER", None)
+    try:
+        spec = SCENES[0]
+        k = _build(solr, spec, "hip")
+        gpu_frame(k)
+        assert hip.solr_hip_order_free_nodes() == 0
+        frames = []
+        for n, (center, angles) in enumerate(STEPS[:3]):
+            k.rotate_primitives(center, angles)
+            assert k.pending_rotations() == n + 1
+            frames.append(gpu_frame(k))
+            assert hip.solr_hip_order_free_nodes() > 0
+        k.flat_scene()                              # the host store replays the rotations
+        assert k.pending_rotations() == 0
+        fresh = gpu_frame(k)                        # a fresh upload of the rotated scene
+        k.finalize()
+        pp, ids, rgb = frames[-1]
+        res = compare_frames(pp, ids, rgb, fresh[0], fresh[1], fresh[2])
+        assert res["ids_all_equal"] and res["max_ulp"] == 0 and res["rgb_max_diff"] == 0, res
+    finally:
+        if saved is not None:
+            os.environ["SOLR_HIP_FREE_AFTER"] = saved
