@@ -1429,13 +1429,39 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
      * rays qualify (|direction| is thousands); bounce rays are unit vectors and walk the reference's order. */
     const bool freeOrder =
         tidy && S.nbBoxesFree > 0 && ballot(active && !longRay(r.d)) == 0ull;
+    /* Unit-length rays (the bounce rays) in the order-free lists, CHECKED.  For |direction| = 1 the reference's
+     * cut-off is a distance cut-off, exact up to rounding: which primitive wins can then depend on the order of
+     * the leaves when two candidates - or a candidate and the initial bound - lie within rounding of each other,
+     * and only then.  So the walk runs order-free with a margin of 1e-3 (a thousand times the rounding), keeps the
+     * second smallest distance it met, accepts nothing within 2e-3 of the initial bound, and afterwards the lanes
+     * whose best hit has a rival within the margin (or lies in that band) are walked again in the reference's
+     * order - they find a hit there if they found one here (a candidate outside the band passes the reference's
+     * cut-off against the initial bound), so nothing needs restoring.  For every other lane the minimum is unique
+     * by a margin no rounding bridges, and the reference, whose cut-off cannot hide it from any larger bound,
+     * returns it.  Only in the long-list triangle instantiations (the mesh's bounce rays along the terrain were
+     * its longest waves: one frame alone 0.435 -> 0.417 ms); compiled into every kernel it costs the Cornell box
+     * 3 % and the molecule 0.7 % (short lists, few bounce rays, the bookkeeping in every accept). */
+    constexpr bool CHECKED_BUILD = !COUNT && (FEAT & F_DEEP) != 0 && (FEAT & F_TRI) != 0;
+    const float dd = dot(r.d, r.d);
+    const bool unitRays = CHECKED_BUILD && tidy && S.nbBoxesFree > 0 && !freeOrder &&
+                          ballot(active && !(dd >= 0.9998f && dd < 4.f)) == 0ull;
+    const float initialDistance = minDistance;
+    const float slack = 1.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
+    const float bandStart = initialDistance * (1.f - 2.0e-3f) - 2.f * slack;
+    float second = INFINITY;
+    bool bandHit = false;
+    bool lanesNow = active;
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+    const bool checked = unitRays && attempt == 0;
+    const bool freeList = freeOrder || checked;
     Scene W = S;
-    if (freeOrder)
+    if (freeList)
     {
         /* eight flattenings of the same hierarchy, the near child first for a direction of that sign octant: the
          * wave takes the octant of its first active lane (any list gives the same result) */
         const int signs = (r.d.x < 0.f ? 1 : 0) | (r.d.y < 0.f ? 2 : 0) | (r.d.z < 0.f ? 4 : 0);
-        const int lane = (int)__builtin_ctzll(ballot(active));
+        const int lane = (int)__builtin_ctzll(ballot(lanesNow));
         const int octant = __builtin_amdgcn_readlane(signs, lane);
         W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
         W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
@@ -1447,16 +1473,24 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
      * of both sides: 2e-4 of the distance for the computed hit distance and the products, 1e-4 of the origin's
      * coordinates for the cancellation in (bound - origin) - a thousand times the half-ulp that subtraction can
      * lose.  With the near child first this is what ends a walk early. */
-    const float invLength = freeOrder ? 1.f / length(r.d) : 1.f;
-    const float farScale = freeOrder ? 1.0002f * invLength : 1.f;
-    const float farOffset = freeOrder ? 1.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z)) * invLength : 0.f;
+    const float invLength = freeList ? 1.f / length(r.d) : 1.f;
+    const float farScale = freeList ? (checked ? 1.001f : 1.0002f) * invLength : 1.f;
+    const float farOffset = freeList ? slack * invLength : 0.f;
     int tieIndex = -1; /* the primitive that holds minDistance */
     auto closer = [&](float distance, int pi) {
-        return distance < minDistance || (freeOrder && distance == minDistance && pi < tieIndex);
+        bool better = distance < minDistance || (freeOrder && distance == minDistance && pi < tieIndex);
+        if (checked)
+        {
+            const bool inBand = distance >= bandStart;
+            bandHit = bandHit || inBand;
+            better = better && !inBand;
+            second = fminf(second, better ? minDistance : distance);
+        }
+        return better;
     };
     const PackedRay pr = packRay(r);
     const int nbBoxes = W.nbBoxes;
-    int cursor = active ? 0 : SOLR_CURSOR_DONE;
+    int cursor = lanesNow ? 0 : SOLR_CURSOR_DONE;
     int cur = 0;
     Row2 node;
     node.a = node.b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1469,7 +1503,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         SOLR_T(unsigned long long ta = SOLR_NOW();)
         if (tidy)
         {
-            leaf = advanceTidy<FEAT>(W, pr, freeOrder ? minDistance * farScale + farOffset : minDistance, cursor, cur,
+            leaf = advanceTidy<FEAT>(W, pr, freeList ? minDistance * farScale + farOffset : minDistance, cursor, cur,
                                      nbPrimitives, entered);
             SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)
             if (leaf < 0)
@@ -1708,6 +1742,16 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             }
         }
         SOLR_T(cnt.tLeaf += SOLR_NOW() - ta; ++cnt.nLeaf;)
+    }
+    if (!checked)
+        break;
+    /* the lanes whose result the order could have decided: once more, in the reference's order */
+    const bool again = lanesNow && (intersections ? !(second > minDistance * 1.001f + slack) : bandHit);
+    if (ballot(again) == 0ull)
+        break;
+    lanesNow = again;
+    minDistance = again ? initialDistance : minDistance;
+    intersections = again ? false : intersections;
     }
     SOLR_T(cnt.tClosest += SOLR_NOW() - tw0;)
     return intersections;

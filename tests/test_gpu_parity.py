@@ -710,14 +710,18 @@ def test_ambient_occlusion_on_a_strip_reads_the_neighbours_rows(solr, oracle):
         k.finalize()
 
 
-def _tie_scene(k, width=160, height=120, **info):
+def _tie_scene(k, width=160, height=120, mirror=False, **info):
     """Primitives that tie: every sphere, triangle and cylinder is in the scene twice (and once more with another
     material), at the same place - equal hit distances bit for bit.  The reference keeps the one it visits
     first; which one that is follows from its flatten order, not from the order of insertion."""
     rng = solr_mod.scenes.LCG(11)
-    k.initialize(width=width, height=height, nbRayIterations=2, **info)
+    k.initialize(width=width, height=height, nbRayIterations=3 if mirror else 2, **info)
     mats = [k.add_material(0.9, 0.2, 0.2, specValue=0.3, specPower=40.0), k.add_material(0.2, 0.9, 0.2, reflection=0.4),
             k.add_material(0.2, 0.3, 0.9, specValue=0.8, specPower=100.0)]
+    if mirror:
+        # a mirror floor under everything: most of the frame is bounce rays among the tied primitives
+        floor = k.add_material(0.8, 0.8, 0.8, reflection=0.85)
+        k.add_primitive(solr_mod.ptXZPlane, (0, -5200, 2000), size=(14000, 0, 12000), material=floor)
     u = rng.uniform
     for copy in range(3):
         rng = solr_mod.scenes.LCG(11)       # the same geometry again
@@ -738,23 +742,29 @@ def _tie_scene(k, width=160, height=120, **info):
     k.add_primitive(solr_mod.ptXYPlane, (0, 0, 9000), size=(12000, 8000, 0), material=mats[0])
     X._light(k)
     k.compact_boxes(True)
-    k.set_camera((300.0, 200.0, -15000.0), look_at=(0.0, 0.0, 0.0), angles=(0.02, -0.03, 0.0))
+    if mirror:
+        k.set_camera((300.0, 3000.0, -15000.0), look_at=(0.0, -4000.0, 0.0), angles=(0.02, -0.03, 0.0))
+    else:
+        k.set_camera((300.0, 200.0, -15000.0), look_at=(0.0, 0.0, 0.0), angles=(0.02, -0.03, 0.0))
     return k
 
 
-def test_order_free_walk_resolves_ties_as_the_reference_does(solr, oracle):
+@pytest.mark.parametrize("mirror", [False, True], ids=["primary", "bounce"])
+def test_order_free_walk_resolves_ties_as_the_reference_does(solr, oracle, mirror):
     """Primary rays walk a hierarchy of the engine's own over the scene's leaves, in an order of its own (DESIGN.md
     section 4): equal distances must go to the primitive the reference visits first, and nothing may depend on
     the order otherwise.  A scene in which every primitive exists three times is rendered with the order-free
     lists (the default), without them (variant 6) and by the oracle: ids, depth and RGB8 identical, float
-    colour within 1 ULP of the oracle and bit for bit between the two engine forms."""
+    colour within 1 ULP of the oracle and bit for bit between the two engine forms.  "bounce": the same over a
+    mirror floor - unit-length rays take the lists in the checked form (lanes whose best hit has a rival within
+    the margin walk the reference's order afterwards), and here nearly every hit has one."""
     hip = solr.hip_lib()
     frames = []
     try:
         for variant in (0, 6):
             hip.solr_hip_set_variant(variant)
             k = solr.Kernel(engine="hip")
-            _tie_scene(k)
+            _tie_scene(k, mirror=mirror)
             pp, ids, rgb = gpu_frame(k)
             assert (hip.solr_hip_order_free_nodes() > 0) == (variant == 0)
             if variant == 0:
