@@ -710,7 +710,7 @@ def test_ambient_occlusion_on_a_strip_reads_the_neighbours_rows(solr, oracle):
         k.finalize()
 
 
-def _tie_scene(k, width=160, height=120, mirror=False, **info):
+def _tie_scene(k, width=160, height=120, mirror=False, jitter=0.0, **info):
     """Primitives that tie: every sphere, triangle and cylinder is in the scene twice (and once more with another
     material), at the same place - equal hit distances bit for bit.  The reference keeps the one it visits
     first; which one that is follows from its flatten order, not from the order of insertion."""
@@ -722,21 +722,21 @@ def _tie_scene(k, width=160, height=120, mirror=False, **info):
         # a mirror floor under everything: most of the frame is bounce rays among the tied primitives
         floor = k.add_material(0.8, 0.8, 0.8, reflection=0.85)
         k.add_primitive(solr_mod.ptXZPlane, (0, -5200, 2000), size=(14000, 0, 12000), material=floor)
-    u = rng.uniform
     for copy in range(3):
         rng = solr_mod.scenes.LCG(11)       # the same geometry again
         u = rng.uniform
+        dz = copy * jitter                  # ... or a hair behind it: distances that differ in their last bits
         for i in range(40):
-            c = (u(-6000, 6000), u(-4000, 4000), u(-3000, 6000))
+            c = (u(-6000, 6000), u(-4000, 4000), u(-3000, 6000) + dz)
             k.add_primitive(solr_mod.ptSphere, c, size=(u(300, 900), 0, 0), material=mats[(i + copy) % 3])
         for i in range(60):
-            p0 = (u(-7000, 7000), u(-4500, 4500), u(0, 7000))
+            p0 = (u(-7000, 7000), u(-4500, 4500), u(0, 7000) + dz)
             p1 = (p0[0] + u(-1500, 1500), p0[1] + u(-1500, 1500), p0[2] + u(-800, 800))
             p2 = (p0[0] + u(-1500, 1500), p0[1] + u(-1500, 1500), p0[2] + u(-800, 800))
             t = k.add_primitive(solr_mod.ptTriangle, p0, p1, p2, material=mats[(i + 2 * copy) % 3])
             k.set_normals(t, (0, 0, -1), (0.1, 0, -1), (0, 0.1, -1))
         for i in range(20):
-            a = (u(-6000, 6000), u(-4000, 4000), u(-2000, 5000))
+            a = (u(-6000, 6000), u(-4000, 4000), u(-2000, 5000) + dz)
             b = (a[0] + u(-1200, 1200), a[1] + u(-1200, 1200), a[2] + u(-1200, 1200))
             k.add_primitive(solr_mod.ptCylinder, a, b, size=(u(80, 250), 0, 0), material=mats[(i + copy) % 3])
     k.add_primitive(solr_mod.ptXYPlane, (0, 0, 9000), size=(12000, 8000, 0), material=mats[0])
@@ -749,22 +749,25 @@ def _tie_scene(k, width=160, height=120, mirror=False, **info):
     return k
 
 
-@pytest.mark.parametrize("mirror", [False, True], ids=["primary", "bounce"])
-def test_order_free_walk_resolves_ties_as_the_reference_does(solr, oracle, mirror):
+@pytest.mark.parametrize("mirror,jitter", [(False, 0.0), (True, 0.0), (True, 0.01), (False, 0.004)],
+                         ids=["primary", "bounce", "bounce-near-ties", "primary-near-ties"])
+def test_order_free_walk_resolves_ties_as_the_reference_does(solr, oracle, mirror, jitter):
     """Primary rays walk a hierarchy of the engine's own over the scene's leaves, in an order of its own (DESIGN.md
     section 4): equal distances must go to the primitive the reference visits first, and nothing may depend on
     the order otherwise.  A scene in which every primitive exists three times is rendered with the order-free
     lists (the default), without them (variant 6) and by the oracle: ids, depth and RGB8 identical, float
     colour within 1 ULP of the oracle and bit for bit between the two engine forms.  "bounce": the same over a
     mirror floor - unit-length rays take the lists in the checked form (lanes whose best hit has a rival within
-    the margin walk the reference's order afterwards), and here nearly every hit has one."""
+    the margin walk the reference's order afterwards), and here nearly every hit has one.  "near-ties": the
+    copies lie a hundredth of a unit behind one another, distances of thousands that differ in their last bits or
+    not at all - whatever the reference's strict comparison and cut-off make of them has to come out."""
     hip = solr.hip_lib()
     frames = []
     try:
         for variant in (0, 6):
             hip.solr_hip_set_variant(variant)
             k = solr.Kernel(engine="hip")
-            _tie_scene(k, mirror=mirror)
+            _tie_scene(k, mirror=mirror, jitter=jitter)
             pp, ids, rgb = gpu_frame(k)
             assert (hip.solr_hip_order_free_nodes() > 0) == (variant == 0)
             if variant == 0:
