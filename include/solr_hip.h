@@ -247,6 +247,8 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
 void solr_hip_set_variant(int variant);
 /* nodes per order-free list of the resident scene when long rays' closest-hit walks use them, else 0 */
 int solr_hip_order_free_nodes(void);
+/* 1 if the shadow walks take them as well (nothing in the scene is transparent or a textured plane), else 0 */
+int solr_hip_order_free_shadows(void);
 int solr_hip_get_variant(void);
 
 /* Animated scenes.  The reference re-runs GPUKernel::rotatePrimitives (GPUKernel.cpp:1378-1460: rotate

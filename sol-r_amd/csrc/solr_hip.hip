@@ -4061,6 +4061,13 @@ extern "C" int solr_hip_order_free_nodes(void)
     return (g.initialized && orderFreeListsUsable()) ? g.nbBoxesFree : 0;
 }
 
+/* Extension: 1 if the shadow walks of the resident scene take the order-free lists as well (they are in use and
+ * nothing in the scene is transparent or a textured plane), else 0. */
+extern "C" int solr_hip_order_free_shadows(void)
+{
+    return (g.initialized && orderFreeListsUsable() && g.opaqueShadows) ? 1 : 0;
+}
+
 extern "C" void solr_hip_set_depth_halo(const float *above, int nbAbove, const float *below, int nbBelow)
 {
     if (!ready("solr_hip_set_depth_halo"))

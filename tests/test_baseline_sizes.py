@@ -101,6 +101,8 @@ def test_full_size_frames_match_the_oracle_on_rows_across_the_frame(solr, oracle
         first = device_frame(solr, si)
         _check_rows(first, expected, config + " default")
         assert hip.solr_hip_order_free_nodes() > 0, "primary rays did not walk the order-free lists"
+        # ... and the shadow rays where nothing is transparent (the Cornell room has its glass sphere)
+        assert hip.solr_hip_order_free_shadows() == (0 if config.startswith("cfg1") else 1)
 
         # every walk in the reference's order (no order-free lists)
         hip.solr_hip_set_variant(6)

@@ -770,6 +770,7 @@ def test_order_free_walk_resolves_ties_as_the_reference_does(solr, oracle, mirro
             _tie_scene(k, mirror=mirror, jitter=jitter)
             pp, ids, rgb = gpu_frame(k)
             assert (hip.solr_hip_order_free_nodes() > 0) == (variant == 0)
+            assert hip.solr_hip_order_free_shadows() == (1 if variant == 0 else 0)   # nothing transparent here
             if variant == 0:
                 opp, oids, orgb, _, status = oracle_frame(k, oracle)
                 assert status == 0
