@@ -398,6 +398,8 @@ def main():
                    "host_issue_ms_per_step_rank0": round((t_issued - t0) / args.steps * 1e3, 4),
                    "cost_ordered_launch_rank0": bool(hip.solr_hip_tile_scheduling_active()),
                    "frames_in_flight": int(hip.solr_hip_get_frames_in_flight()),
+                   # untimed set-up frames before the W warm-up steps (clocks, tile-cost feedback, order-free lists)
+                   "setup_frames_before_warmup": PREROLL_FRAMES,
                    # nodes per order-free list when long rays' walks use them, else 0
                    "order_free_nodes": int(hip.solr_hip_order_free_nodes()),
                    "gather": ("none (one GPU)" if not distributed else
