@@ -1,10 +1,13 @@
-"""Copies the summaries of tools/profile_round.sh from gpurun_out/<tag>/ into profiles/<tag>/ (tracked)."""
+"""Copies the summaries of tools/profile_round.sh from gpurun_out/<tag>/ into profiles/<tag>/ (tracked):
+    python tools/collect_profiles.py <tag> <commit the box ran> [scene ...]
+Only the scenes named (all three without names) get their counter summaries rewritten and stamped with the commit."""
 import sys, os, glob, shutil, csv, collections, json
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 commit = sys.argv[2] if len(sys.argv) > 2 else os.environ.get("SOLR_COMMIT", "unknown")   # the tree the box ran
+SCENES = tuple(sys.argv[3:]) or ("cornell", "height_field", "molecule")
 src, dst = "gpurun_out/" + tag, "profiles/" + tag
 os.makedirs(dst, exist_ok=True)
-for scene in ("cornell", "height_field", "molecule"):
+for scene in SCENES:
     b = os.path.join(src, "bench_%s.json" % scene)
     if os.path.exists(b):
         shutil.copy(b, os.path.join(dst, "bench_%s.json" % scene))
@@ -32,7 +35,9 @@ for scene in ("cornell", "height_field", "molecule"):
                "# MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, WRITE_SIZE is exact).\n" % scene)
         open(os.path.join(dst, "pmc_%s.txt" % scene), "w").write(hdr + "\n".join(out) + "\n")
 traffic = {}
-for scene in ("cornell", "height_field", "molecule"):
+if os.path.exists(os.path.join(dst, "hbm_traffic.json")):
+    traffic = json.load(open(os.path.join(dst, "hbm_traffic.json")))   # the scenes not named keep their entries
+for scene in SCENES:
     vals = {}
     for p, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         v = []
