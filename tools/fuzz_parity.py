@@ -10,6 +10,8 @@ from helpers import compare_frames, gpu_frame, oracle_frame
 S = solr.scenes
 
 def build(k, seed, width=72, height=48):
+    if os.environ.get("FUZZ_SIZE"):     # e.g. 160x120: more waves per frame, other mixes of rays in a wave
+        width, height = (int(v) for v in os.environ["FUZZ_SIZE"].split("x"))
     rng = S.LCG(seed)
     u = lambda a, b: rng.uniform(a, b)
     pick = lambda seq: seq[rng.next() % len(seq)]
