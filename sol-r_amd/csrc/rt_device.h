@@ -1453,263 +1453,286 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     bool lanesNow = active;
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-    const bool checked = unitRays && attempt == 0;
-    const bool freeList = freeOrder || checked;
-    Scene W = S;
-    if (freeList)
-    {
-        /* eight flattenings of the same hierarchy, the near child first for a direction of that sign octant: the
-         * wave takes the octant of its first active lane (any list gives the same result) */
-        const int signs = (r.d.x < 0.f ? 1 : 0) | (r.d.y < 0.f ? 2 : 0) | (r.d.z < 0.f ? 4 : 0);
-        const int lane = (int)__builtin_ctzll(ballot(lanesNow));
-        const int octant = __builtin_amdgcn_readlane(signs, lane);
-        W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
-        W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
-        W.nbBoxes = S.nbBoxesFree;
-    }
-    /* The reference's cut-off never culls for such rays (a slab parameter of order 1 against a distance of
-     * thousands).  The order-free walk may cull by the TRUE distance: a box whose entry point lies farther than the
-     * closest hit so far holds nothing that could replace it, not even on a tie.  The margins cover the rounding
-     * of both sides: 2e-4 of the distance for the computed hit distance and the products, 1e-4 of the origin's
-     * coordinates for the cancellation in (bound - origin) - a thousand times the half-ulp that subtraction can
-     * lose.  With the near child first this is what ends a walk early. */
-    const float invLength = freeList ? 1.f / length(r.d) : 1.f;
-    const float farScale = freeList ? (checked ? 1.001f : 1.0002f) * invLength : 1.f;
-    const float farOffset = freeList ? slack * invLength : 0.f;
-    int tieIndex = -1; /* the primitive that holds minDistance */
-    auto closer = [&](float distance, int pi) {
-        bool better = distance < minDistance || (freeOrder && distance == minDistance && pi < tieIndex);
-        if (checked)
+        const bool checked = unitRays && attempt == 0;
+        const bool freeList = freeOrder || checked;
+        Scene W = S;
+        if (freeList)
         {
-            const bool inBand = distance >= bandStart;
-            bandHit = bandHit || inBand;
-            better = better && !inBand;
-            second = fminf(second, better ? minDistance : distance);
+            /* eight flattenings of the same hierarchy, the near child first for a direction of that sign octant: the
+             * wave takes the octant of its first active lane (any list gives the same result) */
+            const int signs = (r.d.x < 0.f ? 1 : 0) | (r.d.y < 0.f ? 2 : 0) | (r.d.z < 0.f ? 4 : 0);
+            const int lane = (int)__builtin_ctzll(ballot(lanesNow));
+            const int octant = __builtin_amdgcn_readlane(signs, lane);
+            W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
+            W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
+            W.nbBoxes = S.nbBoxesFree;
         }
-        return better;
-    };
-    const PackedRay pr = packRay(r);
-    const int nbBoxes = W.nbBoxes;
-    int cursor = lanesNow ? 0 : SOLR_CURSOR_DONE;
-    int cur = 0;
-    Row2 node;
-    node.a = node.b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!tidy)
-        node = boxNode(S, 0);
-    while (cur < nbBoxes)
-    {
-        int leaf = cur, nbPrimitives;
-        bool entered;
-        SOLR_T(unsigned long long ta = SOLR_NOW();)
-        if (tidy)
-        {
-            leaf = advanceTidy<FEAT>(W, pr, freeList ? minDistance * farScale + farOffset : minDistance, cursor, cur,
-                                     nbPrimitives, entered);
-            SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)
-            if (leaf < 0)
-                break;
-        }
-        else
-        {
-            if (!stepGeneral<COUNT>(S, r, fastBoxes, minDistance, cursor, cur, node, nbPrimitives, entered, cnt))
-                continue;
-            if (showBoxes)
+        /* The reference's cut-off never culls for such rays (a slab parameter of order 1 against a distance of
+         * thousands).  The order-free walk may cull by the TRUE distance: a box whose entry point lies farther than the
+         * closest hit so far holds nothing that could replace it, not even on a tie.  The margins cover the rounding
+         * of both sides: 2e-4 of the distance for the computed hit distance and the products, 1e-4 of the origin's
+         * coordinates for the cancellation in (bound - origin) - a thousand times the half-ulp that subtraction can
+         * lose.  With the near child first this is what ends a walk early. */
+        const float invLength = freeList ? 1.f / length(r.d) : 1.f;
+        const float farScale = freeList ? (checked ? 1.001f : 1.0002f) * invLength : 1.f;
+        const float farOffset = freeList ? slack * invLength : 0.f;
+        int tieIndex = -1; /* the primitive that holds minDistance */
+        auto closer = [&](float distance, int pi) {
+            bool better = distance < minDistance || (freeOrder && distance == minDistance && pi < tieIndex);
+            if (checked)
             {
-                if (entered)
-                {
-                    const int start = boxStart(S, leaf);
-                    const float4 c = loadMaterialHot(S, (int)((unsigned)start % (unsigned)NB_MAX_MATERIALS)).color;
-                    colorBox.x += c.x / 200.f;
-                    colorBox.y += c.y / 200.f;
-                    colorBox.z += c.z / 200.f;
-                }
-                continue;
+                const bool inBand = distance >= bandStart;
+                bandHit = bandHit || inBand;
+                better = better && !inBand;
+                second = fminf(second, better ? minDistance : distance);
             }
-            if (nbPrimitives <= 0)
-                continue;
-        }
-        /* (readfirstlane: the compiler takes an inline-asm result for divergent and would fetch the record per lane) */
-        const Row4 L = leafRecord(W, uniform(leaf));
-        const int start = uniform(asint(L.d.w));
-        for (int k = 0; k < nbPrimitives; ++k)
+            return better;
+        };
+        const PackedRay pr = packRay(r);
+        const int nbBoxes = W.nbBoxes;
+        int cursor = lanesNow ? 0 : SOLR_CURSOR_DONE;
+        int cur = 0;
+        Row2 node;
+        node.a = node.b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!tidy)
+            node = boxNode(S, 0);
+        while (cur < nbBoxes)
         {
-            const PrimRec rec = leafPrimitive<FEAT>(S, si, L, start, k);
-            const int pi = rec.pi;
-            const Row2 &head = rec.head;
-            const int tag = uniform(asint(head.a.w));
-            const int materialId = uniform(asint(head.b.w));
-            const int kind = primKind<FEAT>(si, tag);
-            /* Short paths.  A primitive with a kind has a FAST0 material (GI:704-705: every lane that entered the
-             * leaf tests it) and its type and material facts are settled: the general tests with constants. */
-            if ((FEAT & F_SPHERE) && kind == KIND_SPHERE)
+            int leaf = cur, nbPrimitives;
+            bool entered;
+            SOLR_T(unsigned long long ta = SOLR_NOW();)
+            if (tidy)
             {
-                countAdd<COUNT>(cnt.wPrims, 1);
-                if (entered)
-                    countAdd<COUNT>(cnt.prims, 1);
-                Hit h;
-                bool back;
-                const bool i = sphereHit(si, V4(head.a), head.b.x, r, entered, h.intersection, back);
-                const float distance = length(h.intersection - r.o);
-                const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
-                if (ballot(keep) != 0ull)
+                leaf = advanceTidy<FEAT>(W, pr, freeList ? minDistance * farScale + farOffset : minDistance, cursor,
+                                         cur, nbPrimitives, entered);
+                SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)
+                if (leaf < 0)
+                    break;
+            }
+            else
+            {
+                if (!stepGeneral<COUNT>(S, r, fastBoxes, minDistance, cursor, cur, node, nbPrimitives, entered, cnt))
+                    continue;
+                if (showBoxes)
                 {
-                    if (keep)
+                    if (entered)
                     {
-                        sphereNormal<false>(si, V4(head.a), V4(head.b), false, false, back, r, h);
-                        minDistance = distance;
-                        tieIndex = pi;
-                        closestPrimitive = pi;
-                        closestIntersection = h.intersection;
-                        closestNormal = h.normal;
-                        closestAreas = V(0.f, 0.f, 0.f);
-                        intersections = true;
+                        const int start = boxStart(S, leaf);
+                        const float4 c = loadMaterialHot(S, (int)((unsigned)start % (unsigned)NB_MAX_MATERIALS)).color;
+                        colorBox.x += c.x / 200.f;
+                        colorBox.y += c.y / 200.f;
+                        colorBox.z += c.z / 200.f;
                     }
+                    continue;
                 }
-                continue;
+                if (nbPrimitives <= 0)
+                    continue;
             }
-            if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY && kind <= KIND_PLANE_XZ)
+            /* (readfirstlane: the compiler takes an inline-asm result for divergent and would fetch the record per
+             * lane) */
+            const Row4 L = leafRecord(W, uniform(leaf));
+            const int start = uniform(asint(L.d.w));
+            for (int k = 0; k < nbPrimitives; ++k)
             {
-                countAdd<COUNT>(cnt.wPrims, 1);
-                if (entered)
+                const PrimRec rec = leafPrimitive<FEAT>(S, si, L, start, k);
+                const int pi = rec.pi;
+                const Row2 &head = rec.head;
+                const int tag = uniform(asint(head.a.w));
+                const int materialId = uniform(asint(head.b.w));
+                const int kind = primKind<FEAT>(si, tag);
+                /* Short paths.  A primitive with a kind has a FAST0 material (GI:704-705: every lane that entered the
+                 * leaf tests it) and its type and material facts are settled: the general tests with constants. */
+                if ((FEAT & F_SPHERE) && kind == KIND_SPHERE)
                 {
-                    countAdd<COUNT>(cnt.prims, 1);
+                    countAdd<COUNT>(cnt.wPrims, 1);
+                    if (entered)
+                        countAdd<COUNT>(cnt.prims, 1);
+                    Hit h;
+                    bool back;
+                    const bool i = sphereHit(si, V4(head.a), head.b.x, r, entered, h.intersection, back);
+                    const float distance = length(h.intersection - r.o);
+                    const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
+                    if (ballot(keep) != 0ull)
+                    {
+                        if (keep)
+                        {
+                            sphereNormal<false>(si, V4(head.a), V4(head.b), false, false, back, r, h);
+                            minDistance = distance;
+                            tieIndex = pi;
+                            closestPrimitive = pi;
+                            closestIntersection = h.intersection;
+                            closestNormal = h.normal;
+                            closestAreas = V(0.f, 0.f, 0.f);
+                            intersections = true;
+                        }
+                    }
+                    continue;
+                }
+                if ((FEAT & F_PLANE) && kind >= KIND_PLANE_XY && kind <= KIND_PLANE_XZ)
+                {
+                    countAdd<COUNT>(cnt.wPrims, 1);
+                    if (entered)
+                    {
+                        countAdd<COUNT>(cnt.prims, 1);
+                        Hit h;
+                        h.intersection = V(0.f, 0.f, 0.f);
+                        h.normal = V(0.f, 0.f, 0.f);
+                        h.shadowIntensity = 0.f;
+                        const bool i = planePlain(S, si, kind, V4(head.a), V4(head.b), recPlaneNormal(S, rec),
+                                                  recPlaneAverage(S, rec), r, h);
+                        const float distance = length(h.intersection - r.o);
+                        if (i && distance > si.geometryEpsilon && closer(distance, pi))
+                        {
+                            minDistance = distance;
+                            tieIndex = pi;
+                            closestPrimitive = pi;
+                            closestIntersection = h.intersection;
+                            closestNormal = h.normal;
+                            closestAreas = V(0.f, 0.f, 0.f);
+                            intersections = true;
+                        }
+                    }
+                    continue;
+                }
+                if ((FEAT & F_TRI) && kind == KIND_TRIANGLE)
+                {
+                    /* as the general triangle branch below */
+                    countAdd<COUNT>(cnt.wPrims, 1);
+                    if (entered)
+                        countAdd<COUNT>(cnt.prims, 1);
                     Hit h;
                     h.intersection = V(0.f, 0.f, 0.f);
-                    h.normal = V(0.f, 0.f, 0.f);
-                    h.shadowIntensity = 0.f;
-                    const bool i = planePlain(S, si, kind, V4(head.a), V4(head.b), recPlaneNormal(S, rec),
-                                              recPlaneAverage(S, rec), r, h);
+                    bool i = false;
+                    const v3 p0 = V4(head.a);
+                    const v3 p1 = recP1(S, rec);
+                    const v3 p2 = recP2(S, rec);
+                    if (entered)
+                        i = triangleHit(si, p0, p1, p2, r, h.intersection);
                     const float distance = length(h.intersection - r.o);
-                    if (i && distance > si.geometryEpsilon && closer(distance, pi))
+                    const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
+                    if (ballot(keep) != 0ull)
                     {
-                        minDistance = distance;
-                        tieIndex = pi;
-                        closestPrimitive = pi;
-                        closestIntersection = h.intersection;
-                        closestNormal = h.normal;
-                        closestAreas = V(0.f, 0.f, 0.f);
-                        intersections = true;
+                        const v3 n0 = V4(primRow(S, pi, ROW_N0));
+                        const v3 n1 = V4(primRow(S, pi, ROW_N1));
+                        const v3 n2 = V4(primRow(S, pi, ROW_N2));
+                        if (keep)
+                        {
+                            triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
+                            minDistance = distance;
+                            tieIndex = pi;
+                            closestPrimitive = pi;
+                            closestIntersection = h.intersection;
+                            closestNormal = h.normal;
+                            closestAreas = h.areas;
+                            intersections = true;
+                        }
                     }
+                    continue;
                 }
-                continue;
-            }
-            if ((FEAT & F_TRI) && kind == KIND_TRIANGLE)
-            {
-                /* as the general triangle branch below */
+                if ((FEAT & F_CYL) && kind == KIND_CYLINDER)
+                {
+                    countAdd<COUNT>(cnt.wPrims, 1);
+                    if (entered)
+                    {
+                        countAdd<COUNT>(cnt.prims, 1);
+                        Hit h;
+                        h.intersection = V(0.f, 0.f, 0.f);
+                        h.normal = V(0.f, 0.f, 0.f);
+                        h.shadowIntensity = 0.f;
+                        const bool i = cylinderIntersection(si, V4(head.a), recP1(S, rec), recP2(S, rec),
+                                                            V4(primRow(S, pi, ROW_N1)), V4(head.b), r, h);
+                        const float distance = length(h.intersection - r.o);
+                        if (i && distance > si.geometryEpsilon && closer(distance, pi))
+                        {
+                            minDistance = distance;
+                            tieIndex = pi;
+                            closestPrimitive = pi;
+                            closestIntersection = h.intersection;
+                            closestNormal = h.normal;
+                            closestAreas = V(0.f, 0.f, 0.f);
+                            intersections = true;
+                        }
+                    }
+                    continue;
+                }
+                /* GI:704-705 */
+                const bool lanes = entered && ((tag & PRIM_FAST0) != 0 ||
+                                               ((tag & PRIM_FAST1) != 0 && currentMaterialId != materialId));
+                if (ballot(lanes) == 0ull)
+                    continue;
                 countAdd<COUNT>(cnt.wPrims, 1);
-                if (entered)
-                    countAdd<COUNT>(cnt.prims, 1);
-                Hit h;
-                h.intersection = V(0.f, 0.f, 0.f);
-                bool i = false;
-                const v3 p0 = V4(head.a);
-                const v3 p1 = recP1(S, rec);
-                const v3 p2 = recP2(S, rec);
-                if (entered)
-                    i = triangleHit(si, p0, p1, p2, r, h.intersection);
-                const float distance = length(h.intersection - r.o);
-                const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
-                if (ballot(keep) != 0ull)
-                {
-                    const v3 n0 = V4(primRow(S, pi, ROW_N0));
-                    const v3 n1 = V4(primRow(S, pi, ROW_N1));
-                    const v3 n2 = V4(primRow(S, pi, ROW_N2));
-                    if (keep)
-                    {
-                        triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
-                        minDistance = distance;
-                        tieIndex = pi;
-                        closestPrimitive = pi;
-                        closestIntersection = h.intersection;
-                        closestNormal = h.normal;
-                        closestAreas = h.areas;
-                        intersections = true;
-                    }
-                }
-                continue;
-            }
-            if ((FEAT & F_CYL) && kind == KIND_CYLINDER)
-            {
-                countAdd<COUNT>(cnt.wPrims, 1);
-                if (entered)
-                {
-                    countAdd<COUNT>(cnt.prims, 1);
-                    Hit h;
-                    h.intersection = V(0.f, 0.f, 0.f);
-                    h.normal = V(0.f, 0.f, 0.f);
-                    h.shadowIntensity = 0.f;
-                    const bool i = cylinderIntersection(si, V4(head.a), recP1(S, rec), recP2(S, rec),
-                                                        V4(primRow(S, pi, ROW_N1)), V4(head.b), r, h);
-                    const float distance = length(h.intersection - r.o);
-                    if (i && distance > si.geometryEpsilon && closer(distance, pi))
-                    {
-                        minDistance = distance;
-                        tieIndex = pi;
-                        closestPrimitive = pi;
-                        closestIntersection = h.intersection;
-                        closestNormal = h.normal;
-                        closestAreas = V(0.f, 0.f, 0.f);
-                        intersections = true;
-                    }
-                }
-                continue;
-            }
-            /* GI:704-705 */
-            const bool lanes = entered && ((tag & PRIM_FAST0) != 0 ||
-                                           ((tag & PRIM_FAST1) != 0 && currentMaterialId != materialId));
-            if (ballot(lanes) == 0ull)
-                continue;
-            countAdd<COUNT>(cnt.wPrims, 1);
-            if (lanes)
-                countAdd<COUNT>(cnt.prims, 1);
-            const int type = tag & PRIM_TYPE_MASK;
-            if ((FEAT & (F_SPHERE | F_PROC)) && extendedGeometry<FEAT>(si) && (type == ptSphere || type == ptEnvironment))
-            {
-                /* spheres: decide on the intersection point, pay for the normal only when
-                 * the hit becomes the closest one (GI:749-760 uses nothing else before) */
-                Hit h;
-                bool back;
-                const bool i = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
-                const float distance = length(h.intersection - r.o);
-                const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
-                if (ballot(keep) != 0ull)
-                {
-                    if (keep)
-                    {
-                        sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b), (tag & PRIM_PROCEDURAL) != 0,
-                                                           false, back, r, h);
-                        minDistance = distance;
-                        tieIndex = pi;
-                        closestPrimitive = pi;
-                        closestIntersection = h.intersection;
-                        closestNormal = h.normal;
-                        closestAreas = V(0.f, 0.f, 0.f);
-                        intersections = true;
-                    }
-                }
-            }
-            else if ((FEAT & F_TRI) && (type == ptTriangle || !extendedGeometry<FEAT>(si)))
-            {
-                /* triangles (every primitive, without extended geometry, GI:743-747): areas and the
-                 * interpolated normal only for hits that become the closest one */
-                Hit h;
-                h.intersection = V(0.f, 0.f, 0.f);
-                bool i = false;
-                const v3 p0 = V4(head.a);
-                const v3 p1 = recP1(S, rec);
-                const v3 p2 = recP2(S, rec);
                 if (lanes)
-                    i = triangleHit(si, p0, p1, p2, r, h.intersection);
-                const float distance = length(h.intersection - r.o);
-                const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
-                if (ballot(keep) != 0ull)
+                    countAdd<COUNT>(cnt.prims, 1);
+                const int type = tag & PRIM_TYPE_MASK;
+                if ((FEAT & (F_SPHERE | F_PROC)) && extendedGeometry<FEAT>(si) &&
+                    (type == ptSphere || type == ptEnvironment))
                 {
-                    const v3 n0 = V4(primRow(S, pi, ROW_N0));
-                    const v3 n1 = V4(primRow(S, pi, ROW_N1));
-                    const v3 n2 = V4(primRow(S, pi, ROW_N2));
-                    if (keep)
+                    /* spheres: decide on the intersection point, pay for the normal only when
+                     * the hit becomes the closest one (GI:749-760 uses nothing else before) */
+                    Hit h;
+                    bool back;
+                    const bool i = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
+                    const float distance = length(h.intersection - r.o);
+                    const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
+                    if (ballot(keep) != 0ull)
                     {
-                        triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
+                        if (keep)
+                        {
+                            sphereNormal<(FEAT & F_PROC) != 0>(si, V4(head.a), V4(head.b), (tag & PRIM_PROCEDURAL) != 0,
+                                                               false, back, r, h);
+                            minDistance = distance;
+                            tieIndex = pi;
+                            closestPrimitive = pi;
+                            closestIntersection = h.intersection;
+                            closestNormal = h.normal;
+                            closestAreas = V(0.f, 0.f, 0.f);
+                            intersections = true;
+                        }
+                    }
+                }
+                else if ((FEAT & F_TRI) && (type == ptTriangle || !extendedGeometry<FEAT>(si)))
+                {
+                    /* triangles (every primitive, without extended geometry, GI:743-747): areas and the
+                     * interpolated normal only for hits that become the closest one */
+                    Hit h;
+                    h.intersection = V(0.f, 0.f, 0.f);
+                    bool i = false;
+                    const v3 p0 = V4(head.a);
+                    const v3 p1 = recP1(S, rec);
+                    const v3 p2 = recP2(S, rec);
+                    if (lanes)
+                        i = triangleHit(si, p0, p1, p2, r, h.intersection);
+                    const float distance = length(h.intersection - r.o);
+                    const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
+                    if (ballot(keep) != 0ull)
+                    {
+                        const v3 n0 = V4(primRow(S, pi, ROW_N0));
+                        const v3 n1 = V4(primRow(S, pi, ROW_N1));
+                        const v3 n2 = V4(primRow(S, pi, ROW_N2));
+                        if (keep)
+                        {
+                            triangleNormal(p0, p1, p2, n0, n1, n2, r, h);
+                            minDistance = distance;
+                            tieIndex = pi;
+                            closestPrimitive = pi;
+                            closestIntersection = h.intersection;
+                            closestNormal = h.normal;
+                            closestAreas = h.areas;
+                            intersections = true;
+                        }
+                    }
+                }
+                else if (lanes)
+                {
+                    Hit h;
+                    h.intersection = V(0.f, 0.f, 0.f);
+                    h.normal = V(0.f, 0.f, 0.f);
+                    h.areas = V(0.f, 0.f, 0.f);
+                    h.shadowIntensity = 0.f;
+                    const bool i = testPrimitive<false, FEAT>(S, si, rec, tag, r, h);
+                    const float distance = length(h.intersection - r.o);
+                    if (i && distance > si.geometryEpsilon && closer(distance, pi))
+                    {
                         minDistance = distance;
                         tieIndex = pi;
                         closestPrimitive = pi;
@@ -1720,38 +1743,17 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     }
                 }
             }
-            else if (lanes)
-            {
-                Hit h;
-                h.intersection = V(0.f, 0.f, 0.f);
-                h.normal = V(0.f, 0.f, 0.f);
-                h.areas = V(0.f, 0.f, 0.f);
-                h.shadowIntensity = 0.f;
-                const bool i = testPrimitive<false, FEAT>(S, si, rec, tag, r, h);
-                const float distance = length(h.intersection - r.o);
-                if (i && distance > si.geometryEpsilon && closer(distance, pi))
-                {
-                    minDistance = distance;
-                    tieIndex = pi;
-                    closestPrimitive = pi;
-                    closestIntersection = h.intersection;
-                    closestNormal = h.normal;
-                    closestAreas = h.areas;
-                    intersections = true;
-                }
-            }
+            SOLR_T(cnt.tLeaf += SOLR_NOW() - ta; ++cnt.nLeaf;)
         }
-        SOLR_T(cnt.tLeaf += SOLR_NOW() - ta; ++cnt.nLeaf;)
-    }
-    if (!checked)
-        break;
-    /* the lanes whose result the order could have decided: once more, in the reference's order */
-    const bool again = lanesNow && (intersections ? !(second > minDistance * 1.001f + slack) : bandHit);
-    if (ballot(again) == 0ull)
-        break;
-    lanesNow = again;
-    minDistance = again ? initialDistance : minDistance;
-    intersections = again ? false : intersections;
+        if (!checked)
+            break;
+        /* the lanes whose result the order could have decided: once more, in the reference's order */
+        const bool again = lanesNow && (intersections ? !(second > minDistance * 1.001f + slack) : bandHit);
+        if (ballot(again) == 0ull)
+            break;
+        lanesNow = again;
+        minDistance = again ? initialDistance : minDistance;
+        intersections = again ? false : intersections;
     }
     SOLR_T(cnt.tClosest += SOLR_NOW() - tw0;)
     return intersections;
