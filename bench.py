@@ -62,6 +62,10 @@ def parse():
                          "--scene height_field, cfg3 = --scene molecule, cfg4 = Cornell 3840x2160 through passes 0...73 "
                          "(refinement + 64 accumulated samples, natural depth of field, ambient-occlusion kernel): a "
                          "step is then one pass of that cycle")
+    ap.add_argument("--balanced-strips", action="store_true",
+                    help="N > 1: after the set-up frames, re-cut the row strips so that every rank gets the same cost "
+                         "(solr_hip_balance_strips: the rows' measured costs, one ncclAllReduce, strips on tile "
+                         "boundaries) instead of the same number of rows; implies --native-gather")
     ap.add_argument("--native-gather", action="store_true",
                     help="N > 1: gather the strips with RCCL called from the engine's C ABI (solr_hip_gather_strips, on "
                          "the stream that rendered the frame) instead of torch.distributed's gather; torch then only "
@@ -103,7 +107,8 @@ def main():
     distributed = world > 1 or os.environ.get("SOLR_BENCH_FORCE_DIST") == "1"
     # cfg4's ambient-occlusion taps cross the strips: with the library's own communicator cudaRender trades the
     # boundary rows' depths between neighbouring ranks (no seams); the torch gather has no such leg
-    native = distributed and (args.native_gather or cfg4 or os.environ.get("SOLR_BENCH_NATIVE_GATHER") == "1")
+    native = distributed and (args.native_gather or args.balanced_strips or cfg4 or
+                              os.environ.get("SOLR_BENCH_NATIVE_GATHER") == "1")
     if native:
         import torch
         import torch.distributed as dist
@@ -256,6 +261,16 @@ def main():
     for _ in range(PREROLL_FRAMES):
         frame()
     sync()
+    strips = "equal rows"
+    if args.balanced_strips and native:
+        # equal strips share out rows, not work (profiles/r2/strip_balance_*.txt): re-cut them by the cost the
+        # set-up frames recorded, then let the tile-cost feedback settle on the new strips
+        if hip.solr_hip_balance_strips() != 0:
+            k.check(-1, "solr_hip_balance_strips")
+        strips = "balanced by cost"
+        for _ in range(PREROLL_FRAMES // 2):
+            frame()
+        sync()
     for _ in range(args.warmup):
         frame()
     sync()
@@ -405,6 +420,7 @@ def main():
                    "gather": ("none (one GPU)" if not distributed else
                               "RCCL from the engine's C ABI (solr_hip_gather_strips)" if native else
                               "torch.distributed gather (RCCL)"),
+                   "strips": strips,
                    "parallelism": "tile%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,

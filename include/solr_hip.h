@@ -124,7 +124,16 @@ void solr_hip_set_strip(int firstRow, int nbRows);
  *   solr_hip_gathered_frame   root: device pointer of the assembled height x width x 3 frame
  *   solr_hip_d2h_gathered     root: waits for the gather and copies the assembled frame to the host
  *   solr_hip_comm_finalize    leaves the communicator
- * All return 0, or -1 with solr_hip_last_error set.  RCCL is loaded when the first of them is called. */
+ * All return 0, or -1 with solr_hip_last_error set.  RCCL is loaded when the first of them is called.
+ *
+ * Cost-balanced strips (an extension; the reference's split is equal, CudaRayTracer.cu:1694-1696): equal strips
+ * share out rows, not work - the frame is as slow as its slowest rank.
+ *   solr_hip_strip_row_costs  what each row of this process's strip cost in the last frame (tile durations)
+ *   solr_hip_balanced_strips  pure arithmetic: contiguous strips of equal cost from the rows' costs of the whole
+ *                             frame, boundaries on multiples of `align` rows (8 = a tile)
+ *   solr_hip_set_strip_table  the strips of all ranks, for the gather and the halo exchange (world = 0: forget)
+ *   solr_hip_balance_strips   all of it with one ncclAllReduce: every rank, between frames; sets this process's
+ *                             strip as well */
 void solr_hip_strip_rows(int rank, int world, int height, int *firstRow, int *nbRows, int *rowsPerRank);
 int solr_hip_comm_unique_id(void *id128);
 int solr_hip_comm_init(int rank, int world, const void *id128);
@@ -132,6 +141,10 @@ int solr_hip_gather_strips(int root);
 void *solr_hip_gathered_frame(void);
 int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap);
 void solr_hip_comm_finalize(void);
+int solr_hip_strip_row_costs(float *rowCost, int height);
+int solr_hip_balanced_strips(const float *rowCost, int height, int world, int align, int *firstRows, int *nbRows);
+int solr_hip_set_strip_table(const int *firstRows, const int *nbRows, int world, int height);
+int solr_hip_balance_strips(void);
 
 /* Neighbourhood post-processing on a strip.  The ambient-occlusion kernel (CudaRayTracer.cu:1128-1181) compares a
  * pixel's depth with 256 taps up to 16 * param2 * max|random| / 10 pixels away: rows of the ranks above and below.

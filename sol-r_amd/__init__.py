@@ -506,6 +506,38 @@ def strip_rows(rank, world, height):
     return first, count, rows_per_rank
 
 
+def strip_row_costs(height):
+    """What each row of this process's strip cost in the frame rendered last (float32[height], 0 outside the
+    strip): solr_hip_strip_row_costs."""
+    import numpy as np
+    cost = np.zeros(height, np.float32)
+    if hip_lib().solr_hip_strip_row_costs(cost.ctypes.data_as(C.POINTER(C.c_float)), height) != 0:
+        raise SolrError("solr_hip_strip_row_costs failed")
+    return cost
+
+
+def balanced_strips(row_cost, world, align=8):
+    """[(first_row, nb_rows)] * world: contiguous strips of equal cost (solr_hip_balanced_strips; pure arithmetic,
+    no GPU needed).  row_cost: the cost of every row of the frame, summed over the ranks."""
+    import numpy as np
+    cost = np.ascontiguousarray(row_cost, np.float32)
+    first, count = (C.c_int * world)(), (C.c_int * world)()
+    if hip_lib().solr_hip_balanced_strips(cost.ctypes.data_as(C.POINTER(C.c_float)), len(cost), world, align,
+                                          first, count) != 0:
+        raise ValueError("solr_hip_balanced_strips: bad arguments")
+    return list(zip(first, count))
+
+
+def set_strip_table(strips, height):
+    """the strips of all ranks ([(first_row, nb_rows)] in rank order) for the library's gather and halo exchange;
+    None forgets the table (back to the equal strips of strip_rows)"""
+    if strips is None:
+        return hip_lib().solr_hip_set_strip_table(None, None, 0, 0)
+    world = len(strips)
+    first, count = (C.c_int * world)(*[s[0] for s in strips]), (C.c_int * world)(*[s[1] for s in strips])
+    return hip_lib().solr_hip_set_strip_table(first, count, world, height)
+
+
 def gather_strips(dist, torch, strip, rows_per_rank, width, height, rank, world, dst=0, slots=None, assemble=True):
     """One collective: every rank's RGB8 strip (a flat uint8 tensor of count*width*3 bytes) to `dst`.
     Returns the assembled (height, width, 3) image on `dst`, None elsewhere.  Works for the nccl

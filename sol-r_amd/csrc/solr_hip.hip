@@ -3940,6 +3940,7 @@ struct Rccl
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 0;
@@ -3967,9 +3968,10 @@ bool loadRccl()
     rccl.GroupEnd = (decltype(rccl.GroupEnd))dlsym(rccl.lib, "ncclGroupEnd");
     rccl.Send = (decltype(rccl.Send))dlsym(rccl.lib, "ncclSend");
     rccl.Recv = (decltype(rccl.Recv))dlsym(rccl.lib, "ncclRecv");
+    rccl.AllReduce = (decltype(rccl.AllReduce))dlsym(rccl.lib, "ncclAllReduce");
     rccl.GetErrorString = (decltype(rccl.GetErrorString))dlsym(rccl.lib, "ncclGetErrorString");
     if (!rccl.GetUniqueId || !rccl.CommInitRank || !rccl.CommDestroy || !rccl.GroupStart || !rccl.GroupEnd ||
-        !rccl.Send || !rccl.Recv)
+        !rccl.Send || !rccl.Recv || !rccl.AllReduce)
     {
         setError(-1, "librccl.so lacks an entry point the strip gather needs", __FILE__, __LINE__);
         dlclose(rccl.lib);
@@ -3994,6 +3996,25 @@ bool rcclOk(int result, const char *what)
  * stream that rendered the strip, between the renderer and the post-processing kernel - so that the assembled frame
  * is the one a single GPU renders.  Only with a communicator and the strips of solr_hip_strip_rows; `wanted`
  * follows from the post-processing parameters and the random buffer, which every rank holds alike. */
+/* The strips of all ranks when they are not the equal ones of solr_hip_strip_rows (solr_hip_set_strip_table) */
+struct StripTable
+{
+    std::vector<int> first, count;
+    int height = 0;
+} stripTable;
+void stripOf(int rank, int world, int height, int *first, int *count)
+{
+    if ((int)stripTable.first.size() == world && stripTable.height == height && rank >= 0 && rank < world)
+    {
+        if (first)
+            *first = stripTable.first[rank];
+        if (count)
+            *count = stripTable.count[rank];
+        return;
+    }
+    solr_hip_strip_rows(rank, world, height, first, count, nullptr);
+}
+
 const int RCCL_FLOAT32 = 7; /* ncclFloat32, rccl.h */
 void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
                        int wanted, DepthHalo *halo)
@@ -4001,14 +4022,14 @@ void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, in
     if (!rccl.comm || rccl.world < 2 || wanted < 1 || nbRows < 1)
         return;
     int first = 0, count = 0;
-    solr_hip_strip_rows(rccl.rank, rccl.world, frameRows, &first, &count, nullptr);
+    stripOf(rccl.rank, rccl.world, frameRows, &first, &count);
     if (first != firstRow || count != nbRows)
         return; /* a strip layout of the host's own: it hands the rows over itself (solr_hip_set_depth_halo) */
     int upRows = 0, downRows = 0;
     if (rccl.rank > 0)
-        solr_hip_strip_rows(rccl.rank - 1, rccl.world, frameRows, nullptr, &upRows, nullptr);
+        stripOf(rccl.rank - 1, rccl.world, frameRows, nullptr, &upRows);
     if (rccl.rank + 1 < rccl.world)
-        solr_hip_strip_rows(rccl.rank + 1, rccl.world, frameRows, nullptr, &downRows, nullptr);
+        stripOf(rccl.rank + 1, rccl.world, frameRows, nullptr, &downRows);
     const int mine = std::min(wanted, nbRows);
     const int recvAbove = std::min(wanted, upRows), recvBelow = std::min(wanted, downRows);
     const int sendUp = upRows > 0 ? mine : 0, sendDown = downRows > 0 ? mine : 0;
@@ -4114,6 +4135,160 @@ void solr_hip_strip_rows(int rank, int world, int height, int *first, int *count
         *rowsPerRank = per;
 }
 
+/* Cost-balanced strips.  Equal strips share out rows, not work: of the 100k-triangle mesh the strip at the
+ * horizon takes 0.22 ms, the one at the bottom 0.012 (profiles/r2/strip_throughput_height_field.txt), and the
+ * frame is as slow as its slowest rank.  rowCost[y] is what row y costs (any unit; solr_hip_strip_row_costs,
+ * summed over the ranks by the host's control plane or solr_hip_balance_strips): contiguous strips whose
+ * boundaries are multiples of `align` rows (8 = the tiles' height: a tile's cost then belongs to one strip)
+ * chosen where the running sum is nearest to r / world of the total.  Every rank keeps at least `align` rows
+ * while there are enough; rows without a cost count as a thousandth of the mean, so a frame that has not been
+ * rendered yet gives the equal split.  Pure host arithmetic, the same on every rank. */
+int solr_hip_balanced_strips(const float *rowCost, int height, int world, int align, int *firstRows, int *nbRows)
+{
+    if (!rowCost || height < 1 || world < 1 || align < 1 || !firstRows || !nbRows)
+        return -1;
+    const int blocks = (height + align - 1) / align;
+    std::vector<double> prefix((size_t)blocks + 1, 0.0);
+    double total = 0.0;
+    for (int y = 0; y < height; ++y)
+        if (rowCost[y] > 0.f && rowCost[y] < 1e30f)
+            total += rowCost[y];
+    const double floor = total > 0.0 ? 1e-3 * total / height : 1.0;
+    for (int b = 0; b < blocks; ++b)
+    {
+        double sum = 0.0;
+        for (int y = b * align; y < std::min(height, (b + 1) * align); ++y)
+            sum += floor + ((rowCost[y] > 0.f && rowCost[y] < 1e30f) ? (double)rowCost[y] : 0.0);
+        prefix[(size_t)b + 1] = prefix[b] + sum;
+    }
+    const double all = prefix[blocks];
+    std::vector<int> cut((size_t)world + 1, 0); /* in blocks */
+    cut[world] = blocks;
+    int at = 0;
+    for (int r = 1; r < world; ++r)
+    {
+        const double target = all * r / world;
+        while (at < blocks && prefix[(size_t)at + 1] <= target)
+            ++at; /* prefix[at] <= target < prefix[at + 1] */
+        int best = (at < blocks && prefix[(size_t)at + 1] - target < target - prefix[at]) ? at + 1 : at;
+        /* at least one block for every rank if there are that many (else whoever the sums leave without) */
+        const bool room = blocks >= world;
+        best = std::max(best, cut[r - 1] + (room ? 1 : 0));
+        best = std::min(best, room ? blocks - (world - r) : blocks);
+        cut[r] = best;
+    }
+    for (int r = 0; r < world; ++r)
+    {
+        const int from = std::min(height, cut[r] * align), to = std::min(height, cut[r + 1] * align);
+        firstRows[r] = from;
+        nbRows[r] = std::max(0, to - from);
+    }
+    return 0;
+}
+
+/* The strips of all ranks, when they are not solr_hip_strip_rows' (balanced ones): what solr_hip_gather_strips
+ * and the depth-halo exchange take the other ranks' rows from.  Contiguous, in rank order, covering the frame;
+ * world = 0 forgets the table.  This process's own strip is still set with solr_hip_set_strip. */
+int solr_hip_set_strip_table(const int *firstRows, const int *nbRows, int world, int height)
+{
+    if (world == 0 || !firstRows || !nbRows)
+    {
+        stripTable.first.clear();
+        stripTable.count.clear();
+        stripTable.height = 0;
+        return 0;
+    }
+    int next = 0;
+    bool fine = world > 0 && height > 0;
+    for (int r = 0; fine && r < world; ++r)
+    {
+        fine = nbRows[r] >= 0 && (nbRows[r] == 0 || firstRows[r] == next);
+        next += nbRows[r];
+    }
+    if (!fine || next != height)
+    {
+        setError(1, "solr_hip_set_strip_table: the strips are not contiguous, in rank order and covering the frame",
+                 __FILE__, __LINE__);
+        return -1;
+    }
+    stripTable.first.assign(firstRows, firstRows + world);
+    stripTable.count.assign(nbRows, nbRows + world);
+    stripTable.height = height;
+    return 0;
+}
+
+/* What the rows of this process's strip cost in the frame rendered last: rowCost[y] for the rows of the strip
+ * (frame coordinates; a tile's measured duration shared out over its rows), 0 elsewhere.  Needs tile scheduling
+ * (solr_hip_set_tile_scheduling 1 or 2, the default) and a frame; waits for the frames in flight. */
+int solr_hip_strip_row_costs(float *rowCost, int height)
+{
+    if (!ready("solr_hip_strip_row_costs"))
+        return -1;
+    ARGCHECK(rowCost != nullptr && height == g.height, "solr_hip_strip_row_costs: rowCost[height of the frame]");
+    ARGCHECK(g.tileCost.ptr != nullptr && g.costFrames > 0 && g.costKey[0] > 0 && g.costKey[1] > 0,
+             "solr_hip_strip_row_costs: no frame has recorded tile costs (tile scheduling off?)");
+    if (!ok())
+        return -1;
+    quiesce();
+    const int nbTiles = (int)g.costKey[0], tilesX = (int)g.costKey[1], firstRow = (int)g.costKey[2], nbRows = (int)g.costKey[3];
+    std::vector<unsigned> cost((size_t)nbTiles);
+    HIPCHECK(hipMemcpy(cost.data(), g.tileCost.ptr, cost.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (!ok())
+        return -1;
+    for (int y = 0; y < height; ++y)
+        rowCost[y] = 0.f;
+    for (int t = 0; t < nbTiles; ++t)
+    {
+        const int y0 = (t / tilesX) * TILE, y1 = std::min(nbRows, y0 + TILE);
+        for (int y = y0; y < y1; ++y)
+            if (firstRow + y < height)
+                rowCost[firstRow + y] += (float)cost[t] / (float)(y1 - y0);
+    }
+    return 0;
+}
+
+/* Every rank, between frames, after a few frames on the current strips: the rows' costs of all ranks summed
+ * (one ncclAllReduce of `height` floats), balanced strips from them, the table for the gather and this
+ * process's own strip set - the next cudaRender renders it.  A host without a control plane of its own needs
+ * nothing else; one that has (torch.distributed in bench.py) can do the sum there and call
+ * solr_hip_balanced_strips + solr_hip_set_strip_table + solr_hip_set_strip itself. */
+int solr_hip_balance_strips(void)
+{
+    if (!ready("solr_hip_balance_strips"))
+        return -1;
+    ARGCHECK(rccl.comm != nullptr, "solr_hip_balance_strips: no communicator (solr_hip_comm_init)");
+    if (!ok())
+        return -1;
+    const int height = g.height;
+    std::vector<float> cost((size_t)height, 0.f);
+    if (stripRows() > 0 && solr_hip_strip_row_costs(cost.data(), height) != 0)
+        return -1;
+    DeviceBuffer sum;
+    reserve(sum, cost.size() * sizeof(float));
+    if (!ok())
+        return -1;
+    const hipStream_t stream = flightStream(0);
+    HIPCHECK(hipMemcpyAsync(sum.ptr, cost.data(), cost.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    const int RCCL_SUM = 0; /* ncclSum, rccl.h */
+    bool fine = ok() && rcclOk(rccl.AllReduce(sum.ptr, sum.ptr, cost.size(), RCCL_FLOAT32, RCCL_SUM, rccl.comm, stream),
+                               "ncclAllReduce");
+    if (fine)
+    {
+        HIPCHECK(hipMemcpyAsync(cost.data(), sum.ptr, cost.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        fine = ok();
+    }
+    release(sum);
+    if (!fine)
+        return -1;
+    std::vector<int> first((size_t)rccl.world), count((size_t)rccl.world);
+    if (solr_hip_balanced_strips(cost.data(), height, rccl.world, TILE, first.data(), count.data()) != 0 ||
+        solr_hip_set_strip_table(first.data(), count.data(), rccl.world, height) != 0)
+        return -1;
+    solr_hip_set_strip(first[rccl.rank], count[rccl.rank]);
+    return ok() ? 0 : -1;
+}
+
 int solr_hip_comm_unique_id(void *id128)
 {
     if (!id128 || !loadRccl())
@@ -4160,10 +4335,11 @@ int solr_hip_gather_strips(int root)
     const int flight = g.current;
     const hipStream_t stream = flightStream(flight);
     const size_t rowBytes = (size_t)g.width * SOLR_COLOR_DEPTH;
-    int first = 0, count = 0, per = 0;
-    solr_hip_strip_rows(rccl.rank, rccl.world, g.height, &first, &count, &per);
+    int first = 0, count = 0;
+    stripOf(rccl.rank, rccl.world, g.height, &first, &count);
     ARGCHECK(rccl.world == 1 || (g.nbRows == count && (count == 0 || g.firstRow == first)),
-             "solr_hip_gather_strips: this process's strip is not the one solr_hip_strip_rows gives its rank");
+             "solr_hip_gather_strips: this process's strip is not the one solr_hip_strip_rows (or the table of "
+             "solr_hip_set_strip_table) gives its rank");
     if (!ok())
         return -1;
     if (rccl.world == 1) /* one process: the strip is whatever was set, the "gather" a copy into the frame */
@@ -4184,7 +4360,7 @@ int solr_hip_gather_strips(int root)
         {
             int rf = first, rc = count;
             if (rccl.world > 1)
-                solr_hip_strip_rows(r, rccl.world, g.height, &rf, &rc, nullptr);
+                stripOf(r, rccl.world, g.height, &rf, &rc);
             if (rc > 0)
                 fine = rcclOk(rccl.Recv((char *)rccl.frame[flight].ptr + (size_t)rf * rowBytes, (size_t)rc * rowBytes,
                                         RCCL_UINT8, r, rccl.comm, stream),
@@ -4222,6 +4398,7 @@ int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap)
 
 void solr_hip_comm_finalize(void)
 {
+    solr_hip_set_strip_table(nullptr, nullptr, 0, 0); /* the table was that communicator's */
     if (rccl.comm)
     {
         (void)hipDeviceSynchronize();

@@ -1,6 +1,7 @@
 """Development aid: what ONE rank of an N-GPU run sustains in the renderer - frames of its row strip per
 millisecond with 1 ... 4 frames in flight, on one GPU (no gather).  A 1/8 strip of the 1080p frame is one
-round of waves: its frame takes as long as its longest wave unless several frames overlap."""
+round of waves: its frame takes as long as its longest wave unless several frames overlap.
+    python tools/strip_throughput.py [scene] [all]      # all: every rank of the eight, not ranks 0, 4 and 7"""
 import os, sys, time, importlib, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 solr = importlib.import_module("sol-r_amd")
@@ -8,7 +9,7 @@ hip = solr.hip_lib()
 scene = sys.argv[1] if len(sys.argv) > 1 else "cornell"
 W, H = 1920, 1080
 for world in (1, 8):
-    for rank in sorted(set([0, world // 2, world - 1])):
+    for rank in (range(world) if "all" in sys.argv[2:] else sorted(set([0, world // 2, world - 1]))):
         k = solr.Kernel(engine="hip", device=0)
         kw = dict(width=W, height=H)
         if scene == "cornell":
