@@ -4261,7 +4261,10 @@ int solr_hip_balance_strips(void)
         return -1;
     const int height = g.height;
     std::vector<float> cost((size_t)height, 0.f);
-    if (stripRows() > 0 && solr_hip_strip_row_costs(cost.data(), height) != 0)
+    /* a rank that has nothing to report (an empty strip, tile scheduling off, no frame yet) still takes part in
+     * the sum - staying away would leave the others waiting in the collective */
+    const bool recorded = stripRows() > 0 && g.tileCost.ptr != nullptr && g.costFrames > 0 && g.costKey[0] > 0;
+    if (recorded && solr_hip_strip_row_costs(cost.data(), height) != 0)
         return -1;
     DeviceBuffer sum;
     reserve(sum, cost.size() * sizeof(float));
