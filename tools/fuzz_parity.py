@@ -187,8 +187,11 @@ if __name__ == "__main__":
             world = 2 + seed % 3
             full = k.render()
             assembled = np.zeros_like(full)
+            # odd seeds: strips of equal cost (from the tile durations of the frame just rendered) instead of
+            # equal strips
+            cut = solr.balanced_strips(solr.strip_row_costs(H), world) if seed % 2 else None
             for rank in range(world):
-                row0, rows, _ = solr.strip_rows(rank, world, H)
+                row0, rows = cut[rank] if cut else solr.strip_rows(rank, world, H)[:2]
                 if rows <= 0:
                     continue
                 hip.solr_hip_set_strip(row0, rows)
