@@ -686,14 +686,16 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
          * work were spread evenly over the chip's 4096 wave slots (256 CUs x 16 resident waves of this
          * kernel) - such a tile IS the frame's critical path - and more than twice the mean.  A frame whose
          * longest tile is short against that (Cornell: 0.1 ms of 0.35; the molecule: 0.5 of 1.0) is bound by
-         * throughput, and there the 3.2 x work of four quadrant waves is a loss; so it is with several frames
-         * in flight, which hide a critical path behind the next frame (sort == 2: no split). */
+         * throughput, and there the 3.2 x work of four quadrant waves is a loss.  Frames in flight (sort = how
+         * many) hide a critical path behind the next frames: the bar is that many times higher - which no tile
+         * of a whole 1080p frame passes, but the horizon tile of the mesh in a 1/8 strip does (a rank of an
+         * eight-GPU frame: its strip is as slow as that one wave however many frames overlap). */
         const unsigned c = (unsigned)t;
         const float mean = (float)sumCost / (float)max(n, 1);
-        const float critical = fmaxf(2.f * mean, (float)sumCost / 5120.f);
+        const float critical = fmaxf(2.f * mean, (float)sort * (float)sumCost / 5120.f);
         const unsigned above = min(63u, (unsigned)(critical * toClass)) + 1u;
         const unsigned upTo = scan[1023 - (c << 4)];
-        if (sort == 1 && c >= above && c < 64u && upTo <= (unsigned)SPLIT_TILES_MAX)
+        if (c >= above && c < 64u && upTo <= (unsigned)SPLIT_TILES_MAX)
             atomicMin(&splitClass, c);
     }
     __syncthreads();
@@ -2081,7 +2083,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             DeviceBuffer &orderOut = target ? g.tileOrder2 : g.tileOrder;
             hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, stream, (const unsigned *)g.tileCost.ptr,
                                (unsigned *)g.tileCostSnapshot.ptr, (unsigned *)orderOut.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev,
-                               sort ? (twoFlights() ? 2 : 1) : 0);
+                               sort ? activeFlights() : 0);
             HIPCHECK(hipGetLastError());
             if (sort)
             {
