@@ -208,7 +208,7 @@ void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYI
 void solr_hip_enable_timing(int enable);
 double solr_hip_kernel_time(int *nbLaunches, int reset);
 
-/* Frames in flight.  n = 2..4: consecutive first-pass frames (pathTracingIteration == 0) rotate over n
+/* Frames in flight.  n = 2..4 (whole frames gain nothing beyond 3, a 1/8 strip of a multi-GPU frame up to 4): consecutive first-pass frames (pathTracingIteration == 0) rotate over n
  * streams and n sets of per-pixel buffers owned by the engine, so that the tail of a frame - a few long
  * waves on an otherwise idle chip - overlaps the start of the next one (the 100k-triangle frame:
  * 0.76 -> 0.60 ms with two).  Refinement and accumulation passes stay on the set of the pass before them.

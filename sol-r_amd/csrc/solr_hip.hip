@@ -1229,6 +1229,10 @@ struct DeviceBuffer
     size_t bytes = 0;
 };
 
+/* frames in flight at most (per-pixel buffer sets and streams).  Whole 1080p frames gain nothing beyond three, a
+ * 1/8 strip - one round of waves, as slow as its longest - up to four; six and eight were tried (the mesh's
+ * slowest strip: 0.114 ms with three, 0.089 with four, 0.12 and 0.11 with six and eight). */
+const int MAX_FLIGHTS = 4;
 struct Engine
 {
     bool initialized = false;
@@ -1279,7 +1283,7 @@ struct Engine
     /* per-pixel buffers of the strip */
     DeviceBuffer pp, ids, bitmap, counters, tileClock, tileCost, tileCostSnapshot, tileOrder;
     /* ambient occlusion across strips: the depths of the neighbours' rows next to this rank's strip */
-    DeviceBuffer haloAbove[4], haloBelow[4], haloSendTop[4], haloSendBottom[4]; /* per frame in flight (MAX_FLIGHTS) */
+    DeviceBuffer haloAbove[MAX_FLIGHTS], haloBelow[MAX_FLIGHTS], haloSendTop[MAX_FLIGHTS], haloSendBottom[MAX_FLIGHTS]; /* per frame in flight */
     DeviceBuffer haloGivenAbove, haloGivenBelow; /* solr_hip_set_depth_halo */
     int haloSuppliedAbove = 0, haloSuppliedBelow = 0; /* rows handed over by solr_hip_set_depth_halo (0: none) */
     float randomsReach = 0.f;                          /* max |randoms[i]|, i < 356: what the 256 taps can read */
@@ -1287,13 +1291,13 @@ struct Engine
      * over n streams and n sets of per-pixel buffers, so that the tail of one frame - a few long waves
      * on an otherwise idle chip - overlaps the start of the next.  Set 0 is the members above. */
     int flights = 1;
-    hipStream_t extraStream[3] = {nullptr, nullptr, nullptr}; /* streams of sets 1..3 */
+    hipStream_t extraStream[MAX_FLIGHTS - 1] = {}; /* streams of sets 1 .. MAX_FLIGHTS - 1 */
     bool callerStreams = false; /* the streams belong to the caller (solr_hip_set_flight_streams) */
-    DeviceBuffer ppX[3], idsX[3], bitmapX[3], tileOrder2;
+    DeviceBuffer ppX[MAX_FLIGHTS - 1], idsX[MAX_FLIGHTS - 1], bitmapX[MAX_FLIGHTS - 1], tileOrder2;
     int current = 0;           /* set / stream of the last render */
     unsigned frameSerial = 0;
     hipEvent_t orderEvent = nullptr; /* completion of the last tile sort */
-    bool orderWait[4] = {false, false, false, false}; /* that stream has not yet waited for it */
+    bool orderWait[MAX_FLIGHTS] = {}; /* that stream has not yet waited for it */
     int orderBuffer = 0;       /* which of tileOrder / tileOrder2 holds the valid order */
     /* cost-ordered launch: 0 off, 1 automatic (default), 2 always */
     int tileScheduling = 1;
@@ -1336,7 +1340,6 @@ struct Engine
 
 Engine g;
 
-const int MAX_FLIGHTS = 4;
 /* how many frames may really be in flight: what was asked for, as far as streams exist */
 int activeFlights()
 {

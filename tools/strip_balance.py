@@ -11,7 +11,7 @@ hip = solr.hip_lib()
 scene = sys.argv[1] if len(sys.argv) > 1 else "cornell"
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 W, H = 1920, 1080
-FLIGHTS = 3
+FLIGHTS = int(os.environ.get("STRIP_FLIGHTS", "3"))
 
 
 def strip_time(first, count, costs=None):
