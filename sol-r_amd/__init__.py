@@ -538,11 +538,16 @@ def set_strip_table(strips, height):
     return hip_lib().solr_hip_set_strip_table(first, count, world, height)
 
 
-def gather_strips(dist, torch, strip, rows_per_rank, width, height, rank, world, dst=0, slots=None, assemble=True):
+def gather_strips(dist, torch, strip, rows_per_rank, width, height, rank, world, dst=0, slots=None, assemble=True,
+                  strips=None):
     """One collective: every rank's RGB8 strip (a flat uint8 tensor of count*width*3 bytes) to `dst`.
     Returns the assembled (height, width, 3) image on `dst`, None elsewhere.  Works for the nccl
     (= RCCL over xGMI) and gloo backends.  `slots` lets the caller keep the receive buffers across
-    frames; assemble=False skips the final concatenation (the strips then stay in `slots`)."""
+    frames; assemble=False skips the final concatenation (the strips then stay in `slots`).
+    `strips` = [(first_row, nb_rows)] in rank order when they are not the equal ones of strip_rows (balanced_strips):
+    the slots are then as large as the largest strip and the image is put together from their used parts."""
+    if strips is not None:
+        rows_per_rank = max(1, max(count for _, count in strips))
     slot = rows_per_rank * width * 3
     send = strip
     if strip.numel() != slot:  # the last strip may be shorter: gather needs equal slots
@@ -553,6 +558,8 @@ def gather_strips(dist, torch, strip, rows_per_rank, width, height, rank, world,
     dist.gather(send, slots if rank == dst else None, dst=dst)
     if rank != dst or not assemble:
         return None
+    if strips is not None:
+        return torch.cat([slots[r][: count * width * 3] for r, (_, count) in enumerate(strips)]).reshape(height, width, 3)
     return torch.cat(slots)[: height * width * 3].reshape(height, width, 3)
 
 

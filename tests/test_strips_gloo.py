@@ -123,3 +123,68 @@ def test_pipelined_gather_assembles_every_frame(solr, tmp_path, height, pipeline
     c = np.arange(3).reshape(1, 1, -1)
     for i in range(nb_frames):
         assert np.array_equal(images[i], ((y * 7 + x * 3 + c * 5 + i * 11) % 251).astype(np.uint8)), i
+
+
+def _balanced_worker(rank, world, port, width, height, out_path):
+    """the cost-balanced form of the loop: equal strips first, the rows' costs summed over
+    the ranks, the same balanced table on every rank, the new strips rendered and gathered.  The cost of a row
+    is taken from the oracle's frame here (pixels that hit something) - on the GPU it is the tiles' durations."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    solr = importlib.import_module("sol-r_amd")
+    from oracle import loader
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k = solr.Kernel(engine="host-only")
+    solr.scenes.cornell(k, width=width, height=height, iterations=2, room=False)
+    k.set_camera((0.0, 0.0, -15000.0), look_at=(0.0, 3500.0, 0.0))    # the spheres in the lower half of the frame
+    flat = k.flat_scene()
+    si, ppi, eye, direction, angles = k.frame_parameters()
+    first, count, _ = solr.strip_rows(rank, world, height)
+    cost = torch.zeros(height, dtype=torch.float32)
+    if count > 0:
+        _, ids, _, _, status = loader.render(flat, si, ppi, eye, direction, angles, first_row=first, nb_rows=count,
+                                             nthreads=2)
+        assert status == 0
+        cost[first:first + count] = torch.from_numpy((ids[..., 0] >= 0).sum(axis=1).astype(np.float32))
+    dist.all_reduce(cost)
+    table = solr.balanced_strips(cost.numpy(), world)
+    first, count = table[rank]
+    rgb = np.zeros((0, width, 3), np.uint8)
+    if count > 0:
+        _, _, rgb, _, status = loader.render(flat, si, ppi, eye, direction, angles, first_row=first, nb_rows=count,
+                                             nthreads=2)
+        assert status == 0
+    strip = torch.from_numpy(rgb.reshape(-1).copy())
+    image = solr.gather_strips(dist, torch, strip, 0, width, height, rank, world, strips=table)
+    if rank == 0:
+        np.savez(out_path, image=image.numpy(), table=np.array(table), cost=cost.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height,world", [(64, 2), (72, 3)])
+def test_balanced_strips_equal_the_full_frame(solr, oracle, tmp_path, height, world):
+    import torch.multiprocessing as mp
+    width = 64
+    out = str(tmp_path / "balanced.npz")
+    port = 31500 + (os.getpid() % 2000) + height
+    mp.spawn(_balanced_worker, args=(world, port, width, height, out), nprocs=world, join=True)
+    got = np.load(out)
+    k = solr.Kernel(engine="host-only")
+    solr.scenes.cornell(k, width=width, height=height, iterations=2, room=False)
+    k.set_camera((0.0, 0.0, -15000.0), look_at=(0.0, 3500.0, 0.0))    # the spheres in the lower half of the frame
+    flat = k.flat_scene()
+    si, ppi, eye, direction, angles = k.frame_parameters()
+    _, _, full, _, status = oracle.render(flat, si, ppi, eye, direction, angles, nthreads=2)
+    assert status == 0
+    assert np.array_equal(got["image"], full)
+    table, cost = got["table"], got["cost"]
+    assert table[:, 1].sum() == height and (table[:, 0] % 8 == 0).all()
+    # without the room the spheres sit in the middle rows: the balanced strips are not the equal ones, and no
+    # strip carries more than its share plus a tile row
+    assert [tuple(t) for t in table] != [solr.strip_rows(r, world, height)[:2] for r in range(world)]
+    shares = [cost[f:f + c].sum() for f, c in table]
+    assert max(shares) <= cost.sum() / world + cost.reshape(-1, 8).sum(axis=1).max() + 1e-3
