@@ -12,6 +12,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _spawn(worker, args, world):
+    """`world` fresh processes running worker(rank, *args).  The parent does not import torch: torch brings its own
+    copy of the HIP runtime, and a process that has the engine library's copy initialised already (the GPU tests
+    of the same pytest run on a GPU box) corrupts its heap on exit with both."""
+    import multiprocessing
+    ctx = multiprocessing.get_context("spawn")
+    procs = [ctx.Process(target=worker, args=(rank,) + tuple(args)) for rank in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
 def _worker(rank, world, port, width, height, out_path):
     sys.path.insert(0, ROOT)
     import torch
@@ -42,11 +56,10 @@ def _worker(rank, world, port, width, height, out_path):
 # 45: the last strip is one row shorter; (4, 3): strips of 2 rows leave the third process without a row
 @pytest.mark.parametrize("height,world", [(48, 2), (45, 2), (4, 3)])
 def test_strips_equal_the_full_frame(solr, oracle, tmp_path, height, world):
-    import torch.multiprocessing as mp
     width = 64
     out = str(tmp_path / "gathered.npz")
     port = 29500 + (os.getpid() % 2000) + height
-    mp.spawn(_worker, args=(world, port, width, height, out), nprocs=world, join=True)
+    _spawn(_worker, (world, port, width, height, out), world)
     got = np.load(out)
     k = solr.Kernel(engine="host-only")
     solr.scenes.cornell(k, width=width, height=height, iterations=2)
@@ -111,11 +124,10 @@ def _pipeline_worker(rank, world, port, width, height, nb_frames, out_path, pipe
 def test_pipelined_gather_assembles_every_frame(solr, tmp_path, height, pipelined):
     """StripGather (what bench.py runs at N > 1): in-order on one buffer, or two buffers in flight;
     every frame assembled intact."""
-    import torch.multiprocessing as mp
     width, world, nb_frames = 40, 2, 5
     out = str(tmp_path / "frames.npz")
     port = 31500 + (os.getpid() % 2000) + height + (7 if pipelined else 0)
-    mp.spawn(_pipeline_worker, args=(world, port, width, height, nb_frames, out, pipelined), nprocs=world, join=True)
+    _spawn(_pipeline_worker, (world, port, width, height, nb_frames, out, pipelined), world)
     images = np.load(out)["images"]
     assert images.shape == (nb_frames, height, width, 3)
     y = np.arange(height).reshape(-1, 1, 1)
@@ -167,11 +179,10 @@ def _balanced_worker(rank, world, port, width, height, out_path):
 
 @pytest.mark.parametrize("height,world", [(64, 2), (72, 3)])
 def test_balanced_strips_equal_the_full_frame(solr, oracle, tmp_path, height, world):
-    import torch.multiprocessing as mp
     width = 64
     out = str(tmp_path / "balanced.npz")
     port = 31500 + (os.getpid() % 2000) + height
-    mp.spawn(_balanced_worker, args=(world, port, width, height, out), nprocs=world, join=True)
+    _spawn(_balanced_worker, (world, port, width, height, out), world)
     got = np.load(out)
     k = solr.Kernel(engine="host-only")
     solr.scenes.cornell(k, width=width, height=height, iterations=2, room=False)
