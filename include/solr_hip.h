@@ -133,7 +133,9 @@ void solr_hip_set_strip(int firstRow, int nbRows);
  *                             frame, boundaries on multiples of `align` rows (8 = a tile)
  *   solr_hip_set_strip_table  the strips of all ranks, for the gather and the halo exchange (world = 0: forget)
  *   solr_hip_balance_strips   all of it with one ncclAllReduce: every rank, between frames; sets this process's
- *                             strip as well */
+ *                             strip as well.  With the ambient-occlusion post-process the strips are cut on
+ *                             multiples of the taps' reach (a multiple of 8 rows), so that the halo exchange, which
+ *                             trades rows with the next rank only, still covers every tap */
 void solr_hip_strip_rows(int rank, int world, int height, int *firstRow, int *nbRows, int *rowsPerRank);
 int solr_hip_comm_unique_id(void *id128);
 int solr_hip_comm_init(int rank, int world, const void *id128);

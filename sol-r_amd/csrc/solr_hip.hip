@@ -1287,6 +1287,7 @@ struct Engine
     DeviceBuffer haloGivenAbove, haloGivenBelow; /* solr_hip_set_depth_halo */
     int haloSuppliedAbove = 0, haloSuppliedBelow = 0; /* rows handed over by solr_hip_set_depth_halo (0: none) */
     float randomsReach = 0.f;                          /* max |randoms[i]|, i < 356: what the 256 taps can read */
+    int haloWanted = -1; /* rows beyond a strip the last frame's post-processing reached (0: none; -1: no frame here) */
     /* Frames in flight (solr_hip_set_frames_in_flight): with n > 1, consecutive first-pass frames rotate
      * over n streams and n sets of per-pixel buffers, so that the tail of one frame - a few long waves
      * on an otherwise idle chip - overlaps the start of the next.  Set 0 is the members above. */
@@ -2174,6 +2175,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         g.events.push_back(std::make_pair(e0, e1));
     }
 
+    g.haloWanted = 0;
     if (neighbourhood)
     {
         const int nbPixels = sceneInfo.size.x * F.nbRows;
@@ -2187,6 +2189,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             {
                 const float reach = 16.f * fabsf(ppInfo.param2) * g.randomsReach / 10.f;
                 const int wanted = reach < 4096.f ? (int)reach + 2 : 4096;
+                g.haloWanted = wanted;
                 if (g.haloSuppliedAbove || g.haloSuppliedBelow)
                 {
                     halo.above = (const float *)g.haloGivenAbove.ptr;
@@ -4265,7 +4268,15 @@ int solr_hip_balance_strips(void)
     if (!ok())
         return -1;
     const int height = g.height;
-    std::vector<float> cost((size_t)height, 0.f);
+    /* two more floats ride along: the rows the ambient-occlusion taps reach beyond a strip (the halo exchange
+     * delivers rows of the next rank only, so no strip may be lower than that) from the ranks that have rendered
+     * a frame, and how many they are - every rank must cut with the same `align` */
+    std::vector<float> cost((size_t)height + 2, 0.f);
+    if (g.haloWanted >= 0)
+    {
+        cost[(size_t)height] = (float)g.haloWanted;
+        cost[(size_t)height + 1] = 1.f;
+    }
     /* a rank that has nothing to report (an empty strip, tile scheduling off, no frame yet) still takes part in
      * the sum - staying away would leave the others waiting in the collective */
     const bool recorded = stripRows() > 0 && g.tileCost.ptr != nullptr && g.costFrames > 0 && g.costKey[0] > 0;
@@ -4289,8 +4300,10 @@ int solr_hip_balance_strips(void)
     release(sum);
     if (!fine)
         return -1;
+    const int reach = cost[(size_t)height + 1] > 0.f ? (int)(cost[(size_t)height] / cost[(size_t)height + 1] + 0.5f) : 0;
+    const int align = std::max(TILE, (reach + TILE - 1) / TILE * TILE);
     std::vector<int> first((size_t)rccl.world), count((size_t)rccl.world);
-    if (solr_hip_balanced_strips(cost.data(), height, rccl.world, TILE, first.data(), count.data()) != 0 ||
+    if (solr_hip_balanced_strips(cost.data(), height, rccl.world, align, first.data(), count.data()) != 0 ||
         solr_hip_set_strip_table(first.data(), count.data(), rccl.world, height) != 0)
         return -1;
     solr_hip_set_strip(first[rccl.rank], count[rccl.rank]);
