@@ -140,6 +140,14 @@ def test_balanced_strips_partition_the_frame_and_even_out_the_cost(solr):
     cost[:56] = 1.0e6
     strips = solr.balanced_strips(cost, 8)
     assert [c for _, c in strips[:7]] == [8] * 7 and strips[7] == (56, 1024)
+    # strips no lower than the reach of the ambient-occlusion taps: cut on multiples of it
+    rng = np.random.RandomState(9)
+    cost = rng.gamma(0.3, 1000.0, size=2160).astype(np.float32)
+    for align in (24, 40, 272):
+        strips = solr.balanced_strips(cost, 8, align=align)
+        _check_partition(strips, 2160, align=align)
+        if (2160 + align - 1) // align >= 8:
+            assert all(count >= min(align, 2160 - first) for first, count in strips)
     hip = solr.hip_lib()
     assert hip.solr_hip_balanced_strips(None, 10, 2, 8, None, None) == -1
 
