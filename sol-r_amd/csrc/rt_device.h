@@ -1438,8 +1438,8 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
      * order - they find a hit there if they found one here (a candidate outside the band passes the reference's
      * cut-off against the initial bound), so nothing needs restoring.  For every other lane the minimum is unique
      * by a margin no rounding bridges, and the reference, whose cut-off cannot hide it from any larger bound,
-     * returns it.  Only in the long-list triangle instantiations (the mesh's bounce rays along the terrain were
-     * its longest waves: one frame alone 0.435 -> 0.417 ms); compiled into every kernel it costs the Cornell box
+     * returns it.  Only in the long-list triangle instantiations (the mesh: its bounce rays along the terrain
+     * are a third of its longest wave, one frame alone 0.435 -> 0.417 ms); compiled into every kernel it costs the Cornell box
      * 3 % and the molecule 0.7 % (short lists, few bounce rays, the bookkeeping in every accept). */
     constexpr bool CHECKED_BUILD = !COUNT && (FEAT & F_DEEP) != 0 && (FEAT & F_TRI) != 0;
     const float dd = dot(r.d, r.d);
