@@ -7,7 +7,12 @@ k_standardRenderer over this rank's row strip (scene resident in HBM, uploaded b
 the timed region) and, for N > 1, the RCCL gather of the RGB strips to rank 0.
 
   python bench.py --gpus 1 --steps 200 --warmup 3
+  python bench.py --gpus N ...                      (bare: starts its own N rank processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: row strips re-cut by measured cost (solr_hip_balance_strips), gathered to rank 0 with RCCL called from the
+engine's C ABI on the stream that rendered the frame; the reference's equal split is timed as a second segment, the
+assembled frame is compared with the frame rank 0 renders alone, per-rank times and the gather alone are reported.
 
 Rank 0 prints ONE JSON line.  `value` = (closest-hit walks + shadow walks of the whole
 frame) * steps / wall time / 1e6, summed over all ranks, max wall time over ranks.
@@ -33,6 +38,7 @@ PREROLL_FRAMES = 48    # untimed setup frames before the W warmup steps
 # algorithmic bytes per pixel of one launch of the renderer (SURVEY.md section 8d with k_default fused):
 FIRST_PASS_BYTES_PER_PIXEL = 51    # pass 0: 16 (ids write) + 32 (float frame buffer write) + 3 (RGB); nothing is read
 LATER_PASS_BYTES_PER_PIXEL = 99    # refinement / accumulation passes also read the ids (16) and the frame buffer (32)
+SURVEY_FUSED_BYTES_PER_PIXEL = 67  # SURVEY.md 8(d) with k_default fused: + the 16 B ids read of the early-out test
 # MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 vector instruction issues over 2 cycles; one scalar unit per CU
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
 SALU_PEAK_WAVE_INSTS_PER_S = 256 * 2.4e9
@@ -56,27 +62,27 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="consecutive frames rotate over this many streams and buffer sets of the engine, so a "
                          "frame's tail overlaps the next frame's start; 1: the reference's one frame at a time. "
-                         "Default: 2 at N = 1, 3 at N > 1 (strips are one round of waves with a long tail)")
+                         "Default 3 (strips are one round of waves with a long tail)")
     ap.add_argument("--config", default="", choices=["", "cfg1", "cfg2", "cfg3", "cfg4"],
                     help="a BASELINE.json configuration by name: cfg1 = the default (Cornell 1080p, 3 bounces), cfg2 = "
                          "--scene height_field, cfg3 = --scene molecule, cfg4 = Cornell 3840x2160 through passes 0...73 "
                          "(refinement + 64 accumulated samples, natural depth of field, ambient-occlusion kernel): a "
                          "step is then one pass of that cycle")
-    ap.add_argument("--balanced-strips", action="store_true",
-                    help="N > 1: after the set-up frames, re-cut the row strips so that every rank gets the same cost "
-                         "(solr_hip_balance_strips: the rows' measured costs, one ncclAllReduce, strips on tile "
-                         "boundaries) instead of the same number of rows; implies --native-gather")
-    ap.add_argument("--native-gather", action="store_true",
-                    help="N > 1: gather the strips with RCCL called from the engine's C ABI (solr_hip_gather_strips, on "
-                         "the stream that rendered the frame) instead of torch.distributed's gather; torch then only "
-                         "carries the rendezvous, the barrier and the timing reduction (gloo).  Also SOLR_BENCH_NATIVE_GATHER=1")
+    ap.add_argument("--equal-strips", action="store_true",
+                    help="N > 1: keep the reference's equal row strips for the headline segment (default: strips re-cut "
+                         "by measured cost after the set-up frames, solr_hip_balance_strips; the equal split is then "
+                         "timed as a second segment and reported next to it)")
+    ap.add_argument("--torch-gather", action="store_true",
+                    help="N > 1: gather the strips with torch.distributed's gather (NCCL backend = RCCL) on equal strips "
+                         "instead of RCCL called from the engine's C ABI on the frame's own stream (the default)")
+    # accepted for the command lines of earlier rounds: both are the default now
+    ap.add_argument("--balanced-strips", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--native-gather", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-check", action="store_true",
+                    help="N > 1: skip the comparison of the gathered frame with the frame rank 0 renders alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
-
-
-def main():
-    args = parse()
+    args = ap.parse_args()
     if args.config == "cfg2":
         args.scene = "height_field"
     elif args.config == "cfg3":
@@ -84,9 +90,79 @@ def main():
     elif args.config == "cfg4":
         args.scene, args.width, args.height, args.iterations = "cornell", 3840, 2160, 1
         args.frames_in_flight = 1          # every pass reads what the pass before left in the frame buffers
-    cfg4 = args.config == "cfg4"
     if args.steps is None:
-        args.steps = 74 if cfg4 else 200   # cfg4's passes differ in cost (refinement passes re-render with more bounces)
+        args.steps = 74 if args.config == "cfg4" else 200   # cfg4's passes differ in cost: whole cycles
+    if args.frames_in_flight <= 0:
+        args.frames_in_flight = 3   # measured: 1 -> 0.311, 2 -> 0.292, 3 -> 0.288, 4 -> 0.286 ms per Cornell frame
+    return args
+
+
+def launch(args):
+    """`python bench.py --gpus N` started bare: this process becomes the launcher - it never touches the GPU - and
+    starts N fresh rank processes of this same command (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, exactly what torch.distributed.run would set).  Rank 0's stdout is relayed (its last line is the
+    JSON line), the other ranks' goes to stderr.  Any rank that ends with an error ends the job: the others get ten
+    seconds, then are killed by pid, and the launcher exits with that rank's code."""
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    share = os.environ.get("SOLR_BENCH_SHARE_GPU") == "1"
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("SOLR_BENCH_TIMEOUT", "1500"))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = bad[0] if bad else (-1, 124)
+            grace = time.time() + 10.0
+            while time.time() < grace and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    reader.join(timeout=5.0)
+    sys.stdout.write("".join(x.decode(errors="replace") if isinstance(x, bytes) else x for x in lines))
+    sys.stdout.flush()
+    bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+    if failed or bad:
+        r, code = failed or bad[0]
+        print("bench.py: %s; the job is void" % ("rank %d ended with code %s" % (r, code) if r >= 0 else
+                                                   "no result within SOLR_BENCH_TIMEOUT"), file=sys.stderr)
+        return code if isinstance(code, int) and 0 < code < 256 else 1
+    return 0
+
+
+def spread(samples, divide=1.0):
+    """min / median / max of a list of milliseconds (the error bar of a short timed region)"""
+    xs = sorted(float(x) / divide for x in samples if x is not None and x >= 0.0)
+    if not xs:
+        return None
+    return {"min": round(xs[0], 5), "median": round(xs[len(xs) // 2], 5), "max": round(xs[-1], 5), "samples": len(xs)}
+
+
+def main():
+    args = parse()
+    # bare `python bench.py --gpus N` (no launcher's environment): become the launcher, before anything of the GPU
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args))
+    cfg4 = args.config == "cfg4"
     if os.environ.get("SOLR_BENCH_DEBUG"):
         import faulthandler
         import signal
@@ -96,28 +172,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    share = os.environ.get("SOLR_BENCH_SHARE_GPU") == "1"   # rehearsal on a one-GPU box: every rank on GPU 0
+    if share:
+        local_rank = 0
 
     torch = dist = None
-    # SOLR_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, strip binding, gather) with a
+    # SOLR_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, strips, communicator, gather, check) with a
     # single rank: a 1-GPU box can then exercise it against RCCL
     distributed = world > 1 or os.environ.get("SOLR_BENCH_FORCE_DIST") == "1"
-    # cfg4's ambient-occlusion taps cross the strips: with the library's own communicator cudaRender trades the
-    # boundary rows' depths between neighbouring ranks (no seams); the torch gather has no such leg
-    native = distributed and (args.native_gather or args.balanced_strips or cfg4 or
-                              os.environ.get("SOLR_BENCH_NATIVE_GATHER") == "1")
-    if native:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="gloo")       # control plane only: rendezvous, barrier, timing reduction
-    elif distributed:
+    torch_gather = distributed and args.torch_gather and not cfg4   # (cfg4's ambient-occlusion taps cross the strips:
+    native = distributed and not torch_gather                       #  only the library's own communicator trades them)
+    balanced = native and not args.equal_strips
+    if distributed:
         # torch BEFORE the engine library: torch brings its own copy of the HIP runtime and importing it
         # into a process in which another copy is already initialised hangs
         import torch
@@ -126,13 +194,18 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     solr = importlib.import_module("sol-r_amd")
     hip = solr.hip_lib()
-    if hip.solr_hip_device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    visible = hip.solr_hip_device_count()
+    if visible < 1 or (local_rank >= visible):
+        raise SystemExit("bench.py rank %d needs a GPU (device %d of %d visible): the engine has no CPU fallback"
+                         % (rank, local_rank, visible))
+    if native:
+        dist.init_process_group(backend="gloo")       # control plane only: rendezvous, barrier, timing reduction
+    elif distributed:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = args.width, args.height
     first_row, nb_rows, rows_per_rank = solr.strip_rows(rank, world, H)
@@ -157,15 +230,12 @@ def main():
         k.set_scene_info(graphicsLevel=args.graphics_level)
     hip.solr_hip_set_variant(args.variant)
     hip.solr_hip_set_tile_scheduling(args.tile_scheduling)
-    if args.frames_in_flight <= 0:
-        args.frames_in_flight = 3   # measured: 1 -> 0.311, 2 -> 0.292, 3 -> 0.288, 4 -> 0.286 ms per Cornell frame
-    if not distributed:
+    if not distributed or native:
         hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
     pipe = None
     if native:
         # the data path without torch: this rank's strip, K frames in flight on the engine's own streams, and
         # behind every frame the library's own RCCL gather on that frame's stream
-        hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
         hip.solr_hip_set_strip(first_row, nb_rows)
     elif distributed:
         # every frame: render on one of the engine's streams, then the gather in order on that same
@@ -189,6 +259,7 @@ def main():
             pass_counter[0] += 1
         hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
 
+    rccl_ranks = None
     if native:
         # the communicator: rank 0's id to everybody over the control plane, then ncclCommInitRank in the library
         uid = C.create_string_buffer(128)
@@ -199,11 +270,12 @@ def main():
         uid = C.create_string_buffer(box[0], 128)
         if hip.solr_hip_comm_init(rank, world, uid) != 0:
             k.check(-1, "solr_hip_comm_init")
+        rccl_ranks = int(hip.solr_hip_comm_ranks())
 
     def frame():
         # N = 1: the renderer alone.  N > 1: the renderer writes RGB8 straight into a strip buffer and the
-        # single collective of the path - strips -> rank 0, RCCL over xGMI - follows (StripPipeline, or the
-        # library's own gather)
+        # single collective of the path - strips -> rank 0, RCCL over xGMI - follows (the library's own gather on
+        # the frame's stream, or StripPipeline)
         if native:
             render()
             if hip.solr_hip_gather_strips(0) != 0:
@@ -223,7 +295,8 @@ def main():
         if distributed:
             dist.barrier()
 
-    # ---- ray census of this rank's strip (untimed; input-determined)
+    # ---- ray census of this rank's (equal) strip (untimed; input-determined; the frame's total does not depend on
+    # how it is cut)
     counts = (C.c_ulonglong * 8)()
     hip.solr_hip_render_counting(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles),
                                  counts)
@@ -256,42 +329,65 @@ def main():
     watchdog.daemon = True
     watchdog.start()
 
+    stride = 4 if distributed else 1   # event pairs cost launch gaps: every launch at N = 1, every fourth on strips
+
+    def timed(steps, warmup):
+        """W untimed steps, then exactly K timed ones between barrier + synchronisation on both sides"""
+        for _ in range(warmup):
+            frame()
+        sync()
+        hip.solr_hip_kernel_time(None, 1)
+        hip.solr_hip_enable_timing(stride)
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            frame()
+        t_issued = time.perf_counter()
+        sync()
+        t_drained = time.perf_counter()
+        barrier()
+        t1 = time.perf_counter()
+        hip.solr_hip_enable_timing(0)
+        k.check(0, "timed frames")
+        n = max(steps // stride + 2, 4)
+        kernel_samples, gap_samples = (C.c_float * n)(), (C.c_float * n)()
+        got = hip.solr_hip_timing_samples(kernel_samples, gap_samples, n)
+        launches = C.c_int(0)
+        kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
+        return {"elapsed": t1 - t0, "issued": t_issued - t0, "drained": t_drained - t0,
+                "kernel_avg_ms": kernel_ms / max(launches.value, 1), "kernel_samples": list(kernel_samples[:got]),
+                "gap_samples": list(gap_samples[:got]), "strip": current_strip()}
+
+    def current_strip():
+        a, b = C.c_int(), C.c_int()
+        hip.solr_hip_get_strip(C.byref(a), C.byref(b))
+        return [a.value, b.value]
+
     # setup, untimed: let the clocks and the tile-cost feedback of the engine settle before the W
     # warmup steps (a frame is 0.4 ms; W = 3 alone is 1.2 ms of GPU work, shorter than the power ramp)
     for _ in range(PREROLL_FRAMES):
         frame()
     sync()
-    strips = "equal rows"
-    if args.balanced_strips and native:
-        # equal strips share out rows, not work (profiles/r2/strip_balance_*.txt): re-cut them by the cost the
-        # set-up frames recorded, then let the tile-cost feedback settle on the new strips
+    second = None
+    if balanced:
+        # equal strips share out rows, not work (profiles/r2/strip_balance_*.txt): the reference's equal split is
+        # timed first, as the second figure; then the strips are re-cut by the cost the frames recorded, the
+        # tile-cost feedback settles on the new strips, and the headline segment runs on them
+        if world > 1:
+            second = timed(args.steps, args.warmup)
         if hip.solr_hip_balance_strips() != 0:
             k.check(-1, "solr_hip_balance_strips")
-        strips = "balanced by cost"
         for _ in range(PREROLL_FRAMES // 2):
             frame()
         sync()
-    for _ in range(args.warmup):
-        frame()
-    sync()
-    hip.solr_hip_kernel_time(None, 1)
-    # event pairs cost launch gaps: every launch at N = 1, every fourth when frames are short (N > 1)
-    hip.solr_hip_enable_timing(4 if distributed else 1)
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame()
-    t_issued = time.perf_counter()
-    sync()
-    barrier()
-    t1 = time.perf_counter()
-    hip.solr_hip_enable_timing(0)
-    watchdog.cancel()
-    k.check(0, "timed frames")
-    elapsed = t1 - t0
-    launches = C.c_int(0)
-    kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
+    main_run = timed(args.steps, args.warmup)
+    elapsed = main_run["elapsed"]
+    t_issued_ms = main_run["issued"] / args.steps * 1e3
+    kernel_avg_ms = main_run["kernel_avg_ms"]
+    kernel_spread = spread(main_run["kernel_samples"])
+    step_spread = spread(main_run["gap_samples"], divide=float(stride))
+    strips = "balanced by cost" if balanced else "equal rows"
     kernel_basis = "HIP events around every launch of the timed region"
     if distributed and args.frames_in_flight > 1:
         kernel_basis = ("HIP events around every fourth launch of the timed region; with %d frames in flight the launches "
@@ -304,12 +400,17 @@ def main():
         for _ in range(8):
             frame()
         sync()
+        hip.solr_hip_kernel_time(None, 1)
         hip.solr_hip_enable_timing(1)
         for _ in range(16):
             frame()
         sync()
         hip.solr_hip_enable_timing(0)
-        kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
+        samples = (C.c_float * 32)()
+        got = hip.solr_hip_timing_samples(samples, None, 32)
+        kernel_spread = spread(list(samples[:got]))
+        launches = C.c_int(0)
+        kernel_avg_ms = hip.solr_hip_kernel_time(C.byref(launches), 1) / max(launches.value, 1)
         hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
         kernel_basis = "HIP events around each of 16 launches issued one at a time after the timed region"
 
@@ -352,10 +453,58 @@ def main():
                  "cudaRender_plus_image": (with_image_d2h, "render + read-back of the RGB image alone (the ids stay on "
                                            "the device until picking asks: HipKernel::render_end)")}
 
+    # ---- N > 1 extras (untimed): the gather alone, and the assembled frame against the frame one GPU renders
+    gather_only_ms = None
+    check = None
+    if native:
+        import numpy as np
+        for _ in range(8):
+            hip.solr_hip_gather_strips(0)
+        sync()
+        barrier()
+        ta = time.perf_counter()
+        for _ in range(64):
+            hip.solr_hip_gather_strips(0)
+        sync()
+        barrier()
+        gather_only_ms = (time.perf_counter() - ta) / 64 * 1e3
+        k.check(0, "gather alone")
+        if not args.no_check:
+            # one more frame (cfg4: one more cycle of passes 0...73) on the strips of the timed region, gathered;
+            # then everybody leaves the communicator and rank 0 renders the same frame alone, whole
+            keep = {}
+            passes = range(74) if cfg4 else range(1)
+            pass_counter[0] = 0
+            for it in passes:
+                frame()
+                if rank == 0 and it in (0, 11, 73):
+                    got = np.zeros((H, W, 3), np.uint8)
+                    if hip.solr_hip_d2h_gathered(C.c_void_p(got.ctypes.data)) != 0:
+                        k.check(-1, "solr_hip_d2h_gathered")
+                    keep[it] = got
+            sync()
+            barrier()
+            hip.solr_hip_comm_finalize()
+            if rank == 0:
+                hip.solr_hip_set_strip(0, -1)
+                hip.solr_hip_set_frames_in_flight(1)
+                pass_counter[0] = 0
+                same = True
+                for it in passes:
+                    render()
+                    if it in keep:
+                        alone = np.zeros((H, W, 3), np.uint8)
+                        hip.solr_hip_d2h(C.byref(si), C.c_void_p(alone.ctypes.data), None)
+                        same = same and bool(np.array_equal(alone, keep[it]))
+                k.check(0, "the frame on one GPU")
+                check = same
+
     rays_total = rays_local
+    per_rank = None
+    second_out = None
     if distributed:
-        t = torch.tensor([elapsed, float(rays_local), kernel_ms / max(launches.value, 1)], dtype=torch.float64,
-                         device="cpu" if native else "cuda")
+        t = torch.tensor([elapsed, float(rays_local), kernel_avg_ms, second["elapsed"] if second else 0.0],
+                         dtype=torch.float64, device="cpu" if native else "cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -363,14 +512,24 @@ def main():
         elapsed = float(tmax[0])
         rays_total = int(tsum[1])
         kernel_avg_ms = float(tmax[2])
+        mine = {"rank": rank, "rows": main_run["strip"], "ms_per_step_until_own_stream_drained":
+                round(main_run["drained"] / args.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issued_ms, 4),
+                "kernel_ms": round(main_run["kernel_avg_ms"], 5)}
+        if second:
+            mine["equal_strips"] = {"rows": second["strip"], "ms_per_step_until_own_stream_drained":
+                                    round(second["drained"] / args.steps * 1e3, 4),
+                                    "kernel_ms": round(second["kernel_avg_ms"], 5)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        if second:
+            second_out = float(tmax[3])
         # every rank empties its C stdout buffer (RCCL's version banner sits there until exit) before rank 0
         # may print: the JSON line is then the last thing the job writes to stdout
         C.CDLL(None).fflush(None)
         sys.stdout.flush()
         dist.barrier()
-    else:
-        kernel_avg_ms = kernel_ms / max(launches.value, 1)
 
+    watchdog.cancel()
     if native:
         hip.solr_hip_comm_finalize()
     if rank != 0:
@@ -383,8 +542,13 @@ def main():
                    176 * len(set(int(m) for m in flat.primitives["materialId"])))
     # per launch, rank 0's strip: pass 0 writes only; cfg4 cycles through 1 first pass and 73 later ones
     per_pixel = FIRST_PASS_BYTES_PER_PIXEL if not cfg4 else (FIRST_PASS_BYTES_PER_PIXEL + 73 * LATER_PASS_BYTES_PER_PIXEL) / 74.0
-    algo_bytes = int(nb_rows * W * per_pixel) + scene_bytes
+    rows_rank0 = main_run["strip"][1] if distributed else nb_rows
+    algo_bytes = int(rows_rank0 * W * per_pixel) + scene_bytes
     achieved = algo_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+    # the same launch priced with SURVEY.md 8(d)'s fused figure (67 B per pixel: it counts the ids read of the
+    # early-out test, which a first pass does not make)
+    survey_bytes = int(rows_rank0 * W * (SURVEY_FUSED_BYTES_PER_PIXEL if not cfg4 else per_pixel)) + scene_bytes
+    achieved_survey = survey_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
     traffic, traffic_source, traffic_commit = measured_traffic(args, world)
     valu = measured_counters(args, world)
     label = {"cornell": "Cornell", "height_field": "triangle mesh", "molecule": "molecule"}.get(args.scene, args.scene)
@@ -404,22 +568,25 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if args.scene not in ("irt_model", "obj_model", "swc_morphology", "pdb_molecule") else "the reference's sample scene file",
-        "config": {"workload": "%s%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, row strips of %d" %
+        "config": {"workload": "%s%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, %s" %
                    ((args.config + ": ") if args.config else "", args.scene, W, H, si.nbRayIterations, len(flat.boxes),
-                    len(flat.primitives), rows_per_rank),
+                    len(flat.primitives), ("%d row strips, %s" % (world, strips)) if distributed else "one GPU, whole frame"),
                    "rays_per_frame": rays_total, "closest_hit_walks_rank0": int(counts[0]),
                    "shadow_walks_rank0": int(counts[1]), "lane_nodes": int(counts[2]), "lane_prim_tests": int(counts[3]),
                    "wave_nodes": int(counts[4]), "wave_prim_tests": int(counts[5]), "wave_walks": int(counts[6]) + int(counts[7]), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 2),
-                   "host_issue_ms_per_step_rank0": round((t_issued - t0) / args.steps * 1e3, 4),
+                   "host_issue_ms_per_step_rank0": round(t_issued_ms, 4),
                    "cost_ordered_launch_rank0": bool(hip.solr_hip_tile_scheduling_active()),
-                   "frames_in_flight": int(hip.solr_hip_get_frames_in_flight()),
+                   "frames_in_flight": args.frames_in_flight,
                    # untimed set-up frames before the W warm-up steps (clocks, tile-cost feedback, order-free lists)
                    "setup_frames_before_warmup": PREROLL_FRAMES,
+                   # the error bar of the timed region: the time from the end of a timed launch to the end of the next
+                   # (HIP events on the launch streams), per step
+                   "step_ms_spread": step_spread,
                    # nodes per order-free list when long rays' walks use them, else 0
                    "order_free_nodes": int(hip.solr_hip_order_free_nodes()),
                    "gather": ("none (one GPU)" if not distributed else
-                              "RCCL from the engine's C ABI (solr_hip_gather_strips)" if native else
-                              "torch.distributed gather (RCCL)"),
+                              "RCCL from the engine's C ABI (solr_hip_gather_strips), on the stream that rendered the frame"
+                              if native else "torch.distributed gather (RCCL)"),
                    "strips": strips,
                    "parallelism": "tile%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -429,8 +596,29 @@ def main():
                                      "by this run (a process cannot profile itself); null when the workload differs "
                                      "from the profiled one",
                      "kernel": "k_standardRenderer", "kernel_ms": round(kernel_avg_ms, 5), "kernel_ms_basis": kernel_basis,
-                     "algorithmic_bytes": algo_bytes, "algorithmic_bytes_per_pixel": round(per_pixel, 2)},
+                     "kernel_ms_spread": kernel_spread,
+                     "algorithmic_bytes": algo_bytes, "algorithmic_bytes_per_pixel": round(per_pixel, 2),
+                     "frac_with_survey_8d_bytes": round(achieved_survey / HBM_PEAK_GBPS, 6),
+                     "survey_8d_bytes_per_pixel": SURVEY_FUSED_BYTES_PER_PIXEL if not cfg4 else round(per_pixel, 2)},
     }
+    if distributed:
+        slowest = max(per_rank, key=lambda r: r["ms_per_step_until_own_stream_drained"])
+        out["config"].update({
+            "rccl_ranks": rccl_ranks, "per_rank": per_rank, "slowest_rank": slowest["rank"],
+            "gather_only_ms": round(gather_only_ms, 4) if gather_only_ms is not None else None,
+            "gather_only_note": "64 gathers of the last strips back to back on one stream, no rendering in between",
+            # the assembled frame of the strips of the timed region against the same frame rendered whole by rank 0
+            # alone (cfg4: after passes 0, 11 and 73 of a cycle, through the depth-halo exchange), RGB8 bit for bit
+            "gathered_equals_single_gpu": check,
+            "rates_mrays_per_s": {("balanced_strips" if balanced else "equal_strips") +
+                                  ("_native_gather" if native else "_torch_gather"): round(mrays, 1)}})
+        if second_out:
+            out["config"]["rates_mrays_per_s"]["equal_strips_native_gather"] = round(rays_total * args.steps / second_out / 1e6, 1)
+            out["config"]["rates_note"] = {"equal_strips_native_gather": "the reference's equal split, same loop, timed "
+                                           "before the strips were re-cut: %.4f ms per step" % (second_out / args.steps * 1e3)}
+        if share:
+            out["config"]["rehearsal"] = ("SOLR_BENCH_SHARE_GPU=1: every rank on GPU 0 - a rehearsal of the N > 1 code "
+                                          "path, not a measurement of N GPUs")
     if rates:
         out["config"]["rates_mrays_per_s"] = {"pipelined_device_resident": round(mrays, 1)}
         out["config"]["rates_note"] = {"pipelined_device_resident": "`value`: %d frames in flight, image left in HBM" %

@@ -99,6 +99,7 @@ void solr_hip_clear_error(void);
 int solr_hip_device_count(void);
 /* device this process renders on (call before initialize_scene; default 0) */
 void solr_hip_set_device(int device);
+int solr_hip_get_device(void);
 /* stream (a hipStream_t passed as void*) every copy and launch is issued on;
  * NULL = a stream owned by the engine */
 void solr_hip_set_stream(void *stream);
@@ -111,20 +112,39 @@ void solr_hip_synchronize(void);
  * nothing.  The device buffers hold only the strip (row 0 of the buffer =
  * firstRow); d2h_bitmap places it at its position in a full-size host image. */
 void solr_hip_set_strip(int firstRow, int nbRows);
+/* the strip in force (after solr_hip_balance_strips: the one it cut for this rank) */
+void solr_hip_get_strip(int *firstRow, int *nbRows);
 
 /* Multi-GPU without any framework: one process per GPU, the frame split into row strips as the reference
  * splits it over the devices of its one process (CudaRayTracer.cu:1694-1696, 1709-1815), the strips sent
  * to one root with RCCL (xGMI) where the reference copies them through the host (d2h_bitmap :1647-1672).
  *   solr_hip_strip_rows       the rows of rank r of n (contiguous strips, the last absorbs the remainder)
  *   solr_hip_comm_unique_id   rank 0: 128 bytes to hand to every other rank (ncclGetUniqueId)
- *   solr_hip_comm_init        every rank, after initialize_scene: joins the communicator (ncclCommInitRank)
+ *   solr_hip_comm_init        every rank, after initialize_scene and the uploads of its first frame: joins the
+ *                             communicator (ncclCommInitRank) and takes over rank 0's random buffer (below)
+ *   solr_hip_comm_ranks       ranks of the communicator as RCCL reports them (ncclCommCount); 0 without one
  *   solr_hip_gather_strips    after cudaRender, every rank, every frame: this rank's strip -> root, enqueued on
  *                             the stream that rendered the frame (one grouped ncclSend / ncclRecv per peer);
  *                             returns at once
  *   solr_hip_gathered_frame   root: device pointer of the assembled height x width x 3 frame
  *   solr_hip_d2h_gathered     root: waits for the gather and copies the assembled frame to the host
+ *   solr_hip_gather_ids       every rank, when picking asks (GPUKernel::getPrimitiveAt, GPUKernel.cpp:729-739): the
+ *                             PrimitiveXYIdBuffer strips of the frame rendered last -> root (the reference copies them
+ *                             after every frame, CudaRayTracer.cu:1664-1670: 16 bytes per pixel, five times the image)
+ *   solr_hip_d2h_gathered_ids root: waits for that gather and copies the height x width records to the host
  *   solr_hip_comm_finalize    leaves the communicator
- * All return 0, or -1 with solr_hip_last_error set.  RCCL is loaded when the first of them is called.
+ * All return 0, or -1 with solr_hip_last_error set.  RCCL is loaded when the first of them is called
+ * (SOLR_HIP_RCCL_LIBRARY names another build of it).
+ *
+ * What the ranks owe each other.  They run the same host program: the same sequence of
+ * these calls, of cudaRender and of h2d_randoms on every rank, with the same SceneInfo (timestamp and
+ * pathTracingIteration included) and PostProcessingInfo.  Given that, no rank can leave another waiting: a rank in
+ * an error state, or whose strip is not the one the strip table gives it, still takes part in every collective -
+ * it contributes zeros, keeps its error and returns -1 - and the blocking collectives fail on all ranks together.
+ * The random buffer (ambient-occlusion taps, depth of field, jitter of accumulation passes) is rank 0's on every
+ * rank: solr_hip_comm_init and every h2d_randoms / solr_hip_h2d_randoms_sized after it end with a broadcast, since
+ * hosts seed theirs from the clock unless told otherwise (GPUKernel.cpp:89) and strips rendered from different
+ * buffers do not assemble to the frame one GPU renders.
  *
  * Cost-balanced strips (an extension; the reference's split is equal, CudaRayTracer.cu:1694-1696): equal strips
  * share out rows, not work - the frame is as slow as its slowest rank.
@@ -139,9 +159,12 @@ void solr_hip_set_strip(int firstRow, int nbRows);
 void solr_hip_strip_rows(int rank, int world, int height, int *firstRow, int *nbRows, int *rowsPerRank);
 int solr_hip_comm_unique_id(void *id128);
 int solr_hip_comm_init(int rank, int world, const void *id128);
+int solr_hip_comm_ranks(void);
 int solr_hip_gather_strips(int root);
 void *solr_hip_gathered_frame(void);
 int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap);
+int solr_hip_gather_ids(int root);
+int solr_hip_d2h_gathered_ids(PrimitiveXYIdBuffer *hostIds);
 void solr_hip_comm_finalize(void);
 int solr_hip_strip_row_costs(float *rowCost, int height);
 int solr_hip_balanced_strips(const float *rowCost, int height, int world, int align, int *firstRows, int *nbRows);
@@ -154,7 +177,9 @@ int solr_hip_balance_strips(void);
  * section 8e asks for a halo).  Here, with a communicator (solr_hip_comm_init) and the strips of
  * solr_hip_strip_rows, cudaRender trades the depths of the boundary rows with the neighbouring ranks over RCCL,
  * on the frame's stream, between the renderer and the post-processing kernel: the assembled frame is the one a
- * single GPU renders.  A host that moves the rows itself hands them over with solr_hip_set_depth_halo:
+ * single GPU renders.  How many rows are traded is agreed over the communicator (the maximum of the ranks' own
+ * figures; one all-reduce whenever the random buffer was uploaded or param2 changed), so neighbours always post
+ * transfers of the same size.  A host that moves the rows itself hands them over with solr_hip_set_depth_halo:
  * nbAbove rows of `width` floats (PostProcessingBuffer.colorInfo.w) just above its strip, nbBelow just below;
  * they are used by the frames that follow until (NULL, 0, NULL, 0) ends it.  The other neighbourhood kernels
  * (depth of field, radiosity: random gathers over the frame) stay inside the strip as in the reference. */
@@ -209,6 +234,9 @@ void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYI
  * writes the number of timed launches; reset != 0 clears both afterwards. */
 void solr_hip_enable_timing(int enable);
 double solr_hip_kernel_time(int *nbLaunches, int reset);
+/* the same launches one by one: each one's kernel duration and the time from the end of the timed launch before it
+ * to its own end (-1 for the first); call before the resetting solr_hip_kernel_time.  Returns the samples written. */
+int solr_hip_timing_samples(float *kernelMs, float *intervalMs, int capacity);
 
 /* Frames in flight.  n = 2..4 (whole frames gain nothing beyond 3, a 1/8 strip of a multi-GPU frame up to 4): consecutive first-pass frames (pathTracingIteration == 0) rotate over n
  * streams and n sets of per-pixel buffers owned by the engine, so that the tail of a frame - a few long

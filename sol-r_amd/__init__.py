@@ -162,6 +162,7 @@ def _declare_hip(L):
     L.solr_hip_enable_timing.argtypes = [C.c_int]
     L.solr_hip_kernel_time.argtypes = [P(C.c_int), C.c_int]
     L.solr_hip_kernel_time.restype = C.c_double
+    L.solr_hip_timing_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.solr_hip_set_frames_in_flight.argtypes = [C.c_int]
     L.solr_hip_get_frames_in_flight.restype = C.c_int
     L.solr_hip_flight_stream.argtypes = [C.c_int]
@@ -174,6 +175,16 @@ def _declare_hip(L):
     L.solr_hip_tile_clocks.argtypes = [C.c_void_p, C.c_int]
     L.solr_hip_tile_clocks.restype = C.c_int
     L.solr_hip_set_variant.argtypes = [C.c_int]
+    L.solr_hip_get_strip.argtypes = [P(C.c_int), P(C.c_int)]
+    L.solr_hip_comm_unique_id.argtypes = [C.c_void_p]
+    L.solr_hip_comm_init.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    L.solr_hip_comm_ranks.restype = C.c_int
+    L.solr_hip_gather_strips.argtypes = [C.c_int]
+    L.solr_hip_gather_ids.argtypes = [C.c_int]
+    L.solr_hip_gathered_frame.restype = C.c_void_p
+    L.solr_hip_d2h_gathered.argtypes = [C.c_void_p]
+    L.solr_hip_d2h_gathered_ids.argtypes = [C.c_void_p]
+    L.solr_hip_h2d_randoms_sized.argtypes = [C.c_void_p, C.c_long]
     L.solr_hip_get_variant.restype = C.c_int
     L.solr_hip_memory_usage.argtypes = [P(C.c_ulonglong)]
     L.solr_hip_set_movable.argtypes = [C.c_void_p, C.c_int]

@@ -1322,6 +1322,7 @@ struct Engine
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double timedMs = 0.0;
     int timedLaunches = 0;
+    std::vector<float> kernelSamples, intervalSamples; /* per timed launch: its duration; end-to-end gap to the one before */
 
     /* device-side rotation (solr_hip_rotate_primitives): what to refit, in which order */
     DeviceBuffer movable, refitPlan;
@@ -1908,11 +1909,36 @@ void maybeBuildOrderFreeLists();
 /* (defined with the RCCL layer at the end of this file) */
 void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
                        int wanted, DepthHalo *halo);
+int agreedHaloRows(const PostProcessingInfo &ppInfo);
+bool haveCommunicator();
+
+/* A frame with the ambient-occlusion post-process on a rank of a communicator owes its neighbours the boundary rows
+ * of its strip, whatever becomes of the frame on this rank: when renderImpl leaves before it got there (an argument
+ * check, an error state, a strip it holds no row of), the exchange is posted with zeros on the way out. */
+struct HaloDebt
+{
+    bool owed = false;
+    int wanted = 0, width = 0, frameRows = 0;
+    ~HaloDebt()
+    {
+        if (owed)
+            exchangeDepthHalo(g.current, flightStream(g.current), nullptr, width, 0, 0, frameRows, wanted, nullptr);
+    }
+};
 
 void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProcessingInfo &ppInfo,
                 const float origin[3], const float direction[3], const float angles[4], bool counting,
                 unsigned long long counts[8])
 {
+    HaloDebt debt;
+    if (ppInfo.type == ppe_ambientOcclusion && haveCommunicator())
+    {
+        /* (every rank, before anything rank-local can end the call: an all-reduce when the figure is stale) */
+        debt.wanted = agreedHaloRows(ppInfo);
+        debt.width = sceneInfo.size.x;
+        debt.frameRows = sceneInfo.size.y;
+        debt.owed = !(g.haloSuppliedAbove || g.haloSuppliedBelow);
+    }
     if (!ready("cudaRender"))
         return;
     ARGCHECK(sceneInfo.size.x > 0 && sceneInfo.size.y > 0, "cudaRender: empty image");
@@ -2188,7 +2214,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             if (g.nbRows >= 0 && F.nbRows > 0)
             {
                 const float reach = 16.f * fabsf(ppInfo.param2) * g.randomsReach / 10.f;
-                const int wanted = reach < 4096.f ? (int)reach + 2 : 4096;
+                const int wanted = debt.owed ? debt.wanted : (reach < 4096.f ? (int)reach + 2 : 4096);
                 g.haloWanted = wanted;
                 if (g.haloSuppliedAbove || g.haloSuppliedBelow)
                 {
@@ -2197,9 +2223,12 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                     halo.nbAbove = g.haloSuppliedAbove;
                     halo.nbBelow = g.haloSuppliedBelow;
                 }
-                else
+                else if (debt.owed)
+                {
+                    debt.owed = false;
                     exchangeDepthHalo(flight, stream, (const PixelRecord *)flightPp(flight).ptr, sceneInfo.size.x, F.firstRow,
                                       F.nbRows, sceneInfo.size.y, wanted, &halo);
+                }
             }
             if (ok())
                 hipLaunchKernelGGL(k_ambientOcclusion,
@@ -2235,17 +2264,28 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
 
 void collectEvents()
 {
+    hipEvent_t before = nullptr;
     for (auto &ev : g.events)
     {
-        float ms = 0.f;
+        float ms = 0.f, gap = 0.f;
         if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess)
         {
             g.timedMs += ms;
             g.timedLaunches++;
+            if (g.kernelSamples.size() < 65536)
+            {
+                g.kernelSamples.push_back(ms);
+                /* end of the launch before to the end of this one: what a step of a pipelined loop takes */
+                g.intervalSamples.push_back((before && hipEventElapsedTime(&gap, before, ev.second) == hipSuccess) ? gap : -1.f);
+            }
         }
+        if (before)
+            (void)hipEventDestroy(before);
         (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+        before = ev.second;
     }
+    if (before)
+        (void)hipEventDestroy(before);
     g.events.clear();
 }
 } // namespace
@@ -2278,6 +2318,12 @@ int solr_hip_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess)
         return 0;
     return n;
+}
+
+/* (for the other translation units of the library: sol-r_amd/csrc/solr_tree.hip builds on the engine's device) */
+int solr_hip_get_device(void)
+{
+    return g.device;
 }
 
 void solr_hip_set_device(int device)
@@ -2365,6 +2411,16 @@ void *solr_hip_device_postprocessing(void)
 {
     return flightPp(g.current).ptr;
 }
+/* the strip this process renders now (solr_hip_set_strip, solr_hip_balance_strips): rows [*firstRow, *firstRow +
+ * *nbRows) of the frame; the full frame reads as (0, height of the last frame or 0 before one) */
+void solr_hip_get_strip(int *firstRow, int *nbRows)
+{
+    if (firstRow)
+        *firstRow = g.nbRows >= 0 ? g.firstRow : 0;
+    if (nbRows)
+        *nbRows = stripRows();
+}
+
 void solr_hip_bind_device_bitmap(void *deviceBitmap)
 {
     g.boundBitmap = deviceBitmap;
@@ -3004,10 +3060,14 @@ void maybeBuildOrderFreeLists()
             }
             else if (type == ptSphere)
                 grow[1] = grow[2] = grow[0];
-            const float eps = 1.0e-3f; /* the builder subtracts and adds in another order: an ulp of slack */
-            encloses = rows[2 * i].x <= lo[0] - fabsf(grow[0]) + eps && rows[2 * i].y <= lo[1] - fabsf(grow[1]) + eps &&
-                       rows[2 * i].z <= lo[2] - fabsf(grow[2]) + eps && rows[2 * i + 1].x >= hi[0] + fabsf(grow[0]) - eps &&
-                       rows[2 * i + 1].y >= hi[1] + fabsf(grow[1]) - eps && rows[2 * i].w >= hi[2] + fabsf(grow[2]) - eps;
+            /* the builder subtracts and adds in another order: four ulps of the coordinates' magnitude of slack, per
+             * axis - relative, so that it stays far below the order-free walks' cut-off margin (2e-4 of the distance
+             * + 1e-4 of the origin's coordinates, rt_device.h) whatever the scale of the scene */
+            auto slack = [&](int k) { return 4.f * 1.1920929e-7f * std::max(std::max(fabsf(lo[k]), fabsf(hi[k])), fabsf(grow[k])); };
+            const float ex = slack(0), ey = slack(1), ez = slack(2);
+            encloses = rows[2 * i].x <= lo[0] - fabsf(grow[0]) + ex && rows[2 * i].y <= lo[1] - fabsf(grow[1]) + ey &&
+                       rows[2 * i].z <= lo[2] - fabsf(grow[2]) + ez && rows[2 * i + 1].x >= hi[0] + fabsf(grow[0]) - ex &&
+                       rows[2 * i + 1].y >= hi[1] + fabsf(grow[1]) - ey && rows[2 * i].w >= hi[2] + fabsf(grow[2]) - ez;
         }
     }
     if (!encloses)
@@ -3630,6 +3690,10 @@ void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
     }
 }
 
+namespace
+{
+bool shareRandoms(); /* (with the RCCL layer at the end of this file) */
+}
 static void noteRandomsReach(const std::vector<float> &r)
 {
     /* the ambient-occlusion taps read randoms[i] and randoms[i + 100], i < 256 (CRT:1146-1153) */
@@ -3639,20 +3703,27 @@ static void noteRandomsReach(const std::vector<float> &r)
     g.randomsReach = reach;
 }
 
+static void uploadRandoms(const float *randoms, long count, const char *who)
+{
+    if (ready(who))
+    {
+        quiesce();
+        std::vector<float> r(randoms, randoms + count);
+        HIPCHECK(hipSetDevice(g.device));
+        upload(g.randoms, r);
+        if (ok())
+            g.nbRandoms = count;
+        noteRandomsReach(r);
+    }
+    /* with a communicator rank 0's buffer is everybody's: every rank ends its upload here, in whatever state */
+    shareRandoms();
+}
+
 void h2d_randoms(vec2i, float *randoms)
 {
-    if (!ready("h2d_randoms"))
-        return;
-    quiesce();
-    ARGCHECK(randoms != nullptr, "h2d_randoms: null buffer");
-    if (!ok())
-        return;
-    std::vector<float> r(randoms, randoms + MAX_BITMAP_SIZE);
-    HIPCHECK(hipSetDevice(g.device));
-    upload(g.randoms, r);
-    if (ok())
-        g.nbRandoms = MAX_BITMAP_SIZE;
-    noteRandomsReach(r);
+    if (g.initialized && ok())
+        ARGCHECK(randoms != nullptr, "h2d_randoms: null buffer");
+    uploadRandoms(randoms, MAX_BITMAP_SIZE, "h2d_randoms");
 }
 
 /* Frames larger than the reference's 1920 x 1080 limit: its natural depth of field indexes the buffer with
@@ -3662,19 +3733,10 @@ void h2d_randoms(vec2i, float *randoms)
  * as the expression can reach; reads beyond what was handed over return 0 (rt_device.h rnd()). */
 void solr_hip_h2d_randoms_sized(const float *randoms, long count)
 {
-    if (!ready("solr_hip_h2d_randoms_sized"))
-        return;
-    quiesce();
-    ARGCHECK(randoms != nullptr && count >= MAX_BITMAP_SIZE && count <= (1L << 30),
-             "solr_hip_h2d_randoms_sized: needs at least MAX_BITMAP_SIZE values");
-    if (!ok())
-        return;
-    std::vector<float> r(randoms, randoms + count);
-    HIPCHECK(hipSetDevice(g.device));
-    upload(g.randoms, r);
-    if (ok())
-        g.nbRandoms = count;
-    noteRandomsReach(r);
+    if (g.initialized && ok())
+        ARGCHECK(randoms != nullptr && count >= MAX_BITMAP_SIZE && count <= (1L << 30),
+                 "solr_hip_h2d_randoms_sized: needs at least MAX_BITMAP_SIZE values");
+    uploadRandoms(randoms, count, "solr_hip_h2d_randoms_sized");
 }
 
 void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
@@ -3896,8 +3958,30 @@ double solr_hip_kernel_time(int *nbLaunches, int reset)
     {
         g.timedMs = 0.0;
         g.timedLaunches = 0;
+        g.kernelSamples.clear();
+        g.intervalSamples.clear();
     }
     return ms;
+}
+
+/* The timed launches one by one (since the last reset of solr_hip_kernel_time; call before it): kernelMs[i] the
+ * duration of the renderer kernel of launch i, intervalMs[i] the time from the end of the timed launch before it to
+ * its own end (-1 for the first of a batch) - with frames in flight that is what a step takes, and its spread is the
+ * error bar of a short timed region.  Returns the number of samples written (at most `capacity`). */
+int solr_hip_timing_samples(float *kernelMs, float *intervalMs, int capacity)
+{
+    if (g.initialized && g.stream)
+        (void)hipStreamSynchronize(g.stream);
+    collectEvents();
+    const int n = std::min((int)g.kernelSamples.size(), std::max(capacity, 0));
+    for (int i = 0; i < n; ++i)
+    {
+        if (kernelMs)
+            kernelMs[i] = g.kernelSamples[i];
+        if (intervalMs)
+            intervalMs[i] = g.intervalSamples[i];
+    }
+    return n;
 }
 
 void solr_hip_set_variant(int variant)
@@ -3944,6 +4028,7 @@ struct Rccl
     int (*GetUniqueId)(ncclUniqueId *) = nullptr;
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -3953,17 +4038,42 @@ struct Rccl
     ncclComm_t comm = nullptr;
     int rank = 0, world = 0;
     DeviceBuffer frame[MAX_FLIGHTS]; /* root: the assembled RGB8 frame of each flight */
+    DeviceBuffer idsFrame;           /* root: the assembled primitive ids (solr_hip_gather_ids) */
+    int idsFlight = 0;               /* the flight whose stream carried that gather */
+    DeviceBuffer zeros;              /* what a rank sends when it cannot send its own rows (see joinWith) */
+    DeviceBuffer scratch;            /* the few floats of the blocking all-reduces */
     int lastFlight = 0;
+    /* the rows of a neighbour's strip the ambient-occlusion taps reach, AGREED over the communicator (the maximum of
+     * what the ranks derive from their own parameters and random buffers); -1: not agreed yet */
+    int haloAgreed = -1;
+    bool haloStale = true;  /* something it depends on was uploaded since (or nothing was agreed yet) */
+    int haloParam2Bits = 0; /* PostProcessingInfo.param2 of the agreement */
 } rccl;
 const int RCCL_UINT8 = 1; /* ncclUint8, rccl.h:460 */
+const int RCCL_INT32 = 2; /* ncclInt32 */
+const int RCCL_FLOAT32 = 7; /* ncclFloat32 */
+const int RCCL_SUM = 0, RCCL_MAX = 2; /* ncclSum, ncclMax */
 
 bool loadRccl()
 {
     if (rccl.lib)
         return true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-        if ((rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
-            break;
+    /* SOLR_HIP_RCCL_LIBRARY: another build of the library (a site's own RCCL; tests/loopback_rccl.c, which lets
+     * several ranks share the one GPU of a test box) */
+    const char *named = getenv("SOLR_HIP_RCCL_LIBRARY");
+    if (named && named[0])
+    {
+        if (!(rccl.lib = dlopen(named, RTLD_NOW | RTLD_GLOBAL)))
+        {
+            setError(-1, (std::string("SOLR_HIP_RCCL_LIBRARY=") + named + " could not be loaded: " + dlerror()).c_str(), __FILE__,
+                     __LINE__);
+            return false;
+        }
+    }
+    else
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+                break;
     if (!rccl.lib)
     {
         setError(-1, "RCCL (librccl.so) could not be loaded", __FILE__, __LINE__);
@@ -3972,6 +4082,7 @@ bool loadRccl()
     rccl.GetUniqueId = (decltype(rccl.GetUniqueId))dlsym(rccl.lib, "ncclGetUniqueId");
     rccl.CommInitRank = (decltype(rccl.CommInitRank))dlsym(rccl.lib, "ncclCommInitRank");
     rccl.CommDestroy = (decltype(rccl.CommDestroy))dlsym(rccl.lib, "ncclCommDestroy");
+    rccl.CommCount = (decltype(rccl.CommCount))dlsym(rccl.lib, "ncclCommCount");
     rccl.GroupStart = (decltype(rccl.GroupStart))dlsym(rccl.lib, "ncclGroupStart");
     rccl.GroupEnd = (decltype(rccl.GroupEnd))dlsym(rccl.lib, "ncclGroupEnd");
     rccl.Send = (decltype(rccl.Send))dlsym(rccl.lib, "ncclSend");
@@ -3998,12 +4109,151 @@ bool rcclOk(int result, const char *what)
     return false;
 }
 
-/* Ambient occlusion on a strip: the 256 taps of a pixel reach up to `wanted` rows into the strips of the ranks above
- * and below (SURVEY.md section 8e: "exchange a 16-row halo").  Every rank packs the depths of its first and last
- * `wanted` rows and trades them with its neighbours - one grouped ncclSend / ncclRecv pair per neighbour, on the
- * stream that rendered the strip, between the renderer and the post-processing kernel - so that the assembled frame
- * is the one a single GPU renders.  Only with a communicator and the strips of solr_hip_strip_rows; `wanted`
- * follows from the post-processing parameters and the random buffer, which every rank holds alike. */
+/* ---- collectives that every rank joins ---------------------------------------------------------------------------
+ * The ranks of a communicator run the same host program (the same sequence of C-ABI calls on
+ * every rank).  A collective that one rank leaves out - because an argument check failed on it alone, because it is
+ * in an error state, because its strip is not the one the others think it has - leaves the others waiting for
+ * ever.  So nothing rank-local decides WHETHER a rank takes part, only WHAT it contributes:
+ *   - the blocking all-reduces carry a failure slot: a rank in trouble contributes zeros and raises it, and all
+ *     ranks fail together after the sum;
+ *   - the point-to-point transfers behind a frame (strip gather, depth-halo exchange) have their sizes fixed by the
+ *     strip table and the agreed halo height - facts every rank holds alike - and a rank that cannot send its own rows
+ *     sends that many bytes of zeros, records its error and returns -1: the frame is wrong and says so, nobody hangs. */
+
+/* a device allocation that does not depend on (or change) the engine's error state */
+bool reserveQuietly(DeviceBuffer &b, size_t bytes, bool zero)
+{
+    bytes = std::max(bytes, (size_t)16);
+    if (b.ptr && b.bytes >= bytes)
+        return true;
+    if (b.ptr)
+        (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.bytes = 0;
+    if (hipMalloc(&b.ptr, bytes) != hipSuccess)
+    {
+        b.ptr = nullptr;
+        return false;
+    }
+    b.bytes = bytes;
+    if (zero)
+        (void)hipMemset(b.ptr, 0, bytes);
+    return true;
+}
+
+/* `bytes` of zeros in HBM (the stand-in payload) */
+const void *zeroPayload(size_t bytes)
+{
+    return reserveQuietly(rccl.zeros, bytes, true) ? rccl.zeros.ptr : nullptr;
+}
+
+/* blocking all-reduce (sum or max) of a few floats, in place, on the engine's first stream; every rank, same count.
+ * Works in an error state too - that is the point. */
+bool allReduceFloats(float *values, size_t n, int op, const char *what)
+{
+    if (!rccl.comm)
+        return false;
+    (void)hipSetDevice(g.device);
+    const hipStream_t stream = flightStream(0);
+    bool fine = reserveQuietly(rccl.scratch, n * sizeof(float), false);
+    /* (a rank that cannot even allocate the few floats still has to show up: it reduces in the zero buffer) */
+    void *buffer = fine ? rccl.scratch.ptr : (void *)zeroPayload(n * sizeof(float));
+    if (!buffer)
+    {
+        setError(-1, (std::string(what) + ": no device memory for the all-reduce; the other ranks are left waiting").c_str(),
+                 __FILE__, __LINE__);
+        return false;
+    }
+    if (fine)
+        fine = hipMemcpyAsync(buffer, values, n * sizeof(float), hipMemcpyHostToDevice, stream) == hipSuccess;
+    const int result = rccl.AllReduce(buffer, buffer, n, RCCL_FLOAT32, op, rccl.comm, stream);
+    if (result != 0)
+    {
+        (void)rcclOk(result, what);
+        return false;
+    }
+    if (hipMemcpyAsync(values, buffer, n * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        fine = false;
+    if (!fine)
+        setError(-1, (std::string(what) + ": a copy around the all-reduce failed").c_str(), __FILE__, __LINE__);
+    return fine;
+}
+
+/* The rows of the neighbouring strips the 256 ambient-occlusion taps of a pixel can reach (CRT:1146-1153: 16 * param2
+ * * |random| / 10 pixels), as ALL ranks will use it for the exchange below.  Each rank derives a figure from its own
+ * post-processing parameters and random buffer; hosts seed their random buffers differently unless told otherwise
+ * (GPUKernel.cpp:89, fillRandoms: srand(time(0))), and where 16 * param2 * reach / 10 straddles an integer two
+ * neighbours would post sends and receives of different sizes.  So the figure is agreed - one all-reduce (max) -
+ * whenever something it depends on was uploaded (communicator, random buffer) or param2 differs from the last
+ * agreement's: events of the host program, the same on every rank, not values.  Called by every rank at the top of
+ * every cudaRender with the ambient-occlusion post-process, whatever state the rank is in. */
+int agreedHaloRows(const PostProcessingInfo &ppInfo)
+{
+    const float reach = 16.f * fabsf(ppInfo.param2) * g.randomsReach / 10.f;
+    const int wanted = reach < 4096.f ? (int)reach + 2 : 4096;
+    if (!rccl.comm || rccl.world < 2)
+        return wanted;
+    if (rccl.haloStale || rccl.haloAgreed < 0 || bitsi(ppInfo.param2) != rccl.haloParam2Bits)
+    {
+        float v[2] = {(float)wanted, ok() ? 0.f : 1.f};
+        if (!allReduceFloats(v, 2, RCCL_MAX, "ncclAllReduce (rows of the depth halo)"))
+            return wanted;
+        rccl.haloAgreed = (int)v[0];
+        rccl.haloStale = false;
+        rccl.haloParam2Bits = bitsi(ppInfo.param2);
+        if (v[1] > 0.f && ok())
+            setError(-1, "cudaRender: another rank of the communicator is in an error state", __FILE__, __LINE__);
+    }
+    return rccl.haloAgreed;
+}
+
+/* Rank 0's random buffer to every rank (the buffer feeds the taps of the ambient-occlusion kernel, the depth of field
+ * and the jitter of accumulation passes: strips rendered from different buffers do not assemble to the frame one GPU
+ * renders).  With a communicator, rank 0's buffer is THE buffer: solr_hip_comm_init and every h2d_randoms after it
+ * end with this.  Blocking; every rank. */
+bool shareRandoms()
+{
+    if (!rccl.comm || rccl.world < 2)
+        return true;
+    rccl.haloStale = true;
+    const long n = g.randoms.ptr ? g.nbRandoms : 0;
+    /* the same count everywhere?  (two 16-bit halves: a float holds them exactly) */
+    float v[6] = {(float)(n >> 16), -(float)(n >> 16), (float)(n & 0xffff), -(float)(n & 0xffff), ok() ? 0.f : 1.f,
+                  rccl.rank == 0 ? g.randomsReach : 0.f};
+    if (!allReduceFloats(v, 6, RCCL_MAX, "ncclAllReduce (size of the random buffer)"))
+        return false;
+    if (v[0] != -v[1] || v[2] != -v[3])
+    {
+        setError(-1, "the ranks of the communicator hold random buffers of different sizes (h2d_randoms on some only?)",
+                 __FILE__, __LINE__);
+        return false;
+    }
+    if (v[4] > 0.f)
+    {
+        if (ok())
+            setError(-1, "another rank of the communicator is in an error state", __FILE__, __LINE__);
+        return false; /* every rank leaves here */
+    }
+    if (n == 0)
+        return true;
+    (void)hipSetDevice(g.device);
+    const hipStream_t stream = flightStream(0);
+    bool fine = rcclOk(rccl.GroupStart(), "ncclGroupStart");
+    if (fine && rccl.rank == 0)
+        for (int r = 1; r < rccl.world && fine; ++r)
+            fine = rcclOk(rccl.Send(g.randoms.ptr, (size_t)n, RCCL_FLOAT32, r, rccl.comm, stream), "ncclSend (random buffer)");
+    else if (fine)
+        fine = rcclOk(rccl.Recv(g.randoms.ptr, (size_t)n, RCCL_FLOAT32, 0, rccl.comm, stream), "ncclRecv (random buffer)");
+    if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd"))
+        fine = false;
+    if (hipStreamSynchronize(stream) != hipSuccess)
+        fine = false;
+    if (fine)
+        g.randomsReach = v[5];
+    return fine;
+}
+
 /* The strips of all ranks when they are not the equal ones of solr_hip_strip_rows (solr_hip_set_strip_table) */
 struct StripTable
 {
@@ -4023,45 +4273,65 @@ void stripOf(int rank, int world, int height, int *first, int *count)
     solr_hip_strip_rows(rank, world, height, first, count, nullptr);
 }
 
-const int RCCL_FLOAT32 = 7; /* ncclFloat32, rccl.h */
+/* Ambient occlusion on a strip: the 256 taps of a pixel reach up to `wanted` rows into the strips of the ranks above
+ * and below (SURVEY.md section 8e: "exchange a 16-row halo").  Every rank packs the depths of its first and last
+ * `wanted` rows and trades them with its neighbours - one grouped ncclSend / ncclRecv pair per neighbour, on the
+ * stream that rendered the strip, between the renderer and the post-processing kernel - so that the assembled frame
+ * is the one a single GPU renders.  The sizes follow from the strip table and from `wanted` = agreedHaloRows alone,
+ * so neighbours always post matching transfers; pp == nullptr (a rank that returned early from cudaRender, or whose
+ * strip is not the table's) sends zeros and sets the error. */
 void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
                        int wanted, DepthHalo *halo)
 {
-    if (!rccl.comm || rccl.world < 2 || wanted < 1 || nbRows < 1)
+    if (!rccl.comm || rccl.world < 2 || wanted < 1 || W < 1 || frameRows < 1)
         return;
     int first = 0, count = 0;
     stripOf(rccl.rank, rccl.world, frameRows, &first, &count);
-    if (first != firstRow || count != nbRows)
-        return; /* a strip layout of the host's own: it hands the rows over itself (solr_hip_set_depth_halo) */
+    if (count < 1)
+        return; /* no row of the frame is this rank's: its neighbours know and trade nothing with it */
     int upRows = 0, downRows = 0;
     if (rccl.rank > 0)
         stripOf(rccl.rank - 1, rccl.world, frameRows, nullptr, &upRows);
     if (rccl.rank + 1 < rccl.world)
         stripOf(rccl.rank + 1, rccl.world, frameRows, nullptr, &downRows);
-    const int mine = std::min(wanted, nbRows);
+    const int mine = std::min(wanted, count);
     const int recvAbove = std::min(wanted, upRows), recvBelow = std::min(wanted, downRows);
     const int sendUp = upRows > 0 ? mine : 0, sendDown = downRows > 0 ? mine : 0;
     if (!(recvAbove || recvBelow || sendUp || sendDown))
         return;
-    reserve(g.haloAbove[flight], (size_t)std::max(recvAbove, 1) * W * sizeof(float));
-    reserve(g.haloBelow[flight], (size_t)std::max(recvBelow, 1) * W * sizeof(float));
-    reserve(g.haloSendTop[flight], (size_t)mine * W * sizeof(float));
-    reserve(g.haloSendBottom[flight], (size_t)mine * W * sizeof(float));
-    if (!ok())
+    const size_t mineBytes = (size_t)mine * W * sizeof(float);
+    bool own = pp != nullptr && ok() && first == firstRow && count == nbRows;
+    if (pp != nullptr && ok() && !own)
+        setError(-1, "cudaRender: this process's strip is not the one solr_hip_strip_rows (or the table of "
+                     "solr_hip_set_strip_table) gives its rank; its neighbours received zeros for its boundary rows",
+                 __FILE__, __LINE__);
+    const bool room = reserveQuietly(g.haloAbove[flight], (size_t)std::max(recvAbove, 1) * W * sizeof(float), false) &&
+                      reserveQuietly(g.haloBelow[flight], (size_t)std::max(recvBelow, 1) * W * sizeof(float), false);
+    if (own && !(reserveQuietly(g.haloSendTop[flight], mineBytes, false) && reserveQuietly(g.haloSendBottom[flight], mineBytes, false)))
+        own = false;
+    const void *top = own ? g.haloSendTop[flight].ptr : zeroPayload(mineBytes);
+    const void *bottom = own ? g.haloSendBottom[flight].ptr : top;
+    if (!room || !top)
+    {
+        setError(-1, "cudaRender: no device memory for the depth-halo exchange; the neighbouring ranks are left waiting",
+                 __FILE__, __LINE__);
         return;
-    const dim3 grid((unsigned)((mine * W + 255) / 256)), block(256);
-    if (sendUp)
-        hipLaunchKernelGGL(k_packDepthRows, grid, block, 0, stream, pp, W, 0, mine, (float *)g.haloSendTop[flight].ptr);
-    if (sendDown)
-        hipLaunchKernelGGL(k_packDepthRows, grid, block, 0, stream, pp, W, nbRows - mine, mine,
-                           (float *)g.haloSendBottom[flight].ptr);
-    HIPCHECK(hipGetLastError());
-    bool fine = ok() && rcclOk(rccl.GroupStart(), "ncclGroupStart");
+    }
+    if (own)
+    {
+        const dim3 grid((unsigned)((mine * W + 255) / 256)), block(256);
+        if (sendUp)
+            hipLaunchKernelGGL(k_packDepthRows, grid, block, 0, stream, pp, W, 0, mine, (float *)g.haloSendTop[flight].ptr);
+        if (sendDown)
+            hipLaunchKernelGGL(k_packDepthRows, grid, block, 0, stream, pp, W, nbRows - mine, mine,
+                               (float *)g.haloSendBottom[flight].ptr);
+        HIPCHECK(hipGetLastError());
+    }
+    bool fine = rcclOk(rccl.GroupStart(), "ncclGroupStart");
     if (fine && sendUp)
-        fine = rcclOk(rccl.Send(g.haloSendTop[flight].ptr, (size_t)mine * W, RCCL_FLOAT32, rccl.rank - 1, rccl.comm, stream),
-                      "ncclSend (depth rows, up)");
+        fine = rcclOk(rccl.Send(top, (size_t)mine * W, RCCL_FLOAT32, rccl.rank - 1, rccl.comm, stream), "ncclSend (depth rows, up)");
     if (fine && sendDown)
-        fine = rcclOk(rccl.Send(g.haloSendBottom[flight].ptr, (size_t)mine * W, RCCL_FLOAT32, rccl.rank + 1, rccl.comm, stream),
+        fine = rcclOk(rccl.Send(bottom, (size_t)mine * W, RCCL_FLOAT32, rccl.rank + 1, rccl.comm, stream),
                       "ncclSend (depth rows, down)");
     if (fine && recvAbove)
         fine = rcclOk(rccl.Recv(g.haloAbove[flight].ptr, (size_t)recvAbove * W, RCCL_FLOAT32, rccl.rank - 1, rccl.comm, stream),
@@ -4069,12 +4339,18 @@ void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, in
     if (fine && recvBelow)
         fine = rcclOk(rccl.Recv(g.haloBelow[flight].ptr, (size_t)recvBelow * W, RCCL_FLOAT32, rccl.rank + 1, rccl.comm, stream),
                       "ncclRecv (depth rows, below)");
-    if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd") || !fine)
+    if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd") || !fine || !own || !halo)
         return;
     halo->above = (const float *)g.haloAbove[flight].ptr;
     halo->below = (const float *)g.haloBelow[flight].ptr;
     halo->nbAbove = recvAbove;
     halo->nbBelow = recvBelow;
+}
+
+/* (for renderImpl, which is defined before this layer) */
+bool haveCommunicator()
+{
+    return rccl.comm != nullptr && rccl.world > 1;
 }
 } // namespace
 
@@ -4259,48 +4535,48 @@ int solr_hip_strip_row_costs(float *rowCost, int height)
  * (one ncclAllReduce of `height` floats), balanced strips from them, the table for the gather and this
  * process's own strip set - the next cudaRender renders it.  A host without a control plane of its own needs
  * nothing else; one that has (torch.distributed in bench.py) can do the sum there and call
- * solr_hip_balanced_strips + solr_hip_set_strip_table + solr_hip_set_strip itself. */
+ * solr_hip_balanced_strips + solr_hip_set_strip_table + solr_hip_set_strip itself.
+ * Two all-reduces, and every rank that has a communicator takes part in both whatever its own state: first the
+ * maximum of {rows the ambient-occlusion taps reach beyond a strip, a failure flag, the frame height and its
+ * negative} - the halo exchange delivers rows of the next rank only, so no strip may be lower than the LARGEST reach
+ * any rank has seen, every rank must cut with the same `align`, and ranks that disagree about the frame must not meet
+ * in a sum of different lengths - then, if nobody failed, the sum of the rows' costs. */
 int solr_hip_balance_strips(void)
 {
-    if (!ready("solr_hip_balance_strips"))
+    if (!g.initialized || !rccl.comm)
+    {
+        /* the same on every rank of a correct program: nobody is waiting */
+        if (ok())
+            setError(-1, !g.initialized ? "solr_hip_balance_strips: initialize_scene has not been called"
+                                        : "solr_hip_balance_strips: no communicator (solr_hip_comm_init)",
+                     __FILE__, __LINE__);
         return -1;
-    ARGCHECK(rccl.comm != nullptr, "solr_hip_balance_strips: no communicator (solr_hip_comm_init)");
-    if (!ok())
-        return -1;
+    }
+    bool mine = ok();
     const int height = g.height;
-    /* two more floats ride along: the rows the ambient-occlusion taps reach beyond a strip (the halo exchange
-     * delivers rows of the next rank only, so no strip may be lower than that) from the ranks that have rendered
-     * a frame, and how many they are - every rank must cut with the same `align` */
-    std::vector<float> cost((size_t)height + 2, 0.f);
-    if (g.haloWanted >= 0)
-    {
-        cost[(size_t)height] = (float)g.haloWanted;
-        cost[(size_t)height + 1] = 1.f;
-    }
-    /* a rank that has nothing to report (an empty strip, tile scheduling off, no frame yet) still takes part in
-     * the sum - staying away would leave the others waiting in the collective */
-    const bool recorded = stripRows() > 0 && g.tileCost.ptr != nullptr && g.costFrames > 0 && g.costKey[0] > 0;
+    std::vector<float> cost((size_t)std::max(height, 1), 0.f);
+    /* a rank that has nothing to report (an empty strip, tile scheduling off, no frame yet) contributes zeros */
+    const bool recorded = mine && height > 0 && stripRows() > 0 && g.tileCost.ptr != nullptr && g.costFrames > 0 && g.costKey[0] > 0;
     if (recorded && solr_hip_strip_row_costs(cost.data(), height) != 0)
-        return -1;
-    DeviceBuffer sum;
-    reserve(sum, cost.size() * sizeof(float));
-    if (!ok())
-        return -1;
-    const hipStream_t stream = flightStream(0);
-    HIPCHECK(hipMemcpyAsync(sum.ptr, cost.data(), cost.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    const int RCCL_SUM = 0; /* ncclSum, rccl.h */
-    bool fine = ok() && rcclOk(rccl.AllReduce(sum.ptr, sum.ptr, cost.size(), RCCL_FLOAT32, RCCL_SUM, rccl.comm, stream),
-                               "ncclAllReduce");
-    if (fine)
     {
-        HIPCHECK(hipMemcpyAsync(cost.data(), sum.ptr, cost.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
-        HIPCHECK(hipStreamSynchronize(stream));
-        fine = ok();
+        mine = false;
+        std::fill(cost.begin(), cost.end(), 0.f);
     }
-    release(sum);
-    if (!fine)
+    quiesce();
+    float head[4] = {(float)std::max(g.haloWanted, 0), mine ? 0.f : 1.f, (float)height, -(float)height};
+    if (!allReduceFloats(head, 4, RCCL_MAX, "ncclAllReduce (balance: reach, failures, frame height)"))
         return -1;
-    const int reach = cost[(size_t)height + 1] > 0.f ? (int)(cost[(size_t)height] / cost[(size_t)height + 1] + 0.5f) : 0;
+    if (head[1] > 0.f || head[2] != -head[3] || height < 1)
+    {
+        if (ok())
+            setError(-1, head[1] > 0.f ? "solr_hip_balance_strips: another rank could not report its rows' costs"
+                                       : "solr_hip_balance_strips: the ranks do not render frames of the same height",
+                     __FILE__, __LINE__);
+        return -1; /* on every rank */
+    }
+    if (!allReduceFloats(cost.data(), (size_t)height, RCCL_SUM, "ncclAllReduce (balance: rows' costs)"))
+        return -1;
+    const int reach = (int)head[0];
     const int align = std::max(TILE, (reach + TILE - 1) / TILE * TILE);
     std::vector<int> first((size_t)rccl.world), count((size_t)rccl.world);
     if (solr_hip_balanced_strips(cost.data(), height, rccl.world, align, first.data(), count.data()) != 0 ||
@@ -4321,6 +4597,9 @@ int solr_hip_comm_unique_id(void *id128)
     return 0;
 }
 
+/* Joins the communicator and, when it has more than one rank, makes rank 0's random buffer everybody's (see
+ * shareRandoms; hosts seed theirs from the clock unless told otherwise).  Every rank, after initialize_scene and
+ * after the uploads of its first frame. */
 int solr_hip_comm_init(int rank, int world, const void *id128)
 {
     if (!ready("solr_hip_comm_init") || !loadRccl())
@@ -4339,60 +4618,136 @@ int solr_hip_comm_init(int rank, int world, const void *id128)
     }
     rccl.rank = rank;
     rccl.world = world;
-    return 0;
+    rccl.haloAgreed = -1;
+    rccl.haloStale = true;
+    quiesce();
+    if (!shareRandoms())
+        return -1;
+    return ok() ? 0 : -1;
 }
 
-/* the strip of the frame rendered last -> `root`, on that frame's stream.  Every rank calls it once per frame,
- * in the same order of frames.  Returns immediately. */
-int solr_hip_gather_strips(int root)
+/* ranks of the communicator as the library itself reports them (ncclCommCount), 0 without one */
+int solr_hip_comm_ranks(void)
 {
-    if (!ready("solr_hip_gather_strips"))
+    if (!rccl.comm)
+        return 0;
+    int n = rccl.world;
+    if (rccl.CommCount && rccl.CommCount(rccl.comm, &n) != 0)
         return -1;
-    ARGCHECK(rccl.comm != nullptr, "solr_hip_gather_strips: no communicator (solr_hip_comm_init)");
-    ARGCHECK(root >= 0 && root < rccl.world, "solr_hip_gather_strips: no such root");
-    ARGCHECK(g.width > 0 && g.height > 0, "solr_hip_gather_strips: no frame was rendered");
-    if (!ok())
-        return -1;
-    const int flight = g.current;
-    const hipStream_t stream = flightStream(flight);
-    const size_t rowBytes = (size_t)g.width * SOLR_COLOR_DEPTH;
+    return n;
+}
+
+namespace
+{
+/* One gather: rows [first, first + count) of this rank -> `root`, `rowBytes` per row, on `stream`; the root receives
+ * every rank's rows at their place in `assembled`.  Sizes come from the strip table alone; `own` == nullptr (this
+ * rank cannot send its own rows) sends zeros. */
+bool gatherRows(int root, const void *own, void *assembled, size_t rowBytes, int datatype, size_t perByte, hipStream_t stream,
+                const char *what)
+{
     int first = 0, count = 0;
     stripOf(rccl.rank, rccl.world, g.height, &first, &count);
-    ARGCHECK(rccl.world == 1 || (g.nbRows == count && (count == 0 || g.firstRow == first)),
-             "solr_hip_gather_strips: this process's strip is not the one solr_hip_strip_rows (or the table of "
-             "solr_hip_set_strip_table) gives its rank");
-    if (!ok())
-        return -1;
     if (rccl.world == 1) /* one process: the strip is whatever was set, the "gather" a copy into the frame */
     {
         first = g.nbRows >= 0 ? g.firstRow : 0;
         count = stripRows();
     }
-    const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr;
-    if (rccl.rank == root)
+    const void *payload = own;
+    if (!payload && count > 0 && !(payload = zeroPayload((size_t)count * rowBytes)))
     {
-        reserve(rccl.frame[flight], (size_t)g.height * rowBytes);
-        if (!ok())
-            return -1;
+        setError(-1, (std::string(what) + ": no device memory; the other ranks are left waiting").c_str(), __FILE__, __LINE__);
+        return false;
     }
     bool fine = rcclOk(rccl.GroupStart(), "ncclGroupStart");
-    if (fine && rccl.rank == root)
+    if (fine && rccl.rank == root && assembled)
         for (int r = 0; r < rccl.world && fine; ++r)
         {
             int rf = first, rc = count;
             if (rccl.world > 1)
                 stripOf(r, rccl.world, g.height, &rf, &rc);
             if (rc > 0)
-                fine = rcclOk(rccl.Recv((char *)rccl.frame[flight].ptr + (size_t)rf * rowBytes, (size_t)rc * rowBytes,
-                                        RCCL_UINT8, r, rccl.comm, stream),
+                fine = rcclOk(rccl.Recv((char *)assembled + (size_t)rf * rowBytes, (size_t)rc * rowBytes / perByte, datatype, r,
+                                        rccl.comm, stream),
                               "ncclRecv");
         }
     if (fine && count > 0)
-        fine = rcclOk(rccl.Send(src, (size_t)count * rowBytes, RCCL_UINT8, root, rccl.comm, stream), "ncclSend");
+        fine = rcclOk(rccl.Send(payload, (size_t)count * rowBytes / perByte, datatype, root, rccl.comm, stream), "ncclSend");
     if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd"))
         fine = false;
-    rccl.lastFlight = flight;
-    return fine ? 0 : -1;
+    return fine;
+}
+
+/* this process's strip is the one its rank has in the eyes of the others */
+bool stripIsTheTables()
+{
+    if (rccl.world == 1)
+        return true;
+    int first = 0, count = 0;
+    stripOf(rccl.rank, rccl.world, g.height, &first, &count);
+    return stripRows() == count && (count == 0 || (g.nbRows >= 0 ? g.firstRow : 0) == first);
+}
+
+int gatherImpl(int root, bool ids, const char *who)
+{
+    if (!g.initialized || !rccl.comm || root < 0 || root >= rccl.world || g.width < 1 || g.height < 1)
+    {
+        /* program errors, the same on every rank: nobody is waiting */
+        if (ok())
+            setError(-1, (std::string(who) + (!g.initialized ? ": initialize_scene has not been called"
+                                              : !rccl.comm   ? ": no communicator (solr_hip_comm_init)"
+                                              : g.width < 1  ? ": no frame was rendered"
+                                                             : ": no such root")).c_str(),
+                     __FILE__, __LINE__);
+        return -1;
+    }
+    (void)hipSetDevice(g.device);
+    const int flight = g.current;
+    const hipStream_t stream = flightStream(flight);
+    const size_t rowBytes = (size_t)g.width * (ids ? sizeof(PrimitiveXYIdBuffer) : (size_t)SOLR_COLOR_DEPTH);
+    /* rank-local trouble decides what is sent, not whether (see the note on collectives above) */
+    bool mine = ok();
+    if (mine && !stripIsTheTables())
+    {
+        setError(-1, (std::string(who) + ": this process's strip is not the one solr_hip_strip_rows (or the table of "
+                                         "solr_hip_set_strip_table) gives its rank; the root received zeros for its rows").c_str(),
+                 __FILE__, __LINE__);
+        mine = false;
+    }
+    const void *src = ids ? flightIds(flight).ptr : (g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr);
+    if (!src)
+        mine = false;
+    DeviceBuffer &assembled = ids ? rccl.idsFrame : rccl.frame[flight];
+    if (rccl.rank == root && !reserveQuietly(assembled, (size_t)g.height * rowBytes, true))
+    {
+        setError(-1, (std::string(who) + ": no device memory for the assembled frame; the other ranks are left waiting").c_str(),
+                 __FILE__, __LINE__);
+        return -1;
+    }
+    const bool fine = gatherRows(root, mine ? src : nullptr, rccl.rank == root ? assembled.ptr : nullptr, rowBytes,
+                                 ids ? RCCL_INT32 : RCCL_UINT8, ids ? 4 : 1, stream, who);
+    if (!ids)
+        rccl.lastFlight = flight;
+    else
+        rccl.idsFlight = flight;
+    return (fine && mine && ok()) ? 0 : -1;
+}
+} // namespace
+
+/* the strip of the frame rendered last -> `root`, on that frame's stream.  Every rank calls it once per frame,
+ * in the same order of frames.  Returns immediately. */
+int solr_hip_gather_strips(int root)
+{
+    return gatherImpl(root, false, "solr_hip_gather_strips");
+}
+
+/* Picking on an N-GPU frame (GPUKernel::getPrimitiveAt, GPUKernel.cpp:729-739, reads primitivesXYIds of the whole
+ * frame; the reference's d2h_bitmap copies every device's strip of them after every frame, CudaRayTracer.cu:1664-1670):
+ * the PrimitiveXYIdBuffer strips of the frame rendered last -> `root`, 16 bytes per pixel - five times the image, so
+ * on demand, when picking asks, not per frame.  Every rank calls it; solr_hip_d2h_gathered_ids on the root waits and
+ * copies the assembled height x width records to the host. */
+int solr_hip_gather_ids(int root)
+{
+    return gatherImpl(root, true, "solr_hip_gather_ids");
 }
 
 /* root: the assembled frame of the gather issued last (device memory, height x width x 3; valid once the
@@ -4417,6 +4772,20 @@ int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap)
     return ok() ? 0 : -1;
 }
 
+int solr_hip_d2h_gathered_ids(PrimitiveXYIdBuffer *hostIds)
+{
+    if (!ready("solr_hip_d2h_gathered_ids"))
+        return -1;
+    ARGCHECK(hostIds != nullptr && rccl.idsFrame.ptr != nullptr, "solr_hip_d2h_gathered_ids: nothing was gathered on this rank");
+    if (!ok())
+        return -1;
+    const hipStream_t stream = flightStream(rccl.idsFlight);
+    HIPCHECK(hipMemcpyAsync(hostIds, rccl.idsFrame.ptr, (size_t)g.height * g.width * sizeof(PrimitiveXYIdBuffer),
+                            hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    return ok() ? 0 : -1;
+}
+
 void solr_hip_comm_finalize(void)
 {
     solr_hip_set_strip_table(nullptr, nullptr, 0, 0); /* the table was that communicator's */
@@ -4428,7 +4797,12 @@ void solr_hip_comm_finalize(void)
     }
     for (DeviceBuffer &b : rccl.frame)
         release(b);
+    release(rccl.idsFrame);
+    release(rccl.zeros);
+    release(rccl.scratch);
     rccl.world = 0;
+    rccl.haloAgreed = -1;
+    rccl.haloStale = true;
 }
 
 #ifdef SOLR_TIMING

@@ -410,6 +410,24 @@ extern "C" int solr_hip_build_tree(const Primitive *primitives, const unsigned c
     }
     const int n = nbPrimitives;
     hipStream_t stream = nullptr;
+    /* on the engine's device, whichever thread calls (one process per GPU: a tree built on the calling thread's
+     * current device - GPU 0 in a fresh thread - would put every rank's build, and a context, there); the caller's
+     * current device is restored on the way out */
+    struct DeviceScope
+    {
+        int before = -1;
+        DeviceScope()
+        {
+            if (hipGetDevice(&before) != hipSuccess)
+                before = -1;
+            (void)hipSetDevice(solr_hip_get_device());
+        }
+        ~DeviceScope()
+        {
+            if (before >= 0)
+                (void)hipSetDevice(before);
+        }
+    } deviceScope;
 
     /* depth and grid sizes, GPUKernel.cpp:1056-1076 */
     int depth = 0;

@@ -1,0 +1,97 @@
+"""bench.py at N > 1.  The driver starts it bare (`python bench.py --gpus N`): it must then launch its own rank
+processes, relay rank 0's JSON line, and fail cleanly - no hang, a non-zero exit - when a rank cannot run.
+
+CPU: the launcher in this GPU-less container (both ranks get as far as "needs a GPU").  GPU: a rehearsal of the whole
+N = 2 job on the box's one GPU - SOLR_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and tests/loopback_rccl.c stands in
+for RCCL (which refuses two ranks on one device) - so that the strips, the communicator, the balance, both timed
+segments, the gather-alone timing and the gathered-frame check of the JSON line have all run with two ranks before
+the first real 8-GPU run.  Its numbers mean nothing; its `gathered_equals_single_gpu` does."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bare_launch_without_gpus_fails_cleanly(solr, have_gpu):
+    if have_gpu:
+        pytest.skip("this is the GPU-less container's test")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=180)
+    assert res.returncode != 0
+    assert "rank 0 needs a GPU" in res.stderr and "rank 1 needs a GPU" in res.stderr, res.stderr[-2000:]
+    assert "the job is void" in res.stderr
+    assert res.stdout.strip() == ""          # no JSON line from a job that did not run
+
+
+def test_a_launchers_environment_is_respected(solr, have_gpu):
+    """under torch.distributed.run (RANK / WORLD_SIZE set) bench.py is a rank, not a launcher; a world size that
+    does not match --gpus is refused at once"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 2 and "WORLD_SIZE=1" in res.stderr
+
+
+def _rehearse(extra, timeout):
+    from test_multi_rank_gpu import build_loopback
+    directory = tempfile.mkdtemp(prefix="solr_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        env.update(SOLR_BENCH_SHARE_GPU="1", SOLR_HIP_RCCL_LIBRARY=build_loopback(directory), SOLR_LOOPBACK_DIR=directory,
+                   SOLR_LOOPBACK_TIMEOUT="60", SOLR_BENCH_TIMEOUT=str(timeout))
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + extra,
+                             env=env, capture_output=True, text=True, timeout=timeout + 60)
+        assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
+        return json.loads(res.stdout.strip().splitlines()[-1])
+    finally:
+        shutil.rmtree(directory, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_of_the_default_job(solr):
+    line = _rehearse(["--steps", "12", "--warmup", "3", "--width", "640", "--height", "360"], 600)
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["steps"] == 12 and line["warmup"] == 3 and line["scaling"] == "strong"
+    assert cfg["rccl_ranks"] == 2 and cfg["strips"] == "balanced by cost"
+    assert cfg["gathered_equals_single_gpu"] is True
+    assert len(cfg["per_rank"]) == 2 and [r["rank"] for r in cfg["per_rank"]] == [0, 1]
+    rows = [r["rows"] for r in cfg["per_rank"]]
+    assert rows[0][0] == 0 and rows[0][1] + rows[1][1] == 360 and rows[1][0] == rows[0][1] and rows[0][1] % 8 == 0
+    assert [r["equal_strips"]["rows"] for r in cfg["per_rank"]] == [[0, 180], [180, 180]]
+    assert cfg["slowest_rank"] in (0, 1) and cfg["gather_only_ms"] > 0
+    assert set(cfg["rates_mrays_per_s"]) == {"balanced_strips_native_gather", "equal_strips_native_gather"}
+    assert cfg["rates_mrays_per_s"]["balanced_strips_native_gather"] == pytest.approx(line["value"], rel=1e-3)
+    assert "rehearsal" in cfg and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
+    assert cfg["step_ms_spread"]["min"] <= cfg["step_ms_spread"]["median"] <= cfg["step_ms_spread"]["max"]
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_of_cfg4(solr):
+    """BASELINE configs[4] on two ranks: passes 0...73 at 3840 x 2160, natural depth of field, ambient occlusion
+    through the depth-halo exchange on cost-balanced strips; the assembled frames after passes 0, 11 and 73 equal
+    the ones rank 0 renders alone"""
+    line = _rehearse(["--config", "cfg4", "--steps", "74", "--warmup", "2"], 1200)
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["gathered_equals_single_gpu"] is True and cfg["rccl_ranks"] == 2
+    rows = [r["rows"] for r in cfg["per_rank"]]
+    assert rows[0][1] + rows[1][1] == 2160
+
+
+@pytest.mark.gpu
+def test_one_rank_through_the_distributed_path_over_rccl(solr):
+    """SOLR_BENCH_FORCE_DIST=1: the N > 1 path with a communicator of one rank of the real RCCL"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(SOLR_BENCH_FORCE_DIST="1", MASTER_PORT="29613")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline",
+                          "--width", "640", "--height", "360"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["config"]["gathered_equals_single_gpu"] is True
+    assert line["config"]["per_rank"][0]["rows"] == [0, 360]

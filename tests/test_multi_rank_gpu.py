@@ -1,0 +1,165 @@
+"""The engine's multi-rank code with MORE THAN ONE RANK (tests/multi_rank_worker.py is a rank): strips gathered to a
+root, primitive ids gathered for picking, frames in flight, the depth-halo exchange of ambient-occlusion frames with
+an agreed height and a shared random buffer, cost-balanced strips, and a rank in trouble that must not leave the
+others waiting - every assembled frame compared bit for bit with the frame one GPU renders.
+
+Two transports.  "rccl": the real library, one GPU per rank - skipped where the box has fewer GPUs than ranks (the
+test boxes have one).  "loopback": tests/loopback_rccl.c, a file-based stand-in for the handful of RCCL entry points
+the engine resolves, with which the ranks share GPU 0; it turns a missing peer or a count mismatch - a hang under
+RCCL - into an error code.  The transport's own test runs on CPU (host buffers)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import shutil
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build_loopback(directory):
+    lib = os.path.join(directory, "libloopback_rccl.so")
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", lib, os.path.join(HERE, "loopback_rccl.c"), "-ldl"], check=True)
+    return lib
+
+
+def run_ranks(world, transport, timeout=420):
+    directory = tempfile.mkdtemp(prefix="solr_ranks_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        if transport == "loopback":
+            build_loopback(directory)
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multi_rank_worker.py"), str(r), str(world), directory,
+                                   transport], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for r in range(world)]
+        outputs = []
+        try:
+            for p in procs:
+                outputs.append(p.communicate(timeout=timeout)[0])
+        except subprocess.TimeoutExpired:
+            for p in procs:
+                p.kill()
+            tails = [p.communicate()[0][-3000:] for p in procs]
+            pytest.fail("ranks still running after %d s:\n%s" % (timeout, "\n-----\n".join(tails)))
+        for r, (p, out) in enumerate(zip(procs, outputs)):
+            assert p.returncode == 0 and "MULTI_RANK_OK %d of %d" % (r, world) in out, "rank %d:\n%s" % (r, out[-6000:])
+        reports = [json.load(open(os.path.join(directory, "report.%d" % r))) for r in range(world)]
+    finally:
+        shutil.rmtree(directory, ignore_errors=True)
+    return reports
+
+
+def check_partitions(reports, height=136):
+    for key, align in (("equal_strip", 1), ("balanced_strip", 8), ("balanced_strip_with_reach", 16)):
+        at = 0
+        for rep in sorted(reports, key=lambda r: r["rank"]):
+            first, count = rep[key]
+            if count:
+                assert first == at and first % align == 0, (key, reports)
+                at += count
+        assert at == height, (key, reports)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_assemble_the_one_gpu_frame(solr, world):
+    check_partitions(run_ranks(world, "loopback"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_over_rccl_assemble_the_one_gpu_frame(solr, world):
+    if solr.hip_lib().solr_hip_device_count() < world:
+        pytest.skip("needs %d GPUs: RCCL refuses two ranks on one device" % world)
+    check_partitions(run_ranks(world, "rccl"))
+
+
+# ---- the stand-in transport itself, on CPU (host buffers) --------------------------------------------------------
+
+_TRANSPORT_RANK = r'''
+import ctypes as C, os, sys, time
+import numpy as np
+rank, world, directory = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+L = C.CDLL(os.path.join(directory, "libloopback_rccl.so"))
+L.ncclSend.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+L.ncclRecv.argtypes = L.ncclSend.argtypes
+L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+L.ncclCommDestroy.argtypes = [C.c_void_p]
+class Id(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Id, C.c_int]
+uid = Id()
+path = os.path.join(directory, "uid")
+if rank == 0:
+    assert L.ncclGetUniqueId(C.byref(uid)) == 0
+    open(path + ".part", "wb").write(bytes(uid)); os.rename(path + ".part", path)
+else:
+    while not os.path.exists(path): time.sleep(0.005)
+    C.memmove(C.byref(uid), open(path, "rb").read(), 128)
+comm = C.c_void_p()
+assert L.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+U8, F32, SUM, MAX = 1, 7, 0, 2
+# a gather to rank 0 with unequal counts, twice (ordering per pair), inside groups
+for rnd in range(2):
+    mine = np.full(1000 * (rank + 1), 10 * rnd + rank, np.uint8)
+    got = [np.zeros(1000 * (r + 1), np.uint8) for r in range(world)]
+    assert L.ncclGroupStart() == 0
+    if rank == 0:
+        for r in range(world):
+            assert L.ncclRecv(got[r].ctypes.data, got[r].size, U8, r, comm, None) == 0
+    assert L.ncclSend(mine.ctypes.data, mine.size, U8, 0, comm, None) == 0
+    assert L.ncclGroupEnd() == 0
+    if rank == 0:
+        for r in range(world):
+            assert (got[r] == 10 * rnd + r).all()
+# neighbours trade rows both ways in one group
+up, down = np.zeros(64, np.float32), np.zeros(64, np.float32)
+mine = np.full(64, float(rank), np.float32)
+assert L.ncclGroupStart() == 0
+if rank > 0:
+    L.ncclSend(mine.ctypes.data, 64, F32, rank - 1, comm, None); L.ncclRecv(up.ctypes.data, 64, F32, rank - 1, comm, None)
+if rank + 1 < world:
+    L.ncclSend(mine.ctypes.data, 64, F32, rank + 1, comm, None); L.ncclRecv(down.ctypes.data, 64, F32, rank + 1, comm, None)
+assert L.ncclGroupEnd() == 0
+assert rank == 0 or (up == rank - 1).all()
+assert rank + 1 == world or (down == rank + 1).all()
+# all-reduce: sum and max, the same bits on every rank
+v = np.arange(5, dtype=np.float32) + rank
+assert L.ncclAllReduce(v.ctypes.data, v.ctypes.data, 5, F32, SUM, comm, None) == 0
+assert (v == world * np.arange(5) + sum(range(world))).all()
+v = np.array([rank, -rank], np.float32)
+assert L.ncclAllReduce(v.ctypes.data, v.ctypes.data, 2, F32, MAX, comm, None) == 0
+assert tuple(v) == (world - 1, 0)
+# a receive larger than its send is an error, not a truncation; a send nobody posted is a timeout, not a hang
+if world > 1:
+    if rank == 1:
+        small = np.zeros(10, np.uint8)
+        assert L.ncclSend(small.ctypes.data, 10, U8, 0, comm, None) == 0
+    if rank == 0:
+        big = np.zeros(20, np.uint8)
+        assert L.ncclRecv(big.ctypes.data, 20, U8, 1, comm, None) == 5
+        os.environ["SOLR_LOOPBACK_TIMEOUT"] = "0.3"
+        assert L.ncclRecv(big.ctypes.data, 20, U8, 1, comm, None) == 2
+        os.environ["SOLR_LOOPBACK_TIMEOUT"] = "30"
+assert L.ncclCommDestroy(comm) == 0
+print("TRANSPORT_OK", rank)
+'''
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_loopback_transport_on_host_buffers(world):
+    directory = tempfile.mkdtemp(prefix="solr_loopback_")
+    try:
+        build_loopback(directory)
+        env = dict(os.environ, SOLR_LOOPBACK_HOST="1", SOLR_LOOPBACK_DIR=directory, SOLR_LOOPBACK_TIMEOUT="30")
+        procs = [subprocess.Popen([sys.executable, "-c", _TRANSPORT_RANK, str(r), str(world), directory], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        for r, p in enumerate(procs):
+            out = p.communicate(timeout=120)[0]
+            assert p.returncode == 0 and "TRANSPORT_OK %d" % r in out, out[-3000:]
+        left = [f for f in os.listdir(directory) if f.startswith("lb")]
+        assert not left, left     # rank 0 swept the communicator's files
+    finally:
+        shutil.rmtree(directory, ignore_errors=True)
