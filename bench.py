@@ -149,12 +149,18 @@ def launch(args):
     return 0
 
 
-def spread(samples, divide=1.0):
-    """min / median / max of a list of milliseconds (the error bar of a short timed region)"""
-    xs = sorted(float(x) / divide for x in samples if x is not None and x >= 0.0)
+def spread(samples, divide=1.0, window=1):
+    """min / median / max of a list of milliseconds (the error bar of a short timed region).  window > 1: of the mean
+    over every run of `window` consecutive samples - with frames in flight the launches end in bursts, and only a run
+    longer than the flights says what a step takes."""
+    xs = [float(x) / divide for x in samples if x is not None and x >= 0.0]
+    if window > 1 and len(xs) >= window:
+        xs = [sum(xs[i:i + window]) / window for i in range(len(xs) - window + 1)]
+    xs.sort()
     if not xs:
         return None
-    return {"min": round(xs[0], 5), "median": round(xs[len(xs) // 2], 5), "max": round(xs[-1], 5), "samples": len(xs)}
+    return {"min": round(xs[0], 5), "median": round(xs[len(xs) // 2], 5), "max": round(xs[-1], 5), "samples": len(xs),
+            "window": window}
 
 
 def main():
@@ -386,7 +392,7 @@ def main():
     t_issued_ms = main_run["issued"] / args.steps * 1e3
     kernel_avg_ms = main_run["kernel_avg_ms"]
     kernel_spread = spread(main_run["kernel_samples"])
-    step_spread = spread(main_run["gap_samples"], divide=float(stride))
+    step_spread = spread(main_run["gap_samples"], divide=float(stride), window=max(2 * args.frames_in_flight // stride, 2))
     strips = "balanced by cost" if balanced else "equal rows"
     kernel_basis = "HIP events around every launch of the timed region"
     if distributed and args.frames_in_flight > 1:
@@ -580,7 +586,7 @@ def main():
                    # untimed set-up frames before the W warm-up steps (clocks, tile-cost feedback, order-free lists)
                    "setup_frames_before_warmup": PREROLL_FRAMES,
                    # the error bar of the timed region: the time from the end of a timed launch to the end of the next
-                   # (HIP events on the launch streams), per step
+                   # (HIP events on the launch streams), per step, averaged over runs of `window` launches
                    "step_ms_spread": step_spread,
                    # nodes per order-free list when long rays' walks use them, else 0
                    "order_free_nodes": int(hip.solr_hip_order_free_nodes()),

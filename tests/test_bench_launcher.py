@@ -44,7 +44,7 @@ def _rehearse(extra, timeout):
     directory = tempfile.mkdtemp(prefix="solr_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-        env.update(SOLR_BENCH_SHARE_GPU="1", SOLR_HIP_RCCL_LIBRARY=build_loopback(directory), SOLR_LOOPBACK_DIR=directory,
+        env.update(SOLR_BENCH_SHARE_GPU="1", SOLR_HIP_RCCL_LIBRARY=build_loopback(), SOLR_LOOPBACK_DIR=directory,
                    SOLR_LOOPBACK_TIMEOUT="60", SOLR_BENCH_TIMEOUT=str(timeout))
         res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + extra,
                              env=env, capture_output=True, text=True, timeout=timeout + 60)

@@ -20,19 +20,27 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def build_loopback(directory):
-    lib = os.path.join(directory, "libloopback_rccl.so")
-    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", lib, os.path.join(HERE, "loopback_rccl.c"), "-ldl"], check=True)
+def build_loopback():
+    """tests/loopback_rccl.c -> build/libloopback_rccl.so (in the tree: /dev/shm and /tmp may be mounted noexec)"""
+    out = os.path.join(os.path.dirname(HERE), "build")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, "libloopback_rccl.so")
+    src = os.path.join(HERE, "loopback_rccl.c")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        tmp = "%s.%d" % (lib, os.getpid())
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", tmp, src, "-ldl"], check=True)
+        os.rename(tmp, lib)
     return lib
 
 
 def run_ranks(world, transport, timeout=420):
     directory = tempfile.mkdtemp(prefix="solr_ranks_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
+        env = dict(os.environ)
         if transport == "loopback":
-            build_loopback(directory)
+            env.update(SOLR_HIP_RCCL_LIBRARY=build_loopback(), SOLR_LOOPBACK_DIR=directory, SOLR_LOOPBACK_TIMEOUT="45")
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multi_rank_worker.py"), str(r), str(world), directory,
-                                   transport], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                                   transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
                  for r in range(world)]
         outputs = []
         try:
@@ -82,7 +90,7 @@ _TRANSPORT_RANK = r'''
 import ctypes as C, os, sys, time
 import numpy as np
 rank, world, directory = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-L = C.CDLL(os.path.join(directory, "libloopback_rccl.so"))
+L = C.CDLL(os.environ["SOLR_HIP_RCCL_LIBRARY"])
 L.ncclSend.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 L.ncclRecv.argtypes = L.ncclSend.argtypes
 L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -152,8 +160,7 @@ print("TRANSPORT_OK", rank)
 def test_loopback_transport_on_host_buffers(world):
     directory = tempfile.mkdtemp(prefix="solr_loopback_")
     try:
-        build_loopback(directory)
-        env = dict(os.environ, SOLR_LOOPBACK_HOST="1", SOLR_LOOPBACK_DIR=directory, SOLR_LOOPBACK_TIMEOUT="30")
+        env = dict(os.environ, SOLR_HIP_RCCL_LIBRARY=build_loopback(), SOLR_LOOPBACK_HOST="1", SOLR_LOOPBACK_DIR=directory, SOLR_LOOPBACK_TIMEOUT="30")
         procs = [subprocess.Popen([sys.executable, "-c", _TRANSPORT_RANK, str(r), str(world), directory], env=env,
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
         for r, p in enumerate(procs):
