@@ -133,6 +133,34 @@ SOLR_DEV v3 project(v3 A, v3 B) { return B * (dot(A, B) / dot(B, B)); }
 /* out of line: never taken on sane inputs, and inlining it doubles the live registers at its call site */
 __device__ __attribute__((noinline)) float pow_general(float a, float b) { return (float)pow((double)a, (double)b); }
 
+/* The polynomials' coefficients are materialised where they are used, in scalar registers, by instructions the
+ * compiler cannot move: left to itself it hoists the nineteen binary64 constants out of the bounce loop - a 64-bit
+ * immediate is a pair of moves it does not know how to re-materialise - and some thirty vector registers of the
+ * kernel's 128 then hold them through every walk of the frame, six of them by way of scratch memory
+ * (profiles/r3/isa_notes.txt).  Two s_mov_b32 per coefficient per call instead, and v_fma_f64 takes the pair as its
+ * addend. */
+template <unsigned long long BITS>
+SOLR_DEV double scalarConstant()
+{
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3"
+                 : "=s"(lo), "=s"(hi)
+                 : "n"((unsigned)(BITS & 0xffffffffull)), "n"((unsigned)(BITS >> 32)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+constexpr double POW_LOG_COEFFS[8] = SOLR_POW_LOG_COEFFS;
+constexpr double POW_EXP_COEFFS[13] = SOLR_POW_EXP_COEFFS;
+/* p * x + c[K], then on down to c[0] */
+template <int K, const double *C>
+SOLR_DEV double hornerDown(double p, double x)
+{
+    p = __builtin_fma(p, x, scalarConstant<__builtin_bit_cast(unsigned long long, C[K])>());
+    if constexpr (K > 0)
+        return hornerDown<K - 1, C>(p, x);
+    else
+        return p;
+}
+
 SOLR_DEV float pow_f(float a, float b)
 {
 #ifdef SOLR_LIBRARY_POW /* A/B builds: the library routine everywhere */
@@ -148,20 +176,12 @@ SOLR_DEV float pow_f(float a, float b)
     const double m = (double)__int_as_float((ix & 0x007fffff) | 0x3f800000);
     const double invc = SOLR_POW_LOG_TABLE[2 * idx], log2c = SOLR_POW_LOG_TABLE[2 * idx + 1];
     const double r = __builtin_fma(m, invc, -1.0); /* exact: 24-bit m times 28-bit invc */
-    const double lc[8] = SOLR_POW_LOG_COEFFS;
-    double p = lc[7];
-#pragma unroll
-    for (int k = 6; k >= 0; --k)
-        p = __builtin_fma(p, r, lc[k]);
+    const double p = hornerDown<6, POW_LOG_COEFFS>(scalarConstant<__builtin_bit_cast(unsigned long long, POW_LOG_COEFFS[7])>(), r);
     const double L = ((double)e + log2c) + p * r;
     const double t = (double)b * L;
     const double kk = __builtin_rint(t);
     const double f = t - kk;
-    const double ec[13] = SOLR_POW_EXP_COEFFS;
-    double q = ec[10];
-#pragma unroll
-    for (int k = 9; k >= 0; --k)
-        q = __builtin_fma(q, f, ec[k]);
+    const double q = hornerDown<9, POW_EXP_COEFFS>(scalarConstant<__builtin_bit_cast(unsigned long long, POW_EXP_COEFFS[10])>(), f);
     const float result = (float)__builtin_ldexp(q, (int)kk);
     return zero ? 0.f : result;
 }
