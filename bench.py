@@ -451,6 +451,29 @@ def main():
             frame()
             hip.solr_hip_d2h(C.byref(si), C.c_void_p(host_rgb.ctypes.data), None)
         with_image_d2h = (time.perf_counter() - ta) / n_extra
+        # the same read-back pipelined (solr_hip_d2h_image_async: the copy on a stream of its own behind the
+        # kernel, into a page-locked image; the host takes frame n - 2 while frames n - 1 and n are under way)
+        with_image_pipelined = None
+        if not cfg4:
+            from collections import deque
+            hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
+            tickets = deque()
+
+            def piped():
+                frame()
+                tickets.append(hip.solr_hip_d2h_image_async())
+                while len(tickets) > 2:
+                    if not hip.solr_hip_image_wait(tickets.popleft()):
+                        k.check(-1, "solr_hip_image_wait")
+
+            for _ in range(8):
+                piped()
+            ta = time.perf_counter()
+            for _ in range(n_extra):
+                piped()
+            while tickets:
+                hip.solr_hip_image_wait(tickets.popleft())
+            with_image_pipelined = (time.perf_counter() - ta) / n_extra
         k.check(0, "frame protocol rates")
         hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
         rates = {"one_frame_at_a_time": (one_at_a_time, "render, wait for it, render the next"),
@@ -458,6 +481,10 @@ def main():
                                                 "(the reference's render_begin / render_end, SURVEY.md 8d)"),
                  "cudaRender_plus_image": (with_image_d2h, "render + read-back of the RGB image alone (the ids stay on "
                                            "the device until picking asks: HipKernel::render_end)")}
+        if with_image_pipelined:
+            rates["cudaRender_plus_image_pipelined"] = (
+                with_image_pipelined, "render + read-back of the RGB image on a copy stream behind the kernel, the host "
+                "takes the image two frames back (solr_hip_d2h_image_async; HipKernel::setFramesInFlight)")
 
     # ---- N > 1 extras (untimed): the gather alone, and the assembled frame against the frame one GPU renders
     gather_only_ms = None

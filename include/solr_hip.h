@@ -216,6 +216,17 @@ void solr_hip_bind_device_bitmap(void *deviceBitmap);
  * can reach width * height + 10 000.  Reads past `count` give 0. */
 void solr_hip_h2d_randoms_sized(const float *randoms, long count);
 
+/* Pipelined read-back of the image: after cudaRender, solr_hip_d2h_image_async enqueues the copy of the RGB image
+ * of the frame rendered last (this process's strip at its place in a full-size image) into a page-locked host image
+ * owned by the engine, on a copy stream behind that frame's kernel, and returns a ticket (>= 0) at once; with
+ * solr_hip_set_frames_in_flight(2 ... 4) the next frames render while it lands.  solr_hip_image_wait(ticket) waits
+ * for that copy alone and returns the host image, valid until four more tickets have been handed out.  d2h_bitmap
+ * (CudaRayTracer.cu:1647-1672: wait for the frame, then copy, nothing rendering meanwhile) keeps working next to it;
+ * the primitive ids are still fetched with d2h_bitmap when picking asks.  HipKernel::setFramesInFlight builds the
+ * reference's render_begin / render_end protocol on this. */
+int solr_hip_d2h_image_async(void);
+const BitmapBuffer *solr_hip_image_wait(int ticket);
+
 /* Float framebuffer of the strip back to the host (parity tests) */
 void solr_hip_d2h_postprocessing(PostProcessingBuffer *hostBuffer);
 /* Host float framebuffer / primitive ids into the strip (accumulation tests) */

@@ -185,6 +185,9 @@ def _declare_hip(L):
     L.solr_hip_d2h_gathered.argtypes = [C.c_void_p]
     L.solr_hip_d2h_gathered_ids.argtypes = [C.c_void_p]
     L.solr_hip_h2d_randoms_sized.argtypes = [C.c_void_p, C.c_long]
+    L.solr_hip_d2h_image_async.restype = C.c_int
+    L.solr_hip_image_wait.argtypes = [C.c_int]
+    L.solr_hip_image_wait.restype = C.c_void_p
     L.solr_hip_get_variant.restype = C.c_int
     L.solr_hip_memory_usage.argtypes = [P(C.c_ulonglong)]
     L.solr_hip_set_movable.argtypes = [C.c_void_p, C.c_int]
@@ -236,6 +239,8 @@ def _declare_host(L):
     L.SolRx_SetDeterministic.argtypes = [C.c_long]
     L.SolRx_LastError.argtypes = [C.c_char_p, i]
     L.SolRx_Render.argtypes = [d]
+    L.SolRx_SetFramesInFlight.argtypes = [i]
+    L.SolRx_GetBitmap.restype = C.c_void_p
     for name in ("SolRx_GetBoxes", "SolRx_GetPrimitives", "SolRx_GetMaterials", "SolRx_GetRandoms",
                  "SolRx_GetPrimitiveIds"):
         getattr(L, name).argtypes = [P(C.c_void_p), P(i)]

@@ -1324,6 +1324,21 @@ struct Engine
     int timedLaunches = 0;
     std::vector<float> kernelSamples, intervalSamples; /* per timed launch: its duration; end-to-end gap to the one before */
 
+    /* pipelined read-back (solr_hip_d2h_image_async): a ring of page-locked host images, a copy stream, and per
+     * slot the event that says its copy has landed */
+    static const int IMAGE_RING = MAX_FLIGHTS + 1;
+    hipStream_t copyStream = nullptr;
+    BitmapBuffer *pinnedImage[MAX_FLIGHTS + 1] = {};
+    size_t pinnedBytes = 0;
+    hipEvent_t imageDone[MAX_FLIGHTS + 1] = {};
+    hipEvent_t frameRendered = nullptr;
+    int imageNext = 0;
+    /* every buffer set has a second RGB image ("side") for the time a copy still reads the first: a refinement or
+     * accumulation pass stays on the set of the pass before it, and would otherwise wait for that pass's copy */
+    DeviceBuffer bitmapAlt[MAX_FLIGHTS];
+    int bitmapSide[MAX_FLIGHTS] = {0, 0, 0, 0};
+    int flightCopy[MAX_FLIGHTS][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}; /* slot whose copy reads that image, or -1 */
+
     /* device-side rotation (solr_hip_rotate_primitives): what to refit, in which order */
     DeviceBuffer movable, refitPlan;
     int nbMovable = -1;                 /* flags uploaded for that many primitives, -1: none */
@@ -1356,7 +1371,7 @@ bool twoFlights() { return activeFlights() > 1; }
 hipStream_t flightStream(int f) { return f ? g.extraStream[f - 1] : g.stream; }
 DeviceBuffer &flightPp(int f) { return f ? g.ppX[f - 1] : g.pp; }
 DeviceBuffer &flightIds(int f) { return f ? g.idsX[f - 1] : g.ids; }
-DeviceBuffer &flightBitmap(int f) { return f ? g.bitmapX[f - 1] : g.bitmap; }
+DeviceBuffer &flightBitmap(int f) { return g.bitmapSide[f] ? g.bitmapAlt[f] : (f ? g.bitmapX[f - 1] : g.bitmap); }
 /* nothing may touch scene or frame buffers while a frame is still in flight on the other stream */
 void quiesce()
 {
@@ -1365,6 +1380,8 @@ void quiesce()
             (void)hipStreamSynchronize(extra);
     if (g.stream)
         (void)hipStreamSynchronize(g.stream);
+    if (g.copyStream)
+        (void)hipStreamSynchronize(g.copyStream);
 }
 
 void setError(int code, const char *what, const char *file, int line)
@@ -1972,6 +1989,22 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         flight = 0;
     const hipStream_t stream = flightStream(flight);
     g.current = flight;
+    if (!g.boundBitmap && g.flightCopy[flight][g.bitmapSide[flight]] >= 0)
+    {
+        /* an asynchronous read-back (solr_hip_d2h_image_async) may still be reading the image this set rendered
+         * last: this frame goes to the set's other image; only the copy of the frame before last - long done - is
+         * waited for */
+        const int side = g.bitmapSide[flight] ^ 1;
+        reserve(g.bitmapAlt[flight], flightBitmap(flight).bytes);
+        if (!ok())
+            return;
+        g.bitmapSide[flight] = side;
+        if (g.flightCopy[flight][side] >= 0)
+        {
+            HIPCHECK(hipStreamWaitEvent(stream, g.imageDone[g.flightCopy[flight][side]], 0));
+            g.flightCopy[flight][side] = -1;
+        }
+    }
 
     /* the box-debug view and the census count every node of the original tree */
     const bool full = sceneInfo.renderBoxes != 0 || sceneInfo.advancedIllumination == aiBasic ||
@@ -2262,6 +2295,35 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     }
 }
 
+void releaseImageRing()
+{
+    if (g.copyStream)
+        (void)hipStreamSynchronize(g.copyStream);
+    for (int i = 0; i < Engine::IMAGE_RING; ++i)
+    {
+        if (g.pinnedImage[i])
+            (void)hipHostFree(g.pinnedImage[i]);
+        g.pinnedImage[i] = nullptr;
+        if (g.imageDone[i])
+            (void)hipEventDestroy(g.imageDone[i]);
+        g.imageDone[i] = nullptr;
+    }
+    if (g.frameRendered)
+        (void)hipEventDestroy(g.frameRendered);
+    g.frameRendered = nullptr;
+    if (g.copyStream)
+        (void)hipStreamDestroy(g.copyStream);
+    g.copyStream = nullptr;
+    g.pinnedBytes = 0;
+    g.imageNext = 0;
+    for (int f = 0; f < MAX_FLIGHTS; ++f)
+    {
+        g.flightCopy[f][0] = g.flightCopy[f][1] = -1;
+        g.bitmapSide[f] = 0;
+        release(g.bitmapAlt[f]);
+    }
+}
+
 void collectEvents()
 {
     hipEvent_t before = nullptr;
@@ -2500,6 +2562,7 @@ void finalize_scene(vec2i)
         release(g.bitmapX[f]);
     }
     dropExtraStreams();
+    releaseImageRing();
     if (g.orderEvent)
         (void)hipEventDestroy(g.orderEvent);
     g.orderEvent = nullptr;
@@ -3829,6 +3892,73 @@ void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYI
     occ.x = 1;
     occ.y = 1;
     d2h_bitmap(occ, *sceneInfo, bitmap, primitivesXYIds);
+}
+
+/* Pipelined read-back of the image (SURVEY.md 8d defines the metric over cudaRender + d2h_bitmap; d2h_bitmap waits
+ * for the frame and then for the copy, CudaRayTracer.cu:1647-1672, and nothing renders meanwhile).  Called after
+ * cudaRender, solr_hip_d2h_image_async enqueues the copy of the RGB image of the frame rendered last - this
+ * process's strip at its place in a full-size image, like d2h_bitmap - into a page-locked host image of the
+ * engine's, on a copy stream of its own behind that frame's kernel, and returns a ticket at once; the render
+ * streams are free for the next frames (solr_hip_set_frames_in_flight), whose kernels overlap the copy.
+ * solr_hip_image_wait(ticket) waits for that one copy and returns the host image; it stays valid until
+ * MAX_FLIGHTS more tickets have been handed out.  The ids stay on the device until d2h_bitmap asks for them. */
+int solr_hip_d2h_image_async(void)
+{
+    if (!ready("solr_hip_d2h_image_async"))
+        return -1;
+    ARGCHECK(g.width > 0 && g.height > 0, "solr_hip_d2h_image_async: no frame was rendered");
+    if (!ok())
+        return -1;
+    HIPCHECK(hipSetDevice(g.device));
+    const size_t frameBytes = (size_t)g.width * g.height * SOLR_COLOR_DEPTH;
+    if (g.pinnedBytes < frameBytes)
+    {
+        releaseImageRing();
+        for (int i = 0; i < Engine::IMAGE_RING && ok(); ++i)
+        {
+            HIPCHECK(hipHostMalloc((void **)&g.pinnedImage[i], frameBytes, hipHostMallocDefault));
+            if (ok())
+                memset(g.pinnedImage[i], 0, frameBytes);
+        }
+        if (ok())
+            g.pinnedBytes = frameBytes;
+    }
+    if (ok() && !g.copyStream)
+    {
+        HIPCHECK(hipStreamCreateWithFlags(&g.copyStream, hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&g.frameRendered, hipEventDisableTiming));
+        for (int i = 0; i < Engine::IMAGE_RING && ok(); ++i)
+            HIPCHECK(hipEventCreateWithFlags(&g.imageDone[i], hipEventDisableTiming));
+    }
+    if (!ok())
+        return -1;
+    const int flight = g.current;
+    const int slot = g.imageNext;
+    g.imageNext = (g.imageNext + 1) % Engine::IMAGE_RING;
+    const int rows = stripRows();
+    const int first = g.nbRows >= 0 ? g.firstRow : 0;
+    const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr;
+    HIPCHECK(hipEventRecord(g.frameRendered, flightStream(flight)));
+    HIPCHECK(hipStreamWaitEvent(g.copyStream, g.frameRendered, 0));
+    if (rows > 0 && src)
+        HIPCHECK(hipMemcpyAsync(g.pinnedImage[slot] + (size_t)g.width * first * SOLR_COLOR_DEPTH, src,
+                                (size_t)g.width * rows * SOLR_COLOR_DEPTH, hipMemcpyDeviceToHost, g.copyStream));
+    HIPCHECK(hipEventRecord(g.imageDone[slot], g.copyStream));
+    if (!g.boundBitmap)
+        g.flightCopy[flight][g.bitmapSide[flight]] = slot;
+    return ok() ? slot : -1;
+}
+
+const BitmapBuffer *solr_hip_image_wait(int ticket)
+{
+    if (!ready("solr_hip_image_wait"))
+        return nullptr;
+    ARGCHECK(ticket >= 0 && ticket < Engine::IMAGE_RING && g.pinnedImage[ticket] != nullptr,
+             "solr_hip_image_wait: no such ticket");
+    if (!ok())
+        return nullptr;
+    HIPCHECK(hipEventSynchronize(g.imageDone[ticket]));
+    return ok() ? g.pinnedImage[ticket] : nullptr;
 }
 
 void solr_hip_d2h_postprocessing(PostProcessingBuffer *hostBuffer)

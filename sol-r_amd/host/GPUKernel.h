@@ -296,10 +296,25 @@ public:
     /* ---------- Rendering (GPUKernel.h:100-102) ---------- */
     virtual void render_begin(const float timer);
     virtual void render_end() = 0;
-    BitmapBuffer *getBitmap() { return m_bitmap.empty() ? nullptr : m_bitmap.data(); }
+    /* the image of the frame render_end delivered last (with frames in flight - setFramesInFlight - that is the
+     * engine's page-locked copy of it, not m_bitmap: nothing is copied twice) */
+    BitmapBuffer *getBitmap() { return m_bitmapView ? m_bitmapView : (m_bitmap.empty() ? nullptr : m_bitmap.data()); }
+    /* Extension (no reference equivalent; the reference's render_end waits for the frame and then copies it,
+     * CudaKernel.cpp:304-312).  n > 1: render_begin also starts the read-back of its frame's image, and render_end
+     * delivers the image of the frame n - 1 calls back - the one whose copy has had n - 1 frames' time to land -
+     * while the newer ones render; flushFrames() waits for all of them and delivers the newest.  1 (default): the
+     * reference's protocol.  Engines without a device ignore it. */
+    virtual void setFramesInFlight(int n) { (void)n; }
+    virtual int getFramesInFlight() const { return 1; }
+    virtual void flushFrames() {}
     /* 0 = ok, otherwise the engine's pending error (no reference equivalent:
      * the reference exits the process on a device error) */
     virtual int lastError(std::string *message = nullptr) { (void)message; return 0; }
+
+protected:
+    BitmapBuffer *m_bitmapView = nullptr; /* see getBitmap */
+
+public:
 
     /* ---------- Primitives (GPUKernel.h:108-149) ---------- */
     int addPrimitive(PrimitiveType type, bool belongsToModel = false);

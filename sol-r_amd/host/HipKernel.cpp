@@ -61,6 +61,10 @@ void HipKernel::releaseDevice()
 {
     syncHost(); /* rotations that only the device has seen would be lost with it */
     fetchPrimitiveIds(); /* and so would the last frame's ids */
+    flushFrames();
+    if (m_bitmapView && !m_bitmap.empty())
+        memcpy(m_bitmap.data(), m_bitmapView, m_bitmap.size()); /* the engine's page-locked images go with it */
+    m_bitmapView = nullptr;
     if (m_deviceInitialized)
         finalize_scene(m_occupancyParameters);
     m_deviceInitialized = false;
@@ -68,6 +72,8 @@ void HipKernel::releaseDevice()
 
 void HipKernel::reshape()
 {
+    flushFrames();
+    m_bitmapView = nullptr; /* the engine's images are re-made for the new size */
     GPUKernel::reshape();
     m_idsOnDevice = false; /* the buffers are re-made for the new size */
     if (m_deviceInitialized)
@@ -136,6 +142,13 @@ void HipKernel::render_begin(const float timer)
 
         cudaRender(m_occupancyParameters, m_blockSize, sceneInfo, objects, m_postProcessingInfo, m_viewPos, m_viewDir,
                    m_angles);
+        if (m_flights > 1)
+        {
+            /* frames in flight: the image starts for the host behind the kernel, on the engine's copy stream */
+            const int ticket = solr_hip_d2h_image_async();
+            if (ticket >= 0)
+                m_tickets.push_back(ticket);
+        }
     }
     m_refresh = (m_sceneInfo.pathTracingIteration < m_sceneInfo.maxPathTracingIterations);
 }
@@ -211,8 +224,46 @@ void HipKernel::render_end()
 {
     /* the image now, the ids when somebody asks (fetchPrimitiveIds): they stay valid on the device until
      * the next frame is rendered into the same buffers */
+    if (m_flights > 1)
+    {
+        /* frames in flight: the oldest read-backs are delivered until fewer than m_flights are under way - the
+         * frame render_begin has just launched keeps rendering.  (The ids on the device are the newest frame's.) */
+        while ((int)m_tickets.size() >= m_flights)
+        {
+            deliver(m_tickets.front());
+            m_tickets.pop_front();
+        }
+        m_idsOnDevice = true;
+        return;
+    }
+    m_bitmapView = nullptr;
     d2h_bitmap(m_occupancyParameters, m_sceneInfo, m_bitmap.data(), nullptr);
     m_idsOnDevice = true;
+}
+
+void HipKernel::deliver(int ticket)
+{
+    const BitmapBuffer *image = solr_hip_image_wait(ticket);
+    if (image)
+        m_bitmapView = const_cast<BitmapBuffer *>(image);
+}
+
+void HipKernel::setFramesInFlight(int n)
+{
+    flushFrames();
+    m_flights = n < 1 ? 1 : (n > 4 ? 4 : n);
+    solr_hip_set_frames_in_flight(m_flights);
+    if (m_flights == 1)
+        m_bitmapView = nullptr;
+}
+
+void HipKernel::flushFrames()
+{
+    while (!m_tickets.empty())
+    {
+        deliver(m_tickets.front());
+        m_tickets.pop_front();
+    }
 }
 
 void HipKernel::fetchPrimitiveIds()

@@ -11,6 +11,8 @@
  */
 #pragma once
 
+#include <deque>
+
 #include "GPUKernel.h"
 
 namespace solr
@@ -36,6 +38,9 @@ public:
     void render_begin(const float timer) override;
     void render_end() override;
     int lastError(std::string *message = nullptr) override;
+    void setFramesInFlight(int n) override;
+    int getFramesInFlight() const override { return m_flights; }
+    void flushFrames() override;
 
     /* reference: CudaKernel.h:59-65; accepted and forwarded, the wave64 tile
      * shape is the engine's choice */
@@ -61,6 +66,9 @@ private:
     int m_sharedMemSize;
     bool m_deviceInitialized;
     bool m_idsOnDevice = false;
+    int m_flights = 1;            /* frames in flight through render_begin / render_end (setFramesInFlight) */
+    std::deque<int> m_tickets;    /* read-backs under way, oldest first (solr_hip_d2h_image_async) */
+    void deliver(int ticket);
 };
 
 /* Scene store without a device: everything up to compactBoxes works, any

@@ -136,6 +136,27 @@ int SolRx_Render(double timer)
     return engineStatus();
 }
 
+/* Extension: frames in flight through SolR_RunKernel / SolRx_Render (GPUKernel::setFramesInFlight): with n > 1 a
+ * call delivers the image of the frame n - 1 calls back while the newer ones render; SolRx_FlushFrames waits for
+ * all of them, the next getBitmap / SolRx_GetBitmap is then the newest frame's. */
+int SolRx_SetFramesInFlight(int n)
+{
+    SingletonKernel::kernel()->setFramesInFlight(n);
+    return engineStatus();
+}
+
+int SolRx_FlushFrames(void)
+{
+    SingletonKernel::kernel()->flushFrames();
+    return engineStatus();
+}
+
+/* the image render_end delivered last, without a copy (valid until four more frames were rendered) */
+const BitmapBuffer *SolRx_GetBitmap(void)
+{
+    return SingletonKernel::kernel()->getBitmap();
+}
+
 int SolR_RunKernel(double timer, BitmapBuffer *image)
 {
     int status = SolRx_Render(timer);

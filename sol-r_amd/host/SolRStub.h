@@ -131,6 +131,12 @@ int SolRx_HostBuild(int hostOnly);
 int SolRx_LastError(char *buf, int len);
 /* render_begin + render_end without copying the bitmap */
 int SolRx_Render(double timer);
+/* frames in flight through SolR_RunKernel / SolRx_Render (GPUKernel::setFramesInFlight, 1 ... 4; 1 = the reference's
+ * protocol): a call delivers the image of the frame n - 1 calls back while the newer ones render;
+ * SolRx_FlushFrames waits for all of them; SolRx_GetBitmap is the image delivered last, without a copy */
+int SolRx_SetFramesInFlight(int n);
+int SolRx_FlushFrames(void);
+const BitmapBuffer *SolRx_GetBitmap(void);
 /* flattened arrays of the current frame (owned by the engine, valid until
  * the next compactBoxes / material change) */
 int SolRx_GetBoxes(const BoundingBox **boxes, int *nbBoxes);

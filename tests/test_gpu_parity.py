@@ -810,3 +810,66 @@ def test_order_free_lists_arrive_with_the_second_frame(solr, oracle):
     finally:
         if saved is not None:
             os.environ["SOLR_HIP_FREE_AFTER"] = saved
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flights", [2, 3])
+def test_frames_in_flight_through_the_frame_protocol(solr, flights):
+    """GPUKernel::setFramesInFlight: render_begin starts the read-back of its frame behind the kernel, render_end
+    delivers the image of the frame `flights - 1` calls back while the newer ones render.  Same frames, bit for bit,
+    as the reference's one-at-a-time protocol: with a moving camera (first-pass frames rotate over the engine's
+    buffer sets) and through refinement and accumulation passes (which stay on one set: its second RGB image takes
+    every other pass, so that no pass waits for the copy of the pass before)."""
+    import ctypes as C
+    W, H = 192, 120
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=2, maxPathTracingIterations=40)
+    L = k.L
+
+    def delivered():
+        ptr = L.SolRx_GetBitmap()
+        return np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3).copy()
+
+    def frames(n, moving):
+        for i in range(n):
+            if moving:
+                k.set_camera((300.0 * i, 0.0, -15000.0))
+                k.set_scene_info(pathTracingIteration=0)
+            else:
+                k.set_scene_info(pathTracingIteration=i)
+            yield i
+
+    try:
+        for moving in (True, False):
+            n = 9 if moving else 14
+            L.SolRx_SetFramesInFlight(1)
+            expected = []
+            for i in frames(n, moving):
+                expected.append(k.render().copy())
+            assert any(not np.array_equal(expected[0], e) for e in expected[1:])
+            L.SolRx_SetFramesInFlight(flights)
+            lag = flights - 1
+            caller = np.zeros((H, W, 3), np.uint8)
+            for i in frames(n, moving):
+                if i % 2:
+                    assert L.SolR_RunKernel(0.0, caller.ctypes.data) == 0     # ... which also copies what was delivered
+                else:
+                    assert L.SolRx_Render(0.0) == 0
+                if i >= lag:
+                    assert np.array_equal(delivered(), expected[i - lag]), (moving, i)
+                    if i % 2:
+                        assert np.array_equal(caller, expected[i - lag])
+            assert L.SolRx_FlushFrames() == 0
+            assert np.array_equal(delivered(), expected[n - 1]), moving
+            k.check(0, "frames in flight")
+        # picking still sees the newest frame's ids
+        L.SolRx_SetFramesInFlight(1)
+        k.set_scene_info(pathTracingIteration=0)
+        k.render()
+        ids = k.primitive_ids().copy()
+        L.SolRx_SetFramesInFlight(flights)
+        L.SolRx_Render(0.0)
+        assert np.array_equal(k.primitive_ids(), ids)
+    finally:
+        L.SolRx_SetFramesInFlight(1)
+        k.finalize()

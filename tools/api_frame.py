@@ -35,6 +35,19 @@ for name, call in (("SolRx_Render (render_begin + render_end)", lambda: k.L.SolR
         call()
     dt = time.perf_counter() - t0
     print("%-44s %.3f ms per frame (%s %dx%d, %d frames)" % (name, 1e3 * dt / a.frames, a.scene, a.width, a.height, a.frames))
+for flights in (2, 3):
+    k.L.SolRx_SetFramesInFlight(flights)
+    for name, call in (("SolRx_Render, %d frames in flight" % flights, lambda: k.L.SolRx_Render(0.0)),
+                       ("SolR_RunKernel, %d frames in flight" % flights, lambda: k.L.SolR_RunKernel(0.0, image.ctypes.data))):
+        for _ in range(8):
+            call()
+        t0 = time.perf_counter()
+        for _ in range(a.frames):
+            call()
+        k.L.SolRx_FlushFrames()
+        dt = time.perf_counter() - t0
+        print("%-44s %.3f ms per frame (%s %dx%d, %d frames)" % (name, 1e3 * dt / a.frames, a.scene, a.width, a.height, a.frames))
+k.L.SolRx_SetFramesInFlight(1)
 t0 = time.perf_counter()
 k.primitive_at(10, 10)
 print("first getPrimitiveAt after a frame (ids read-back) %.3f ms" % (1e3 * (time.perf_counter() - t0)))
