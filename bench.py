@@ -456,7 +456,7 @@ def main():
         with_image_pipelined = None
         if not cfg4:
             from collections import deque
-            hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
+            hip.solr_hip_set_frames_in_flight(2)   # (a third render stream shares a hardware queue with the copies)
             tickets = deque()
 
             def piped():

@@ -3925,6 +3925,12 @@ int solr_hip_d2h_image_async(void)
     }
     if (ok() && !g.copyStream)
     {
+        /* (at the render streams' priority.  Measured, profiles/r3/readback_probe.txt: with one or two render streams
+         * the copies cost nothing - 0.286 ms per Cornell frame with the image against 0.285 without; with three the
+         * frame takes 0.45 ms whatever the host's lag - the runtime's hardware queues are dealt out in turn and a
+         * render stream ends up sharing one with this stream; a stream of the highest priority, which gets queues of
+         * its own, was slower in every combination (0.33 at best).  HipKernel::setFramesInFlight therefore keeps
+         * the engine at two buffer sets and puts the rest of the depth into the host's lag.) */
         HIPCHECK(hipStreamCreateWithFlags(&g.copyStream, hipStreamNonBlocking));
         HIPCHECK(hipEventCreateWithFlags(&g.frameRendered, hipEventDisableTiming));
         for (int i = 0; i < Engine::IMAGE_RING && ok(); ++i)
