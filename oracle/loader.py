@@ -30,14 +30,37 @@ def build():
 
 
 _lib = None
+_use_coverage = False
+COVERAGE_LIB = os.path.join(_HERE, "libsolr_oracle_cov.so")
+
+
+def use_coverage_build():
+    """tests/test_cuda_text_model.py, before the library is first loaded in its process: load the build with a
+    counter on every dialect switch (make -C oracle coverage) instead of the normal one"""
+    global _use_coverage
+    if _lib is not None and not _use_coverage:
+        raise RuntimeError("the oracle is already loaded without the site counters")
+    res = subprocess.run(["make", "-C", _HERE, "coverage"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("oracle coverage build failed:\n" + res.stdout + res.stderr)
+    _use_coverage = True
+
+
+def site_hits(reset=False):
+    """[(hits in the CUDA dialect, hits in the OpenCL dialect)] per dialect switch of solr_oracle.c, in source
+    order; empty with the normal build"""
+    L = lib()
+    hits = (C.c_ulong * 256)()
+    n = L.oracle_site_hits(hits, 256, 1 if reset else 0)
+    return [(int(hits[2 * i]), int(hits[2 * i + 1])) for i in range(n)]
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
+        if not _use_coverage and not os.path.exists(LIB):
             build()
-        L = C.CDLL(LIB)
+        L = C.CDLL(COVERAGE_LIB if _use_coverage else LIB)
         L.oracle_render.argtypes = [C.POINTER(OracleScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int]

@@ -103,6 +103,47 @@ int oracle_get_rounded_transcendentals(void) { return roundedTrigOn() && correct
  * thereby pinned to reference output; what a switch selects in dialect 0 is the cited CUDA statement.
  * Test infrastructure only; never set by the parity tests of the product. */
 static int g_cl = 0;
+/* Every place where the two dialects part reads the switch through DIALECT(site).  A build with
+ * -DORACLE_SITE_COVERAGE (oracle/Makefile, target `coverage`: libsolr_oracle_cov.so, used by
+ * tests/test_cuda_text_model.py alone) counts, per site, how often it was evaluated in each dialect, so that a test
+ * can show that its cases execute the CUDA arm of every switch; the normal build reads the flag and nothing else. */
+#define ORACLE_NB_SITES 36
+#ifdef ORACLE_SITE_COVERAGE
+static unsigned long g_siteHits[ORACLE_NB_SITES][2];
+static int g_siteFlipped = -1; /* that one site reads the other dialect (oracle_flip_site): does any test notice? */
+#define DIALECT(site) (g_siteHits[site][g_cl ? 1 : 0]++, ((site) == g_siteFlipped) ? !g_cl : g_cl)
+#else
+#define DIALECT(site) g_cl
+#endif
+/* counting build only: site >= 0 makes that one switch read the other dialect, -1 ends it.  The tests flip every
+ * switch in turn and demand that some case then differs from the model: a switch no case can tell apart is not pinned. */
+void oracle_flip_site(int site)
+{
+#ifdef ORACLE_SITE_COVERAGE
+    g_siteFlipped = site;
+#else
+    (void)site;
+#endif
+}
+/* hits[2 * site + dialect]; returns the number of sites, or 0 in a build without the counters */
+int oracle_site_hits(unsigned long *hits, int capacity, int reset)
+{
+#ifdef ORACLE_SITE_COVERAGE
+    for (int i = 0; i < ORACLE_NB_SITES && 2 * i + 1 < capacity; ++i)
+    {
+        hits[2 * i] = g_siteHits[i][0];
+        hits[2 * i + 1] = g_siteHits[i][1];
+    }
+    if (reset)
+        memset(g_siteHits, 0, sizeof(g_siteHits));
+    return ORACLE_NB_SITES;
+#else
+    (void)hits;
+    (void)capacity;
+    (void)reset;
+    return 0;
+#endif
+}
 void oracle_set_dialect(int openclEngine)
 {
     g_cl = openclEngine ? 1 : 0;
@@ -265,7 +306,7 @@ static inline float rnd(const OracleScene *s, long i, Stats *st)
 /* ref GI:36-44 */
 static inline void computeRayAttributes(Ray *ray)
 {
-    const float zero = g_cl ? 0.f : 1.f; /* CL:365-367 gives a zero component 0.f, GI:39-41 1.f */
+    const float zero = DIALECT(0) ? 0.f : 1.f; /* CL:365-367 gives a zero component 0.f, GI:39-41 1.f */
     ray->inv_direction.x = ray->direction.x != 0.f ? 1.f / ray->direction.x : zero;
     ray->inv_direction.y = ray->direction.y != 0.f ? 1.f / ray->direction.y : zero;
     ray->inv_direction.z = ray->direction.z != 0.f ? 1.f / ray->direction.z : zero;
@@ -323,7 +364,7 @@ static inline void normalMap(int index, const Material *m, const BitmapBuffer *t
     BitmapBuffer r = tex[i], g = tex[i + 1];
     normal->x -= strength * (r / 256.f - 0.5f);
     normal->y -= strength * (g / 256.f - 0.5f);
-    if (!g_cl) /* TM:39; CL:505-514 leaves z alone */
+    if (!DIALECT(1)) /* TM:39; CL:505-514 leaves z alone */
         normal->z = 0.f;
 }
 /* ref TM:45-57 */
@@ -338,7 +379,7 @@ static inline void specularMap(int index, const Material *m, const BitmapBuffer 
 {
     int i = m->textureOffset.w + index;
     BitmapBuffer r = tex[i], g = tex[i + 1], b = tex[i + 2];
-    if (g_cl) /* CL:533-541 scales the specular value by the texel's brightness */
+    if (DIALECT(2)) /* CL:533-541 scales the specular value by the texel's brightness */
     {
         specular->x *= (r + g + b) / 768.f;
         return;
@@ -450,7 +491,7 @@ static inline void fetchTexel(const Material *material, const BitmapBuffer *text
     if (material->textureIds.z != TEXTURE_NONE)
     {
         bumpMap(index, material, textures, &strength);
-        if (g_cl && triangleMapper) /* CL:815-819: the triangle mapper also scales the opacity; TM:260-264 does not */
+        if (DIALECT(3) && triangleMapper) /* CL:815-819: the triangle mapper also scales the opacity; TM:260-264 does not */
             attributes->w *= strength / 10.f;
     }
     if (material->textureIds.y != TEXTURE_NONE)
@@ -776,7 +817,7 @@ static int cylinderIntersection(const SceneInfo *si, const Primitive *cyl, const
 #define PLANE_NORMAL(NX, NY, NZ, SIGN)                                                                           \
     do                                                                                                           \
     {                                                                                                            \
-        if (g_cl)                                                                                                \
+        if (DIALECT(4))                                                                                                \
             *normal = V((SIGN) * (NX), (SIGN) * (NY), (SIGN) * (NZ));                                            \
         else if ((SIGN) < 0.f)                                                                                   \
             *normal = vneg(*normal);                                                                             \
@@ -788,8 +829,8 @@ static int planeIntersection(const SceneInfo *si, const Primitive *primitive, co
     int collision = 0;
     float reverted = reverse ? -1.f : 1.f;
     const Material *mat = &materials[primitive->materialId];
-    const int masks = !g_cl; /* GI:447-449, 463-471 ... : wireframe / chessboard-light masks, absent from CL */
-    if (!g_cl)
+    const int masks = !DIALECT(5); /* GI:447-449, 463-471 ... : wireframe / chessboard-light masks, absent from CL */
+    if (!DIALECT(6))
         *normal = primitive->n0;
     switch (primitive->type)
     {
@@ -858,7 +899,7 @@ static int planeIntersection(const SceneInfo *si, const Primitive *primitive, co
             if (masks && mat->attributes.z == 2)
                 collision &= wireFrameMapping(intersection->x, intersection->y, mat->attributes.w);
         }
-        if (!(g_cl && primitive->type == ptCamera) /* CL:1266-1281 */ && !collision &&
+        if (!(DIALECT(7) && primitive->type == ptCamera) /* CL:1266-1281 */ && !collision &&
             reverted * ray->direction.z > 0.f && reverted * ray->origin.z < reverted * primitive->p0.z)
         {
             PLANE_NORMAL(0.f, 0.f, 1.f, -1.f);
@@ -937,16 +978,16 @@ static int triangleIntersection(const SceneInfo *si, const Primitive *tri, const
     areas->x = 0.5f * vlength(crossProduct(v1, v2));
     areas->y = 0.5f * vlength(crossProduct(v0, v2));
     areas->z = 0.5f * vlength(crossProduct(v0, v1));
-    if (g_cl) /* CL:1374 normalises the areas; GI:626-628 keeps them */
+    if (DIALECT(8)) /* CL:1374 normalises the areas; GI:626-628 keeps them */
         *areas = vnormalize(*areas);
     v3 wn = vadd(vadd(vscale(tri->n0, areas->x), vscale(tri->n1, areas->y)), vscale(tri->n2, areas->z));
     *normal = vdivs(wn, areas->x + areas->y + areas->z);
-    if (!g_cl) /* GI:630-631 normalises the interpolated normal; CL:1376-1377 does not */
+    if (!DIALECT(9)) /* GI:630-631 normalises the interpolated normal; CL:1376-1377 does not */
         *normal = vnormalize(*normal);
     if (si->doubleSidedTriangles)
     {
         v3 N = vnormalize(ray->direction);
-        if (g_cl)
+        if (DIALECT(10))
         {
             /* CL:1379-1394: shadow rays keep the faces turned away from the lamp, view rays those turned to the eye */
             if (processingShadows)
@@ -987,7 +1028,7 @@ static inline int testPrimitive(const SceneInfo *si, const Primitive *primitive,
         case ptSphere:
             return sphereIntersection(si, primitive, materials, r, intersection, normal, shadowIntensity);
         case ptCone:
-            if (g_cl) /* CL:1846-1869 has no cone: the type falls through to the plane test, which ignores it */
+            if (DIALECT(11)) /* CL:1846-1869 has no cone: the type falls through to the plane test, which ignores it */
                 return planeIntersection(si, primitive, materials, textures, r, intersection, normal, shadowIntensity,
                                          0);
             /* fall through */
@@ -1019,7 +1060,7 @@ static inline int testPrimitiveShadow(const SceneInfo *si, const Primitive *prim
         case ptEllipsoid:
             return ellipsoidIntersection(si, primitive, r, intersection, normal, shadowIntensity);
         case ptCone:
-            if (g_cl) /* CL:1544-1569: no cone */
+            if (DIALECT(12)) /* CL:1544-1569: no cone */
                 return planeIntersection(si, primitive, materials, textures, r, intersection, normal, shadowIntensity,
                                          0);
             /* fall through */
@@ -1093,7 +1134,7 @@ static int intersectionWithPrimitives(const OracleScene *s, const SceneInfo *si,
             {
                 /* GI:695: NB_MAX_MATERIALS is unsigned in the reference */
                 const Material *m = &s->materials[(unsigned)box->startIndex % (unsigned)NB_MAX_MATERIALS];
-                const float share = g_cl ? 50.f : 200.f; /* GI:695; CL:1894 */
+                const float share = DIALECT(13) ? 50.f : 200.f; /* GI:695; CL:1894 */
                 colorBox->x += m->color.x / share;
                 colorBox->y += m->color.y / share;
                 colorBox->z += m->color.z / share;
@@ -1182,7 +1223,7 @@ static float processShadows(const OracleScene *s, const SceneInfo *si, v3 lampCe
         const BoundingBox *box = &s->boxes[cptBoxes];
         st->boxes++;
         /* GI:817 tests the node against [0, minDistance]; CL:1528 against [0.05, minDistance] */
-        if (boxIntersection(box, &r, g_cl ? 0.05f : 0.f, minDistance))
+        if (boxIntersection(box, &r, DIALECT(14) ? 0.05f : 0.f, minDistance))
         {
             int cptPrimitives = 0;
             while (result < si->shadowIntensity && cptPrimitives < box->nbPrimitives)
@@ -1195,7 +1236,7 @@ static float processShadows(const OracleScene *s, const SceneInfo *si, v3 lampCe
                 const Material *pm = &s->materials[primitive->materialId];
                 /* GI:829 leaves out the lamp and the shaded primitive; CL:1539 only what its caller passes as
                  * objectId, which is the lamp's primitive (CL:1709-1711) */
-                if (primitive->index != lightId && (g_cl || primitive->index != objectId) && pm->attributes.x == 0)
+                if (primitive->index != lightId && (DIALECT(15) || primitive->index != objectId) && pm->attributes.x == 0)
                 {
                     st->prims++;
                     int hit = testPrimitiveShadow(si, primitive, s->materials, s->textures, &r, &intersection,
@@ -1215,7 +1256,7 @@ static float processShadows(const OracleScene *s, const SceneInfo *si, v3 lampCe
                                 /* GI:885-886; CL:1589-1591 lets 20 % more through */
                                 float rr = (pm->transparency == 0.f)
                                                ? 1.f
-                                               : (g_cl ? (1.f - 0.8f * pm->transparency) : (1.f - pm->transparency));
+                                               : (DIALECT(16) ? (1.f - 0.8f * pm->transparency) : (1.f - pm->transparency));
                                 ratio *= rr * a;
                                 color->x += ratio * (0.3f - 0.3f * pm->color.x);
                                 color->y += ratio * (0.3f - 0.3f * pm->color.y);
@@ -1264,7 +1305,7 @@ static f4 intersectionShader(const SceneInfo *si, const Primitive *primitive, co
         switch (primitive->type)
         {
         case ptCone:
-            if (g_cl) /* CL:1422-1487: no cone */
+            if (DIALECT(17)) /* CL:1422-1487: no cone */
                 break;
             /* fall through */
         case ptCylinder:
@@ -1353,7 +1394,7 @@ static c3 primitiveShader(const OracleScene *s, int index, const SceneInfo *si, 
     *normal = vadd(*normal, bumpNormal);
     *normal = vnormalize(*normal);
 
-    if (g_cl)
+    if (DIALECT(18))
     {
         /* CL:1652-1659: unshaded frames, emissive and any wireframe material return the texel */
         if (si->graphicsLevel == glNoShading || material->innerIllumination.x != 0.f || material->attributes.z != 0)
@@ -1368,7 +1409,7 @@ static c3 primitiveShader(const OracleScene *s, int index, const SceneInfo *si, 
         closestColor->y *= material->innerIllumination.x;
         closestColor->z *= material->innerIllumination.x;
         /* GI:956: once per entry of the light list; CL:1664-1665: once */
-        for (int cpt = 0; cpt < (g_cl ? 1 : s->nbLights); ++cpt)
+        for (int cpt = 0; cpt < (DIALECT(19) ? 1 : s->nbLights); ++cpt)
         {
             /* GI:958-960: lamp 0 is applied nbLights times below iteration 10 */
             int cptLamp = (si->pathTracingIteration >= NB_MAX_ITERATIONS) ? (si->pathTracingIteration % s->nbLights) : 0;
@@ -1380,7 +1421,7 @@ static c3 primitiveShader(const OracleScene *s, int index, const SceneInfo *si, 
                 const Material *m = &s->materials[li->materialId];
                 /* CL:1678-1682 jitters only lamps that are primitives of the scene */
                 if (si->pathTracingIteration >= NB_MAX_ITERATIONS &&
-                    (!g_cl || (li->primitiveId >= 0 && li->primitiveId < s->nbPrimitives)))
+                    (!DIALECT(20) || (li->primitiveId >= 0 && li->primitiveId < s->nbPrimitives)))
                 {
                     float a = m->innerIllumination.y * 10.f * si->pathTracingIteration / si->maxPathTracingIterations;
                     center.x += rnd(s, t, st) * a;
@@ -1394,7 +1435,7 @@ static c3 primitiveShader(const OracleScene *s, int index, const SceneInfo *si, 
                     c3 shadowColor = {0.f, 0.f, 0.f};
                     lightRay = vnormalize(lightRay);
                     /* GI:985; CL:1701 has the bare cosine */
-                    float lambert = g_cl ? vdot(*normal, lightRay)
+                    float lambert = DIALECT(21) ? vdot(*normal, lightRay)
                                          : material->innerIllumination.x + vdot(*normal, lightRay);
                     if (lambert > 0.f && si->graphicsLevel > 3 && iteration < 4 && material->innerIllumination.x == 0.f)
                         *shadowIntensity = processShadows(s, si, center, intersection, li->primitiveId, iteration,
@@ -1463,14 +1504,14 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
     v3 closestIntersection = {0.f, 0.f, 0.f};
     v3 firstIntersection = {0.f, 0.f, 0.f};
     v3 normal = {0.f, 0.f, 0.f};
-    int closestPrimitive = g_cl ? 0 : -1; /* CRT:76; CL:2117 */
+    int closestPrimitive = DIALECT(22) ? 0 : -1; /* CRT:76; CL:2117 */
     int carryon = 1;
     Ray rayOrigin = *ray;
     float initialRefraction = 1.f;
     int iteration = 0;
     primitiveXYId->x = -1;
     primitiveXYId->z = 0;
-    if (!g_cl) /* CRT:83; CL:2122-2123 leaves w as the caller's buffer holds it */
+    if (!DIALECT(23)) /* CRT:83; CL:2122-2123 leaves w as the caller's buffer holds it */
         primitiveXYId->w = 0;
     int currentMaterialId = -2;
 
@@ -1530,10 +1571,10 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
                 colorContributions[iteration] = 1.f;
                 firstIntersection = closestIntersection;
                 latestIntersection = closestIntersection;
-                if (!g_cl) /* CRT:139; CL:2411-2412 takes the length after the loop, hit or not */
+                if (!DIALECT(24)) /* CRT:139; CL:2411-2412 takes the length after the loop, hit or not */
                     *depthOfField = vlength(vsub(firstIntersection, ray->origin));
 
-                if (!g_cl && cm->innerIllumination.x == 0.f && /* the CL global-illumination ray is not restated */
+                if (!DIALECT(25) && cm->innerIllumination.x == 0.f && /* the CL global-illumination ray is not restated */
                     (si->advancedIllumination == aiBasic || si->advancedIllumination == aiFull))
                 {
                     int t = (index + si->pathTracingIteration * 100 + si->timestamp) % (MAX_BITMAP_SIZE - 3);
@@ -1555,7 +1596,7 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
                                                 closestIntersection, areas, &closestColor, iteration,
                                                 &shadowIntensity, &rBlinn, &attributes, st);
 
-            if (g_cl)
+            if (DIALECT(26))
             {
                 /* CL:2226-2227: sixteen per bounce whose shaded colour is brighter than the colour key */
                 float colorLight = colors[iteration].x + colors[iteration].y + colors[iteration].z;
@@ -1635,13 +1676,13 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
             if (si->skyboxMaterialId != MATERIAL_NONE)
             {
                 colors[iteration] = skyboxMapping(si, s->materials, s->textures, &rayOrigin);
-                if (!g_cl) /* CRT:274-275; absent from CL:2314-2315 */
+                if (!DIALECT(27)) /* CRT:274-275; absent from CL:2314-2315 */
                 {
                     float rad = colors[iteration].x + colors[iteration].y + colors[iteration].z;
                     primitiveXYId->z = f2i((float)primitiveXYId->z + ((rad > 2.5f) ? rad * 256.f : 0.f));
                 }
             }
-            else if (g_cl ? (si->extendedGeometry == 2) /* CL:2318 */ : si->gradientBackground)
+            else if (DIALECT(28) ? (si->extendedGeometry == 2) /* CL:2318 */ : si->gradientBackground)
             {
                 v3 up = {0.f, 1.f, 0.f};
                 v3 dir = vnormalize(vsub(rayOrigin.direction, rayOrigin.origin));
@@ -1671,7 +1712,7 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
             attributes.x = s->materials[s->primitives[closestPrimitive].materialId].reflection;
             /* CRT:307-311 shades it as bounce `reflectedRays`, CL:2345-2349 as bounce `iteration` */
             c3 color = primitiveShader(s, index, si, reflectedRay.origin, &normal, closestPrimitive,
-                                       closestIntersection, areas, &closestColor, g_cl ? iteration : reflectedRays,
+                                       closestIntersection, areas, &closestColor, DIALECT(29) ? iteration : reflectedRays,
                                        &shadowIntensity, &rBlinn, &attributes, st);
             colors[reflectedRays].x += color.x * reflectedRatio;
             colors[reflectedRays].y += color.y * reflectedRatio;
@@ -1759,7 +1800,7 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
         intersectionColor = colors[0];
 
     float len = *depthOfField;
-    if (g_cl)
+    if (DIALECT(30))
     {
         /* CL:2411-2418: the depth is taken here, from the first hit or from the origin of the frame of reference
          * when there was none; a wireframe material under the last hit pushes the fog to the horizon */
@@ -1783,7 +1824,7 @@ static c3 launchRayTracing(const OracleScene *s, int index, const Ray *ray, cons
     intersectionColor.x -= colorBox.x;
     intersectionColor.y -= colorBox.y;
     intersectionColor.z -= colorBox.z;
-    if (g_cl) /* CL:2438; CRT:404-407 returns the colour as it is */
+    if (DIALECT(31)) /* CL:2438; CRT:404-407 returns the colour as it is */
         saturate3(&intersectionColor);
     return intersectionColor;
 }
@@ -2145,7 +2186,7 @@ static void postDepthOfField(const OracleScene *s, const SceneInfo *si, const Po
     for (int i = 0; i < ppi->param3; ++i)
     {
         int ix = i % wh;
-        int iy = (i + (g_cl ? 100 : 1000)) % wh; /* CRT:1101; CL:2968 */
+        int iy = (i + (DIALECT(32) ? 100 : 1000)) % wh; /* CRT:1101; CL:2968 */
         int xx = f2i(x + depth * rnd(s, ix, st) * ppi->param2);
         int yy = f2i(y + depth * rnd(s, iy, st) * ppi->param2);
         if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
@@ -2208,7 +2249,7 @@ static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, cons
             if (xx >= 0 && xx < si->size.x && yy >= 0 && yy < rows)
             {
                 int localIndex = yy * si->size.x + xx;
-                if (g_cl)
+                if (DIALECT(33))
                 {
                     /* CL:3026-3027: nearer neighbours darken, by more the nearer they are */
                     if (pp[localIndex].colorInfo.w < depth)
@@ -2220,7 +2261,7 @@ static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, cons
             else
                 occ += 1.f;
         }
-    if (g_cl)
+    if (DIALECT(34))
     {
         /* CL:3033-3043: the occlusion is subtracted, after the division by the number of samples */
         occ /= 5.f * c;
@@ -2245,7 +2286,7 @@ static void postAmbientOcclusion(const OracleScene *s, const SceneInfo *si, cons
         localColor.y /= d;
         localColor.z /= d;
     }
-    if (g_cl)
+    if (DIALECT(35))
     {
         localColor.x -= occ;
         localColor.y -= occ;
