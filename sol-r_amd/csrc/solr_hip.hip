@@ -28,6 +28,7 @@
 
 #include "../../include/solr_hip.h"
 #include "rt_device.h"
+#include "lists_device.h"
 
 using namespace solrdev;
 
@@ -2831,6 +2832,10 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
                 clo[k] = std::min(clo[k], c);
                 chi[k] = std::max(chi[k], c);
             }
+        /* zeros are +0 (std::min keeps whichever zero it met first; the device builder of solr_lists.hip, whose
+         * minima are atomics, could not tell which that was) */
+        for (int k = 0; k < 3; ++k)
+            t.lo[k] += 0.f, t.hi[k] += 0.f;
         /* binned surface-area split: one pass over the leaves fills the bins of all three axes */
         const int BINS = 16;
         int bestAxis = -1, bestBin = 0;
@@ -2914,7 +2919,9 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
             const float scale = BINS / (chi[bestAxis] - clo[bestAxis]);
             const float origin = clo[bestAxis];
             const int axis = bestAxis, bin = bestBin;
-            mid = (int)(std::partition(leaves.begin() + r.from, leaves.begin() + r.to,
+            /* stable: the order inside a node stays the order of the leaf list (it decides the halving by position
+             * below, and the device builder partitions the same way) */
+            mid = (int)(std::stable_partition(leaves.begin() + r.from, leaves.begin() + r.to,
                                        [&](const Leaf &l) {
                                            const float c = 0.5f * (l.lo[axis] + l.hi[axis]);
                                            return std::min(BINS - 1, std::max(0, (int)((c - origin) * scale))) <= bin;
@@ -3146,7 +3153,20 @@ void maybeBuildOrderFreeLists()
     std::vector<float4> boxesF;
     std::vector<int> startF, originF;
     int prunedFree = 0;
-    const int count = buildFreeOrderLists(rows, start, origin, boxesF, startF, originF, &prunedFree);
+    /* on the device (solr_lists.hip: the same tree level by level, the same lists bit for bit) unless told otherwise
+     * or declined */
+    int count = -1;
+    const bool onHost = getenv("SOLR_HIP_LISTS_ON_HOST") != nullptr || getenv("SOLR_HIP_FREE_WIDE") != nullptr;
+    if (!onHost)
+    {
+        HIPCHECK(hipSetDevice(g.device));
+        const double threshold = getenv("SOLR_HIP_PRUNE") ? atof(getenv("SOLR_HIP_PRUNE")) : 1.0;
+        if (ok() && threshold > 0.0)
+            count = solrBuildOrderFreeListsOnDevice(rows.data(), start.data(), origin.data(), n, threshold, boxesF, startF, originF,
+                                                    &prunedFree, g.stream);
+    }
+    if (count < 0)
+        count = buildFreeOrderLists(rows, start, origin, boxesF, startF, originF, &prunedFree);
     if (getenv("SOLR_HIP_DEBUG_TREE"))
         fprintf(stderr, "solr_hip: order-free lists: 8 x %d nodes (%d inner nodes that hardly cull left out)\n", count, prunedFree);
     if (count <= 0)

@@ -1,0 +1,76 @@
+"""The order-free node lists built on the device (sol-r_amd/csrc/solr_lists.hip) against the host builder
+(solr_hip.hip buildFreeOrderLists): the eight lists - bounds, primitive counts, skip pointers, the inner nodes that
+were left out - must be the host's bit for bit, on BASELINE's scenes at their full size, on scenes whose leaves
+coincide (twins: the split that halves by position, which only a stable partition on both sides makes the same),
+and after the frames rendered from them equal the ones of the reference-order walks (variant 6)."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes_extra as X
+
+pytestmark = pytest.mark.gpu
+
+
+def _lists(solr, build, **kw):
+    k = solr.Kernel(engine="hip")
+    build(k, **kw)
+    image = k.render()                 # (tests build the lists with the first frame: conftest.py)
+    image = k.render()
+    k.check(0, "frames")
+    n = solr.hip_lib().solr_hip_order_free_nodes()
+    lists = [k.device_nodes(order_free=o).copy() for o in range(8)] if n else []
+    k.finalize()
+    return n, lists, image
+
+
+def _twins(k, width=96, height=64, **info):
+    """spheres in identical pairs, each pair in two different grid cells' worth of distance apart so that they are
+    leaves of their own - but some exactly on top of each other in separate leaves is what the reference's grid does
+    not produce; coinciding CENTRES of different leaves come from equal boxes: cylinders and their end spheres"""
+    k.initialize(width=width, height=height, nbRayIterations=2, **info)
+    m = k.add_material(0.6, 0.5, 0.4, specValue=0.3, specPower=20.0)
+    rng = solr_rng(3)
+    for i in range(300):
+        c = (rng.uniform(-6000, 6000), rng.uniform(-4000, 4000), rng.uniform(-3000, 6000))
+        k.add_primitive(k_solr.ptSphere, c, size=(120.0, 0, 0), material=m)
+        k.add_primitive(k_solr.ptSphere, c, size=(120.0, 0, 0), material=m)          # the same box again
+        k.add_primitive(k_solr.ptCylinder, c, (c[0] + 1.0, c[1], c[2]), size=(119.5, 0, 0), material=m)
+    X._light(k)
+    k.compact_boxes(True)
+    return k
+
+
+k_solr = None
+
+
+def solr_rng(seed):
+    return k_solr.scenes.LCG(seed)
+
+
+@pytest.mark.parametrize("scene,kw", [("cornell", dict(width=160, height=120, iterations=2)),
+                                      ("height_field", dict(n=224, width=160, height=120)),
+                                      ("molecule", dict(atoms=50000, width=160, height=120)),
+                                      ("molecule", dict(atoms=3000, width=160, height=120)),
+                                      ("twins", dict())],
+                         ids=["cfg1-cornell", "cfg2-mesh", "cfg3-molecule", "small-molecule", "twins"])
+def test_device_lists_are_the_hosts(solr, scene, kw):
+    global k_solr
+    k_solr = solr
+    build = _twins if scene == "twins" else getattr(solr.scenes, scene)
+    os.environ.pop("SOLR_HIP_LISTS_ON_HOST", None)
+    n_dev, dev, image_dev = _lists(solr, build, **kw)
+    os.environ["SOLR_HIP_LISTS_ON_HOST"] = "1"
+    try:
+        n_host, host, image_host = _lists(solr, build, **kw)
+    finally:
+        os.environ.pop("SOLR_HIP_LISTS_ON_HOST", None)
+    assert n_dev == n_host and n_dev > 0, (n_dev, n_host)
+    for o in range(8):
+        a, b = dev[o].view(np.int32), host[o].view(np.int32)
+        assert a.shape == b.shape
+        if not np.array_equal(a, b):
+            bad = np.argwhere((a != b).any(axis=(1, 2)))[:5].ravel()
+            raise AssertionError("octant %d: nodes %s differ, e.g. device %s host %s" % (o, bad, dev[o][bad[0]], host[o][bad[0]]))
+    assert np.array_equal(image_dev, image_host)
