@@ -11,3 +11,7 @@
 int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const int *origin, int n, double threshold,
                                     std::vector<float4> &outRows, std::vector<int> &outStart, std::vector<int> &outOrigin,
                                     int *nbPruned, hipStream_t stream);
+
+/* pruneInnerNodes' decisions (solr_hip.hip) for a nested node list: keep[i] = 0 for the inner nodes that are left
+ * out.  Returns how many, or -1 when left to the host. */
+int solrPruneDecisionsOnDevice(const float4 *rows, int n, double threshold, std::vector<char> &keep, hipStream_t stream);

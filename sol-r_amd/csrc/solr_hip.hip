@@ -1347,6 +1347,8 @@ struct Engine
     std::vector<int> refitWalkLevels;   /* walk-order list, same form */
     std::vector<int> refitFreeLevels;   /* the eight order-free lists as one forest, same form */
     bool refitReady = false;
+    bool refitPlanPending = false;      /* the lists changed: the plan is made when the first rotation asks (ensureRefitPlan) */
+    std::vector<int> hostOriginFree;    /* per node of the order-free lists: the node of the reference's list it is, -1: ours */
     bool exactStale = false;            /* the exact list has not been refitted since the last rotation */
     float exactStaleViewDistance = 0.f;
     bool deviceAhead = false;           /* the arena has moved on from the host images */
@@ -2584,6 +2586,8 @@ void finalize_scene(vec2i)
     g.ownStream = false;
     g.initialized = false;
     g.refitReady = false;
+    g.refitPlanPending = false;
+    g.hostOriginFree.clear();
     g.exactStale = false;
     g.deviceAhead = false;
     g.nbMovable = -1;
@@ -2655,68 +2659,79 @@ static int pruneInnerNodes(std::vector<float4> &rows, std::vector<int> &start, s
         const double x = (double)hi(i, 0) - lo(i, 0), y = (double)hi(i, 1) - lo(i, 1), z = (double)hi(i, 2) - lo(i, 2);
         return x * y + y * z + z * x;
     };
-    std::vector<int> leaves; /* node indices of the leaves, in walk order */
-    std::vector<int> leavesBefore(n + 1, 0);
-    for (int i = 0; i < n; ++i)
-    {
-        leavesBefore[i + 1] = leavesBefore[i] + (countOf(i) > 0 ? 1 : 0);
-        if (countOf(i) > 0)
-            leaves.push_back(i);
-    }
     std::vector<char> keep(n, 1);
-    struct Open
+    /* the decisions: on the device (solr_lists.hip, one launch per depth of the list; the same arithmetic, the same
+     * decisions) unless told otherwise or declined */
+    int decided = -1;
+    if (!everyInnerNode && g.initialized && !getenv("SOLR_HIP_LISTS_ON_HOST"))
+        decided = solrPruneDecisionsOnDevice(rows.data(), n, threshold, keep, g.stream);
+    if (decided >= 0)
+        *nbPruned = decided;
+    else
     {
-        int node, end;
-    };
-    std::vector<Open> open; /* kept ancestors of node i */
-    double sceneLo[3] = {1e300, 1e300, 1e300}, sceneHi[3] = {-1e300, -1e300, -1e300};
-    for (int j = 0; j < n; j += skipOf(j))
-        for (int k = 0; k < 3; ++k)
+        keep.assign(n, 1);
+        std::vector<int> leaves; /* node indices of the leaves, in walk order */
+        std::vector<int> leavesBefore(n + 1, 0);
+        for (int i = 0; i < n; ++i)
         {
-            sceneLo[k] = std::min(sceneLo[k], (double)lo(j, k));
-            sceneHi[k] = std::max(sceneHi[k], (double)hi(j, k));
+            leavesBefore[i + 1] = leavesBefore[i] + (countOf(i) > 0 ? 1 : 0);
+            if (countOf(i) > 0)
+                leaves.push_back(i);
         }
-    const double sceneArea = (sceneHi[0] - sceneLo[0]) * (sceneHi[1] - sceneLo[1]) + (sceneHi[1] - sceneLo[1]) * (sceneHi[2] - sceneLo[2]) +
-                             (sceneHi[2] - sceneLo[2]) * (sceneHi[0] - sceneLo[0]);
-    for (int i = 0; i < n; ++i)
-    {
-        while (!open.empty() && open.back().end <= i)
-            open.pop_back();
-        const int end = std::min(i + skipOf(i), n);
-        if (countOf(i) == 0 && end > i + 1)
+        struct Open
         {
-            const int parentFrom = open.empty() ? 0 : open.back().node, parentTo = open.empty() ? n : open.back().end;
-            const double parentArea = open.empty() ? sceneArea : areaOf(open.back().node);
-            const double bySurface = parentArea > 0.0 ? std::min(1.0, areaOf(i) / parentArea) : 1.0;
-            /* share of the parent's leaves whose centre lies in the node (sampled beyond 4096 leaves) */
-            const int firstLeaf = leavesBefore[parentFrom], lastLeaf = leavesBefore[parentTo];
-            const int stride = std::max(1, (lastLeaf - firstLeaf) / 4096);
-            int sampled = 0, inside = 0;
-            for (int q = firstLeaf; q < lastLeaf; q += stride)
+            int node, end;
+        };
+        std::vector<Open> open; /* kept ancestors of node i */
+        double sceneLo[3] = {1e300, 1e300, 1e300}, sceneHi[3] = {-1e300, -1e300, -1e300};
+        for (int j = 0; j < n; j += skipOf(j))
+            for (int k = 0; k < 3; ++k)
             {
-                const int leaf = leaves[q];
-                bool in = true;
-                for (int k = 0; k < 3 && in; ++k)
+                sceneLo[k] = std::min(sceneLo[k], (double)lo(j, k));
+                sceneHi[k] = std::max(sceneHi[k], (double)hi(j, k));
+            }
+        const double sceneArea = (sceneHi[0] - sceneLo[0]) * (sceneHi[1] - sceneLo[1]) + (sceneHi[1] - sceneLo[1]) * (sceneHi[2] - sceneLo[2]) +
+                                 (sceneHi[2] - sceneLo[2]) * (sceneHi[0] - sceneLo[0]);
+        for (int i = 0; i < n; ++i)
+        {
+            while (!open.empty() && open.back().end <= i)
+                open.pop_back();
+            const int end = std::min(i + skipOf(i), n);
+            if (countOf(i) == 0 && end > i + 1)
+            {
+                const int parentFrom = open.empty() ? 0 : open.back().node, parentTo = open.empty() ? n : open.back().end;
+                const double parentArea = open.empty() ? sceneArea : areaOf(open.back().node);
+                const double bySurface = parentArea > 0.0 ? std::min(1.0, areaOf(i) / parentArea) : 1.0;
+                /* share of the parent's leaves whose centre lies in the node (sampled beyond 4096 leaves) */
+                const int firstLeaf = leavesBefore[parentFrom], lastLeaf = leavesBefore[parentTo];
+                const int stride = std::max(1, (lastLeaf - firstLeaf) / 4096);
+                int sampled = 0, inside = 0;
+                for (int q = firstLeaf; q < lastLeaf; q += stride)
                 {
-                    const double c = 0.5 * ((double)lo(leaf, k) + hi(leaf, k));
-                    in = c >= lo(i, k) && c <= hi(i, k);
+                    const int leaf = leaves[q];
+                    bool in = true;
+                    for (int k = 0; k < 3 && in; ++k)
+                    {
+                        const double c = 0.5 * ((double)lo(leaf, k) + hi(leaf, k));
+                        in = c >= lo(i, k) && c <= hi(i, k);
+                    }
+                    ++sampled;
+                    inside += in ? 1 : 0;
                 }
-                ++sampled;
-                inside += in ? 1 : 0;
+                const double byOrigin = sampled ? (double)inside / sampled : 1.0;
+                bool encloses = true; /* every child within the node: what the argument above rests on */
+                for (int j = i + 1; j < end && encloses; j += skipOf(j))
+                    for (int k = 0; k < 3; ++k)
+                        encloses = encloses && lo(j, k) >= lo(i, k) && hi(j, k) <= hi(i, k);
+                if (encloses && (1.0 - std::max(bySurface, byOrigin)) * (end - i - 1) < threshold)
+                {
+                    keep[i] = 0;
+                    ++*nbPruned;
+                    continue;
+                }
             }
-            const double byOrigin = sampled ? (double)inside / sampled : 1.0;
-            bool encloses = true; /* every child within the node: what the argument above rests on */
-            for (int j = i + 1; j < end && encloses; j += skipOf(j))
-                for (int k = 0; k < 3; ++k)
-                    encloses = encloses && lo(j, k) >= lo(i, k) && hi(j, k) <= hi(i, k);
-            if (encloses && (1.0 - std::max(bySurface, byOrigin)) * (end - i - 1) < threshold)
-            {
-                keep[i] = 0;
-                ++*nbPruned;
-                continue;
-            }
+            open.push_back({i, end});
         }
-        open.push_back({i, end});
     }
     if (*nbPruned == 0)
         return n;
@@ -3176,9 +3191,10 @@ void maybeBuildOrderFreeLists()
     g.hostBoxStartFree.swap(startF);
     g.nbBoxesFree = count;
     g.freeStale = false;
-    buildRefitPlan(g.hostBoxes, g.hostBoxesCompact, g.hostOriginCompact, g.hostBoxesFree, originF);
+    g.hostOriginFree.swap(originF);
+    g.refitReady = false;
+    g.refitPlanPending = true; /* 8-12 ms for 100 k primitives: only scenes that are rotated on the device pay them */
     g.geometryDirty = true; /* the arena is laid out and uploaded again with the lists in it */
-    phase.mark("order-free: refit plan");
 }
 } // namespace
 
@@ -3518,8 +3534,10 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     if (prims.empty())
         prims.assign(8, make_float4(0.f, 0.f, 0.f, 0.f)); /* inactive lanes read record 0 */
     phase.mark("h2d_scene: primitive rows");
-    buildRefitPlan(boxes, boxesC, originC, boxesF, originF);
-    phase.mark("h2d_scene: refit plan");
+    g.refitReady = false;
+    g.exactStale = false;
+    g.refitPlanPending = true;
+    g.hostOriginFree.swap(originF);
     g.deviceAhead = false;
     g.nbMovable = -1;
     g.hostBoxes.swap(boxes);
@@ -3577,6 +3595,12 @@ int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], 
 {
     if (!ready("solr_hip_rotate_primitives") || !ok())
         return 0;
+    if (g.refitPlanPending)
+    {
+        /* which nodes to refit, in which order: made for the first rotation after the lists changed */
+        g.refitPlanPending = false;
+        buildRefitPlan(g.hostBoxes, g.hostBoxesCompact, g.hostOriginCompact, g.hostBoxesFree, g.hostOriginFree);
+    }
     /* the seeds of the two box updates only commute with the unions while viewDistance <= 1e6, and a
      * tree cut off at NB_MAX_BOXES has host-side children the flattened list does not show */
     if (!g.refitReady || g.nbMovable != g.nbPrimitives || g.nbPrimitives <= 0 || !(viewDistance <= 1000000.f) ||

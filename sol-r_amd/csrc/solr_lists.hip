@@ -37,10 +37,29 @@
 #include <cstring>
 #include <vector>
 
+#include <chrono>
+
 #include "lists_device.h"
 
 namespace
 {
+struct Phase
+{
+    const bool on = getenv("SOLR_HIP_DEBUG_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char *what, int detail = -1)
+    {
+        if (!on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        if (detail >= 0)
+            fprintf(stderr, "solr_lists: %-24s %8.2f ms (%d)\n", what, std::chrono::duration<double, std::milli>(now - last).count(), detail);
+        else
+            fprintf(stderr, "solr_lists: %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
 const int BINS = 16;
 const int MAX_DEPTH = 64;
 
@@ -99,12 +118,23 @@ __device__ inline void atomicMaxF(float *addr, float v)
 }
 
 /* open nodes of the level [first, first + count): bounds start empty */
-__global__ void k_open(Node *nodes, int first, int count)
+__global__ void k_open(Node *nodes, BinSet *bins, int first, int count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count)
         return;
     Node &t = nodes[first + i];
+    BinSet &b = bins[i];
+    for (int axis = 0; axis < 3; ++axis)
+        for (int bin = 0; bin < BINS; ++bin)
+        {
+            b.count[axis][bin] = 0;
+            for (int k = 0; k < 3; ++k)
+            {
+                b.lo[axis][bin][k] = 1e30f;
+                b.hi[axis][bin][k] = -1e30f;
+            }
+        }
     for (int k = 0; k < 3; ++k)
     {
         t.lo[k] = t.clo[k] = 1e30f;
@@ -119,50 +149,76 @@ __global__ void k_open(Node *nodes, int first, int count)
     t.mid = t.from;
 }
 
-__global__ void k_bounds(Node *nodes, const int *nodeOf, const int *order, const float *llo, const float *lhi, int nbLeaves,
-                         int levelFirst)
+__device__ inline float waveMin(float v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+        v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ inline float waveMax(float v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+        v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_bounds(Node *nodes, const int *nodeOf, const int *order, const float *llo, const float *lhi,
+                                                 int nbLeaves, int levelFirst)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nbLeaves)
-        return;
-    const int t = nodeOf[i];
-    if (t < levelFirst)
-        return; /* its node closed on a level above */
-    Node &node = nodes[t];
-    const int leaf = order[i];
-    if (node.to - node.from == 1)
+    const int t = i < nbLeaves ? nodeOf[i] : -1;
+    const bool open = t >= levelFirst && nodes[t].to - nodes[t].from > 1;
+    if (t >= levelFirst && !open)
     {
+        Node &node = nodes[t]; /* a node of one leaf */
+        const int leaf = order[i];
         for (int k = 0; k < 3; ++k)
         {
             node.lo[k] = llo[3 * leaf + k];
             node.hi[k] = lhi[3 * leaf + k];
         }
         node.leaf = leaf;
-        return;
     }
-    for (int k = 0; k < 3; ++k)
+    /* near the root a node holds thousands of consecutive leaves: a wave that lies inside one node reduces first and
+     * sends one atomic per value instead of sixty-four to the same address */
+    const int firstNode = __builtin_amdgcn_readfirstlane(t);
+    const bool uniform = __builtin_amdgcn_ballot_w64(!open || t != firstNode) == 0ull;
+    float lo[3], hi[3], c[3];
+    if (open)
     {
-        const float lo = llo[3 * leaf + k], hi = lhi[3 * leaf + k];
-        const float c = 0.5f * (lo + hi);
-        atomicMinF(&node.lo[k], lo);
-        atomicMaxF(&node.hi[k], hi);
-        atomicMinF(&node.clo[k], c);
-        atomicMaxF(&node.chi[k], c);
+        const int leaf = order[i];
+        for (int k = 0; k < 3; ++k)
+        {
+            lo[k] = llo[3 * leaf + k];
+            hi[k] = lhi[3 * leaf + k];
+            c[k] = 0.5f * (lo[k] + hi[k]);
+        }
     }
-}
-
-__global__ void k_clearBins(BinSet *bins, int count)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count * 3 * BINS)
-        return;
-    BinSet &b = bins[i / (3 * BINS)];
-    const int axis = (i / BINS) % 3, bin = i % BINS;
-    b.count[axis][bin] = 0;
-    for (int k = 0; k < 3; ++k)
+    if (uniform)
     {
-        b.lo[axis][bin][k] = 1e30f;
-        b.hi[axis][bin][k] = -1e30f;
+        Node &node = nodes[firstNode];
+        for (int k = 0; k < 3; ++k)
+        {
+            const float a = waveMin(lo[k]), b = waveMax(hi[k]), d = waveMin(c[k]), e = waveMax(c[k]);
+            if ((threadIdx.x & 63) == 0)
+            {
+                atomicMinF(&node.lo[k], a);
+                atomicMaxF(&node.hi[k], b);
+                atomicMinF(&node.clo[k], d);
+                atomicMaxF(&node.chi[k], e);
+            }
+        }
+    }
+    else if (open)
+    {
+        Node &node = nodes[t];
+        for (int k = 0; k < 3; ++k)
+        {
+            atomicMinF(&node.lo[k], lo[k]);
+            atomicMaxF(&node.hi[k], hi[k]);
+            atomicMinF(&node.clo[k], c[k]);
+            atomicMaxF(&node.chi[k], c[k]);
+        }
     }
 }
 
@@ -171,39 +227,105 @@ __device__ inline int binOf(float c, float origin, float scale)
     return min(BINS - 1, max(0, (int)((c - origin) * scale)));
 }
 
-__global__ void k_bins(const Node *nodes, BinSet *bins, const int *nodeOf, const int *order, const float *llo, const float *lhi,
-                       int nbLeaves, int levelFirst)
+__device__ inline void ldsMinF(float *addr, float v)
 {
+    v += 0.f;
+    if (v >= 0.f)
+        atomicMin((int *)addr, __float_as_int(v));
+    else
+        atomicMax((unsigned *)addr, __float_as_uint(v));
+}
+__device__ inline void ldsMaxF(float *addr, float v)
+{
+    v += 0.f;
+    if (v >= 0.f)
+        atomicMax((int *)addr, __float_as_int(v));
+    else
+        atomicMin((unsigned *)addr, __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void k_bins(const Node *nodes, BinSet *bins, const int *nodeOf, const int *order, const float *llo,
+                                               const float *lhi, int nbLeaves, int levelFirst)
+{
+    __shared__ BinSet local;
+    __shared__ int sameNode;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nbLeaves)
-        return;
-    const int t = nodeOf[i];
-    if (t < levelFirst)
-        return;
-    const Node &node = nodes[t];
-    if (node.to - node.from < 2)
-        return;
-    BinSet &b = bins[t - levelFirst];
-    const int leaf = order[i];
-    float lo[3], hi[3];
-    for (int k = 0; k < 3; ++k)
+    const int t = i < nbLeaves ? nodeOf[i] : -1;
+    const bool open = t >= levelFirst && nodes[t].to - nodes[t].from > 1;
+    /* does the whole workgroup lie in one open node?  (near the root: always) */
+    if (threadIdx.x == 0)
+        sameNode = t;
+    __syncthreads();
+    const int blockNode = sameNode;
+    __syncthreads();
+    if (!open || t != blockNode)
+        sameNode = -1; /* benign race: every writer writes the same value */
+    __syncthreads();
+    const bool together = sameNode >= 0;
+    if (together)
     {
-        lo[k] = llo[3 * leaf + k];
-        hi[k] = lhi[3 * leaf + k];
+        for (int q = threadIdx.x; q < 3 * BINS; q += blockDim.x)
+        {
+            const int axis = q / BINS, bin = q % BINS;
+            local.count[axis][bin] = 0;
+            for (int k = 0; k < 3; ++k)
+            {
+                local.lo[axis][bin][k] = 1e30f;
+                local.hi[axis][bin][k] = -1e30f;
+            }
+        }
+        __syncthreads();
     }
-    for (int axis = 0; axis < 3; ++axis)
+    if (open)
     {
-        const float extent = node.chi[axis] - node.clo[axis];
-        const float scale = extent > 0.f ? BINS / extent : 0.f;
-        if (!(scale > 0.f))
-            continue;
-        const float c = 0.5f * (lo[axis] + hi[axis]);
-        const int bin = binOf(c, node.clo[axis], scale);
-        atomicAdd(&b.count[axis][bin], 1);
+        const Node &node = nodes[t];
+        BinSet &b = together ? local : bins[t - levelFirst];
+        const int leaf = order[i];
+        float lo[3], hi[3];
         for (int k = 0; k < 3; ++k)
         {
-            atomicMinF(&b.lo[axis][bin][k], lo[k]);
-            atomicMaxF(&b.hi[axis][bin][k], hi[k]);
+            lo[k] = llo[3 * leaf + k];
+            hi[k] = lhi[3 * leaf + k];
+        }
+        for (int axis = 0; axis < 3; ++axis)
+        {
+            const float extent = node.chi[axis] - node.clo[axis];
+            const float scale = extent > 0.f ? BINS / extent : 0.f;
+            if (!(scale > 0.f))
+                continue;
+            const float c = 0.5f * (lo[axis] + hi[axis]);
+            const int bin = binOf(c, node.clo[axis], scale);
+            atomicAdd(&b.count[axis][bin], 1);
+            for (int k = 0; k < 3; ++k)
+            {
+                if (together)
+                {
+                    ldsMinF(&b.lo[axis][bin][k], lo[k]);
+                    ldsMaxF(&b.hi[axis][bin][k], hi[k]);
+                }
+                else
+                {
+                    atomicMinF(&b.lo[axis][bin][k], lo[k]);
+                    atomicMaxF(&b.hi[axis][bin][k], hi[k]);
+                }
+            }
+        }
+    }
+    if (together)
+    {
+        __syncthreads();
+        BinSet &out = bins[blockNode - levelFirst];
+        for (int q = threadIdx.x; q < 3 * BINS; q += blockDim.x)
+        {
+            const int axis = q / BINS, bin = q % BINS;
+            if (local.count[axis][bin] == 0)
+                continue;
+            atomicAdd(&out.count[axis][bin], local.count[axis][bin]);
+            for (int k = 0; k < 3; ++k)
+            {
+                atomicMinF(&out.lo[axis][bin][k], local.lo[axis][bin][k]);
+                atomicMaxF(&out.hi[axis][bin][k], local.hi[axis][bin][k]);
+            }
         }
     }
 }
@@ -215,7 +337,7 @@ __device__ inline double areaOf(const float *lo, const float *hi)
 }
 
 /* the host's cost loop (solr_hip.hip buildFreeOrderLists), one thread per open node */
-__global__ void k_split(Node *nodes, const BinSet *bins, int levelFirst, int count)
+__global__ void k_split(Node *nodes, const BinSet *bins, int levelFirst, int count, int nextFree, int *splitting)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count)
@@ -285,31 +407,14 @@ __global__ void k_split(Node *nodes, const BinSet *bins, int levelFirst, int cou
         t.bin = bestBin;
         t.mid = t.from + lc;
     }
-}
-
-/* children of the nodes that split: two new nodes each, in the order of their parents */
-__global__ void k_children(Node *nodes, const int *rank, int levelFirst, int count, int nextFree)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count)
-        return;
-    Node &t = nodes[levelFirst + i];
-    if (!t.split)
-        return;
-    const int left = nextFree + 2 * rank[i];
+    /* two children (which pair of the level's new nodes is no matter: the lists follow from the tree's shape) */
+    const int left = nextFree + 2 * atomicAdd(splitting, 1);
     t.left = left;
     t.right = left + 1;
     nodes[left].from = t.from;
     nodes[left].to = t.mid;
     nodes[left + 1].from = t.mid;
     nodes[left + 1].to = t.to;
-}
-
-__global__ void k_splitFlags(const Node *nodes, int *flags, int levelFirst, int count)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count)
-        flags[i] = nodes[levelFirst + i].split;
 }
 
 /* 1 for a leaf that goes to the left child of its node */
@@ -480,6 +585,7 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
                                     int *nbPruned, hipStream_t stream)
 {
     *nbPruned = 0;
+    Phase phase;
     /* the leaves: every node with primitives */
     std::vector<float> llo, lhi;
     std::vector<float4> leafRows;
@@ -500,17 +606,18 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
     const int L = (int)leafStart.size();
     if (L < 2)
         return -1;
+    phase.mark("leaves gathered", L);
     const int maxNodes = 2 * L - 1;
     Dev<float> dLo, dHi;
     Dev<float4> dLeafRows, dOutRows;
-    Dev<int> dLeafStart, dLeafOrigin, dOrder[2], dNodeOf[2], dFlags, dBefore, dRank, dPlace, dOutStart, dOutOrigin, dPruned;
+    Dev<int> dLeafStart, dLeafOrigin, dOrder[2], dNodeOf[2], dFlags, dBefore, dPlace, dOutStart, dOutOrigin, dPruned;
     Dev<Node> dNodes;
     Dev<BinSet> dBins;
     Dev<char> dTemp;
     if (!dLo.alloc(3 * (size_t)L) || !dHi.alloc(3 * (size_t)L) || !dLeafRows.alloc(2 * (size_t)L) || !dLeafStart.alloc(L) ||
         !dLeafOrigin.alloc(L) || !dOrder[0].alloc(L) || !dOrder[1].alloc(L) || !dNodeOf[0].alloc(L) || !dNodeOf[1].alloc(L) ||
-        !dFlags.alloc((size_t)L + 1) || !dBefore.alloc((size_t)L + 1) || !dRank.alloc((size_t)L + 1) || !dNodes.alloc(maxNodes) ||
-        !dBins.alloc(L) || !dPlace.alloc(8 * (size_t)maxNodes) || !dPruned.alloc(1))
+        !dFlags.alloc((size_t)L + 1) || !dBefore.alloc((size_t)L + 1) || !dNodes.alloc(maxNodes) ||
+        !dBins.alloc(L) || !dPlace.alloc(8 * (size_t)maxNodes) || !dPruned.alloc(2))
         return -1;
     size_t tempBytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tempBytes, dFlags.p, dBefore.p, L + 1, stream);
@@ -525,6 +632,7 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
             return -1;                                                                                                 \
         }                                                                                                              \
     } while (0)
+    phase.mark("allocations");
     LISTS_CHECK(hipMemcpyAsync(dLo.p, llo.data(), llo.size() * 4, hipMemcpyHostToDevice, stream));
     LISTS_CHECK(hipMemcpyAsync(dHi.p, lhi.data(), lhi.size() * 4, hipMemcpyHostToDevice, stream));
     LISTS_CHECK(hipMemcpyAsync(dLeafRows.p, leafRows.data(), leafRows.size() * 16, hipMemcpyHostToDevice, stream));
@@ -549,22 +657,18 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
             return -1; /* a degenerate scene: the host's stack does not mind */
         levelFirst.push_back(first);
         levelCount.push_back(count);
-        hipLaunchKernelGGL(k_open, blocksFor(count), dim3(256), 0, stream, dNodes.p, first, count);
+        hipLaunchKernelGGL(k_open, blocksFor(count, 64), dim3(64), 0, stream, dNodes.p, dBins.p, first, count);
         hipLaunchKernelGGL(k_bounds, blocksFor(L), dim3(256), 0, stream, dNodes.p, dNodeOf[cur].p, dOrder[cur].p, dLo.p, dHi.p, L, first);
-        hipLaunchKernelGGL(k_clearBins, blocksFor((size_t)count * 3 * BINS), dim3(256), 0, stream, dBins.p, count);
         hipLaunchKernelGGL(k_bins, blocksFor(L), dim3(256), 0, stream, dNodes.p, dBins.p, dNodeOf[cur].p, dOrder[cur].p, dLo.p, dHi.p, L, first);
-        hipLaunchKernelGGL(k_split, blocksFor(count, 64), dim3(64), 0, stream, dNodes.p, dBins.p, first, count);
-        /* children: two per node that splits */
-        hipLaunchKernelGGL(k_splitFlags, blocksFor(count), dim3(256), 0, stream, dNodes.p, dFlags.p, first, count);
-        LISTS_CHECK(hipcub::DeviceScan::ExclusiveSum(dTemp.p, tempBytes, dFlags.p, dRank.p, count + 1, stream));
+        LISTS_CHECK(hipMemsetAsync(dPruned.p + 1, 0, 4, stream));
+        hipLaunchKernelGGL(k_split, blocksFor(count, 64), dim3(64), 0, stream, dNodes.p, dBins.p, first, count, nextFree, dPruned.p + 1);
         int splitting = 0;
-        LISTS_CHECK(hipMemcpyAsync(&splitting, dRank.p + count, 4, hipMemcpyDeviceToHost, stream));
+        LISTS_CHECK(hipMemcpyAsync(&splitting, dPruned.p + 1, 4, hipMemcpyDeviceToHost, stream));
         LISTS_CHECK(hipStreamSynchronize(stream));
         if (splitting == 0)
             break;
         if (nextFree + 2 * splitting > maxNodes)
             return -1;
-        hipLaunchKernelGGL(k_children, blocksFor(count), dim3(256), 0, stream, dNodes.p, dRank.p, first, count, nextFree);
         /* the stable partition of every splitting node's leaves */
         hipLaunchKernelGGL(k_flags, blocksFor(L), dim3(256), 0, stream, dNodes.p, dNodeOf[cur].p, dOrder[cur].p, dLo.p, dHi.p, dFlags.p, L, first);
         LISTS_CHECK(hipcub::DeviceScan::ExclusiveSum(dTemp.p, tempBytes, dFlags.p, dBefore.p, L + 1, stream));
@@ -577,6 +681,7 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
     }
     const int nbNodes = nextFree;
     const int levels = (int)levelFirst.size();
+    phase.mark("tree, level by level", levels);
     /* which inner nodes stay: top-down */
     for (int d = 0; d < levels; ++d)
         hipLaunchKernelGGL(k_prune, dim3((unsigned)levelCount[d]), dim3(256), 0, stream, dNodes.p, dOrder[cur].p, dLo.p, dHi.p, levelFirst[d],
@@ -591,6 +696,7 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
     LISTS_CHECK(hipMemcpyAsync(nbPruned, dPruned.p, 4, hipMemcpyDeviceToHost, stream));
     LISTS_CHECK(hipStreamSynchronize(stream));
     const int listLength = rootNow.size;
+    phase.mark("pruning, sizes, places", listLength);
     if (listLength < 2)
         return -1;
     if (!dOutRows.alloc(16 * (size_t)listLength) || !dOutStart.alloc(8 * (size_t)listLength) || !dOutOrigin.alloc(8 * (size_t)listLength))
@@ -606,5 +712,171 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
     LISTS_CHECK(hipMemcpyAsync(outOrigin.data(), dOutOrigin.p, outOrigin.size() * 4, hipMemcpyDeviceToHost, stream));
     LISTS_CHECK(hipStreamSynchronize(stream));
 #undef LISTS_CHECK
+    phase.mark("lists written and copied back");
     return listLength;
+}
+
+
+/* ---- pruneInnerNodes' decisions for a node list with skip pointers (solr_hip.hip), on the device ------------------------
+ * The host walks the list once and, for every inner node, samples up to 8 000 leaf centres of its nearest kept
+ * ancestor: 13 + 8 ms of h2d_scene for the 100k-primitive scenes.  The decisions of one depth of the list are
+ * independent of each other once the depths above are decided, so: parents and depths on the host (one pass with a
+ * stack), then one launch per depth, one workgroup per inner node, the host's arithmetic in double. */
+namespace
+{
+__global__ __launch_bounds__(256) void k_pruneList(const float4 *rows, const int *parent, const int *nodesOfDepth, int count,
+                                                    const int *leavesBefore, const int *leaves, int n, double threshold,
+                                                    double sceneArea, char *keep, int *keptAncestor)
+{
+    if ((int)blockIdx.x >= count)
+        return;
+    const int i = nodesOfDepth[blockIdx.x];
+    __shared__ int inside, sampled, outside;
+    const float4 a = rows[2 * i], b = rows[2 * i + 1];
+    const int skip = max(__float_as_int(b.w), 1);
+    const int end = min(i + skip, n);
+    const int up = parent[i];
+    const int ancestor = up < 0 ? -1 : (keep[up] ? up : keptAncestor[up]);
+    if (threadIdx.x == 0)
+    {
+        keptAncestor[i] = ancestor;
+        inside = sampled = outside = 0;
+    }
+    if (__float_as_int(b.z) != 0 || end <= i + 1)
+        return; /* a leaf (or an inner node without children): stays */
+    __syncthreads();
+    const float lo[3] = {a.x, a.y, a.z}, hi[3] = {b.x, b.y, a.w};
+    int parentFrom = 0, parentTo = n;
+    double parentArea = sceneArea;
+    if (ancestor >= 0)
+    {
+        const float4 pa = rows[2 * ancestor], pb = rows[2 * ancestor + 1];
+        parentFrom = ancestor;
+        parentTo = min(ancestor + max(__float_as_int(pb.w), 1), n);
+        const float plo[3] = {pa.x, pa.y, pa.z}, phi[3] = {pb.x, pb.y, pa.w};
+        parentArea = areaOf(plo, phi);
+    }
+    const int firstLeaf = leavesBefore[parentFrom], lastLeaf = leavesBefore[parentTo];
+    const int stride = max(1, (lastLeaf - firstLeaf) / 4096);
+    int mine = 0, seen = 0;
+    for (int q = firstLeaf + (int)threadIdx.x * stride; q < lastLeaf; q += (int)blockDim.x * stride)
+    {
+        const int leaf = leaves[q];
+        const float4 la = rows[2 * leaf], lb = rows[2 * leaf + 1];
+        const float llo[3] = {la.x, la.y, la.z}, lhi[3] = {lb.x, lb.y, la.w};
+        bool in = true;
+        for (int k = 0; k < 3 && in; ++k)
+        {
+            const double c = 0.5 * ((double)llo[k] + lhi[k]);
+            in = c >= lo[k] && c <= hi[k];
+        }
+        ++seen;
+        mine += in ? 1 : 0;
+    }
+    /* every child within the node?  A child's position follows from the skips of the ones before it: one thread
+     * walks them */
+    int bad = 0;
+    if (threadIdx.x == 0)
+        for (int j = i + 1; j < end && !bad; j += max(__float_as_int(rows[2 * j + 1].w), 1))
+        {
+            const float4 ca = rows[2 * j], cb = rows[2 * j + 1];
+            if (!(ca.x >= lo[0] && ca.y >= lo[1] && ca.z >= lo[2] && cb.x <= hi[0] && cb.y <= hi[1] && ca.w <= hi[2]))
+                bad = 1;
+        }
+    atomicAdd(&inside, mine);
+    atomicAdd(&sampled, seen);
+    if (bad)
+        atomicAdd(&outside, 1);
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    const double bySurface = parentArea > 0.0 ? fmin(1.0, areaOf(lo, hi) / parentArea) : 1.0;
+    const double byOrigin = sampled ? (double)inside / sampled : 1.0;
+    if (!outside && (1.0 - fmax(bySurface, byOrigin)) * (end - i - 1) < threshold)
+        keep[i] = 0;
+}
+} // namespace
+
+int solrPruneDecisionsOnDevice(const float4 *rows, int n, double threshold, std::vector<char> &keepOut, hipStream_t stream)
+{
+    if (n < 2)
+        return -1;
+    Phase phase;
+    /* parents, depths, the leaves in list order, the scene's extent: one pass */
+    std::vector<int> parent(n, -1), depth(n, 0), leaves, leavesBefore((size_t)n + 1, 0), stack;
+    int deepest = 0;
+    double sceneLo[3] = {1e300, 1e300, 1e300}, sceneHi[3] = {-1e300, -1e300, -1e300};
+    auto skipOf = [&](int i) {
+        int s;
+        memcpy(&s, &rows[2 * i + 1].w, 4);
+        return std::max(s, 1);
+    };
+    for (int i = 0; i < n; ++i)
+    {
+        while (!stack.empty() && i >= stack.back() + skipOf(stack.back()))
+            stack.pop_back();
+        parent[i] = stack.empty() ? -1 : stack.back();
+        depth[i] = stack.empty() ? 0 : depth[stack.back()] + 1;
+        deepest = std::max(deepest, depth[i]);
+        stack.push_back(i);
+        int count;
+        memcpy(&count, &rows[2 * i + 1].z, 4);
+        leavesBefore[(size_t)i + 1] = leavesBefore[i] + (count > 0 ? 1 : 0);
+        if (count > 0)
+            leaves.push_back(i);
+        if (parent[i] < 0)
+        {
+            const float lo[3] = {rows[2 * i].x, rows[2 * i].y, rows[2 * i].z}, hi[3] = {rows[2 * i + 1].x, rows[2 * i + 1].y, rows[2 * i].w};
+            for (int k = 0; k < 3; ++k)
+            {
+                sceneLo[k] = std::min(sceneLo[k], (double)lo[k]);
+                sceneHi[k] = std::max(sceneHi[k], (double)hi[k]);
+            }
+        }
+    }
+    if (deepest > 256 || leaves.empty())
+        return -1;
+    const double sceneArea = (sceneHi[0] - sceneLo[0]) * (sceneHi[1] - sceneLo[1]) + (sceneHi[1] - sceneLo[1]) * (sceneHi[2] - sceneLo[2]) +
+                             (sceneHi[2] - sceneLo[2]) * (sceneHi[0] - sceneLo[0]);
+    /* nodes by depth */
+    std::vector<int> firstOfDepth((size_t)deepest + 2, 0), byDepth(n);
+    for (int i = 0; i < n; ++i)
+        ++firstOfDepth[(size_t)depth[i] + 1];
+    for (int d = 0; d <= deepest; ++d)
+        firstOfDepth[(size_t)d + 1] += firstOfDepth[d];
+    {
+        std::vector<int> at(firstOfDepth.begin(), firstOfDepth.end() - 1);
+        for (int i = 0; i < n; ++i)
+            byDepth[at[depth[i]]++] = i;
+    }
+    phase.mark("prune: parents and depths", deepest + 1);
+    Dev<float4> dRows;
+    Dev<int> dParent, dByDepth, dLeavesBefore, dLeaves, dAncestor;
+    Dev<char> dKeep;
+    if (!dRows.alloc(2 * (size_t)n) || !dParent.alloc(n) || !dByDepth.alloc(n) || !dLeavesBefore.alloc((size_t)n + 1) ||
+        !dLeaves.alloc(leaves.size()) || !dAncestor.alloc(n) || !dKeep.alloc(n))
+        return -1;
+    bool fine = hipMemcpyAsync(dRows.p, rows, 2 * (size_t)n * 16, hipMemcpyHostToDevice, stream) == hipSuccess &&
+                hipMemcpyAsync(dParent.p, parent.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream) == hipSuccess &&
+                hipMemcpyAsync(dByDepth.p, byDepth.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream) == hipSuccess &&
+                hipMemcpyAsync(dLeavesBefore.p, leavesBefore.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, stream) == hipSuccess &&
+                hipMemcpyAsync(dLeaves.p, leaves.data(), leaves.size() * 4, hipMemcpyHostToDevice, stream) == hipSuccess &&
+                hipMemsetAsync(dKeep.p, 1, n, stream) == hipSuccess;
+    if (!fine)
+        return -1;
+    for (int d = 0; d <= deepest; ++d)
+    {
+        const int count = firstOfDepth[(size_t)d + 1] - firstOfDepth[d];
+        if (count > 0)
+            hipLaunchKernelGGL(k_pruneList, dim3((unsigned)count), dim3(256), 0, stream, dRows.p, dParent.p, dByDepth.p + firstOfDepth[d], count,
+                               dLeavesBefore.p, dLeaves.p, n, threshold, sceneArea, dKeep.p, dAncestor.p);
+    }
+    keepOut.assign(n, 1);
+    if (hipMemcpyAsync(keepOut.data(), dKeep.p, n, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+        return -1;
+    phase.mark("prune: decisions");
+    int pruned = 0;
+    for (char k : keepOut)
+        pruned += k ? 0 : 1;
+    return pruned;
 }

@@ -9,6 +9,9 @@
  */
 #include "GPUKernel.h"
 
+#include <chrono>
+#include <cstdio>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -649,9 +652,27 @@ void GPUKernel::ensureLevels()
         buildLevelsOnHost();
 }
 
+namespace
+{
+struct HostPhase
+{
+    const bool on = getenv("SOLR_HIP_DEBUG_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char *what)
+    {
+        if (!on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "solr host: %-30s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+} // namespace
+
 /* compactBoxes(true) through the engine: true when the flattened arrays, lamps and light list are in place */
 bool GPUKernel::buildTreeOnDevice()
 {
+    HostPhase phase;
     if (m_hostBuildOnly || getenv("SOLR_HOST_BUILD"))
         return false;
     m_frames[m_frame].levelsBuilt = true; /* whatever was left unbuilt is about to be replaced */
@@ -663,12 +684,14 @@ bool GPUKernel::buildTreeOnDevice()
      * up by that number when it streams them: the two agree when the ids are 0..n-1 */
     std::vector<Primitive> prims(n);
     std::vector<unsigned char> emissive(n);
+    std::vector<CPUPrimitive *> byId(n); /* (a look-up per primitive in the loop further down was a third of this function) */
     int rank = 0;
     for (auto &entry : f.primitives)
     {
         if ((int)entry.first != rank)
             return false;
-        const CPUPrimitive &p = entry.second;
+        CPUPrimitive &p = entry.second;
+        byId[rank] = &p;
         Primitive &out = prims[rank];
         memset(&out, 0, sizeof(out));
         out.index = rank;
@@ -686,7 +709,9 @@ bool GPUKernel::buildTreeOnDevice()
     std::vector<BoundingBox> boxes;
     std::vector<int> order;
     int nbLamps = 0;
+    phase.mark("compactBoxes: primitive records");
     const int depth = deviceBuildTree(prims, emissive, f.minPos, f.maxPos, m_sceneInfo.viewDistance, boxes, order, nbLamps);
+    phase.mark("compactBoxes: device build");
     if (depth < 1 || (int)order.size() != n || boxes.empty() || boxes.size() >= (size_t)NB_MAX_BOXES)
         return false;
 
@@ -712,10 +737,12 @@ bool GPUKernel::buildTreeOnDevice()
     for (int k = 0; k < n; ++k)
     {
         const long id = order[k];
-        appendPrimitive(id, k >= nbLamps);
+        if (id < 0 || id >= n)
+            return false;
+        appendPrimitive(id, k >= nbLamps, byId[id]);
         if (k < nbLamps)
         {
-            CPUPrimitive &primitive = f.primitives[(unsigned int)id];
+            CPUPrimitive &primitive = *byId[id];
             Material &material = m_hMaterials[primitive.materialId];
             LightInformation li;
             memset(&li, 0, sizeof(li));
@@ -736,12 +763,13 @@ bool GPUKernel::buildTreeOnDevice()
     for (const BoundingBox &b : m_hBoundingBoxes)
         m_maxPrimitivesPerBox = std::max(m_maxPrimitivesPerBox, (size_t)std::max(b.nbPrimitives, 0));
     m_frames[m_frame].levelsBuilt = false; /* the maps follow when somebody needs them (frame()) */
+    phase.mark("compactBoxes: flattened arrays");
     return true;
 }
 
-void GPUKernel::appendPrimitive(long id, bool inLevel0Box)
+void GPUKernel::appendPrimitive(long id, bool inLevel0Box, CPUPrimitive *known)
 {
-    CPUPrimitive &primitive = frame().primitives[(unsigned int)id];
+    CPUPrimitive &primitive = known ? *known : frame().primitives[(unsigned int)id];
     Primitive out;
     memset(&out, 0, sizeof(out));
     out.index = (int)id;

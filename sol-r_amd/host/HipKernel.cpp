@@ -6,6 +6,7 @@
 #include "HipKernel.h"
 
 #include <cstring>
+#include <memory>
 #include <vector>
 #include <iostream>
 
@@ -170,20 +171,23 @@ int HipKernel::deviceBuildTree(const std::vector<Primitive> &primitives, const s
     if (solr_hip_device_count() < 1)
         return -2;
     const int n = (int)primitives.size();
-    /* every level has at most as many boxes as the one below, the top one box more: (depth + 1) n + 1 at most */
-    boxes.resize((size_t)n * 12 + 16);
+    /* every level has at most as many boxes as the one below, the top one box more: (depth + 1) n + 1 at most.
+     * Uninitialised memory for that worst case (a value-initialised vector of it is 58 MB of zeros for 100 k
+     * primitives, twice the time of the build itself); the nodes that exist are copied out */
+    const size_t capacity = (size_t)n * 12 + 16;
+    std::unique_ptr<BoundingBox[]> raw(new BoundingBox[capacity]);
     order.resize((size_t)n);
     const float mn[3] = {minPos.x, minPos.y, minPos.z}, mx[3] = {maxPos.x, maxPos.y, maxPos.z};
     int nbBoxes = 0;
-    const int depth = solr_hip_build_tree(primitives.data(), emissive.data(), n, mn, mx, viewDistance, boxes.data(),
-                                          (int)boxes.size(), order.data(), &nbBoxes, &nbLamps);
+    const int depth = solr_hip_build_tree(primitives.data(), emissive.data(), n, mn, mx, viewDistance, raw.get(), (int)capacity,
+                                          order.data(), &nbBoxes, &nbLamps);
     if (depth < 1)
     {
         boxes.clear();
         order.clear();
         return depth;
     }
-    boxes.resize((size_t)nbBoxes);
+    boxes.assign(raw.get(), raw.get() + nbBoxes);
     return depth;
 }
 

@@ -21,6 +21,7 @@ def _lists(solr, build, **kw):
     k.check(0, "frames")
     n = solr.hip_lib().solr_hip_order_free_nodes()
     lists = [k.device_nodes(order_free=o).copy() for o in range(8)] if n else []
+    lists.append(k.device_nodes(exact=False).copy())     # the walk-order list: its pruning decisions are made there too
     k.finalize()
     return n, lists, image
 
@@ -67,10 +68,10 @@ def test_device_lists_are_the_hosts(solr, scene, kw):
     finally:
         os.environ.pop("SOLR_HIP_LISTS_ON_HOST", None)
     assert n_dev == n_host and n_dev > 0, (n_dev, n_host)
-    for o in range(8):
+    for o in range(9):
         a, b = dev[o].view(np.int32), host[o].view(np.int32)
         assert a.shape == b.shape
         if not np.array_equal(a, b):
             bad = np.argwhere((a != b).any(axis=(1, 2)))[:5].ravel()
-            raise AssertionError("octant %d: nodes %s differ, e.g. device %s host %s" % (o, bad, dev[o][bad[0]], host[o][bad[0]]))
+            raise AssertionError("list %d (8 = the walk-order list): nodes %s differ, e.g. device %s host %s" % (o, bad, dev[o][bad[0]], host[o][bad[0]]))
     assert np.array_equal(image_dev, image_host)
