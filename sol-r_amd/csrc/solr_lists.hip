@@ -724,9 +724,34 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
  * stack), then one launch per depth, one workgroup per inner node, the host's arithmetic in double. */
 namespace
 {
+/* the centres of the leaves, in list order, as the decisions compare them: 0.5 * ((double)lo + hi) */
+__global__ void k_leafCentres(const float4 *rows, const int *leaves, int nbLeaves, double *centres)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nbLeaves)
+        return;
+    const int leaf = leaves[q];
+    const float4 la = rows[2 * leaf], lb = rows[2 * leaf + 1];
+    centres[3 * (size_t)q] = 0.5 * ((double)la.x + lb.x);
+    centres[3 * (size_t)q + 1] = 0.5 * ((double)la.y + lb.y);
+    centres[3 * (size_t)q + 2] = 0.5 * ((double)la.z + la.w);
+}
+
+/* a node that does not lie within its parent marks the parent: such a parent is never left out */
+__global__ void k_strayChildren(const float4 *rows, const int *parent, int n, char *stray)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || parent[j] < 0)
+        return;
+    const int i = parent[j];
+    const float4 a = rows[2 * i], b = rows[2 * i + 1], ca = rows[2 * j], cb = rows[2 * j + 1];
+    if (!(ca.x >= a.x && ca.y >= a.y && ca.z >= a.z && cb.x <= b.x && cb.y <= b.y && ca.w <= a.w))
+        stray[i] = 1;
+}
+
 __global__ __launch_bounds__(256) void k_pruneList(const float4 *rows, const int *parent, const int *nodesOfDepth, int count,
                                                     const int *leavesBefore, const int *leaves, int n, double threshold,
-                                                    double sceneArea, char *keep, int *keptAncestor)
+                                                    double sceneArea, char *keep, int *keptAncestor, const char *stray, const double *centres)
 {
     if ((int)blockIdx.x >= count)
         return;
@@ -761,31 +786,15 @@ __global__ __launch_bounds__(256) void k_pruneList(const float4 *rows, const int
     int mine = 0, seen = 0;
     for (int q = firstLeaf + (int)threadIdx.x * stride; q < lastLeaf; q += (int)blockDim.x * stride)
     {
-        const int leaf = leaves[q];
-        const float4 la = rows[2 * leaf], lb = rows[2 * leaf + 1];
-        const float llo[3] = {la.x, la.y, la.z}, lhi[3] = {lb.x, lb.y, la.w};
-        bool in = true;
-        for (int k = 0; k < 3 && in; ++k)
-        {
-            const double c = 0.5 * ((double)llo[k] + lhi[k]);
-            in = c >= lo[k] && c <= hi[k];
-        }
+        const double cx = centres[3 * (size_t)q], cy = centres[3 * (size_t)q + 1], cz = centres[3 * (size_t)q + 2];
+        const bool in = cx >= lo[0] && cx <= hi[0] && cy >= lo[1] && cy <= hi[1] && cz >= lo[2] && cz <= hi[2];
         ++seen;
         mine += in ? 1 : 0;
     }
-    /* every child within the node?  A child's position follows from the skips of the ones before it: one thread
-     * walks them */
-    int bad = 0;
-    if (threadIdx.x == 0)
-        for (int j = i + 1; j < end && !bad; j += max(__float_as_int(rows[2 * j + 1].w), 1))
-        {
-            const float4 ca = rows[2 * j], cb = rows[2 * j + 1];
-            if (!(ca.x >= lo[0] && ca.y >= lo[1] && ca.z >= lo[2] && cb.x <= hi[0] && cb.y <= hi[1] && ca.w <= hi[2]))
-                bad = 1;
-        }
+    const int bad = stray[i]; /* a child outside the node (k_strayChildren) */
     atomicAdd(&inside, mine);
     atomicAdd(&sampled, seen);
-    if (bad)
+    if (bad && threadIdx.x == 0)
         atomicAdd(&outside, 1);
     __syncthreads();
     if (threadIdx.x != 0)
@@ -852,8 +861,9 @@ int solrPruneDecisionsOnDevice(const float4 *rows, int n, double threshold, std:
     phase.mark("prune: parents and depths", deepest + 1);
     Dev<float4> dRows;
     Dev<int> dParent, dByDepth, dLeavesBefore, dLeaves, dAncestor;
-    Dev<char> dKeep;
-    if (!dRows.alloc(2 * (size_t)n) || !dParent.alloc(n) || !dByDepth.alloc(n) || !dLeavesBefore.alloc((size_t)n + 1) ||
+    Dev<char> dKeep, dStray;
+    Dev<double> dCentres;
+    if (!dCentres.alloc(3 * leaves.size()) || !dStray.alloc(n) || !dRows.alloc(2 * (size_t)n) || !dParent.alloc(n) || !dByDepth.alloc(n) || !dLeavesBefore.alloc((size_t)n + 1) ||
         !dLeaves.alloc(leaves.size()) || !dAncestor.alloc(n) || !dKeep.alloc(n))
         return -1;
     bool fine = hipMemcpyAsync(dRows.p, rows, 2 * (size_t)n * 16, hipMemcpyHostToDevice, stream) == hipSuccess &&
@@ -861,15 +871,17 @@ int solrPruneDecisionsOnDevice(const float4 *rows, int n, double threshold, std:
                 hipMemcpyAsync(dByDepth.p, byDepth.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream) == hipSuccess &&
                 hipMemcpyAsync(dLeavesBefore.p, leavesBefore.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, stream) == hipSuccess &&
                 hipMemcpyAsync(dLeaves.p, leaves.data(), leaves.size() * 4, hipMemcpyHostToDevice, stream) == hipSuccess &&
-                hipMemsetAsync(dKeep.p, 1, n, stream) == hipSuccess;
+                hipMemsetAsync(dKeep.p, 1, n, stream) == hipSuccess && hipMemsetAsync(dStray.p, 0, n, stream) == hipSuccess;
     if (!fine)
         return -1;
+    hipLaunchKernelGGL(k_strayChildren, blocksFor(n), dim3(256), 0, stream, dRows.p, dParent.p, n, dStray.p);
+    hipLaunchKernelGGL(k_leafCentres, blocksFor(leaves.size()), dim3(256), 0, stream, dRows.p, dLeaves.p, (int)leaves.size(), dCentres.p);
     for (int d = 0; d <= deepest; ++d)
     {
         const int count = firstOfDepth[(size_t)d + 1] - firstOfDepth[d];
         if (count > 0)
             hipLaunchKernelGGL(k_pruneList, dim3((unsigned)count), dim3(256), 0, stream, dRows.p, dParent.p, dByDepth.p + firstOfDepth[d], count,
-                               dLeavesBefore.p, dLeaves.p, n, threshold, sceneArea, dKeep.p, dAncestor.p);
+                               dLeavesBefore.p, dLeaves.p, n, threshold, sceneArea, dKeep.p, dAncestor.p, dStray.p, dCentres.p);
     }
     keepOut.assign(n, 1);
     if (hipMemcpyAsync(keepOut.data(), dKeep.p, n, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
