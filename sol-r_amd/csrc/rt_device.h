@@ -1570,6 +1570,8 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     Hit h;
                     bool back;
                     const bool i = sphereHit(si, V4(head.a), head.b.x, r, entered, h.intersection, back);
+                    if (ballot(i) == 0ull)
+                        continue; /* nobody hit it: no distance to take (a square root) */
                     const float distance = length(h.intersection - r.o);
                     const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
                     if (ballot(keep) != 0ull)
@@ -1600,7 +1602,9 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                         h.shadowIntensity = 0.f;
                         const bool i = planePlain(S, si, kind, V4(head.a), V4(head.b), recPlaneNormal(S, rec),
                                                   recPlaneAverage(S, rec), r, h);
-                        const float distance = length(h.intersection - r.o);
+                        float distance = 0.f;
+                        if (i)
+                            distance = length(h.intersection - r.o); /* (skipped by the wave when nobody hit) */
                         if (i && distance > si.geometryEpsilon && closer(distance, pi))
                         {
                             minDistance = distance;
@@ -1628,6 +1632,8 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     const v3 p2 = recP2(S, rec);
                     if (entered)
                         i = triangleHit(si, p0, p1, p2, r, h.intersection);
+                    if (ballot(i) == 0ull)
+                        continue;
                     const float distance = length(h.intersection - r.o);
                     const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
                     if (ballot(keep) != 0ull)
@@ -1661,7 +1667,9 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                         h.shadowIntensity = 0.f;
                         const bool i = cylinderIntersection(si, V4(head.a), recP1(S, rec), recP2(S, rec),
                                                             V4(primRow(S, pi, ROW_N1)), V4(head.b), r, h);
-                        const float distance = length(h.intersection - r.o);
+                        float distance = 0.f;
+                        if (i)
+                            distance = length(h.intersection - r.o); /* (skipped by the wave when nobody hit) */
                         if (i && distance > si.geometryEpsilon && closer(distance, pi))
                         {
                             minDistance = distance;
@@ -1692,7 +1700,9 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     Hit h;
                     bool back;
                     const bool i = sphereHit(si, V4(head.a), head.b.x, r, lanes, h.intersection, back);
-                    const float distance = length(h.intersection - r.o);
+                    float distance = 0.f;
+                    if (i)
+                        distance = length(h.intersection - r.o);
                     const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
                     if (ballot(keep) != 0ull)
                     {
@@ -1722,7 +1732,9 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     const v3 p2 = recP2(S, rec);
                     if (lanes)
                         i = triangleHit(si, p0, p1, p2, r, h.intersection);
-                    const float distance = length(h.intersection - r.o);
+                    float distance = 0.f;
+                    if (i)
+                        distance = length(h.intersection - r.o);
                     const bool keep = i && distance > si.geometryEpsilon && closer(distance, pi);
                     if (ballot(keep) != 0ull)
                     {
@@ -1750,7 +1762,9 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                     h.areas = V(0.f, 0.f, 0.f);
                     h.shadowIntensity = 0.f;
                     const bool i = testPrimitive<false, FEAT>(S, si, rec, tag, r, h);
-                    const float distance = length(h.intersection - r.o);
+                    float distance = 0.f;
+                    if (i)
+                        distance = length(h.intersection - r.o);
                     if (i && distance > si.geometryEpsilon && closer(distance, pi))
                     {
                         minDistance = distance;
