@@ -20,7 +20,13 @@ dialect that the product is held to) and must reproduce
     launchRayTracing pixel, which adds that term, within 2 ULP on at most 2 % of the pixels;
   * the build with ROCm's own builtins (fused dot products, approximate reciprocal square root) within the
     bounds written at `AS_BUILT`: same decision on >= 98 % of the elements - a hit that sits on an epsilon can
-    go either way - and, where the decision is the same, values within 1e-3 relative.
+    go either way - and, where the decision is the same, values within 1e-3 relative.  And EVERY element whose
+    decision differs (hit or miss, which primitive, a pixel's ids) is shown to sit on such an epsilon: the oracle
+    itself gives the as-built answer once the element's ray is nudged by a few parts in a million
+    (`explain_differences`: each component of origin and target by 2^-22 ... 2^-18 of the coordinates, then
+    random nudges of that size) - a difference the rounding of a dot product can make; an element the oracle
+    decides the same way under every nudge while the reference as built decides otherwise would be a real
+    difference, and there is none.
 
 Two forms of the same checks: on CPU against tests/golden/reference_probes.npz (inputs + reference outputs,
 made on an MI355X by tests/golden/make_probe_fixtures.py), and live on the GPU box with freshly built inputs.
@@ -75,7 +81,65 @@ def check_source_order(probes, name, out, ref):
 AS_BUILT = {"decision": 0.98, "primitive": 0.95, "values": 2e-3, "launch_ids": 0.995, "launch_median": 1e-6}
 
 
-def check_as_built(probes, name, out, ref):
+RAY_KEYS = ("directions", "targets", "origins", "lamps")
+
+
+def _decisions(out):
+    keys = [k for k in ("hit", "primitive", "ids") if k in out]
+    return np.concatenate([out[k].reshape(len(out[k]), -1) for k in keys], axis=1) if keys else None
+
+
+def explain_differences(probes, name, case, out, ref):
+    """every element on which the as-built reference decides differently is one the oracle decides that way too
+    when its ray is nudged by rounding-sized amounts; returns (differing, unexplained element indices)"""
+    mine, theirs = _decisions(out), _decisions(ref)
+    if mine is None:
+        return 0, []
+    n = len(mine)
+    differing = np.flatnonzero((mine != theirs).any(axis=1))
+    if len(differing) == 0:
+        return 0, []
+    sub = {k: (v[differing].copy() if isinstance(v, np.ndarray) and len(v) == n and k not in ("materials", "textures") else v)
+           for k, v in case.items()}
+    want = theirs[differing]
+    explained = np.zeros(len(differing), bool)
+
+    def attempt(changed):
+        nonlocal explained
+        trial = dict(sub)
+        trial.update(changed)
+        explained |= (_decisions(probes.oracle_outputs(trial)) == want).all(axis=1)
+
+    for eps in (2.0 ** -22, 2.0 ** -20, 2.0 ** -18):
+        for key in RAY_KEYS:
+            if key not in sub:
+                continue
+            scale = np.maximum(np.abs(sub[key]).max(axis=1), 1.0)
+            for component in range(3):
+                for sign in (1.0, -1.0):
+                    a = sub[key].copy()
+                    a[:, component] = (a[:, component] + sign * eps * scale).astype(np.float32)
+                    attempt({key: a})
+        if explained.all():
+            break
+    rng = np.random.default_rng(5)
+    for _ in range(256):
+        if explained.all():
+            break
+        changed = {}
+        for key in RAY_KEYS:
+            if key in sub:
+                scale = np.maximum(np.abs(sub[key]).max(axis=1, keepdims=True), 1.0)
+                changed[key] = (sub[key] + rng.uniform(-1, 1, sub[key].shape) * scale * 2.0 ** -float(rng.integers(17, 23))).astype(np.float32)
+        attempt(changed)
+    return len(differing), [int(i) for i in differing[~explained]]
+
+
+def check_as_built(probes, name, out, ref, case=None):
+    if case is not None:
+        differing, unexplained = explain_differences(probes, name, case, out, ref)
+        assert not unexplained, "%s: %d of %d differing elements are not explained by rounding: %s" % (
+            name, len(unexplained), differing, unexplained[:8])
     n = len(next(iter(out.values())))
     same = np.ones(n, bool)
     if "hit" in out:
@@ -109,7 +173,7 @@ def _check(probes, name, case, reference):
         assert np.array_equal(out["bitmap"], reference["renderer"]["bitmap"]), name
         return
     check_source_order(probes, name, out, reference["source_order"])
-    check_as_built(probes, name, out, reference["as_built"])
+    check_as_built(probes, name, out, reference["as_built"], case)
 
 
 # ---- on CPU, from the committed outputs of the reference --------------------------------------------------
