@@ -160,6 +160,10 @@ void solr_hip_strip_rows(int rank, int world, int height, int *firstRow, int *nb
 int solr_hip_comm_unique_id(void *id128);
 int solr_hip_comm_init(int rank, int world, const void *id128);
 int solr_hip_comm_ranks(void);
+/* a number every rank holds alike (rank 0's draw at solr_hip_comm_init; 0 without a communicator of several ranks):
+ * the seed for whatever the hosts draw per frame - GPUKernel::render_begin's timestamp (GPUKernel.cpp:2712-2727) - so
+ * that every rank renders the same frame without a word per frame between them */
+unsigned solr_hip_comm_shared_seed(void);
 int solr_hip_gather_strips(int root);
 void *solr_hip_gathered_frame(void);
 int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap);

@@ -179,6 +179,7 @@ def _declare_hip(L):
     L.solr_hip_comm_unique_id.argtypes = [C.c_void_p]
     L.solr_hip_comm_init.argtypes = [C.c_int, C.c_int, C.c_void_p]
     L.solr_hip_comm_ranks.restype = C.c_int
+    L.solr_hip_comm_shared_seed.restype = C.c_uint
     L.solr_hip_gather_strips.argtypes = [C.c_int]
     L.solr_hip_gather_ids.argtypes = [C.c_int]
     L.solr_hip_gathered_frame.restype = C.c_void_p

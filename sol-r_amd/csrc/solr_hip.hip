@@ -4228,6 +4228,7 @@ struct Rccl
     int haloAgreed = -1;
     bool haloStale = true;  /* something it depends on was uploaded since (or nothing was agreed yet) */
     int haloParam2Bits = 0; /* PostProcessingInfo.param2 of the agreement */
+    unsigned sharedSeed = 0; /* rank 0's draw at solr_hip_comm_init, the same on every rank (solr_hip_comm_shared_seed) */
 } rccl;
 const int RCCL_UINT8 = 1; /* ncclUint8, rccl.h:460 */
 const int RCCL_INT32 = 2; /* ncclInt32 */
@@ -4399,10 +4400,20 @@ bool shareRandoms()
     rccl.haloStale = true;
     const long n = g.randoms.ptr ? g.nbRandoms : 0;
     /* the same count everywhere?  (two 16-bit halves: a float holds them exactly) */
-    float v[6] = {(float)(n >> 16), -(float)(n >> 16), (float)(n & 0xffff), -(float)(n & 0xffff), ok() ? 0.f : 1.f,
-                  rccl.rank == 0 ? g.randomsReach : 0.f};
-    if (!allReduceFloats(v, 6, RCCL_MAX, "ncclAllReduce (size of the random buffer)"))
+    /* (two more slots: a seed of rank 0's, in 16-bit halves, for what the hosts draw per frame - see
+     * solr_hip_comm_shared_seed) */
+    unsigned draw = 0;
+    if (rccl.rank == 0)
+    {
+        draw = (unsigned)std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u;
+        draw = (draw ^ (draw >> 15)) | 1u;
+    }
+    float v[8] = {(float)(n >> 16), -(float)(n >> 16), (float)(n & 0xffff), -(float)(n & 0xffff), ok() ? 0.f : 1.f,
+                  rccl.rank == 0 ? g.randomsReach : 0.f, (float)(draw >> 16), (float)(draw & 0xffffu)};
+    if (!allReduceFloats(v, 8, RCCL_MAX, "ncclAllReduce (size of the random buffer)"))
         return false;
+    if (rccl.sharedSeed == 0)
+        rccl.sharedSeed = ((unsigned)v[6] << 16) | (unsigned)v[7];
     if (v[0] != -v[1] || v[2] != -v[3])
     {
         setError(-1, "the ranks of the communicator hold random buffers of different sizes (h2d_randoms on some only?)",
@@ -4806,6 +4817,17 @@ int solr_hip_comm_init(int rank, int world, const void *id128)
     return ok() ? 0 : -1;
 }
 
+/* A number every rank of the communicator holds alike (rank 0 drew it at solr_hip_comm_init), 0 without a
+ * communicator of more than one rank.  What a host draws per frame - GPUKernel::render_begin takes the frame's
+ * timestamp from rand() (GPUKernel.cpp:2712-2727), and the timestamp indexes the random buffer in the shader, the
+ * depth of field and the procedural spheres - has to be the same on every rank or the strips do not assemble to one
+ * frame: hosts seed a generator of their own with this (sol-r_amd/host/HipKernel.cpp does) instead of talking to
+ * each other every frame. */
+unsigned solr_hip_comm_shared_seed(void)
+{
+    return (rccl.comm && rccl.world > 1) ? rccl.sharedSeed : 0u;
+}
+
 /* ranks of the communicator as the library itself reports them (ncclCommCount), 0 without one */
 int solr_hip_comm_ranks(void)
 {
@@ -4983,6 +5005,7 @@ void solr_hip_comm_finalize(void)
     rccl.world = 0;
     rccl.haloAgreed = -1;
     rccl.haloStale = true;
+    rccl.sharedSeed = 0;
 }
 
 #ifdef SOLR_TIMING

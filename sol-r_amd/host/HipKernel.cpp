@@ -94,6 +94,22 @@ int HipKernel::lastError(std::string *message)
 void HipKernel::render_begin(const float timer)
 {
     GPUKernel::render_begin(timer);
+    if (m_deterministicSeed < 0)
+    {
+        /* one process of several (solr_hip_comm_init): the timestamp the base class has just drawn from rand() has to
+         * be every rank's - drawn from a generator that all of them seeded alike instead */
+        const unsigned shared = solr_hip_comm_shared_seed();
+        if (shared != m_sharedSeed)
+        {
+            m_sharedSeed = shared;
+            m_sharedState = shared;
+        }
+        if (shared != 0)
+        {
+            m_sharedState = m_sharedState * 1664525u + 1013904223u;
+            m_sceneInfo.timestamp = (int)((m_sharedState >> 8) % 10000u);
+        }
+    }
     if (m_refresh)
     {
         if (!m_primitivesTransfered)

@@ -66,6 +66,7 @@ private:
     int m_sharedMemSize;
     bool m_deviceInitialized;
     bool m_idsOnDevice = false;
+    unsigned m_sharedSeed = 0, m_sharedState = 0; /* solr_hip_comm_shared_seed and the generator it seeds (render_begin) */
     int m_flights = 1;            /* frames in flight through render_begin / render_end (setFramesInFlight) */
     std::deque<int> m_tickets;    /* read-backs under way, oldest first (solr_hip_d2h_image_async) */
     void deliver(int ticket);

@@ -109,9 +109,11 @@ def main():
     assert hip.solr_hip_comm_init(rank, world, uid) == 0
     k.check(0, "solr_hip_comm_init")
     assert hip.solr_hip_comm_ranks() == world
+    shared_seed = int(hip.solr_hip_comm_shared_seed())
+    assert (shared_seed != 0) == (world > 1)
     first, count, _ = solr.strip_rows(rank, world, H)
     hip.solr_hip_set_strip(first, count)
-    report = {"rank": rank, "equal_strip": [first, count]}
+    report = {"rank": rank, "equal_strip": [first, count], "shared_seed": shared_seed}
 
     # 1. equal strips, one frame, image and ids
     render()

@@ -60,6 +60,7 @@ def run_ranks(world, transport, timeout=420):
 
 
 def check_partitions(reports, height=136):
+    assert len({rep["shared_seed"] for rep in reports}) == 1      # rank 0's draw, on every rank
     for key, align in (("equal_strip", 1), ("balanced_strip", 8), ("balanced_strip_with_reach", 16)):
         at = 0
         for rep in sorted(reports, key=lambda r: r["rank"]):
