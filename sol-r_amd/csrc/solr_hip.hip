@@ -28,6 +28,7 @@
 
 #include "../../include/solr_hip.h"
 #include "rt_device.h"
+#include "device_pool.h"
 #include "lists_device.h"
 
 using namespace solrdev;
@@ -1089,6 +1090,72 @@ __global__ __launch_bounds__(256) void k_buildLeafRecords(float4 *__restrict__ a
     out[3] = r3;
 }
 
+/* maybeBuildOrderFreeLists' precondition, for the exact list as the arena holds it: every inner node holds its
+ * direct children, every leaf its primitives (the same float arithmetic as the host loop there, which stays as the
+ * route for an arena that is not laid out).  *bad is raised for a node that does not. */
+__global__ __launch_bounds__(256) void k_listEncloses(const float4 *__restrict__ arena, unsigned offNodes, unsigned offStart,
+                                                      unsigned offPrims, int nbNodes, int nbPrims, int *bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbNodes)
+        return;
+    const float4 a = arena[offNodes + 2u * (unsigned)i], b = arena[offNodes + 2u * (unsigned)i + 1u];
+    const int count = __float_as_int(b.z);
+    const int end = min(i + max(__float_as_int(b.w), 1), nbNodes);
+    bool encloses = true;
+    if (count <= 0)
+    {
+        for (int j = i + 1; j < end && encloses;)
+        {
+            const float4 ca = arena[offNodes + 2u * (unsigned)j], cb = arena[offNodes + 2u * (unsigned)j + 1u];
+            encloses = ca.x >= a.x && ca.y >= a.y && ca.z >= a.z && cb.x <= b.x && cb.y <= b.y && ca.w <= a.w;
+            j += max(__float_as_int(cb.w), 1);
+        }
+    }
+    else
+    {
+        const int start = ((const int *)arena)[offStart + (unsigned)i];
+        for (int k = 0; k < count && encloses; ++k)
+        {
+            const long long pi = (long long)start + k;
+            if (start < 0 || pi >= nbPrims)
+            {
+                encloses = false;
+                break;
+            }
+            const float4 *r = arena + offPrims + (size_t)PRIM_ROWS * (size_t)pi;
+            const float4 p0 = r[ROW_P0_TYPE], size = r[ROW_SIZE_MAT];
+            const int type = __float_as_int(p0.w) & PRIM_TYPE_MASK;
+            float lo[3] = {p0.x, p0.y, p0.z}, hi[3] = {p0.x, p0.y, p0.z};
+            auto add = [&](const float4 &v) {
+                lo[0] = v.x < lo[0] ? v.x : lo[0], lo[1] = v.y < lo[1] ? v.y : lo[1], lo[2] = v.z < lo[2] ? v.z : lo[2];
+                hi[0] = hi[0] < v.x ? v.x : hi[0], hi[1] = hi[1] < v.y ? v.y : hi[1], hi[2] = hi[2] < v.z ? v.z : hi[2];
+            };
+            float grow[3] = {size.x, size.y, size.z};
+            if (type == ptTriangle)
+            {
+                add(r[ROW_P1_INDEX]);
+                add(r[ROW_P2]);
+                grow[0] = grow[1] = grow[2] = 0.f;
+            }
+            else if (type == ptCylinder)
+            {
+                add(r[ROW_P1_INDEX]);
+                grow[1] = grow[2] = grow[0];
+            }
+            else if (type == ptSphere)
+                grow[1] = grow[2] = grow[0];
+            auto larger = [](float x, float y) { return x < y ? y : x; }; /* std::max */
+            auto slack = [&](int k) { return 4.f * 1.1920929e-7f * larger(larger(fabsf(lo[k]), fabsf(hi[k])), fabsf(grow[k])); };
+            const float ex = slack(0), ey = slack(1), ez = slack(2);
+            encloses = a.x <= lo[0] - fabsf(grow[0]) + ex && a.y <= lo[1] - fabsf(grow[1]) + ey && a.z <= lo[2] - fabsf(grow[2]) + ez &&
+                       b.x >= hi[0] + fabsf(grow[0]) - ex && b.y >= hi[1] + fabsf(grow[1]) - ey && a.w >= hi[2] + fabsf(grow[2]) - ez;
+        }
+    }
+    if (!encloses)
+        *bad = 1;
+}
+
 __global__ __launch_bounds__(256) void k_rotatePrimitives(float4 *__restrict__ arena, unsigned offPrims, int nbPrimitives,
                                                           const unsigned char *__restrict__ movable,
                                                           const RotationArgs R)
@@ -1252,6 +1319,12 @@ struct Engine
     /* the order-free list: the leaves of the scene under a surface-area hierarchy of our own (buildFreeOrderList) */
     std::vector<float4> hostBoxesFree;
     std::vector<int> hostBoxStartFree;
+    /* lists built on the device stay there: `freeRows` float4 rows (16 per node of a list) that go into the arena with
+     * a device-to-device copy (freeStage, until the next flushGeometry); the host images above are filled from the
+     * arena when somebody needs them (ensureHostFreeLists: the refit plan of a rotated scene, a second layout) */
+    size_t freeRows = 0;
+    bool freeHostValid = true;
+    SolrDeviceLists freeStage;
     unsigned offBoxesFree = 0, offBoxStartFree = 0, offLeafFree = 0;
     int nbBoxesFree = 0;        /* nodes per list; there are eight, one per direction octant */
     bool freeStale = false;     /* rotated on the device since it was built: not refitted, not walked */
@@ -1684,6 +1757,52 @@ static void refreshExactList()
     g.exactStale = false;
 }
 
+/* the buffers the device builder left its lists in: rows and start indices until they are in the arena, the origins
+ * (only the refit plan reads them) until the host has them or the lists go */
+static void dropFreeStage(bool originToo)
+{
+    if (g.freeStage.rows)
+        (void)hipFree(g.freeStage.rows);
+    if (g.freeStage.start)
+        (void)hipFree(g.freeStage.start);
+    g.freeStage.rows = nullptr;
+    g.freeStage.start = nullptr;
+    if (originToo && g.freeStage.origin)
+    {
+        (void)hipFree(g.freeStage.origin);
+        g.freeStage.origin = nullptr;
+    }
+}
+
+/* host images of order-free lists that were built on the device: from where they are now */
+static void ensureHostFreeLists()
+{
+    if (g.freeHostValid || !ok())
+        return;
+    quiesce();
+    g.hostBoxesFree.resize(g.freeRows);
+    g.hostBoxStartFree.resize(g.freeRows / 2);
+    g.hostOriginFree.resize(g.freeRows / 2);
+    const bool staged = g.freeStage.rows != nullptr;
+    const char *arena = (const char *)g.geometry.ptr;
+    if (!staged && !arena)
+    {
+        setError(-1, "order-free lists neither staged nor in the arena", __FILE__, __LINE__);
+        return;
+    }
+    HIPCHECK(hipMemcpy(g.hostBoxesFree.data(), staged ? (const void *)g.freeStage.rows : arena + (size_t)g.offBoxesFree * 16, g.freeRows * 16,
+                       hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(g.hostBoxStartFree.data(), staged ? (const void *)g.freeStage.start : arena + (size_t)g.offBoxStartFree * 4,
+                       g.freeRows / 2 * 4, hipMemcpyDeviceToHost));
+    if (g.freeStage.origin)
+        HIPCHECK(hipMemcpy(g.hostOriginFree.data(), g.freeStage.origin, g.freeRows / 2 * 4, hipMemcpyDeviceToHost));
+    if (ok())
+    {
+        g.freeHostValid = true;
+        dropFreeStage(true); /* the next layout takes them from the host images */
+    }
+}
+
 /* the arena moved on (device-side rotations): bring the host images up to date before anything reads them */
 static void pullGeometry()
 {
@@ -1697,7 +1816,8 @@ static void pullGeometry()
     };
     get(g.offBoxes, g.hostBoxes.data(), g.hostBoxes.size() * 16);
     get(g.offBoxesCompact, g.hostBoxesCompact.data(), g.hostBoxesCompact.size() * 16);
-    get(g.offBoxesFree, g.hostBoxesFree.data(), g.hostBoxesFree.size() * 16);
+    if (g.freeHostValid)
+        get(g.offBoxesFree, g.hostBoxesFree.data(), g.hostBoxesFree.size() * 16);
     get(g.offPrims, g.hostPrims.data(), g.hostPrims.size() * 16);
     g.deviceAhead = false;
 }
@@ -1786,7 +1906,7 @@ void buildLeafRecords()
     if (nc > 0)
         hipLaunchKernelGGL(k_buildLeafRecords, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, g.stream, arena,
                            g.offBoxesCompact, g.offBoxStartCompact, g.offPrims, g.offLeafCompact, nc);
-    const int nf = (int)(g.hostBoxesFree.size() / 2);
+    const int nf = (int)(g.freeRows / 2);
     if (nf > 0 && !g.freeStale)
         hipLaunchKernelGGL(k_buildLeafRecords, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, arena,
                            g.offBoxesFree, g.offBoxStartFree, g.offPrims, g.offLeafFree, nf);
@@ -1800,6 +1920,8 @@ void flushGeometry()
     if (!g.geometryDirty)
         return;
     pullGeometry();
+    if (!g.freeStage.rows)
+        ensureHostFreeLists(); /* laid out again from the host images: the lists too, then */
     auto rowsOfInts = [](size_t n) { return (unsigned)((n + 3) / 4); };
     unsigned row = 0;
     /* each node list is followed by one pad record: the walk requests the record after the node it tests
@@ -1809,7 +1931,7 @@ void flushGeometry()
     g.offBoxesCompact = row;
     row += (unsigned)g.hostBoxesCompact.size() + 2u;
     g.offBoxesFree = row;
-    row += (unsigned)g.hostBoxesFree.size() + 2u;
+    row += (unsigned)g.freeRows + 2u;
     row = (row + 3u) & ~3u; /* primitive records start on a 64-byte line */
     g.offPrims = row;
     row += (unsigned)g.hostPrims.size();
@@ -1820,7 +1942,7 @@ void flushGeometry()
     const unsigned startRowCompact = row;
     row += rowsOfInts(g.hostBoxStartCompact.size());
     const unsigned startRowFree = row;
-    row += rowsOfInts(g.hostBoxStartFree.size());
+    row += rowsOfInts(g.freeRows / 2);
     g.offBoxStart = startRow * 4;
     g.offBoxStartCompact = startRowCompact * 4;
     g.offBoxStartFree = startRowFree * 4;
@@ -1830,7 +1952,7 @@ void flushGeometry()
     g.offLeafCompact = row;
     row += 2u * (unsigned)g.hostBoxesCompact.size() + 4u;
     g.offLeafFree = row;
-    row += 2u * (unsigned)g.hostBoxesFree.size() + 4u;
+    row += 2u * (unsigned)g.freeRows + 4u;
     PhaseTimer phase;
     /* the pieces go straight to their rows of the arena (a staged host copy of the whole arena, zero-filled first,
      * took 10-14 ms for 100 k primitives); pad records and the leaf-record area start as zeros */
@@ -1848,9 +1970,21 @@ void flushGeometry()
     put(g.offLights, g.hostLights.data(), g.hostLights.size() * 16);
     put(startRow, g.hostBoxStart.data(), g.hostBoxStart.size() * 4);
     put(startRowCompact, g.hostBoxStartCompact.data(), g.hostBoxStartCompact.size() * 4);
-    put(g.offBoxesFree, g.hostBoxesFree.data(), g.hostBoxesFree.size() * 16);
-    put(startRowFree, g.hostBoxStartFree.data(), g.hostBoxStartFree.size() * 4);
+    if (g.freeStage.rows && ok())
+    {
+        HIPCHECK(hipMemcpyAsync((char *)g.geometry.ptr + (size_t)g.offBoxesFree * 16, g.freeStage.rows, g.freeRows * 16,
+                                hipMemcpyDeviceToDevice, g.stream));
+        HIPCHECK(hipMemcpyAsync((char *)g.geometry.ptr + (size_t)startRowFree * 16, g.freeStage.start, g.freeRows / 2 * 4,
+                                hipMemcpyDeviceToDevice, g.stream));
+    }
+    else
+    {
+        put(g.offBoxesFree, g.hostBoxesFree.data(), g.hostBoxesFree.size() * 16);
+        put(startRowFree, g.hostBoxStartFree.data(), g.hostBoxStartFree.size() * 4);
+    }
     HIPCHECK(hipStreamSynchronize(g.stream)); /* pageable sources: complete for the caller when this returns */
+    if (ok())
+        dropFreeStage(false);
     phase.mark("geometry: upload");
     buildLeafRecords();
     phase.mark("geometry: leaf records");
@@ -1861,7 +1995,7 @@ void flushGeometry()
 /* the order-free lists exist for the resident scene and every condition of their use holds (rt_device.h closestHitWalk) */
 bool orderFreeListsUsable()
 {
-    return g.nbBoxesFree > 0 && g.hostBoxesFree.size() == 16 * (size_t)g.nbBoxesFree && g.primsContained && !g.freeStale &&
+    return g.nbBoxesFree > 0 && g.freeRows == 16 * (size_t)g.nbBoxesFree && g.primsContained && !g.freeStale &&
            g.nested && g.orderedCompact && g.variant != 6;
 }
 
@@ -2603,6 +2737,14 @@ void finalize_scene(vec2i)
     g.hostBoxStartCompact.clear();
     g.hostBoxesFree.clear();
     g.hostBoxStartFree.clear();
+    g.freeRows = 0;
+    g.freeHostValid = true;
+    dropFreeStage(true);
+    {
+        SolrScratchPool &pool = solrScratchPool(); /* the builders' scratch goes with the scene */
+        std::lock_guard<std::mutex> nobodyBuilding(pool.busy);
+        pool.release();
+    }
     g.hostOriginCompact.clear();
     g.nbBoxesFree = 0;
     g.freeCountdown = 0;
@@ -3101,7 +3243,31 @@ void maybeBuildOrderFreeLists()
         return;
     auto skipOf = [&](int i) { return std::max(bitsi(rows[2 * i + 1].w), 1); };
     bool encloses = true;
-    for (int i = 0; i < n && encloses; ++i)
+    /* with the arena laid out as the host images are (the usual case: the scene has been rendered once), the checks
+     * and the builder read the exact list and the primitive records there */
+    const bool fromArena = !g.geometryDirty && g.geometry.ptr != nullptr && !g.exactStale && !g.deviceAhead &&
+                           !getenv("SOLR_HIP_LISTS_ON_HOST") && !getenv("SOLR_HIP_LISTS_VIA_HOST") && !getenv("SOLR_HIP_FREE_WIDE");
+    const float4 *arena = (const float4 *)g.geometry.ptr;
+    if (fromArena)
+    {
+        HIPCHECK(hipSetDevice(g.device));
+        int *bad = nullptr, found = 1;
+        HIPCHECK(hipMalloc((void **)&bad, sizeof(int)));
+        if (ok())
+        {
+            HIPCHECK(hipMemsetAsync(bad, 0, sizeof(int), g.stream));
+            hipLaunchKernelGGL(k_listEncloses, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, arena, g.offBoxes, g.offBoxStart,
+                               g.offPrims, n, (int)(g.hostPrims.size() / PRIM_ROWS), bad);
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipMemcpyAsync(&found, bad, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+            HIPCHECK(hipStreamSynchronize(g.stream));
+            (void)hipFree(bad);
+        }
+        if (!ok())
+            return;
+        encloses = found == 0;
+    }
+    for (int i = 0; i < n && encloses && !fromArena; ++i)
     {
         const int end = std::min(i + skipOf(i), n);
         if (bitsi(rows[2 * i + 1].z) > 0 || end <= i + 1)
@@ -3112,7 +3278,7 @@ void maybeBuildOrderFreeLists()
                        rows[2 * j].w <= rows[2 * i].w;
     }
     const size_t nbPrims = g.hostPrims.size() / PRIM_ROWS;
-    for (int i = 0; i < n && encloses; ++i)
+    for (int i = 0; i < n && encloses && !fromArena; ++i)
     {
         const int count = bitsi(rows[2 * i + 1].z);
         for (int k = 0; k < count && encloses; ++k)
@@ -3162,9 +3328,13 @@ void maybeBuildOrderFreeLists()
         return;
     }
     phase.mark("order-free: checks");
-    std::vector<int> origin(n);
-    for (int i = 0; i < n; ++i)
-        origin[i] = i;
+    std::vector<int> origin;
+    if (!fromArena)
+    {
+        origin.resize(n);
+        for (int i = 0; i < n; ++i)
+            origin[i] = i;
+    }
     std::vector<float4> boxesF;
     std::vector<int> startF, originF;
     int prunedFree = 0;
@@ -3177,11 +3347,27 @@ void maybeBuildOrderFreeLists()
         HIPCHECK(hipSetDevice(g.device));
         const double threshold = getenv("SOLR_HIP_PRUNE") ? atof(getenv("SOLR_HIP_PRUNE")) : 1.0;
         if (ok() && threshold > 0.0)
-            count = solrBuildOrderFreeListsOnDevice(rows.data(), start.data(), origin.data(), n, threshold, boxesF, startF, originF,
-                                                    &prunedFree, g.stream);
+        {
+            dropFreeStage(true);
+            if (fromArena)
+                count = solrBuildOrderFreeListsOnDevice(arena + g.offBoxes, (const int *)arena + g.offBoxStart, nullptr, n, threshold, boxesF,
+                                                        startF, originF, &prunedFree, g.stream, &g.freeStage);
+            else
+                count = solrBuildOrderFreeListsOnDevice(rows.data(), start.data(), origin.data(), n, threshold, boxesF, startF, originF,
+                                                        &prunedFree, g.stream, getenv("SOLR_HIP_LISTS_VIA_HOST") ? nullptr : &g.freeStage);
+        }
     }
+    const bool stayed = count > 0 && g.freeStage.rows != nullptr;
     if (count < 0)
+    {
+        if (origin.empty())
+        {
+            origin.resize(n);
+            for (int i = 0; i < n; ++i)
+                origin[i] = i;
+        }
         count = buildFreeOrderLists(rows, start, origin, boxesF, startF, originF, &prunedFree);
+    }
     if (getenv("SOLR_HIP_DEBUG_TREE"))
         fprintf(stderr, "solr_hip: order-free lists: 8 x %d nodes (%d inner nodes that hardly cull left out)\n", count, prunedFree);
     if (count <= 0)
@@ -3190,6 +3376,8 @@ void maybeBuildOrderFreeLists()
     g.hostBoxesFree.swap(boxesF);
     g.hostBoxStartFree.swap(startF);
     g.nbBoxesFree = count;
+    g.freeRows = 16 * (size_t)count;
+    g.freeHostValid = !stayed;
     g.freeStale = false;
     g.hostOriginFree.swap(originF);
     g.refitReady = false;
@@ -3547,6 +3735,9 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     g.hostOriginCompact = originC;
     g.hostBoxesFree.swap(boxesF);
     g.hostBoxStartFree.swap(startF);
+    g.freeRows = 0;
+    g.freeHostValid = true;
+    dropFreeStage(true);
     g.nbBoxesFree = nbFreeNodes;
     g.freeStale = false;
     g.hostPrims.swap(prims);
@@ -3599,6 +3790,7 @@ int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], 
     {
         /* which nodes to refit, in which order: made for the first rotation after the lists changed */
         g.refitPlanPending = false;
+        ensureHostFreeLists();
         buildRefitPlan(g.hostBoxes, g.hostBoxesCompact, g.hostOriginCompact, g.hostBoxesFree, g.hostOriginFree);
     }
     /* the seeds of the two box updates only commute with the unions while viewDistance <= 1e6, and a
@@ -3660,7 +3852,7 @@ int solr_hip_read_nodes(int exact, float *rows, int capacityRows)
     unsigned at = exact ? g.offBoxes : g.offBoxesCompact;
     if (exact >= 2) /* 2 ... 9: the order-free list of octant exact - 2 (0 rows when there are none) */
     {
-        const bool have = exact <= 9 && g.nbBoxesFree > 0 && !g.freeStale && g.hostBoxesFree.size() == 16 * (size_t)g.nbBoxesFree;
+        const bool have = exact <= 9 && g.nbBoxesFree > 0 && !g.freeStale && g.freeRows == 16 * (size_t)g.nbBoxesFree;
         n = have ? 2 * g.nbBoxesFree : 0;
         at = g.offBoxesFree + 2u * (unsigned)((exact - 2) * g.nbBoxesFree);
     }

@@ -35,10 +35,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <chrono>
 
+#include "device_pool.h"
 #include "lists_device.h"
 
 namespace
@@ -88,14 +90,25 @@ struct Dev
 {
     T *p = nullptr;
     size_t n = 0;
+    bool own = false;
+    /* scratch of this build: from the pool (device_pool.h) while it lasts */
     bool alloc(size_t count)
     {
         n = count;
+        const size_t bytes = std::max(count, (size_t)1) * sizeof(T);
+        p = (T *)solrScratchPool().take(bytes);
+        return p != nullptr || allocOwn(count);
+    }
+    /* memory that may outlive the build */
+    bool allocOwn(size_t count)
+    {
+        n = count;
+        own = true;
         return hipMalloc((void **)&p, std::max(count, (size_t)1) * sizeof(T)) == hipSuccess;
     }
     ~Dev()
     {
-        if (p)
+        if (p && own)
             (void)hipFree(p);
     }
 };
@@ -574,6 +587,31 @@ __global__ void k_iota(int *a, int n, int value, bool counting)
         a[i] = counting ? i : value;
 }
 
+/* the leaves of a node list that is on the device already: which nodes, then their rows in list order */
+__global__ void k_leafFlags(const float4 *rows, int n, int *flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n)
+        flags[i] = i < n && __float_as_int(rows[2 * i + 1].z) > 0 ? 1 : 0;
+}
+__global__ void k_leafGather(const float4 *rows, const int *start, const int *before, int n, float *lo, float *hi, float4 *leafRows,
+                             int *leafStart, int *leafOrigin)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4 a = rows[2 * i], b = rows[2 * i + 1];
+    if (__float_as_int(b.z) <= 0)
+        return;
+    const int l = before[i];
+    lo[3 * l] = a.x, lo[3 * l + 1] = a.y, lo[3 * l + 2] = a.z;
+    hi[3 * l] = b.x, hi[3 * l + 1] = b.y, hi[3 * l + 2] = a.w;
+    leafRows[2 * l] = a;
+    leafRows[2 * l + 1] = b;
+    leafStart[l] = start[i];
+    leafOrigin[l] = i;
+}
+
 inline dim3 blocksFor(size_t n, int block = 256)
 {
     return dim3((unsigned)((n + block - 1) / block));
@@ -582,28 +620,68 @@ inline dim3 blocksFor(size_t n, int block = 256)
 
 int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const int *origin, int n, double threshold,
                                     std::vector<float4> &outRows, std::vector<int> &outStart, std::vector<int> &outOrigin,
-                                    int *nbPruned, hipStream_t stream)
+                                    int *nbPruned, hipStream_t stream, SolrDeviceLists *stay)
 {
     *nbPruned = 0;
     Phase phase;
+    /* scratch: per node of the source list two ints and the scan's; per leaf (a quarter of the nodes in the grid
+     * builder's trees; what a scene with more asks for beyond the pool it gets from hipMalloc) the rows, bounds and
+     * bookkeeping, two tree nodes and a set of bins */
+    SolrScratchPool &pool = solrScratchPool();
+    std::lock_guard<std::mutex> oneBuild(pool.busy);
+    struct Scope
+    {
+        SolrScratchPool &pool;
+        ~Scope() { pool.end(); }
+    } scope{pool};
+    pool.begin((size_t)n * 12 + (size_t)n / 4 * (160 + 2 * sizeof(Node) + sizeof(BinSet) + 64 * sizeof(int)) + ((size_t)4 << 20));
+#define LISTS_CHECK(call)                                                                                              \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if ((call) != hipSuccess)                                                                                      \
+        {                                                                                                              \
+            fprintf(stderr, "solr_lists: %s failed\n", #call);                                                         \
+            return -1;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
     /* the leaves: every node with primitives */
     std::vector<float> llo, lhi;
     std::vector<float4> leafRows;
     std::vector<int> leafStart, leafOrigin;
-    for (int i = 0; i < n; ++i)
+    Dev<int> dLeafFlags, dLeafBefore;
+    Dev<char> dLeafTemp;
+    int L = 0;
+    if (origin == nullptr)
     {
-        int count;
-        memcpy(&count, &rows[2 * i + 1].z, 4);
-        if (count <= 0)
-            continue;
-        llo.insert(llo.end(), {rows[2 * i].x, rows[2 * i].y, rows[2 * i].z});
-        lhi.insert(lhi.end(), {rows[2 * i + 1].x, rows[2 * i + 1].y, rows[2 * i].w});
-        leafRows.push_back(rows[2 * i]);
-        leafRows.push_back(rows[2 * i + 1]);
-        leafStart.push_back(start[i]);
-        leafOrigin.push_back(origin[i]);
+        /* rows and start are the arena's (device memory), every node its own origin */
+        size_t bytes = 0;
+        if (!dLeafFlags.alloc((size_t)n + 1) || !dLeafBefore.alloc((size_t)n + 1))
+            return -1;
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, dLeafFlags.p, dLeafBefore.p, n + 1, stream);
+        if (!dLeafTemp.alloc(bytes + 256))
+            return -1;
+        hipLaunchKernelGGL(k_leafFlags, blocksFor((size_t)n + 1), dim3(256), 0, stream, rows, n, dLeafFlags.p);
+        LISTS_CHECK(hipcub::DeviceScan::ExclusiveSum(dLeafTemp.p, bytes, dLeafFlags.p, dLeafBefore.p, n + 1, stream));
+        LISTS_CHECK(hipMemcpyAsync(&L, dLeafBefore.p + n, 4, hipMemcpyDeviceToHost, stream));
+        LISTS_CHECK(hipStreamSynchronize(stream));
     }
-    const int L = (int)leafStart.size();
+    else
+    {
+        for (int i = 0; i < n; ++i)
+        {
+            int count;
+            memcpy(&count, &rows[2 * i + 1].z, 4);
+            if (count <= 0)
+                continue;
+            llo.insert(llo.end(), {rows[2 * i].x, rows[2 * i].y, rows[2 * i].z});
+            lhi.insert(lhi.end(), {rows[2 * i + 1].x, rows[2 * i + 1].y, rows[2 * i].w});
+            leafRows.push_back(rows[2 * i]);
+            leafRows.push_back(rows[2 * i + 1]);
+            leafStart.push_back(start[i]);
+            leafOrigin.push_back(origin[i]);
+        }
+        L = (int)leafStart.size();
+    }
     if (L < 2)
         return -1;
     phase.mark("leaves gathered", L);
@@ -623,21 +701,18 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tempBytes, dFlags.p, dBefore.p, L + 1, stream);
     if (!dTemp.alloc(tempBytes + 256))
         return -1;
-#define LISTS_CHECK(call)                                                                                              \
-    do                                                                                                                 \
-    {                                                                                                                  \
-        if ((call) != hipSuccess)                                                                                      \
-        {                                                                                                              \
-            fprintf(stderr, "solr_lists: %s failed\n", #call);                                                         \
-            return -1;                                                                                                 \
-        }                                                                                                              \
-    } while (0)
     phase.mark("allocations");
-    LISTS_CHECK(hipMemcpyAsync(dLo.p, llo.data(), llo.size() * 4, hipMemcpyHostToDevice, stream));
-    LISTS_CHECK(hipMemcpyAsync(dHi.p, lhi.data(), lhi.size() * 4, hipMemcpyHostToDevice, stream));
-    LISTS_CHECK(hipMemcpyAsync(dLeafRows.p, leafRows.data(), leafRows.size() * 16, hipMemcpyHostToDevice, stream));
-    LISTS_CHECK(hipMemcpyAsync(dLeafStart.p, leafStart.data(), (size_t)L * 4, hipMemcpyHostToDevice, stream));
-    LISTS_CHECK(hipMemcpyAsync(dLeafOrigin.p, leafOrigin.data(), (size_t)L * 4, hipMemcpyHostToDevice, stream));
+    if (origin == nullptr)
+        hipLaunchKernelGGL(k_leafGather, blocksFor(n), dim3(256), 0, stream, rows, start, dLeafBefore.p, n, dLo.p, dHi.p, dLeafRows.p,
+                           dLeafStart.p, dLeafOrigin.p);
+    else
+    {
+        LISTS_CHECK(hipMemcpyAsync(dLo.p, llo.data(), llo.size() * 4, hipMemcpyHostToDevice, stream));
+        LISTS_CHECK(hipMemcpyAsync(dHi.p, lhi.data(), lhi.size() * 4, hipMemcpyHostToDevice, stream));
+        LISTS_CHECK(hipMemcpyAsync(dLeafRows.p, leafRows.data(), leafRows.size() * 16, hipMemcpyHostToDevice, stream));
+        LISTS_CHECK(hipMemcpyAsync(dLeafStart.p, leafStart.data(), (size_t)L * 4, hipMemcpyHostToDevice, stream));
+        LISTS_CHECK(hipMemcpyAsync(dLeafOrigin.p, leafOrigin.data(), (size_t)L * 4, hipMemcpyHostToDevice, stream));
+    }
     LISTS_CHECK(hipMemsetAsync(dPruned.p, 0, 4, stream));
     hipLaunchKernelGGL(k_iota, blocksFor(L), dim3(256), 0, stream, dOrder[0].p, L, 0, true);
     hipLaunchKernelGGL(k_iota, blocksFor(L), dim3(256), 0, stream, dNodeOf[0].p, L, 0, false);
@@ -699,11 +774,21 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
     phase.mark("pruning, sizes, places", listLength);
     if (listLength < 2)
         return -1;
-    if (!dOutRows.alloc(16 * (size_t)listLength) || !dOutStart.alloc(8 * (size_t)listLength) || !dOutOrigin.alloc(8 * (size_t)listLength))
+    if (stay ? !dOutRows.allocOwn(16 * (size_t)listLength) || !dOutStart.allocOwn(8 * (size_t)listLength) ||
+                   !dOutOrigin.allocOwn(8 * (size_t)listLength)
+             : !dOutRows.alloc(16 * (size_t)listLength) || !dOutStart.alloc(8 * (size_t)listLength) || !dOutOrigin.alloc(8 * (size_t)listLength))
         return -1;
     hipLaunchKernelGGL(k_emit, blocksFor((size_t)nbNodes * 8), dim3(256), 0, stream, dNodes.p, dPlace.p, dLeafRows.p, dLeafStart.p, dLeafOrigin.p,
                        dOutRows.p, dOutStart.p, dOutOrigin.p, nbNodes, listLength);
     LISTS_CHECK(hipGetLastError());
+    if (stay)
+    {
+        LISTS_CHECK(hipStreamSynchronize(stream));
+        stay->rows = dOutRows.p, stay->start = dOutStart.p, stay->origin = dOutOrigin.p;
+        dOutRows.p = nullptr, dOutStart.p = nullptr, dOutOrigin.p = nullptr;
+        phase.mark("lists written");
+        return listLength;
+    }
     outRows.resize(16 * (size_t)listLength);
     outStart.resize(8 * (size_t)listLength);
     outOrigin.resize(8 * (size_t)listLength);
@@ -811,6 +896,14 @@ int solrPruneDecisionsOnDevice(const float4 *rows, int n, double threshold, std:
     if (n < 2)
         return -1;
     Phase phase;
+    SolrScratchPool &pool = solrScratchPool();
+    std::lock_guard<std::mutex> oneBuild(pool.busy);
+    struct Scope
+    {
+        SolrScratchPool &pool;
+        ~Scope() { pool.end(); }
+    } scope{pool};
+    pool.begin((size_t)n * 80 + ((size_t)1 << 20));
     /* parents, depths, the leaves in list order, the scene's extent: one pass */
     std::vector<int> parent(n, -1), depth(n, 0), leaves, leavesBefore((size_t)n + 1, 0), stack;
     int deepest = 0;

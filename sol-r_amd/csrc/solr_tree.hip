@@ -28,9 +28,11 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/solr_hip.h"
+#include "device_pool.h"
 
 namespace
 {
@@ -55,27 +57,36 @@ struct f3
 
 char message[256] = "";
 
+/* arrays of one build: from the scratch pool (device_pool.h) while it lasts */
 template <class T>
 struct Buffer
 {
     T *ptr = nullptr;
     size_t count = 0;
+    bool own = false;
     bool reserve(size_t n)
     {
         if (n <= count && ptr)
             return true;
-        if (ptr)
+        if (ptr && own)
             (void)hipFree(ptr);
         ptr = nullptr;
         count = 0;
-        if (hipMalloc((void **)&ptr, (n ? n : 1) * sizeof(T)) != hipSuccess)
-            return false;
+        own = false;
+        const size_t bytes = (n ? n : 1) * sizeof(T);
+        ptr = (T *)solrScratchPool().take(bytes);
+        if (!ptr)
+        {
+            if (hipMalloc((void **)&ptr, bytes) != hipSuccess)
+                return false;
+            own = true;
+        }
         count = n ? n : 1;
         return true;
     }
     ~Buffer()
     {
-        if (ptr)
+        if (ptr && own)
             (void)hipFree(ptr);
     }
 };
@@ -391,6 +402,12 @@ bool exclusiveScan(Buffer<unsigned char> &temp, const int *in, int *out, int n, 
 }
 } // namespace
 
+SolrScratchPool &solrScratchPool()
+{
+    static SolrScratchPool pool;
+    return pool;
+}
+
 extern "C" const char *solr_hip_build_tree_message(void)
 {
     return message;
@@ -605,7 +622,14 @@ extern "C" int solr_hip_build_tree(const Primitive *primitives, const unsigned c
     };
     *nbLampsOut = 0;
     *nbBoxesOut = 0;
-    if (!body())
+    /* the primitive records, five arrays per primitive, eleven per box of a level (the levels shrink by four or so
+     * each), the sorter's: what a first build asks for; later ones know (device_pool.h) */
+    SolrScratchPool &pool = solrScratchPool();
+    std::lock_guard<std::mutex> oneBuild(pool.busy);
+    pool.begin((size_t)n * (sizeof(Primitive) + 160 + sizeof(BoundingBox) * 4) + ((size_t)8 << 20));
+    const bool built = body();
+    pool.end();
+    if (!built)
     {
         if (!message[0])
             snprintf(message, sizeof(message), "solr_hip_build_tree: device allocation or launch failed");

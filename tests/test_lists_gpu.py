@@ -75,3 +75,59 @@ def test_device_lists_are_the_hosts(solr, scene, kw):
             bad = np.argwhere((a != b).any(axis=(1, 2)))[:5].ravel()
             raise AssertionError("list %d (8 = the walk-order list): nodes %s differ, e.g. device %s host %s" % (o, bad, dev[o][bad[0]], host[o][bad[0]]))
     assert np.array_equal(image_dev, image_host)
+
+
+def _sequence(solr, build, kw, after):
+    """upload, `after` frames until the lists are built, the lists; a material more (the arena is laid out again),
+    the lists; a rotation (the refit plan wants the host images of the lists), a frame"""
+    saved = os.environ.get("SOLR_HIP_FREE_AFTER")
+    os.environ["SOLR_HIP_FREE_AFTER"] = str(after)
+    try:
+        k = solr.Kernel(engine="hip")
+        build(k, **kw)
+        for _ in range(after + 1):
+            k.render()
+        k.check(0, "frames")
+        n = solr.hip_lib().solr_hip_order_free_nodes()
+        first = [k.device_nodes(order_free=o).copy() for o in range(8)]
+        k.add_material(0.1, 0.9, 0.2, specValue=0.5, specPower=10.0)
+        k.render()
+        second = [k.device_nodes(order_free=o).copy() for o in range(8)]
+        k.rotate_primitives((0.0, 0.0, 0.0), (0.05, 0.1, 0.0))
+        image = k.render().copy()
+        k.check(0, "rotated frame")
+        third = [k.device_nodes(order_free=o).copy() for o in range(8)]
+        k.finalize()
+        return n, first, second, third, image
+    finally:
+        if saved is None:
+            os.environ.pop("SOLR_HIP_FREE_AFTER", None)
+        else:
+            os.environ["SOLR_HIP_FREE_AFTER"] = saved
+
+
+@pytest.mark.parametrize("scene,kw", [("cornell", dict(width=160, height=120, iterations=2)),
+                                      ("molecule", dict(atoms=3000, width=160, height=120)),
+                                      ("height_field", dict(n=64, width=160, height=120))],
+                         ids=["cornell", "small-molecule", "small-mesh"])
+@pytest.mark.parametrize("after", [1, 2], ids=["from-host-rows", "from-the-arena"])
+def test_lists_that_stay_on_the_device(solr, scene, kw, after):
+    """The device builder leaves its lists on the device (a device-to-device copy into the arena) and, once the scene
+    has been rendered, reads the exact list from the arena too: the same lists as the host's, through a second layout
+    of the arena (host images fetched from the arena) and a rotation on the device (refit plan from them)."""
+    global k_solr
+    k_solr = solr
+    build = getattr(solr.scenes, scene)
+    for name in ("SOLR_HIP_LISTS_ON_HOST", "SOLR_HIP_LISTS_VIA_HOST"):
+        os.environ.pop(name, None)
+    n_dev, first, second, third, image = _sequence(solr, build, kw, after)
+    os.environ["SOLR_HIP_LISTS_ON_HOST"] = "1"
+    try:
+        n_host, first_h, second_h, third_h, image_h = _sequence(solr, build, kw, after)
+    finally:
+        os.environ.pop("SOLR_HIP_LISTS_ON_HOST", None)
+    assert n_dev == n_host and n_dev > 0
+    for name, a, b in (("as built", first, first_h), ("laid out again", second, second_h), ("rotated", third, third_h)):
+        for o in range(8):
+            assert np.array_equal(a[o].view(np.int32), b[o].view(np.int32)), (name, o)
+    assert np.array_equal(image, image_h)
