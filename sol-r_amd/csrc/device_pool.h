@@ -62,3 +62,10 @@ struct SolrScratchPool
 
 /* the library's one pool (solr_tree.hip) */
 SolrScratchPool &solrScratchPool();
+
+/* Host side of the same story: the host images of a 100k-primitive scene are a dozen vectors of 1-13 MB that live for
+ * one upload.  glibc serves such sizes with mmap and gives them back with munmap, so every upload touches ~100 MB of
+ * fresh pages - 8 of 41 ms for the molecule scene on the measured box (page faults of a virtual machine are dear).
+ * Called once per process by the first engine entry point: large blocks come from the heap and stay in it when freed
+ * (up to 512 MB are kept).  SOLR_HIP_MALLOC_DEFAULTS=1 leaves the allocator alone. */
+void solrTuneHostAllocator();

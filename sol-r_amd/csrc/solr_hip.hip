@@ -1324,6 +1324,8 @@ struct Engine
      * arena when somebody needs them (ensureHostFreeLists: the refit plan of a rotated scene, a second layout) */
     size_t freeRows = 0;
     bool freeHostValid = true;
+    bool freeDirty = false;  /* the staged lists are to be added to an arena that is otherwise up to date */
+    unsigned rowsFixed = 0;  /* rows of the arena in front of the order-free lists */
     SolrDeviceLists freeStage;
     unsigned offBoxesFree = 0, offBoxStartFree = 0, offLeafFree = 0;
     int nbBoxesFree = 0;        /* nodes per list; there are eight, one per direction octant */
@@ -1914,11 +1916,67 @@ void buildLeafRecords()
     HIPCHECK(hipStreamSynchronize(g.stream));
 }
 
+/* where the order-free lists go: behind everything else, so that they can be added to an arena that is laid out */
+static unsigned layoutFreeLists(unsigned row)
+{
+    g.offBoxesFree = row;
+    row += (unsigned)g.freeRows + 2u; /* (one pad record, as behind every node list) */
+    g.offBoxStartFree = row * 4;
+    row += (unsigned)((g.freeRows / 2 + 3) / 4);
+    row = (row + 3u) & ~3u; /* leaf records: one 64-byte line per node */
+    g.offLeafFree = row;
+    row += 2u * (unsigned)g.freeRows + 4u;
+    return row;
+}
+
+/* the lists the device builder has just left (g.freeStage) into an arena that holds everything else already: what
+ * is there stays where it is (moved to a larger allocation when this one is too small), nothing is uploaded again */
+static void appendFreeLists()
+{
+    const unsigned end = layoutFreeLists(g.rowsFixed);
+    const size_t bytes = (size_t)end * 16, fixedBytes = (size_t)g.rowsFixed * 16;
+    PhaseTimer phase;
+    if (g.geometry.bytes < bytes)
+    {
+        DeviceBuffer larger;
+        reserve(larger, bytes);
+        if (!ok())
+            return;
+        HIPCHECK(hipMemcpyAsync(larger.ptr, g.geometry.ptr, fixedBytes, hipMemcpyDeviceToDevice, g.stream));
+        HIPCHECK(hipStreamSynchronize(g.stream));
+        release(g.geometry);
+        g.geometry = larger;
+    }
+    char *arena = (char *)g.geometry.ptr;
+    HIPCHECK(hipMemsetAsync(arena + fixedBytes, 0, bytes - fixedBytes, g.stream));
+    HIPCHECK(hipMemcpyAsync(arena + (size_t)g.offBoxesFree * 16, g.freeStage.rows, g.freeRows * 16, hipMemcpyDeviceToDevice, g.stream));
+    HIPCHECK(hipMemcpyAsync(arena + (size_t)g.offBoxStartFree * 4, g.freeStage.start, g.freeRows / 2 * 4, hipMemcpyDeviceToDevice, g.stream));
+    const int nf = (int)(g.freeRows / 2);
+    if (ok() && nf > 0)
+        hipLaunchKernelGGL(k_buildLeafRecords, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, (float4 *)g.geometry.ptr,
+                           g.offBoxesFree, g.offBoxStartFree, g.offPrims, g.offLeafFree, nf);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(g.stream));
+    phase.mark("geometry: lists appended");
+    if (ok())
+    {
+        dropFreeStage(false);
+        g.freeDirty = false;
+    }
+}
+
 /* assemble and upload the geometry arena from its host images (scene_layout.h) */
 void flushGeometry()
 {
     if (!g.geometryDirty)
-        return;
+    {
+        if (g.freeDirty && g.freeStage.rows && g.geometry.ptr && g.rowsFixed > 0)
+            appendFreeLists();
+        else if (g.freeDirty)
+            g.geometryDirty = true; /* (not the case this shortcut is for: everything again) */
+        if (!g.geometryDirty)
+            return;
+    }
     pullGeometry();
     if (!g.freeStage.rows)
         ensureHostFreeLists(); /* laid out again from the host images: the lists too, then */
@@ -1930,8 +1988,6 @@ void flushGeometry()
     row += (unsigned)g.hostBoxes.size() + 2u;
     g.offBoxesCompact = row;
     row += (unsigned)g.hostBoxesCompact.size() + 2u;
-    g.offBoxesFree = row;
-    row += (unsigned)g.freeRows + 2u;
     row = (row + 3u) & ~3u; /* primitive records start on a 64-byte line */
     g.offPrims = row;
     row += (unsigned)g.hostPrims.size();
@@ -1941,18 +1997,15 @@ void flushGeometry()
     row += rowsOfInts(g.hostBoxStart.size());
     const unsigned startRowCompact = row;
     row += rowsOfInts(g.hostBoxStartCompact.size());
-    const unsigned startRowFree = row;
-    row += rowsOfInts(g.freeRows / 2);
     g.offBoxStart = startRow * 4;
     g.offBoxStartCompact = startRowCompact * 4;
-    g.offBoxStartFree = startRowFree * 4;
     row = (row + 3u) & ~3u; /* leaf records: one 64-byte line per node */
     g.offLeaf = row;
     row += 2u * (unsigned)g.hostBoxes.size() + 4u;
     g.offLeafCompact = row;
     row += 2u * (unsigned)g.hostBoxesCompact.size() + 4u;
-    g.offLeafFree = row;
-    row += 2u * (unsigned)g.freeRows + 4u;
+    g.rowsFixed = row;
+    row = layoutFreeLists(row);
     PhaseTimer phase;
     /* the pieces go straight to their rows of the arena (a staged host copy of the whole arena, zero-filled first,
      * took 10-14 ms for 100 k primitives); pad records and the leaf-record area start as zeros */
@@ -1974,13 +2027,13 @@ void flushGeometry()
     {
         HIPCHECK(hipMemcpyAsync((char *)g.geometry.ptr + (size_t)g.offBoxesFree * 16, g.freeStage.rows, g.freeRows * 16,
                                 hipMemcpyDeviceToDevice, g.stream));
-        HIPCHECK(hipMemcpyAsync((char *)g.geometry.ptr + (size_t)startRowFree * 16, g.freeStage.start, g.freeRows / 2 * 4,
+        HIPCHECK(hipMemcpyAsync((char *)g.geometry.ptr + (size_t)g.offBoxStartFree * 4, g.freeStage.start, g.freeRows / 2 * 4,
                                 hipMemcpyDeviceToDevice, g.stream));
     }
     else
     {
         put(g.offBoxesFree, g.hostBoxesFree.data(), g.hostBoxesFree.size() * 16);
-        put(startRowFree, g.hostBoxStartFree.data(), g.hostBoxStartFree.size() * 4);
+        put(g.offBoxStartFree / 4, g.hostBoxStartFree.data(), g.hostBoxStartFree.size() * 4);
     }
     HIPCHECK(hipStreamSynchronize(g.stream)); /* pageable sources: complete for the caller when this returns */
     if (ok())
@@ -1989,7 +2042,10 @@ void flushGeometry()
     buildLeafRecords();
     phase.mark("geometry: leaf records");
     if (ok())
+    {
         g.geometryDirty = false;
+        g.freeDirty = false;
+    }
 }
 
 /* the order-free lists exist for the resident scene and every condition of their use holds (rt_device.h closestHitWalk) */
@@ -2630,6 +2686,7 @@ void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, 
     if (!ok())
         return;
     (void)occupancyParameters;
+    solrTuneHostAllocator();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -2739,6 +2796,7 @@ void finalize_scene(vec2i)
     g.hostBoxStartFree.clear();
     g.freeRows = 0;
     g.freeHostValid = true;
+    g.freeDirty = false;
     dropFreeStage(true);
     {
         SolrScratchPool &pool = solrScratchPool(); /* the builders' scratch goes with the scene */
@@ -3382,7 +3440,12 @@ void maybeBuildOrderFreeLists()
     g.hostOriginFree.swap(originF);
     g.refitReady = false;
     g.refitPlanPending = true; /* 8-12 ms for 100 k primitives: only scenes that are rotated on the device pay them */
-    g.geometryDirty = true; /* the arena is laid out and uploaded again with the lists in it */
+    /* the lists join the arena: added behind what it holds when they are on the device and it is up to date, else
+     * laid out and uploaded again */
+    if (stayed && fromArena)
+        g.freeDirty = true;
+    else
+        g.geometryDirty = true;
 }
 } // namespace
 
@@ -3737,6 +3800,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
     g.hostBoxStartFree.swap(startF);
     g.freeRows = 0;
     g.freeHostValid = true;
+    g.freeDirty = false;
     dropFreeStage(true);
     g.nbBoxesFree = nbFreeNodes;
     g.freeStale = false;

@@ -26,7 +26,11 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <malloc.h>
+
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -56,6 +60,22 @@ struct f3
     } while (0)
 
 char message[256] = "";
+
+/* SOLR_HIP_DEBUG_TIMING: where a build spends its time (the marks wait for the stream) */
+struct TreePhase
+{
+    const bool on = getenv("SOLR_HIP_DEBUG_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char *what, hipStream_t stream)
+    {
+        if (!on)
+            return;
+        (void)hipStreamSynchronize(stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "solr_tree: %-27s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
 
 /* arrays of one build: from the scratch pool (device_pool.h) while it lasts */
 template <class T>
@@ -402,6 +422,18 @@ bool exclusiveScan(Buffer<unsigned char> &temp, const int *in, int *out, int n, 
 }
 } // namespace
 
+void solrTuneHostAllocator()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("SOLR_HIP_MALLOC_DEFAULTS"))
+            return;
+        (void)mallopt(M_MMAP_THRESHOLD, 256 << 20);
+        (void)mallopt(M_TRIM_THRESHOLD, 512 << 20);
+        (void)mallopt(M_TOP_PAD, 64 << 20);
+    });
+}
+
 SolrScratchPool &solrScratchPool()
 {
     static SolrScratchPool pool;
@@ -420,6 +452,7 @@ extern "C" int solr_hip_build_tree(const Primitive *primitives, const unsigned c
                                    int boxCapacity, int *order, int *nbBoxesOut, int *nbLampsOut)
 {
     message[0] = 0;
+    solrTuneHostAllocator();
     if (!primitives || !emissive || nbPrimitives <= 0 || !minPos || !maxPos || !boxes || !order || !nbBoxesOut || !nbLampsOut)
     {
         snprintf(message, sizeof(message), "solr_hip_build_tree: bad arguments");
@@ -477,6 +510,7 @@ extern "C" int solr_hip_build_tree(const Primitive *primitives, const unsigned c
     const f3 mn = {minPos[0], minPos[1], minPos[2]};
 
     auto body = [&]() -> bool {
+        TreePhase phase;
         Buffer<Primitive> dPrims;
         Buffer<unsigned char> dEmissive, temp;
         Buffer<unsigned> key;
@@ -492,6 +526,7 @@ extern "C" int solr_hip_build_tree(const Primitive *primitives, const unsigned c
         }
         TREE_CHECK(hipMemcpyAsync(dPrims.ptr, primitives, (size_t)n * sizeof(Primitive), hipMemcpyHostToDevice, stream));
         TREE_CHECK(hipMemcpyAsync(dEmissive.ptr, emissive, (size_t)n, hipMemcpyHostToDevice, stream));
+        phase.mark("primitives uploaded", stream);
 
         /* lamps, in index order */
         hipLaunchKernelGGL(k_lampFlags, blocks(n), dim3(256), 0, stream, (const unsigned char *)dEmissive.ptr, n, lampFlag.ptr);
@@ -532,6 +567,7 @@ extern "C" int solr_hip_build_tree(const Primitive *primitives, const unsigned c
                                L.lo.ptr, L.hi.ptr, L.centre.ptr, L.count.ptr);
             hipLaunchKernelGGL(k_leafSizes, blocks(nb), dim3(256), 0, stream, (const int *)L.count.ptr, nb, L.nodes.ptr, L.prims.ptr);
         }
+        phase.mark("lamps, level 0", stream);
         /* outer levels */
         for (int d = 1; d <= depth; ++d)
         {
@@ -556,6 +592,7 @@ extern "C" int solr_hip_build_tree(const Primitive *primitives, const unsigned c
                                viewDistance, (const f3 *)B.lo.ptr, (const f3 *)B.hi.ptr, (const int *)B.nodes.ptr,
                                (const int *)B.prims.ptr, L.lo.ptr, L.hi.ptr, L.centre.ptr, L.nodes.ptr, L.prims.ptr);
         }
+        phase.mark("outer levels", stream);
         /* the cases left to the host */
         Level &T = level[depth];
         unsigned firstKey = 1;
@@ -608,9 +645,11 @@ extern "C" int solr_hip_build_tree(const Primitive *primitives, const unsigned c
                                dBoxes.ptr, dOrder.ptr);
         }
         TREE_CHECK(hipGetLastError());
+        phase.mark("positions, nodes emitted", stream);
         TREE_CHECK(hipMemcpyAsync(boxes, dBoxes.ptr, (size_t)totalNodes * sizeof(BoundingBox), hipMemcpyDeviceToHost, stream));
         TREE_CHECK(hipMemcpyAsync(order, dOrder.ptr, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
         TREE_CHECK(hipStreamSynchronize(stream));
+        phase.mark("nodes and order copied back", stream);
         /* node 0: the lamp box (GPUKernel.cpp:1181-1190) */
         memset(&boxes[0], 0, sizeof(BoundingBox));
         boxes[0].parameters[0].x = boxes[0].parameters[0].y = boxes[0].parameters[0].z = -viewDistance;
@@ -626,7 +665,11 @@ extern "C" int solr_hip_build_tree(const Primitive *primitives, const unsigned c
      * each), the sorter's: what a first build asks for; later ones know (device_pool.h) */
     SolrScratchPool &pool = solrScratchPool();
     std::lock_guard<std::mutex> oneBuild(pool.busy);
-    pool.begin((size_t)n * (sizeof(Primitive) + 160 + sizeof(BoundingBox) * 4) + ((size_t)8 << 20));
+    {
+        TreePhase phase;
+        pool.begin((size_t)n * (sizeof(Primitive) + 160 + sizeof(BoundingBox) * 4) + ((size_t)8 << 20));
+        phase.mark("scratch pool", stream);
+    }
     const bool built = body();
     pool.end();
     if (!built)

@@ -682,9 +682,12 @@ bool GPUKernel::buildTreeOnDevice()
         return false;
     /* the builder numbers the primitives by their rank in the map (GPUKernel.cpp:932-990: `p`) and looks them
      * up by that number when it streams them: the two agree when the ids are 0..n-1 */
+    /* the records are complete (normals and texture coordinates too, which the builder does not read): the
+     * flattened array is these records in the order the builder returns - a gather from one array instead of a
+     * second visit of the primitive store in a random order, which took as long as the build */
     std::vector<Primitive> prims(n);
-    std::vector<unsigned char> emissive(n);
-    std::vector<CPUPrimitive *> byId(n); /* (a look-up per primitive in the loop further down was a third of this function) */
+    std::vector<unsigned char> emissive(n), movable(n);
+    std::vector<CPUPrimitive *> byId(n);
     int rank = 0;
     for (auto &entry : f.primitives)
     {
@@ -699,11 +702,18 @@ bool GPUKernel::buildTreeOnDevice()
         out.p0 = p.p0;
         out.p1 = p.p1;
         out.p2 = p.p2;
+        out.n0 = p.n0;
+        out.n1 = p.n1;
+        out.n2 = p.n2;
         out.size = p.size;
         out.materialId = p.materialId;
+        out.vt0 = p.vt0;
+        out.vt1 = p.vt1;
+        out.vt2 = p.vt2;
         if (p.materialId < 0 || p.materialId > NB_MAX_MATERIALS)
             return false;
         emissive[rank] = m_hMaterials[p.materialId].innerIllumination.x != 0.f;
+        movable[rank] = p.movable && p.type != ptCamera;
         ++rank;
     }
     std::vector<BoundingBox> boxes;
@@ -739,7 +749,8 @@ bool GPUKernel::buildTreeOnDevice()
         const long id = order[k];
         if (id < 0 || id >= n)
             return false;
-        appendPrimitive(id, k >= nbLamps, byId[id]);
+        m_hPrimitives.push_back(prims[id]); /* appendPrimitive's record */
+        m_hMovable.push_back(k >= nbLamps && movable[id]);
         if (k < nbLamps)
         {
             CPUPrimitive &primitive = *byId[id];
@@ -760,6 +771,7 @@ bool GPUKernel::buildTreeOnDevice()
             ++m_lightInformationSize;
         }
     }
+    f.nbActivePrimitives = n;
     for (const BoundingBox &b : m_hBoundingBoxes)
         m_maxPrimitivesPerBox = std::max(m_maxPrimitivesPerBox, (size_t)std::max(b.nbPrimitives, 0));
     m_frames[m_frame].levelsBuilt = false; /* the maps follow when somebody needs them (frame()) */
@@ -767,9 +779,9 @@ bool GPUKernel::buildTreeOnDevice()
     return true;
 }
 
-void GPUKernel::appendPrimitive(long id, bool inLevel0Box, CPUPrimitive *known)
+void GPUKernel::appendPrimitive(long id, bool inLevel0Box)
 {
-    CPUPrimitive &primitive = known ? *known : frame().primitives[(unsigned int)id];
+    CPUPrimitive &primitive = frame().primitives[(unsigned int)id];
     Primitive out;
     memset(&out, 0, sizeof(out));
     out.index = (int)id;

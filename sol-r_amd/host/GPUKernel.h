@@ -516,7 +516,7 @@ protected:
     bool updateOutterBoundingBox(CPUBoundingBox &box, const int depth);
     void resetBox(CPUBoundingBox &box, bool resetPrimitives);
     void recursiveDataStreamToGPU(const int depth, CPUBoundingBox &parent);
-    void appendPrimitive(long id, bool inLevel0Box, CPUPrimitive *known = nullptr);
+    void appendPrimitive(long id, bool inLevel0Box);
     void fillRandoms();
 
     float vectorLength(const vec3f &v);

@@ -5,6 +5,9 @@
  */
 #include "HipKernel.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -93,7 +96,20 @@ int HipKernel::lastError(std::string *message)
 
 void HipKernel::render_begin(const float timer)
 {
+    /* SOLR_HIP_DEBUG_TIMING: the host side of a frame, step by step */
+    static const bool timing = getenv("SOLR_HIP_DEBUG_TIMING") != nullptr;
+    auto last = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - last).count();
+        if (ms >= 0.05)
+            fprintf(stderr, "solr host: %-30s %8.2f ms\n", what, ms);
+        last = now;
+    };
     GPUKernel::render_begin(timer);
+    mark("render_begin: base class");
     if (m_deterministicSeed < 0)
     {
         /* one process of several (solr_hip_comm_init): the timestamp the base class has just drawn from rand() has to
@@ -124,10 +140,12 @@ void HipKernel::render_begin(const float timer)
         {
             h2d_scene(m_occupancyParameters, m_hBoundingBoxes.data(), nbBoxes, m_hPrimitives.data(), nbPrimitives,
                       m_hLamps.data(), nbLamps);
+            mark("render_begin: h2d_scene");
             h2d_lightInformation(m_occupancyParameters, m_lightInformation.data(), m_lightInformationSize);
             solr_hip_set_movable(m_hMovable.data(), (int)m_hMovable.size());
             m_primitivesTransfered = true;
             m_hostTouched = false; /* device and host hold the same scene from here on */
+            mark("render_begin: lights, movable flags");
         }
         if (!m_randomsTransfered)
         {
@@ -136,17 +154,20 @@ void HipKernel::render_begin(const float timer)
             else
                 h2d_randoms(m_occupancyParameters, m_hRandoms.data());
             m_randomsTransfered = true;
+            mark("render_begin: randoms");
         }
         if (!m_materialsTransfered)
         {
             realignTexturesAndMaterials();
             h2d_materials(m_occupancyParameters, m_hMaterials.data(), nbMaterials);
             m_materialsTransfered = true;
+            mark("render_begin: materials");
         }
         if (!m_texturesTransfered)
         {
             h2d_textures(m_occupancyParameters, NB_MAX_TEXTURES, m_hTextures);
             m_texturesTransfered = true;
+            mark("render_begin: textures");
         }
 
         vec4i objects = make_vec4i(nbBoxes, nbPrimitives, nbLamps, m_lightInformationSize);
@@ -159,6 +180,7 @@ void HipKernel::render_begin(const float timer)
 
         cudaRender(m_occupancyParameters, m_blockSize, sceneInfo, objects, m_postProcessingInfo, m_viewPos, m_viewDir,
                    m_angles);
+        mark("render_begin: cudaRender");
         if (m_flights > 1)
         {
             /* frames in flight: the image starts for the host behind the kernel, on the engine's copy stream */
