@@ -1,0 +1,112 @@
+"""The hand-scheduled node loops (sol-r_amd/csrc/rt_device.h advanceTidyShallow / advanceTidy) name fixed registers -
+s[64:94], v[58:63]: sub-registers of pairs cannot be named through operands.  What keeps the compiler from holding
+a live value in one of them across the statement is the clobber list alone, and a register added to the template
+but not to the list would corrupt a frame silently.  This test makes that loud: the device source is run through
+the preprocessor (the templates are assembled from macros), every `asm volatile` statement is taken apart, and
+
+  * every register the template names literally must be in the statement's clobber list (or be exec / vcc / scc
+    / a named special register),
+  * every clobbered register must be named by the template (a stale entry costs the allocator a register),
+  * vcc and scc must be declared when the template writes them,
+  * the fixed registers are the documented banks and no operand is bound to a register by name.
+
+With a complete clobber list the compiler cannot hold a value in these registers across the statement (that is the
+contract of the list, whatever the allocator does in a later release); what the list cannot catch is an edit of the
+template, and that is what is checked.  No GPU needed: hipcc only preprocesses here."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCE = os.path.join(ROOT, "sol-r_amd", "csrc", "solr_hip.hip")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _preprocessed(tmp_path):
+    out = str(tmp_path / "solr_hip.ii")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "--cuda-device-only", "-E", "-std=c++17", SOURCE, "-o", out],
+                   check=True, cwd=str(tmp_path))
+    return open(out).read()
+
+
+def _statements(text):
+    """[(template, outputs, inputs, clobbers)] of every asm volatile statement"""
+    found = []
+    for m in re.finditer(r"asm volatile\(", text):
+        i, depth, in_string, parts, start = m.end(), 1, False, [], m.end()
+        while depth:
+            c = text[i]
+            if in_string:
+                if c == "\\":
+                    i += 1
+                elif c == '"':
+                    in_string = False
+            elif c == '"':
+                in_string = True
+            elif c == "(":
+                depth += 1
+            elif c == ")":
+                depth -= 1
+            elif c == ":" and depth == 1:
+                parts.append(text[start:i])
+                start = i + 1
+            i += 1
+        parts.append(text[start:i - 1])
+        template = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', parts[0])).replace("\\n", "\n").replace("\\t", "\t")
+        clobbers = re.findall(r'"([^"]+)"', parts[3]) if len(parts) > 3 else []
+        found.append((template, parts[1] if len(parts) > 1 else "", parts[2] if len(parts) > 2 else "", clobbers))
+    return found
+
+
+def _literal_registers(template):
+    """registers the template names itself (not through an operand)"""
+    regs = set()
+    body = re.sub(r"%\[\w+\]|%\d+|%=", " ", template)
+    for kind, a, b in re.findall(r"\b([sv])\[(\d+):(\d+)\]", body):
+        regs.update("%s%d" % (kind, k) for k in range(int(a), int(b) + 1))
+    body = re.sub(r"\b[sv]\[\d+:\d+\]", " ", body)
+    for kind, a in re.findall(r"(?<![\w.])([sv])(\d+)\b", body):
+        regs.add("%s%d" % (kind, int(a)))
+    return regs
+
+
+@pytest.fixture(scope="module")
+def statements(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    return _statements(_preprocessed(tmp_path_factory.mktemp("asm")))
+
+
+def test_there_are_the_statements_we_think(statements):
+    loops = [s for s in statements if "s_load_dwordx8" in s[0]]
+    assert len(loops) == 2, [s[0][:40] for s in statements]
+    assert len(statements) >= 3
+
+
+def test_every_fixed_register_is_clobbered_and_every_clobber_is_used(statements):
+    for template, _outputs, _inputs, clobbers in statements:
+        named = _literal_registers(template)
+        listed = {c for c in clobbers if re.fullmatch(r"[sv]\d+", c)}
+        assert named <= listed, "named by the template but not clobbered: %s" % sorted(named - listed)
+        assert listed <= named, "clobbered but not named by the template: %s" % sorted(listed - named)
+        if re.search(r"\bv_cmpx?_\w+_e32\b|\bvcc\b", template):
+            assert "vcc" in clobbers
+        if re.search(r"\bs_(cmp|add|sub|lshl|lshr|and|or|xor|cselect|min|max)\w*\b", template):
+            assert "scc" in clobbers
+
+
+def test_the_fixed_banks_are_the_documented_ones(statements):
+    """DESIGN / the comment above the loops: s[64:94], v[58:63]"""
+    allowed = {"s%d" % k for k in range(64, 95)} | {"v%d" % k for k in range(58, 64)}
+    for template, _o, _i, clobbers in statements:
+        assert _literal_registers(template) <= allowed
+        assert {c for c in clobbers if re.fullmatch(r"[sv]\d+", c)} <= allowed
+
+
+def test_operands_do_not_ask_for_fixed_registers(statements):
+    """nothing binds an operand to a register by name (register asm variables would bypass the list)"""
+    text = open(os.path.join(ROOT, "sol-r_amd", "csrc", "rt_device.h")).read()
+    assert not re.search(r"register\s+\w+\s+\w+\s+asm\s*\(", text)
