@@ -1986,6 +1986,216 @@ static void standardRendererPixel(const OracleScene *s, const SceneInfo *si, con
     }
 }
 
+/* ref GI:1088-1265 intersectionsWithPrimitives, the body of launchVolumeRendering (CRT:50-67): EVERY primitive the
+ * ray meets beyond postProcessingInfo.param1 is shaded (primitiveShader as for a first hit: iteration 0, its own
+ * shadow rays) and kept, nearest first, in ten layers; the layers are then composited front to back along the ray in
+ * 500 steps of viewDistance / 500, each step adding the layer it is in with weight 1 / param2.  The walk is the
+ * closest-hit walk's (skip pointers, boxIntersection against [0, viewDistance]) without its cut-off: nothing hides
+ * anything.  As written there:
+ *   - the insertion shifts colors[9] into colors[10], one element behind the array (GI:1198-1200, MAXDEPTH = 10):
+ *     a store nobody reads; eleven elements here;
+ *   - VOLUME_RENDERING_NORMALS is not defined (GI:22, Consts.h:57): N stays 0;
+ *   - `normalize(color)` (GI:1254) discards its result;
+ *   - the first value of `color` is colors[0] * backgroundColor.w, all four components (GI:1227), and .w is
+ *     overwritten with the nearest layer's distance at the end (GI:1263).
+ * The OpenCL engine's function of the same name (CL:1909-2071) is another effect (no shading, no threshold, bands
+ * subtracted from the background colour, a normalised result): it is not restated, and this one does not depend on
+ * the dialect switch beyond what primitiveShader and the intersection tests do. */
+static f4 volumeIntersectionsWithPrimitives(const OracleScene *s, int index, const SceneInfo *si,
+                                            const PostProcessingInfo *ppi, const Ray *ray, Stats *st)
+{
+    enum { MAXDEPTH = 10 };
+    Ray r;
+    r.origin = ray->origin;
+    r.direction = vsub(ray->direction, ray->origin);
+    computeRayAttributes(&r);
+
+    v3 intersection = ray->origin;
+    v3 normal = {0.f, 0.f, 0.f};
+    float shadowIntensity = 0.f;
+    f4 colors[MAXDEPTH + 1];
+    for (int k = 0; k < MAXDEPTH; ++k)
+    {
+        colors[k].x = colors[k].y = colors[k].z = 0.f;
+        colors[k].w = si->viewDistance;
+    }
+    colors[MAXDEPTH] = colors[MAXDEPTH - 1];
+    st->closest++;
+
+    int nbIntersections = 0;
+    int cptBoxes = 0;
+    while (cptBoxes < s->nbBoxes)
+    {
+        const BoundingBox *box = &s->boxes[cptBoxes];
+        st->boxes++;
+        if (boxIntersection(box, &r, 0.f, si->viewDistance))
+        {
+            for (int cptPrimitives = 0; cptPrimitives < box->nbPrimitives; ++cptPrimitives)
+            {
+                const Primitive *primitive = &s->primitives[box->startIndex + cptPrimitives];
+                const Material *material = &s->materials[primitive->materialId];
+                v3 areas = {0.f, 0.f, 0.f};
+                st->prims++;
+                const int hit = testPrimitive(si, primitive, s->materials, s->textures, &r, &intersection, &normal, &areas,
+                                              &shadowIntensity);
+                if (!hit)
+                    continue;
+                const float dist = vlength(vsub(intersection, r.origin));
+                if (!(dist > ppi->param1))
+                    continue;
+                ++nbIntersections;
+                f4 color = colorOf(material);
+                if (si->graphicsLevel != glNoShading)
+                {
+                    f4 attributes;
+                    attributes.x = material->reflection;
+                    attributes.y = material->transparency;
+                    attributes.z = material->refraction;
+                    attributes.w = material->opacity;
+                    c3 rBlinn = {0.f, 0.f, 0.f};
+                    c3 closestColor = {material->color.x, material->color.y, material->color.z};
+                    shadowIntensity = 0.f;
+                    const c3 shaded = primitiveShader(s, index, si, r.origin, &normal, box->startIndex + cptPrimitives,
+                                                      intersection, areas, &closestColor, 0, &shadowIntensity, &rBlinn,
+                                                      &attributes, st);
+                    color.x = shaded.x;
+                    color.y = shaded.y;
+                    color.z = shaded.z;
+                }
+                for (int k = 0; k < MAXDEPTH; ++k)
+                    if (dist < colors[k].w)
+                    {
+                        const float a = vdot(vnormalize(vsub(ray->direction, ray->origin)), normal);
+                        for (int j = MAXDEPTH - 1; j >= k; --j)
+                            colors[j + 1] = colors[j];
+                        colors[k].x = color.x * fabsf(a);
+                        colors[k].y = color.y * fabsf(a);
+                        colors[k].z = color.z * fabsf(a);
+                        colors[k].w = dist;
+                        break;
+                    }
+            }
+            ++cptBoxes;
+        }
+        else
+            cptBoxes += box->indexForNextBox.x;
+    }
+
+    f4 color;
+    color.x = colors[0].x * si->backgroundColor.w;
+    color.y = colors[0].y * si->backgroundColor.w;
+    color.z = colors[0].z * si->backgroundColor.w;
+    if (nbIntersections > 0)
+    {
+        float D = colors[0].w;
+        const int precision = 500;
+        const float step = si->viewDistance / (float)precision;
+        const float alpha = 1.f / ppi->param2;
+        int c = 0;
+        for (int k = 0; k < precision && c < MAXDEPTH - 1; ++k)
+        {
+            if (D > colors[c].w)
+            {
+                color.x += colors[c].x * alpha;
+                color.y += colors[c].y * alpha;
+                color.z += colors[c].z * alpha;
+            }
+            D += step;
+            if (D >= colors[c + 1].w)
+                ++c;
+        }
+    }
+    color.w = colors[0].w;
+    return color;
+}
+
+/* ref CRT:592-713, k_volumeRenderer for one pixel (dispatched for cameraType == ctVolumeRendering, CRT:1777-1806,
+ * which rules the kernel's own five-ray, orthographic and VR branches out: they are not restated).  What differs
+ * from k_standardRenderer's frame: the rotated-grid offset is added to the DIRECTION on every pass (CRT:670-671: no
+ * test of the pass number), the ids are (-1, 1, 0, unchanged) (CRT:59-61), the depth written on pass 0 is the 0 the
+ * kernel initialised it with (CRT:633, 686-687), and the random index of the depth-of-field jitter is an int
+ * (CRT:626). */
+static void volumeRendererPixel(const OracleScene *s, const SceneInfo *si, const PostProcessingInfo *ppi, v3 origin,
+                                v3 direction, const float angles[4], const Trig *trig, int x, int yLocal, int firstRow,
+                                PostProcessingBuffer *pp, PrimitiveXYIdBuffer *ids, Stats *st)
+{
+    static const float AAx[4] = {3.f, 5.f, -3.f, -5.f};
+    static const float AAy[4] = {5.f, -3.f, -5.f, 3.f};
+    const int index = yLocal * si->size.x + x;
+    const int gindex = (firstRow + yLocal) * si->size.x + x;
+
+    if (si->pathTracingIteration > ids[index].y && ids[index].w == 0 && si->pathTracingIteration > 0 &&
+        si->pathTracingIteration <= NB_MAX_ITERATIONS)
+        return;
+
+    Ray ray;
+    memset(&ray, 0, sizeof(ray));
+    ray.origin = origin;
+    ray.direction = direction;
+    const v3 rotationCenter = {0.f, 0.f, 0.f};
+
+    if (ppi->type != ppe_depthOfField && si->pathTracingIteration >= NB_MAX_ITERATIONS)
+    {
+        const float a = (ppi->param1 / 20000.f);
+        const int rindex = gindex + si->timestamp % (MAX_BITMAP_SIZE - 2);
+        ray.origin.x += rnd(s, rindex, st) * pp[index].colorInfo.w * a;
+        ray.origin.y += rnd(s, rindex + 1, st) * pp[index].colorInfo.w * a;
+    }
+
+    const float dof = 0.f;
+    const int yGlobal = firstRow + yLocal;
+    {
+        const float ratio = (float)si->size.x / (float)si->size.y;
+        const float stepx = ratio * angles[3] / (float)si->size.x;
+        const float stepy = angles[3] / (float)si->size.y;
+        ray.direction.x = ray.direction.x - stepx * (float)(x - (si->size.x / 2));
+        ray.direction.y = ray.direction.y + stepy * (float)(yGlobal - (si->size.y / 2));
+    }
+    ray.origin = vectorRotation(ray.origin, rotationCenter, trig);
+    ray.direction = vectorRotation(ray.direction, rotationCenter, trig);
+
+    Ray r = ray;
+    r.direction.x = ray.direction.x + AAx[si->pathTracingIteration % 4];
+    r.direction.y = ray.direction.y + AAy[si->pathTracingIteration % 4];
+
+    ids[index].x = -1;
+    ids[index].y = 1;
+    ids[index].z = 0;
+    const f4 traced = volumeIntersectionsWithPrimitives(s, gindex, si, ppi, &r, st);
+    c3 color = {0.f + traced.x, 0.f + traced.y, 0.f + traced.z};
+
+    if (si->advancedIllumination == aiRandomIllumination)
+    {
+        const int rindex = (gindex + si->timestamp) % MAX_BITMAP_SIZE;
+        const float rv = rnd(s, rindex, st);
+        color.x += si->backgroundColor.x * rv * 5.f;
+        color.y += si->backgroundColor.y * rv * 5.f;
+        color.z += si->backgroundColor.z * rv * 5.f;
+    }
+
+    if (si->pathTracingIteration == 0)
+        pp[index].colorInfo.w = dof;
+
+    if (si->pathTracingIteration <= NB_MAX_ITERATIONS)
+    {
+        pp[index].colorInfo.x = color.x;
+        pp[index].colorInfo.y = color.y;
+        pp[index].colorInfo.z = color.z;
+        pp[index].sceneInfo.x = color.x;
+        pp[index].sceneInfo.y = color.y;
+        pp[index].sceneInfo.z = color.z;
+    }
+    else
+    {
+        pp[index].sceneInfo.x = (ids[index].z > 0) ? fmaxf(pp[index].sceneInfo.x, color.x) : color.x;
+        pp[index].sceneInfo.y = (ids[index].z > 0) ? fmaxf(pp[index].sceneInfo.y, color.y) : color.y;
+        pp[index].sceneInfo.z = (ids[index].z > 0) ? fmaxf(pp[index].sceneInfo.z, color.z) : color.z;
+        pp[index].colorInfo.x += pp[index].sceneInfo.x;
+        pp[index].colorInfo.y += pp[index].sceneInfo.y;
+        pp[index].colorInfo.z += pp[index].sceneInfo.z;
+    }
+}
+
 /* ref CRT:840-950, k_anaglyphRenderer for one pixel: one trace per eye (origin.x -+ eyeSeparation), red from
  * the left eye's luminance, green and blue from the right eye.  No jitter, no random-illumination term,
  * plain store / accumulate.  The row is the global one (the reference's kernel has no split argument). */
@@ -2445,6 +2655,8 @@ int oracle_render(const OracleScene *scene, const SceneInfo *sceneInfo, const Po
                     anaglyphRendererPixel(scene, sceneInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
                 else if (sceneInfo->cameraType == ctPanoramic)
                     fishEyeRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, x, y, firstRow, pp, ids, &st);
+                else if (sceneInfo->cameraType == ctVolumeRendering)
+                    volumeRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
                 else
                     standardRendererPixel(scene, sceneInfo, ppInfo, o, d, angles, &trig, x, y, firstRow, pp, ids, &st);
             }

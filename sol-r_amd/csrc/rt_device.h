@@ -2746,6 +2746,133 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
     return intersectionColor;
 }
 
+/* CRT:50-67 launchVolumeRendering = GI:1088-1265 intersectionsWithPrimitives, the trace of k_volumeRenderer
+ * (cameraType ctVolumeRendering): every primitive the ray meets beyond ppi.param1 is shaded as a first hit
+ * (primitiveShader, iteration 0, its own shadow rays) and kept, nearest first, in ten layers, which are then
+ * composited along the ray in 500 steps of viewDistance / 500 with weight 1 / param2.  Wave-synchronous like the
+ * other walks: the wave follows the reference's list (the exact one: the host selects it for this camera, a tie
+ * between two layers goes to the primitive the reference meets first), every lane that entered a leaf tests its
+ * primitives, and the lanes that hit one shade it together.  The layers are the lane's colour-stack slots in LDS
+ * (eleven: GI:1198-1200 shifts the tenth into the element behind the array; the host sizes the stack for it).
+ * VOLUME_RENDERING_NORMALS is not defined in the reference (GI:22, Consts.h:57), `normalize(color)` at GI:1254
+ * discards its result. */
+template <bool COUNT, int FEAT>
+SOLR_DEV v3 launchVolumeRendering(const Scene &S, bool active, int index, v3 rayO, v3 rayD, const SceneInfo &si,
+                                  const PostProcessingInfo &ppi, int4 &primitiveXYId, const ColorStack &cs, Counters &cnt)
+{
+    constexpr int MAXDEPTH = 10;
+    primitiveXYId.x = -1;
+    primitiveXYId.y = 1;
+    primitiveXYId.z = 0;
+    for (int k = 0; k <= MAXDEPTH; ++k)
+    {
+        cs.at(k, 0) = 0.f;
+        cs.at(k, 1) = 0.f;
+        cs.at(k, 2) = 0.f;
+        cs.at(k, 3) = si.viewDistance;
+    }
+    if (ballot(active) == 0ull)
+        return V(0.f, 0.f, 0.f);
+    const WalkRay r = makeWalkRay(rayO, rayD - rayO);
+    if (active)
+        countAdd<COUNT>(cnt.closest, 1);
+    countAdd<COUNT>(cnt.wClosest, 1);
+    const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteRay(r)) == 0ull);
+    int nbIntersections = 0;
+    int cursor = active ? 0 : SOLR_CURSOR_DONE;
+    int cur = 0;
+    const int nbBoxes = S.nbBoxes;
+    Row2 node = boxNode(S, 0);
+    while (cur < nbBoxes)
+    {
+        const int leaf = cur;
+        int nbPrimitives;
+        bool entered;
+        if (!stepGeneral<COUNT>(S, r, fastBoxes, si.viewDistance, cursor, cur, node, nbPrimitives, entered, cnt))
+            continue;
+        if (nbPrimitives <= 0)
+            continue;
+        const Row4 L = leafRecord(S, uniform(leaf));
+        const int start = uniform(asint(L.d.w));
+        for (int k = 0; k < nbPrimitives; ++k)
+        {
+            const PrimRec rec = leafPrimitive<FEAT>(S, si, L, start, k);
+            const int pi = rec.pi;
+            const int tag = uniform(asint(rec.head.a.w));
+            const int materialId = uniform(asint(rec.head.b.w));
+            countAdd<COUNT>(cnt.wPrims, 1);
+            Hit h;
+            h.intersection = V(0.f, 0.f, 0.f);
+            h.normal = V(0.f, 0.f, 0.f);
+            h.areas = V(0.f, 0.f, 0.f);
+            h.shadowIntensity = 0.f;
+            bool i = false;
+            if (entered)
+            {
+                countAdd<COUNT>(cnt.prims, 1);
+                i = testPrimitive<false, FEAT>(S, si, rec, tag, r, h);
+            }
+            float dist = 0.f;
+            if (i)
+                dist = length(h.intersection - r.o);
+            const bool keep = i && dist > ppi.param1;
+            if (ballot(keep) == 0ull)
+                continue;
+            const MaterialHot mh = loadMaterialHot(S, materialId);
+            v3 color = V(mh.color.x, mh.color.y, mh.color.z);
+            v3 normal = h.normal;
+            if (si.graphicsLevel != glNoShading)
+            {
+                float4 attributes = make_float4(mh.reflection, mh.transparency, mh.refraction, mh.opacity);
+                v3 rBlinn = V(0.f, 0.f, 0.f);
+                v3 closestColor = V(mh.color.x, mh.color.y, mh.color.z);
+                float shadowIntensity = 0.f;
+                color = primitiveShader<COUNT, FEAT>(S, keep, index, si, r.o, normal, pi, h.intersection, h.areas, closestColor,
+                                                     0, shadowIntensity, rBlinn, attributes, cnt);
+            }
+            if (keep)
+            {
+                ++nbIntersections;
+                for (int layer = 0; layer < MAXDEPTH; ++layer)
+                    if (dist < cs.at(layer, 3))
+                    {
+                        const float a = dot(r.dn, normal);
+                        for (int j = MAXDEPTH - 1; j >= layer; --j)
+                            for (int c = 0; c < 4; ++c)
+                                cs.at(j + 1, c) = cs.at(j, c);
+                        cs.at(layer, 0) = color.x * fabsf(a);
+                        cs.at(layer, 1) = color.y * fabsf(a);
+                        cs.at(layer, 2) = color.z * fabsf(a);
+                        cs.at(layer, 3) = dist;
+                        break;
+                    }
+            }
+        }
+    }
+    v3 color = V(cs.at(0, 0) * si.backgroundColor.w, cs.at(0, 1) * si.backgroundColor.w, cs.at(0, 2) * si.backgroundColor.w);
+    if (nbIntersections > 0)
+    {
+        float D = cs.at(0, 3);
+        const int precision = 500;
+        const float step = si.viewDistance / (float)precision;
+        const float alpha = 1.f / ppi.param2;
+        int c = 0;
+        for (int k = 0; k < precision && c < MAXDEPTH - 1; ++k)
+        {
+            if (D > cs.at(c, 3))
+            {
+                color.x += cs.at(c, 0) * alpha;
+                color.y += cs.at(c, 1) * alpha;
+                color.z += cs.at(c, 2) * alpha;
+            }
+            D += step;
+            if (D >= cs.at(c + 1, 3))
+                ++c;
+        }
+    }
+    return color;
+}
+
 /* GS:132-165 */
 SOLR_DEV void makeColor(const SceneInfo &si, v3 color, unsigned char *__restrict__ bitmap, int index)
 {

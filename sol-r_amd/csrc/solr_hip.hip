@@ -113,13 +113,18 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     const int yGlobal = F.firstRow + yLocal;
     const int gindex = yGlobal * W + x; /* global pixel index: random-buffer addressing */
 
+    /* ctVolumeRendering is dispatched to k_volumeRenderer (CRT:1777-1806, 592-713): the frame of the standard
+     * renderer around another trace (rt_device.h launchVolumeRendering), with the rotated-grid offset on every pass
+     * (CRT:670-671) and ids whose fourth component is left as it was (CRT:59-61) */
+    const bool volume = (FEAT & F_FULL) && (si.cameraType == ctVolumeRendering);
     int4 id = make_int4(0, 0, 0, 0);
     bool active = inside;
-    if (inside && si.pathTracingIteration > 0 && si.pathTracingIteration <= NB_MAX_ITERATIONS)
+    const bool refinementPass = si.pathTracingIteration > 0 && si.pathTracingIteration <= NB_MAX_ITERATIONS;
+    if (inside && (refinementPass || volume))
     {
         /* progressive refinement: skip pixels whose previous pass ended early (CRT:454-458) */
         id = ids[index0];
-        if (si.pathTracingIteration > id.y && id.w == 0)
+        if (refinementPass && si.pathTracingIteration > id.y && id.w == 0)
             active = false;
     }
 
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     rayD = vectorRotation(rayD, rotationCenter, F.trig);
 
     v3 color = V(0.f, 0.f, 0.f);
-    if (!antialiasingActivated && si.pathTracingIteration >= NB_MAX_ITERATIONS)
+    if (!antialiasingActivated && (volume || si.pathTracingIteration >= NB_MAX_ITERATIONS))
     {
         /* rotated-grid jitter of the accumulation passes, CRT:515-522 */
         const int k = si.pathTracingIteration % 4;
@@ -282,7 +287,14 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
                 rO.y += 3.f;
             }
         }
-        v3 c = launchRayTracing<COUNT, FEAT>(S, active, gindex, rO, rD, si, dof, id, cs, cnt);
+        v3 c;
+        if (volume)
+        {
+            c = launchVolumeRendering<COUNT, FEAT>(S, active, gindex, rO, rD, si, F.ppi, id, cs, cnt);
+            c = V(0.f + c.x, 0.f + c.y, 0.f + c.z);
+        }
+        else
+            c = launchRayTracing<COUNT, FEAT>(S, active, gindex, rO, rD, si, dof, id, cs, cnt);
         if (anaglyph)
         {
             if (I == 0)
@@ -2203,8 +2215,10 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     const bool full = sceneInfo.renderBoxes != 0 || sceneInfo.advancedIllumination == aiBasic ||
                       sceneInfo.advancedIllumination == aiFull || sceneInfo.cameraType == ctAntialiazed ||
                       sceneInfo.cameraType == ctAnaglyph || sceneInfo.cameraType == ctPanoramic ||
-                      sceneInfo.cameraType == ctVR;
-    const bool exactNodes = counting || sceneInfo.renderBoxes != 0 || objects.x != g.nbBoxes || g.variant == 3;
+                      sceneInfo.cameraType == ctVR || sceneInfo.cameraType == ctVolumeRendering;
+    /* (the volume camera keeps every hit, nearest first, ties in the order it met them: the reference's list) */
+    const bool exactNodes = counting || sceneInfo.renderBoxes != 0 || objects.x != g.nbBoxes || g.variant == 3 ||
+                            sceneInfo.cameraType == ctVolumeRendering;
     maybeBuildOrderFreeLists();
     flushGeometry();
     if (exactNodes)
@@ -2254,6 +2268,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     maxIt = maxIt > NB_MAX_ITERATIONS ? NB_MAX_ITERATIONS : maxIt;
     maxIt = maxIt < 1 ? 1 : maxIt;
     F.stackSlots = maxIt;
+    if (sceneInfo.cameraType == ctVolumeRendering)
+        F.stackSlots = 11; /* the ten layers of launchVolumeRendering and the element behind them */
     if (sceneInfo.cameraType == ctVR)
     {
         /* the focus pixel of k_3DVisionRenderer (CRT:973, integer expression as written there) as the frame

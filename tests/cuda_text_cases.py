@@ -161,6 +161,14 @@ def large_randoms(flat):
     flat.randoms = (flat.randoms * np.float32(4)).astype(np.float32)
 
 
+CASES["volume camera (CRT:592-713, GI:1088-1265), passes 0-12"] = (cornell, dict(cameraType=M.ctVolumeRendering, iterations=1),
+                                                                    PP(0, 3000.0, 8.0), [0, 1, 2, 10, 11, 12])
+CASES["volume camera, every primitive type, no threshold"] = (mix, dict(cameraType=M.ctVolumeRendering), PP(0, 0.0, 5.0), [0])
+CASES["volume camera without shading (GI:1174)"] = (mix, dict(cameraType=M.ctVolumeRendering, graphicsLevel=M.glNoShading),
+                                                    PP(0, 0.0, 5.0), [0])
+CASES["volume camera with random illumination (CRT:677-682)"] = (cornell, dict(cameraType=M.ctVolumeRendering, iterations=1,
+                                                                                advancedIllumination=M.aiRandomIllumination,
+                                                                                timestamp=5), PP(0, 0.0, 12.0), [0, 11])
 CASES["wireframe grids (GI:458-460, 470-472, 491-493, 525-527; TM:449-456)"] = (grids, {}, None, [0])
 CASES["view noise, passes 0-12 (CRT:257-267)"] = (mix, dict(iterations=2), None, [0, 1, 2, 11, 12], view_noise)
 CASES["global illumination with large random numbers (CRT:168-170)"] = (mix, dict(advancedIllumination=M.aiFull, iterations=1),
@@ -227,7 +235,8 @@ def compare(oracle_out, model_out, frames):
         same = {"status": int(status),
                 "frame_buffer": bool(np.array_equal(opp.view(np.int32)[..., :7], mpp.view(np.int32)[..., :7])),
                 "ids": bool(np.array_equal(oids, mids)), "bitmap": bool(np.array_equal(orgb, mrgb)),
-                "hit_pixels": int((mids[..., 0] >= 0).sum()), "pass": int(frame[0].pathTracingIteration)}
+                "hit_pixels": int((mids[..., 0] >= 0).sum()), "lit_pixels": int((mpp[..., :3].sum(axis=-1) > 0).sum()),
+                "pass": int(frame[0].pathTracingIteration)}
         if not same["frame_buffer"]:
             bad = np.argwhere(opp.view(np.int32)[..., :7] != mpp.view(np.int32)[..., :7])
             y, x = int(bad[0][0]), int(bad[0][1])

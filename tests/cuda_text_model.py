@@ -17,7 +17,7 @@ counts (a build of the oracle with a counter on every switch) that every CUDA ar
 Scope: what those switches touch - untextured spheres, cylinders, cones, ellipsoids, triangles, axis planes and the
 checkerboard (wireframe and chessboard-light masks included), both walks, the shader, the bounce loop with its
 deferred reflection and global-illumination rays, the standard / orthographic / five-ray / anaglyph / fish-eye /
-3D-vision cameras, k_default and the five post-processing kernels.  Texture maps are left to the function-level
+3D-vision / volume cameras, k_default and the five post-processing kernels.  Texture maps are left to the function-level
 cases of tests/test_cuda_text_model.py.  Transcendentals (pow of the Blinn term, cos / sin of the procedural sphere
 and the fish-eye camera) are taken in binary64 and rounded once, which is the oracle's
 oracle_set_rounded_transcendentals(1) form; the camera's cosf / sinf come from the same libm the oracle calls."""
@@ -38,7 +38,7 @@ SKYBOX_LUNINANCE_STRENGTH = F(0.2)          # Consts.h:53
 # types.h: PrimitiveType, CameraType, GraphicsLevel, AdvancedIllumination, PostProcessingEffect
 ptSphere, ptCylinder, ptTriangle, ptCheckboard, ptCamera, ptXYPlane, ptYZPlane, ptXZPlane = range(8)
 ptMagicCarpet, ptEnvironment, ptEllipsoid, ptQuad, ptCone = 8, 9, 10, 11, 12
-ctPerspective, ctOrthographic, ctAnaglyph, ctVR, ctPanoramic, ctAntialiazed = range(6)
+ctPerspective, ctOrthographic, ctAnaglyph, ctVR, ctPanoramic, ctAntialiazed, ctVolumeRendering = range(7)
 glNoShading, glPhong, glPhongAndBlinn, glReflectionsAndRefractions, glFull = range(5)
 aiNone, aiBasic, aiFull, aiRandomIllumination = range(4)
 aeNone, aeFog = 0, 1
@@ -1221,6 +1221,103 @@ def k_cartoon(si, ppi, frame, bitmap):           # CRT:1341-1358
             make_color(si, saturate([depth, depth, depth]), bitmap, y * si.size_x + x)
 
 
+# ---- k_volumeRenderer, CRT:592-713 ----------------------------------------------------------------------------------
+def intersections_with_primitives(si, ppi, s, index, origin, target):   # GI:1088-1265 (VOLUME_RENDERING_NORMALS is not
+    """-> float4 colour.  `target` is ray.direction, a point."""         #  defined: GI:22, Consts.h:57)
+    MAXDEPTH = 10                                                        # GI:1104
+    r = compute_ray_attributes(origin, sub(target, origin))              # GI:1095-1098
+    vd = F(si.viewDistance)
+    # GI:1105-1112; one element more than the text declares: the shift of GI:1198-1200 starts at j = MAXDEPTH - 1 and
+    # writes colors[MAXDEPTH], which nothing reads
+    colors = [[F(0), F(0), F(0), vd] for _ in range(MAXDEPTH + 1)]
+    nb_intersections = 0
+    c = 0
+    n_boxes = len(s.B)
+    while c < n_boxes:                                                   # GI:1120-1221
+        box = s.B[c]
+        if box_intersection(box, r, F(0), vd):
+            for k in range(box["n"]):
+                p = s.P[box["start"] + k]
+                m = s.material(p["mat"])
+                hit, inter, normal, areas = _dispatch_closest(si, s, p, r)     # the switch of GI:1132-1166 is GI:712-747's
+                if hit:
+                    dist = length(sub(inter, r.origin))                  # GI:1169
+                    if dist > F(ppi.param1):                             # GI:1170
+                        nb_intersections += 1
+                        color = (m["color"][0], m["color"][1], m["color"][2])
+                        if si.graphicsLevel != glNoShading:              # GI:1174-1192 (the product of GI:1176 is overwritten)
+                            st = ShaderState()
+                            st.closest_color = [m["color"][0], m["color"][1], m["color"][2]]
+                            color, normal = primitive_shader(si, s, index, r.origin, normal, box["start"] + k, inter, 0, st)
+                        for i in range(MAXDEPTH):                        # GI:1193-1215
+                            if dist < colors[i][3]:
+                                a = dot(normalize(sub(target, origin)), normal)
+                                for j in range(MAXDEPTH - 1, i - 1, -1):
+                                    colors[j + 1] = list(colors[j])
+                                colors[i] = [color[0] * np.abs(a), color[1] * np.abs(a), color[2] * np.abs(a), dist]
+                                break
+            c += 1
+        else:
+            c += box["skip"]
+    bgw = F(si.backgroundColor[3])
+    color = [colors[0][k] * bgw for k in range(4)]                       # GI:1227
+    if nb_intersections > 0:                                             # GI:1228-1262
+        N = 0
+        D = colors[0][3]
+        precision = 500
+        step = vd / F(precision)
+        alpha = F(1) / F(ppi.param2)
+        cc = 0
+        i = 0
+        while i < precision and cc < MAXDEPTH - 1:
+            if D > colors[cc][3] and N == 0:
+                for k in range(3):
+                    color[k] = color[k] + colors[cc][k] * alpha
+            D = D + step
+            if D >= colors[cc + 1][3]:
+                cc += 1
+            i += 1
+        color[3] = F(0)
+        # GI:1254: normalize(color) returns a value nobody takes
+    color[3] = colors[0][3]                                              # GI:1263
+    return color
+
+
+def volume_renderer(si, ppi, s, frame, origin, direction, angles):      # CRT:592-713 for cameraType ctVolumeRendering
+    """(CRT:1777: the only camera type that reaches this kernel, so its orthographic, VR and five-ray branches are dead)"""
+    W, H = si.size_x, si.size_y
+    origin, direction = v(*origin), v(*direction)
+    angles = tuple(F(a) for a in angles)
+    for y in range(H):
+        for x in range(W):
+            index = y * W + x
+            if _skip(si, frame, x, y):                                   # CRT:610-615
+                continue
+            ro, rd = origin, direction
+            center = v(0, 0, 0)
+            if ppi.type != ppe_depthOfField and si.pathTracingIteration >= NB_MAX_ITERATIONS:    # CRT:626-633
+                a = F(ppi.param1) / F(20000)
+                rindex = index + si.timestamp % (MAX_BITMAP_SIZE - 2)
+                w = F(frame.pp[y, x, 3])
+                ro = (ro[0] + s.rnd(rindex) * w * a, ro[1] + s.rnd(rindex + 1) * w * a, ro[2])
+            dof = F(0)                                                   # CRT:635: nothing assigns it afterwards
+            ratio = F(W) / F(H)                                          # CRT:645-651
+            step_x = ratio * angles[3] / F(W)
+            step_y = angles[3] / F(H)
+            rd = (rd[0] - step_x * F(x - (W // 2)), rd[1] + step_y * F(y - (H // 2)), rd[2])
+            ro = vector_rotation(ro, center, angles)                     # CRT:654-655
+            rd = vector_rotation(rd, center, angles)
+            g = AA_ROTATED_GRID[si.pathTracingIteration % 4]             # CRT:670-671: every pass
+            r_d = (rd[0] + g[0], rd[1] + g[1], rd[2])
+            _apply_ids(frame, x, y, [-1, 1, 0, None])                    # CRT:59-61
+            c = intersections_with_primitives(si, ppi, s, index, ro, r_d)
+            color = [F(0) + c[k] for k in range(3)]                      # CRT:657, 673
+            if si.advancedIllumination == aiRandomIllumination:          # CRT:677-682
+                rindex = (index + si.timestamp) % MAX_BITMAP_SIZE
+                color = [color[k] + F(si.backgroundColor[k]) * s.rnd(rindex) * F(5) for k in range(3)]
+            _store(si, frame, x, y, color, dof, True)                    # CRT:686-712
+
+
 def render(si, ppi, flat, origin, direction, angles, pp=None, ids=None, randoms=None, focus_depth=0.0):
     """One cudaRender (CRT:1680-1908 for one device): the camera kernel the dispatch picks, then the post-processing
     kernel.  -> (pp (H, W, 8) float32, ids (H, W, 4) int32, bitmap (H, W, 3) uint8)"""
@@ -1232,6 +1329,8 @@ def render(si, ppi, flat, origin, direction, angles, pp=None, ids=None, randoms=
         vision_renderer(si, ppi, s, frame, origin, direction, angles, focus_depth)
     elif si.cameraType == ctPanoramic:
         fish_eye_renderer(si, ppi, s, frame, origin, direction, angles)
+    elif si.cameraType == ctVolumeRendering:
+        volume_renderer(si, ppi, s, frame, origin, direction, angles)
     else:
         standard_renderer(si, ppi, s, frame, origin, direction, angles)
     bitmap = np.zeros((si.size_y, si.size_x, 3), np.uint8)
