@@ -3304,6 +3304,11 @@ void maybeBuildOrderFreeLists()
 {
     if (g.freeCountdown <= 0 || --g.freeCountdown > 0)
         return;
+    if (!g.primsContained)
+    {
+        g.freeCountdown = 1; /* no walk would take them (orderFreeListsUsable): asked again with the next frame */
+        return;
+    }
     PhaseTimer phase;
     quiesce();
     pullGeometry();

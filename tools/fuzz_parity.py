@@ -210,7 +210,7 @@ if __name__ == "__main__":
             # being handed its own previous frame
             rng = S.LCG(seed * 104729 + 3)
             camera = [solr.ctPerspective, solr.ctOrthographic, solr.ctVR, solr.ctAntialiazed, solr.ctAnaglyph,
-                      solr.ctPanoramic][rng.next() % 6]
+                      solr.ctPanoramic, solr.ctVolumeRendering][rng.next() % 7]
             effect = [solr.ppe_none, solr.ppe_depthOfField, solr.ppe_ambientOcclusion, solr.ppe_radiosity,
                       solr.ppe_filter, solr.ppe_cartoon][rng.next() % 6]
             k.set_post_processing(type=effect, param1=rng.uniform(1000.0, 9000.0), param2=rng.uniform(0.001, 20.0),
