@@ -131,3 +131,40 @@ def test_lists_that_stay_on_the_device(solr, scene, kw, after):
         for o in range(8):
             assert np.array_equal(a[o].view(np.int32), b[o].view(np.int32)), (name, o)
     assert np.array_equal(image, image_h)
+
+
+def test_scene_changes_do_not_leak_device_memory(solr):
+    """upload, lists on the device (staged, appended, fetched back for a refit plan), rotation, finalize - five
+    times: what the device has free afterwards stays where it was after the first round (the builders' pooled
+    scratch, the staged lists and their origins, the arena that was re-allocated to take the lists)"""
+    import ctypes as C
+    runtime = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = C.c_size_t(), C.c_size_t()
+        assert runtime.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    saved = os.environ.get("SOLR_HIP_FREE_AFTER")
+    os.environ["SOLR_HIP_FREE_AFTER"] = "2"
+    try:
+        after = []
+        for cycle in range(5):
+            k = solr.Kernel(engine="hip")
+            solr.scenes.molecule(k, atoms=6000 + 500 * cycle, width=96, height=64)
+            for _ in range(3):
+                k.render()
+            assert solr.hip_lib().solr_hip_order_free_nodes() > 0
+            k.rotate_primitives((0.0, 0.0, 0.0), (0.02, 0.03, 0.0))
+            k.render()
+            k.check(0, "cycle %d" % cycle)
+            k.finalize()
+            after.append(free_bytes())
+    finally:
+        if saved is None:
+            os.environ.pop("SOLR_HIP_FREE_AFTER", None)
+        else:
+            os.environ["SOLR_HIP_FREE_AFTER"] = saved
+    # (the second round settles what the process keeps between scenes - the runtime's own pools among it)
+    assert min(after[2:]) >= after[1] - (16 << 20), [a >> 20 for a in after]
+    assert after[1] >= after[0] - (256 << 20), [a >> 20 for a in after]
