@@ -2284,7 +2284,9 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             HIPCHECK(hipStreamSynchronize(stream));
         }
     }
-    const size_t ldsBytes = ((size_t)F.stackSlots * 4 + COLD_FIELDS) * WAVE * sizeof(float);
+    /* SOLR_HIP_LDS_PAD (bytes, experiments): more LDS per wave = fewer waves per SIMD; what occupancy is worth */
+    static const size_t ldsPad = getenv("SOLR_HIP_LDS_PAD") ? (size_t)atol(getenv("SOLR_HIP_LDS_PAD")) : 0;
+    const size_t ldsBytes = ((size_t)F.stackSlots * 4 + COLD_FIELDS) * WAVE * sizeof(float) + ldsPad;
 
     const dim3 grid(F.tilesX * tilesY), block(WAVE);
     if (g.tileClocks)
