@@ -3550,6 +3550,8 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start, std
         return bestAt;
     };
 
+    /* tuning knobs (tools/group_sweep.sh); parts[] / next[] below hold at most 2^4 parts */
+    const int flatMax = std::max(1, getenv("SOLR_HIP_GROUP_FLAT") ? atoi(getenv("SOLR_HIP_GROUP_FLAT")) : 4);
     struct Emit
     {
         std::function<void(const std::vector<int> &, int, int)> siblings;
@@ -3561,15 +3563,28 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start, std
         outRows.push_back(rows[2 * i + 1]);
         outStart.push_back(start[i]);
         outOrigin.push_back(origin[i]);
-        std::vector<int> children;
-        for (int j = i + 1; j < i + skipOf(i) && j < n; j += std::max(skipOf(j), 1))
-            children.push_back(j);
-        if (!children.empty())
+        /* (most inner nodes have a handful of children, which siblings() would emit as they are: no list is made for
+         * them - a vector per inner node was two thirds of this function's time for a 100k-primitive scene) */
+        const int end = std::min(i + skipOf(i), n);
+        int few = 0;
+        for (int j = i + 1; j < end && few <= flatMax; j += std::max(skipOf(j), 1))
+            ++few;
+        if (few > flatMax)
+        {
+            std::vector<int> children;
+            for (int j = i + 1; j < end; j += std::max(skipOf(j), 1))
+                children.push_back(j);
             emit.siblings(children, 0, (int)children.size());
+        }
+        else
+            for (int j = i + 1; j < end;)
+            {
+                const int next = j + std::max(skipOf(j), 1); /* (read before the node is emitted: rows are not touched, but so it stays) */
+                emit.node(j);
+                j = next;
+            }
         outRows[2 * at + 1].w = bitsf((int)(outStart.size() - at));
     };
-    /* tuning knobs (tools/group_sweep.sh); parts[] / next[] below hold at most 2^4 parts */
-    const int flatMax = std::max(1, getenv("SOLR_HIP_GROUP_FLAT") ? atoi(getenv("SOLR_HIP_GROUP_FLAT")) : 4);
     /* (a list of a few dozen nodes - the Cornell room - gains 2 % from a third round of splits, lists of
      * thousands lose 7 %: profiles/r2/group_sweep.txt) */
     const int levels = std::min(
@@ -3705,46 +3720,41 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
      * of them, so dropping every inner node whose only child has the same
      * bounds changes no result.  Skip pointers are recomputed in the compacted
      * numbering and stay nested. */
+    /* (one pass: which nodes stay, whether every bound is ordered and finite, the compacted numbering) */
     std::vector<char> keep(nbActiveBoxes, 1);
-    if (g.nested)
-        for (int i = 0; i + 1 < nbActiveBoxes; ++i)
-        {
-            const BoundingBox &a = boundingBoxes[i];
-            const BoundingBox &b = boundingBoxes[i + 1];
-            if (a.nbPrimitives == 0 && a.indexForNextBox.x >= 2 && b.indexForNextBox.x == a.indexForNextBox.x - 1 &&
-                memcmp(a.parameters, b.parameters, sizeof(a.parameters)) == 0)
-                keep[i] = 0;
-            /* an inner node without emitted children (its cell held only lights or nothing,
-             * GPUKernel.cpp:1096) leads nowhere: entering or missing it changes nothing */
-            if (a.nbPrimitives == 0 && a.indexForNextBox.x == 1)
-                keep[i] = 0;
-        }
-    if (g.nested && nbActiveBoxes > 0)
-    {
-        const BoundingBox &last = boundingBoxes[nbActiveBoxes - 1];
-        if (last.nbPrimitives == 0 && last.indexForNextBox.x == 1)
-            keep[nbActiveBoxes - 1] = 0;
-    }
-    auto ordered = [&](int i) {
-        const BoundingBox &b = boundingBoxes[i];
-        const float *lo = &b.parameters[0].x, *hi = &b.parameters[1].x;
-        for (int k = 0; k < 3; ++k)
-            if (!(lo[k] <= hi[k]) || !(fabsf(lo[k]) < 1.0e30f) || !(fabsf(hi[k]) < 1.0e30f))
-                return false;
-        return true;
-    };
+    std::vector<int> newIndex((size_t)nbActiveBoxes + 1);
+    newIndex[0] = 0;
     g.orderedExact = 1;
     g.orderedCompact = 1;
     for (int i = 0; i < nbActiveBoxes; ++i)
-        if (!ordered(i))
+    {
+        const BoundingBox &a = boundingBoxes[i];
+        if (g.nested && a.nbPrimitives == 0)
+        {
+            if (i + 1 < nbActiveBoxes)
+            {
+                const BoundingBox &b = boundingBoxes[i + 1];
+                if (a.indexForNextBox.x >= 2 && b.indexForNextBox.x == a.indexForNextBox.x - 1 &&
+                    memcmp(a.parameters, b.parameters, sizeof(a.parameters)) == 0)
+                    keep[i] = 0;
+            }
+            /* an inner node without emitted children (its cell held only lights or nothing,
+             * GPUKernel.cpp:1096) leads nowhere: entering or missing it changes nothing */
+            if (a.indexForNextBox.x == 1)
+                keep[i] = 0;
+        }
+        const float *lo = &a.parameters[0].x, *hi = &a.parameters[1].x;
+        bool ordered = true;
+        for (int k = 0; k < 3; ++k)
+            ordered = ordered && (lo[k] <= hi[k]) && (fabsf(lo[k]) < 1.0e30f) && (fabsf(hi[k]) < 1.0e30f);
+        if (!ordered)
         {
             g.orderedExact = 0;
             if (keep[i])
                 g.orderedCompact = 0;
         }
-    std::vector<int> newIndex(nbActiveBoxes + 1, 0);
-    for (int i = 0; i < nbActiveBoxes; ++i)
-        newIndex[i + 1] = newIndex[i] + (keep[i] ? 1 : 0);
+        newIndex[(size_t)i + 1] = newIndex[i] + (keep[i] ? 1 : 0);
+    }
     const int nc = newIndex[nbActiveBoxes];
     std::vector<float4> boxesC(2 * (size_t)nc);
     std::vector<int> startC(nc), originC(nc);
