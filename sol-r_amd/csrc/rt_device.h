@@ -1221,8 +1221,7 @@ SOLR_DEV PackedRay packRay(const WalkRay &r)
     "v_cmpx_lt_f32_e32 vcc, %[t], %[far]\n"                                                                            \
     "v_cmpx_lt_f32_e32 vcc, 0, v58\n"                                                                                 \
     "v_mov_b32 %[cursor], s85\n"                                                                                       \
-    "s_cmp_lg_u64 exec, 0\n"                                                                                           \
-    "s_cbranch_scc1 LE" SELF "_%=\n"                                                                                   \
+    "s_cbranch_execnz LE" SELF "_%=\n"                                                                                 \
     "s_mov_b64 exec, s[80:81]\n"                                                                                       \
     "s_mov_b32 %[cur], s86\n"                                                                                          \
     "s_cmp_ge_i32 s86, %[n]\n"                                                                                         \
@@ -1326,8 +1325,7 @@ SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDis
     "v_cmpx_lt_f32_e32 vcc, %[t], %[far]\n"                                                                            \
     "v_cmpx_lt_f32_e32 vcc, 0, v58\n"                                                                                 \
     "v_mov_b32 %[cursor], s93\n"                                                                                       \
-    "s_cmp_lg_u64 exec, 0\n"                                                                                           \
-    "s_cbranch_scc1 LE" SELF "_%=\n"                                                                                   \
+    "s_cbranch_execnz LE" SELF "_%=\n"                                                                                 \
     "s_mov_b64 exec, s[88:89]\n"                                                                                       \
     "s_mov_b32 %[cur], s94\n"                                                                                          \
     "s_cmp_ge_i32 s94, %[n]\n"                                                                                         \
