@@ -45,6 +45,7 @@ struct FrameArgs
     float dx, dy, dz;     /* camera look-at */
     float ax, ay, az, aw; /* camera angles, w = field scale */
     Trig trig;            /* cos/sin of the angles, evaluated on the host */
+    float stepx, stepy;   /* the pixel pitch of the perspective cameras (CRT:490-492): the same three binary32 operations, once */
     int firstRow;         /* first image row of this process's strip */
     int nbRows;           /* rows in the strip */
     int tilesX;
@@ -166,12 +167,12 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     }
     else
     {
-        float ratio = (float)si.size.x / (float)si.size.y;
-        float stepx = ratio * F.aw / (float)si.size.x;
-        float stepy = F.aw / (float)si.size.y;
-        rayD.x = rayD.x - stepx * (float)(x - (si.size.x / 2));
-        rayD.y = rayD.y + stepy * (float)(yGlobal - (si.size.y / 2));
+        rayD.x = rayD.x - F.stepx * (float)(x - (si.size.x / 2));
+        rayD.y = rayD.y + F.stepy * (float)(yGlobal - (si.size.y / 2));
     }
+    /* (the camera position is the same for every pixel here, and so is its rotation: taking it from the host
+     * instead - three values in scalar registers for as long as the first trace lasts - measured 5 % slower: the
+     * scalar registers are the scarce ones, profiles/r3/occupancy_experiments.txt) */
     rayO = vectorRotation(rayO, rotationCenter, F.trig);
     rayD = vectorRotation(rayD, rotationCenter, F.trig);
 
@@ -208,9 +209,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
         v3 rD = rayD;
         if (anaglyph)
         {
-            const float ratio = (float)si.size.x / (float)si.size.y;
-            const float stepx = ratio * F.aw / (float)si.size.x;
-            const float stepy = F.aw / (float)si.size.y;
+            const float stepx = F.stepx, stepy = F.stepy;
             rO = V((I == 0) ? F.ox - si.eyeSeparation : F.ox + si.eyeSeparation, F.oy, F.oz);
             rD = V(F.dx - stepx * (float)(x - (si.size.x / 2)), F.dy + stepy * (float)(yGlobal - (si.size.y / 2)), F.dz);
             rO = vectorRotation(rO, V(0.f, 0.f, 0.f), F.trig);
@@ -221,9 +220,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
             const float focus = fabsf(F.focusDepth - F.oz);
             const float eyeSeparation = si.eyeSeparation * (F.dz / focus);
             const int halfWidth = si.size.x / 2;
-            const float ratio = (float)si.size.x / (float)si.size.y;
-            const float stepx = ratio * F.aw / (float)si.size.x;
-            const float stepy = F.aw / (float)si.size.y;
+            const float stepx = F.stepx, stepy = F.stepy;
             const v3 eye = V(F.ox, F.oy, F.oz);
             if (x < halfWidth)
             {
@@ -254,8 +251,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
                 rD.y += rnd(S, rindex + 1) * depth * F.ppi.param2 * a;
                 rD.z += rnd(S, rindex + 2) * depth * F.ppi.param2 * a;
             }
-            const float stepy = F.aw / (float)si.size.y;
-            rD.y = rD.y + stepy * (float)(yGlobal - (si.size.y / 2));
+            rD.y = rD.y + F.stepy * (float)(yGlobal - (si.size.y / 2));
             const float stepx = 2.f * 3.14159265358979323846f / (float)si.size.x;
             const float turn = F.ay + stepx * (float)x;
             Trig t;
@@ -2246,6 +2242,11 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     F.ay = angles[1];
     F.az = angles[2];
     F.aw = angles[3];
+    {
+        const float ratio = (float)sceneInfo.size.x / (float)sceneInfo.size.y;
+        F.stepx = ratio * F.aw / (float)sceneInfo.size.x;
+        F.stepy = F.aw / (float)sceneInfo.size.y;
+    }
     /* VectorUtils.cuh:108-114 evaluates these per pixel; they are uniform */
     F.trig.cx = cosf(angles[0]);
     F.trig.cy = cosf(angles[1]);
