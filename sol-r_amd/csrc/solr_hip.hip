@@ -49,6 +49,8 @@ struct FrameArgs
     int firstRow;         /* first image row of this process's strip */
     int nbRows;           /* rows in the strip */
     int tilesX;
+    unsigned tileMagic;   /* tile / tilesX = (tile * tileMagic) >> (32 + tileShift) for every tile of the frame (checked on the host) */
+    int tileShift;
     int fuseDefault;      /* 1: write the RGB bitmap from the renderer */
     int stackSlots;       /* colour-stack slots per lane in LDS */
     float focusDepth;     /* ctVR: depth of the focus pixel before this frame (k_3DVisionRenderer) */
@@ -101,8 +103,10 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     unsigned long long clock0 = 0ull;
     if (F.tileClock || F.tileCost)
         clock0 = __builtin_amdgcn_s_memrealtime();
-    const int tx = tile % F.tilesX;
-    const int ty = tile / F.tilesX;
+    /* (a division by a number only the host knows is two dozen instructions each time; the frame's reciprocal is one
+     * multiplication) */
+    const int ty = F.tileMagic ? (int)(__umulhi((unsigned)tile, F.tileMagic) >> F.tileShift) : tile;
+    const int tx = tile - ty * F.tilesX;
     const int x = tx * TILE + (lane & (TILE - 1));
     const int yLocal = ty * TILE + (lane >> 3);
     const int W = si.size.x;
@@ -308,8 +312,9 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
      * just to address the stores below. */
     int tileAgain = tile, partAgain = part, laneAgain = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+s"(tileAgain), "+s"(partAgain), "+v"(laneAgain));
-    const int xAgain = (tileAgain % F.tilesX) * TILE + (laneAgain & (TILE - 1));
-    const int yAgain = (tileAgain / F.tilesX) * TILE + (laneAgain >> 3);
+    const int tyAgain = F.tileMagic ? (int)(__umulhi((unsigned)tileAgain, F.tileMagic) >> F.tileShift) : tileAgain;
+    const int xAgain = (tileAgain - tyAgain * F.tilesX) * TILE + (laneAgain & (TILE - 1));
+    const int yAgain = tyAgain * TILE + (laneAgain >> 3);
     const int index = ((xAgain < si.size.x) && (yAgain < F.nbRows)) ? yAgain * si.size.x + xAgain : 0;
     const int gindexAgain = (F.firstRow + yAgain) * si.size.x + xAgain;
 
@@ -2258,6 +2263,33 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     F.nbRows = stripRows();
     F.tilesX = (sceneInfo.size.x + TILE - 1) / TILE;
     const int tilesY = (F.nbRows + TILE - 1) / TILE;
+    {
+        /* the reciprocal of tilesX for the kernel's tile -> (column, row): exact for every tile of this frame
+         * (round-up multiplier of ceil(log2) + 16 extra bits; verified below, once per frame geometry) */
+        static int checkedTilesX = 0, checkedTiles = 0, checkedShift = 0;
+        static unsigned checkedMagic = 0;
+        const int tiles = F.tilesX * tilesY;
+        if (checkedTilesX != F.tilesX || checkedTiles < tiles)
+        {
+            /* shift = ceil(log2 tilesX) - 1: the multiplier ceil(2^(32 + shift) / tilesX) has 32 bits and is exact for
+             * every index below 2^31; one tile per row (magic 0) needs no division */
+            int shift = 0;
+            while ((2 << shift) < F.tilesX)
+                ++shift;
+            const unsigned long long magic =
+                F.tilesX == 1 ? 0ull : ((1ull << (32 + shift)) + (unsigned long long)F.tilesX - 1) / (unsigned long long)F.tilesX;
+            bool exact = magic <= 0xffffffffull;
+            for (int t = 0; t < tiles && exact && magic; ++t)
+                exact = (int)(((unsigned long long)(unsigned)t * magic) >> (32 + shift)) == t / F.tilesX;
+            ARGCHECK(exact, "cudaRender: no exact reciprocal for this frame width");
+            checkedTilesX = F.tilesX;
+            checkedTiles = tiles;
+            checkedMagic = (unsigned)magic;
+            checkedShift = shift;
+        }
+        F.tileMagic = checkedMagic;
+        F.tileShift = checkedShift;
+    }
     const bool neighbourhood = (ppInfo.type == ppe_ambientOcclusion || ppInfo.type == ppe_depthOfField ||
                                 ppInfo.type == ppe_radiosity || ppInfo.type == ppe_filter || ppInfo.type == ppe_cartoon);
     unsigned char *bitmap = (unsigned char *)(g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr);
