@@ -185,10 +185,14 @@ SOLR_DEV float pow_f(float a, float b)
     const float result = (float)__builtin_ldexp(q, (int)kk);
     return zero ? 0.f : result;
 }
-SOLR_DEV float cos_f(float a) { return (float)cos((double)a); }
-SOLR_DEV float sin_f(float a) { return (float)sin((double)a); }
-SOLR_DEV float atan2_f(float a, float b) { return (float)atan2((double)a, (double)b); }
-SOLR_DEV float asin_f(float a) { return (float)asin((double)a); }
+/* (out of line like pow_general: binary64 library routines of a few hundred instructions each, in the kernels of
+ * procedural spheres, texture coordinates and the fish-eye camera only; inlined at every use they were what the
+ * all-features instantiations spilled 300 registers around.  The two procedural textures out of line as well gave
+ * the opposite: 51 -> 133 spills - a call costs its caller every register that is live across it) */
+__device__ __attribute__((noinline)) float cos_f(float a) { return (float)cos((double)a); }
+__device__ __attribute__((noinline)) float sin_f(float a) { return (float)sin((double)a); }
+__device__ __attribute__((noinline)) float atan2_f(float a, float b) { return (float)atan2((double)a, (double)b); }
+__device__ __attribute__((noinline)) float asin_f(float a) { return (float)asin((double)a); }
 
 SOLR_DEV int asint(float f) { return __float_as_int(f); }
 /* lane mask of a predicate, without the int round trip of HIP's ballot(int) */

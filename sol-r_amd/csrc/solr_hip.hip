@@ -81,11 +81,17 @@ struct PixelRecord
 };
 static_assert(sizeof(PixelRecord) == sizeof(PostProcessingBuffer), "PixelRecord layout");
 
-template <bool COUNT, int FEAT>
+/* VOLUME: the instantiations of the volume camera (ctVolumeRendering) - kernels of their own, so that its trace (a
+ * second inlined shader) is not carried, in registers and spills, by every frame of the all-features kernels */
+template <bool COUNT, int FEAT, bool VOLUME = false>
+#ifndef SOLR_GENERIC_WAVES
+#define SOLR_GENERIC_WAVES 0 /* experiments: waves per SIMD the instantiations with the texture tier are compiled for (0: as the
+                             * others; 3 - 168 registers, 1-51 spills instead of 51-176 - measured within 4 % either way) */
+#endif
 #ifndef SOLR_WAVES_PER_EU
 #define SOLR_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(const SceneArgs SA, const FrameArgs F,
+__global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR_GENERIC_WAVES : SOLR_WAVES_PER_EU) void k_standardRenderer(const SceneArgs SA, const FrameArgs F,
                                                            PixelRecord *__restrict__ pp,
                                                            int4 *__restrict__ ids, unsigned char *__restrict__ bitmap,
                                                            unsigned long long *__restrict__ counters)
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
     /* ctVolumeRendering is dispatched to k_volumeRenderer (CRT:1777-1806, 592-713): the frame of the standard
      * renderer around another trace (rt_device.h launchVolumeRendering), with the rotated-grid offset on every pass
      * (CRT:670-671) and ids whose fourth component is left as it was (CRT:59-61) */
-    const bool volume = (FEAT & F_FULL) && (si.cameraType == ctVolumeRendering);
+    constexpr bool volume = VOLUME; /* (the host launches these instantiations for that camera and no other) */
     int4 id = make_int4(0, 0, 0, 0);
     bool active = inside;
     const bool refinementPass = si.pathTracingIteration > 0 && si.pathTracingIteration <= NB_MAX_ITERATIONS;
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_standardRenderer(co
             }
         }
         v3 c;
-        if (volume)
+        if constexpr (volume)
         {
             c = launchVolumeRendering<COUNT, FEAT>(S, active, gindex, rO, rD, si, F.ppi, id, cs, cnt);
             c = V(0.f + c.x, 0.f + c.y, 0.f + c.z);
@@ -2453,12 +2459,13 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     };
     /* a list of more than a thousand nodes does not live in the scalar cache: skips land on cold records */
     const bool deepList = S.nbBoxes > 1024;
-    KernelFn fn = k_standardRenderer<true, F_ALL>;
+    const bool volumeCamera = sceneInfo.cameraType == ctVolumeRendering;
+    KernelFn fn = volumeCamera ? k_standardRenderer<true, F_ALL, true> : k_standardRenderer<true, F_ALL>;
     if (!counting)
     {
-        fn = k_standardRenderer<false, F_ALL | F_DEEP>;
+        fn = volumeCamera ? k_standardRenderer<false, F_ALL | F_DEEP, true> : k_standardRenderer<false, F_ALL | F_DEEP>;
         for (const auto &v : variants)
-            if ((need & ~v.features) == 0 && g.variant != 4)
+            if ((need & ~v.features) == 0 && g.variant != 4 && !volumeCamera)
             {
                 fn = deepList ? v.deep : v.shallow;
                 break;
