@@ -2454,6 +2454,11 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         {F_SPHERE | F_CYL, k_standardRenderer<false, F_SPHERE | F_CYL>, k_standardRenderer<false, F_SPHERE | F_CYL | F_DEEP>},
         {F_SPHERE | F_PLANE | F_TRI | F_CYL, k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_DEEP>,
          k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_DEEP>},
+        /* textured scenes of the usual primitives (OBJ meshes with their MTL images; a textured room): the texture tier
+         * without the procedural spheres and the ellipsoids */
+        {F_SPHERE | F_TRI | F_TEX, k_standardRenderer<false, F_SPHERE | F_TRI | F_TEX>, k_standardRenderer<false, F_SPHERE | F_TRI | F_TEX | F_DEEP>},
+        {F_SPHERE | F_PLANE | F_TRI | F_CYL | F_TEX, k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_TEX | F_DEEP>,
+         k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_TEX | F_DEEP>},
         {F_ALL & ~F_FULL, k_standardRenderer<false, (F_ALL & ~F_FULL) | F_DEEP>, k_standardRenderer<false, (F_ALL & ~F_FULL) | F_DEEP>},
         {F_ALL, k_standardRenderer<false, F_ALL | F_DEEP>, k_standardRenderer<false, F_ALL | F_DEEP>},
     };
