@@ -2459,6 +2459,10 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         {F_SPHERE | F_TRI | F_TEX, k_standardRenderer<false, F_SPHERE | F_TRI | F_TEX>, k_standardRenderer<false, F_SPHERE | F_TRI | F_TEX | F_DEEP>},
         {F_SPHERE | F_PLANE | F_TRI | F_CYL | F_TEX, k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_TEX | F_DEEP>,
          k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_TEX | F_DEEP>},
+        /* the special cameras, global illumination and the box-debug view over the usual untextured primitives (the
+         * texture tier is what costs the registers: profiles/r3/generic_kernels.txt) */
+        {F_SPHERE | F_PLANE | F_TRI | F_CYL | F_FULL, k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_FULL | F_DEEP>,
+         k_standardRenderer<false, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_FULL | F_DEEP>},
         {F_ALL & ~F_FULL, k_standardRenderer<false, (F_ALL & ~F_FULL) | F_DEEP>, k_standardRenderer<false, (F_ALL & ~F_FULL) | F_DEEP>},
         {F_ALL, k_standardRenderer<false, F_ALL | F_DEEP>, k_standardRenderer<false, F_ALL | F_DEEP>},
     };
