@@ -2439,6 +2439,9 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         need = F_TRI | (g.sceneFeatures & F_TEX);
     if (full)
         need |= F_FULL;
+    /* SOLR_HIP_FORCE_FEATURES=mask (experiments, rt_device.h enum Feature): as if the scene had these features too */
+    static const int forced = getenv("SOLR_HIP_FORCE_FEATURES") ? atoi(getenv("SOLR_HIP_FORCE_FEATURES")) & F_ALL : 0;
+    need |= forced;
     if (sceneInfo.skyboxMaterialId >= 0 && sceneInfo.skyboxMaterialId < (int)g.materialTags.size() &&
         (g.materialTags[sceneInfo.skyboxMaterialId] & PRIM_TEXTURED))
         need |= F_TEX;
