@@ -923,6 +923,7 @@ struct Counters
     /* development build (make EXTRA_HIPFLAGS=-DSOLR_TIMING, tools/wave_time_split.py): shader-clock cycles a wave
      * spends in the node loop, at leaves, in either walk as a whole, and how often */
     unsigned long long tNode, tLeaf, tClosest, tShadow;
+    unsigned long long tShade, tTrace; /* primitiveShader (its shadow walks included), launchRayTracing as a whole */
     unsigned int nAdvance, nLeaf;
 #endif
 };
@@ -2110,6 +2111,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
                             int objectId, v3 intersection, v3 areas, v3 &closestColor, int iteration,
                             float &shadowIntensity, v3 &totalBlinn, float4 &attributes, Counters &cnt)
 {
+    SOLR_T(const unsigned long long tShade0 = SOLR_NOW();)
     const int pi = active ? objectId : 0;
     const int type = asint(primRow(S, pi, ROW_P0_TYPE).w) & PRIM_TYPE_MASK; /* row 0 carries type + material facts */
     const int materialId = asint(primRow(S, pi, ROW_SIZE_MAT).w);
@@ -2240,6 +2242,7 @@ SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneI
     else if (shade)
         closestColor = intersectionColor;
 
+    SOLR_T(cnt.tShade += SOLR_NOW() - tShade0;)
     return wire ? intersectionColor : closestColor;
 }
 
@@ -2371,6 +2374,7 @@ template <bool COUNT, int FEAT>
 SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3 rayD, const SceneInfo &si,
                              float &depthOfField, int4 &primitiveXYId, const ColorStack &cs, Counters &cnt)
 {
+    SOLR_T(const unsigned long long tTrace0 = SOLR_NOW();)
     v3 intersectionColor = V(0.f, 0.f, 0.f);
     v3 closestIntersection = V(0.f, 0.f, 0.f);
     v3 normal = V(0.f, 0.f, 0.f);
@@ -2745,6 +2749,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
     primitiveXYId.x = idX;
     primitiveXYId.z = idZ;
     primitiveXYId.w = idW;
+    SOLR_T(cnt.tTrace += SOLR_NOW() - tTrace0;)
     return intersectionColor;
 }
 

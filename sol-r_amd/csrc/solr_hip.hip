@@ -312,6 +312,7 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
             color = color + c;
     }
 
+    SOLR_T(const unsigned long long tEpilogue0 = SOLR_NOW();)
     /* The pixel's coordinates once more, from the wave's tile number and the lane's position in the wave,
      * through values the compiler cannot identify with the ones above: what the prologue computed would
      * otherwise stay alive - in vector registers, in practice in scratch - through the whole path trace
@@ -418,8 +419,11 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
     if (!COUNT && laneAgain == 0 && counters)
     {
         /* one record per workgroup, summed by the host (atomics on one address would serialise the frame) */
-        unsigned long long *slot = counters + 16 + 8ull * blockIdx.x;
+        unsigned long long *slot = counters + 16 + 16ull * blockIdx.x;
         slot[0] += SOLR_NOW() - tKernel0;
+        slot[8] += cnt.tShade;
+        slot[9] += cnt.tTrace;
+        slot[10] += SOLR_NOW() - tEpilogue0;
         slot[1] += cnt.tClosest;
         slot[2] += cnt.tShadow;
         slot[3] += cnt.tNode;
@@ -1592,7 +1596,7 @@ void allocateFrame()
 #ifdef SOLR_TIMING
     if (!g.counters.ptr)
     {
-        reserve(g.counters, (16 + 8 * SOLR_TIMING_SLOTS) * sizeof(unsigned long long));
+        reserve(g.counters, (16 + 16 * SOLR_TIMING_SLOTS) * sizeof(unsigned long long));
         if (ok())
             HIPCHECK(hipMemset(g.counters.ptr, 0, g.counters.bytes));
     }
@@ -5352,19 +5356,20 @@ void solr_hip_comm_finalize(void)
 #ifdef SOLR_TIMING
 /* development build only (tools/wave_time_split.py): shader-clock cycles summed over the waves of every frame
  * since the last reset - [0] whole kernel, [1] closest-hit walks, [2] shadow walks, [3] node loop, [4] leaves,
- * [5] calls of the node loop, [6] leaf visits, [7] waves */
-void solr_hip_wave_cycles(unsigned long long out[8], int reset)
+ * [5] calls of the node loop, [6] leaf visits, [7] waves, [8] primitiveShader (its shadow walks included), [9] launchRayTracing,
+ * [10] from the end of the trace to the end of the kernel */
+void solr_hip_wave_cycles(unsigned long long out[16], int reset)
 {
     (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> slots(8 * SOLR_TIMING_SLOTS);
+    std::vector<unsigned long long> slots(16 * SOLR_TIMING_SLOTS);
     (void)hipMemcpy(slots.data(), (unsigned long long *)g.counters.ptr + 16, slots.size() * sizeof(unsigned long long),
                     hipMemcpyDeviceToHost);
     if (out)
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 16; ++k)
         {
             out[k] = 0;
             for (size_t w = 0; w < SOLR_TIMING_SLOTS; ++w)
-                out[k] += slots[8 * w + k];
+                out[k] += slots[16 * w + k];
         }
     if (reset)
         (void)hipMemset((unsigned long long *)g.counters.ptr + 16, 0, slots.size() * sizeof(unsigned long long));

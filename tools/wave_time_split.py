@@ -25,7 +25,7 @@ getattr(solr.scenes, a.scene)(k, **kw)
 hip.solr_hip_set_frames_in_flight(1)
 for _ in range(4):
     k.render()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 hip.solr_hip_wave_cycles(out, 1)
 import time
 hip.solr_hip_synchronize()
@@ -35,7 +35,7 @@ for _ in range(a.frames):
 hip.solr_hip_synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / a.frames
 hip.solr_hip_wave_cycles(out, 1)
-total, closest, shadow, node, leaf, nadv, nleaf, waves = [float(v) for v in out]
+total, closest, shadow, node, leaf, nadv, nleaf, waves, shade, trace, epilogue = [float(v) for v in out][:11]
 k.finalize()
 per = lambda v: v / waves  # noqa: E731
 print("scene %s %dx%d: %d waves per frame, %.3f ms per frame in this build; shader-clock cycles per wave" % (a.scene, a.width, a.height, waves / a.frames, ms))
@@ -46,3 +46,7 @@ print("    node loop            %9.0f  %5.1f %%   %6.1f calls per wave, %6.0f cy
 print("    leaves               %9.0f  %5.1f %%   %6.1f visits per wave, %6.0f cycles per visit" % (per(leaf), 100 * leaf / total, per(nleaf), leaf / max(nleaf, 1)))
 print("    walk set-up          %9.0f  %5.1f %%" % (per(closest + shadow - node - leaf), 100 * (closest + shadow - node - leaf) / total))
 print("  shading, camera, output %8.0f  %5.1f %%" % (per(total - closest - shadow), 100 * (total - closest - shadow) / total))
+print("    primitiveShader without its shadow walks %8.0f  %5.1f %%" % (per(shade - shadow), 100 * (shade - shadow) / total))
+print("    the rest of launchRayTracing (bounce bookkeeping, sky, blend) %8.0f  %5.1f %%" % (per(trace - closest - shade), 100 * (trace - closest - shade) / total))
+print("    camera set-up (kernel start to the trace) %8.0f  %5.1f %%" % (per(total - trace - epilogue), 100 * (total - trace - epilogue) / total))
+print("    stores and the rest (end of the trace to the end) %8.0f  %5.1f %%" % (per(epilogue), 100 * epilogue / total))
