@@ -64,8 +64,13 @@ struct FrameArgs
 /* An entry of the launch order: the tile in bits 0-27, and in bits 28-30 which part of it this wave renders -
  * 0 the whole 8 x 8 tile, 1-4 one of its 4 x 4 quadrants (the few most expensive tiles are rendered by four
  * waves, see k_orderTiles).  ORDER_NOTHING pads the list to its fixed length. */
-#define ORDER_TILE_MASK 0x0fffffffu
-#define ORDER_PART_SHIFT 28
+#define ORDER_TILE_MASK 0x03ffffffu
+#define ORDER_PART_SHIFT 26
+/* a split tile is rendered by (2^SOLR_SPLIT_LOG2)^2 waves: 1 = four 4 x 4 quadrants, 2 = sixteen 2 x 2 blocks (experiments) */
+#ifndef SOLR_SPLIT_LOG2
+#define SOLR_SPLIT_LOG2 1
+#endif
+#define SPLIT_PARTS (1 << (2 * SOLR_SPLIT_LOG2))
 #define ORDER_NOTHING 0xffffffffu
 #define SOLR_TIMING_SLOTS (160000ul) /* timing build: workgroups of the largest frame it is used on (3840 x 2160 + split tiles) */
 #define SPLIT_TILES_MAX 256
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
     if (entry == ORDER_NOTHING)
         return;
     const int tile = (int)min(entry & ORDER_TILE_MASK, (unsigned)F.nbTiles - 1u);
-    const int part = (int)((entry >> ORDER_PART_SHIFT) & 7u); /* 0: the whole tile, 1-4: one 4 x 4 quadrant */
+    const int part = (int)((entry >> ORDER_PART_SHIFT) & 31u); /* 0: the whole tile, 1 ... SPLIT_PARTS: one of its square parts */
     unsigned long long clock0 = 0ull;
     if (F.tileClock || F.tileCost)
         clock0 = __builtin_amdgcn_s_memrealtime();
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
     const int W = si.size.x;
     /* a quadrant wave: only the lanes of its quadrant take part; every lane's path is its own (the walks are
      * wave-synchronous, not wave-dependent), so the pixels come out the same whichever wave renders them */
-    const bool mine = part == 0 || (((lane >> 2) & 1) | ((lane >> 5) << 1)) == part - 1;
+    const bool mine = part == 0 || ((((lane & 7) >> (3 - SOLR_SPLIT_LOG2)) | ((lane >> 3) >> (3 - SOLR_SPLIT_LOG2)) << SOLR_SPLIT_LOG2)) == part - 1;
     const bool inside = mine && (x < W) && (yLocal < F.nbRows);
     const int index0 = inside ? yLocal * W + x : 0;
     const int yGlobal = F.firstRow + yLocal;
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
          * as twice its own time, a split tile stays among the expensive ones and stays split (four waves write
          * the same word; any of them will do) */
         const unsigned cost = (unsigned)(__builtin_amdgcn_s_memrealtime() - clock0);
-        F.tileCost[tileAgain] = partAgain ? 2u * cost : cost;
+        F.tileCost[tileAgain] = partAgain ? (unsigned)(SOLR_SPLIT_LOG2 + 1) * cost : cost;
     }
 #ifdef SOLR_TIMING
     if (!COUNT && laneAgain == 0 && counters)
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
         nbSplit = splitClass < 64u ? scan[1023 - (splitClass << 4)] : 0u;
     __syncthreads();
     const unsigned split = nbSplit;
-    for (int i = n + 3 * (int)split + t; i < n + 3 * SPLIT_TILES_MAX; i += 1024)
+    for (int i = n + (SPLIT_PARTS - 1) * (int)split + t; i < n + (SPLIT_PARTS - 1) * SPLIT_TILES_MAX; i += 1024)
         order[i] = ORDER_NOTHING;
     for (int base = 0; base < n; base += BATCH * 1024)
     {
@@ -748,10 +753,10 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
                 const unsigned b = (min(63u, (unsigned)((float)c[k] * toClass)) << 4) | ((unsigned)i & 15u);
                 const unsigned at = atomicAdd(&bins[b], 1u); /* position in descending order of cost */
                 if (at < split)
-                    for (unsigned q = 0; q < 4u; ++q)
-                        order[4u * at + q] = (unsigned)i | ((q + 1u) << ORDER_PART_SHIFT);
+                    for (unsigned q = 0; q < (unsigned)SPLIT_PARTS; ++q)
+                        order[(unsigned)SPLIT_PARTS * at + q] = (unsigned)i | ((q + 1u) << ORDER_PART_SHIFT);
                 else
-                    order[at + 3u * split] = (unsigned)i;
+                    order[at + (unsigned)(SPLIT_PARTS - 1) * split] = (unsigned)i;
             }
         }
     }
@@ -2363,7 +2368,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             for (DeviceBuffer *b : {&g.tileCost, &g.tileCostSnapshot, &g.tileOrder, &g.tileOrder2})
             {
                 const void *before = b->ptr;
-                reserve(*b, ((size_t)grid.x + 3 * SPLIT_TILES_MAX) * sizeof(unsigned));
+                reserve(*b, ((size_t)grid.x + (SPLIT_PARTS - 1) * SPLIT_TILES_MAX) * sizeof(unsigned));
                 if (ok() && b->ptr != before)
                     HIPCHECK(hipMemset(b->ptr, 0, b->bytes));
             }
@@ -2492,7 +2497,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     /* the ordered launch has a fixed number of extra workgroups for the quadrant waves of split tiles
      * (k_orderTiles); the ones the order does not use return at once */
     F.nbTiles = (int)grid.x;
-    const dim3 launchGrid(F.tileOrder ? grid.x + 3u * SPLIT_TILES_MAX : grid.x);
+    const dim3 launchGrid(F.tileOrder ? grid.x + (unsigned)(SPLIT_PARTS - 1) * SPLIT_TILES_MAX : grid.x);
     hipLaunchKernelGGL(fn, launchGrid, block, ldsBytes, stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
     HIPCHECK(hipGetLastError());
     if (e0)
