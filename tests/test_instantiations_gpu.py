@@ -1,0 +1,62 @@
+"""Every instantiation of the renderer kernel on the same scene: the host launches the smallest one that covers a
+scene's primitive types, textures and camera (solr_hip.hip, the `variants` ladder), so a plain scene only ever runs
+the lean ones.  SOLR_HIP_FORCE_FEATURES=mask (read once per process) makes the engine choose as if the scene had
+those features too: the Cornell box and a molecule through each step of the ladder must be the frame the oracle
+renders - ids exact, RGB8 exact, float colour <= 1 ULP - and the same bits as through their own kernel."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CHILD = r"""
+import importlib, json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+solr = importlib.import_module("sol-r_amd")
+from oracle import loader
+from helpers import compare_frames, gpu_frame, oracle_frame
+loader.lib().oracle_set_rounded_transcendentals(1)
+out = {}
+for name, build, kw in (("cornell", solr.scenes.cornell, dict(width=96, height=64, iterations=3)),
+                        ("molecule", solr.scenes.molecule, dict(atoms=400, width=96, height=64))):
+    k = solr.Kernel(engine="hip")
+    build(k, **kw)
+    pp, ids, rgb = gpu_frame(k)
+    opp, oids, orgb, counts, status = oracle_frame(k, loader)
+    res = compare_frames(pp, ids, rgb, opp, oids, orgb)
+    res["status"] = int(status)
+    res["digest"] = [int(pp.view(np.uint32).sum(dtype=np.uint64)), int(ids.astype(np.int64).sum()), int(rgb.astype(np.int64).sum())]
+    out[name] = res
+    k.finalize()
+print(json.dumps(out))
+"""
+
+# rt_device.h enum Feature: SPHERE 1, PROC 2, CYL 4, ELL 8, TRI 16, PLANE 32, TEX 64, FULL 128
+LADDER = {"the scene's own": 0, "sphere + plane + triangle + cylinder": 53, "textured sphere + triangle": 81, "the textured mix": 117,
+          "the untextured mix with the special cameras": 181, "every type + textures": 127, "everything": 255}
+
+
+def _run(mask):
+    env = dict(os.environ, SOLR_HIP_FORCE_FEATURES=str(mask))
+    code = CHILD % {"root": os.path.dirname(HERE), "here": HERE}
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return json.loads(res.stdout.strip().splitlines()[-1])
+
+
+@pytest.fixture(scope="module")
+def own():
+    return _run(0)
+
+
+@pytest.mark.parametrize("name", list(LADDER))
+def test_every_instantiation_renders_the_oracles_frame(own, name):
+    got = own if LADDER[name] == 0 else _run(LADDER[name])
+    for scene, res in got.items():
+        assert res["status"] == 0 and res["ids_all_equal"] and res["rgb_equal"] and res["max_ulp"] <= 1 and res["depth_max_ulp"] == 0, (scene, res)
+        assert res["digest"] == own[scene]["digest"], (scene, "not the bits of the scene's own kernel")
