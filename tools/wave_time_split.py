@@ -21,7 +21,12 @@ k = solr.Kernel(engine="hip")
 kw = dict(width=a.width, height=a.height)
 if a.iterations is not None:
     kw["iterations"] = a.iterations
-getattr(solr.scenes, a.scene)(k, **kw)
+if hasattr(solr.scenes, a.scene):
+    getattr(solr.scenes, a.scene)(k, **kw)
+else:           # the test scenes: textured, primitives_mix, triangles_only, sticks ...
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import scenes_extra
+    getattr(scenes_extra, a.scene)(k, **kw)
 hip.solr_hip_set_frames_in_flight(1)
 for _ in range(4):
     k.render()
