@@ -132,6 +132,8 @@ def _populate(k, kernel, rng, u, pick, mats, textures, n, span):
     return k
 
 if __name__ == "__main__":
+    if os.environ.get("SOLR_ORACLE_ROUNDED_TRANSCENDENTALS"):   # sin / cos / atan2 / asin / pow through binary64, as the engine takes them
+        loader.lib().oracle_set_rounded_transcendentals(1)
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1, 40)
     bad = free_lists = free_shadows = 0
     for seed in range(first, first + count):
