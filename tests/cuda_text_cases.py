@@ -163,6 +163,8 @@ def large_randoms(flat):
 
 CASES["volume camera (CRT:592-713, GI:1088-1265), passes 0-12"] = (cornell, dict(cameraType=M.ctVolumeRendering, iterations=1),
                                                                     PP(0, 3000.0, 8.0), [0, 1, 2, 10, 11, 12])
+CASES["volume camera, hits nearer than the threshold left out (GI:1170)"] = (cornell, dict(cameraType=M.ctVolumeRendering, iterations=1),
+                                                                             PP(0, 15500.0, 6.0), [0])
 CASES["volume camera, every primitive type, no threshold"] = (mix, dict(cameraType=M.ctVolumeRendering), PP(0, 0.0, 5.0), [0])
 CASES["volume camera without shading (GI:1174)"] = (mix, dict(cameraType=M.ctVolumeRendering, graphicsLevel=M.glNoShading),
                                                     PP(0, 0.0, 5.0), [0])
