@@ -78,6 +78,8 @@ def lib():
         L.oracle_vector_rotation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_make_color.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_set_misround_mask.argtypes = [C.c_void_p, C.c_long]
+        L.oracle_set_misround_mask.restype = None
         _lib = L
     return _lib
 
@@ -115,11 +117,13 @@ def _f(a):
 
 
 def render(flat, scene_info, pp_info, eye, direction, angles, first_row=0, nb_rows=None, pp=None, ids=None,
-           nthreads=0):
+           nthreads=0, misround=None):
     """oracle_render for rows [first_row, first_row + nb_rows).
 
     scene_info / pp_info are ctypes structures laid out like include/solr_types.h.
     Returns (pp (rows, W, 8) float32, ids (rows, W, 4) int32, bitmap (rows, W, 3) uint8, counts[4], status).
+    misround: a zeroed (rows, W) uint8 array that receives, per pixel, bit 0 where a powf and bit 1 where a
+    sinf / cosf / atan2f / asinf of that pixel was not the correctly rounded value (oracle_set_misround_mask).
     """
     L = lib()
     s = Scene(flat)
@@ -130,9 +134,16 @@ def render(flat, scene_info, pp_info, eye, direction, angles, first_row=0, nb_ro
     bitmap = np.zeros((rows, w, 3), np.uint8)
     counts = (C.c_ulonglong * 4)()
     eye, direction, angles = _f(eye), _f(direction), _f(angles)
-    status = L.oracle_render(C.byref(s.c), C.addressof(scene_info), C.addressof(pp_info), eye.ctypes.data,
-                             direction.ctypes.data, angles.ctypes.data, first_row, rows, pp.ctypes.data,
-                             ids.ctypes.data, bitmap.ctypes.data, C.addressof(counts), nthreads)
+    if misround is not None:
+        assert misround.dtype == np.uint8 and misround.shape == (rows, w) and misround.flags.c_contiguous
+        L.oracle_set_misround_mask(C.c_void_p(misround.ctypes.data), C.c_long(rows * w))
+    try:
+        status = L.oracle_render(C.byref(s.c), C.addressof(scene_info), C.addressof(pp_info), eye.ctypes.data,
+                                 direction.ctypes.data, angles.ctypes.data, first_row, rows, pp.ctypes.data,
+                                 ids.ctypes.data, bitmap.ctypes.data, C.addressof(counts), nthreads)
+    finally:
+        if misround is not None:
+            L.oracle_set_misround_mask(None, C.c_long(0))
     return pp, ids, bitmap, [int(c) for c in counts], status
 
 

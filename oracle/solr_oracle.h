@@ -109,6 +109,11 @@ void oracle_set_dialect(int openclEngine);
  * specified to an error bound only); off by default = libm's binary32 routines */
 void oracle_set_rounded_transcendentals(int on);
 int oracle_get_rounded_transcendentals(void);
+/* mask: one byte per pixel of the strip the next oracle_render calls render (NULL ends it).  While set and the
+ * transcendentals are libm's, every powf (bit 0) and sinf / cosf / atan2f / asinf (bit 1) is also evaluated in
+ * binary64 and rounded once; a pixel whose libm result is not that value gets the bit.  tests/: the pixels where
+ * the engine may be a second ULP from the oracle as pinned are exactly such pixels, and they are counted. */
+void oracle_set_misround_mask(unsigned char *mask, long n);
 int oracle_get_dialect(void);
 /* batched function-level entry points (oracle_probe_*) and oracle_postprocess: see the end of solr_oracle.c
  * and oracle/probes.py */

@@ -6,15 +6,18 @@ cfg3  molecule, 50 000 atoms = 100k spheres + cylinders, 1920 x 1080, 3 bounces 
 cfg4  3840 x 2160, passes 0...73 (10 refinement + 64 accumulated samples), natural depth of field + the
       ambient-occlusion post-process - beyond the reference's 1920 x 1080 limit
 
-The engine renders the full frame; the oracle - minutes per full frame of the large scenes on this box's CPU
-share - renders 36 full rows spread over the frame (oracle.render(first_row, nb_rows), the same strip
-interface the multi-GPU split uses) and those rows must be what the engine produced: primitive ids exact,
-first-hit depth exact, RGB8 exact, float colour within 1 ULP.  Each configuration runs in the engine's
-default form (order-free lists for the primary rays, walk-order node list with grouping nodes for the rest,
-automatic tile order), with every walk in the reference's order (variant 6: the whole frame must be the default
-form's bit for bit), with the reference's own node list (variant 3), without grouping nodes (variant 5), and with
-two frames in flight under the forced cost-ordered launch.  cfg4 walks row strips through all 74 passes on both sides (every pass reads what the
-pass before left in the frame buffers) and ties the full-size frame to those strips.
+The engine renders the full frame and so does the oracle (seconds on the box's cores): EVERY pixel of the 1080p
+frames of cfg1-cfg3 is compared with the oracle as pinned - libm's binary32 powf, not the engine's correctly rounded
+power: primitive ids exact, first-hit depth exact, RGB8 exact, float colour within 1 ULP, except on a counted
+handful of pixels per frame (MAX_EXCEPTIONS) which are at most 2 ULP / one RGB8 step off and which the oracle
+itself shows to have gone through a powf result that is not the correctly rounded value (helpers.
+assert_parity_pinned).  Each configuration runs in the engine's default form (order-free lists for the primary
+rays, walk-order node list with grouping nodes for the rest, automatic tile order), with every walk in the
+reference's order (variant 6: the whole frame must be the default form's bit for bit), with the reference's own
+node list (variant 3), without grouping nodes (variant 5), and with two frames in flight under the forced
+cost-ordered launch - all of them against the whole oracle frame.  cfg4 walks row strips through all 74 passes on
+both sides and ties the full-size frame to those strips; every pass is held to 1 ULP against the oracle's pass over
+the ENGINE's previous buffers, and to 2 ULP against the oracle's own running sum.
 """
 import ctypes as C
 import importlib
@@ -22,12 +25,12 @@ import importlib
 import numpy as np
 import pytest
 
-from helpers import assert_parity, compare_frames, device_frame
+from helpers import assert_parity, assert_parity_pinned, compare_frames, device_frame
 
 solr_mod = importlib.import_module("sol-r_amd")
 
 W, H = 1920, 1080
-ROWS = [15 + 30 * i for i in range(36)]      # 36 rows, every 30th, from row 15 to row 1065
+MAX_EXCEPTIONS = 24      # pixels of a 2 073 600-pixel frame that may be 2 ULP off, each behind a mis-rounded powf
 
 
 def _frame_args(solr, k):
@@ -43,27 +46,20 @@ def _render(solr, args):
     solr.hip_lib().solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
 
 
-def _oracle_rows(oracle, args, rows, nthreads=0):
+def _oracle_frame(oracle, args):
+    """the whole frame by the oracle as pinned, and which of its pixels met a mis-rounded libm result"""
     flat, si, ppi, eye, direction, angles, _ = args
-    out = {}
-    scene = None
-    for row in rows:
-        opp, oids, orgb, counts, status = oracle.render(flat, si, ppi, eye, direction, angles, first_row=row, nb_rows=1,
-                                                        nthreads=nthreads)
-        assert status == 0
-        out[row] = (opp[0], oids[0], orgb[0])
-    return out
+    assert not oracle.lib().oracle_get_rounded_transcendentals()
+    misround = np.zeros((si.size_y, si.size_x), np.uint8)
+    opp, oids, orgb, counts, status = oracle.render(flat, si, ppi, eye, direction, angles, misround=misround)
+    assert status == 0
+    return (opp, oids, orgb), misround
 
 
-def _check_rows(frame, expected, what):
-    pp, ids, rgb = frame
-    rows = sorted(expected)
-    epp = np.stack([expected[r][0] for r in rows])
-    eids = np.stack([expected[r][1] for r in rows])
-    ergb = np.stack([expected[r][2] for r in rows])
-    res = compare_frames(pp[rows], ids[rows], rgb[rows], epp, eids, ergb)
-    res["what"] = what
-    assert_parity(res)
+def _check_frame(frame, expected, what, worst=None):
+    res = assert_parity_pinned(frame, expected[0], expected[1], MAX_EXCEPTIONS, what)
+    if worst is not None and res["pixels_outside_the_bar"] >= worst.get("pixels_outside_the_bar", 0):
+        worst.update(res)
     return res
 
 
@@ -76,7 +72,7 @@ CONFIGS = {
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("config", list(CONFIGS))
-def test_full_size_frames_match_the_oracle_on_rows_across_the_frame(solr, oracle, config):
+def test_full_size_frames_match_the_oracle_on_every_pixel(solr, oracle, config):
     build, nb_primitives, bounces = CONFIGS[config]
     hip = solr.hip_lib()
     k = solr.Kernel(engine="hip")
@@ -90,16 +86,17 @@ def test_full_size_frames_match_the_oracle_on_rows_across_the_frame(solr, oracle
         assert len(flat.primitives) == nb_primitives and si.nbRayIterations == bounces
         assert (si.size_x, si.size_y) == (W, H)
         si.pathTracingIteration = 0
-        expected = _oracle_rows(oracle, args, ROWS)
-        lit = np.mean([(e[1][:, 0] >= 0).mean() for e in expected.values()])
-        assert lit > 0.2, "the rows hardly see the scene (%.3f)" % lit
+        expected = _oracle_frame(oracle, args)
+        lit = (expected[0][1][..., 0] >= 0).mean()
+        assert lit > 0.2, "the frame hardly sees the scene (%.3f)" % lit
+        worst = {}
 
         # the engine's default form
         hip.solr_hip_set_tile_scheduling(1)
         hip.solr_hip_set_frames_in_flight(1)
         _render(solr, args)
         first = device_frame(solr, si)
-        _check_rows(first, expected, config + " default")
+        _check_frame(first, expected, config + " default", worst)
         assert hip.solr_hip_order_free_nodes() > 0, "primary rays did not walk the order-free lists"
         # ... and the shadow rays where nothing is transparent (the Cornell room has its glass sphere)
         assert hip.solr_hip_order_free_shadows() == (0 if config.startswith("cfg1") else 1)
@@ -108,14 +105,14 @@ def test_full_size_frames_match_the_oracle_on_rows_across_the_frame(solr, oracle
         hip.solr_hip_set_variant(6)
         _render(solr, args)
         ordered = device_frame(solr, si)
-        _check_rows(ordered, expected, config + " variant 6")
+        _check_frame(ordered, expected, config + " variant 6", worst)
         assert np.array_equal(ordered[1], first[1]) and np.array_equal(ordered[2], first[2])
         assert np.array_equal(ordered[0].view(np.uint32), first[0].view(np.uint32))
 
         # the reference's own node list
         hip.solr_hip_set_variant(3)
         _render(solr, args)
-        _check_rows(device_frame(solr, si), expected, config + " variant 3")
+        _check_frame(device_frame(solr, si), expected, config + " variant 3", worst)
 
         # two frames in flight, cost-ordered launch forced: 40 frames so that the order is sorted twice while
         # frames are running (the camera does not move: every frame must be the first one again)
@@ -127,7 +124,7 @@ def test_full_size_frames_match_the_oracle_on_rows_across_the_frame(solr, oracle
         k.check(0, "frames in flight")
         for _ in range(2):                            # the newest frame of either buffer set
             frame = device_frame(solr, si)
-            _check_rows(frame, expected, config + " two frames in flight, cost order")
+            _check_frame(frame, expected, config + " two frames in flight, cost order", worst)
             assert np.array_equal(frame[1], first[1]) and np.array_equal(frame[2], first[2])
             assert np.array_equal(frame[0].view(np.uint32), first[0].view(np.uint32))
             _render(solr, args)
@@ -140,7 +137,8 @@ def test_full_size_frames_match_the_oracle_on_rows_across_the_frame(solr, oracle
         k.render()
         k.check(0, "variant 5")
         _render(solr, args)
-        _check_rows(device_frame(solr, si), expected, config + " variant 5")
+        _check_frame(device_frame(solr, si), expected, config + " variant 5", worst)
+        print(worst)
     finally:
         hip.solr_hip_set_variant(0)
         hip.solr_hip_set_frames_in_flight(1)
@@ -162,15 +160,19 @@ def test_cfg0_whole_frame(solr, oracle):
         assert (si.size_x, si.size_y, si.nbRayIterations) == (512, 512, 1)
         _render(solr, args)
         frame = device_frame(solr, si)
-        # the Blinn power evaluated as the engine evaluates it (binary64, rounded once; glibc's powf is the nearest
-        # float in all but a few results per frame, which would show as 2 ULP on a pixel or two of 262 144)
+        # against the oracle as pinned (glibc's powf): every pixel within the bar but a counted few, each of which
+        # the oracle shows to sit behind a powf result that is not the correctly rounded value
+        expected = _oracle_frame(oracle, args)
+        res = assert_parity_pinned(frame, expected[0], expected[1], 4, "cfg0")
+        print(res)
+        assert (expected[0][1][..., 0] >= 0).mean() > 0.5
+        # and with the power rounded once on both sides there is no exception at all
         oracle.lib().oracle_set_rounded_transcendentals(1)
         opp, oids, orgb, _, status = oracle.render(flat, si, ppi, eye, direction, angles)
         assert status == 0
         res = compare_frames(frame[0], frame[1], frame[2], opp, oids, orgb)
-        res["what"] = "cfg0"
+        res["what"] = "cfg0, pow rounded once on both sides"
         assert_parity(res)
-        assert (oids[..., 0] >= 0).mean() > 0.5
     finally:
         oracle.lib().oracle_set_rounded_transcendentals(0)
         k.finalize()
@@ -208,8 +210,9 @@ def test_cfg4_strips_through_all_74_passes(solr, oracle):
     """3840 x 2160, passes 0...73: refinement passes 1-10 re-render with more bounces, passes 11-73 jitter the
     ray (anti-aliasing grid, natural depth of field from the random buffer, lamp position) and accumulate; the
     ambient-occlusion kernel turns the running sum into the bitmap after every pass.  Engine and oracle walk
-    the same row strips of the full-size frame; every pass is compared (ids exact, RGB8 exact, float colour
-    within 2 ULP of the running sum, as tests/test_gpu_parity.py::test_accumulation_passes)."""
+    the same row strips of the full-size frame; every pass is compared twice: with the oracle's pass over the engine's
+    own previous buffers (ids exact, RGB8 exact, float colour within 1 ULP: the bar), and with the oracle's own
+    running sum (within 2 ULP: a rounding per accumulated sample, tests/test_gpu_parity.py::progressive)."""
     hip = solr.hip_lib()
     k = solr.Kernel(engine="hip")
     _cfg4_scene(solr, k)
@@ -218,6 +221,7 @@ def test_cfg4_strips_through_all_74_passes(solr, oracle):
         for first, rows in STRIPS:
             hip.solr_hip_set_strip(first, rows)
             opp = oids = None
+            previous = None
             for it in PASSES:
                 k.set_scene_info(pathTracingIteration=it, maxPathTracingIterations=74)
                 img = k.render()
@@ -228,6 +232,15 @@ def test_cfg4_strips_through_all_74_passes(solr, oracle):
                 spp = np.zeros((rows, W4, 8), np.float32)
                 hip.solr_hip_d2h_postprocessing(C.c_void_p(spp.ctypes.data))
                 sids = k.primitive_ids()[first:first + rows]
+                if previous is not None:
+                    # this pass alone: the oracle's pass over the ENGINE's previous buffers, held to the bar itself
+                    qpp, qids, qrgb, _, status = oracle.render(flat, si, ppi, eye, direction, angles, first_row=first,
+                                                               nb_rows=rows, pp=previous[0], ids=previous[1])
+                    assert status == 0
+                    one = compare_frames(spp, sids, img[first:first + rows], qpp, qids, qrgb)
+                    one["pass"], one["strip"], one["what"] = it, (first, rows), "one pass over the engine's buffers"
+                    assert_parity(one)
+                previous = (spp.copy(), np.array(sids, copy=True))
                 opp, oids, orgb, _, status = oracle.render(flat, si, ppi, eye, direction, angles, first_row=first,
                                                            nb_rows=rows, pp=opp, ids=oids)
                 assert status == 0, "the oracle read outside the random buffer at pass %d" % it

@@ -151,15 +151,25 @@ def test_textures_without_sphere_uv(solr, oracle, rounded_transcendentals):
 
 
 def progressive(solr, oracle, build, passes, **info):
-    """frames with pathTracingIteration = 0, 1, 2, ...: the engine keeps its buffers on the device, the
-    oracle is handed its own previous frame"""
+    """frames with pathTracingIteration = 0, 1, 2, ...: the engine keeps its buffers on the device.  Every pass is
+    compared twice: with the oracle's pass over the ENGINE's previous buffers - one pass, one rounding of the
+    running sum, held to the bar (<= 1 ULP) right here - and with the oracle handed its own previous frame, whose
+    running sum drifts by a rounding per accumulated sample (the figures returned; callers allow 2 ULP)."""
     k = solr.Kernel(engine="hip")
     build(k, **info)
     opp = oids = None
+    previous = None
     worst = None
     for it in passes:
         k.set_scene_info(pathTracingIteration=it, maxPathTracingIterations=max(passes) + 1)
         pp, ids, rgb = gpu_frame(k)
+        if previous is not None:
+            spp, sids, srgb, _, status = oracle_frame(k, oracle, pp=previous[0], ids=previous[1])
+            assert status == 0
+            seeded = compare_frames(pp, ids, rgb, spp, sids, srgb)
+            seeded["iteration"], seeded["what"] = it, "one pass over the engine's previous buffers"
+            assert_parity(seeded)
+        previous = (pp.copy(), ids.copy())
         opp, oids, orgb, counts, status = oracle_frame(k, oracle, pp=opp, ids=oids)
         assert status == 0, "oracle read outside the random buffer"
         res = compare_frames(pp, ids, rgb, opp, oids, orgb)

@@ -110,10 +110,16 @@ def test_refinement_and_accumulation_passes(solr, oracle):
     solr.scenes.cornell(k, width=96, height=64, iterations=1)
     _volume(k, 2000.0, 10.0)
     opp = oids = None
+    previous = None
     frames = []
     for it in range(0, 14):
         k.set_scene_info(pathTracingIteration=it, maxPathTracingIterations=20)
         pp, ids, rgb = gpu_frame(k)
+        if previous is not None:    # one pass over the engine's previous buffers: the bar itself
+            spp, sids, srgb, _, status = oracle_frame(k, oracle, pp=previous[0], ids=previous[1])
+            assert status == 0
+            assert_parity(compare_frames(pp, ids, rgb, spp, sids, srgb))
+        previous = (pp.copy(), ids.copy())
         opp, oids, orgb, counts, status = oracle_frame(k, oracle, pp=opp, ids=oids)
         assert status == 0
         res = compare_frames(pp, ids, rgb, opp, oids, orgb)
