@@ -2164,6 +2164,24 @@ struct HaloDebt
     }
 };
 
+/* the features a frame of the resident scene needs (rt_device.h, enum Feature): decides the kernel instantiation */
+int neededFeatures(const SceneInfo &sceneInfo, bool full)
+{
+    int need = g.sceneFeatures;
+    if (!sceneInfo.extendedGeometry)
+        /* every primitive is tested as a triangle, GI:743-747 - and textured as one (GI:916-931) */
+        need = F_TRI | (g.sceneFeatures & F_TEX);
+    if (full)
+        need |= F_FULL;
+    /* SOLR_HIP_FORCE_FEATURES=mask (experiments, rt_device.h enum Feature): as if the scene had these features too */
+    static const int forced = getenv("SOLR_HIP_FORCE_FEATURES") ? atoi(getenv("SOLR_HIP_FORCE_FEATURES")) & F_ALL : 0;
+    need |= forced;
+    if (sceneInfo.skyboxMaterialId >= 0 && sceneInfo.skyboxMaterialId < (int)g.materialTags.size() &&
+        (g.materialTags[sceneInfo.skyboxMaterialId] & PRIM_TEXTURED))
+        need |= F_TEX;
+    return need;
+}
+
 void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProcessingInfo &ppInfo,
                 const float origin[3], const float direction[3], const float angles[4], bool counting,
                 unsigned long long counts[8])
@@ -2442,18 +2460,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     int4 *idPtr = (int4 *)flightIds(flight).ptr;
     unsigned long long *cntPtr = (unsigned long long *)g.counters.ptr;
     /* smallest instantiation that covers the scene (rt_device.h, enum Feature) */
-    int need = g.sceneFeatures;
-    if (!sceneInfo.extendedGeometry)
-        /* every primitive is tested as a triangle, GI:743-747 - and textured as one (GI:916-931) */
-        need = F_TRI | (g.sceneFeatures & F_TEX);
-    if (full)
-        need |= F_FULL;
-    /* SOLR_HIP_FORCE_FEATURES=mask (experiments, rt_device.h enum Feature): as if the scene had these features too */
-    static const int forced = getenv("SOLR_HIP_FORCE_FEATURES") ? atoi(getenv("SOLR_HIP_FORCE_FEATURES")) & F_ALL : 0;
-    need |= forced;
-    if (sceneInfo.skyboxMaterialId >= 0 && sceneInfo.skyboxMaterialId < (int)g.materialTags.size() &&
-        (g.materialTags[sceneInfo.skyboxMaterialId] & PRIM_TEXTURED))
-        need |= F_TEX;
+    const int need = neededFeatures(sceneInfo, full);
     typedef void (*KernelFn)(const SceneArgs, const FrameArgs, PixelRecord *, int4 *, unsigned char *,
                              unsigned long long *);
     static const struct
@@ -2623,6 +2630,38 @@ void collectEvents()
     g.events.clear();
 }
 } // namespace
+
+/* For csrc/solr_probes.hip (the test-only entry points of include/solr_hip_probes.h): the resident scene exactly as
+ * renderImpl hands it to the renderer - pending uploads flushed, the order-free lists built when they are due - the
+ * features a frame with this SceneInfo needs, whether the renderer would take the three-bank node loop, and the
+ * engine's stream.  exactNodes: the reference's own node list instead of the walk-order list.  Returns 0, or -1 with
+ * the engine's error set. */
+namespace solrprobe
+{
+int residentScene(const SceneInfo &sceneInfo, bool exactNodes, SceneArgs *S, int *features, int *deepList, hipStream_t *stream)
+{
+    if (!ready("solr_hip_probe"))
+        return -1;
+    quiesce();
+    HIPCHECK(hipSetDevice(g.device));
+    ARGCHECK(g.materials.ptr != nullptr, "solr_hip_probe: no materials uploaded");
+    if (!ok())
+        return -1;
+    checkTextureTables();
+    maybeBuildOrderFreeLists();
+    flushGeometry();
+    if (exactNodes)
+        refreshExactList();
+    if (!ok())
+        return -1;
+    *S = makeScene(exactNodes);
+    *features = neededFeatures(sceneInfo, false);
+    *deepList = S->nbBoxes > 1024;
+    *stream = flightStream(0);
+    return 0;
+}
+void fail(int code, const char *what) { setError(code, what, __FILE__, __LINE__); }
+} // namespace solrprobe
 
 /* ======================================================================= */
 /* C ABI                                                                    */

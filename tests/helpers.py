@@ -80,12 +80,27 @@ def gpu_frame(k):
     return k.postprocessing_buffer(), k.primitive_ids(), rgb
 
 
-def oracle_frame(k, oracle, pp=None, ids=None, first_row=0, nb_rows=None, nthreads=0):
+def oracle_frame(k, oracle, pp=None, ids=None, first_row=0, nb_rows=None, nthreads=0, misround=None):
     flat = k.flat_scene()
     si, ppi, eye, direction, angles = k.frame_parameters()
     opp, oids, orgb, counts, status = oracle.render(flat, si, ppi, eye, direction, angles, first_row=first_row,
-                                                    nb_rows=nb_rows, pp=pp, ids=ids, nthreads=nthreads)
+                                                    nb_rows=nb_rows, pp=pp, ids=ids, nthreads=nthreads,
+                                                    misround=misround)
     return opp, oids, orgb, counts, status
+
+
+def assert_pass_parity(k, oracle, gpu, previous, max_exceptions=2, what="", first_row=0, nb_rows=None):
+    """ONE pass held to the bar: the oracle (as pinned) renders the pass over the ENGINE's previous buffers
+    (`previous` = (pp, ids) of the frame before, None for a first pass), so the running sum of an accumulation takes
+    one rounding on either side; ids, depth exact, RGB8 exact, float colour and last sample <= 1 ULP but for the
+    counted pixels behind a mis-rounded libm result (assert_parity_pinned)."""
+    rows = gpu[0].shape[0]
+    misround = np.zeros((rows, gpu[0].shape[1]), np.uint8)
+    pp, ids = (None, None) if previous is None else previous
+    opp, oids, orgb, _, status = oracle_frame(k, oracle, pp=pp, ids=ids, first_row=first_row, nb_rows=nb_rows,
+                                              misround=misround)
+    assert status == 0, "the oracle read outside the random buffer"
+    return assert_parity_pinned(gpu, (opp, oids, orgb), misround, max_exceptions, what)
 
 
 def f3(*v):

@@ -217,6 +217,7 @@ def test_cfg4_strips_through_all_74_passes(solr, oracle):
     k = solr.Kernel(engine="hip")
     _cfg4_scene(solr, k)
     worst = {"max_ulp": 0}
+    exceptions = 0
     try:
         for first, rows in STRIPS:
             hip.solr_hip_set_strip(first, rows)
@@ -234,12 +235,15 @@ def test_cfg4_strips_through_all_74_passes(solr, oracle):
                 sids = k.primitive_ids()[first:first + rows]
                 if previous is not None:
                     # this pass alone: the oracle's pass over the ENGINE's previous buffers, held to the bar itself
+                    # (as pinned: the few pixels behind a powf result that is not the correctly rounded value are counted)
+                    misround = np.zeros((rows, W4), np.uint8)
                     qpp, qids, qrgb, _, status = oracle.render(flat, si, ppi, eye, direction, angles, first_row=first,
-                                                               nb_rows=rows, pp=previous[0], ids=previous[1])
+                                                               nb_rows=rows, pp=previous[0], ids=previous[1],
+                                                               misround=misround)
                     assert status == 0
-                    one = compare_frames(spp, sids, img[first:first + rows], qpp, qids, qrgb)
-                    one["pass"], one["strip"], one["what"] = it, (first, rows), "one pass over the engine's buffers"
-                    assert_parity(one)
+                    one = assert_parity_pinned((spp, sids, img[first:first + rows]), (qpp, qids, qrgb), misround, 2,
+                                               "pass %d of strip %s over the engine's buffers" % (it, (first, rows)))
+                    exceptions += one["pixels_outside_the_bar"]
                 previous = (spp.copy(), np.array(sids, copy=True))
                 opp, oids, orgb, _, status = oracle.render(flat, si, ppi, eye, direction, angles, first_row=first,
                                                            nb_rows=rows, pp=opp, ids=oids)
@@ -254,7 +258,8 @@ def test_cfg4_strips_through_all_74_passes(solr, oracle):
     finally:
         hip.solr_hip_set_strip(0, -1)
         k.finalize()
-    print(worst)
+    print(worst, "pixels behind a mis-rounded powf outside the bar, all passes:", exceptions)
+    assert exceptions <= 16          # of 74 passes x 30 rows x 3 840 pixels
 
 
 @pytest.mark.gpu

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import scenes_extra as X
-from helpers import assert_parity, compare_frames, device_frame, gpu_frame, oracle_frame
+from helpers import assert_parity, assert_pass_parity, compare_frames, device_frame, gpu_frame, oracle_frame
 
 pytestmark = pytest.mark.gpu
 solr_mod = importlib.import_module("sol-r_amd")
@@ -164,11 +164,7 @@ def progressive(solr, oracle, build, passes, **info):
         k.set_scene_info(pathTracingIteration=it, maxPathTracingIterations=max(passes) + 1)
         pp, ids, rgb = gpu_frame(k)
         if previous is not None:
-            spp, sids, srgb, _, status = oracle_frame(k, oracle, pp=previous[0], ids=previous[1])
-            assert status == 0
-            seeded = compare_frames(pp, ids, rgb, spp, sids, srgb)
-            seeded["iteration"], seeded["what"] = it, "one pass over the engine's previous buffers"
-            assert_parity(seeded)
+            assert_pass_parity(k, oracle, (pp, ids, rgb), previous, what="pass %d over the engine's previous buffers" % it)
         previous = (pp.copy(), ids.copy())
         opp, oids, orgb, counts, status = oracle_frame(k, oracle, pp=opp, ids=oids)
         assert status == 0, "oracle read outside the random buffer"

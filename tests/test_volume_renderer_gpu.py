@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import scenes_extra as X
-from helpers import assert_parity, compare_frames, gpu_frame, oracle_frame
+from helpers import assert_parity, assert_pass_parity, compare_frames, gpu_frame, oracle_frame
 
 pytestmark = pytest.mark.gpu
 solr_mod = importlib.import_module("sol-r_amd")
@@ -116,9 +116,7 @@ def test_refinement_and_accumulation_passes(solr, oracle):
         k.set_scene_info(pathTracingIteration=it, maxPathTracingIterations=20)
         pp, ids, rgb = gpu_frame(k)
         if previous is not None:    # one pass over the engine's previous buffers: the bar itself
-            spp, sids, srgb, _, status = oracle_frame(k, oracle, pp=previous[0], ids=previous[1])
-            assert status == 0
-            assert_parity(compare_frames(pp, ids, rgb, spp, sids, srgb))
+            assert_pass_parity(k, oracle, (pp, ids, rgb), previous, what="volume camera, pass %d" % it)
         previous = (pp.copy(), ids.copy())
         opp, oids, orgb, counts, status = oracle_frame(k, oracle, pp=opp, ids=oids)
         assert status == 0
