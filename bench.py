@@ -2,23 +2,33 @@
 """bench.py - Mrays/s of the Sol-R per-pixel rendering path on MI355X.
 
 Workload (BASELINE.json configs[1]): Cornell box, 1920x1080, 3 reflection bounces +
-shadow rays, synthetic scene from sol-r_amd/scenes.py.  One "step" = one frame:
+shadow rays, synthetic scene from sol-r_amd/scenes.py.  One "step" = one frame DELIVERED:
 k_standardRenderer over this rank's row strip (scene resident in HBM, uploaded before
-the timed region) and, for N > 1, the RCCL gather of the RGB strips to rank 0.
+the timed region), for N > 1 the RCCL gather of the RGB strips to rank 0, and the frame's image copied to a
+page-locked host image behind it (copy stream; the host takes the image of the frame `frames in flight - 1` back
+while the newer ones render - what HipKernel::setFramesInFlight does for the reference's render_begin / render_end).
+The primitive ids stay on the device until picking asks (d2h_bitmap).
 
   python bench.py --gpus 1 --steps 200 --warmup 3
   python bench.py --gpus N ...                      (bare: starts its own N rank processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Timing: W warm-up steps, then the timed region - EXACTLY K steps between barrier + synchronisation on both sides, the
+last image on the host when it ends, no event or other instrument inside it - is run R >= 25 times back to back (as
+many as keep the GPU busy for 0.2 s).  `ms_per_step` and `value` are the MEDIAN region's (the slowest rank's time, region
+by region); `config.step_ms_spread` gives the fastest and the slowest region, which bracket it by construction.
+
 N > 1: row strips re-cut by measured cost (solr_hip_balance_strips), gathered to rank 0 with RCCL called from the
 engine's C ABI on the stream that rendered the frame; the reference's equal split is timed as a second segment, the
-assembled frame is compared with the frame rank 0 renders alone, per-rank times and the gather alone are reported.
+assembled frame is compared with the frame rank 0 renders alone, per-rank times and the gather alone are reported,
+and which communicator mode ran (one for everything, or SOLR_HIP_COMM_PER_FLIGHT=1: one per frame in flight).
 
 Rank 0 prints ONE JSON line.  `value` = (closest-hit walks + shadow walks of the whole
-frame) * steps / wall time / 1e6, summed over all ranks, max wall time over ranks.
+frame) * steps / the median region's wall time / 1e6, summed over all ranks, max wall time over ranks.
 `roofline` prices the renderer kernel against HBM bandwidth with the algorithmic bytes
 of DESIGN.md (51 B per pixel on a first pass + one read of the scene), timed with HIP events on the
-launch stream; `config.rates_mrays_per_s` holds, next to `value`, the rates of the reference's own frame
+launch stream around launches issued one at a time AFTER the timed regions; `config.rates_mrays_per_s` holds, next to
+`value`, the frames left in HBM (earlier rounds' headline) and the rates of the reference's own frame
 protocol (one frame at a time; cudaRender + d2h_bitmap).  `cpu_baseline` times the CPU oracle (a port of the reference algorithm,
 see oracle/solr_oracle.h) on the host cores of the same box on a bounded sample.
 """
@@ -48,7 +58,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps (default 200 - a 60 ms timed region; --config cfg4: 74, one whole cycle of passes)")
+                    help="timed steps per region (default 200 - a 60 ms region, run at least 25 times; --config cfg4: 74, one whole cycle of passes)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -265,7 +275,7 @@ def main():
             pass_counter[0] += 1
         hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
 
-    rccl_ranks = None
+    rccl_ranks = comm_count = None
     if native:
         # the communicator: rank 0's id to everybody over the control plane, then ncclCommInitRank in the library
         uid = C.create_string_buffer(128)
@@ -277,6 +287,7 @@ def main():
         if hip.solr_hip_comm_init(rank, world, uid) != 0:
             k.check(-1, "solr_hip_comm_init")
         rccl_ranks = int(hip.solr_hip_comm_ranks())
+        comm_count = int(hip.solr_hip_comm_count())
 
     def frame():
         # N = 1: the renderer alone.  N > 1: the renderer writes RGB8 straight into a strip buffer and the
@@ -322,104 +333,175 @@ def main():
         rays_local = total // 74
         si.pathTracingIteration = 0
 
-    # a frame loop that does not come back is reported, not sat out: the multi-GPU loop chains work
-    # across streams and ranks, and a stuck collective would otherwise hang the whole launch
+    # a phase that does not come back is reported, not sat out: the multi-GPU loop chains work across streams and
+    # ranks, and a stuck collective would otherwise hang the whole launch.  The timer is re-armed per phase (the
+    # whole job may well take longer than one phase's budget: 8 ranks rehearsing on one GPU, cfg4's 74 passes)
     import threading
+    phase_budget = float(os.environ.get("SOLR_BENCH_PHASE_TIMEOUT", "600"))
+    watch = {"timer": None, "phase": "set-up"}
 
-    def stuck():
-        print("bench.py: rank %d made no progress for 600 s (frames in flight %d, distributed %s): giving up"
-              % (rank, args.frames_in_flight, distributed), file=sys.stderr, flush=True)
-        os._exit(3)
+    def arm(phase):
+        if watch["timer"] is not None:
+            watch["timer"].cancel()
+        watch["phase"] = phase
 
-    watchdog = threading.Timer(600.0, stuck)
-    watchdog.daemon = True
-    watchdog.start()
+        def stuck():
+            print("bench.py: rank %d: phase '%s' has been running for %.0f s (SOLR_BENCH_PHASE_TIMEOUT; frames in flight "
+                  "%d, distributed %s): giving up" % (rank, phase, phase_budget, args.frames_in_flight, distributed),
+                  file=sys.stderr, flush=True)
+            os._exit(3)
 
-    stride = 4 if distributed else 1   # event pairs cost launch gaps: every launch at N = 1, every fourth on strips
+        watch["timer"] = threading.Timer(phase_budget, stuck)
+        watch["timer"].daemon = True
+        watch["timer"].start()
 
-    def timed(steps, warmup):
-        """W untimed steps, then exactly K timed ones between barrier + synchronisation on both sides"""
+    def disarm():
+        if watch["timer"] is not None:
+            watch["timer"].cancel()
+            watch["timer"] = None
+
+    arm("set-up frames")
+
+    # ---- the step that is timed: a frame DELIVERED - rendered and, N > 1, gathered to rank 0, and its image on the
+    # host (SURVEY.md 8d defines the metric over cudaRender + d2h_bitmap; the north star's path ends at getBitmap).
+    # Pipelined as HipKernel::setFramesInFlight does it: the image of a frame is copied to a page-locked host image on
+    # a copy stream behind its kernel (behind its gather on rank 0), the host takes the image `lag` frames back while
+    # the newer ones render.  The engine runs one buffer set up to a depth of two, two beyond (a third render stream
+    # ends up sharing a hardware queue with the copy stream: profiles/r3/readback_probe.txt); the rest is host lag.
+    from collections import deque
+    # (cfg4: every pass reads the buffers of the pass before - one buffer set - but its image can land while the next
+    # pass renders: a set has a second RGB image for that)
+    depth = 2 if cfg4 else max(1, args.frames_in_flight)
+    engine_sets = 1 if depth <= 2 else 2
+    lag = depth - 1
+    tickets = deque()
+    delivered = [0]
+    hip.solr_hip_image_wait.restype = C.c_void_p
+
+    def take(ticket):
+        if ticket >= 0:
+            if not hip.solr_hip_image_wait(ticket):
+                k.check(-1, "solr_hip_image_wait")
+            delivered[0] += 1
+
+    def step():
+        if pipe is not None:                    # --torch-gather: the older loop, the frame stays on the device
+            pipe.frame(render)
+            return
+        frame()
+        tickets.append(hip.solr_hip_d2h_gathered_async() if native else hip.solr_hip_d2h_image_async())
+        if tickets[-1] == -1:
+            k.check(-1, "read-back of the frame")
+        while len(tickets) > lag:
+            take(tickets.popleft())              # (-2 on the ranks that are not the root: nothing to deliver)
+
+    def drain():
+        while tickets:
+            take(tickets.popleft())
+        sync()
+
+    def use_delivery_pipeline():
+        if pipe is None:
+            hip.solr_hip_set_frames_in_flight(engine_sets)
+
+    def timed(steps, warmup, regions):
+        """W untimed steps, then `regions` regions back to back, each EXACTLY `steps` steps between barrier +
+        synchronisation on both sides (a region ends when its last image is on the host).  No event, no instrument
+        of any kind inside a region.  Returns every region's wall time."""
         for _ in range(warmup):
-            frame()
-        sync()
-        hip.solr_hip_kernel_time(None, 1)
-        hip.solr_hip_enable_timing(stride)
-        barrier()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            frame()
-        t_issued = time.perf_counter()
-        sync()
-        t_drained = time.perf_counter()
-        barrier()
-        t1 = time.perf_counter()
-        hip.solr_hip_enable_timing(0)
+            step()
+        drain()
+        out, own = [], []
+        issued = 0.0
+        for _ in range(regions):
+            barrier()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            t_issued = time.perf_counter()
+            drain()
+            own.append(time.perf_counter() - t0)
+            barrier()
+            out.append(time.perf_counter() - t0)
+            issued += t_issued - t0
         k.check(0, "timed frames")
-        n = max(steps // stride + 2, 4)
-        kernel_samples, gap_samples = (C.c_float * n)(), (C.c_float * n)()
-        got = hip.solr_hip_timing_samples(kernel_samples, gap_samples, n)
-        launches = C.c_int(0)
-        kernel_ms = hip.solr_hip_kernel_time(C.byref(launches), 1)
-        return {"elapsed": t1 - t0, "issued": t_issued - t0, "drained": t_drained - t0,
-                "kernel_avg_ms": kernel_ms / max(launches.value, 1), "kernel_samples": list(kernel_samples[:got]),
-                "gap_samples": list(gap_samples[:got]), "strip": current_strip()}
+        return {"regions": out, "own": own, "issued": issued / max(regions, 1), "strip": current_strip()}
 
     def current_strip():
         a, b = C.c_int(), C.c_int()
         hip.solr_hip_get_strip(C.byref(a), C.byref(b))
         return [a.value, b.value]
 
-    # setup, untimed: let the clocks and the tile-cost feedback of the engine settle before the W
-    # warmup steps (a frame is 0.4 ms; W = 3 alone is 1.2 ms of GPU work, shorter than the power ramp)
-    for _ in range(PREROLL_FRAMES):
-        frame()
-    sync()
-    second = None
-    if balanced:
-        # equal strips share out rows, not work (profiles/r2/strip_balance_*.txt): the reference's equal split is
-        # timed first, as the second figure; then the strips are re-cut by the cost the frames recorded, the
-        # tile-cost feedback settles on the new strips, and the headline segment runs on them
-        if world > 1:
-            second = timed(args.steps, args.warmup)
-        if hip.solr_hip_balance_strips() != 0:
-            k.check(-1, "solr_hip_balance_strips")
-        for _ in range(PREROLL_FRAMES // 2):
-            frame()
-        sync()
-    main_run = timed(args.steps, args.warmup)
-    elapsed = main_run["elapsed"]
-    t_issued_ms = main_run["issued"] / args.steps * 1e3
-    kernel_avg_ms = main_run["kernel_avg_ms"]
-    kernel_spread = spread(main_run["kernel_samples"])
-    step_spread = spread(main_run["gap_samples"], divide=float(stride), window=max(2 * args.frames_in_flight // stride, 2))
-    strips = "balanced by cost" if balanced else "equal rows"
-    kernel_basis = "HIP events around every launch of the timed region"
-    if distributed and args.frames_in_flight > 1:
-        kernel_basis = ("HIP events around every fourth launch of the timed region; with %d frames in flight the launches "
-                        "overlap, so this is the latency of a launch, not its share of the GPU" % args.frames_in_flight)
-    if not distributed and hip.solr_hip_get_frames_in_flight() > 1:
-        # with two frames in flight consecutive launches overlap and an event pair around one of them
-        # spans parts of two frames; the kernel's own duration is taken from a short one-at-a-time
-        # segment after the timed region (same frame, same buffers)
+    def region_count(steps):
+        """at least 25 regions, and enough of them to keep the GPU busy for a fifth of a second: a 20-step region of
+        this workload is 6 ms, and neither a median of three nor a utilisation sampler sees that"""
+        if os.environ.get("SOLR_BENCH_REGIONS"):
+            return max(1, int(os.environ["SOLR_BENCH_REGIONS"]))
+        probe = timed(steps, 0, 1)["regions"][0]
+        n = max(25, int(0.2 / max(probe, 1e-6)) + 1)
+        if distributed:
+            t = torch.tensor([float(n)], dtype=torch.float64, device="cpu" if native else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank runs the same number of regions
+            n = int(t[0])
+        return min(n, 400)
+
+    def kernel_segment():
+        """the renderer's own duration: HIP events around each of 16 launches issued one at a time, outside every timed
+        region (an event pair around an overlapped launch spans parts of two frames)"""
+        if pipe is not None:
+            return 0.0, None
         hip.solr_hip_set_frames_in_flight(1)
         for _ in range(8):
             frame()
         sync()
         hip.solr_hip_kernel_time(None, 1)
         hip.solr_hip_enable_timing(1)
-        for _ in range(16):
+        for _ in range(16 if not cfg4 else 74):
             frame()
-        sync()
+            sync()
         hip.solr_hip_enable_timing(0)
-        samples = (C.c_float * 32)()
-        got = hip.solr_hip_timing_samples(samples, None, 32)
-        kernel_spread = spread(list(samples[:got]))
+        samples = (C.c_float * 128)()
+        got = hip.solr_hip_timing_samples(samples, None, 128)
         launches = C.c_int(0)
-        kernel_avg_ms = hip.solr_hip_kernel_time(C.byref(launches), 1) / max(launches.value, 1)
-        hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
-        kernel_basis = "HIP events around each of 16 launches issued one at a time after the timed region"
+        avg = hip.solr_hip_kernel_time(C.byref(launches), 1) / max(launches.value, 1)
+        use_delivery_pipeline()
+        return avg, spread(list(samples[:got]))
 
+    # setup, untimed: let the clocks and the tile-cost feedback of the engine settle before the W
+    # warmup steps (a frame is 0.4 ms; W = 3 alone is 1.2 ms of GPU work, shorter than the power ramp)
+    use_delivery_pipeline()
+    for _ in range(PREROLL_FRAMES):
+        step()
+    drain()
+    arm("choosing the number of regions")
+    regions = region_count(args.steps)
+    second = None
+    if balanced:
+        # equal strips share out rows, not work (profiles/r2/strip_balance_*.txt): the reference's equal split is
+        # timed first, as the second figure; then the strips are re-cut by the cost the frames recorded, the
+        # tile-cost feedback settles on the new strips, and the headline segment runs on them
+        if world > 1:
+            arm("equal strips")
+            second = timed(args.steps, args.warmup, max(regions // 3, 5))
+        if hip.solr_hip_balance_strips() != 0:
+            k.check(-1, "solr_hip_balance_strips")
+        for _ in range(PREROLL_FRAMES // 2):
+            step()
+        drain()
+    arm("the timed regions")
+    main_run = timed(args.steps, args.warmup, regions)
+    t_issued_ms = main_run["issued"] / args.steps * 1e3
+    strips = "balanced by cost" if balanced else "equal rows"
+    arm("kernel time")
+    kernel_avg_ms, kernel_spread = kernel_segment()
+    main_run["kernel_avg_ms"] = kernel_avg_ms
+    if second:
+        second["kernel_avg_ms"] = kernel_avg_ms
+    kernel_basis = ("HIP events around each of %d launches issued one at a time after the timed regions (none inside them)"
+                    % (74 if cfg4 else 16))
+
+    arm("frame protocols")
     # ---- the same frame under the reference's own frame protocol (N = 1; untimed extras, reported next to
     # `value`): one frame at a time - render, wait - and cudaRender + d2h_bitmap, the wall time SURVEY.md
     # section 8(d) defines the metric over (kernel + read-back of the RGB image and the primitive ids)
@@ -451,40 +533,33 @@ def main():
             frame()
             hip.solr_hip_d2h(C.byref(si), C.c_void_p(host_rgb.ctypes.data), None)
         with_image_d2h = (time.perf_counter() - ta) / n_extra
-        # the same read-back pipelined (solr_hip_d2h_image_async: the copy on a stream of its own behind the
-        # kernel, into a page-locked image; the host takes frame n - 2 while frames n - 1 and n are under way)
-        with_image_pipelined = None
+        # the frames left in HBM, pipelined over the engine's buffer sets (earlier rounds' headline: nothing delivered)
+        device_resident = None
         if not cfg4:
-            from collections import deque
-            hip.solr_hip_set_frames_in_flight(2)   # (a third render stream shares a hardware queue with the copies)
-            tickets = deque()
-
-            def piped():
-                frame()
-                tickets.append(hip.solr_hip_d2h_image_async())
-                while len(tickets) > 2:
-                    if not hip.solr_hip_image_wait(tickets.popleft()):
-                        k.check(-1, "solr_hip_image_wait")
-
+            hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
             for _ in range(8):
-                piped()
-            ta = time.perf_counter()
-            for _ in range(n_extra):
-                piped()
-            while tickets:
-                hip.solr_hip_image_wait(tickets.popleft())
-            with_image_pipelined = (time.perf_counter() - ta) / n_extra
+                frame()
+            sync()
+            samples = []
+            for _ in range(9):
+                sync()
+                ta = time.perf_counter()
+                for _ in range(args.steps):
+                    frame()
+                sync()
+                samples.append((time.perf_counter() - ta) / args.steps)
+            device_resident = sorted(samples)[len(samples) // 2]
         k.check(0, "frame protocol rates")
-        hip.solr_hip_set_frames_in_flight(args.frames_in_flight)
+        use_delivery_pipeline()
         rates = {"one_frame_at_a_time": (one_at_a_time, "render, wait for it, render the next"),
                  "cudaRender_plus_d2h_bitmap": (with_d2h, "render + read-back of the RGB image and the primitive ids "
                                                 "(the reference's render_begin / render_end, SURVEY.md 8d)"),
                  "cudaRender_plus_image": (with_image_d2h, "render + read-back of the RGB image alone (the ids stay on "
                                            "the device until picking asks: HipKernel::render_end)")}
-        if with_image_pipelined:
-            rates["cudaRender_plus_image_pipelined"] = (
-                with_image_pipelined, "render + read-back of the RGB image on a copy stream behind the kernel, the host "
-                "takes the image two frames back (solr_hip_d2h_image_async; HipKernel::setFramesInFlight)")
+        if device_resident:
+            rates["pipelined_device_resident"] = (
+                device_resident, "%d frames in flight, the image left in HBM, nothing delivered (what earlier rounds "
+                "reported as `value`; median of 9 regions of %d steps)" % (args.frames_in_flight, args.steps))
 
     # ---- N > 1 extras (untimed): the gather alone, and the assembled frame against the frame one GPU renders
     gather_only_ms = None
@@ -535,34 +610,40 @@ def main():
     rays_total = rays_local
     per_rank = None
     second_out = None
+    def median(xs):
+        xs = sorted(xs)
+        return xs[len(xs) // 2]
+
+    region_times = list(main_run["regions"])
+    second_times = list(second["regions"]) if second else []
     if distributed:
-        t = torch.tensor([elapsed, float(rays_local), kernel_avg_ms, second["elapsed"] if second else 0.0],
-                         dtype=torch.float64, device="cpu" if native else "cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        rays_total = int(tsum[1])
-        kernel_avg_ms = float(tmax[2])
-        mine = {"rank": rank, "rows": main_run["strip"], "ms_per_step_until_own_stream_drained":
-                round(main_run["drained"] / args.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issued_ms, 4),
+        # every region's time is the slowest rank's (MAX over ranks, region by region); rays are summed
+        t = torch.tensor(region_times + second_times + [kernel_avg_ms], dtype=torch.float64,
+                         device="cpu" if native else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        region_times = [float(x) for x in t[:len(region_times)]]
+        second_times = [float(x) for x in t[len(region_times):len(region_times) + len(second_times)]]
+        kernel_avg_ms = float(t[-1])
+        r = torch.tensor([float(rays_local)], dtype=torch.float64, device="cpu" if native else "cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_total = int(r[0])
+        mine = {"rank": rank, "rows": main_run["strip"], "ms_per_step_until_own_frames_delivered":
+                round(median(main_run["own"]) / args.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issued_ms, 4),
                 "kernel_ms": round(main_run["kernel_avg_ms"], 5)}
         if second:
-            mine["equal_strips"] = {"rows": second["strip"], "ms_per_step_until_own_stream_drained":
-                                    round(second["drained"] / args.steps * 1e3, 4),
-                                    "kernel_ms": round(second["kernel_avg_ms"], 5)}
+            mine["equal_strips"] = {"rows": second["strip"], "ms_per_step_until_own_frames_delivered":
+                                    round(median(second["own"]) / args.steps * 1e3, 4)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         if second:
-            second_out = float(tmax[3])
+            second_out = median(second_times)
         # every rank empties its C stdout buffer (RCCL's version banner sits there until exit) before rank 0
         # may print: the JSON line is then the last thing the job writes to stdout
         C.CDLL(None).fflush(None)
         sys.stdout.flush()
         dist.barrier()
 
-    watchdog.cancel()
+    disarm()
     if native:
         hip.solr_hip_comm_finalize()
     if rank != 0:
@@ -570,6 +651,13 @@ def main():
         C.CDLL(None).fflush(None)
         return
 
+    # the headline: the MEDIAN region (each exactly --steps frames between barrier + synchronisation), with the
+    # fastest and the slowest region as its error bar - which brackets it by construction
+    elapsed = median(region_times)
+    step_spread = {"min": round(min(region_times) / args.steps * 1e3, 5), "median": round(elapsed / args.steps * 1e3, 5),
+                   "max": round(max(region_times) / args.steps * 1e3, 5), "regions": len(region_times),
+                   "steps_per_region": args.steps,
+                   "timed_seconds_in_all": round(sum(region_times), 4)}
     mrays = rays_total * args.steps / elapsed / 1e6
     scene_bytes = (48 * len(flat.boxes) + 128 * len(flat.primitives) + 48 * len(flat.lights) +
                    176 * len(set(int(m) for m in flat.primitives["materialId"])))
@@ -595,6 +683,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "regions": len(region_times),
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "strong",
@@ -612,9 +701,15 @@ def main():
                    "frames_in_flight": args.frames_in_flight,
                    # untimed set-up frames before the W warm-up steps (clocks, tile-cost feedback, order-free lists)
                    "setup_frames_before_warmup": PREROLL_FRAMES,
-                   # the error bar of the timed region: the time from the end of a timed launch to the end of the next
-                   # (HIP events on the launch streams), per step, averaged over runs of `window` launches
+                   # the error bar of `ms_per_step`: the timed region - exactly `steps` frames delivered, between barrier +
+                   # synchronisation - is run `regions` times back to back; ms_per_step is the median region, min / max
+                   # the fastest and the slowest one (ms per step each)
                    "step_ms_spread": step_spread,
+                   "delivery": ("frames left on the device (--torch-gather)" if pipe is not None else
+                                "every frame's image lands on the host: page-locked ring, copy stream behind the %s, "
+                                "the host %d frame(s) behind; %d buffer set(s) in the engine; primitive ids on demand "
+                                "(d2h_bitmap when picking asks)" % ("gather on rank 0" if native else "kernel", lag, engine_sets)),
+                   "frames_delivered": delivered[0],
                    # nodes per order-free list when long rays' walks use them, else 0
                    "order_free_nodes": int(hip.solr_hip_order_free_nodes()),
                    "gather": ("none (one GPU)" if not distributed else
@@ -635,9 +730,12 @@ def main():
                      "survey_8d_bytes_per_pixel": SURVEY_FUSED_BYTES_PER_PIXEL if not cfg4 else round(per_pixel, 2)},
     }
     if distributed:
-        slowest = max(per_rank, key=lambda r: r["ms_per_step_until_own_stream_drained"])
+        slowest = max(per_rank, key=lambda r: r["ms_per_step_until_own_frames_delivered"])
         out["config"].update({
-            "rccl_ranks": rccl_ranks, "per_rank": per_rank, "slowest_rank": slowest["rank"],
+            "rccl_ranks": rccl_ranks, "rccl_communicators": comm_count,
+            "rccl_communicator_mode": ("one per frame in flight (SOLR_HIP_COMM_PER_FLIGHT=1)" if comm_count and comm_count > 1
+                                       else "one for everything (default; SOLR_HIP_COMM_PER_FLIGHT=1 for the A/B)"),
+            "per_rank": per_rank, "slowest_rank": slowest["rank"],
             "gather_only_ms": round(gather_only_ms, 4) if gather_only_ms is not None else None,
             "gather_only_note": "64 gathers of the last strips back to back on one stream, no rendering in between",
             # the assembled frame of the strips of the timed region against the same frame rendered whole by rank 0
@@ -653,9 +751,9 @@ def main():
             out["config"]["rehearsal"] = ("SOLR_BENCH_SHARE_GPU=1: every rank on GPU 0 - a rehearsal of the N > 1 code "
                                           "path, not a measurement of N GPUs")
     if rates:
-        out["config"]["rates_mrays_per_s"] = {"pipelined_device_resident": round(mrays, 1)}
-        out["config"]["rates_note"] = {"pipelined_device_resident": "`value`: %d frames in flight, image left in HBM" %
-                                       int(hip.solr_hip_get_frames_in_flight())}
+        out["config"]["rates_mrays_per_s"] = {"delivered_pipelined": round(mrays, 1)}
+        out["config"]["rates_note"] = {"delivered_pipelined": "`value`: every frame's image on the host, the host %d "
+                                       "frame(s) behind the renderer" % lag}
         for name, (seconds, what) in rates.items():
             out["config"]["rates_mrays_per_s"][name] = round(rays_total / seconds / 1e6, 1)
             out["config"]["rates_note"][name] = "%s: %.4f ms per frame" % (what, seconds * 1e3)

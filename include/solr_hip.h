@@ -35,11 +35,16 @@ extern "C" {
 /* Part 1 - the reference boundary                                          */
 /* ======================================================================= */
 
-/* CudaRayTracer.h:25 / CudaRayTracer.cu:1408-1491.  occupancyParameters.x is
- * the reference's in-process GPU count; this engine is one process per GPU
- * and ignores any value other than 1 there (multi-GPU = solr_hip_set_strip +
- * an RCCL gather done by the launcher).  The nb* capacities are hints: device
- * arrays are sized to the scene actually uploaded, not to NB_MAX_*. */
+/* CudaRayTracer.h:25 / CudaRayTracer.cu:1408-1491.  occupancyParameters.x is the reference's in-process GPU
+ * count and is honoured as the reference honours it (CudaRayTracer.cu:1413-1424, 1536-1555, 1647-1672,
+ * 1694-1815): that many devices of THIS process (clamped, with a notice, to the devices there are), the scene
+ * replicated by every h2d_* call, the frame cut into equal row strips - device d renders strip d - and d2h_bitmap
+ * copying every device's strip to its place in the host arrays.  Values below 1 read as 1 here and as "what
+ * initialize_scene was given" in the other nine calls; any other value there is an error.  occupancyParameters.y
+ * (streams per device) is accepted and not used.  Several devices in one process and the one-process-per-GPU
+ * model of part 2 (solr_hip_set_strip, solr_hip_comm_*) refuse each other; neighbourhood post-processing stays
+ * inside a device's strip in this mode, as in the reference.  The nb* capacities are hints: device arrays are
+ * sized to the scene actually uploaded, not to NB_MAX_*. */
 void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int nbPrimitives, int nbLamps,
                       int nbMaterials);
 
@@ -97,6 +102,10 @@ void solr_hip_clear_error(void);
 
 /* number of visible GPUs (0 when none / no driver); never sets the error */
 int solr_hip_device_count(void);
+/* in-process devices: what the pointer form solr_hip_initialize passes as occupancyParameters.x (default 1), and
+ * how many engines are rendering since the last initialize_scene */
+void solr_hip_set_gpu_count(int n);
+int solr_hip_gpu_count(void);
 /* device this process renders on (call before initialize_scene; default 0) */
 void solr_hip_set_device(int device);
 int solr_hip_get_device(void);
@@ -160,6 +169,13 @@ void solr_hip_strip_rows(int rank, int world, int height, int *firstRow, int *nb
 int solr_hip_comm_unique_id(void *id128);
 int solr_hip_comm_init(int rank, int world, const void *id128);
 int solr_hip_comm_ranks(void);
+/* One communicator per frame in flight (call before solr_hip_comm_init, every rank alike; SOLR_HIP_COMM_PER_FLIGHT=0/1
+ * in the environment overrides).  RCCL orders the operations of one communicator whatever streams they are on, so
+ * with frames in flight the gather of frame n + 1 waits for the gather of frame n; communicators split off the
+ * first one (ncclCommSplit) do not order against each other.  Default 0 (one for everything) until an N > 1 run
+ * has measured both; solr_hip_comm_count: how many this process holds (0, 1, or one per possible flight). */
+void solr_hip_comm_set_per_flight(int on);
+int solr_hip_comm_count(void);
 /* a number every rank holds alike (rank 0's draw at solr_hip_comm_init; 0 without a communicator of several ranks):
  * the seed for whatever the hosts draw per frame - GPUKernel::render_begin's timestamp (GPUKernel.cpp:2712-2727) - so
  * that every rank renders the same frame without a word per frame between them */
@@ -167,6 +183,10 @@ unsigned solr_hip_comm_shared_seed(void);
 int solr_hip_gather_strips(int root);
 void *solr_hip_gathered_frame(void);
 int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap);
+/* root: the assembled frame of the gather issued last -> a page-locked host image on the copy stream, behind that
+ * gather; returns a ticket for solr_hip_image_wait at once (the next gather into the same flight's frame waits for
+ * the copy).  Other ranks: -2, nothing to deliver (no error).  The delivered frame of an N-GPU job, pipelined. */
+int solr_hip_d2h_gathered_async(void);
 int solr_hip_gather_ids(int root);
 int solr_hip_d2h_gathered_ids(PrimitiveXYIdBuffer *hostIds);
 void solr_hip_comm_finalize(void);
@@ -224,7 +244,10 @@ void solr_hip_h2d_randoms_sized(const float *randoms, long count);
  * of the frame rendered last (this process's strip at its place in a full-size image) into a page-locked host image
  * owned by the engine, on a copy stream behind that frame's kernel, and returns a ticket (>= 0) at once; with
  * solr_hip_set_frames_in_flight(2 ... 4) the next frames render while it lands.  solr_hip_image_wait(ticket) waits
- * for that copy alone and returns the host image, valid until four more tickets have been handed out.  d2h_bitmap
+ * for that copy alone and returns the host image, valid until five more tickets have been handed out (a ring of six).
+ * A ticket carries its generation: waiting on one whose image has since been handed out again - or re-allocated for
+ * a larger frame - is an error (NULL, solr_hip_last_error), never another frame's image.  With several in-process
+ * devices every device copies its strip into the same image and the wait is for all of them.  d2h_bitmap
  * (CudaRayTracer.cu:1647-1672: wait for the frame, then copy, nothing rendering meanwhile) keeps working next to it;
  * the primitive ids are still fetched with d2h_bitmap when picking asks.  HipKernel::setFramesInFlight builds the
  * reference's render_begin / render_end protocol on this. */

@@ -144,6 +144,8 @@ def _declare_hip(L):
     L.solr_hip_last_error.restype = C.c_int
     L.solr_hip_clear_error.argtypes = []
     L.solr_hip_device_count.restype = C.c_int
+    L.solr_hip_set_gpu_count.argtypes = [C.c_int]
+    L.solr_hip_gpu_count.restype = C.c_int
     L.solr_hip_set_device.argtypes = [C.c_int]
     L.solr_hip_set_stream.argtypes = [C.c_void_p]
     L.solr_hip_synchronize.argtypes = []
@@ -241,6 +243,8 @@ def _declare_host(L):
     L.SolRx_LastError.argtypes = [C.c_char_p, i]
     L.SolRx_Render.argtypes = [d]
     L.SolRx_SetFramesInFlight.argtypes = [i]
+    L.SolRx_SetGpuCount.argtypes = [i]
+    L.SolRx_SetGpuCount.restype = i
     L.SolRx_GetBitmap.restype = C.c_void_p
     for name in ("SolRx_GetBoxes", "SolRx_GetPrimitives", "SolRx_GetMaterials", "SolRx_GetRandoms",
                  "SolRx_GetPrimitiveIds"):
@@ -346,6 +350,12 @@ class Kernel:
     def finalize(self):
         self.L.SolR_FinalizeKernel()
         self.initialized = False
+
+    def set_gpu_count(self, n):
+        """the frame shared out over n devices of this process (occupancyParameters.x); returns the number in use"""
+        got = self.L.SolRx_SetGpuCount(n)
+        self.check(0 if got >= 1 else -1, "SolRx_SetGpuCount")
+        return got
 
     # -- materials / primitives ---------------------------------------------------
     def add_material(self, r=1.0, g=1.0, b=1.0, noise=0.0, reflection=0.0, refraction=0.0, procedural=False,

@@ -1430,13 +1430,19 @@ struct Engine
 
     /* pipelined read-back (solr_hip_d2h_image_async): a ring of page-locked host images, a copy stream, and per
      * slot the event that says its copy has landed */
-    static const int IMAGE_RING = MAX_FLIGHTS + 1;
+    static const int IMAGE_RING = MAX_FLIGHTS + 2; /* MAX_FLIGHTS tickets outstanding, the image on show, one spare */
     hipStream_t copyStream = nullptr;
-    BitmapBuffer *pinnedImage[MAX_FLIGHTS + 1] = {};
+    BitmapBuffer *pinnedImage[IMAGE_RING] = {};
     size_t pinnedBytes = 0;
-    hipEvent_t imageDone[MAX_FLIGHTS + 1] = {};
+    hipEvent_t imageDone[IMAGE_RING] = {};
     hipEvent_t frameRendered = nullptr;
-    int imageNext = 0;
+    /* a ticket is serial * IMAGE_RING + slot: the serial tells a ticket whose slot has been handed out again (or
+     * whose ring was re-allocated for a larger frame) from a live one */
+    long imageSerial = 0;
+    long slotSerial[IMAGE_RING] = {};
+    /* the reciprocal of tilesX that was verified for a frame geometry (renderImpl) */
+    int tileCheckedX = 0, tileCheckedTiles = 0, tileCheckedShift = 0;
+    unsigned tileCheckedMagic = 0;
     /* every buffer set has a second RGB image ("side") for the time a copy still reads the first: a refinement or
      * accumulation pass stays on the set of the pass before it, and would otherwise wait for that pass's copy */
     DeviceBuffer bitmapAlt[MAX_FLIGHTS];
@@ -1461,7 +1467,34 @@ struct Engine
     bool grouping = true; /* groupSiblings(); variant 5 turns it off for A/B measurements */
 };
 
-Engine g;
+/* One Engine per device this process renders on.  The reference drives occupancyParameters.x devices from ONE host
+ * thread - per-device allocations and uploads (CudaRayTracer.cu:1404-1480, 1536-1625), one launch per device on an
+ * equal row strip (:1694-1696, 1709-1815), every device's strip copied to its place in the host arrays (:1647-1672) -
+ * and so does this library when initialize_scene is handed occupancyParameters.x > 1: the ten entry points of the
+ * boundary then run once per engine (the wrappers at the end of the C ABI), each engine on its own device with its
+ * own streams, buffers and error state, the scene replicated, the frame shared out in equal row strips.  Engine 0
+ * always exists and is the engine of every one-device process (all the multi-process machinery: strips, RCCL).
+ * `g` is the engine a function works on. */
+Engine gFirst;
+Engine *gEngines[SOLR_MAX_GPU_COUNT] = {&gFirst};
+int gDevices = 1;   /* engines in use since initialize_scene: min(occupancyParameters.x, devices visible) */
+int gRequested = 1; /* occupancyParameters.x as initialize_scene was given it */
+Engine *gCurrent = &gFirst;
+#define g (*gCurrent)
+template <class F>
+void onEveryDevice(F &&f)
+{
+    for (int d = 0; d < gDevices; ++d)
+    {
+        gCurrent = gEngines[d];
+        if (gDevices > 1)
+            (void)hipSetDevice(g.device); /* (allocations and launches go to the calling thread's device) */
+        f(d);
+    }
+    gCurrent = &gFirst;
+    if (gDevices > 1)
+        (void)hipSetDevice(g.device);
+}
 
 /* how many frames may really be in flight: what was asked for, as far as streams exist */
 int activeFlights()
@@ -2299,10 +2332,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     {
         /* the reciprocal of tilesX for the kernel's tile -> (column, row): exact for every tile of this frame
          * (round-up multiplier of ceil(log2) + 16 extra bits; verified below, once per frame geometry) */
-        static int checkedTilesX = 0, checkedTiles = 0, checkedShift = 0;
-        static unsigned checkedMagic = 0;
         const int tiles = F.tilesX * tilesY;
-        if (checkedTilesX != F.tilesX || checkedTiles < tiles)
+        if (g.tileCheckedX != F.tilesX || g.tileCheckedTiles < tiles)
         {
             /* shift = ceil(log2 tilesX) - 1: the multiplier ceil(2^(32 + shift) / tilesX) has 32 bits and is exact for
              * every index below 2^31; one tile per row (magic 0) needs no division */
@@ -2315,13 +2346,15 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             for (int t = 0; t < tiles && exact && magic; ++t)
                 exact = (int)(((unsigned long long)(unsigned)t * magic) >> (32 + shift)) == t / F.tilesX;
             ARGCHECK(exact, "cudaRender: no exact reciprocal for this frame width");
-            checkedTilesX = F.tilesX;
-            checkedTiles = tiles;
-            checkedMagic = (unsigned)magic;
-            checkedShift = shift;
+            if (!exact)
+                return; /* (cannot happen below 2^31 tiles; nothing is cached, the next frame checks again) */
+            g.tileCheckedX = F.tilesX;
+            g.tileCheckedTiles = tiles;
+            g.tileCheckedMagic = (unsigned)magic;
+            g.tileCheckedShift = shift;
         }
-        F.tileMagic = checkedMagic;
-        F.tileShift = checkedShift;
+        F.tileMagic = g.tileCheckedMagic;
+        F.tileShift = g.tileCheckedShift;
     }
     const bool neighbourhood = (ppInfo.type == ppe_ambientOcclusion || ppInfo.type == ppe_depthOfField ||
                                 ppInfo.type == ppe_radiosity || ppInfo.type == ppe_filter || ppInfo.type == ppe_cartoon);
@@ -2594,7 +2627,8 @@ void releaseImageRing()
         (void)hipStreamDestroy(g.copyStream);
     g.copyStream = nullptr;
     g.pinnedBytes = 0;
-    g.imageNext = 0;
+    for (long &serial : g.slotSerial)
+        serial = -1;
     for (int f = 0; f < MAX_FLIGHTS; ++f)
     {
         g.flightCopy[f][0] = g.flightCopy[f][1] = -1;
@@ -2671,18 +2705,30 @@ extern "C" {
 
 int solr_hip_last_error(char *buf, int len)
 {
+    /* the first engine in trouble speaks for the process (one engine unless occupancyParameters.x asked for more) */
+    const Engine *bad = &gFirst;
+    for (int d = 0; d < gDevices; ++d)
+        if (gEngines[d] && gEngines[d]->errorCode != 0)
+        {
+            bad = gEngines[d];
+            break;
+        }
     if (buf && len > 0)
     {
-        strncpy(buf, g.errorText.c_str(), len - 1);
+        strncpy(buf, bad->errorText.c_str(), len - 1);
         buf[len - 1] = 0;
     }
-    return g.errorCode;
+    return bad->errorCode;
 }
 
 void solr_hip_clear_error(void)
 {
-    g.errorCode = 0;
-    g.errorText.clear();
+    for (Engine *e : gEngines)
+        if (e)
+        {
+            e->errorCode = 0;
+            e->errorText.clear();
+        }
 }
 
 int solr_hip_device_count(void)
@@ -2753,7 +2799,7 @@ void solr_hip_set_stream(void *stream)
     }
 }
 
-void solr_hip_synchronize(void)
+static void synchronizeOne()
 {
     if (!ready("solr_hip_synchronize"))
         return;
@@ -2765,6 +2811,14 @@ void solr_hip_synchronize(void)
 
 void solr_hip_set_strip(int firstRow, int nbRows)
 {
+    if (gDevices > 1)
+    {
+        /* the frame is already shared out between this process's devices (occupancyParameters.x): a strip of the
+         * multi-process split on top of that is a different program */
+        setError(-1, "solr_hip_set_strip: this process renders on several devices (occupancyParameters.x > 1); strips "
+                     "belong to the one-process-per-GPU model", __FILE__, __LINE__);
+        return;
+    }
     quiesce();
     g.firstRow = nbRows >= 0 ? firstRow : 0;
     g.nbRows = nbRows >= 0 ? nbRows : -1;
@@ -2799,11 +2853,10 @@ void solr_hip_bind_device_bitmap(void *deviceBitmap)
     g.boundBitmap = deviceBitmap;
 }
 
-void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, int)
+static void initializeOne(const SceneInfo &sceneInfo)
 {
     if (!ok())
         return;
-    (void)occupancyParameters;
     solrTuneHostAllocator();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -2833,15 +2886,8 @@ void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, 
     g.height = sceneInfo.size.y;
 }
 
-void solr_hip_initialize(const SceneInfo *sceneInfo)
-{
-    vec2i occ;
-    occ.x = 1;
-    occ.y = 1;
-    initialize_scene(occ, *sceneInfo, 0, 0, 0);
-}
 
-void finalize_scene(vec2i)
+static void finalizeOne()
 {
     if (!g.initialized)
         return;
@@ -2931,7 +2977,7 @@ void finalize_scene(vec2i)
     /* no hipDeviceReset: the process may share the device with torch/RCCL */
 }
 
-void reshape_scene(vec2i, SceneInfo sceneInfo)
+static void reshapeOne(const SceneInfo &sceneInfo)
 {
     if (!ready("reshape_scene"))
         return;
@@ -2941,13 +2987,6 @@ void reshape_scene(vec2i, SceneInfo sceneInfo)
     allocateFrame();
 }
 
-void solr_hip_reshape(const SceneInfo *sceneInfo)
-{
-    vec2i occ;
-    occ.x = 1;
-    occ.y = 1;
-    reshape_scene(occ, *sceneInfo);
-}
 
 /* Inner nodes that hardly ever cull are left out of the walk list.  An inner node - one of the reference's tree
  * whose children all lie inside it, or a grouping node, which is the union of its members - passes whenever one
@@ -3772,8 +3811,8 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start, std
     return (int)start.size();
 }
 
-void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *primitives, int nbPrimitives,
-               Lamp *lamps, int nbLamps)
+static void h2dSceneOne(BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *primitives, int nbPrimitives, Lamp *lamps,
+                        int nbLamps)
 {
     if (!ready("h2d_scene"))
         return;
@@ -3954,7 +3993,7 @@ void h2d_scene(vec2i, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *
 
 /* Extension: per flattened primitive, whether GPUKernel::rotatePrimitives would move it (it sits in a
  * level-0 box, is movable and is not the camera primitive).  Valid until the next h2d_scene. */
-void solr_hip_set_movable(const unsigned char *flags, int nbPrimitives)
+static void setMovableOne(const unsigned char *flags, int nbPrimitives)
 {
     if (!ready("solr_hip_set_movable"))
         return;
@@ -3978,8 +4017,7 @@ void solr_hip_set_movable(const unsigned char *flags, int nbPrimitives)
  * (GPUKernel.cpp:1378-1460, 1151-1281 of the reference), see k_rotatePrimitives.  Returns 1 when the
  * arena now holds the rotated scene, 0 when the request cannot be served here and the caller has to
  * take the host route (nothing was changed). */
-int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], const float sinAngles[3],
-                               float viewDistance)
+static int rotatePrimitivesOne(const float center[3], const float cosAngles[3], const float sinAngles[3], float viewDistance)
 {
     if (!ready("solr_hip_rotate_primitives") || !ok())
         return 0;
@@ -4079,7 +4117,7 @@ int solr_hip_read_primitives(float *rows, int capacityRows)
     return ok() ? n : -1;
 }
 
-void h2d_materials(vec2i, Material *materials, int nbActiveMaterials)
+static void h2dMaterialsOne(Material *materials, int nbActiveMaterials)
 {
     if (!ready("h2d_materials"))
         return;
@@ -4215,7 +4253,7 @@ static void uploadRandoms(const float *randoms, long count, const char *who)
     shareRandoms();
 }
 
-void h2d_randoms(vec2i, float *randoms)
+static void h2dRandomsOne(float *randoms)
 {
     if (g.initialized && ok())
         ARGCHECK(randoms != nullptr, "h2d_randoms: null buffer");
@@ -4227,7 +4265,7 @@ void h2d_randoms(vec2i, float *randoms)
  * W * H + 9999 + 1 - beyond MAX_BITMAP_SIZE floats as soon as the frame is larger (and by up to 9 999 floats
  * even at that size).  A host that renders such frames hands over as many values
  * as the expression can reach; reads beyond what was handed over return 0 (rt_device.h rnd()). */
-void solr_hip_h2d_randoms_sized(const float *randoms, long count)
+static void h2dRandomsSizedOne(const float *randoms, long count)
 {
     if (g.initialized && ok())
         ARGCHECK(randoms != nullptr && count >= MAX_BITMAP_SIZE && count <= (1L << 30),
@@ -4235,7 +4273,7 @@ void solr_hip_h2d_randoms_sized(const float *randoms, long count)
     uploadRandoms(randoms, count, "solr_hip_h2d_randoms_sized");
 }
 
-void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
+static void h2dTexturesOne(int activeTextures, TextureInfo *textureInfos)
 {
     if (!ready("h2d_textures"))
         return;
@@ -4276,7 +4314,7 @@ void h2d_textures(vec2i, int activeTextures, TextureInfo *textureInfos)
     g.textureTablesChecked = false;
 }
 
-void h2d_lightInformation(vec2i, LightInformation *lightInformation, int lightInformationSize)
+static void h2dLightInformationOne(LightInformation *lightInformation, int lightInformationSize)
 {
     if (!ready("h2d_lightInformation"))
         return;
@@ -4298,7 +4336,8 @@ void h2d_lightInformation(vec2i, LightInformation *lightInformation, int lightIn
     g.nbLights = lightInformationSize;
 }
 
-void d2h_bitmap(vec2i, SceneInfo sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds)
+/* wait == false: the copies are enqueued and d2hBitmapWait() is owed (several devices copy side by side) */
+static void d2hBitmapOne(const SceneInfo &sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds, bool wait)
 {
     if (!ready("d2h_bitmap"))
         return;
@@ -4316,15 +4355,13 @@ void d2h_bitmap(vec2i, SceneInfo sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdB
     if (primitivesXYIds && flightIds(g.current).ptr)
         HIPCHECK(hipMemcpyAsync(primitivesXYIds + offset, flightIds(g.current).ptr,
                                 pixels * sizeof(PrimitiveXYIdBuffer), hipMemcpyDeviceToHost, stream));
-    HIPCHECK(hipStreamSynchronize(stream));
+    if (wait)
+        HIPCHECK(hipStreamSynchronize(stream));
 }
-
-void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds)
+static void d2hBitmapWait()
 {
-    vec2i occ;
-    occ.x = 1;
-    occ.y = 1;
-    d2h_bitmap(occ, *sceneInfo, bitmap, primitivesXYIds);
+    if (g.initialized && ok())
+        HIPCHECK(hipStreamSynchronize(flightStream(g.current)));
 }
 
 /* Pipelined read-back of the image (SURVEY.md 8d defines the metric over cudaRender + d2h_bitmap; d2h_bitmap waits
@@ -4335,6 +4372,91 @@ void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYI
  * streams are free for the next frames (solr_hip_set_frames_in_flight), whose kernels overlap the copy.
  * solr_hip_image_wait(ticket) waits for that one copy and returns the host image; it stays valid until
  * MAX_FLIGHTS more tickets have been handed out.  The ids stay on the device until d2h_bitmap asks for them. */
+namespace
+{
+/* the copy stream of the current engine and its events (one per slot of the ring) */
+void ensureCopyStream()
+{
+    if (g.copyStream)
+        return;
+    /* (at the render streams' priority.  Measured, profiles/r3/readback_probe.txt: with one or two render streams
+     * the copies cost nothing - 0.286 ms per Cornell frame with the image against 0.285 without; with three the
+     * frame takes 0.45 ms whatever the host's lag - the runtime's hardware queues are dealt out in turn and a
+     * render stream ends up sharing one with this stream; a stream of the highest priority, which gets queues of
+     * its own, was slower in every combination (0.33 at best).  HipKernel::setFramesInFlight therefore keeps
+     * the engine at two buffer sets and puts the rest of the depth into the host's lag.) */
+    HIPCHECK(hipStreamCreateWithFlags(&g.copyStream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&g.frameRendered, hipEventDisableTiming));
+    for (int i = 0; i < Engine::IMAGE_RING && ok(); ++i)
+        HIPCHECK(hipEventCreateWithFlags(&g.imageDone[i], hipEventDisableTiming));
+}
+
+/* the ring of page-locked images lives in engine 0 (every in-process device copies its strip into the same image) */
+bool ensureImageRing()
+{
+    Engine &e = gFirst;
+    const size_t frameBytes = (size_t)e.width * e.height * SOLR_COLOR_DEPTH;
+    if (e.pinnedBytes >= frameBytes)
+        return true;
+    Engine *const was = gCurrent;
+    gCurrent = &gFirst;
+    releaseImageRing(); /* (outstanding tickets are void from here on: their serial no longer matches) */
+    for (int i = 0; i < Engine::IMAGE_RING && ok(); ++i)
+    {
+        HIPCHECK(hipHostMalloc((void **)&g.pinnedImage[i], frameBytes, hipHostMallocPortable));
+        if (ok())
+            memset(g.pinnedImage[i], 0, frameBytes);
+    }
+    if (ok())
+        g.pinnedBytes = frameBytes;
+    const bool fine = ok();
+    gCurrent = was;
+    return fine;
+}
+
+/* the current engine's strip of the frame it rendered last -> its rows of `image`, on the engine's copy stream behind
+ * that frame's kernel; `slot` names the event that says the copy has landed */
+void copyStripBehindFrame(BitmapBuffer *image, int slot)
+{
+    if (!ok())
+        return;
+    HIPCHECK(hipSetDevice(g.device));
+    ensureCopyStream();
+    if (!ok())
+        return;
+    const int flight = g.current;
+    const int rows = stripRows();
+    const int first = g.nbRows >= 0 ? g.firstRow : 0;
+    const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr;
+    HIPCHECK(hipEventRecord(g.frameRendered, flightStream(flight)));
+    HIPCHECK(hipStreamWaitEvent(g.copyStream, g.frameRendered, 0));
+    if (rows > 0 && src)
+        HIPCHECK(hipMemcpyAsync(image + (size_t)g.width * first * SOLR_COLOR_DEPTH, src,
+                                (size_t)g.width * rows * SOLR_COLOR_DEPTH, hipMemcpyDeviceToHost, g.copyStream));
+    HIPCHECK(hipEventRecord(g.imageDone[slot], g.copyStream));
+    if (!g.boundBitmap)
+        g.flightCopy[flight][g.bitmapSide[flight]] = slot;
+}
+
+/* hands out the next slot of the ring; the ticket is serial * IMAGE_RING + slot */
+int nextTicket(int *slot)
+{
+    Engine &e = gFirst;
+    const long serial = ++e.imageSerial;
+    *slot = (int)(serial % Engine::IMAGE_RING);
+    e.slotSerial[*slot] = serial;
+    return (int)(serial * Engine::IMAGE_RING + *slot);
+}
+
+bool liveTicket(int ticket, int *slot)
+{
+    if (ticket < 0)
+        return false;
+    *slot = ticket % Engine::IMAGE_RING;
+    return gFirst.pinnedImage[*slot] != nullptr && gFirst.slotSerial[*slot] == (long)(ticket / Engine::IMAGE_RING);
+}
+} // namespace
+
 int solr_hip_d2h_image_async(void)
 {
     if (!ready("solr_hip_d2h_image_async"))
@@ -4343,74 +4465,50 @@ int solr_hip_d2h_image_async(void)
     if (!ok())
         return -1;
     HIPCHECK(hipSetDevice(g.device));
-    const size_t frameBytes = (size_t)g.width * g.height * SOLR_COLOR_DEPTH;
-    if (g.pinnedBytes < frameBytes)
-    {
-        releaseImageRing();
-        for (int i = 0; i < Engine::IMAGE_RING && ok(); ++i)
-        {
-            HIPCHECK(hipHostMalloc((void **)&g.pinnedImage[i], frameBytes, hipHostMallocDefault));
-            if (ok())
-                memset(g.pinnedImage[i], 0, frameBytes);
-        }
-        if (ok())
-            g.pinnedBytes = frameBytes;
-    }
-    if (ok() && !g.copyStream)
-    {
-        /* (at the render streams' priority.  Measured, profiles/r3/readback_probe.txt: with one or two render streams
-         * the copies cost nothing - 0.286 ms per Cornell frame with the image against 0.285 without; with three the
-         * frame takes 0.45 ms whatever the host's lag - the runtime's hardware queues are dealt out in turn and a
-         * render stream ends up sharing one with this stream; a stream of the highest priority, which gets queues of
-         * its own, was slower in every combination (0.33 at best).  HipKernel::setFramesInFlight therefore keeps
-         * the engine at two buffer sets and puts the rest of the depth into the host's lag.) */
-        HIPCHECK(hipStreamCreateWithFlags(&g.copyStream, hipStreamNonBlocking));
-        HIPCHECK(hipEventCreateWithFlags(&g.frameRendered, hipEventDisableTiming));
-        for (int i = 0; i < Engine::IMAGE_RING && ok(); ++i)
-            HIPCHECK(hipEventCreateWithFlags(&g.imageDone[i], hipEventDisableTiming));
-    }
-    if (!ok())
+    if (!ensureImageRing())
         return -1;
-    const int flight = g.current;
-    const int slot = g.imageNext;
-    g.imageNext = (g.imageNext + 1) % Engine::IMAGE_RING;
-    const int rows = stripRows();
-    const int first = g.nbRows >= 0 ? g.firstRow : 0;
-    const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr;
-    HIPCHECK(hipEventRecord(g.frameRendered, flightStream(flight)));
-    HIPCHECK(hipStreamWaitEvent(g.copyStream, g.frameRendered, 0));
-    if (rows > 0 && src)
-        HIPCHECK(hipMemcpyAsync(g.pinnedImage[slot] + (size_t)g.width * first * SOLR_COLOR_DEPTH, src,
-                                (size_t)g.width * rows * SOLR_COLOR_DEPTH, hipMemcpyDeviceToHost, g.copyStream));
-    HIPCHECK(hipEventRecord(g.imageDone[slot], g.copyStream));
-    if (!g.boundBitmap)
-        g.flightCopy[flight][g.bitmapSide[flight]] = slot;
-    return ok() ? slot : -1;
+    int slot = 0;
+    const int ticket = nextTicket(&slot);
+    BitmapBuffer *const image = gFirst.pinnedImage[slot];
+    onEveryDevice([&](int) { copyStripBehindFrame(image, slot); });
+    return solr_hip_last_error(nullptr, 0) == 0 ? ticket : -1;
 }
 
+/* Waits for the copy (every in-process device's strip) behind `ticket` and returns the host image.  A ticket is good
+ * until IMAGE_RING - 1 more have been handed out, or the frame grew and the ring with it: after that it names a
+ * frame that is gone, and asking for it is an error - not, silently, a newer frame's image. */
 const BitmapBuffer *solr_hip_image_wait(int ticket)
 {
     if (!ready("solr_hip_image_wait"))
         return nullptr;
-    ARGCHECK(ticket >= 0 && ticket < Engine::IMAGE_RING && g.pinnedImage[ticket] != nullptr,
-             "solr_hip_image_wait: no such ticket");
+    int slot = 0;
+    ARGCHECK(liveTicket(ticket, &slot), "solr_hip_image_wait: no such ticket, or one so old that its image has been "
+                                        "handed out again (or re-allocated for a larger frame)");
     if (!ok())
         return nullptr;
-    HIPCHECK(hipEventSynchronize(g.imageDone[ticket]));
-    return ok() ? g.pinnedImage[ticket] : nullptr;
+    onEveryDevice([&](int) {
+        if (g.imageDone[slot])
+            HIPCHECK(hipEventSynchronize(g.imageDone[slot]));
+    });
+    return solr_hip_last_error(nullptr, 0) == 0 ? gFirst.pinnedImage[slot] : nullptr;
 }
 
+/* the float frame buffer of the strip rendered last (strip-sized host buffer; with several in-process devices the
+ * whole frame: every device's rows at their place) */
 void solr_hip_d2h_postprocessing(PostProcessingBuffer *hostBuffer)
 {
-    if (!ready("solr_hip_d2h_postprocessing"))
-        return;
-    ARGCHECK(hostBuffer != nullptr && flightPp(g.current).ptr != nullptr, "solr_hip_d2h_postprocessing: no buffer");
-    if (!ok())
-        return;
-    const size_t pixels = (size_t)g.width * stripRows();
-    HIPCHECK(hipMemcpyAsync(hostBuffer, flightPp(g.current).ptr, pixels * sizeof(PostProcessingBuffer),
-                            hipMemcpyDeviceToHost, flightStream(g.current)));
-    HIPCHECK(hipStreamSynchronize(flightStream(g.current)));
+    onEveryDevice([&](int) {
+        if (!ready("solr_hip_d2h_postprocessing"))
+            return;
+        ARGCHECK(hostBuffer != nullptr && flightPp(g.current).ptr != nullptr, "solr_hip_d2h_postprocessing: no buffer");
+        if (!ok())
+            return;
+        const size_t pixels = (size_t)g.width * stripRows();
+        const size_t offset = gDevices > 1 ? (size_t)g.width * (g.nbRows >= 0 ? g.firstRow : 0) : 0;
+        HIPCHECK(hipMemcpyAsync(hostBuffer + offset, flightPp(g.current).ptr, pixels * sizeof(PostProcessingBuffer),
+                                hipMemcpyDeviceToHost, flightStream(g.current)));
+        HIPCHECK(hipStreamSynchronize(flightStream(g.current)));
+    });
 }
 
 void solr_hip_h2d_postprocessing(const PostProcessingBuffer *hostBuffer, const PrimitiveXYIdBuffer *ids)
@@ -4433,41 +4531,47 @@ void solr_hip_h2d_postprocessing(const PostProcessingBuffer *hostBuffer, const P
     HIPCHECK(hipStreamSynchronize(stream));
 }
 
-void cudaRender(vec2i, vec4i, SceneInfo sceneInfo, vec4i objects, PostProcessingInfo postProcessingInfo,
-                vec3f origin, vec3f direction, vec4f angles)
-{
-    const float o[3] = {origin.x, origin.y, origin.z};
-    const float d[3] = {direction.x, direction.y, direction.z};
-    const float a[4] = {angles.x, angles.y, angles.z, angles.w};
-    renderImpl(sceneInfo, objects, postProcessingInfo, o, d, a, false, nullptr);
-}
-
-void solr_hip_render(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
-                     const float origin[3], const float direction[3], const float angles[4])
-{
-    renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, false, nullptr);
-}
 
 void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
                               const PostProcessingInfo *postProcessingInfo, const float origin[3],
                               const float direction[3], const float angles[4], unsigned long long counts[8])
 {
-    renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, true, counts);
+    if (gDevices < 2)
+    {
+        renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, true, counts);
+        return;
+    }
+    /* several in-process devices: the census of the frame is the sum over their strips */
+    unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    onEveryDevice([&](int) {
+        unsigned long long mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, true, mine);
+        for (int i = 0; i < 8; ++i)
+            sum[i] += mine[i];
+    });
+    if (counts)
+        memcpy(counts, sum, sizeof(sum));
 }
 
 void solr_hip_enable_timing(int enable)
 {
-    g.timing = enable > 0 ? enable : 0;
-    g.timingTick = 0;
+    onEveryDevice([&](int) {
+        g.timing = enable > 0 ? enable : 0;
+        g.timingTick = 0;
+    });
 }
 
 void solr_hip_set_frames_in_flight(int n)
 {
-    quiesce();
-    g.flights = n < 1 ? 1 : (n > MAX_FLIGHTS ? MAX_FLIGHTS : n);
-    g.current = 0;
-    if (g.initialized && g.width > 0)
-        allocateFrame();
+    onEveryDevice([&](int) {
+        quiesce();
+        if (g.initialized)
+            (void)hipSetDevice(g.device);
+        g.flights = n < 1 ? 1 : (n > MAX_FLIGHTS ? MAX_FLIGHTS : n);
+        g.current = 0;
+        if (g.initialized && g.width > 0)
+            allocateFrame();
+    });
 }
 
 int solr_hip_get_frames_in_flight(void)
@@ -4487,10 +4591,12 @@ int solr_hip_next_flight(void)
 
 void solr_hip_set_tile_scheduling(int mode)
 {
-    g.tileScheduling = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
-    g.costFrames = 0;
-    g.reorder = false;
-    g.orderValid = false;
+    onEveryDevice([&](int) {
+        g.tileScheduling = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+        g.costFrames = 0;
+        g.reorder = false;
+        g.orderValid = false;
+    });
 }
 
 int solr_hip_tile_scheduling_active(void)
@@ -4555,8 +4661,10 @@ int solr_hip_timing_samples(float *kernelMs, float *intervalMs, int capacity)
 
 void solr_hip_set_variant(int variant)
 {
-    g.variant = variant;
-    g.grouping = (variant != 5); /* takes effect at the next h2d_scene */
+    onEveryDevice([&](int) {
+        g.variant = variant;
+        g.grouping = (variant != 5); /* takes effect at the next h2d_scene */
+    });
 }
 
 int solr_hip_get_variant(void)
@@ -4604,9 +4712,19 @@ struct Rccl
     int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr; /* (optional: one communicator per flight) */
     ncclComm_t comm = nullptr;
+    /* One communicator per frame in flight (SOLR_HIP_COMM_PER_FLIGHT=1 / solr_hip_comm_set_per_flight).  RCCL orders
+     * the operations of ONE communicator, whatever streams they are enqueued on: with frames in flight on several
+     * streams, the gather of frame n + 1 (stream B) then waits for the gather of frame n (stream A) and the frames
+     * partly serialise.  Communicators split off the first one (ncclCommSplit, same ranks) do not order against each
+     * other; flightComm[f] carries the per-frame transfers of flight f (strip gather, depth halo), `comm` the blocking
+     * collectives and flight 0.  Off by default until an N > 1 run has measured both (bench.py prints the mode). */
+    ncclComm_t flightComm[MAX_FLIGHTS] = {};
+    bool perFlight = false;
     int rank = 0, world = 0;
     DeviceBuffer frame[MAX_FLIGHTS]; /* root: the assembled RGB8 frame of each flight */
+    int frameCopy[MAX_FLIGHTS] = {-1, -1, -1, -1}; /* the slot of the image ring whose copy still reads that frame, or -1 */
     DeviceBuffer idsFrame;           /* root: the assembled primitive ids (solr_hip_gather_ids) */
     int idsFlight = 0;               /* the flight whose stream carried that gather */
     DeviceBuffer zeros;              /* what a rank sends when it cannot send its own rows (see joinWith) */
@@ -4659,6 +4777,7 @@ bool loadRccl()
     rccl.Recv = (decltype(rccl.Recv))dlsym(rccl.lib, "ncclRecv");
     rccl.AllReduce = (decltype(rccl.AllReduce))dlsym(rccl.lib, "ncclAllReduce");
     rccl.GetErrorString = (decltype(rccl.GetErrorString))dlsym(rccl.lib, "ncclGetErrorString");
+    rccl.CommSplit = (decltype(rccl.CommSplit))dlsym(rccl.lib, "ncclCommSplit");
     if (!rccl.GetUniqueId || !rccl.CommInitRank || !rccl.CommDestroy || !rccl.GroupStart || !rccl.GroupEnd ||
         !rccl.Send || !rccl.Recv || !rccl.AllReduce)
     {
@@ -4677,6 +4796,12 @@ bool rcclOk(int result, const char *what)
     std::string text = std::string(what) + ": " + (rccl.GetErrorString ? rccl.GetErrorString(result) : "RCCL error");
     setError(-1, text.c_str(), __FILE__, __LINE__);
     return false;
+}
+
+/* the communicator that carries the per-frame transfers of `flight` */
+ncclComm_t commOf(int flight)
+{
+    return (rccl.perFlight && flight >= 0 && flight < MAX_FLIGHTS && rccl.flightComm[flight]) ? rccl.flightComm[flight] : rccl.comm;
 }
 
 /* ---- collectives that every rank joins ---------------------------------------------------------------------------
@@ -4909,15 +5034,15 @@ void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, in
     }
     bool fine = rcclOk(rccl.GroupStart(), "ncclGroupStart");
     if (fine && sendUp)
-        fine = rcclOk(rccl.Send(top, (size_t)mine * W, RCCL_FLOAT32, rccl.rank - 1, rccl.comm, stream), "ncclSend (depth rows, up)");
+        fine = rcclOk(rccl.Send(top, (size_t)mine * W, RCCL_FLOAT32, rccl.rank - 1, commOf(flight), stream), "ncclSend (depth rows, up)");
     if (fine && sendDown)
-        fine = rcclOk(rccl.Send(bottom, (size_t)mine * W, RCCL_FLOAT32, rccl.rank + 1, rccl.comm, stream),
+        fine = rcclOk(rccl.Send(bottom, (size_t)mine * W, RCCL_FLOAT32, rccl.rank + 1, commOf(flight), stream),
                       "ncclSend (depth rows, down)");
     if (fine && recvAbove)
-        fine = rcclOk(rccl.Recv(g.haloAbove[flight].ptr, (size_t)recvAbove * W, RCCL_FLOAT32, rccl.rank - 1, rccl.comm, stream),
+        fine = rcclOk(rccl.Recv(g.haloAbove[flight].ptr, (size_t)recvAbove * W, RCCL_FLOAT32, rccl.rank - 1, commOf(flight), stream),
                       "ncclRecv (depth rows, above)");
     if (fine && recvBelow)
-        fine = rcclOk(rccl.Recv(g.haloBelow[flight].ptr, (size_t)recvBelow * W, RCCL_FLOAT32, rccl.rank + 1, rccl.comm, stream),
+        fine = rcclOk(rccl.Recv(g.haloBelow[flight].ptr, (size_t)recvBelow * W, RCCL_FLOAT32, rccl.rank + 1, commOf(flight), stream),
                       "ncclRecv (depth rows, below)");
     if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd") || !fine || !own || !halo)
         return;
@@ -5182,6 +5307,12 @@ int solr_hip_comm_unique_id(void *id128)
  * after the uploads of its first frame. */
 int solr_hip_comm_init(int rank, int world, const void *id128)
 {
+    if (gDevices > 1)
+    {
+        setError(-1, "solr_hip_comm_init: this process renders on several devices (occupancyParameters.x > 1); a "
+                     "communicator belongs to the one-process-per-GPU model", __FILE__, __LINE__);
+        return -1;
+    }
     if (!ready("solr_hip_comm_init") || !loadRccl())
         return -1;
     ARGCHECK(id128 != nullptr && world >= 1 && rank >= 0 && rank < world, "solr_hip_comm_init: bad arguments");
@@ -5200,10 +5331,53 @@ int solr_hip_comm_init(int rank, int world, const void *id128)
     rccl.world = world;
     rccl.haloAgreed = -1;
     rccl.haloStale = true;
+    for (ncclComm_t &c : rccl.flightComm)
+        c = nullptr;
+    for (int &slot : rccl.frameCopy)
+        slot = -1;
+    const char *env = getenv("SOLR_HIP_COMM_PER_FLIGHT");
+    if (env && env[0])
+        rccl.perFlight = env[0] != '0';
+    if (rccl.perFlight)
+    {
+        /* every rank, in the same order: the split is a collective of the parent communicator */
+        if (!rccl.CommSplit)
+        {
+            setError(-1, "solr_hip_comm_init: one communicator per flight was asked for and this RCCL has no ncclCommSplit",
+                     __FILE__, __LINE__);
+            return -1;
+        }
+        rccl.flightComm[0] = rccl.comm;
+        for (int f = 1; f < MAX_FLIGHTS; ++f)
+            if (!rcclOk(rccl.CommSplit(rccl.comm, 0, rank, &rccl.flightComm[f], nullptr), "ncclCommSplit"))
+            {
+                rccl.flightComm[f] = nullptr;
+                return -1;
+            }
+    }
     quiesce();
     if (!shareRandoms())
         return -1;
     return ok() ? 0 : -1;
+}
+
+/* before solr_hip_comm_init: 1 = one communicator per frame in flight (see struct Rccl), 0 = one for everything (the
+ * default; SOLR_HIP_COMM_PER_FLIGHT in the environment overrides either).  Every rank alike. */
+void solr_hip_comm_set_per_flight(int on)
+{
+    rccl.perFlight = on != 0;
+}
+
+/* communicators this process holds: 0 without one, 1, or one per possible flight */
+int solr_hip_comm_count(void)
+{
+    if (!rccl.comm)
+        return 0;
+    int n = 1;
+    for (int f = 1; f < MAX_FLIGHTS; ++f)
+        if (rccl.perFlight && rccl.flightComm[f])
+            ++n;
+    return n;
 }
 
 /* A number every rank of the communicator holds alike (rank 0 drew it at solr_hip_comm_init), 0 without a
@@ -5234,7 +5408,7 @@ namespace
  * every rank's rows at their place in `assembled`.  Sizes come from the strip table alone; `own` == nullptr (this
  * rank cannot send its own rows) sends zeros. */
 bool gatherRows(int root, const void *own, void *assembled, size_t rowBytes, int datatype, size_t perByte, hipStream_t stream,
-                const char *what)
+                ncclComm_t comm, const char *what)
 {
     int first = 0, count = 0;
     stripOf(rccl.rank, rccl.world, g.height, &first, &count);
@@ -5258,11 +5432,11 @@ bool gatherRows(int root, const void *own, void *assembled, size_t rowBytes, int
                 stripOf(r, rccl.world, g.height, &rf, &rc);
             if (rc > 0)
                 fine = rcclOk(rccl.Recv((char *)assembled + (size_t)rf * rowBytes, (size_t)rc * rowBytes / perByte, datatype, r,
-                                        rccl.comm, stream),
+                                        comm, stream),
                               "ncclRecv");
         }
     if (fine && count > 0)
-        fine = rcclOk(rccl.Send(payload, (size_t)count * rowBytes / perByte, datatype, root, rccl.comm, stream), "ncclSend");
+        fine = rcclOk(rccl.Send(payload, (size_t)count * rowBytes / perByte, datatype, root, comm, stream), "ncclSend");
     if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd"))
         fine = false;
     return fine;
@@ -5314,8 +5488,16 @@ int gatherImpl(int root, bool ids, const char *who)
                  __FILE__, __LINE__);
         return -1;
     }
+    if (!ids && rccl.rank == root && rccl.frameCopy[flight] >= 0)
+    {
+        /* a pipelined read-back (solr_hip_d2h_gathered_async) may still be copying the frame this flight assembled
+         * last: the gather that overwrites it goes behind that copy */
+        if (gFirst.imageDone[rccl.frameCopy[flight]])
+            (void)hipStreamWaitEvent(stream, gFirst.imageDone[rccl.frameCopy[flight]], 0);
+        rccl.frameCopy[flight] = -1;
+    }
     const bool fine = gatherRows(root, mine ? src : nullptr, rccl.rank == root ? assembled.ptr : nullptr, rowBytes,
-                                 ids ? RCCL_INT32 : RCCL_UINT8, ids ? 4 : 1, stream, who);
+                                 ids ? RCCL_INT32 : RCCL_UINT8, ids ? 4 : 1, stream, commOf(flight), who);
     if (!ids)
         rccl.lastFlight = flight;
     else
@@ -5363,6 +5545,35 @@ int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap)
     return ok() ? 0 : -1;
 }
 
+/* The delivered frame of an N-GPU job, pipelined: on the root, the assembled frame of the gather issued last is copied
+ * to a page-locked host image on the engine's copy stream, behind that gather, and a ticket comes back at once
+ * (solr_hip_image_wait(ticket) waits for it and returns the image) - the read-back of frame n overlaps the rendering
+ * and the gather of frames n + 1 ..., like solr_hip_d2h_image_async does on one GPU.  The next gather into the same
+ * flight's frame waits for the copy.  On the other ranks: nothing to deliver, returns -2 (no error). */
+int solr_hip_d2h_gathered_async(void)
+{
+    if (!ready("solr_hip_d2h_gathered_async"))
+        return -1;
+    if (!rccl.comm || !rccl.frame[rccl.lastFlight].ptr)
+        return -2;
+    HIPCHECK(hipSetDevice(g.device));
+    if (!ensureImageRing())
+        return -1;
+    ensureCopyStream();
+    if (!ok())
+        return -1;
+    const int flight = rccl.lastFlight;
+    int slot = 0;
+    const int ticket = nextTicket(&slot);
+    HIPCHECK(hipEventRecord(g.frameRendered, flightStream(flight)));
+    HIPCHECK(hipStreamWaitEvent(g.copyStream, g.frameRendered, 0));
+    HIPCHECK(hipMemcpyAsync(g.pinnedImage[slot], rccl.frame[flight].ptr, (size_t)g.height * g.width * SOLR_COLOR_DEPTH,
+                            hipMemcpyDeviceToHost, g.copyStream));
+    HIPCHECK(hipEventRecord(g.imageDone[slot], g.copyStream));
+    rccl.frameCopy[flight] = slot;
+    return ok() ? ticket : -1;
+}
+
 int solr_hip_d2h_gathered_ids(PrimitiveXYIdBuffer *hostIds)
 {
     if (!ready("solr_hip_d2h_gathered_ids"))
@@ -5383,9 +5594,16 @@ void solr_hip_comm_finalize(void)
     if (rccl.comm)
     {
         (void)hipDeviceSynchronize();
+        for (int f = 1; f < MAX_FLIGHTS; ++f)
+            if (rccl.flightComm[f] && rccl.flightComm[f] != rccl.comm)
+                (void)rccl.CommDestroy(rccl.flightComm[f]);
         (void)rccl.CommDestroy(rccl.comm);
         rccl.comm = nullptr;
     }
+    for (ncclComm_t &c : rccl.flightComm)
+        c = nullptr;
+    for (int &slot : rccl.frameCopy)
+        slot = -1;
     for (DeviceBuffer &b : rccl.frame)
         release(b);
     release(rccl.idsFrame);
@@ -5419,4 +5637,294 @@ void solr_hip_wave_cycles(unsigned long long out[16], int reset)
         (void)hipMemset((unsigned long long *)g.counters.ptr + 16, 0, slots.size() * sizeof(unsigned long long));
 }
 #endif
+}
+
+/* ======================================================================= */
+/* The boundary, once per in-process device                                  */
+/* ======================================================================= */
+/* CudaRayTracer.h:25-67 with occupancyParameters.x honoured as the reference honours it: that many devices of THIS
+ * process (clamped to the devices there are, CudaRayTracer.cu:1413-1424), every upload repeated per device
+ * (:1536-1625), the frame cut into equal row strips, device d rendering strip d (:1694-1696, 1709-1815), and
+ * d2h_bitmap copying every device's strip to its place in the host arrays (:1647-1672).  One device - what every
+ * caller of this library but a host that edits CudaKernel.cpp:90 asks for - is engine 0 alone and nothing below adds
+ * to it.  occupancyParameters.y (streams per device; the reference's arithmetic for it is broken) is
+ * accepted and not used: how a device's strip is scheduled is the engine's business, like blockSize.
+ * Several devices in one process and the one-process-per-GPU model (solr_hip_set_strip, solr_hip_comm_*) do not
+ * combine; either refuses the other.  Neighbourhood post-processing (ambient occlusion, depth of field, radiosity,
+ * filter) stays inside a device's strip here, as in the reference (the multi-process path trades the boundary rows).
+ * SOLR_HIP_VIRTUAL_DEVICES=n (tests on a one-GPU box): pretend n devices, engine d on device d mod the real ones. */
+namespace
+{
+bool gSplit = false; /* the strips of the engines are the in-process split's */
+int gAskNext = 1;    /* solr_hip_set_gpu_count: what solr_hip_initialize (the pointer form) asks for */
+
+int devicesThereAre()
+{
+    int real = 0;
+    if (hipGetDeviceCount(&real) != hipSuccess)
+        real = 0;
+    static const int pretend = getenv("SOLR_HIP_VIRTUAL_DEVICES") ? atoi(getenv("SOLR_HIP_VIRTUAL_DEVICES")) : 0;
+    return (real > 0 && pretend > real) ? pretend : real;
+}
+
+/* engines 0 ... n - 1 exist; the later ones take the settings of engine 0 and the devices that follow its device */
+void ensureEngines(int n)
+{
+    int real = 0;
+    if (hipGetDeviceCount(&real) != hipSuccess || real < 1)
+        real = 1;
+    for (int d = 1; d < n && d < SOLR_MAX_GPU_COUNT; ++d)
+    {
+        if (!gEngines[d])
+            gEngines[d] = new Engine;
+        Engine &e = *gEngines[d];
+        e.device = (gFirst.device + d) % real;
+        e.variant = gFirst.variant;
+        e.grouping = gFirst.grouping;
+        e.flights = gFirst.flights;
+        e.tileScheduling = gFirst.tileScheduling;
+        e.timing = gFirst.timing;
+    }
+}
+
+/* equal row strips, device d the d-th (the split of solr_hip_strip_rows, what the multi-process path uses too) */
+void splitRows(int height)
+{
+    if (gDevices < 2)
+    {
+        if (gSplit)
+        {
+            gSplit = false;
+            quiesce();
+            gFirst.firstRow = 0;
+            gFirst.nbRows = -1;
+        }
+        return;
+    }
+    gSplit = true;
+    onEveryDevice([&](int d) {
+        int first = 0, count = 0;
+        solr_hip_strip_rows(d, gDevices, height, &first, &count, nullptr);
+        if (g.firstRow != first || g.nbRows != count)
+        {
+            quiesce();
+            g.firstRow = first;
+            g.nbRows = count;
+        }
+    });
+}
+
+bool sameOccupancy(const vec2i &occ, const char *who)
+{
+    if (occ.x < 1 || occ.x == gRequested || (occ.x > SOLR_MAX_GPU_COUNT && gRequested == SOLR_MAX_GPU_COUNT))
+        return true;
+    Engine *const was = gCurrent;
+    gCurrent = &gFirst;
+    setError(-1, (std::string(who) + ": occupancyParameters.x is not what initialize_scene was given").c_str(), __FILE__, __LINE__);
+    gCurrent = was;
+    return false;
+}
+} // namespace
+
+extern "C" {
+
+void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, int)
+{
+    if (solr_hip_last_error(nullptr, 0) != 0)
+        return;
+    int asked = occupancyParameters.x < 1 ? 1 : occupancyParameters.x;
+    if (asked > SOLR_MAX_GPU_COUNT)
+        asked = SOLR_MAX_GPU_COUNT; /* CudaRayTracer.cu:1415-1416 */
+    int use = asked;
+    if (asked > 1)
+    {
+        if (rccl.comm)
+        {
+            setError(-1, "initialize_scene: occupancyParameters.x > 1 asks for several devices in this process, which has "
+                         "joined a communicator (one process per GPU): the two do not combine", __FILE__, __LINE__);
+            return;
+        }
+        const int have = devicesThereAre();
+        if (asked > have)
+        {
+            /* CudaRayTracer.cu:1419-1424: "You asked for n CUDA-capable devices, but only m are available" */
+            fprintf(stderr, "solr_hip: initialize_scene was asked for %d devices (occupancyParameters.x), %d are available\n",
+                    asked, have);
+            use = have < 1 ? 1 : have;
+        }
+    }
+    /* engines an earlier call set up beyond what this one uses */
+    for (int d = use; d < SOLR_MAX_GPU_COUNT; ++d)
+        if (d > 0 && gEngines[d] && gEngines[d]->initialized)
+        {
+            gCurrent = gEngines[d];
+            (void)hipSetDevice(g.device);
+            finalizeOne();
+            gCurrent = &gFirst;
+        }
+    gRequested = asked;
+    gDevices = use;
+    ensureEngines(use);
+    onEveryDevice([&](int) { initializeOne(sceneInfo); });
+    splitRows(sceneInfo.size.y);
+}
+
+void solr_hip_set_gpu_count(int n)
+{
+    gAskNext = n < 1 ? 1 : n;
+}
+
+int solr_hip_gpu_count(void)
+{
+    return gDevices;
+}
+
+void solr_hip_initialize(const SceneInfo *sceneInfo)
+{
+    vec2i occ;
+    occ.x = gAskNext;
+    occ.y = 1;
+    initialize_scene(occ, *sceneInfo, 0, 0, 0);
+}
+
+void finalize_scene(vec2i)
+{
+    /* every engine that is up, whatever occupancyParameters says by now */
+    const int devices = gDevices;
+    gDevices = SOLR_MAX_GPU_COUNT;
+    for (int d = 0; d < SOLR_MAX_GPU_COUNT; ++d)
+        if (gEngines[d] && gEngines[d]->initialized)
+        {
+            gCurrent = gEngines[d];
+            if (devices > 1)
+                (void)hipSetDevice(g.device);
+            finalizeOne();
+        }
+    gCurrent = &gFirst;
+    gDevices = devices;
+    if (devices > 1)
+        (void)hipSetDevice(g.device);
+}
+
+void reshape_scene(vec2i occupancyParameters, SceneInfo sceneInfo)
+{
+    if (!sameOccupancy(occupancyParameters, "reshape_scene"))
+        return;
+    splitRows(sceneInfo.size.y);
+    onEveryDevice([&](int) { reshapeOne(sceneInfo); });
+}
+
+void solr_hip_reshape(const SceneInfo *sceneInfo)
+{
+    vec2i occ;
+    occ.x = 0;
+    occ.y = 1;
+    reshape_scene(occ, *sceneInfo);
+}
+
+void h2d_scene(vec2i occupancyParameters, BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *primitives,
+               int nbPrimitives, Lamp *lamps, int nbLamps)
+{
+    if (!sameOccupancy(occupancyParameters, "h2d_scene"))
+        return;
+    onEveryDevice([&](int) { h2dSceneOne(boundingBoxes, nbActiveBoxes, primitives, nbPrimitives, lamps, nbLamps); });
+}
+
+void h2d_materials(vec2i occupancyParameters, Material *materials, int nbActiveMaterials)
+{
+    if (!sameOccupancy(occupancyParameters, "h2d_materials"))
+        return;
+    onEveryDevice([&](int) { h2dMaterialsOne(materials, nbActiveMaterials); });
+}
+
+void h2d_randoms(vec2i occupancyParameters, float *randoms)
+{
+    if (!sameOccupancy(occupancyParameters, "h2d_randoms"))
+        return;
+    onEveryDevice([&](int) { h2dRandomsOne(randoms); });
+}
+
+void solr_hip_h2d_randoms_sized(const float *randoms, long count)
+{
+    onEveryDevice([&](int) { h2dRandomsSizedOne(randoms, count); });
+}
+
+void h2d_textures(vec2i occupancyParameters, int activeTextures, TextureInfo *textureInfos)
+{
+    if (!sameOccupancy(occupancyParameters, "h2d_textures"))
+        return;
+    onEveryDevice([&](int) { h2dTexturesOne(activeTextures, textureInfos); });
+}
+
+void h2d_lightInformation(vec2i occupancyParameters, LightInformation *lightInformation, int lightInformationSize)
+{
+    if (!sameOccupancy(occupancyParameters, "h2d_lightInformation"))
+        return;
+    onEveryDevice([&](int) { h2dLightInformationOne(lightInformation, lightInformationSize); });
+}
+
+void cudaRender(vec2i occupancyParameters, vec4i, SceneInfo sceneInfo, vec4i objects, PostProcessingInfo postProcessingInfo,
+                vec3f origin, vec3f direction, vec4f angles)
+{
+    if (!sameOccupancy(occupancyParameters, "cudaRender"))
+        return;
+    const float o[3] = {origin.x, origin.y, origin.z};
+    const float d[3] = {direction.x, direction.y, direction.z};
+    const float a[4] = {angles.x, angles.y, angles.z, angles.w};
+    splitRows(sceneInfo.size.y);
+    /* (asynchronous: the devices render their strips side by side) */
+    onEveryDevice([&](int) { renderImpl(sceneInfo, objects, postProcessingInfo, o, d, a, false, nullptr); });
+}
+
+void solr_hip_render(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
+                     const float origin[3], const float direction[3], const float angles[4])
+{
+    splitRows(sceneInfo->size.y);
+    onEveryDevice([&](int) { renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, false, nullptr); });
+}
+
+void d2h_bitmap(vec2i occupancyParameters, SceneInfo sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds)
+{
+    if (!sameOccupancy(occupancyParameters, "d2h_bitmap"))
+        return;
+    if (gDevices < 2)
+    {
+        d2hBitmapOne(sceneInfo, bitmap, primitivesXYIds, true);
+        return;
+    }
+    /* every device's strip to its place in the host arrays (CudaRayTracer.cu:1647-1672): enqueued on all of them,
+     * then waited for */
+    onEveryDevice([&](int) { d2hBitmapOne(sceneInfo, bitmap, primitivesXYIds, false); });
+    onEveryDevice([&](int) { d2hBitmapWait(); });
+}
+
+void solr_hip_d2h(const SceneInfo *sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds)
+{
+    vec2i occ;
+    occ.x = 0;
+    occ.y = 1;
+    d2h_bitmap(occ, *sceneInfo, bitmap, primitivesXYIds);
+}
+
+void solr_hip_synchronize(void)
+{
+    onEveryDevice([&](int) { synchronizeOne(); });
+}
+
+void solr_hip_set_movable(const unsigned char *flags, int nbPrimitives)
+{
+    onEveryDevice([&](int) { setMovableOne(flags, nbPrimitives); });
+}
+
+/* (every in-process device holds the scene and rotates its own copy; 1 only when all of them did) */
+int solr_hip_rotate_primitives(const float center[3], const float cosAngles[3], const float sinAngles[3], float viewDistance)
+{
+    int status = 1; /* 1: rotated on the device */
+    onEveryDevice([&](int) {
+        const int mine = rotatePrimitivesOne(center, cosAngles, sinAngles, viewDistance);
+        if (mine != 1 && status == 1)
+            status = mine;
+    });
+    return status;
+}
 }

@@ -307,6 +307,10 @@ public:
     virtual void setFramesInFlight(int n) { (void)n; }
     virtual int getFramesInFlight() const { return 1; }
     virtual void flushFrames() {}
+    /* devices of this process the frame is shared out over (m_occupancyParameters.x, which the reference leaves at 1
+     * with no way to set it: CudaKernel.cpp:90); engines without a device keep 1 */
+    virtual void setGpuCount(int n) { (void)n; }
+    virtual int getGpuCount() const { return 1; }
     /* 0 = ok, otherwise the engine's pending error (no reference equivalent:
      * the reference exits the process on a device error) */
     virtual int lastError(std::string *message = nullptr) { (void)message; return 0; }

@@ -67,7 +67,12 @@ void HipKernel::releaseDevice()
     fetchPrimitiveIds(); /* and so would the last frame's ids */
     flushFrames();
     if (m_bitmapView && !m_bitmap.empty())
-        memcpy(m_bitmap.data(), m_bitmapView, m_bitmap.size()); /* the engine's page-locked images go with it */
+    {
+        /* the engine's page-locked images go with it.  They are as large as the frame rendered last; m_bitmap only
+         * ever grows (GPUKernel::render_begin) and may be larger - after a reshape to a smaller size */
+        const size_t frame = (size_t)m_sceneInfo.size.x * (size_t)m_sceneInfo.size.y * (size_t)SOLR_COLOR_DEPTH;
+        memcpy(m_bitmap.data(), m_bitmapView, frame < m_bitmap.size() ? frame : m_bitmap.size());
+    }
     m_bitmapView = nullptr;
     if (m_deviceInitialized)
         finalize_scene(m_occupancyParameters);
@@ -269,8 +274,12 @@ void HipKernel::render_end()
     if (m_flights > 1)
     {
         /* frames in flight: the oldest read-backs are delivered until fewer than m_flights are under way - the
-         * frame render_begin has just launched keeps rendering.  (The ids on the device are the newest frame's.) */
-        while ((int)m_tickets.size() >= m_flights)
+         * frame render_begin has just launched keeps rendering.  (The ids on the device - getPrimitiveAt - are the
+         * NEWEST frame's, up to m_flights - 1 frames ahead of the image on show.)
+         * While nothing has been delivered since the pipeline was switched on (or the frame re-shaped) the oldest
+         * frame is waited for at once: every render_end that returns hands the caller a rendered image, never the
+         * zeros or the stale frame from before the switch; the lag builds up over the following calls. */
+        while ((int)m_tickets.size() >= m_flights || (m_bitmapView == nullptr && !m_tickets.empty()))
         {
             deliver(m_tickets.front());
             m_tickets.pop_front();
@@ -300,6 +309,32 @@ void HipKernel::setFramesInFlight(int n)
     solr_hip_set_frames_in_flight(m_flights <= 2 ? 1 : 2);
     if (m_flights == 1)
         m_bitmapView = nullptr;
+}
+
+/* occupancyParameters.x: how many devices of this process the frame is shared out over (the reference's
+ * CudaKernel.cpp:90 - a member nobody can set there; include/solr_hip.h initialize_scene).  Takes the device down
+ * and up again; everything is uploaded anew with the next frame. */
+void HipKernel::setGpuCount(int n)
+{
+    n = n < 1 ? 1 : n;
+    if (n == m_occupancyParameters.x)
+        return;
+    const bool up = m_deviceInitialized;
+    if (up)
+        releaseDevice();
+    m_occupancyParameters.x = n;
+    if (up)
+    {
+        initializeDevice();
+        setFramesInFlight(m_flights);
+        m_primitivesTransfered = m_materialsTransfered = m_texturesTransfered = m_randomsTransfered = false;
+        m_refresh = true;
+    }
+}
+
+int HipKernel::getGpuCount() const
+{
+    return m_deviceInitialized ? solr_hip_gpu_count() : m_occupancyParameters.x;
 }
 
 void HipKernel::flushFrames()

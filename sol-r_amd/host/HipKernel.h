@@ -41,6 +41,8 @@ public:
     void setFramesInFlight(int n) override;
     int getFramesInFlight() const override { return m_flights; }
     void flushFrames() override;
+    void setGpuCount(int n) override;
+    int getGpuCount() const override;
 
     /* reference: CudaKernel.h:59-65; accepted and forwarded, the wave64 tile
      * shape is the engine's choice */

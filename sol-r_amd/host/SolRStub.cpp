@@ -145,6 +145,14 @@ int SolRx_SetFramesInFlight(int n)
     return engineStatus();
 }
 
+/* Extension: the frame shared out over n devices of THIS process (the reference's occupancyParameters.x, which its
+ * API cannot set: CudaKernel.cpp:90); returns the number in use after the change (fewer when fewer are there) or -1 */
+int SolRx_SetGpuCount(int n)
+{
+    SingletonKernel::kernel()->setGpuCount(n);
+    return engineStatus() == 0 ? SingletonKernel::kernel()->getGpuCount() : -1;
+}
+
 int SolRx_FlushFrames(void)
 {
     SingletonKernel::kernel()->flushFrames();

@@ -136,6 +136,10 @@ int SolRx_Render(double timer);
  * SolRx_FlushFrames waits for all of them; SolRx_GetBitmap is the image delivered last, without a copy */
 int SolRx_SetFramesInFlight(int n);
 int SolRx_FlushFrames(void);
+/* the frame shared out over n devices of this process (occupancyParameters.x of the boundary, include/solr_hip.h);
+ * returns the number in use, or -1.  With frames in flight the ids behind SolR_GetPrimitiveAt are the newest
+ * frame's, up to n - 1 frames ahead of the image on show. */
+int SolRx_SetGpuCount(int n);
 const BitmapBuffer *SolRx_GetBitmap(void);
 /* flattened arrays of the current frame (owned by the engine, valid until
  * the next compactBoxes / material change) */

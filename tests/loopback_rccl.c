@@ -77,7 +77,7 @@ typedef struct ncclComm
     char token[64];
     char dir[160];
     int rank, world;
-    unsigned long sent[LB_MAX_RANKS], received[LB_MAX_RANKS], reductions;
+    unsigned long sent[LB_MAX_RANKS], received[LB_MAX_RANKS], reductions, splits;
 } Comm;
 typedef Comm *ncclComm_t;
 
@@ -379,6 +379,21 @@ int ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank)
     }
     *comm = c;
     return ncclSuccess;
+}
+
+/* ncclCommSplit with one colour: a second communicator of the same ranks, whose messages and sequence numbers are its
+ * own (the engine asks for one per frame in flight: operations of different communicators do not order against each
+ * other).  Collective on the parent, called by every rank in the same order: the child's token is the parent's plus
+ * the number of the split. */
+int ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t *newcomm, void *config)
+{
+    (void)config;
+    if (!comm || !newcomm || color != 0 || key != comm->rank)
+        return ncclInvalidArgument;
+    ncclUniqueId id;
+    memset(&id, 0, sizeof(id));
+    snprintf(id.internal, sizeof(id.internal), "%.40ss%lu", comm->token, ++comm->splits);
+    return ncclCommInitRank(newcomm, comm->world, id, comm->rank);
 }
 
 int ncclCommCount(const ncclComm_t comm, int *count)

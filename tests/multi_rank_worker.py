@@ -113,7 +113,8 @@ def main():
     assert (shared_seed != 0) == (world > 1)
     first, count, _ = solr.strip_rows(rank, world, H)
     hip.solr_hip_set_strip(first, count)
-    report = {"rank": rank, "equal_strip": [first, count], "shared_seed": shared_seed}
+    report = {"rank": rank, "equal_strip": [first, count], "shared_seed": shared_seed,
+              "communicators": int(hip.solr_hip_comm_count())}
 
     # 1. equal strips, one frame, image and ids
     render()

@@ -1,0 +1,213 @@
+"""occupancyParameters.x honoured: several devices driven from ONE host process through the kept boundary.
+
+The reference's engine loops over `occupancyParameters.x` devices inside every one of its ten entry points
+(CudaRayTracer.cu:1404-1480 per-device set-up, :1536-1625 uploads, :1694-1815 one launch per device on an equal row
+strip, :1647-1672 every device's strip copied to its place in the host arrays); so does this one (the wrappers at the
+end of sol-r_amd/csrc/solr_hip.hip: one Engine per device).  The test boxes have one GPU: SOLR_HIP_VIRTUAL_DEVICES
+lets the library count it several times - engine d on device d mod 1 - so that every line of the per-device code runs:
+separate streams, buffers, scene copies, strips, the assembled read-back.  What is compared is what counts for a host
+that links unchanged: the frame (image, float frame buffer, primitive ids) is the one-device frame BIT FOR BIT, one
+frame at a time, with frames in flight, through refinement and accumulation passes, and after rotations on the
+resident scenes.  Also here: the checks ADVICE.md (round 3) asked for on the read-back ring and HipKernel's teardown.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+os.environ.setdefault("SOLR_HIP_VIRTUAL_DEVICES", "4")
+
+pytestmark = pytest.mark.gpu
+W, H = 200, 148          # 148 rows: not a multiple of 3 devices, nor of the 8-pixel tiles within a strip
+
+
+def _frame(k):
+    image = k.render()
+    return image.copy(), k.postprocessing_buffer(), k.primitive_ids().copy()
+
+
+def _same(a, b, what):
+    assert np.array_equal(a[0], b[0]), what + ": image"
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), what + ": float frame buffer"
+    assert np.array_equal(a[2], b[2]), what + ": primitive ids"
+
+
+def _error(hip):
+    buf = C.create_string_buffer(512)
+    code = hip.solr_hip_last_error(buf, 512)
+    return code, buf.value.decode(errors="replace")
+
+
+@pytest.mark.parametrize("devices", [2, 3])
+def test_the_frame_of_several_in_process_devices_is_the_one_device_frame(solr, devices):
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=3, maxPathTracingIterations=40)
+    try:
+        assert hip.solr_hip_gpu_count() == 1
+        one = [_frame(k)]
+        for it in range(1, 13):                     # refinement passes 1-10, accumulation passes 11-12
+            k.set_scene_info(pathTracingIteration=it)
+            one.append(_frame(k))
+        assert (one[0][2][..., 0] >= 0).mean() > 0.5
+
+        assert k.set_gpu_count(devices) == devices
+        assert hip.solr_hip_gpu_count() == devices
+        for it in range(0, 13):
+            k.set_scene_info(pathTracingIteration=it)
+            _same(_frame(k), one[it], "%d devices, pass %d" % (devices, it))
+
+        # frames in flight through the frame protocol: the pipelined read-back assembles every device's strip
+        k.set_scene_info(pathTracingIteration=0)
+        k.L.SolRx_SetFramesInFlight(3)
+        caller = np.zeros((H, W, 3), np.uint8)
+        for _ in range(7):
+            assert k.L.SolR_RunKernel(0.0, caller.ctypes.data) == 0
+            assert np.array_equal(caller, one[0][0])          # (every call delivers a rendered frame, the first too)
+        assert k.L.SolRx_FlushFrames() == 0
+        k.L.SolRx_SetFramesInFlight(1)
+
+        # the census of the frame is the sum over the devices' strips
+        flat = k.flat_scene()
+        si, ppi, eye, direction, angles = k.frame_parameters()
+        si.pathTracingIteration = 0
+        objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        counts = (C.c_ulonglong * 8)()
+        hip.solr_hip_render_counting(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles), counts)
+        several = [int(c) for c in counts[:4]]
+        assert k.set_gpu_count(1) == 1
+        k.render()
+        hip.solr_hip_render_counting(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles), counts)
+        assert several == [int(c) for c in counts[:4]] and several[0] > W * H
+        _same(_frame(k), one[0], "back on one device")
+        k.check(0, "in-process devices")
+    finally:
+        k.L.SolRx_SetFramesInFlight(1)
+        k.finalize()
+    assert hip.solr_hip_gpu_count() >= 1
+
+
+def test_rotations_on_the_resident_scenes_of_every_device(solr):
+    """SolR_RotatePrimitives on a scene that is resident: every device rotates its own copy (solr_hip_rotate_primitives)"""
+    import scenes_extra as X
+    frames = {}
+    for devices in (1, 2):
+        k = solr.Kernel(engine="hip")
+        X.sticks(k, width=W, height=H)
+        try:
+            assert k.set_gpu_count(devices) == devices
+            got = [_frame(k)]
+            for step in range(3):
+                k.rotate_primitives(center=(0.0, 0.0, 0.0), angles=(0.05 * (step + 1), 0.11, -0.07))
+                got.append(_frame(k))
+            assert solr.hip_lib().solr_hip_device_rotations() == 3, "the rotations ran on the host route"
+            frames[devices] = got
+            k.check(0, "rotations")
+        finally:
+            k.finalize()
+    assert not np.array_equal(frames[1][0][0], frames[1][3][0])
+    for i in range(4):
+        _same(frames[2][i], frames[1][i], "after %d rotations" % i)
+
+
+def test_more_devices_than_there_are_and_what_does_not_combine(solr, capfd):
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=1)
+    try:
+        reference = _frame(k)
+        # CudaRayTracer.cu:1419-1424: asked for more than there are -> a notice, and the devices there are
+        assert k.set_gpu_count(40) == 4                       # SOLR_HIP_VIRTUAL_DEVICES=4
+        assert "asked for 32 devices" in capfd.readouterr().err     # MAX_GPU_COUNT caps the request first (:1415-1416)
+        _same(_frame(k), reference, "clamped to the devices there are")
+        # the one-process-per-GPU model refuses a process that renders on several devices, loudly
+        hip.solr_hip_set_strip(0, 8)
+        code, text = _error(hip)
+        assert code == -1 and "occupancyParameters.x" in text and "one-process-per-GPU" in text
+        hip.solr_hip_clear_error()
+        uid = C.create_string_buffer(128)
+        assert hip.solr_hip_comm_init(0, 1, uid) == -1
+        code, text = _error(hip)
+        assert code == -1 and "communicator" in text
+        hip.solr_hip_clear_error()
+        # the other nine calls must be given what initialize_scene was given (or nothing: values below 1)
+        hip.h2d_randoms(C.c_uint64(2), np.zeros(1920 * 1080, np.float32).ctypes.data)
+        code, text = _error(hip)
+        assert code == -1 and "not what initialize_scene was given" in text
+        hip.solr_hip_clear_error()
+        _same(_frame(k), reference, "after the refusals")
+        k.check(0, "refusals")
+    finally:
+        hip.solr_hip_clear_error()
+        k.finalize()
+
+
+# ---- ADVICE.md, round 3 -----------------------------------------------------------------------------------------
+def test_a_stale_ticket_is_an_error_not_another_frames_image(solr):
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=1)
+    try:
+        k.render()
+        first = hip.solr_hip_d2h_image_async()
+        assert first >= 0 and hip.solr_hip_image_wait(first)
+        later = [hip.solr_hip_d2h_image_async() for _ in range(6)]      # the ring has six images
+        assert len(set(later + [first])) == 7                          # no two tickets alike
+        assert hip.solr_hip_image_wait(later[-1])
+        assert not hip.solr_hip_image_wait(first)                      # its image was handed out again
+        code, text = _error(hip)
+        assert code == -1 and "ticket" in text
+        hip.solr_hip_clear_error()
+        # a larger frame re-allocates the ring: tickets from before are void
+        keep = hip.solr_hip_d2h_image_async()
+        k.set_scene_info(width=2 * W, height=2 * H)
+        k.render()
+        assert hip.solr_hip_d2h_image_async() >= 0
+        assert not hip.solr_hip_image_wait(keep)
+        hip.solr_hip_clear_error()
+    finally:
+        hip.solr_hip_clear_error()
+        k.finalize()
+
+
+def test_teardown_after_a_reshape_to_a_smaller_frame_with_frames_in_flight(solr):
+    """HipKernel::releaseDevice copies the image on show out of the engine's page-locked ring: as many bytes as the
+    frame has now, not as m_bitmap - which only grows - was once sized for"""
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=1920, height=1080, iterations=1)
+    try:
+        k.render()
+        k.set_scene_info(width=256, height=256)
+        k.L.SolRx_SetFramesInFlight(2)
+        small = np.zeros((256, 256, 3), np.uint8)
+        for _ in range(3):
+            assert k.L.SolR_RunKernel(0.0, small.ctypes.data) == 0
+        assert small.any()
+        k.check(0, "small frames")
+    finally:
+        k.finalize()              # used to read 1920 x 1080 x 3 bytes out of a 256 x 256 x 3 image
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=64, height=48, iterations=1)
+    try:
+        assert k.render().any()
+    finally:
+        k.finalize()
+
+
+def test_the_first_call_with_frames_in_flight_delivers_a_rendered_frame(solr):
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=1)
+    try:
+        expected = k.render().copy()
+        k.set_camera((900.0, 0.0, -15000.0))
+        moved = k.render().copy()
+        assert not np.array_equal(moved, expected)
+        k.L.SolRx_SetFramesInFlight(4)
+        caller = np.zeros((H, W, 3), np.uint8)
+        assert k.L.SolR_RunKernel(0.0, caller.ctypes.data) == 0
+        assert np.array_equal(caller, moved)        # not zeros, not the frame from before the switch
+    finally:
+        k.L.SolRx_SetFramesInFlight(1)
+        k.finalize()

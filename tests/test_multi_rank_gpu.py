@@ -33,10 +33,10 @@ def build_loopback():
     return lib
 
 
-def run_ranks(world, transport, timeout=420):
+def run_ranks(world, transport, timeout=420, **extra_env):
     directory = tempfile.mkdtemp(prefix="solr_ranks_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
-        env = dict(os.environ)
+        env = dict(os.environ, **extra_env)
         if transport == "loopback":
             env.update(SOLR_HIP_RCCL_LIBRARY=build_loopback(), SOLR_LOOPBACK_DIR=directory, SOLR_LOOPBACK_TIMEOUT="45")
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multi_rank_worker.py"), str(r), str(world), directory,
@@ -75,6 +75,15 @@ def check_partitions(reports, height=136):
 @pytest.mark.parametrize("world", [2, 3])
 def test_ranks_sharing_one_gpu_assemble_the_one_gpu_frame(solr, world):
     check_partitions(run_ranks(world, "loopback"))
+
+
+@pytest.mark.gpu
+def test_ranks_with_one_communicator_per_flight(solr):
+    """SOLR_HIP_COMM_PER_FLIGHT=1: the per-frame transfers of flight f on a communicator of their own (split off the
+    first: the mode the first N > 1 run can A/B against the single communicator) - the same frames"""
+    reports = run_ranks(3, "loopback", SOLR_HIP_COMM_PER_FLIGHT="1")
+    check_partitions(reports)
+    assert all(rep["communicators"] == 4 for rep in reports), reports
 
 
 @pytest.mark.gpu
@@ -152,6 +161,20 @@ if world > 1:
         os.environ["SOLR_LOOPBACK_TIMEOUT"] = "0.3"
         assert L.ncclRecv(big.ctypes.data, 20, U8, 1, comm, None) == 2
         os.environ["SOLR_LOOPBACK_TIMEOUT"] = "30"
+# a second communicator of the same ranks (ncclCommSplit): its messages do not mix with the parent's
+L.ncclCommSplit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
+child = C.c_void_p()
+assert L.ncclCommSplit(comm, 0, rank, C.byref(child), None) == 0
+a, b = np.full(8, 100 + rank, np.uint8), np.full(8, 200 + rank, np.uint8)
+ga, gb = np.zeros(8, np.uint8), np.zeros(8, np.uint8)
+peer = (rank + 1) % world
+source = (rank - 1) % world
+assert L.ncclGroupStart() == 0
+L.ncclSend(b.ctypes.data, 8, U8, peer, child, None); L.ncclSend(a.ctypes.data, 8, U8, peer, comm, None)
+L.ncclRecv(ga.ctypes.data, 8, U8, source, comm, None); L.ncclRecv(gb.ctypes.data, 8, U8, source, child, None)
+assert L.ncclGroupEnd() == 0
+assert (ga == 100 + source).all() and (gb == 200 + source).all()
+assert L.ncclCommDestroy(child) == 0
 assert L.ncclCommDestroy(comm) == 0
 print("TRANSPORT_OK", rank)
 '''

@@ -33,10 +33,16 @@ def test_gather_without_a_communicator_is_refused(solr, have_gpu):
 
 
 @pytest.mark.gpu
-def test_native_rccl_gather_with_one_rank(solr):
+@pytest.mark.parametrize("per_flight", [0, 1], ids=["one communicator", "one communicator per flight"])
+def test_native_rccl_gather_with_one_rank(solr, per_flight):
+    """both communicator modes (solr_hip_comm_set_per_flight): RCCL orders the operations of ONE communicator, so the
+    first N > 1 run can A/B whether gathers of frames in flight on different streams serialise; with real RCCL and one
+    rank both carry the same frames"""
     W, H = 192, 136
     hip = solr.hip_lib()
     hip.solr_hip_gathered_frame.restype = C.c_void_p
+    hip.solr_hip_image_wait.restype = C.c_void_p
+    hip.solr_hip_comm_set_per_flight(per_flight)
     k = solr.Kernel(engine="hip")
     solr.scenes.cornell(k, width=W, height=H, iterations=2)
     full = k.render()
@@ -57,6 +63,7 @@ def test_native_rccl_gather_with_one_rank(solr):
         assert hip.solr_hip_comm_unique_id(uid) == 0
         assert hip.solr_hip_comm_init(0, 1, uid) == 0
         k.check(0, "communicator")
+        assert hip.solr_hip_comm_count() == (4 if per_flight else 1) and hip.solr_hip_comm_ranks() == 1
         # the whole frame
         render()
         assert hip.solr_hip_gather_strips(0) == 0
@@ -87,10 +94,33 @@ def test_native_rccl_gather_with_one_rank(solr):
         hip.solr_hip_d2h(C.byref(si), C.c_void_p(expected.ctypes.data), None)
         assert np.array_equal(image, expected)
         k.check(0, "gather loop")
+        # the delivered frame, pipelined: the assembled frame of every gather copied to a page-locked image behind
+        # it, the host two frames behind (solr_hip_d2h_gathered_async; what bench.py's headline times at N > 1)
+        hip.solr_hip_set_frames_in_flight(2)
+        tickets, seen = [], []
+        for dx in shifts:
+            render(dx)
+            assert hip.solr_hip_gather_strips(0) == 0
+            tickets.append(hip.solr_hip_d2h_gathered_async())
+            assert tickets[-1] >= 0
+            if len(tickets) > 2:
+                ptr = hip.solr_hip_image_wait(tickets[-3])
+                assert ptr
+                seen.append(np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3).copy())
+        for t in tickets[-2:]:
+            ptr = hip.solr_hip_image_wait(t)
+            seen.append(np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3).copy())
+        hip.solr_hip_set_frames_in_flight(1)
+        for dx, got in zip(shifts, seen):
+            render(dx)
+            hip.solr_hip_d2h(C.byref(si), C.c_void_p(expected.ctypes.data), None)
+            assert np.array_equal(got, expected), dx
+        k.check(0, "pipelined delivery")
     finally:
         hip.solr_hip_set_strip(0, -1)
         hip.solr_hip_set_frames_in_flight(1)
         hip.solr_hip_comm_finalize()
+        hip.solr_hip_comm_set_per_flight(0)
         hip.solr_hip_clear_error()
         k.finalize()
 
