@@ -39,13 +39,14 @@ def test_a_launchers_environment_is_respected(solr, have_gpu):
     assert res.returncode == 2 and "WORLD_SIZE=1" in res.stderr
 
 
-def _rehearse(extra, timeout):
+def _rehearse(extra, timeout, **more_env):
     from test_multi_rank_gpu import build_loopback
     directory = tempfile.mkdtemp(prefix="solr_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         env.update(SOLR_BENCH_SHARE_GPU="1", SOLR_HIP_RCCL_LIBRARY=build_loopback(), SOLR_LOOPBACK_DIR=directory,
-                   SOLR_LOOPBACK_TIMEOUT="60", SOLR_BENCH_TIMEOUT=str(timeout))
+                   SOLR_LOOPBACK_TIMEOUT="60", SOLR_BENCH_TIMEOUT=str(timeout), SOLR_BENCH_REGIONS="3")
+        env.update(more_env)     # (three timed regions: a rehearsal's numbers mean nothing, and its transport is files)
         res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + extra,
                              env=env, capture_output=True, text=True, timeout=timeout + 60)
         assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
@@ -70,6 +71,22 @@ def test_two_rank_rehearsal_of_the_default_job(solr):
     assert cfg["rates_mrays_per_s"]["balanced_strips_native_gather"] == pytest.approx(line["value"], rel=1e-3)
     assert "rehearsal" in cfg and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
     assert cfg["step_ms_spread"]["min"] <= cfg["step_ms_spread"]["median"] <= cfg["step_ms_spread"]["max"]
+    # ms_per_step IS the median region, the spread its fastest and slowest: it brackets the headline by construction
+    assert line["regions"] == 3 == cfg["step_ms_spread"]["regions"]
+    assert cfg["step_ms_spread"]["median"] == pytest.approx(line["ms_per_step"], rel=1e-3)
+    # every frame of the timed regions was delivered to rank 0's host memory (the gathered frame, pipelined)
+    assert "gather on rank 0" in cfg["delivery"] and cfg["frames_delivered"] >= 3 * 12
+    assert cfg["rccl_communicators"] == 1 and "one for everything" in cfg["rccl_communicator_mode"]
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_with_one_communicator_per_flight(solr):
+    """the switch the first real N > 1 run can A/B (RCCL orders the operations of one communicator across streams)"""
+    line = _rehearse(["--steps", "12", "--warmup", "3", "--width", "640", "--height", "360"], 600,
+                     SOLR_HIP_COMM_PER_FLIGHT="1")
+    cfg = line["config"]
+    assert cfg["rccl_ranks"] == 2 and cfg["rccl_communicators"] == 4 and "one per frame in flight" in cfg["rccl_communicator_mode"]
+    assert cfg["gathered_equals_single_gpu"] is True
 
 
 @pytest.mark.gpu
