@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the comparison of the gathered frame with the frame rank 0 renders alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-walk-bound", action="store_true",
+                    help="skip the walk's own ceiling (roofline.walk_bound_mrays: a gigabyte of records for one 1080p frame)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
     if args.config == "cfg2":
@@ -561,6 +563,29 @@ def main():
                 device_resident, "%d frames in flight, the image left in HBM, nothing delivered (what earlier rounds "
                 "reported as `value`; median of 9 regions of %d steps)" % (args.frames_in_flight, args.steps))
 
+    # ---- the walk's own ceiling (SURVEY.md 8d's second yardstick; N = 1, untimed extra): the walks of one recorded
+    # frame replayed with nothing but the node loop (include/solr_hip.h solr_hip_walk_bound)
+    walk_bound = None
+    if not distributed and not cfg4 and not args.no_walk_bound:
+        arm("the walk's own ceiling")
+        hip.solr_hip_set_frames_in_flight(1)
+        for _ in range(24):                  # the launch order the timed frames had settles again on one buffer set
+            frame()
+        sync()
+        ms3 = (C.c_double * 3)()
+        stats = (C.c_ulonglong * 4)()
+        if hip.solr_hip_walk_bound(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles), 20,
+                                   ms3, stats) == 0:
+            walk_bound = {"replay_ms": float(ms3[1]), "replay_ms_min": float(ms3[2]), "walks_recorded_per_wave": int(stats[0]),
+                          "walks_not_replayed": int(stats[1]), "leaf_entries_per_lane": int(stats[2]),
+                          "workgroups": int(stats[3])}
+        else:
+            buf = C.create_string_buffer(512)
+            hip.solr_hip_last_error(buf, 512)
+            walk_bound = {"error": buf.value.decode(errors="replace")}
+            hip.solr_hip_clear_error()
+        use_delivery_pipeline()
+
     # ---- N > 1 extras (untimed): the gather alone, and the assembled frame against the frame one GPU renders
     gather_only_ms = None
     check = None
@@ -757,6 +782,24 @@ def main():
         for name, (seconds, what) in rates.items():
             out["config"]["rates_mrays_per_s"][name] = round(rays_total / seconds / 1e6, 1)
             out["config"]["rates_note"][name] = "%s: %.4f ms per frame" % (what, seconds * 1e3)
+    if walk_bound and "replay_ms" in walk_bound and walk_bound["replay_ms"] > 0:
+        # the frame's walks with nothing but the node loop (the same waves, rays and lists; shadow walks node for node,
+        # closest-hit walks with their final cut-off from the first node): what the walk STRUCTURE costs, and the rate
+        # a renderer whose leaves and shading were free would reach on this frame
+        bound = rays_total / (walk_bound["replay_ms"] * 1e-3) / 1e6
+        out["roofline"]["walk_bound_mrays"] = round(bound, 1)
+        out["roofline"]["walk_bound"] = {
+            "node_loop_only_ms": round(walk_bound["replay_ms"], 5), "node_loop_only_ms_min": round(walk_bound["replay_ms_min"], 5),
+            "frac_of_bound_achieved": round(mrays / bound, 4),
+            "frac_of_bound_achieved_by_the_kernel_alone": round(walk_bound["replay_ms"] / kernel_avg_ms, 4) if kernel_avg_ms > 0 else None,
+            "walks_recorded_per_wave": walk_bound["walks_recorded_per_wave"],
+            "walks_not_replayed": walk_bound["walks_not_replayed"],
+            "leaf_entries_per_lane": walk_bound["leaf_entries_per_lane"], "workgroups": walk_bound["workgroups"],
+            "note": "solr_hip_walk_bound: one frame's walks recorded (list, ray, cut-off, when a shadow lane was done), "
+                    "replayed 20 times with the node loop alone at the renderer's occupancy, HIP events around each launch"}
+    elif walk_bound:
+        out["roofline"]["walk_bound_mrays"] = None
+        out["roofline"]["walk_bound"] = walk_bound
     if valu and kernel_avg_ms > 0:
         # instruction-issue view of the same launch (informative; the contract's roofline is the HBM one): vector
         # instructions against 4 SIMD-32 per CU x one wave64 instruction per 2 cycles, scalar instructions against

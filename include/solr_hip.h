@@ -95,6 +95,19 @@ void cudaRender(vec2i occupancyParameters, vec4i blockSize, SceneInfo sceneInfo,
 /* Part 2 - extensions                                                      */
 /* ======================================================================= */
 
+/* Diagnostics: the walk's own ceiling ("achieved Mrays/s vs a measured empty-traversal upper bound").
+ * Renders one frame whose walks are recorded - which list, and per lane the ray, the cut-off, the leaf visit after which
+ * a shadow lane was done - and replays those walks `repeats` times with NOTHING BUT THE NODE LOOP: the same waves with
+ * the same 64 rays together, the same lists, no leaf record, no primitive test, no shading, no camera, no frame buffer,
+ * at the renderer's occupancy.  Shadow walks replay node for node; a closest-hit walk runs with its final cut-off in
+ * place from the first node (the fewest nodes a walk that finds that hit can visit).  ms[1] / ms[2]: mean / fastest
+ * replay in milliseconds (HIP events, one launch at a time); rays of the frame / that time is the ceiling.  stats: walks
+ * recorded (per wave), walks left out of the replay, leaf entries of the replay (per lane), workgroups.  One GPU, engine
+ * 0, scenes of untextured spheres / planes / triangles / cylinders (the lean kernels).  0, or -1 with the error set. */
+int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
+                        const float origin[3], const float direction[3], const float angles[4], int repeats, double ms[3],
+                        unsigned long long stats[4]);
+
 /* 0 when no error is pending; otherwise the HIP error code (or -1 for an
  * argument/state error) and, if buf != NULL, its text. Does not clear. */
 int solr_hip_last_error(char *buf, int len);

@@ -919,6 +919,8 @@ struct Counters
 {
     unsigned int closest, shadow, boxes, prims; /* per lane */
     unsigned int wNodes, wPrims, wClosest, wShadow; /* per wave (only lane 0's copy is reported) */
+    char *record;          /* COUNT == 2: this workgroup's slot of walk records */
+    unsigned int ordinal;  /* ... and the number of walks it has recorded */
 #ifdef SOLR_TIMING
     /* development build (make EXTRA_HIPFLAGS=-DSOLR_TIMING, tools/wave_time_split.py): shader-clock cycles a wave
      * spends in the node loop, at leaves, in either walk as a whole, and how often */
@@ -934,10 +936,13 @@ struct Counters
 #define SOLR_T(...)
 #endif
 
-template <bool COUNT>
+/* COUNT: 0 a frame; 1 the ray census (solr_hip_render_counting: every walk in its general form, counted);
+ * 2 a frame whose walks are RECORDED for the walk's own ceiling (WalkRecord below) - the frame itself is a frame
+ * like any other */
+template <int COUNT>
 SOLR_DEV void countAdd(unsigned int &c, unsigned int v)
 {
-    if (COUNT)
+    if (COUNT == 1)
         c += v;
 }
 
@@ -953,6 +958,39 @@ SOLR_DEV int waveMinInt(int v)
 }
 
 #define SOLR_CURSOR_DONE 0x7fffffff
+
+/* ---- the walk's own ceiling ("achieved Mrays/s vs a measured empty-traversal upper bound") ----------
+ * A frame rendered with COUNT == 2 leaves, per workgroup, a record of every walk its wave made: which list, and per
+ * lane the ray, the cut-off and when the lane dropped out.  k_walkBound (solr_hip.hip) then replays the frame's walks
+ * with NOTHING BUT THE NODE LOOP: the same waves, the same 64 rays together, the same lists, advanceTidy and nothing
+ * else - no leaf record, no primitive test, no shading, no camera, no frame buffer.  Shadow walks replay exactly (their
+ * cut-off is constant, and a lane leaves after the leaf visit it left after in the frame); a closest-hit walk is
+ * replayed with its FINAL cut-off in place from the first node - the fewest nodes any walk that finds that hit can
+ * visit.  The replay's time is what the walk structure alone costs this frame: rays / that time is the ceiling.
+ * Slot layout: int4 head[SOLR_WALK_SLOTS + 1] (head[0].x = walks recorded; head[1 + j] = {kind, free list?, octant, 0}),
+ * then float4 lanes[SOLR_WALK_SLOTS][64][2] = {origin.xyz, cut-off} {direction.xyz, bits: leaf visit after which the
+ * lane is done, 0x7fffffff never, -1 the lane took no part}. */
+#define SOLR_WALK_SLOTS 16
+#define SOLR_WALK_SLOT_BYTES (16 * (SOLR_WALK_SLOTS + 1) + SOLR_WALK_SLOTS * 64 * 32)
+enum WalkKind
+{
+    WALK_CLOSEST = 0,
+    WALK_SHADOW = 1,
+    WALK_GENERAL = 2 /* not through the node loop (a list that is not nested, non-finite rays): not replayed */
+};
+SOLR_DEV void recordWalk(Counters &cnt, int kind, bool freeList, int octant, bool took_part, const WalkRay &r, float cutOff,
+                         int doneAfter)
+{
+    const unsigned j = cnt.ordinal++;
+    if (j >= SOLR_WALK_SLOTS || !cnt.record)
+        return;
+    const int lane = (int)threadIdx.x & 63;
+    float4 *lanes = (float4 *)(cnt.record + 16 * (SOLR_WALK_SLOTS + 1)) + ((size_t)j * 64 + lane) * 2;
+    lanes[0] = make_float4(r.o.x, r.o.y, r.o.z, cutOff);
+    lanes[1] = make_float4(r.d.x, r.d.y, r.d.z, __int_as_float(took_part ? doneAfter : -1));
+    if (lane == 0)
+        ((int4 *)cnt.record)[1 + j] = make_int4(kind, freeList ? 1 : 0, octant, 0);
+}
 
 /* What a walk holds of the primitive it is testing.  The first primitive of a leaf comes with the leaf's record
  * (scene_layout.h: one 64-byte scalar load brings head, the two rows its test reads next, and the start
@@ -1122,7 +1160,7 @@ SOLR_DEV int nextNode(const Scene &S, int cur, int skip, bool anyEntered, int cu
  * progress, any bounds, any reciprocal.  Tests node `cur` (already in `node`)
  * for the lanes whose cursor is there, moves the lane cursors, picks the next
  * node for the wave and fetches it.  Returns whether any lane entered. */
-template <bool COUNT>
+template <int COUNT>
 SOLR_DEV bool stepGeneral(const Scene &S, const WalkRay &r, bool fastBoxes, float farDistance, int &cursor, int &cur,
                           Row2 &node, int &nbPrimitives, bool &entered, Counters &cnt)
 {
@@ -1424,7 +1462,7 @@ SOLR_DEV bool longRay(v3 d)
     return dd >= 4.f && dd <= 1.0e24f;
 }
 
-template <bool COUNT, int FEAT>
+template <int COUNT, int FEAT>
 SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v3 origin, v3 target, int iteration,
                              int currentMaterialId, int &closestPrimitive, v3 &closestIntersection,
                              v3 &closestNormal, v3 &closestAreas, v3 &colorBox, Counters &cnt)
@@ -1442,7 +1480,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     /* sign-free slab test when it is provably identical (see boxIntersectionFast) */
     const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteRay(r)) == 0ull);
     const bool showBoxes = (FEAT & F_FULL) && si.renderBoxes != 0;
-    const bool tidy = !COUNT && fastBoxes && S.nested && !showBoxes;
+    const bool tidy = COUNT != 1 && fastBoxes && S.nested && !showBoxes;
     /* The order-free list (solr_hip.hip, buildFreeOrderList): the same leaves under a hierarchy of our own, in an
      * order of our own.  The reference's result does not depend on the order in which the leaves are visited when
      * (a) ties go to the smaller flattened index - the primitive the reference visits first - and (b) the cut-off
@@ -1464,7 +1502,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
      * returns it.  Only in the long-list triangle instantiations (the mesh: its bounce rays along the terrain
      * are a third of its longest wave, one frame alone 0.435 -> 0.417 ms); compiled into every kernel it costs the Cornell box
      * 3 % and the molecule 0.7 % (short lists, few bounce rays, the bookkeeping in every accept). */
-    constexpr bool CHECKED_BUILD = !COUNT && (FEAT & F_DEEP) != 0 && (FEAT & F_TRI) != 0;
+    constexpr bool CHECKED_BUILD = COUNT != 1 && (FEAT & F_DEEP) != 0 && (FEAT & F_TRI) != 0;
     const float dd = dot(r.d, r.d);
     const bool unitRays = CHECKED_BUILD && tidy && S.nbBoxesFree > 0 && !freeOrder &&
                           ballot(active && !(dd >= 0.9998f && dd < 4.f)) == 0ull;
@@ -1479,13 +1517,14 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         const bool checked = unitRays && attempt == 0;
         const bool freeList = freeOrder || checked;
         Scene W = S;
+        int octant = 0;
         if (freeList)
         {
             /* eight flattenings of the same hierarchy, the near child first for a direction of that sign octant: the
              * wave takes the octant of its first active lane (any list gives the same result) */
             const int signs = (r.d.x < 0.f ? 1 : 0) | (r.d.y < 0.f ? 2 : 0) | (r.d.z < 0.f ? 4 : 0);
             const int lane = (int)__builtin_ctzll(ballot(lanesNow));
-            const int octant = __builtin_amdgcn_readlane(signs, lane);
+            octant = __builtin_amdgcn_readlane(signs, lane);
             W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
             W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
             W.nbBoxes = S.nbBoxesFree;
@@ -1782,6 +1821,9 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             }
             SOLR_T(cnt.tLeaf += SOLR_NOW() - ta; ++cnt.nLeaf;)
         }
+        if (COUNT == 2) /* this attempt, for the walk's own ceiling: the cut-off it ended with */
+            recordWalk(cnt, tidy ? WALK_CLOSEST : WALK_GENERAL, freeList, octant, lanesNow, r,
+                       freeList ? minDistance * farScale + farOffset : minDistance, SOLR_CURSOR_DONE);
         if (!checked)
             break;
         /* the lanes whose result the order could have decided: once more, in the reference's order */
@@ -1798,7 +1840,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
 
 /* GI:798-908, wave-synchronous.  objectId is the flattened index of the
  * shaded primitive, compared with Primitive.index like the reference does. */
-template <bool COUNT, int FEAT>
+template <int COUNT, int FEAT>
 SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 lampCenter, v3 origin, int lightId,
                           int iteration, v3 &color, int objectId, Counters &cnt)
 {
@@ -1816,7 +1858,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     countAdd<COUNT>(cnt.wShadow, 1);
 
     const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteRay(r)) == 0ull);
-    const bool tidy = !COUNT && fastBoxes && S.nested;
+    const bool tidy = COUNT != 1 && fastBoxes && S.nested;
     /* Order-free shadows.  Where no primitive of the scene is transparent (or a textured plane) the first occluder
      * between the point and the lamp saturates the shadow - result = 0 + 1 x shadowIntensity, exactly - and the
      * lane is done: which occluder that was, and in which order the leaves were visited, cannot be seen in the
@@ -1830,11 +1872,12 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
                            ballot(active && !(longRay(r.d) && minDistance >= 2.f)) == 0ull;
     Scene W = S;
     float farFree = 0.f;
+    int octant = 0;
     if (freeOrder)
     {
         const int signs = ((r.d.x < 0.f ? 1 : 0) | (r.d.y < 0.f ? 2 : 0) | (r.d.z < 0.f ? 4 : 0)) ^ 7;
         const int lane = (int)__builtin_ctzll(ballot(active));
-        const int octant = __builtin_amdgcn_readlane(signs, lane);
+        octant = __builtin_amdgcn_readlane(signs, lane);
         W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
         W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
         W.nbBoxes = S.nbBoxesFree;
@@ -1843,6 +1886,8 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     const int nbBoxes = W.nbBoxes;
     const PackedRay pr = packRay(r);
     int cursor = (active && result < si.shadowIntensity) ? 0 : SOLR_CURSOR_DONE;
+    const bool walked = cursor != SOLR_CURSOR_DONE;
+    int visit = 0, doneAfter = SOLR_CURSOR_DONE; /* (COUNT == 2: the leaf visit after which the lane had its shadow) */
     int cur = 0;
     Row2 node;
     node.a = node.b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1990,10 +2035,19 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
             }
         }
         /* the reference re-tests `result < shadowIntensity` before every node */
+        if (COUNT == 2)
+            ++visit;
         if (cursor != SOLR_CURSOR_DONE && !(result < si.shadowIntensity))
+        {
             cursor = SOLR_CURSOR_DONE;
+            if (COUNT == 2)
+                doneAfter = visit;
+        }
         SOLR_T(cnt.tLeaf += SOLR_NOW() - ta; ++cnt.nLeaf;)
     }
+    if (COUNT == 2)
+        recordWalk(cnt, tidy ? WALK_SHADOW : WALK_GENERAL, freeOrder, octant, walked, r, freeOrder ? farFree : minDistance,
+                   doneAfter);
     result = fmaxf(0.f, fminf(result, si.shadowIntensity));
     SOLR_T(cnt.tShadow += SOLR_NOW() - tw0;)
     return result;
@@ -2106,7 +2160,7 @@ SOLR_DEV float4 intersectionShader(const Scene &S, const SceneInfo &si, int pi, 
 /* GI:916-1080.  Every lane of the wave calls this together; `active` marks
  * the lanes that actually shade.  The light loop is wave-uniform, the shadow
  * walk inside it is wave-synchronous. */
-template <bool COUNT, int FEAT>
+template <int COUNT, int FEAT>
 SOLR_DEV v3 primitiveShader(const Scene &S, bool active, int index, const SceneInfo &si, v3 origin, v3 &normal,
                             int objectId, v3 intersection, v3 areas, v3 &closestColor, int iteration,
                             float &shadowIntensity, v3 &totalBlinn, float4 &attributes, Counters &cnt)
@@ -2370,7 +2424,7 @@ struct V3Ref
  * phases 0, 1 and 2 of one wave-uniform loop with a single walk and a single
  * shader call site, which keeps the instruction footprint and the live
  * register set of the kernel small. */
-template <bool COUNT, int FEAT>
+template <int COUNT, int FEAT>
 SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3 rayD, const SceneInfo &si,
                              float &depthOfField, int4 &primitiveXYId, const ColorStack &cs, Counters &cnt)
 {
@@ -2763,7 +2817,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
  * (eleven: GI:1198-1200 shifts the tenth into the element behind the array; the host sizes the stack for it).
  * VOLUME_RENDERING_NORMALS is not defined in the reference (GI:22, Consts.h:57), `normalize(color)` at GI:1254
  * discards its result. */
-template <bool COUNT, int FEAT>
+template <int COUNT, int FEAT>
 SOLR_DEV v3 launchVolumeRendering(const Scene &S, bool active, int index, v3 rayO, v3 rayD, const SceneInfo &si,
                                   const PostProcessingInfo &ppi, int4 &primitiveXYId, const ColorStack &cs, Counters &cnt)
 {

@@ -88,7 +88,7 @@ static_assert(sizeof(PixelRecord) == sizeof(PostProcessingBuffer), "PixelRecord 
 
 /* VOLUME: the instantiations of the volume camera (ctVolumeRendering) - kernels of their own, so that its trace (a
  * second inlined shader) is not carried, in registers and spills, by every frame of the all-features kernels */
-template <bool COUNT, int FEAT, bool VOLUME = false>
+template <int COUNT, int FEAT, bool VOLUME = false>
 #ifndef SOLR_GENERIC_WAVES
 #define SOLR_GENERIC_WAVES 0 /* experiments: waves per SIMD the instantiations with the texture tier are compiled for (0: as the
                              * others; 3 - 168 registers, 1-51 spills instead of 51-176 - measured within 4 % either way) */
@@ -150,6 +150,8 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
     cs.cold = 4 * F.stackSlots;
 
     Counters cnt = {};
+    if (COUNT == 2) /* a frame whose walks are recorded (rt_device.h recordWalk): `counters` is the record buffer */
+        cnt.record = (char *)counters + (size_t)blockIdx.x * SOLR_WALK_SLOT_BYTES;
     SOLR_T(const unsigned long long tKernel0 = SOLR_NOW();)
 
     v3 rayO = V(F.ox, F.oy, F.oz);
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
         F.tileCost[tileAgain] = partAgain ? (unsigned)(SOLR_SPLIT_LOG2 + 1) * cost : cost;
     }
 #ifdef SOLR_TIMING
-    if (!COUNT && laneAgain == 0 && counters)
+    if (COUNT == 0 && laneAgain == 0 && counters)
     {
         /* one record per workgroup, summed by the host (atomics on one address would serialise the frame) */
         unsigned long long *slot = counters + 16 + 16ull * blockIdx.x;
@@ -438,7 +440,9 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
         slot[7] += 1ull;
     }
 #endif
-    if (COUNT)
+    if (COUNT == 2 && lane == 0)
+        ((int4 *)cnt.record)[0] = make_int4((int)cnt.ordinal, 0, 0, 0);
+    if (COUNT == 1)
     {
         unsigned int vals[4] = {cnt.closest, cnt.shadow, cnt.boxes, cnt.prims};
 #pragma unroll
@@ -459,6 +463,71 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
         }
     }
 }
+
+/* The walk's own ceiling (rt_device.h, WalkRecord): the walks a recorded frame made, replayed with nothing but the node
+ * loop.  Same grid as the recorded launch - workgroup b replays what workgroup b recorded - same dynamic LDS (so that as
+ * many waves share a CU as in the renderer), same FEAT (the two-bank or the three-bank loop).  `visits` keeps the loop
+ * observable: leaf entries per lane. */
+template <int FEAT>
+__global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_walkBound(const SceneArgs SA, const char *__restrict__ records,
+                                                                       unsigned *__restrict__ visits, unsigned *__restrict__ skipped)
+{
+    extern __shared__ float ldsStack[];
+    const Scene S = makeScene(SA);
+    const int lane = threadIdx.x;
+    const char *slot = records + (size_t)blockIdx.x * SOLR_WALK_SLOT_BYTES;
+    const int4 *head = (const int4 *)slot;
+    const float4 *rays = (const float4 *)(slot + 16 * (SOLR_WALK_SLOTS + 1));
+    const int recorded = __builtin_amdgcn_readfirstlane(head[0].x);
+    const int walks = recorded < SOLR_WALK_SLOTS ? recorded : SOLR_WALK_SLOTS;
+    unsigned entries = 0;
+    int left_out = recorded - walks;
+    for (int j = 0; j < walks; ++j)
+    {
+        const int4 h = head[1 + j];
+        const int kind = __builtin_amdgcn_readfirstlane(h.x);
+        if (kind == WALK_GENERAL)
+        {
+            ++left_out;
+            continue;
+        }
+        const float4 a = rays[((size_t)j * 64 + lane) * 2], b = rays[((size_t)j * 64 + lane) * 2 + 1];
+        const int doneAfter = __float_as_int(b.w);
+        const bool took_part = doneAfter >= 0;
+        /* (a lane that took no part gets a harmless ray: its cursor is done from the start) */
+        const WalkRay r = makeWalkRay(V(a.x, a.y, a.z), took_part ? V(b.x, b.y, b.z) : V(1.f, 1.f, 1.f));
+        Scene W = S;
+        if (__builtin_amdgcn_readfirstlane(h.y))
+        {
+            const int octant = __builtin_amdgcn_readfirstlane(h.z);
+            W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
+            W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
+            W.nbBoxes = S.nbBoxesFree;
+        }
+        const PackedRay pr = packRay(r);
+        const float cutOff = a.w;
+        int cursor = took_part ? 0 : SOLR_CURSOR_DONE;
+        int cur = 0, visit = 0;
+        while (cur < W.nbBoxes)
+        {
+            if (ballot(cursor != SOLR_CURSOR_DONE) == 0ull)
+                break;
+            int nbPrimitives;
+            bool entered;
+            const int leaf = advanceTidy<FEAT>(W, pr, cutOff, cursor, cur, nbPrimitives, entered);
+            if (leaf < 0)
+                break;
+            ++visit;
+            entries += entered ? 1u : 0u;
+            if (doneAfter == visit)
+                cursor = SOLR_CURSOR_DONE;
+        }
+    }
+    visits[(size_t)blockIdx.x * WAVE + lane] = entries;
+    if (lane == 0 && left_out > 0)
+        atomicAdd(skipped, (unsigned)left_out);
+}
+
 
 /* CRT:1057-1073 */
 __global__ __launch_bounds__(256) void k_default(const SceneInfo si, int nbPixels,
@@ -1465,6 +1534,16 @@ struct Engine
 
     int variant = 0;
     bool grouping = true; /* groupSiblings(); variant 5 turns it off for A/B measurements */
+
+    /* the walk's own ceiling (solr_hip_walk_bound): the next frame records its walks; how that frame was launched */
+    DeviceBuffer walkRecords, walkVisits;
+    bool recordNext = false;
+    bool recorded = false;
+    unsigned recordGrid = 0;
+    size_t recordLds = 0;
+    int recordVariant = -1; /* row of renderImpl's table */
+    bool recordDeep = false;
+    SceneArgs recordScene;
 };
 
 /* One Engine per device this process renders on.  The reference drives occupancyParameters.x devices from ONE host
@@ -2525,12 +2604,18 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     if (!counting)
     {
         fn = volumeCamera ? k_standardRenderer<false, F_ALL | F_DEEP, true> : k_standardRenderer<false, F_ALL | F_DEEP>;
+        int row = 0, chosen = -1;
         for (const auto &v : variants)
+        {
             if ((need & ~v.features) == 0 && g.variant != 4 && !volumeCamera)
             {
                 fn = deepList ? v.deep : v.shallow;
+                chosen = row;
                 break;
             }
+            ++row;
+        }
+        g.recordVariant = chosen;
     }
     else
         HIPCHECK(hipMemsetAsync(g.counters.ptr, 0, 8 * sizeof(unsigned long long), stream));
@@ -2538,6 +2623,35 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
      * (k_orderTiles); the ones the order does not use return at once */
     F.nbTiles = (int)grid.x;
     const dim3 launchGrid(F.tileOrder ? grid.x + (unsigned)(SPLIT_PARTS - 1) * SPLIT_TILES_MAX : grid.x);
+    if (g.recordNext && !counting)
+    {
+        /* this frame leaves a record of its walks (rt_device.h recordWalk; solr_hip_walk_bound): the same kernel with
+         * COUNT == 2, launched exactly as it would have been - grid, order, LDS - with the record buffer in place of the
+         * counters.  Only the lean rows of the table have such an instantiation. */
+        static const KernelFn recording[4][2] = {
+            {k_standardRenderer<2, F_SPHERE | F_PLANE>, k_standardRenderer<2, F_SPHERE | F_PLANE | F_DEEP>},
+            {k_standardRenderer<2, F_SPHERE | F_TRI>, k_standardRenderer<2, F_SPHERE | F_TRI | F_DEEP>},
+            {k_standardRenderer<2, F_SPHERE | F_CYL>, k_standardRenderer<2, F_SPHERE | F_CYL | F_DEEP>},
+            {k_standardRenderer<2, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_DEEP>, k_standardRenderer<2, F_SPHERE | F_PLANE | F_TRI | F_CYL | F_DEEP>}};
+        g.recordNext = false;
+        ARGCHECK(g.recordVariant >= 0 && g.recordVariant < 4,
+                 "solr_hip_walk_bound: the kernel this scene needs has no recording instantiation (untextured spheres, "
+                 "planes, triangles, cylinders only)");
+        if (!ok())
+            return;
+        reserve(g.walkRecords, (size_t)launchGrid.x * SOLR_WALK_SLOT_BYTES);
+        reserve(g.walkVisits, (size_t)launchGrid.x * WAVE * sizeof(unsigned) + 64);
+        if (!ok())
+            return;
+        HIPCHECK(hipMemsetAsync(g.walkRecords.ptr, 0, (size_t)launchGrid.x * SOLR_WALK_SLOT_BYTES, stream));
+        fn = recording[g.recordVariant][deepList ? 1 : 0];
+        cntPtr = (unsigned long long *)g.walkRecords.ptr;
+        g.recordGrid = launchGrid.x;
+        g.recordLds = ldsBytes;
+        g.recordDeep = deepList || g.recordVariant == 3;
+        g.recordScene = S;
+        g.recorded = true;
+    }
     hipLaunchKernelGGL(fn, launchGrid, block, ldsBytes, stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
     HIPCHECK(hipGetLastError());
     if (e0)
@@ -2900,7 +3014,8 @@ static void finalizeOne()
     collectEvents();
     DeviceBuffer *all[] = {&g.geometry, &g.materials, &g.textures, &g.randoms, &g.lamps,
                            &g.pp,       &g.ids,       &g.bitmap,   &g.counters, &g.tileClock,
-                           &g.tileCost, &g.tileCostSnapshot, &g.tileOrder, &g.tileOrder2, &g.movable,  &g.refitPlan};
+                           &g.tileCost, &g.tileCostSnapshot, &g.tileOrder, &g.tileOrder2, &g.movable,  &g.refitPlan,
+                           &g.walkRecords, &g.walkVisits};
     for (DeviceBuffer *b : all)
         release(*b);
     for (int f = 0; f < MAX_FLIGHTS; ++f)
@@ -4551,6 +4666,99 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
     });
     if (counts)
         memcpy(counts, sum, sizeof(sum));
+}
+
+/* The walk's own ceiling (SURVEY.md 8d's second yardstick; rt_device.h WalkRecord, k_walkBound).  Renders one frame
+ * whose walks are recorded - a frame like any other, launched as the frames before it were - and then replays those
+ * walks `repeats` times with nothing but the node loop, one launch at a time, HIP events around each.  Out:
+ *   ms[0] the recorded frame's own kernel (with the stores of the record: slower than a frame), ms[1] mean, ms[2] min of
+ *   the replays; stats[0] walks recorded (per wave), [1] walks left out of the replay (slots full, or not through the node
+ *   loop), [2] leaf entries the replay made (per lane), [3] workgroups.
+ * Engine 0, one GPU; the lean instantiations only (untextured spheres / planes / triangles / cylinders).  0, or -1. */
+int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
+                        const float origin[3], const float direction[3], const float angles[4], int repeats, double ms[3],
+                        unsigned long long stats[4])
+{
+    if (!ready("solr_hip_walk_bound") || gDevices > 1)
+        return -1;
+    quiesce();
+    HIPCHECK(hipSetDevice(g.device));
+    g.recorded = false;
+    g.recordNext = true;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    if (!ok())
+        return -1;
+    renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, false, nullptr);
+    g.recordNext = false;
+    const hipStream_t stream = flightStream(g.current);
+    HIPCHECK(hipStreamSynchronize(stream));
+    if (!ok() || !g.recorded)
+    {
+        if (ok())
+            setError(-1, "solr_hip_walk_bound: the frame was not recorded", __FILE__, __LINE__);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return -1;
+    }
+    typedef void (*BoundFn)(const SceneArgs, const char *, unsigned *, unsigned *);
+    static const BoundFn replay[4][2] = {
+        {k_walkBound<F_SPHERE | F_PLANE>, k_walkBound<F_SPHERE | F_PLANE | F_DEEP>},
+        {k_walkBound<F_SPHERE | F_TRI>, k_walkBound<F_SPHERE | F_TRI | F_DEEP>},
+        {k_walkBound<F_SPHERE | F_CYL>, k_walkBound<F_SPHERE | F_CYL | F_DEEP>},
+        {k_walkBound<F_SPHERE | F_PLANE | F_TRI | F_CYL | F_DEEP>, k_walkBound<F_SPHERE | F_PLANE | F_TRI | F_CYL | F_DEEP>}};
+    const BoundFn fn = replay[g.recordVariant][g.recordDeep ? 1 : 0];
+    unsigned *visits = (unsigned *)g.walkVisits.ptr;
+    unsigned *skipped = visits + (size_t)g.recordGrid * WAVE;
+    double sum = 0.0, best = 1.0e30;
+    repeats = repeats < 1 ? 1 : repeats;
+    for (int i = 0; i < repeats + 2 && ok(); ++i)
+    {
+        HIPCHECK(hipMemsetAsync(skipped, 0, sizeof(unsigned), stream));
+        HIPCHECK(hipEventRecord(e0, stream));
+        hipLaunchKernelGGL(fn, dim3(g.recordGrid), dim3(WAVE), g.recordLds, stream, g.recordScene, (const char *)g.walkRecords.ptr,
+                           visits, skipped);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipEventRecord(e1, stream));
+        HIPCHECK(hipEventSynchronize(e1));
+        float t = 0.f;
+        HIPCHECK(hipEventElapsedTime(&t, e0, e1));
+        if (i >= 2) /* (two launches to warm the instruction cache and the clocks) */
+        {
+            sum += t;
+            best = t < best ? t : best;
+        }
+    }
+    if (ok() && stats)
+    {
+        std::vector<unsigned> v((size_t)g.recordGrid * WAVE + 1);
+        HIPCHECK(hipMemcpy(v.data(), visits, v.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        std::vector<int> heads((size_t)g.recordGrid * 4);
+        HIPCHECK(hipMemcpy2D(heads.data(), 16, g.walkRecords.ptr, SOLR_WALK_SLOT_BYTES, 16, g.recordGrid, hipMemcpyDeviceToHost));
+        unsigned long long walks = 0, entries = 0;
+        for (unsigned b = 0; b < g.recordGrid; ++b)
+            walks += (unsigned long long)heads[4 * (size_t)b];
+        for (size_t i = 0; i + 1 < v.size(); ++i)
+            entries += v[i];
+        stats[0] = walks;
+        stats[1] = v.back();
+        stats[2] = entries;
+        stats[3] = g.recordGrid;
+    }
+    if (ms)
+    {
+        ms[0] = 0.0;
+        ms[1] = sum / repeats;
+        ms[2] = best;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    /* the buffers are a gigabyte for a 1080p frame: given back at once */
+    release(g.walkRecords);
+    release(g.walkVisits);
+    g.recorded = false;
+    return ok() ? 0 : -1;
 }
 
 void solr_hip_enable_timing(int enable)
