@@ -88,6 +88,12 @@ def parse():
     # accepted for the command lines of earlier rounds: both are the default now
     ap.add_argument("--balanced-strips", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--native-gather", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--delivery", default="strips", choices=["strips", "gathered"],
+                    help="N > 1, how the frame reaches the host: 'strips' - every rank copies its strip over its own PCIe "
+                         "link into one page-locked image the ranks' processes share (solr_hip_image_share; the reference's "
+                         "d2h_bitmap does the same with the devices of its one process) - or 'gathered': rank 0 copies the "
+                         "frame the RCCL gather assembled in its HBM (one PCIe link for the whole frame).  The gather over "
+                         "xGMI runs behind every frame either way")
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the comparison of the gathered frame with the frame rank 0 renders alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -290,6 +296,15 @@ def main():
             k.check(-1, "solr_hip_comm_init")
         rccl_ranks = int(hip.solr_hip_comm_ranks())
         comm_count = int(hip.solr_hip_comm_count())
+        if args.delivery == "strips":
+            # one host image for all ranks: rank 0 creates the segment, the others open it
+            name = ("/solr_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getuid())).encode()
+            if rank == 0 and hip.solr_hip_image_share(name, rank, world) != 0:
+                k.check(-1, "solr_hip_image_share")
+            dist.barrier()
+            if rank != 0 and hip.solr_hip_image_share(name, rank, world) != 0:
+                k.check(-1, "solr_hip_image_share")
+            dist.barrier()
 
     def frame():
         # N = 1: the renderer alone.  N > 1: the renderer writes RGB8 straight into a strip buffer and the
@@ -391,7 +406,8 @@ def main():
             pipe.frame(render)
             return
         frame()
-        tickets.append(hip.solr_hip_d2h_gathered_async() if native else hip.solr_hip_d2h_image_async())
+        tickets.append(hip.solr_hip_d2h_gathered_async() if (native and args.delivery == "gathered")
+                       else hip.solr_hip_d2h_image_async())
         if tickets[-1] == -1:
             k.check(-1, "read-back of the frame")
         while len(tickets) > lag:
@@ -454,7 +470,7 @@ def main():
         if pipe is not None:
             return 0.0, None
         hip.solr_hip_set_frames_in_flight(1)
-        for _ in range(8):
+        for _ in range(PREROLL_FRAMES):     # the tile-cost feedback settles on the one buffer set (sorted every 16th frame)
             frame()
         sync()
         hip.solr_hip_kernel_time(None, 1)
@@ -733,7 +749,12 @@ def main():
                    "delivery": ("frames left on the device (--torch-gather)" if pipe is not None else
                                 "every frame's image lands on the host: page-locked ring, copy stream behind the %s, "
                                 "the host %d frame(s) behind; %d buffer set(s) in the engine; primitive ids on demand "
-                                "(d2h_bitmap when picking asks)" % ("gather on rank 0" if native else "kernel", lag, engine_sets)),
+                                "(d2h_bitmap when picking asks)" %
+                                (("gather on rank 0 (the assembled frame over rank 0's PCIe link)" if args.delivery == "gathered"
+                                  else "kernel on every rank: each strip over its rank's own PCIe link into one image the "
+                                       "ranks' processes share (solr_hip_image_share), rank 0 waits for all of them; the "
+                                       "RCCL gather assembles the same frame in rank 0's HBM") if native else "kernel",
+                                 lag, engine_sets)),
                    "frames_delivered": delivered[0],
                    # nodes per order-free list when long rays' walks use them, else 0
                    "order_free_nodes": int(hip.solr_hip_order_free_nodes()),

@@ -266,6 +266,14 @@ void solr_hip_h2d_randoms_sized(const float *randoms, long count);
  * reference's render_begin / render_end protocol on this. */
 int solr_hip_d2h_image_async(void);
 const BitmapBuffer *solr_hip_image_wait(int ticket);
+/* One host image for all ranks of a multi-process job: the ring of page-locked images becomes a POSIX shared-memory
+ * segment `name` ("/something"; rank 0 creates it, the others open it), registered with the HIP runtime in every
+ * process.  Every rank's solr_hip_d2h_image_async then copies its strip, over its own PCIe link, to its rows of the
+ * same image - what the reference's d2h_bitmap does with the devices of its one process (CudaRayTracer.cu:1647-1672)
+ * - and solr_hip_image_wait on rank 0 returns when every rank's strip of that frame has landed (the others return
+ * when theirs has).  The ranks run the same program: the same sequence of tickets.  After reshape_scene (the frame
+ * size is the segment's); undone by finalize_scene.  0, or -1 with the error set. */
+int solr_hip_image_share(const char *name, int rank, int world);
 
 /* Float framebuffer of the strip back to the host (parity tests) */
 void solr_hip_d2h_postprocessing(PostProcessingBuffer *hostBuffer);

@@ -16,6 +16,13 @@
  */
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 
 #include <cmath>
 #include <cstdio>
@@ -1398,6 +1405,14 @@ struct DeviceBuffer
  * 1/8 strip - one round of waves, as slow as its longest - up to four; six and eight were tried (the mesh's
  * slowest strip: 0.114 ms with three, 0.089 with four, 0.12 and 0.11 with six and eight). */
 const int MAX_FLIGHTS = 4;
+/* head of the shared segment of solr_hip_image_share; the images follow, page-aligned.  done[r][slot]: the serial of
+ * the last copy of rank r into that slot that has landed; consumed: the last serial the root has handed to its host. */
+struct SharedRing
+{
+    std::atomic<long> done[64][MAX_FLIGHTS + 2];
+    std::atomic<long> consumed;
+    long frameBytes, imageStride;
+};
 struct Engine
 {
     bool initialized = false;
@@ -1509,6 +1524,12 @@ struct Engine
      * whose ring was re-allocated for a larger frame) from a live one */
     long imageSerial = 0;
     long slotSerial[IMAGE_RING] = {};
+    /* the ring in memory that several processes share (solr_hip_image_share): every rank's strip lands, over that
+     * rank's own PCIe link, at its rows of ONE host image */
+    struct SharedRing *sharedRing = nullptr;
+    size_t sharedBytes = 0;
+    std::string sharedName;
+    int shareRank = 0, shareWorld = 0;
     /* the reciprocal of tilesX that was verified for a frame geometry (renderImpl) */
     int tileCheckedX = 0, tileCheckedTiles = 0, tileCheckedShift = 0;
     unsigned tileCheckedMagic = 0;
@@ -2727,7 +2748,7 @@ void releaseImageRing()
         (void)hipStreamSynchronize(g.copyStream);
     for (int i = 0; i < Engine::IMAGE_RING; ++i)
     {
-        if (g.pinnedImage[i])
+        if (g.pinnedImage[i] && !g.sharedRing)
             (void)hipHostFree(g.pinnedImage[i]);
         g.pinnedImage[i] = nullptr;
         if (g.imageDone[i])
@@ -2743,6 +2764,15 @@ void releaseImageRing()
     g.pinnedBytes = 0;
     for (long &serial : g.slotSerial)
         serial = -1;
+    if (g.sharedRing)
+    {
+        (void)hipHostUnregister(g.sharedRing);
+        (void)munmap(g.sharedRing, g.sharedBytes);
+        if (g.shareRank == 0)
+            (void)shm_unlink(g.sharedName.c_str());
+        g.sharedRing = nullptr;
+        g.sharedBytes = 0;
+    }
     for (int f = 0; f < MAX_FLIGHTS; ++f)
     {
         g.flightCopy[f][0] = g.flightCopy[f][1] = -1;
@@ -4513,6 +4543,11 @@ bool ensureImageRing()
     const size_t frameBytes = (size_t)e.width * e.height * SOLR_COLOR_DEPTH;
     if (e.pinnedBytes >= frameBytes)
         return true;
+    if (e.sharedRing)
+    {
+        setError(-1, "the frame has grown beyond the host image the ranks share (solr_hip_image_share): share again", __FILE__, __LINE__);
+        return false;
+    }
     Engine *const was = gCurrent;
     gCurrent = &gFirst;
     releaseImageRing(); /* (outstanding tickets are void from here on: their serial no longer matches) */
@@ -4584,9 +4619,110 @@ int solr_hip_d2h_image_async(void)
         return -1;
     int slot = 0;
     const int ticket = nextTicket(&slot);
+    if (g.sharedRing)
+    {
+        /* the slot's last frame must have been handed to the root's host before this rank overwrites its rows (ranks
+         * are a few frames apart at most: normally no wait at all) */
+        const long serial = ticket / Engine::IMAGE_RING;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (g.sharedRing->consumed.load(std::memory_order_acquire) < serial - Engine::IMAGE_RING)
+        {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
+            {
+                setError(-1, "solr_hip_d2h_image_async: the root has not taken the frame this slot of the shared image ring "
+                             "still holds (60 s)", __FILE__, __LINE__);
+                return -1;
+            }
+            sched_yield();
+        }
+    }
     BitmapBuffer *const image = gFirst.pinnedImage[slot];
     onEveryDevice([&](int) { copyStripBehindFrame(image, slot); });
     return solr_hip_last_error(nullptr, 0) == 0 ? ticket : -1;
+}
+
+/* One host image for all ranks of a multi-process job.  The reference copies every device's strip to its place in
+ * the host bitmap over that device's own link (d2h_bitmap, CudaRayTracer.cu:1647-1672); with one process per GPU the
+ * strips meet in memory the processes share: the ring of page-locked images of solr_hip_d2h_image_async becomes a
+ * POSIX shared-memory segment `name` (rank 0 creates it - call it there first, e.g. before a barrier - the others
+ * open it), registered with the HIP runtime in every process.  From then on every rank's solr_hip_d2h_image_async
+ * copies its strip to its rows of the same image, and solr_hip_image_wait on the ROOT (rank 0) returns when every
+ * rank's strip of that frame has landed: the assembled frame on the host at the bandwidth of N PCIe links, not one.
+ * The ranks run the same program (the same sequence of tickets).  After initialize_scene / reshape_scene (the frame
+ * size is the segment's); undone by finalize_scene.  0, or -1 with the error set. */
+int solr_hip_image_share(const char *name, int rank, int world)
+{
+    if (!ready("solr_hip_image_share"))
+        return -1;
+    ARGCHECK(name && name[0] == '/' && rank >= 0 && world >= 1 && world <= 64 && rank < world && gDevices == 1,
+             "solr_hip_image_share: a name like /solr_frame, 0 <= rank < world <= 64, one device per process");
+    ARGCHECK(g.width > 0 && g.height > 0, "solr_hip_image_share: no frame size yet (reshape_scene)");
+    if (!ok())
+        return -1;
+    quiesce();
+    HIPCHECK(hipSetDevice(g.device));
+    releaseImageRing();
+    const size_t frameBytes = (size_t)g.width * g.height * SOLR_COLOR_DEPTH;
+    const size_t stride = (frameBytes + 4095) & ~(size_t)4095;
+    const size_t head = (sizeof(SharedRing) + 4095) & ~(size_t)4095;
+    const size_t bytes = head + stride * Engine::IMAGE_RING;
+    int fd = -1;
+    if (rank == 0)
+    {
+        (void)shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)bytes) != 0)
+        {
+            close(fd);
+            fd = -1;
+        }
+    }
+    else
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        struct stat st;
+        while ((fd = shm_open(name, O_RDWR, 0600)) < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < bytes)
+        {
+            if (fd >= 0)
+                close(fd);
+            fd = -1;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+                break;
+            usleep(2000);
+        }
+    }
+    void *base = fd >= 0 ? mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+    if (fd >= 0)
+        close(fd);
+    if (base == MAP_FAILED)
+    {
+        setError(-1, "solr_hip_image_share: the shared segment could not be created / opened", __FILE__, __LINE__);
+        return -1;
+    }
+    SharedRing *ring = (SharedRing *)base;
+    if (rank == 0)
+    {
+        memset(base, 0, head);
+        ring->frameBytes = (long)frameBytes;
+        ring->imageStride = (long)stride;
+        ring->consumed.store(0, std::memory_order_release);
+    }
+    HIPCHECK(hipHostRegister(base, bytes, hipHostRegisterPortable));
+    if (!ok())
+    {
+        (void)munmap(base, bytes);
+        return -1;
+    }
+    g.sharedRing = ring;
+    g.sharedBytes = bytes;
+    g.sharedName = name;
+    g.shareRank = rank;
+    g.shareWorld = world;
+    for (int i = 0; i < Engine::IMAGE_RING; ++i)
+        g.pinnedImage[i] = (BitmapBuffer *)base + head + stride * i;
+    g.pinnedBytes = frameBytes;
+    g.imageSerial = 0; /* the ranks count their tickets alike from here */
+    return 0;
 }
 
 /* Waits for the copy (every in-process device's strip) behind `ticket` and returns the host image.  A ticket is good
@@ -4605,6 +4741,30 @@ const BitmapBuffer *solr_hip_image_wait(int ticket)
         if (g.imageDone[slot])
             HIPCHECK(hipEventSynchronize(g.imageDone[slot]));
     });
+    if (g.sharedRing && ok())
+    {
+        /* this rank's strip of that frame has landed; the root returns when everybody's has */
+        const long serial = ticket / Engine::IMAGE_RING;
+        SharedRing &ring = *g.sharedRing;
+        ring.done[g.shareRank][slot].store(serial, std::memory_order_release);
+        if (g.shareRank == 0)
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 1; r < g.shareWorld; ++r)
+                while (ring.done[r][slot].load(std::memory_order_acquire) < serial)
+                {
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
+                    {
+                        setError(-1, "solr_hip_image_wait: a rank's strip of this frame has not landed in the shared image (60 s)",
+                                 __FILE__, __LINE__);
+                        return nullptr;
+                    }
+                    sched_yield();
+                }
+            if (ring.consumed.load(std::memory_order_relaxed) < serial)
+                ring.consumed.store(serial, std::memory_order_release);
+        }
+    }
     return solr_hip_last_error(nullptr, 0) == 0 ? gFirst.pinnedImage[slot] : nullptr;
 }
 

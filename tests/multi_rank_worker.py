@@ -138,6 +138,46 @@ def main():
     hip.solr_hip_set_frames_in_flight(1)
     k.check(0, "frames in flight")
 
+    # 2b. the delivered frame: one page-locked host image shared by the ranks' processes (solr_hip_image_share) - every
+    # rank copies its strip over its own link behind its kernel, the host lags two frames, rank 0's wait returns when
+    # every strip of that frame has landed; and the same frames through the gathered route (rank 0 copies the assembled
+    # frame).  Eighteen frames: the ring of six is gone round three times
+    hip.solr_hip_image_wait.restype = C.c_void_p
+    name = ("/solr_ranks_%s" % os.path.basename(directory)).encode()
+    if rank == 0:
+        assert hip.solr_hip_image_share(name, rank, world) == 0
+    barrier("shared image created")
+    if rank != 0:
+        assert hip.solr_hip_image_share(name, rank, world) == 0
+    barrier("shared image open")
+    hip.solr_hip_set_frames_in_flight(2)
+
+    def image_of(ticket):
+        ptr = hip.solr_hip_image_wait(ticket)
+        assert ptr, "solr_hip_image_wait"
+        return np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3).copy()
+
+    for route in ("strips", "gathered"):
+        tickets, seen = [], []
+        for i in range(18):
+            render(dx=100.0 * (i % 9))
+            assert hip.solr_hip_gather_strips(0) == 0
+            t = hip.solr_hip_d2h_image_async() if route == "strips" else hip.solr_hip_d2h_gathered_async()
+            assert t >= 0 or (route == "gathered" and rank != 0 and t == -2), (route, t)
+            tickets.append(t)
+            if len(tickets) > 2 and tickets[-3] >= 0:
+                seen.append(image_of(tickets[-3]))
+        for t in tickets[-2:]:
+            if t >= 0:
+                seen.append(image_of(t))
+        if rank == 0:
+            assert len(seen) == 18
+            for i, got in enumerate(seen):
+                assert np.array_equal(got, ref_moved[i % 9]), "delivered frame %d (%s) is not the one-GPU frame" % (i, route)
+        k.check(0, "delivered frames, " + route)
+        barrier("delivered " + route)
+    hip.solr_hip_set_frames_in_flight(1)
+
     # 3. ambient occlusion across the strips: agreed halo height, rank 0's random buffer on every rank
     render(occlusion)
     assert hip.solr_hip_gather_strips(0) == 0

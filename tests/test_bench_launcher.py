@@ -75,7 +75,7 @@ def test_two_rank_rehearsal_of_the_default_job(solr):
     assert line["regions"] == 3 == cfg["step_ms_spread"]["regions"]
     assert cfg["step_ms_spread"]["median"] == pytest.approx(line["ms_per_step"], rel=1e-3)
     # every frame of the timed regions was delivered to rank 0's host memory (the gathered frame, pipelined)
-    assert "gather on rank 0" in cfg["delivery"] and cfg["frames_delivered"] >= 3 * 12
+    assert "one image the ranks' processes share" in cfg["delivery"] and cfg["frames_delivered"] >= 3 * 12
     assert cfg["rccl_communicators"] == 1 and "one for everything" in cfg["rccl_communicator_mode"]
 
 
@@ -87,6 +87,15 @@ def test_two_rank_rehearsal_with_one_communicator_per_flight(solr):
     cfg = line["config"]
     assert cfg["rccl_ranks"] == 2 and cfg["rccl_communicators"] == 4 and "one per frame in flight" in cfg["rccl_communicator_mode"]
     assert cfg["gathered_equals_single_gpu"] is True
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_delivering_the_gathered_frame(solr):
+    """--delivery gathered: rank 0 copies the frame the gather assembled in its HBM (the A/B of the delivery route)"""
+    line = _rehearse(["--steps", "12", "--warmup", "3", "--width", "640", "--height", "360", "--delivery", "gathered"], 600)
+    cfg = line["config"]
+    assert "gather on rank 0" in cfg["delivery"] and cfg["gathered_equals_single_gpu"] is True
+    assert cfg["frames_delivered"] >= 3 * 12
 
 
 @pytest.mark.gpu
