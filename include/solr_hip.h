@@ -271,7 +271,8 @@ const BitmapBuffer *solr_hip_image_wait(int ticket);
  * process.  Every rank's solr_hip_d2h_image_async then copies its strip, over its own PCIe link, to its rows of the
  * same image - what the reference's d2h_bitmap does with the devices of its one process (CudaRayTracer.cu:1647-1672)
  * - and solr_hip_image_wait on rank 0 returns when every rank's strip of that frame has landed (the others return
- * when theirs has).  The ranks run the same program: the same sequence of tickets.  After reshape_scene (the frame
+ * when theirs has); the image stays valid until rank 0's NEXT solr_hip_image_wait (only then may a rank that runs
+ * ahead overwrite its rows).  The ranks run the same program: the same sequence of tickets.  After reshape_scene (the frame
  * size is the segment's); undone by finalize_scene.  0, or -1 with the error set. */
 int solr_hip_image_share(const char *name, int rank, int world);
 

@@ -1530,6 +1530,8 @@ struct Engine
     size_t sharedBytes = 0;
     std::string sharedName;
     int shareRank = 0, shareWorld = 0;
+    bool slotOfStrips[IMAGE_RING] = {}; /* that slot's ticket was for every rank's strip (not the root's gathered frame) */
+    long lastHandedOut = 0;             /* root: the serial of the image its last solr_hip_image_wait returned */
     /* the reciprocal of tilesX that was verified for a frame geometry (renderImpl) */
     int tileCheckedX = 0, tileCheckedTiles = 0, tileCheckedShift = 0;
     unsigned tileCheckedMagic = 0;
@@ -4636,6 +4638,7 @@ int solr_hip_d2h_image_async(void)
             sched_yield();
         }
     }
+    g.slotOfStrips[slot] = g.sharedRing != nullptr;
     BitmapBuffer *const image = gFirst.pinnedImage[slot];
     onEveryDevice([&](int) { copyStripBehindFrame(image, slot); });
     return solr_hip_last_error(nullptr, 0) == 0 ? ticket : -1;
@@ -4722,6 +4725,7 @@ int solr_hip_image_share(const char *name, int rank, int world)
         g.pinnedImage[i] = (BitmapBuffer *)base + head + stride * i;
     g.pinnedBytes = frameBytes;
     g.imageSerial = 0; /* the ranks count their tickets alike from here */
+    g.lastHandedOut = 0;
     return 0;
 }
 
@@ -4749,8 +4753,13 @@ const BitmapBuffer *solr_hip_image_wait(int ticket)
         ring.done[g.shareRank][slot].store(serial, std::memory_order_release);
         if (g.shareRank == 0)
         {
+            /* asking for the next image gives the last one back: only now may the other ranks overwrite its rows (a
+             * rank can be frames ahead of the root's host - a transport that buffers its sends lets it) */
+            if (ring.consumed.load(std::memory_order_relaxed) < g.lastHandedOut)
+                ring.consumed.store(g.lastHandedOut, std::memory_order_release);
             const auto t0 = std::chrono::steady_clock::now();
-            for (int r = 1; r < g.shareWorld; ++r)
+            /* (a ticket of solr_hip_d2h_gathered_async is the root's own copy of the assembled frame: nobody to wait for) */
+            for (int r = 1; r < g.shareWorld && g.slotOfStrips[slot]; ++r)
                 while (ring.done[r][slot].load(std::memory_order_acquire) < serial)
                 {
                     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
@@ -4761,8 +4770,7 @@ const BitmapBuffer *solr_hip_image_wait(int ticket)
                     }
                     sched_yield();
                 }
-            if (ring.consumed.load(std::memory_order_relaxed) < serial)
-                ring.consumed.store(serial, std::memory_order_release);
+            g.lastHandedOut = serial;
         }
     }
     return solr_hip_last_error(nullptr, 0) == 0 ? gFirst.pinnedImage[slot] : nullptr;
@@ -5923,7 +5931,16 @@ int solr_hip_d2h_gathered_async(void)
     if (!ready("solr_hip_d2h_gathered_async"))
         return -1;
     if (!rccl.comm || !rccl.frame[rccl.lastFlight].ptr)
-        return -2;
+    {
+        if (!g.sharedRing)
+            return -2;
+        /* with a ring the ranks share (solr_hip_image_share) every rank takes the ticket, so that the ranks keep
+         * counting alike; only the root has something to copy */
+        int slot = 0;
+        const int ticket = nextTicket(&slot);
+        g.slotOfStrips[slot] = false;
+        return ticket;
+    }
     HIPCHECK(hipSetDevice(g.device));
     if (!ensureImageRing())
         return -1;
@@ -5938,6 +5955,7 @@ int solr_hip_d2h_gathered_async(void)
     HIPCHECK(hipMemcpyAsync(g.pinnedImage[slot], rccl.frame[flight].ptr, (size_t)g.height * g.width * SOLR_COLOR_DEPTH,
                             hipMemcpyDeviceToHost, g.copyStream));
     HIPCHECK(hipEventRecord(g.imageDone[slot], g.copyStream));
+    g.slotOfStrips[slot] = false;
     rccl.frameCopy[flight] = slot;
     return ok() ? ticket : -1;
 }
