@@ -849,9 +849,14 @@ def main():
 
 
 def _profiled_workload(args, world):
-    if world != 1 or (args.width, args.height) != (1920, 1080) or args.graphics_level != 4 or args.config == "cfg4":
-        return False
-    return not (args.scene == "cornell" and args.iterations != 3)
+    """the key of this workload in the committed profiles (a scene name, or cfg4), None when it was not profiled"""
+    if world != 1 or args.graphics_level != 4:
+        return None
+    if args.config == "cfg4":
+        return "cfg4"
+    if (args.width, args.height) != (1920, 1080) or (args.scene == "cornell" and args.iterations != 3):
+        return None
+    return args.scene
 
 
 def measured_traffic(args, world):
@@ -859,14 +864,15 @@ def measured_traffic(args, world):
     command (profiles/rNN/hbm_traffic.json, written by tools/collect_profiles.py), the file it came from and the
     commit the profile was taken at; None when the workload differs from the profiled one."""
     import glob
-    if not _profiled_workload(args, world):
+    key = _profiled_workload(args, world)
+    if not key:
         return None, None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
         try:
             data = json.load(open(path))
         except (OSError, ValueError):
             continue
-        entry = data.get(args.scene)
+        entry = data.get(key)
         if entry:
             return entry["bytes_per_launch"], os.path.relpath(path, ROOT), entry.get("commit", data.get("commit"))
     return None, None, None
@@ -876,9 +882,10 @@ def measured_counters(args, world):
     """SQ instruction counters per launch of the renderer from the committed PMC passes of this same command
     (profiles/rNN/pmc_<scene>.txt), or None."""
     import glob
-    if not _profiled_workload(args, world):
+    key = _profiled_workload(args, world)
+    if not key:
         return None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_%s.txt" % args.scene)), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_%s.txt" % key)), reverse=True):
         found = {"source": os.path.relpath(path, ROOT)}
         try:
             for line in open(path):

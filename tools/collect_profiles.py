@@ -30,9 +30,10 @@ for scene in SCENES:
     if out:
         hdr = ("# commit %s\n" % commit +
                "# rocprofv3 --pmc, separate passes (two sets of SQ counters; FETCH_SIZE; WRITE_SIZE) of\n"
-               "#   python3 bench.py --scene %s --steps 24 --warmup 12 --no-cpu-baseline --frames-in-flight 1\n"
+               "#   SOLR_BENCH_REGIONS=3 python3 bench.py %s --warmup 12 --no-cpu-baseline --no-walk-bound --frames-in-flight 1\n"
                "# per launch of the renderer kernel.  FETCH_SIZE / WRITE_SIZE are in KB (L2 <-> fabric requests x 64 B;\n"
-               "# MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, WRITE_SIZE is exact).\n" % scene)
+               "# MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, WRITE_SIZE is exact).\n"
+               % ("--config cfg4 --steps 74" if scene == "cfg4" else "--scene %s --steps 24" % scene))
         open(os.path.join(dst, "pmc_%s.txt" % scene), "w").write(hdr + "\n".join(out) + "\n")
 traffic = {}
 if os.path.exists(os.path.join(dst, "hbm_traffic.json")):
@@ -48,7 +49,8 @@ for scene in SCENES:
         if v:
             vals[name] = sum(v) / len(v)
     if len(vals) == 2:
-        traffic[scene] = {"workload": "%s 1920x1080" % scene, "commit": commit, "FETCH_SIZE_KB": round(vals["FETCH_SIZE"], 1),
+        traffic[scene] = {"workload": "%s 1920x1080" % scene if scene != "cfg4" else "cfg4: Cornell 3840x2160, mean over the launches of passes 0...73",
+                          "commit": commit, "FETCH_SIZE_KB": round(vals["FETCH_SIZE"], 1),
                           "WRITE_SIZE_KB": round(vals["WRITE_SIZE"], 1),
                           "bytes_per_launch": int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
                           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB -> bytes; "
@@ -58,10 +60,7 @@ if traffic:
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "tile_timeline_*.txt")) + glob.glob(os.path.join(src, "strip_times_*.txt")) + \
         glob.glob(os.path.join(src, "reference_opencl_speed.txt")) + glob.glob(os.path.join(src, "valu_issue_bench.txt")) + \
-        glob.glob(os.path.join(src, "wave_time_split_*.txt")) + glob.glob(os.path.join(src, "bench_cfg4.json")) + \
+        glob.glob(os.path.join(src, "wave_time_split_*.txt")) + \
         glob.glob(os.path.join(src, "upload_time.txt")) + glob.glob(os.path.join(src, "group_sweep.txt")):
     shutil.copy(f, dst)
-st = os.path.join(src, "trace_cfg4", "trace_kernel_stats.csv")
-if os.path.exists(st):
-    shutil.copy(st, os.path.join(dst, "kernel_stats_cfg4.csv"))
 print(sorted(os.listdir(dst)))

@@ -7,10 +7,14 @@
 TAG=${1:-r1}; SCENE=${2:-cornell}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 EXTRA=""; [ "$SCENE" != cornell ] && EXTRA="--no-cpu-baseline"
-python bench.py --scene $SCENE $EXTRA > $OUT/bench_$SCENE.json 2> $OUT/bench_$SCENE.err; tail -1 $OUT/bench_$SCENE.json | cut -c1-400
+WHAT="--scene $SCENE"; STEPS=24
+# cfg4: BASELINE configs[4], 3840 x 2160 through passes 0...73 (a step is a pass; whole cycles)
+[ "$SCENE" = cfg4 ] && { WHAT="--config cfg4"; STEPS=74; }
+python bench.py $WHAT $EXTRA > $OUT/bench_$SCENE.json 2> $OUT/bench_$SCENE.err; tail -1 $OUT/bench_$SCENE.json | cut -c1-400
 # one frame at a time under the profiler: per-launch durations and counters are then those of the kernel alone
-# (bench.py takes roofline.kernel_ms the same way)
-CMD="python3 $ROOT/bench.py --scene $SCENE --steps 24 --warmup 12 --no-cpu-baseline --frames-in-flight 1"
+# (bench.py takes roofline.kernel_ms the same way).  Three timed regions are plenty for counters; no walk replay.
+export SOLR_BENCH_REGIONS=3
+CMD="python3 $ROOT/bench.py $WHAT --steps $STEPS --warmup 12 --no-cpu-baseline --no-walk-bound --frames-in-flight 1"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$SCENE -o trace -- $CMD > $OUT/trace_$SCENE.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_BUSY_CYCLES \
