@@ -390,6 +390,10 @@ def main():
     # pass renders: a set has a second RGB image for that)
     depth = 2 if cfg4 else max(1, args.frames_in_flight)
     engine_sets = 1 if depth <= 2 else 2
+    if os.environ.get("SOLR_BENCH_ENGINE_SETS"):          # experiments (profiles/r4/readback_routes.txt)
+        engine_sets = max(1, min(4, int(os.environ["SOLR_BENCH_ENGINE_SETS"])))
+    if os.environ.get("SOLR_BENCH_LAG"):
+        depth = int(os.environ["SOLR_BENCH_LAG"]) + 1
     lag = depth - 1
     tickets = deque()
     delivered = [0]

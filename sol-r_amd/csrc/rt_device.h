@@ -59,12 +59,39 @@ SOLR_DEV v3 V(float x, float y, float z)
     return r;
 }
 SOLR_DEV v3 V4(const float4 &a) { return V(a.x, a.y, a.z); }
+#ifdef SOLR_PACKED_V3
+/* experiment (profiles/r4/packed_v3.txt): the x and y components of the vector operators as ONE packed instruction
+ * (v_pk_add_f32 / v_pk_mul_f32: two IEEE binary32 operations, each rounded as the single one is - no contraction,
+ * the same bits), the z component on its own.  The products of a dot product are summed in source order. */
+typedef float pk2 __attribute__((ext_vector_type(2)));
+SOLR_DEV v3 operator+(v3 a, v3 b)
+{
+    const pk2 r = (pk2){a.x, a.y} + (pk2){b.x, b.y};
+    return V(r.x, r.y, a.z + b.z);
+}
+SOLR_DEV v3 operator-(v3 a, v3 b)
+{
+    const pk2 r = (pk2){a.x, a.y} - (pk2){b.x, b.y};
+    return V(r.x, r.y, a.z - b.z);
+}
+SOLR_DEV v3 operator*(v3 a, float b)
+{
+    const pk2 r = (pk2){a.x, a.y} * (pk2){b, b};
+    return V(r.x, r.y, a.z * b);
+}
+SOLR_DEV float dot(v3 a, v3 b)
+{
+    const pk2 p = (pk2){a.x, a.y} * (pk2){b.x, b.y};
+    return p.x + p.y + a.z * b.z;
+}
+#else
 SOLR_DEV v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
 SOLR_DEV v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 SOLR_DEV v3 operator*(v3 a, float b) { return V(a.x * b, a.y * b, a.z * b); }
+SOLR_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+#endif
 SOLR_DEV v3 vdivs(v3 a, float b) { return V(a.x / b, a.y / b, a.z / b); }
 SOLR_DEV v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
-SOLR_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 /* correctly rounded square root: __builtin_sqrtf gets hipcc's IEEE expansion
  * (v_sqrt_f32 + one fma-based correction step); __fsqrt_rn does NOT - it
  * lowers to the bare 1-ULP v_sqrt_f32 on gfx950 */
@@ -79,11 +106,18 @@ SOLR_DEV v3 normalize(v3 v)
 /* VU:45-52 */
 SOLR_DEV v3 cross(v3 b, v3 c)
 {
+#if defined(SOLR_PACKED_V3) && SOLR_PACKED_V3 >= 2
+    const pk2 m1 = (pk2){b.y, b.z} * (pk2){c.z, c.x};
+    const pk2 m2 = (pk2){b.z, b.x} * (pk2){c.y, c.z};
+    const pk2 r = m1 - m2;
+    return V(r.x, r.y, b.x * c.y - b.y * c.x);
+#else
     v3 a;
     a.x = b.y * c.z - b.z * c.y;
     a.y = b.z * c.x - b.x * c.z;
     a.z = b.x * c.y - b.y * c.x;
     return a;
+#endif
 }
 SOLR_DEV float sat1(float v)
 {

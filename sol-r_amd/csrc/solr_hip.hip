@@ -4580,12 +4580,19 @@ void copyStripBehindFrame(BitmapBuffer *image, int slot)
     const int rows = stripRows();
     const int first = g.nbRows >= 0 ? g.firstRow : 0;
     const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr;
-    HIPCHECK(hipEventRecord(g.frameRendered, flightStream(flight)));
-    HIPCHECK(hipStreamWaitEvent(g.copyStream, g.frameRendered, 0));
+    /* SOLR_HIP_COPY_INLINE=1 (experiment, profiles/r4/readback_routes.txt): the copy on the frame's own stream instead of
+     * the copy stream - it then delays that stream's next frame, not the other streams' */
+    static const bool inlineCopy = getenv("SOLR_HIP_COPY_INLINE") && getenv("SOLR_HIP_COPY_INLINE")[0] == '1';
+    const hipStream_t copyOn = inlineCopy ? flightStream(flight) : g.copyStream;
+    if (!inlineCopy)
+    {
+        HIPCHECK(hipEventRecord(g.frameRendered, flightStream(flight)));
+        HIPCHECK(hipStreamWaitEvent(g.copyStream, g.frameRendered, 0));
+    }
     if (rows > 0 && src)
         HIPCHECK(hipMemcpyAsync(image + (size_t)g.width * first * SOLR_COLOR_DEPTH, src,
-                                (size_t)g.width * rows * SOLR_COLOR_DEPTH, hipMemcpyDeviceToHost, g.copyStream));
-    HIPCHECK(hipEventRecord(g.imageDone[slot], g.copyStream));
+                                (size_t)g.width * rows * SOLR_COLOR_DEPTH, hipMemcpyDeviceToHost, copyOn));
+    HIPCHECK(hipEventRecord(g.imageDone[slot], copyOn));
     if (!g.boundBitmap)
         g.flightCopy[flight][g.bitmapSide[flight]] = slot;
 }
