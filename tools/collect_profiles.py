@@ -20,7 +20,7 @@ for scene in SCENES:
         meta = None
         for f in glob.glob(os.path.join(src, "pmc_%s_%s" % (p, scene), "*counter_collection.csv")):
             for r in csv.DictReader(open(f)):
-                if "k_standardRenderer<false" in r["Kernel_Name"]:
+                if ("k_standardRenderer<0," in r["Kernel_Name"] or "k_standardRenderer<false" in r["Kernel_Name"]):
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"])); meta = r
         for k in sorted(agg):
             out.append("%-22s %16.0f   (mean of %d launches)" % (k, sum(agg[k]) / len(agg[k]), len(agg[k])))
@@ -44,7 +44,7 @@ for scene in SCENES:
         v = []
         for f in glob.glob(os.path.join(src, "pmc_%s_%s" % (p, scene), "*counter_collection.csv")):
             for r in csv.DictReader(open(f)):
-                if "k_standardRenderer<false" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                if ("k_standardRenderer<0," in r["Kernel_Name"] or "k_standardRenderer<false" in r["Kernel_Name"]) and r["Counter_Name"] == name:
                     v.append(float(r["Counter_Value"]))
         if v:
             vals[name] = sum(v) / len(v)

@@ -16,7 +16,7 @@ for p in ("i", "d"):
     agg = collections.defaultdict(list)
     for f in glob.glob("$OUT/%s/*counter_collection.csv" % p):
         for r in csv.DictReader(open(f)):
-            if "k_standardRenderer<false" in r["Kernel_Name"]:
+            if "k_standardRenderer<0," in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k in sorted(agg):
         print("%-30s %16.0f   (mean of %d launches)" % (k, sum(agg[k]) / len(agg[k]), len(agg[k])))

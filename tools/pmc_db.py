@@ -1,7 +1,7 @@
 """Per-kernel averages from rocprofv3 --pmc result databases (development aid).
 usage: pmc_db.py 'glob/of/*.db' [kernel-substring]"""
 import sqlite3, glob, sys, collections
-kernel = sys.argv[2] if len(sys.argv) > 2 else "k_standardRenderer<false"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "k_standardRenderer<0,"
 for f in sorted(glob.glob(sys.argv[1], recursive=True)):
     c = sqlite3.connect(f)
     cols = [r[1] for r in c.execute("pragma table_info('counters_collection')")]

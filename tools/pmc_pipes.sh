@@ -27,7 +27,7 @@ out, scene = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(list)
 for f in glob.glob("%s/pipes_%s_*/**/*counter_collection.csv" % (out, scene), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_standardRenderer<false" in r["Kernel_Name"]:
+        if "k_standardRenderer<0," in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("%s/pipes_%s.txt" % (out, scene), "w") as o:
     for k in sorted(agg):

@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc counter_collection.csv files for one kernel (development aid)."""
 import csv, collections, glob, sys
 pattern = sys.argv[1]
-kernel = sys.argv[2] if len(sys.argv) > 2 else "k_standardRenderer<false, false>"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "k_standardRenderer<0,"
 agg = collections.defaultdict(list)
 meta = None
 for f in glob.glob(pattern, recursive=True):

@@ -8,7 +8,7 @@ for t in $TAGS; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/vt_$c; (cd /tmp && rocprofv3 --pmc $c --output-format csv -d /tmp/vt_$c -o pmc -- python3 $ROOT/bench.py --scene $SCENE --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
   done
-  f=$(python3 tools/pmc_summary.py "/tmp/vt_FETCH_SIZE/*counter_collection.csv" "k_standardRenderer<false" | head -1 | awk '{print $2}')
-  w=$(python3 tools/pmc_summary.py "/tmp/vt_WRITE_SIZE/*counter_collection.csv" "k_standardRenderer<false" | head -1 | awk '{print $2}')
+  f=$(python3 tools/pmc_summary.py "/tmp/vt_FETCH_SIZE/*counter_collection.csv" "k_standardRenderer<0," | head -1 | awk '{print $2}')
+  w=$(python3 tools/pmc_summary.py "/tmp/vt_WRITE_SIZE/*counter_collection.csv" "k_standardRenderer<0," | head -1 | awk '{print $2}')
   echo "$t $SCENE kernel_ms=$ms FETCH_KB=$f WRITE_KB=$w"
 done
