@@ -390,10 +390,19 @@ def main():
     # pass renders: a set has a second RGB image for that)
     depth = 2 if cfg4 else max(1, args.frames_in_flight)
     engine_sets = 1 if depth <= 2 else 2
+    copy_inline = False
+    if native and world > 1 and not cfg4 and nb_rows * W <= 200 * 1920:
+        # a strip of a round of waves or two is as slow as its slowest wave: three buffer sets, each copy on its frame's
+        # own stream, the host three frames behind (a 1/8 strip of the Cornell frame: 0.038 ms per delivered frame
+        # against 0.045 with the whole frame's settings; a quarter of the frame and more is served as well or better by
+        # the whole frame's: profiles/r4/readback_routes.txt)
+        depth, engine_sets, copy_inline = 4, 3, True
     if os.environ.get("SOLR_BENCH_ENGINE_SETS"):          # experiments (profiles/r4/readback_routes.txt)
         engine_sets = max(1, min(4, int(os.environ["SOLR_BENCH_ENGINE_SETS"])))
     if os.environ.get("SOLR_BENCH_LAG"):
         depth = int(os.environ["SOLR_BENCH_LAG"]) + 1
+    if distributed and os.environ.get("SOLR_BENCH_STRIP_SETTINGS") == "1":   # (experiments: a one-rank job with a strip's settings)
+        depth, engine_sets, copy_inline = 4, 3, True
     lag = depth - 1
     tickets = deque()
     delivered = [0]
@@ -422,9 +431,13 @@ def main():
             take(tickets.popleft())
         sync()
 
+    if os.environ.get("SOLR_BENCH_COPY_INLINE"):
+        copy_inline = os.environ["SOLR_BENCH_COPY_INLINE"] == "1"
+
     def use_delivery_pipeline():
         if pipe is None:
             hip.solr_hip_set_frames_in_flight(engine_sets)
+            hip.solr_hip_set_copy_route(1 if copy_inline else 0)
 
     def timed(steps, warmup, regions):
         """W untimed steps, then `regions` regions back to back, each EXACTLY `steps` steps between barrier +
@@ -758,7 +771,7 @@ def main():
                                   else "kernel on every rank: each strip over its rank's own PCIe link into one image the "
                                        "ranks' processes share (solr_hip_image_share), rank 0 waits for all of them; the "
                                        "RCCL gather assembles the same frame in rank 0's HBM") if native else "kernel",
-                                 lag, engine_sets)),
+                                 lag, engine_sets)) + ("; copies on the frames' own streams" if copy_inline else ""),
                    "frames_delivered": delivered[0],
                    # nodes per order-free list when long rays' walks use them, else 0
                    "order_free_nodes": int(hip.solr_hip_order_free_nodes()),

@@ -266,6 +266,10 @@ void solr_hip_h2d_randoms_sized(const float *randoms, long count);
  * reference's render_begin / render_end protocol on this. */
 int solr_hip_d2h_image_async(void);
 const BitmapBuffer *solr_hip_image_wait(int ticket);
+/* where the copy of solr_hip_d2h_image_async is enqueued: 0 (default) a copy stream of its own behind the frame's
+ * kernel - best for whole frames with two buffer sets; 1 the frame's own stream (it delays that stream's next frame
+ * only) - best for a rank's strip of an N-GPU frame with three buffer sets (profiles/r4/readback_routes.txt) */
+void solr_hip_set_copy_route(int onTheFramesOwnStream);
 /* One host image for all ranks of a multi-process job: the ring of page-locked images becomes a POSIX shared-memory
  * segment `name` ("/something"; rank 0 creates it, the others open it), registered with the HIP runtime in every
  * process.  Every rank's solr_hip_d2h_image_async then copies its strip, over its own PCIe link, to its rows of the

@@ -1112,6 +1112,64 @@ __global__ __launch_bounds__(256) void k_depthOfField(const SceneInfo si, const 
 namespace
 {
 /* SOLR_HIP_DEBUG_TIMING=1: where the host side of an upload spends its time (stderr) */
+/* SOLR_HIP_HOST_PROFILE=1 (diagnostics): what the HOST spends per call inside the entry points of a frame - at eight
+ * GPUs a strip takes 0.04 ms and the host's own 0.04-0.05 ms per step is what bounds the frame rate.  Totals go to stderr
+ * at finalize_scene. */
+struct HostProfile
+{
+    const bool on = getenv("SOLR_HIP_HOST_PROFILE") != nullptr;
+    struct Entry
+    {
+        const char *name;
+        double seconds;
+        long calls;
+    } entries[16] = {};
+    int used = 0;
+    Entry *find(const char *name)
+    {
+        for (int i = 0; i < used; ++i)
+            if (entries[i].name == name)
+                return &entries[i];
+        if (used < 16)
+        {
+            entries[used].name = name;
+            return &entries[used++];
+        }
+        return nullptr;
+    }
+    void report()
+    {
+        if (!on)
+            return;
+        for (int i = 0; i < used; ++i)
+            fprintf(stderr, "solr_hip host: %-34s %9.3f us per call over %ld calls\n", entries[i].name,
+                    1e6 * entries[i].seconds / (entries[i].calls ? entries[i].calls : 1), entries[i].calls);
+        used = 0;
+    }
+    ~HostProfile() { report(); } /* (a host that never finalizes: at exit) */
+};
+HostProfile gHostProfile;
+struct HostSpan
+{
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostSpan(const char *n) : name(n)
+    {
+        if (gHostProfile.on)
+            t0 = std::chrono::steady_clock::now();
+    }
+    ~HostSpan()
+    {
+        if (!gHostProfile.on)
+            return;
+        if (HostProfile::Entry *e = gHostProfile.find(name))
+        {
+            e->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            e->calls++;
+        }
+    }
+};
+
 struct PhaseTimer
 {
     const bool on = getenv("SOLR_HIP_DEBUG_TIMING") != nullptr;
@@ -1532,6 +1590,7 @@ struct Engine
     int shareRank = 0, shareWorld = 0;
     bool slotOfStrips[IMAGE_RING] = {}; /* that slot's ticket was for every rank's strip (not the root's gathered frame) */
     long lastHandedOut = 0;             /* root: the serial of the image its last solr_hip_image_wait returned */
+    bool copyOnRenderStream = false;    /* solr_hip_set_copy_route */
     /* the reciprocal of tilesX that was verified for a frame geometry (renderImpl) */
     int tileCheckedX = 0, tileCheckedTiles = 0, tileCheckedShift = 0;
     unsigned tileCheckedMagic = 0;
@@ -2321,6 +2380,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                 const float origin[3], const float direction[3], const float angles[4], bool counting,
                 unsigned long long counts[8])
 {
+    HostSpan whole("cudaRender (whole)");
     HaloDebt debt;
     if (ppInfo.type == ppe_ambientOcclusion && haveCommunicator())
     {
@@ -2675,7 +2735,10 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         g.recordScene = S;
         g.recorded = true;
     }
-    hipLaunchKernelGGL(fn, launchGrid, block, ldsBytes, stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
+    {
+        HostSpan launch("  of which the kernel launch");
+        hipLaunchKernelGGL(fn, launchGrid, block, ldsBytes, stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
+    }
     HIPCHECK(hipGetLastError());
     if (e0)
     {
@@ -3035,6 +3098,7 @@ static void initializeOne(const SceneInfo &sceneInfo)
 
 static void finalizeOne()
 {
+    gHostProfile.report();
     if (!g.initialized)
         return;
     (void)hipSetDevice(g.device);
@@ -4580,9 +4644,13 @@ void copyStripBehindFrame(BitmapBuffer *image, int slot)
     const int rows = stripRows();
     const int first = g.nbRows >= 0 ? g.firstRow : 0;
     const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr;
-    /* SOLR_HIP_COPY_INLINE=1 (experiment, profiles/r4/readback_routes.txt): the copy on the frame's own stream instead of
-     * the copy stream - it then delays that stream's next frame, not the other streams' */
-    static const bool inlineCopy = getenv("SOLR_HIP_COPY_INLINE") && getenv("SOLR_HIP_COPY_INLINE")[0] == '1';
+    /* The copy on the frame's own stream instead of the copy stream (solr_hip_set_copy_route; SOLR_HIP_COPY_INLINE=0/1
+     * overrides): it then delays that stream's next frame, not the other streams'.  Measured, profiles/r4/readback_routes.txt:
+     * a whole 1080p frame is best served by two buffer sets and the copy stream (0.272 ms; three sets and their own
+     * streams 0.280), a 1/8 strip - one round of waves, as slow as its slowest - by three sets and their own streams
+     * (0.038 ms against 0.045). */
+    static const char *forced = getenv("SOLR_HIP_COPY_INLINE");
+    const bool inlineCopy = forced && forced[0] ? forced[0] == '1' : gFirst.copyOnRenderStream;
     const hipStream_t copyOn = inlineCopy ? flightStream(flight) : g.copyStream;
     if (!inlineCopy)
     {
@@ -4616,8 +4684,16 @@ bool liveTicket(int ticket, int *slot)
 }
 } // namespace
 
+/* 0 (default): the pipelined read-back copies on a stream of its own behind the frame's kernel; 1: on the frame's own
+ * stream (what to choose: see copyStripBehindFrame) */
+void solr_hip_set_copy_route(int onTheFramesOwnStream)
+{
+    gFirst.copyOnRenderStream = onTheFramesOwnStream != 0;
+}
+
 int solr_hip_d2h_image_async(void)
 {
+    HostSpan whole("solr_hip_d2h_image_async");
     if (!ready("solr_hip_d2h_image_async"))
         return -1;
     ARGCHECK(g.width > 0 && g.height > 0, "solr_hip_d2h_image_async: no frame was rendered");
@@ -4741,6 +4817,7 @@ int solr_hip_image_share(const char *name, int rank, int world)
  * frame that is gone, and asking for it is an error - not, silently, a newer frame's image. */
 const BitmapBuffer *solr_hip_image_wait(int ticket)
 {
+    HostSpan whole("solr_hip_image_wait");
     if (!ready("solr_hip_image_wait"))
         return nullptr;
     int slot = 0;
@@ -5837,6 +5914,7 @@ bool stripIsTheTables()
 
 int gatherImpl(int root, bool ids, const char *who)
 {
+    HostSpan whole("solr_hip_gather_strips / _ids");
     if (!g.initialized || !rccl.comm || root < 0 || root >= rccl.world || g.width < 1 || g.height < 1)
     {
         /* program errors, the same on every rank: nobody is waiting */
