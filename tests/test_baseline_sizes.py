@@ -30,7 +30,8 @@ from helpers import assert_parity, assert_parity_pinned, compare_frames, device_
 solr_mod = importlib.import_module("sol-r_amd")
 
 W, H = 1920, 1080
-MAX_EXCEPTIONS = 24      # pixels of a 2 073 600-pixel frame that may be 2 ULP off, each behind a mis-rounded powf
+MAX_EXCEPTIONS = 8       # pixels of a 2 073 600-pixel frame that may be 2 ULP off, each behind a mis-rounded powf
+                         # (measured: Cornell 1, mesh 0, molecule 1; 900-7 600 pixels of a frame meet such a powf at all)
 
 
 def _frame_args(solr, k):
@@ -163,7 +164,7 @@ def test_cfg0_whole_frame(solr, oracle):
         # against the oracle as pinned (glibc's powf): every pixel within the bar but a counted few, each of which
         # the oracle shows to sit behind a powf result that is not the correctly rounded value
         expected = _oracle_frame(oracle, args)
-        res = assert_parity_pinned(frame, expected[0], expected[1], 4, "cfg0")
+        res = assert_parity_pinned(frame, expected[0], expected[1], 3, "cfg0")       # (measured: 1 of 262 144)
         print(res)
         assert (expected[0][1][..., 0] >= 0).mean() > 0.5
         # and with the power rounded once on both sides there is no exception at all
@@ -259,7 +260,7 @@ def test_cfg4_strips_through_all_74_passes(solr, oracle):
         hip.solr_hip_set_strip(0, -1)
         k.finalize()
     print(worst, "pixels behind a mis-rounded powf outside the bar, all passes:", exceptions)
-    assert exceptions <= 16          # of 74 passes x 30 rows x 3 840 pixels
+    assert exceptions <= 8           # of 74 passes x 30 rows x 3 840 pixels (measured: 3)
 
 
 @pytest.mark.gpu
