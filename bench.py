@@ -284,6 +284,7 @@ def main():
         hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
 
     rccl_ranks = comm_count = None
+    delivery_fallback = None
     if native:
         # the communicator: rank 0's id to everybody over the control plane, then ncclCommInitRank in the library
         uid = C.create_string_buffer(128)
@@ -297,13 +298,30 @@ def main():
         rccl_ranks = int(hip.solr_hip_comm_ranks())
         comm_count = int(hip.solr_hip_comm_count())
         if args.delivery == "strips":
-            # one host image for all ranks: rank 0 creates the segment, the others open it
+            # one host image for all ranks: rank 0 creates the segment, the others open it.  A box that does not let
+            # the processes share page-locked memory (no /dev/shm, a registration the driver refuses) must not void the
+            # job: all ranks then fall back, together, to rank 0 copying the gathered frame - and the line says so
             name = ("/solr_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getuid())).encode()
-            if rank == 0 and hip.solr_hip_image_share(name, rank, world) != 0:
-                k.check(-1, "solr_hip_image_share")
+            mine = 0
+            if os.environ.get("SOLR_BENCH_FAIL_SHARE") == "1" and rank == world - 1:
+                name = b"no-leading-slash"          # (tests: the last rank cannot open the segment)
+            if rank == 0:
+                mine = hip.solr_hip_image_share(name, rank, world)
             dist.barrier()
-            if rank != 0 and hip.solr_hip_image_share(name, rank, world) != 0:
-                k.check(-1, "solr_hip_image_share")
+            if rank != 0:
+                mine = hip.solr_hip_image_share(name, rank, world)
+            failed = torch.tensor([1.0 if mine != 0 else 0.0], dtype=torch.float64)
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+            if float(failed[0]) > 0:
+                buf = C.create_string_buffer(512)
+                hip.solr_hip_last_error(buf, 512)
+                delivery_fallback = "solr_hip_image_share failed on some rank (%s): --delivery gathered instead" % \
+                    (buf.value.decode(errors="replace") or "on another rank")
+                hip.solr_hip_clear_error()
+                hip.solr_hip_image_unshare()
+                args.delivery = "gathered"
+                if rank == 0:
+                    print("bench.py: " + delivery_fallback, file=sys.stderr, flush=True)
             dist.barrier()
 
     def frame():
@@ -772,7 +790,7 @@ def main():
                                        "ranks' processes share (solr_hip_image_share), rank 0 waits for all of them; the "
                                        "RCCL gather assembles the same frame in rank 0's HBM") if native else "kernel",
                                  lag, engine_sets)) + ("; copies on the frames' own streams" if copy_inline else ""),
-                   "frames_delivered": delivered[0],
+                   "frames_delivered": delivered[0], "delivery_fallback": delivery_fallback,
                    # nodes per order-free list when long rays' walks use them, else 0
                    "order_free_nodes": int(hip.solr_hip_order_free_nodes()),
                    "gather": ("none (one GPU)" if not distributed else

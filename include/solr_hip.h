@@ -279,6 +279,7 @@ void solr_hip_set_copy_route(int onTheFramesOwnStream);
  * ahead overwrite its rows).  The ranks run the same program: the same sequence of tickets.  After reshape_scene (the frame
  * size is the segment's); undone by finalize_scene.  0, or -1 with the error set. */
 int solr_hip_image_share(const char *name, int rank, int world);
+void solr_hip_image_unshare(void);
 
 /* Float framebuffer of the strip back to the host (parity tests) */
 void solr_hip_d2h_postprocessing(PostProcessingBuffer *hostBuffer);

@@ -4727,6 +4727,16 @@ int solr_hip_d2h_image_async(void)
     return solr_hip_last_error(nullptr, 0) == 0 ? ticket : -1;
 }
 
+/* back to a ring of this process's own (after solr_hip_image_share; outstanding tickets are void) */
+void solr_hip_image_unshare(void)
+{
+    if (!g.initialized || !g.sharedRing)
+        return;
+    quiesce();
+    (void)hipSetDevice(g.device);
+    releaseImageRing();
+}
+
 /* One host image for all ranks of a multi-process job.  The reference copies every device's strip to its place in
  * the host bitmap over that device's own link (d2h_bitmap, CudaRayTracer.cu:1647-1672); with one process per GPU the
  * strips meet in memory the processes share: the ring of page-locked images of solr_hip_d2h_image_async becomes a

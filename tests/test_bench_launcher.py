@@ -99,6 +99,16 @@ def test_two_rank_rehearsal_delivering_the_gathered_frame(solr):
 
 
 @pytest.mark.gpu
+def test_a_box_that_cannot_share_the_host_image_falls_back_to_the_gathered_frame(solr):
+    """one rank cannot open the shared segment: every rank falls back, together, to rank 0 copying the gathered frame -
+    the job is not void, and its line says what happened"""
+    line = _rehearse(["--steps", "12", "--warmup", "3", "--width", "640", "--height", "360"], 600, SOLR_BENCH_FAIL_SHARE="1")
+    cfg = line["config"]
+    assert "solr_hip_image_share failed" in cfg["delivery_fallback"] and "gather on rank 0" in cfg["delivery"]
+    assert cfg["gathered_equals_single_gpu"] is True and cfg["frames_delivered"] >= 3 * 12
+
+
+@pytest.mark.gpu
 def test_two_rank_rehearsal_of_cfg4(solr):
     """BASELINE configs[4] on two ranks: passes 0...73 at 3840 x 2160, natural depth of field, ambient occlusion
     through the depth-halo exchange on cost-balanced strips; the assembled frames after passes 0, 11 and 73 equal
