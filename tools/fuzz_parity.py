@@ -2,6 +2,7 @@
 parity bar (ids exact, colour <= 1 ULP, RGB8 within 1)."""
 import os, sys, importlib
 os.environ.setdefault("SOLR_HIP_FREE_AFTER", "1")   # one frame per scene: build the order-free lists with it
+os.environ.setdefault("SOLR_HIP_VIRTUAL_DEVICES", "4")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 solr = importlib.import_module("sol-r_amd")
@@ -135,16 +136,45 @@ if __name__ == "__main__":
     if os.environ.get("SOLR_ORACLE_ROUNDED_TRANSCENDENTALS"):   # sin / cos / atan2 / asin / pow through binary64, as the engine takes them
         loader.lib().oracle_set_rounded_transcendentals(1)
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1, 40)
-    bad = free_lists = free_shadows = 0
+    bad = free_lists = free_shadows = explained = 0
     for seed in range(first, first + count):
         k = solr.Kernel(engine="hip")
         build(k, seed)
         pp, ids, rgb = gpu_frame(k)
-        opp, oids, orgb, counts, status = oracle_frame(k, loader)
+        # against the oracle as pinned (libm's binary32 transcendentals): a pixel outside the bar must be one the oracle
+        # marks as having met a libm result that is not the correctly rounded value (oracle_set_misround_mask), and
+        # then at most 2 ULP / one RGB8 step off; such pixels are counted
+        import numpy as np
+        misround = np.zeros(pp.shape[:2], np.uint8)
+        opp, oids, orgb, counts, status = oracle_frame(k, loader, misround=misround)
         res = compare_frames(pp, ids, rgb, opp, oids, orgb)
         flat = k.flat_scene()
         good = lambda r: r["ids_all_equal"] and r["max_ulp"] <= 1 and r["rgb_max_diff"] <= 1 and r["depth_max_ulp"] == 0
         ok = good(res) and status == 0
+        if not ok and status == 0 and res["ids_all_equal"] and res["depth_max_ulp"] == 0 and \
+                not loader.lib().oracle_get_rounded_transcendentals():
+            from helpers import ulp_distance
+            ulp = np.maximum(ulp_distance(pp[..., :3], opp[..., :3]), ulp_distance(pp[..., 4:7], opp[..., 4:7])).max(axis=-1)
+            step = np.abs(rgb.astype(int) - orgb.astype(int)).max(axis=-1)
+            outside = (ulp > 1) | (step > 1)
+            if not (outside & (misround == 0)).any() and ulp[outside].max() <= 2 and step.max() <= 1:
+                ok = True
+                explained += int(outside.sum())
+        if os.environ.get("FUZZ_DEVICES") and ok:
+            # occupancyParameters.x: the same frame from 2 ... 4 engines of this process (SOLR_HIP_VIRTUAL_DEVICES lets a
+            # one-GPU box count its GPU several times), bit for bit
+            n = 2 + seed % 3
+            ids0 = k.primitive_ids().copy()
+            if k.set_gpu_count(n) != n:
+                ok = False
+                res = dict(res, after="%d in-process devices were not granted" % n)
+            else:
+                pp2, ids2, rgb2 = gpu_frame(k)
+                if not (np.array_equal(pp2.view(np.uint32), pp.view(np.uint32)) and np.array_equal(ids2, ids0) and
+                        np.array_equal(rgb2, rgb)):
+                    ok = False
+                    res = dict(res, after="the frame of %d in-process devices differs from the one-device frame" % n)
+                k.set_gpu_count(1)
         if os.environ.get("FUZZ_ROTATE"):
             # animated-scene route: rotations on the resident scene, then the frame against the oracle on the
             # host store's replay of them
@@ -238,6 +268,7 @@ if __name__ == "__main__":
         if not ok:
             bad += 1
             print("seed %d: %d boxes %d prims: %s" % (seed, len(flat.boxes), len(flat.primitives), res))
-    print("fuzz: %d scenes (%d with order-free lists, %d also for the shadows), %d outside the bar%s" % (
-        count, free_lists, free_shadows, bad, "" if not os.environ.get("SOLR_ORACLE_CORRECTLY_ROUNDED_POW")
-        else " (oracle with the correctly rounded specular power)"))
+    print("fuzz: %d scenes (%d with order-free lists, %d also for the shadows), %d outside the bar%s; %d pixel(s) in all "
+          "2 ULP off behind a libm result the oracle shows to be mis-rounded" % (
+              count, free_lists, free_shadows, bad, "" if not os.environ.get("SOLR_ORACLE_CORRECTLY_ROUNDED_POW")
+              else " (oracle with the correctly rounded specular power)", explained))
