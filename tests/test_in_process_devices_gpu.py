@@ -211,3 +211,57 @@ def test_the_first_call_with_frames_in_flight_delivers_a_rendered_frame(solr):
     finally:
         k.L.SolRx_SetFramesInFlight(1)
         k.finalize()
+
+
+@pytest.mark.parametrize("route, sets, lag", [(0, 2, 2), (1, 3, 3), (1, 2, 1), (0, 1, 3)])
+def test_delivered_frames_are_the_same_by_either_copy_route(solr, route, sets, lag):
+    """solr_hip_set_copy_route: the read-back copy on a stream of its own, or on the frame's own stream (what bench.py
+    picks for a rank's small strip) - a moving camera, every delivered image the frame rendered one at a time"""
+    hip = solr.hip_lib()
+    hip.solr_hip_image_wait.restype = C.c_void_p
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=2)
+    try:
+        k.render()
+        flat = k.flat_scene()
+        si, ppi, eye, direction, angles = k.frame_parameters()
+        si.pathTracingIteration = 0
+        objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+
+        def render(i):
+            e = eye.copy()
+            e[0] += 150.0 * i
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(e), fp(direction), fp(angles))
+
+        expected = []
+        for i in range(12):
+            render(i)
+            rgb = np.zeros((H, W, 3), np.uint8)
+            hip.solr_hip_d2h(C.byref(si), C.c_void_p(rgb.ctypes.data), None)
+            expected.append(rgb)
+        hip.solr_hip_set_copy_route(route)
+        hip.solr_hip_set_frames_in_flight(sets)
+        tickets, seen = [], []
+
+        def take(t):
+            ptr = hip.solr_hip_image_wait(t)
+            assert ptr
+            seen.append(np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3).copy())
+
+        for i in range(12):
+            render(i)
+            tickets.append(hip.solr_hip_d2h_image_async())
+            assert tickets[-1] >= 0
+            if len(tickets) > lag:
+                take(tickets[-1 - lag])
+        for t in tickets[-lag:]:
+            take(t)
+        k.check(0, "delivered frames")
+        assert len(seen) == 12
+        for i in range(12):
+            assert np.array_equal(seen[i], expected[i]), (route, sets, lag, i)
+    finally:
+        hip.solr_hip_set_copy_route(0)
+        hip.solr_hip_set_frames_in_flight(1)
+        k.finalize()
