@@ -131,6 +131,17 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
     /* a quadrant wave: only the lanes of its quadrant take part; every lane's path is its own (the walks are
      * wave-synchronous, not wave-dependent), so the pixels come out the same whichever wave renders them */
     const bool mine = part == 0 || ((((lane & 7) >> (3 - SOLR_SPLIT_LOG2)) | ((lane >> 3) >> (3 - SOLR_SPLIT_LOG2)) << SOLR_SPLIT_LOG2)) == part - 1;
+#ifdef SOLR_PRIORITY_FOR_SPLIT_TILES
+    /* experiment (profiles/r4/wave_priority.txt): the waves of a split tile - the frame's critical path - ask the SIMD's
+     * arbiter for priority over the waves they share it with */
+    if (part != 0)
+        __builtin_amdgcn_s_setprio(SOLR_PRIORITY_FOR_SPLIT_TILES);
+#endif
+#ifdef SOLR_PRIORITY_FOR_FIRST_WAVES
+    /* experiment: the cost-ordered launch starts the most expensive tiles first; they also get priority */
+    if (F.tileOrder && blockIdx.x < SOLR_PRIORITY_FOR_FIRST_WAVES)
+        __builtin_amdgcn_s_setprio(2);
+#endif
     const bool inside = mine && (x < W) && (yLocal < F.nbRows);
     const int index0 = inside ? yLocal * W + x : 0;
     const int yGlobal = F.firstRow + yLocal;
