@@ -4952,7 +4952,10 @@ int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const 
                         const float origin[3], const float direction[3], const float angles[4], int repeats, double ms[3],
                         unsigned long long stats[4])
 {
-    if (!ready("solr_hip_walk_bound") || gDevices > 1)
+    if (!ready("solr_hip_walk_bound"))
+        return -1;
+    ARGCHECK(gDevices == 1, "solr_hip_walk_bound: a diagnostic of one engine; this process renders on several devices");
+    if (!ok())
         return -1;
     quiesce();
     HIPCHECK(hipSetDevice(g.device));

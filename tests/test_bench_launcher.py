@@ -131,3 +131,28 @@ def test_one_rank_through_the_distributed_path_over_rccl(solr):
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["config"]["gathered_equals_single_gpu"] is True
     assert line["config"]["per_rank"][0]["rows"] == [0, 360]
+
+
+@pytest.mark.gpu
+def test_the_drivers_own_command_line_for_two_ranks(solr):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 2 --steps K --warmup W` - how the driver starts an N > 1 run - rehearsed on the box's one GPU (every rank on
+    GPU 0, the stand-in transport): one JSON line on stdout, last, from rank 0"""
+    from test_multi_rank_gpu import build_loopback
+    directory = tempfile.mkdtemp(prefix="solr_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+        env.update(SOLR_BENCH_SHARE_GPU="1", SOLR_HIP_RCCL_LIBRARY=build_loopback(), SOLR_LOOPBACK_DIR=directory,
+                   SOLR_LOOPBACK_TIMEOUT="60", SOLR_BENCH_REGIONS="3", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
+                              "--gpus", "2", "--steps", "10", "--warmup", "2", "--width", "640", "--height", "360"],
+                             env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
+        lines = [l for l in res.stdout.strip().splitlines() if l.strip()]
+        line = json.loads(lines[-1])
+        assert line["n_gpus"] == 2 and line["steps"] == 10 and line["warmup"] == 2 and line["config"]["rccl_ranks"] == 2
+        assert line["config"]["gathered_equals_single_gpu"] is True and line["value"] > 0
+        assert "cpu_baseline" not in line            # (N > 1: the CPU baseline is rank 0's at N = 1 only)
+    finally:
+        shutil.rmtree(directory, ignore_errors=True)
