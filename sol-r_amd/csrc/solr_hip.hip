@@ -6284,20 +6284,21 @@ void solr_hip_initialize(const SceneInfo *sceneInfo)
 
 void finalize_scene(vec2i)
 {
-    /* every engine that is up, whatever occupancyParameters says by now */
-    const int devices = gDevices;
-    gDevices = SOLR_MAX_GPU_COUNT;
+    /* every engine that is up, whatever occupancyParameters says by now; afterwards the process is a one-device
+     * process again until initialize_scene says otherwise */
+    const bool several = gDevices > 1;
     for (int d = 0; d < SOLR_MAX_GPU_COUNT; ++d)
         if (gEngines[d] && gEngines[d]->initialized)
         {
             gCurrent = gEngines[d];
-            if (devices > 1)
+            if (several)
                 (void)hipSetDevice(g.device);
             finalizeOne();
         }
     gCurrent = &gFirst;
-    gDevices = devices;
-    if (devices > 1)
+    gDevices = 1;
+    gRequested = 1;
+    if (several)
         (void)hipSetDevice(g.device);
 }
 
