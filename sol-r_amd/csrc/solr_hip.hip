@@ -5012,6 +5012,18 @@ int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const 
         HIPCHECK(hipMemcpy(v.data(), visits, v.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
         std::vector<int> heads((size_t)g.recordGrid * 4);
         HIPCHECK(hipMemcpy2D(heads.data(), 16, g.walkRecords.ptr, SOLR_WALK_SLOT_BYTES, 16, g.recordGrid, hipMemcpyDeviceToHost));
+        if (const char *dump = getenv("SOLR_HIP_WALK_BOUND_DUMP"))
+        {
+            /* diagnostics (tools/longest_wave.py): leaf entries per lane and walks per workgroup of the replay */
+            if (FILE *f = fopen(dump, "wb"))
+            {
+                const unsigned n = g.recordGrid;
+                fwrite(&n, sizeof(n), 1, f);
+                fwrite(v.data(), sizeof(unsigned), (size_t)n * WAVE, f);
+                fwrite(heads.data(), sizeof(int), (size_t)n * 4, f);
+                fclose(f);
+            }
+        }
         unsigned long long walks = 0, entries = 0;
         for (unsigned b = 0; b < g.recordGrid; ++b)
             walks += (unsigned long long)heads[4 * (size_t)b];
