@@ -155,6 +155,11 @@ void solr_hip_get_strip(int *firstRow, int *nbRows);
  *                             after every frame, CudaRayTracer.cu:1664-1670: 16 bytes per pixel, five times the image)
  *   solr_hip_d2h_gathered_ids root: waits for that gather and copies the height x width records to the host
  *   solr_hip_comm_finalize    leaves the communicator
+ *   solr_hip_comm_set_per_flight / solr_hip_comm_count   one communicator for everything (default) or one per frame in
+ *                             flight: RCCL orders the operations of one communicator across streams
+ *   solr_hip_image_share, solr_hip_d2h_image_async, solr_hip_image_wait   the delivered frame: every rank's strip over
+ *                             its own PCIe link into one page-locked host image the ranks' processes share
+ *   solr_hip_d2h_gathered_async   the other route: rank 0 copies the assembled frame, pipelined
  * All return 0, or -1 with solr_hip_last_error set.  RCCL is loaded when the first of them is called
  * (SOLR_HIP_RCCL_LIBRARY names another build of it).
  *
