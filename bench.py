@@ -181,6 +181,31 @@ def spread(samples, divide=1.0, window=1):
             "window": window}
 
 
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def reduce_over_ranks(dist, torch, region_times, second_times, kernel_ms, rays_local, device="cpu"):
+    """What the ranks of an N > 1 job agree on after the timed regions: every region's time is the SLOWEST rank's
+    (MAX over ranks, region by region - the frame is delivered when the last strip is), the kernel time the slowest
+    rank's, the rays the sum.  Returns (region_times, second_times, kernel_ms, rays_total)."""
+    t = torch.tensor(list(region_times) + list(second_times) + [kernel_ms], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n, m = len(region_times), len(second_times)
+    r = torch.tensor([float(rays_local)], dtype=torch.float64, device=device)
+    dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t[:n]], [float(x) for x in t[n:n + m]], float(t[-1]), int(r[0])
+
+
+def agree(dist, torch, failed_here, device="cpu"):
+    """True when ANY rank reports a failure: a decision every rank takes alike (e.g. the delivery route when one of
+    them cannot open the shared host image)"""
+    flag = torch.tensor([1.0 if failed_here else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return float(flag[0]) > 0
+
+
 def main():
     args = parse()
     # bare `python bench.py --gpus N` (no launcher's environment): become the launcher, before anything of the GPU
@@ -310,9 +335,7 @@ def main():
             dist.barrier()
             if rank != 0:
                 mine = hip.solr_hip_image_share(name, rank, world)
-            failed = torch.tensor([1.0 if mine != 0 else 0.0], dtype=torch.float64)
-            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-            if float(failed[0]) > 0:
+            if agree(dist, torch, mine != 0):
                 buf = C.create_string_buffer(512)
                 hip.solr_hip_last_error(buf, 512)
                 delivery_fallback = "solr_hip_image_share failed on some rank (%s): --delivery gathered instead" % \
@@ -686,23 +709,12 @@ def main():
     rays_total = rays_local
     per_rank = None
     second_out = None
-    def median(xs):
-        xs = sorted(xs)
-        return xs[len(xs) // 2]
-
     region_times = list(main_run["regions"])
     second_times = list(second["regions"]) if second else []
     if distributed:
         # every region's time is the slowest rank's (MAX over ranks, region by region); rays are summed
-        t = torch.tensor(region_times + second_times + [kernel_avg_ms], dtype=torch.float64,
-                         device="cpu" if native else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        region_times = [float(x) for x in t[:len(region_times)]]
-        second_times = [float(x) for x in t[len(region_times):len(region_times) + len(second_times)]]
-        kernel_avg_ms = float(t[-1])
-        r = torch.tensor([float(rays_local)], dtype=torch.float64, device="cpu" if native else "cuda")
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays_total = int(r[0])
+        region_times, second_times, kernel_avg_ms, rays_total = reduce_over_ranks(
+            dist, torch, region_times, second_times, kernel_avg_ms, rays_local, "cpu" if native else "cuda")
         mine = {"rank": rank, "rows": main_run["strip"], "ms_per_step_until_own_frames_delivered":
                 round(median(main_run["own"]) / args.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issued_ms, 4),
                 "kernel_ms": round(main_run["kernel_avg_ms"], 5)}

@@ -199,3 +199,44 @@ def test_balanced_strips_equal_the_full_frame(solr, oracle, tmp_path, height, wo
     assert [tuple(t) for t in table] != [solr.strip_rows(r, world, height)[:2] for r in range(world)]
     shares = [cost[f:f + c].sum() for f, c in table]
     assert max(shares) <= cost.sum() / world + cost.reshape(-1, 8).sum(axis=1).max() + 1e-3
+
+
+# ---- what the ranks of bench.py agree on (world size 2, gloo) ---------------------------------------------------
+def _bench_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import json
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 1 is the slower one in regions 0 and 2, rank 0 in region 1; rank 1's kernel is the slower
+    regions = [[0.010, 0.030, 0.011], [0.020, 0.012, 0.015]][rank]
+    second = [[0.5, 0.1], [0.2, 0.3]][rank]
+    got = bench.reduce_over_ranks(dist, torch, regions, second, [0.25, 0.40][rank], [1000, 2345][rank])
+    # only rank 1 fails to open the shared image: both must decide to fall back; nobody failing: nobody falls back
+    fallback = bench.agree(dist, torch, rank == 1)
+    none = bench.agree(dist, torch, False)
+    with open("%s.%d" % (out_path, rank), "w") as f:
+        json.dump({"reduced": got, "fallback": fallback, "none": none, "median": bench.median(got[0])}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_of_the_bench_agree_on_times_rays_and_the_delivery_route(tmp_path):
+    """bench.py at N > 1: a region's time is the slowest rank's, region by region (so that the median region is a
+    region that every rank finished); rays add up; one rank that cannot share the host image sends all of them to the
+    gathered route - the N > 1 decisions, run with two gloo processes"""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "bench_agreement")
+    _spawn(_bench_worker, (2, port, out), 2)
+    a, b = (json.load(open("%s.%d" % (out, r))) for r in (0, 1))
+    assert a == b                                   # every rank holds the same figures
+    regions, second, kernel_ms, rays = a["reduced"]
+    assert regions == [0.020, 0.030, 0.015] and second == [0.5, 0.3] and kernel_ms == 0.40 and rays == 3345
+    assert a["median"] == 0.020 and a["fallback"] is True and a["none"] is False
