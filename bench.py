@@ -15,8 +15,10 @@ The primitive ids stay on the device until picking asks (d2h_bitmap).
 
 Timing: W warm-up steps, then the timed region - EXACTLY K steps between barrier + synchronisation on both sides, the
 last image on the host when it ends, no event or other instrument inside it - is run R >= 25 times back to back (as
-many as keep the GPU busy for 0.2 s).  `ms_per_step` and `value` are the MEDIAN region's (the slowest rank's time, region
-by region); `config.step_ms_spread` gives the fastest and the slowest region, which bracket it by construction.
+many as keep the GPU busy for 0.2 s).  `ms_per_step` and `value` are the MEDIAN region's; `config.step_ms_spread` gives
+the fastest and the slowest region, which bracket it by construction.  At N > 1 a region's time is the MAX over ranks
+of each rank's own time from the start barrier to its last delivered frame (the end barrier itself is the control
+plane's - gloo over TCP - and is reported, not charged).
 
 N > 1: row strips re-cut by measured cost (solr_hip_balance_strips), gathered to rank 0 with RCCL called from the
 engine's C ABI on the stream that rendered the frame; the reference's equal split is timed as a second segment, the
@@ -497,12 +499,15 @@ def main():
                 step()
             t_issued = time.perf_counter()
             drain()
-            own.append(time.perf_counter() - t0)
+            own.append(time.perf_counter() - t0)       # this rank's K frames are delivered: its clock stops here
             barrier()
-            out.append(time.perf_counter() - t0)
+            out.append(time.perf_counter() - t0)       # (with the control plane's barrier: gloo over TCP, not the path's)
             issued += t_issued - t0
         k.check(0, "timed frames")
-        return {"regions": out, "own": own, "issued": issued / max(regions, 1), "strip": current_strip()}
+        # A region's time is the MAX over ranks of `own` (reduce_over_ranks): the moment the slowest rank's last frame
+        # was delivered, counted from the start barrier.  The end barrier brackets the region but is not charged to it -
+        # a gloo barrier of eight ranks is of the order of a 20-step region of an eight-GPU frame
+        return {"regions": own, "with_end_barrier": out, "issued": issued / max(regions, 1), "strip": current_strip()}
 
     def current_strip():
         a, b = C.c_int(), C.c_int()
@@ -716,11 +721,11 @@ def main():
         region_times, second_times, kernel_avg_ms, rays_total = reduce_over_ranks(
             dist, torch, region_times, second_times, kernel_avg_ms, rays_local, "cpu" if native else "cuda")
         mine = {"rank": rank, "rows": main_run["strip"], "ms_per_step_until_own_frames_delivered":
-                round(median(main_run["own"]) / args.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issued_ms, 4),
+                round(median(main_run["regions"]) / args.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issued_ms, 4),
                 "kernel_ms": round(main_run["kernel_avg_ms"], 5)}
         if second:
             mine["equal_strips"] = {"rows": second["strip"], "ms_per_step_until_own_frames_delivered":
-                                    round(median(second["own"]) / args.steps * 1e3, 4)}
+                                    round(median(second["regions"]) / args.steps * 1e3, 4)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         if second:
@@ -829,6 +834,9 @@ def main():
             "rccl_communicator_mode": ("one per frame in flight (SOLR_HIP_COMM_PER_FLIGHT=1)" if comm_count and comm_count > 1
                                        else "one for everything (default; SOLR_HIP_COMM_PER_FLIGHT=1 for the A/B)"),
             "per_rank": per_rank, "slowest_rank": slowest["rank"],
+            # the end barrier of a region belongs to the control plane (gloo over TCP) and is not charged to the region:
+            # a region's time is the MAX over ranks of each rank's own time from the start barrier to its last delivery
+            "control_plane_barrier_ms_rank0": round(1e3 * median([b - a for a, b in zip(main_run["regions"], main_run["with_end_barrier"])]), 4),
             "gather_only_ms": round(gather_only_ms, 4) if gather_only_ms is not None else None,
             "gather_only_note": "64 gathers of the last strips back to back on one stream, no rendering in between",
             # the assembled frame of the strips of the timed region against the same frame rendered whole by rank 0
