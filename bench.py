@@ -837,6 +837,9 @@ def main():
             # the end barrier of a region belongs to the control plane (gloo over TCP) and is not charged to the region:
             # a region's time is the MAX over ranks of each rank's own time from the start barrier to its last delivery
             "control_plane_barrier_ms_rank0": round(1e3 * median([b - a for a, b in zip(main_run["regions"], main_run["with_end_barrier"])]), 4),
+            # (for comparison: the median region on rank 0's clock WITH the end barrier inside it - after a barrier every
+            # rank's clock reads about the same)
+            "ms_per_step_with_the_end_barrier_rank0": round(1e3 * median(main_run["with_end_barrier"]) / args.steps, 4),
             "gather_only_ms": round(gather_only_ms, 4) if gather_only_ms is not None else None,
             "gather_only_note": "64 gathers of the last strips back to back on one stream, no rendering in between",
             # the assembled frame of the strips of the timed region against the same frame rendered whole by rank 0
