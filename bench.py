@@ -669,6 +669,7 @@ def main():
     gather_only_ms = None
     check = None
     if native:
+        arm("the gather alone and the one-GPU check")
         import numpy as np
         for _ in range(8):
             hip.solr_hip_gather_strips(0)
