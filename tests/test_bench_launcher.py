@@ -156,3 +156,41 @@ def test_the_drivers_own_command_line_for_two_ranks(solr):
         assert "cpu_baseline" not in line            # (N > 1: the CPU baseline is rank 0's at N = 1 only)
     finally:
         shutil.rmtree(directory, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_the_one_gpu_line_keeps_the_contract(solr):
+    """`python bench.py --gpus 1 --steps K --warmup W`: one JSON line, last on stdout, with the keys the driver reads -
+    and the headline inside its own error bar"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--cpu-seconds", "1.5"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["metric"].startswith("Mrays/s @1920x1080, 3-bounce Cornell") and line["unit"] == "Mrays/s"
+    assert (line["n_gpus"], line["steps"], line["warmup"]) == (1, 20, 5) and line["higher_is_better"] is True
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and line["vs_baseline"] is None
+    assert "model" not in line["config"] and "workload" in line["config"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3) and 0.0 < roof["frac"] < 1.0
+    assert roof["traffic"] is None or roof["traffic"] > 0.5 * roof["algorithmic_bytes"]
+    # the walk's own ceiling is above the headline, and the node loop alone is a part of the kernel's time
+    assert roof["walk_bound_mrays"] > line["value"] and 0.1 < roof["walk_bound"]["frac_of_bound_achieved"] < 1.0
+    assert roof["walk_bound"]["node_loop_only_ms"] < roof["kernel_ms"] and roof["walk_bound"]["walks_not_replayed"] == 0
+    cpu = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
+    # value = rays x steps / the median region; the spread is the fastest and the slowest region and brackets it
+    sp = line["config"]["step_ms_spread"]
+    assert line["regions"] >= 25 and sp["regions"] == line["regions"]
+    assert sp["min"] <= line["ms_per_step"] <= sp["max"] and sp["median"] == pytest.approx(line["ms_per_step"], rel=1e-3)
+    assert line["value"] == pytest.approx(line["config"]["rays_per_frame"] / (line["ms_per_step"] * 1e-3) / 1e6, rel=2e-3)
+    assert sp["timed_seconds_in_all"] >= 0.15                      # the GPU was busy long enough to be seen
+    assert line["config"]["frames_delivered"] >= line["regions"] * 20
