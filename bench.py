@@ -572,6 +572,7 @@ def main():
         drain()
     arm("the timed regions")
     main_run = timed(args.steps, args.warmup, regions)
+    short_ray_lists = int(hip.solr_hip_short_ray_lists())   # what the engine chose for the delivered frames
     t_issued_ms = main_run["issued"] / args.steps * 1e3
     strips = "balanced by cost" if balanced else "equal rows"
     arm("kernel time")
@@ -811,6 +812,9 @@ def main():
                    "frames_delivered": delivered[0], "delivery_fallback": delivery_fallback,
                    # nodes per order-free list when long rays' walks use them, else 0
                    "order_free_nodes": int(hip.solr_hip_order_free_nodes()),
+                   # 1: bounce rays of the long-list triangle kernels took them too during the timed regions (the engine's
+                   # choice per frame, include/solr_hip.h solr_hip_set_short_ray_lists; nothing to choose for other scenes)
+                   "short_ray_lists": short_ray_lists,
                    "gather": ("none (one GPU)" if not distributed else
                               "RCCL from the engine's C ABI (solr_hip_gather_strips), on the stream that rendered the frame"
                               if native else "torch.distributed gather (RCCL)"),

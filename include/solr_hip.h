@@ -107,6 +107,11 @@ void cudaRender(vec2i occupancyParameters, vec4i blockSize, SceneInfo sceneInfo,
 int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
                         const float origin[3], const float direction[3], const float angles[4], int repeats, double ms[3],
                         unsigned long long stats[4]);
+/* Which list the walks of the frame recorded by the last solr_hip_walk_bound (called with stats != NULL) took, per wave:
+ * closest-hit walks in the reference's order / on an order-free list, shadow walks likewise, walks not through the node
+ * loop, walks beyond a workgroup's record slots (not classified).  A checked walk that repeats lanes in the reference's
+ * order counts once in each. */
+void solr_hip_walk_bound_lists(unsigned long long out[6]);
 
 /* 0 when no error is pending; otherwise the HIP error code (or -1 for an
  * argument/state error) and, if buf != NULL, its text. Does not clear. */
@@ -358,6 +363,13 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
  * h2d_scene); 6 = no order-free lists (every walk in the reference's order).  Every setting renders the same
  * frame. */
 void solr_hip_set_variant(int variant);
+/* Bounce rays (|direction| = 1 - rayEpsilon) of the long-list triangle kernels on the order-free lists, checked: lanes
+ * whose hit has a rival the reference's cut-off could have preferred are walked again in the reference's order
+ * (rt_device.h closestHitWalk).  -1 (default): on with frames in flight (solr_hip_set_frames_in_flight >= 2: the saved
+ * work shows), off one frame at a time (the repeated lanes lengthen the frame's longest tiles); 0 / 1: off / on.
+ * Every setting renders the same frame.  solr_hip_short_ray_lists: what the next frame will do (engine 0). */
+void solr_hip_set_short_ray_lists(int mode);
+int solr_hip_short_ray_lists(void);
 /* nodes per order-free list of the resident scene when long rays' closest-hit walks use them, else 0 */
 int solr_hip_order_free_nodes(void);
 /* 1 if the shadow walks take them as well (nothing in the scene is transparent or a textured plane), else 0 */

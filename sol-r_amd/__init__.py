@@ -162,6 +162,11 @@ def _declare_hip(L):
     L.solr_hip_render_counting.argtypes = L.solr_hip_render.argtypes + [P(C.c_ulonglong)]
     L.solr_hip_walk_bound.argtypes = L.solr_hip_render.argtypes + [C.c_int, P(C.c_double), P(C.c_ulonglong)]
     L.solr_hip_walk_bound.restype = C.c_int
+    L.solr_hip_walk_bound_lists.argtypes = [P(C.c_ulonglong)]
+    L.solr_hip_walk_bound_lists.restype = None
+    L.solr_hip_set_short_ray_lists.argtypes = [C.c_int]
+    L.solr_hip_set_short_ray_lists.restype = None
+    L.solr_hip_short_ray_lists.restype = C.c_int
     L.solr_hip_d2h.argtypes = [P(SceneInfo), C.c_void_p, C.c_void_p]
     L.solr_hip_enable_timing.argtypes = [C.c_int]
     L.solr_hip_kernel_time.argtypes = [P(C.c_int), C.c_int]

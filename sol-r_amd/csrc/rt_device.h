@@ -961,6 +961,10 @@ struct Counters
     unsigned long long tNode, tLeaf, tClosest, tShadow;
     unsigned long long tShade, tTrace; /* primitiveShader (its shadow walks included), launchRayTracing as a whole */
     unsigned int nAdvance, nLeaf;
+    /* ... and finer, for the longest tiles (solr_hip_wave_cycle_slots): the primary ray's closest-hit walk, the second
+     * attempts of the checked unit-ray walks (time, walks, lanes), the node-loop calls of closest-hit walks by attempt */
+    unsigned long long tClosestPrimary, tAgain;
+    unsigned int nAgain, nAgainLanes, nAdvanceFirst, nAdvanceAgain, nChecked;
 #endif
 };
 #ifdef SOLR_TIMING
@@ -1524,25 +1528,38 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
      * rays qualify (|direction| is thousands); bounce rays are unit vectors and walk the reference's order. */
     const bool freeOrder =
         tidy && S.nbBoxesFree > 0 && ballot(active && !longRay(r.d)) == 0ull;
-    /* Unit-length rays (the bounce rays) in the order-free lists, CHECKED.  For |direction| = 1 the reference's
-     * cut-off is a distance cut-off, exact up to rounding: which primitive wins can then depend on the order of
-     * the leaves when two candidates - or a candidate and the initial bound - lie within rounding of each other,
-     * and only then.  So the walk runs order-free with a margin of 1e-3 (a thousand times the rounding), keeps the
-     * second smallest distance it met, accepts nothing within 2e-3 of the initial bound, and afterwards the lanes
-     * whose best hit has a rival within the margin (or lies in that band) are walked again in the reference's
-     * order - they find a hit there if they found one here (a candidate outside the band passes the reference's
-     * cut-off against the initial bound), so nothing needs restoring.  For every other lane the minimum is unique
-     * by a margin no rounding bridges, and the reference, whose cut-off cannot hide it from any larger bound,
-     * returns it.  Only in the long-list triangle instantiations (the mesh: its bounce rays along the terrain
-     * are a third of its longest wave, one frame alone 0.435 -> 0.417 ms); compiled into every kernel it costs the Cornell box
-     * 3 % and the molecule 0.7 % (short lists, few bounce rays, the bookkeeping in every accept). */
+    /* Short rays (the bounce rays: |direction| = 1 - rayEpsilon, CudaRayTracer.cu:322-323) in the order-free lists,
+     * CHECKED.  The reference culls a box when its slab parameter t = (entry distance) / |direction| reaches the closest
+     * DISTANCE so far.  For |direction| = L <= 1 that hides boxes whose entry lies between L x and 1 x the closest
+     * distance - so which primitive wins CAN depend on the order of the leaves, but only like this: the true nearest
+     * hit P (distance D, its leaf entered at e <= D) is passed over iff a farther hit Q was found before it with
+     * D_Q <= e / L <= D / L (the same holds for every inner box around P's leaf, entered earlier still).  So the walk
+     * runs order-free, sees every hit up to 1.001 / L times the closest so far (the cut-off below is widened by that
+     * much), keeps the second smallest distance it met, and afterwards the lanes whose best hit has such a RIVAL - a
+     * second hit within D / L, rounding included - are walked again in the reference's order.  For every other lane
+     * nothing the reference can have found earlier hides P's boxes, and no hit is nearer: the reference returns P
+     * (equal distances: the smaller flattened index, as above).  The same band sits under the initial bound B: a lone
+     * hit at D < L x B has e < L x B and is visited; at D >= L x B it may or may not be - such hits are not accepted
+     * here and send the lane to the second walk too (it finds a hit there if it found one here: a hit outside the band
+     * passes the reference's cut-off against the initial bound, so nothing needs restoring).  For 1 < L < 2 the
+     * reference culls less than the distance would and the margins are those of rounding alone.  Only in the
+     * long-list triangle instantiations (the mesh: the bounce walks are 45 % of its longest tiles); compiled into
+     * every kernel it costs the Cornell box 3 % and the molecule 0.7 % (short lists, few bounce rays, the bookkeeping
+     * in every accept). */
     constexpr bool CHECKED_BUILD = COUNT != 1 && (FEAT & F_DEEP) != 0 && (FEAT & F_TRI) != 0;
     const float dd = dot(r.d, r.d);
+    /* (S.shortRayLists: the host's choice, solr_hip.hip - the repeated lanes lengthen a frame's longest tiles, so a frame
+     * that is as long as its longest tile keeps the reference's order for such rays; either way the same bits.  Rays
+     * within rounding of length 1 need no more than the rounding margins and always qualify.) */
+    const float shortest = S.shortRayLists ? 0.25f : 0.9998f;
     const bool unitRays = CHECKED_BUILD && tidy && S.nbBoxesFree > 0 && !freeOrder &&
-                          ballot(active && !(dd >= 0.9998f && dd < 4.f)) == 0ull;
+                          ballot(active && !(dd >= shortest && dd < 4.f)) == 0ull;
     const float initialDistance = minDistance;
     const float slack = 1.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
-    const float bandStart = initialDistance * (1.f - 2.0e-3f) - 2.f * slack;
+    /* min(L, 1), a little under: the band may be wider than it need be, never narrower */
+    const float shortBy = unitRays ? fminf(sqrtf(dd) * (1.f - 1.0e-5f), 1.f) : 1.f;
+    const float rivalScale = 1.001f / shortBy;
+    const float bandStart = initialDistance * shortBy * (1.f - 2.0e-3f) - 2.f * slack;
     float second = INFINITY;
     bool bandHit = false;
     bool lanesNow = active;
@@ -1550,6 +1567,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     {
         const bool checked = unitRays && attempt == 0;
         const bool freeList = freeOrder || checked;
+        SOLR_T(const unsigned long long tAttempt = SOLR_NOW();)
         Scene W = S;
         int octant = 0;
         if (freeList)
@@ -1570,7 +1588,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
          * coordinates for the cancellation in (bound - origin) - a thousand times the half-ulp that subtraction can
          * lose.  With the near child first this is what ends a walk early. */
         const float invLength = freeList ? 1.f / length(r.d) : 1.f;
-        const float farScale = freeList ? (checked ? 1.001f : 1.0002f) * invLength : 1.f;
+        const float farScale = freeList ? (checked ? rivalScale : 1.0002f) * invLength : 1.f;
         const float farOffset = freeList ? slack * invLength : 0.f;
         int tieIndex = -1; /* the primitive that holds minDistance */
         auto closer = [&](float distance, int pi) {
@@ -1601,7 +1619,8 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             {
                 leaf = advanceTidy<FEAT>(W, pr, freeList ? minDistance * farScale + farOffset : minDistance, cursor,
                                          cur, nbPrimitives, entered);
-                SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)
+                SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;
+                       if (attempt == 0) ++cnt.nAdvanceFirst; else ++cnt.nAdvanceAgain;)
                 if (leaf < 0)
                     break;
             }
@@ -1858,17 +1877,20 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         if (COUNT == 2) /* this attempt, for the walk's own ceiling: the cut-off it ended with */
             recordWalk(cnt, tidy ? WALK_CLOSEST : WALK_GENERAL, freeList, octant, lanesNow, r,
                        freeList ? minDistance * farScale + farOffset : minDistance, SOLR_CURSOR_DONE);
+        SOLR_T(if (attempt == 1) cnt.tAgain += SOLR_NOW() - tAttempt;)
         if (!checked)
             break;
+        SOLR_T(++cnt.nChecked;)
         /* the lanes whose result the order could have decided: once more, in the reference's order */
-        const bool again = lanesNow && (intersections ? !(second > minDistance * 1.001f + slack) : bandHit);
+        const bool again = lanesNow && (intersections ? !(second > minDistance * rivalScale + slack) : bandHit);
         if (ballot(again) == 0ull)
             break;
+        SOLR_T(++cnt.nAgain; cnt.nAgainLanes += (unsigned)__builtin_popcountll(ballot(again));)
         lanesNow = again;
         minDistance = again ? initialDistance : minDistance;
         intersections = again ? false : intersections;
     }
-    SOLR_T(cnt.tClosest += SOLR_NOW() - tw0;)
+    SOLR_T(cnt.tClosest += SOLR_NOW() - tw0; if (iteration == 0) cnt.tClosestPrimary += SOLR_NOW() - tw0;)
     return intersections;
 }
 

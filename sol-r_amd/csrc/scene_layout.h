@@ -155,6 +155,7 @@ struct SceneArgs
     unsigned offBoxesFree, offLeafFree;
     int nbBoxesFree;
     int opaqueShadows; /* no primitive is transparent or a textured plane: any occluder saturates a shadow */
+    int shortRayLists; /* bounce rays (shorter than 1) take the order-free lists, checked (rt_device.h closestHitWalk) */
 };
 
 /* Device view: everything is read through the CONSTANT address space.  The
@@ -190,6 +191,7 @@ struct Scene
     unsigned offBoxesFree, offLeafFree;
     int nbBoxesFree;
     int opaqueShadows;
+    int shortRayLists;
 };
 
 __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
@@ -216,6 +218,7 @@ __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
     s.offLeafFree = a.offLeafFree;
     s.nbBoxesFree = a.nbBoxesFree;
     s.opaqueShadows = a.opaqueShadows;
+    s.shortRayLists = a.shortRayLists;
     return s;
 }
 

@@ -456,6 +456,11 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
         slot[5] += (unsigned long long)cnt.nAdvance;
         slot[6] += (unsigned long long)cnt.nLeaf;
         slot[7] += 1ull;
+        slot[11] += cnt.tClosestPrimary;
+        slot[12] += cnt.tAgain;
+        slot[13] += ((unsigned long long)cnt.nAgain << 32) | cnt.nAgainLanes;
+        slot[14] += ((unsigned long long)cnt.nAdvanceFirst << 32) | cnt.nAdvanceAgain;
+        slot[15] += (unsigned long long)cnt.nChecked;
     }
 #endif
     if (COUNT == 2 && lane == 0)
@@ -1513,6 +1518,9 @@ struct Engine
     bool freeStale = false;     /* rotated on the device since it was built: not refitted, not walked */
     bool primsContained = false; /* every primitive lies inside its leaf's box (retagPrimitives) */
     bool opaqueShadows = false;  /* no transparent primitive, no textured plane (retagPrimitives) */
+    /* bounce rays on the order-free lists, checked (rt_device.h closestHitWalk): -1 the engine decides per frame
+     * (shortRayListsChoice: with frames in flight), 0 / 1 forced */
+    int shortRayListsMode = -1;
     std::vector<int> materialTags; /* PRIM_* bits per material id */
     /* texture tables of the textured materials and the size of the uploaded atlas: checked against each other
      * before the first frame that follows either upload (checkTextureTables) */
@@ -2288,6 +2296,19 @@ bool orderFreeListsUsable()
            g.nested && g.orderedCompact && g.variant != 6;
 }
 
+/* bounce rays on the order-free lists: the API's word, else SOLR_HIP_SHORT_RAY_LISTS=0|1 (experiments), else the engine's
+ * own choice for this frame */
+bool shortRayListsChoice()
+{
+    static const int fromEnv = getenv("SOLR_HIP_SHORT_RAY_LISTS") ? atoi(getenv("SOLR_HIP_SHORT_RAY_LISTS")) : -1;
+    const int mode = g.shortRayListsMode >= 0 ? g.shortRayListsMode : fromEnv;
+    /* The engine's own choice.  Bounce rays on the order-free lists save work in nearly every tile and add some to the
+     * few whose lanes have to be walked again (the mesh's horizon tiles: + 13 %).  With frames in flight the next frame
+     * fills the chip behind those tiles and the saving is what shows (the mesh delivered 0.368 -> 0.356 ms, a 136-row
+     * frame of it 0.239 -> 0.222); one frame at a time is as long as its longest tile and gets longer (0.43 -> 0.48 ms). */
+    return mode < 0 ? activeFlights() >= 2 : mode != 0;
+}
+
 SceneArgs makeScene(bool exactNodes)
 {
     SceneArgs S;
@@ -2315,6 +2336,7 @@ SceneArgs makeScene(bool exactNodes)
         S.offLeafFree = g.offLeafFree;
         S.nbBoxesFree = g.nbBoxesFree; /* per list; the eight lists and their leaf records lie one behind the other */
         S.opaqueShadows = g.opaqueShadows ? 1 : 0;
+        S.shortRayLists = shortRayListsChoice() ? 1 : 0;
     }
     return S;
 }
@@ -4948,6 +4970,13 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
  *   the replays; stats[0] walks recorded (per wave), [1] walks left out of the replay (slots full, or not through the node
  *   loop), [2] leaf entries the replay made (per lane), [3] workgroups.
  * Engine 0, one GPU; the lean instantiations only (untextured spheres / planes / triangles / cylinders).  0, or -1. */
+static unsigned long long walkLists[6];
+void solr_hip_walk_bound_lists(unsigned long long out[6])
+{
+    if (out)
+        memcpy(out, walkLists, sizeof(walkLists));
+}
+
 int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
                         const float origin[3], const float direction[3], const float angles[4], int repeats, double ms[3],
                         unsigned long long stats[4])
@@ -5027,6 +5056,28 @@ int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const 
         unsigned long long walks = 0, entries = 0;
         for (unsigned b = 0; b < g.recordGrid; ++b)
             walks += (unsigned long long)heads[4 * (size_t)b];
+        {
+            /* which list each recorded walk took (solr_hip_walk_bound_lists) */
+            std::vector<int> kinds((size_t)g.recordGrid * 4 * (SOLR_WALK_SLOTS + 1));
+            HIPCHECK(hipMemcpy2D(kinds.data(), 16 * (SOLR_WALK_SLOTS + 1), g.walkRecords.ptr, SOLR_WALK_SLOT_BYTES,
+                                 16 * (SOLR_WALK_SLOTS + 1), g.recordGrid, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 6; ++i)
+                walkLists[i] = 0;
+            for (unsigned b = 0; ok() && b < g.recordGrid; ++b)
+            {
+                const int *slot = &kinds[(size_t)b * 4 * (SOLR_WALK_SLOTS + 1)];
+                const int n = std::min(slot[0], (int)SOLR_WALK_SLOTS);
+                for (int j = 0; j < n; ++j)
+                {
+                    const int kind = slot[4 * (1 + j)], freeList = slot[4 * (1 + j) + 1];
+                    if (kind == WALK_CLOSEST || kind == WALK_SHADOW)
+                        ++walkLists[2 * kind + (freeList ? 1 : 0)];
+                    else
+                        ++walkLists[4];
+                }
+                walkLists[5] += (unsigned long long)(slot[0] - n);
+            }
+        }
         for (size_t i = 0; i + 1 < v.size(); ++i)
             entries += v[i];
         stats[0] = walks;
@@ -5153,6 +5204,16 @@ int solr_hip_timing_samples(float *kernelMs, float *intervalMs, int capacity)
             intervalMs[i] = g.intervalSamples[i];
     }
     return n;
+}
+
+void solr_hip_set_short_ray_lists(int mode)
+{
+    onEveryDevice([&](int) { g.shortRayListsMode = mode < 0 ? -1 : (mode != 0 ? 1 : 0); });
+}
+
+int solr_hip_short_ray_lists(void)
+{
+    return shortRayListsChoice() ? 1 : 0;
 }
 
 void solr_hip_set_variant(int variant)
@@ -6143,6 +6204,16 @@ void solr_hip_wave_cycles(unsigned long long out[16], int reset)
     if (reset)
         (void)hipMemset((unsigned long long *)g.counters.ptr + 16, 0, slots.size() * sizeof(unsigned long long));
 }
+/* the same counters per workgroup (16 words each; [11] the primary ray's closest-hit walk, [12] second attempts of the
+ * checked unit-ray walks, [13] their count << 32 | their lanes, [14] node-loop calls of closest-hit walks: first attempt
+ * << 32 | second, [15] checked walks); returns the workgroups copied */
+int solr_hip_wave_cycle_slots(unsigned long long *out, int capacityWorkgroups)
+{
+    (void)hipDeviceSynchronize();
+    const size_t n = std::min((size_t)std::max(capacityWorkgroups, 0), (size_t)SOLR_TIMING_SLOTS);
+    (void)hipMemcpy(out, (unsigned long long *)g.counters.ptr + 16, 16 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    return (int)n;
+}
 #endif
 }
 
@@ -6187,6 +6258,7 @@ void ensureEngines(int n)
         Engine &e = *gEngines[d];
         e.device = (gFirst.device + d) % real;
         e.variant = gFirst.variant;
+        e.shortRayListsMode = gFirst.shortRayListsMode;
         e.grouping = gFirst.grouping;
         e.flights = gFirst.flights;
         e.tileScheduling = gFirst.tileScheduling;

@@ -117,6 +117,32 @@ def triangles_only(k, width=80, height=60, iterations=2, **info):
     return k
 
 
+def layered_terrain(k, n=36, layers=3, gap=40.0, width=160, height=120, iterations=3, reflection=0.6, **info):
+    """A mirror terrain in `layers` sheets `gap` apart, seen at a grazing angle: every hit has a second hit a few per cent
+    farther along the ray - what the reference's cut-off (slab parameter of a ray shorter than 1 against the closest
+    DISTANCE, rt_device.h closestHitWalk) makes depend on the order of the leaves - and 2 n n layers triangles make
+    the list long enough for the kernels that walk bounce rays order-free, checked."""
+    rng = S.LCG(77)
+    k.initialize(width=width, height=height, nbRayIterations=iterations, **info)
+    mats = [k.add_material(*S._wall_color(rng), reflection=reflection, specValue=0.5, specPower=60.0) for _ in range(5)]
+    def pt(i, j, layer):
+        u, v = i / n - 0.5, j / n - 0.5
+        return (u * 18000.0, 700.0 * math.sin(9.0 * u + 0.4) * math.cos(7.0 * v) - 2500.0 - gap * layer, v * 18000.0)
+    for layer in range(layers):
+        for i in range(n):
+            for j in range(n):
+                a, b, c, d = pt(i, j, layer), pt(i + 1, j, layer), pt(i + 1, j + 1, layer), pt(i, j + 1, layer)
+                m = mats[(i // 3 + j // 3 + layer) % 5]
+                t = k.add_primitive(solr.ptTriangle, a, b, c, material=m)
+                k.set_normals(t, (0, 1, 0), (0.1, 1, 0), (0.1, 1, 0.1))
+                t = k.add_primitive(solr.ptTriangle, a, c, d, material=m)
+                k.set_normals(t, (0, 1, 0), (0.1, 1, 0.1), (0, 1, 0.1))
+    _light(k, pos=(6000.0, 7000.0, -9000.0))
+    k.compact_boxes(True)
+    k.set_camera((0.0, -1200.0, -12000.0), look_at=(0.0, -2400.0, 0.0))
+    return k
+
+
 def sticks(k, width=80, height=60, iterations=2, **info):
     """Molecule-like: spheres joined by cylinders."""
     rng = S.LCG(99)
