@@ -1055,7 +1055,11 @@ SOLR_DEV int recIndex(const Scene &S, const PrimRec &r)
 {
     return asint(r.packed ? r.c.w : primRow(S, r.pi, ROW_P1_INDEX).w);
 }
-/* primitive k of the leaf whose record is L (k == 0) or whose first primitive is `start` */
+/* primitive k of the leaf whose record is L (k == 0) or whose first primitive is `start`.  (Measured, round 4,
+ * profiles/r4/leaf_loads.txt: the further primitives' head + p1 + p2 as ONE 64-byte request instead of the head and then
+ * the rows the test asks for - mesh + 6 %, molecule + 1.5 % slower; the next primitive's record requested before this
+ * one is tested - + 10 ... 18 % on all three scenes.  Sixteen more scalar registers live across a test cost more in
+ * lane spills than the request they save: the kernels hold 540 v_readlane / v_writelane already) */
 template <int FEAT>
 SOLR_DEV PrimRec leafPrimitive(const Scene &S, const SceneInfo &si, const Row4 &L, int start, int k)
 {
