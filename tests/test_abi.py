@@ -80,3 +80,19 @@ def test_calls_before_initialisation_are_rejected(solr, have_gpu):
     buf = C.create_string_buffer(256)
     assert hip.solr_hip_last_error(buf, 256) == -1 and b"initialize_scene" in buf.value
     hip.solr_hip_clear_error()
+
+
+def test_the_short_ray_list_switch_is_state_only(solr):
+    """solr_hip_set_short_ray_lists (include/solr_hip.h): a switch of the engine, no compute - forced on / off it says so,
+    left to the engine it follows the frames in flight (none here: off)"""
+    lib = solr.hip_lib()
+    try:
+        lib.solr_hip_set_short_ray_lists(1)
+        assert lib.solr_hip_short_ray_lists() == 1
+        lib.solr_hip_set_short_ray_lists(0)
+        assert lib.solr_hip_short_ray_lists() == 0
+        lib.solr_hip_set_short_ray_lists(-1)
+        if not os.environ.get("SOLR_HIP_SHORT_RAY_LISTS"):
+            assert lib.solr_hip_short_ray_lists() == 0
+    finally:
+        lib.solr_hip_set_short_ray_lists(-1)
