@@ -348,6 +348,8 @@ def main():
                 if rank == 0:
                     print("bench.py: " + delivery_fallback, file=sys.stderr, flush=True)
             dist.barrier()
+            # every rank has the segment mapped: its NAME can go (a job that dies later leaves nothing in /dev/shm)
+            hip.solr_hip_image_share_sealed()
 
     def frame():
         # N = 1: the renderer alone.  N > 1: the renderer writes RGB8 straight into a strip buffer and the
@@ -379,6 +381,7 @@ def main():
                                  counts)
     k.check(0, "ray census")
     rays_local = int(counts[0]) + int(counts[1])
+    rays_first_pass_local = rays_local     # (cfg4: pass 0's, what the oracle's one check frame is compared with)
     if cfg4:
         # the passes differ (refinement passes skip finished pixels and trace deeper, accumulation passes jitter):
         # census of every pass of the cycle, each on the frame buffers the pass before left; a step = a pass,
@@ -451,10 +454,14 @@ def main():
     delivered = [0]
     hip.solr_hip_image_wait.restype = C.c_void_p
 
+    last_image = [None]       # address of the host image the newest delivered frame is in (rank 0)
+
     def take(ticket):
         if ticket >= 0:
-            if not hip.solr_hip_image_wait(ticket):
+            image = hip.solr_hip_image_wait(ticket)
+            if not image:
                 k.check(-1, "solr_hip_image_wait")
+            last_image[0] = image
             delivered[0] += 1
 
     def step():
@@ -504,10 +511,18 @@ def main():
             out.append(time.perf_counter() - t0)       # (with the control plane's barrier: gloo over TCP, not the path's)
             issued += t_issued - t0
         k.check(0, "timed frames")
+        # the image the LAST timed step delivered, as the host received it (outside the regions; main() compares it
+        # with the oracle's frame: the timed frames are the right frames).  The ring's slot stays untouched until the
+        # next step is issued
+        snapshot = None
+        if rank == 0 and last_image[0] and not cfg4:
+            import numpy as np
+            snapshot = np.ctypeslib.as_array((C.c_ubyte * (W * H * 3)).from_address(last_image[0])).reshape(H, W, 3).copy()
         # A region's time is the MAX over ranks of `own` (reduce_over_ranks): the moment the slowest rank's last frame
         # was delivered, counted from the start barrier.  The end barrier brackets the region but is not charged to it -
         # a gloo barrier of eight ranks is of the order of a 20-step region of an eight-GPU frame
-        return {"regions": own, "with_end_barrier": out, "issued": issued / max(regions, 1), "strip": current_strip()}
+        return {"regions": own, "with_end_barrier": out, "issued": issued / max(regions, 1), "strip": current_strip(),
+                "last_image": snapshot}
 
     def current_strip():
         a, b = C.c_int(), C.c_int()
@@ -900,6 +915,36 @@ def main():
             "scalar_frac": round((valu["SQ_INSTS_SALU"] + valu.get("SQ_INSTS_SMEM", 0)) / seconds / SALU_PEAK_WAVE_INSTS_PER_S, 4),
             "note": "counters from a committed profile of this command; durations from this run"}
 
+    # ---- proof that the timed frames are the right frames (untimed): the image the last timed step delivered against
+    # the frame the CPU oracle renders of the same scene, and the engine's ray census against the oracle's own count
+    # ("counted by an instrumented build of our CPU restatement")
+    rc = 0
+    if not args.no_check and pipe is None:
+        image, first_pass_rays = main_run.get("last_image"), rays_total
+        if cfg4 and not distributed:
+            # a step is a pass and the last delivered image is pass 73's: one pass is checked - pass 0, rendered and
+            # read back once more after the regions - against the oracle's pass 0 with the same post-processing
+            import numpy as np
+            hip.solr_hip_set_frames_in_flight(1)
+            pass_counter[0] = 0
+            render()
+            image = np.zeros((H, W, 3), np.uint8)
+            hip.solr_hip_d2h(C.byref(si), C.c_void_p(image.ctypes.data), None)
+            k.check(0, "the check frame")
+            si.pathTracingIteration = 0
+            first_pass_rays = rays_first_pass_local
+        if image is not None and os.environ.get("SOLR_BENCH_TAMPER") == "1":
+            image = image.copy()             # (tests/test_bench_launcher.py: a wrong frame must fail the job)
+            image[H // 2, W // 3:W // 3 + 16] ^= 0x40
+        if image is not None:
+            proof = prove_frames(flat, si, ppi, eye, direction, angles, image, first_pass_rays)
+            out["config"].update(proof)
+            if proof["rays_equal_oracle_count"] and not cfg4:
+                out["config"]["rays_per_frame"] = proof["oracle_rays_per_frame"]   # the oracle's count IS the figure
+            if proof["delivered_frame_equals_oracle"] is False or proof["rays_equal_oracle_count"] is False:
+                print("bench.py: the delivered frame or the ray census is NOT the oracle's: %s" % json.dumps(proof),
+                      file=sys.stderr, flush=True)
+                rc = 4
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(flat, si, ppi, eye, direction, angles, args.cpu_seconds)
     if distributed:
@@ -909,6 +954,45 @@ def main():
         dist.destroy_process_group()
     C.CDLL(None).fflush(None)
     print(json.dumps(out), flush=True)
+    if rc:
+        sys.exit(rc)     # the line is printed (what was measured, and that it was not the right frame); the job failed
+
+
+MAX_MARKED_PIXELS = 8    # tests/test_baseline_sizes.py MAX_EXCEPTIONS: pixels of a frame one RGB8 step off, each behind a mis-rounded powf
+
+
+def prove_frames(flat, si, ppi, eye, direction, angles, image, engine_rays):
+    """The image a timed step delivered against the oracle's frame of the same scene and camera - RGB8 equal on every
+    pixel but at most MAX_MARKED_PIXELS, each one step off and each marked by the oracle as having gone through a libm
+    result that is not the correctly rounded value (oracle_set_misround_mask; the engine rounds the binary64 result
+    once: DESIGN.md section 2.3) - and the engine's ray census against the rays the oracle counted while rendering it.
+    Returns the keys that go into `config`; a value is None (with `frame_check_error`) when the check itself could not
+    run - that does not fail the job, a frame that differs does."""
+    import numpy as np
+    try:
+        from oracle import loader
+        assert not loader.lib().oracle_get_rounded_transcendentals()
+        misround = np.zeros((si.size_y, si.size_x), np.uint8)
+        t0 = time.perf_counter()
+        _, _, orgb, counts, status = loader.render(flat, si, ppi, eye, direction, angles, misround=misround)
+        seconds = time.perf_counter() - t0
+    except Exception as e:       # noqa: BLE001 - the oracle library missing or unloadable: reported, not fatal
+        return {"delivered_frame_equals_oracle": None, "rays_equal_oracle_count": None,
+                "frame_check_error": "%s: %s" % (type(e).__name__, e)}
+    oracle_rays = int(counts[0]) + int(counts[1])
+    image = np.asarray(image).reshape(orgb.shape)
+    off = np.abs(image.astype(np.int16) - orgb.astype(np.int16)).max(axis=-1)
+    differing = off > 0
+    unmarked = differing & (misround == 0)
+    same = bool(status == 0 and not unmarked.any() and int(differing.sum()) <= MAX_MARKED_PIXELS and int(off.max()) <= 1)
+    return {"delivered_frame_equals_oracle": same, "rays_equal_oracle_count": bool(status == 0 and oracle_rays == int(engine_rays)),
+            "oracle_rays_per_frame": oracle_rays, "engine_census_rays_per_frame": int(engine_rays),
+            "frame_check": {"pixels": int(off.size), "pixels_differing": int(differing.sum()),
+                            "of_which_not_behind_a_misrounded_libm_result": int(unmarked.sum()),
+                            "largest_rgb8_difference": int(off.max()), "pixels_the_oracle_marked": int((misround != 0).sum()),
+                            "allowed_marked_pixels": MAX_MARKED_PIXELS, "oracle_seconds": round(seconds, 2),
+                            "what": "the image the last timed step delivered to the host against the CPU oracle's frame "
+                                    "(as pinned: libm's binary32 powf), whole frame"}}
 
 
 def _profiled_workload(args, world):

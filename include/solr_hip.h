@@ -289,6 +289,9 @@ void solr_hip_set_copy_route(int onTheFramesOwnStream);
  * ahead overwrite its rows).  The ranks run the same program: the same sequence of tickets.  After reshape_scene (the frame
  * size is the segment's); undone by finalize_scene.  0, or -1 with the error set. */
 int solr_hip_image_share(const char *name, int rank, int world);
+/* after a barrier that follows every rank's solr_hip_image_share: the root removes the segment's NAME (the mappings
+ * stay), so that a job that dies later leaves nothing in /dev/shm; a no-op elsewhere */
+void solr_hip_image_share_sealed(void);
 void solr_hip_image_unshare(void);
 
 /* Float framebuffer of the strip back to the host (parity tests) */

@@ -4,8 +4,8 @@
  * Not part of the drop-in boundary (include/solr_hip.h) and not used by the product: they exist so that the
  * engine's OWN device functions - the slab test in its three forms (the reference's compare chain, the sign-free
  * form, the hand-scheduled node loop), the primitive tests as both walks dispatch them, the two walks themselves
- * over the resident scene, refraction / reflection, makeColor, skyboxMapping, intersectionShader with the texture
- * mappers - can be evaluated once per element of arrays of inputs, the arrays that oracle/ref_probes.cl feeds to
+ * over the resident scene, primitiveShader, refraction / reflection, makeColor, skyboxMapping, intersectionShader with
+ * the texture mappers, the post-processing kernels - can be evaluated once per element of arrays of inputs, the arrays that oracle/ref_probes.cl feeds to
  * THE REFERENCE'S OWN functions (RayTracer.cl:847-874, 1151-1394, 1528-1591 ...), and compared with the reference's
  * outputs bit for bit WITH NO ORACLE IN BETWEEN (tests/test_engine_probes_gpu.py against
  * tests/golden/reference_probes.npz).  Every kernel calls the very functions the renderer is built from
@@ -55,6 +55,30 @@ int solr_hip_probe_closest(const SceneInfo *sceneInfo, int n, const float *origi
 int solr_hip_probe_shadow(const SceneInfo *sceneInfo, int n, const float *lampCenters, const float *origins,
                           const int *lightId, const int *objectId, const int *iteration, int features, int exactNodes,
                           float *result, float *color);
+
+/* primitiveShader (GI:916-1080; rt_device.h primitiveShader) with the resident scene, lights and random buffer: element i
+ * shades primitive objectId[i] (index into the flattened array) at intersections[i] as bounce iteration[i] of pixel
+ * index[i], seen from origins[i].  normal, closestColor, totalBlinn (3 per element) and attributes (4) are in/out, as
+ * in the reference (they persist across bounces); returned 3, shadowIntensity 1 per element.  Lamp 0's shadow rays walk
+ * the resident node list (exactNodes as above). */
+int solr_hip_probe_shader(const SceneInfo *sceneInfo, int n, const int *index, const float *origins, const int *objectId,
+                          const float *intersections, const float *areas, const int *iteration, int features, int exactNodes,
+                          float *normal, float *closestColor, float *totalBlinn, float *attributes, float *returned,
+                          float *shadowIntensity);
+
+/* the post-processing stage of cudaRender (CRT:1857-1890) over a frame buffer of the caller's (sceneInfo.size pixels):
+ * k_depthOfField / k_ambientOcclusion / k_radiosity / k_filter / k_cartoon exactly as renderImpl launches them behind the
+ * renderer, or, for ppe_none, the stand-alone k_default (CRT:1057-1073: the conversion the renderer otherwise fuses into
+ * its epilogue).  The random buffer is the resident one (h2d_randoms).  bitmap: 3 bytes per pixel. */
+int solr_hip_probe_postprocess(const SceneInfo *sceneInfo, const PostProcessingInfo *postProcessingInfo,
+                               const PostProcessingBuffer *frame, unsigned char *bitmap);
+
+/* The read-back tickets of solr_hip_d2h_image_async (include/solr_hip.h): the ticket the serial-th frame of a process
+ * gets - always a positive int: (serial mod period) x ring + slot - with its slot and the period (no GPU needed); and
+ * the engine's serial counter, returned, and set first when setTo >= 0 (to put a running engine just before 2^31 / 6
+ * tickets - 27 hours of frames - and render across) */
+int solr_hip_probe_ticket(long long serial, int *slot, long long *period);
+long long solr_hip_probe_image_serial(long long setTo);
 
 /* vectorRefraction (VU:73-87) and vectorReflection (VU:61-64) */
 int solr_hip_probe_vectors(int n, const float *incident, const float *normals, const float *n1, const float *n2,

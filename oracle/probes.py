@@ -428,6 +428,8 @@ def _walk_rays(scene, rng, n):
 
 SCENES = {
     "cornell": lambda: SceneData(_solr().scenes.cornell, width=128, height=96, iterations=3),
+    # the same room without its glass spheres: one lamp, nothing transparent, nothing emissive but the lamp
+    "cornell_opaque": lambda: SceneData(_solr().scenes.cornell, width=128, height=96, iterations=3, glass=0),
     "mix": lambda: SceneData(_extra().primitives_mix, width=96, height=64),
     "sticks": lambda: SceneData(_extra().sticks),
     "triangles": lambda: SceneData(_extra().triangles_only),
@@ -474,26 +476,40 @@ def _surface_points(scene, rng, n):
     return origins[keep], prim[keep], inter[keep], normal[keep], areas[keep]
 
 
-def case_shadow(scene_name, seed=14, n=1024):
-    rng = np.random.default_rng(seed + len(scene_name))
+def case_shadow(scene_name, seed=14, n=1024, moot=False):
+    """moot: the shadow rays of a scene in which the three statements that differ between the reference's two engines
+    (processShadows: node test from 0 / 0.05, the shaded primitive left out / not, the transparent-shadow factor) cannot
+    show - opaque occluders, and only the elements on which the oracle's two dialects return the same bits are kept
+    (`_keep_where_the_dialects_agree`: input selection, like _surface_points).  Such a case also says which primitive
+    each point lies on (`shaded`, its index in the flattened array): the CUDA engine's walk leaves that primitive out
+    (GI:829), and the engine is probed the way its renderer calls it."""
+    rng = np.random.default_rng(seed + len(scene_name) + (100 if moot else 0))
     scene = SCENES[scene_name]()
-    origins, prim, inter, normal, areas = _surface_points(scene, rng, n)
-    n = len(inter)
+    origins, prim, inter, normal, areas = _surface_points(scene, rng, 2 * n if moot else n)
+    n = len(inter) if not moot else n
+    m = len(inter)
     light = scene.lights[0]
-    lamp = (light["location"][None, :] + rng.normal(size=(n, 3)) * 40.0).astype(f32)
-    far = rng.random(n) < 0.15            # lamps elsewhere: rays that cross the scene
+    lamp = (light["location"][None, :] + rng.normal(size=(m, 3)) * 40.0).astype(f32)
+    far = rng.random(m) < 0.15            # lamps elsewhere: rays that cross the scene
     lamp[far] = rng.uniform(-9000, 9000, (int(far.sum()), 3)).astype(f32)
-    object_id = np.full(n, int(light["primitiveId"]), i32)
-    iteration = rng.choice([0, 1, 2, 3], n).astype(i32)
-    return dict(name="shadow", scene=scene, si=scene.si, lamps=lamp, origins=inter.copy(), object_id=object_id,
+    object_id = np.full(m, int(light["primitiveId"]), i32)
+    iteration = rng.choice([0, 1, 2, 3], m).astype(i32)
+    case = dict(name="shadow", scene=scene, si=scene.si, lamps=lamp, origins=inter.copy(), object_id=object_id,
                 iteration=iteration)
+    if moot:
+        case["shaded"] = prim.astype(i32)
+        case = _keep_where_the_dialects_agree(case, n)
+    return case
 
 
-def case_shader(scene_name, seed=15, n=1024, **si_changes):
-    rng = np.random.default_rng(seed + len(scene_name))
+def case_shader(scene_name, seed=15, n=1024, moot=False, **si_changes):
+    """moot: as case_shadow - a scene with one lamp, no emissive or wireframe material but the lamp's, a refinement pass
+    below 10, and only elements on which the oracle's two dialects agree in every output: there the reference's own
+    primitiveShader IS the CUDA engine's answer (statements 18-21 and, through its shadow rays, 14-16 do not show)."""
+    rng = np.random.default_rng(seed + len(scene_name) + (100 if moot else 0))
     scene = SCENES[scene_name]()
-    origins, prim, inter, normal, areas = _surface_points(scene, rng, n)
-    n = len(inter)
+    origins, prim, inter, normal, areas = _surface_points(scene, rng, 2 * n if moot else n)
+    keep, n = n, len(inter)
     mats = scene.materials[scene.prims["materialId"][prim]]
     attributes = np.stack([mats["reflection"], mats["transparency"], mats["refraction"], mats["opacity"]], 1).astype(f32)
     closest_color = np.where(rng.random((n, 1)) < 0.5, 0.0, rng.uniform(0, 1, (n, 3))).astype(f32)
@@ -501,9 +517,10 @@ def case_shader(scene_name, seed=15, n=1024, **si_changes):
     iteration = rng.choice([0, 1, 2, 3, 4, 5], n).astype(i32)
     index = rng.integers(0, 1920 * 1080, n).astype(i32)
     si = _copy_si(scene.si, **si_changes)
-    return dict(name="shader", scene=scene, si=si, ppi=scene.ppi, index=index, origins=origins, normal=normal,
+    case = dict(name="shader", scene=scene, si=si, ppi=scene.ppi, index=index, origins=origins, normal=normal,
                 object_id=prim.astype(i32), inter=inter, areas=areas, closest_color=closest_color, iteration=iteration,
                 total_blinn=total_blinn, attributes=attributes)
+    return _keep_where_the_dialects_agree(case, keep) if moot else case
 
 
 def case_intersection_shader(seed=16, per_primitive=120):
@@ -587,8 +604,11 @@ def case_launch(scene_name, seed=20, width=80, height=56, **si_changes):
                 width=width, height=height)
 
 
-def case_post(seed=21, width=96, height=64, pp_type=0, iteration=0, param1=0.0, param2=0.0, param3=0):
-    """the reference's own post-processing kernels on a synthetic frame buffer with depth discontinuities"""
+def case_post(seed=21, width=96, height=64, pp_type=0, iteration=0, param1=0.0, param2=0.0, param3=0, period=0):
+    """the reference's own post-processing kernels on a synthetic frame buffer with depth discontinuities.
+    period: the random buffer repeats with that period - with 900, randoms[i + 100] == randoms[i + 1000], the one
+    statement in which the two engines' k_depthOfField differ (CRT:1101 / CL:2968) cannot show, and the reference's
+    image is the CUDA engine's on every pixel"""
     rng = np.random.default_rng(seed)
     solr = _solr()
     n = width * height
@@ -600,6 +620,8 @@ def case_post(seed=21, width=96, height=64, pp_type=0, iteration=0, param1=0.0, 
     depth = 8000.0 + 4000.0 * ((xs // 12 + ys // 9) % 3) + rng.uniform(-50, 50, (height, width))
     pp["colorInfo"][:, 3] = depth.reshape(-1).astype(f32)
     randoms = rng.uniform(-1.0, 1.0, max(n, 4096)).astype(f32)
+    if period:
+        randoms = np.ascontiguousarray(np.resize(randoms[:period], len(randoms)))
     si = _scene_info(size_x=width, size_y=height, pathTracingIteration=iteration)
     ppi = solr.PostProcessingInfo(pp_type, param1, param2, param3)
     return dict(name="post", si=si, ppi=ppi, pp=pp, randoms=randoms, width=width, height=height)
@@ -768,9 +790,11 @@ def _oracle_outputs(L, case):
     if name == "shadow":
         n = len(case["origins"])
         result, color = np.zeros(n, f32), np.zeros((n, 3), f32)
-        nobody = np.full(n, -12345, i32)   # the OpenCL dialect leaves out the lamp only
+        # the OpenCL dialect leaves out the lamp only, whatever this argument says; the CUDA dialect also the primitive
+        # the point lies on, when the case names it (`shaded`: the moot cases) - otherwise nobody, as the reference's probe
+        shaded = case["shaded"] if "shaded" in case else np.full(n, -12345, i32)
         L.oracle_probe_shadow(n, C.byref(osc), C.byref(case["si"]), _p(case["lamps"]), _p(case["origins"]),
-                              _p(case["object_id"]), _p(nobody), _p(case["iteration"]), _p(result), _p(color))
+                              _p(case["object_id"]), _p(shaded), _p(case["iteration"]), _p(result), _p(color))
         return dict(result=result, color=color)
     if name == "shader":
         n = len(case["origins"])
@@ -826,6 +850,43 @@ def _oracle_outputs(L, case):
         assert status == 0
         return dict(bitmap=bitmap)
     raise KeyError(name)
+
+
+def both_dialects(case):
+    """(CUDA dialect, OpenCL dialect) outputs of the oracle for a case"""
+    L = loader.lib()
+    assert L.oracle_get_dialect() == 0
+    return _oracle_outputs(L, case), oracle_outputs(case)
+
+
+def dialects_agree(case, per_key=False):
+    """per element: do the oracle's two dialects return the same bits?  Where they do, none of the statements in which
+    the reference's engines differ can be seen in the result, and the reference's own (OpenCL) output is what the CUDA
+    engine computes as well - the elements on which the product can be held to reference output directly.
+    per_key: a dict of masks, one per output (a pixel whose depth is under a switch may still have an unaffected
+    colour); otherwise one mask over all outputs."""
+    cuda, cl = both_dialects(case)
+    masks = {}
+    for key in cuda:
+        same = same_bits(cuda[key], cl[key])
+        masks[key] = same.reshape(len(same), -1).all(axis=1)
+    if per_key:
+        return masks
+    return np.logical_and.reduce(list(masks.values()))
+
+
+def _keep_where_the_dialects_agree(case, n):
+    """the first n elements of a case on which the two dialects agree in every output (input selection only: both
+    sides of a comparison are then handed the same arrays)"""
+    agree = dialects_agree(case)
+    m = len(agree)
+    keep = np.flatnonzero(agree)[:n]
+    assert len(keep) >= min(n, 256), "only %d of %d candidate elements are free of dialect switches" % (len(keep), m)
+    out = {k: (v[keep].copy() if isinstance(v, np.ndarray) and len(v) == m and k not in ("materials", "textures") else v)
+           for k, v in case.items()}
+    out["candidates"] = m
+    out["kept_of_candidates"] = int(agree.sum())
+    return out
 
 
 def _hash_array(h, a):
@@ -891,11 +952,17 @@ CASES = {
     "shadow_cornell": lambda: case_shadow("cornell"),
     "shadow_mix": lambda: case_shadow("mix"),
     "shadow_sticks": lambda: case_shadow("sticks"),
+    "shadow_cornell_opaque_moot": lambda: case_shadow("cornell_opaque", moot=True),
+    "shadow_sticks_moot": lambda: case_shadow("sticks", moot=True),
+    "shadow_triangles_moot": lambda: case_shadow("triangles", moot=True),
     "shader_cornell": lambda: case_shader("cornell"),
     "shader_cornell_blinn_only": lambda: case_shader("cornell", graphicsLevel=2),
     "shader_cornell_accumulation": lambda: case_shader("cornell", pathTracingIteration=12, timestamp=17),
     "shader_mix": lambda: case_shader("mix"),
     "shader_textured": lambda: case_shader("textured"),
+    "shader_cornell_opaque_moot": lambda: case_shader("cornell_opaque", moot=True),
+    "shader_sticks_moot": lambda: case_shader("sticks", moot=True),
+    "shader_triangles_moot": lambda: case_shader("triangles", moot=True, pathTracingIteration=3),
     "intersection_shader": lambda: case_intersection_shader(),
     "skybox": lambda: case_skybox(),
     "vectors": lambda: case_vectors(),
@@ -905,8 +972,11 @@ CASES = {
     "launch_cornell_fog": lambda: case_launch("cornell", atmosphericEffect=1, viewDistance=36000.0),
     "launch_mix": lambda: case_launch("mix"),
     "launch_textured": lambda: case_launch("textured"),
+    "launch_cornell_opaque": lambda: case_launch("cornell_opaque", nbRayIterations=1),
+    "launch_sticks": lambda: case_launch("sticks"),
     "post_default": lambda: case_post(pp_type=0),
     "post_default_accumulated": lambda: case_post(pp_type=0, iteration=13),
     "post_depth_of_field": lambda: case_post(pp_type=1, param1=9000.0, param2=300.0, param3=16),
+    "post_depth_of_field_moot": lambda: case_post(pp_type=1, param1=9000.0, param2=300.0, param3=16, period=900),
     "post_ambient_occlusion": lambda: case_post(pp_type=2, param2=40.0),
 }

@@ -387,63 +387,76 @@ SOLR_DEV void fetchTexel(const MaterialCold &mc, cbp tex, int u, int v, float4 &
     }
 }
 
-/* TM:118-158 */
-SOLR_DEV void juliaSet(const MaterialCold &mc, const SceneInfo &si, float x, float y, float4 &color)
+/* The two procedural textures (TM:118-197): escape-time fractals over the material's texture rectangle, a texel's
+ * shade being 1 - colour x (steps taken / step limit).  Both iterate z <- z * z + c in binary32; the recurrence and
+ * the shade are written once here, with the reference's order of operations, and the two functions keep what they
+ * differ in: Julia looks at the NEW z and does not count the step that escapes, Mandelbrot looks at the OLD z, still
+ * takes the step and counts it; Mandelbrot's imaginary pitch is held in binary64 (TM:172-175). */
+struct Complex32
 {
-    float W = (float)mc.textureMapping.x;
-    float H = (float)mc.textureMapping.y;
-    float cRe = -0.7f + 0.4f * sin_f(si.timestamp / 1500.f);
-    float cIm = 0.27015f + 0.4f * cos_f(si.timestamp / 2000.f);
-    float newRe = 1.5f * (x - W / 2.f) / (0.5f * W);
-    float newIm = (y - H / 2.f) / (0.5f * H);
-    int n;
-    float maxIterations = 40.f + si.pathTracingIteration;
-    for (n = 0; n < maxIterations; n++)
-    {
-        float oldRe = newRe;
-        float oldIm = newIm;
-        newRe = oldRe * oldRe - oldIm * oldIm + cRe;
-        newIm = 2.f * oldRe * oldIm + cIm;
-        if ((newRe * newRe + newIm * newIm) > 4.f)
-            break;
-    }
-    color.x = 1.f - color.x * (n / maxIterations);
-    color.y = 1.f - color.y * (n / maxIterations);
-    color.z = 1.f - color.z * (n / maxIterations);
-    color.w = 1.f - (n / maxIterations);
+    float re, im;
+};
+
+SOLR_DEV Complex32 squaredPlus(Complex32 z, Complex32 c)
+{
+    Complex32 r;
+    r.re = z.re * z.re - z.im * z.im + c.re;
+    r.im = 2.f * z.re * z.im + c.im;
+    return r;
 }
 
-/* TM:160-197 */
+SOLR_DEV bool escaped(Complex32 z) { return (z.re * z.re + z.im * z.im) > 4.f; }
+
+SOLR_DEV void escapeShade(float4 &color, float steps, float limit)
+{
+    const float share = steps / limit;
+    color.x = 1.f - color.x * share;
+    color.y = 1.f - color.y * share;
+    color.z = 1.f - color.z * share;
+    color.w = 1.f - share;
+}
+
+/* TM:118-158: c drifts with the time stamp, z starts at the texel (1.5 : 1 over the rectangle's half extents) */
+SOLR_DEV void juliaSet(const MaterialCold &mc, const SceneInfo &si, float x, float y, float4 &color)
+{
+    const float w = (float)mc.textureMapping.x, h = (float)mc.textureMapping.y;
+    Complex32 c, z;
+    c.re = -0.7f + 0.4f * sin_f(si.timestamp / 1500.f);
+    c.im = 0.27015f + 0.4f * cos_f(si.timestamp / 2000.f);
+    z.re = 1.5f * (x - w / 2.f) / (0.5f * w);
+    z.im = (y - h / 2.f) / (0.5f * h);
+    const float limit = 40.f + si.pathTracingIteration;
+    int steps = 0;
+    while (steps < limit)
+    {
+        z = squaredPlus(z, c);
+        if (escaped(z))
+            break;
+        ++steps;
+    }
+    escapeShade(color, (float)steps, limit);
+}
+
+/* TM:160-197: c is the texel in the window re -2 ... 1, im -1.2 ... -1.2 + 3 h / w, z starts at c */
 SOLR_DEV void mandelbrotSet(const MaterialCold &mc, const SceneInfo &si, float x, float y, float4 &color)
 {
-    float W = (float)mc.textureMapping.x;
-    float H = (float)mc.textureMapping.y;
-    float MinRe = -2.f;
-    float MaxRe = 1.f;
-    float MinIm = -1.2f;
-    float MaxIm = MinIm + (MaxRe - MinRe) * H / W;
-    float Re_factor = (MaxRe - MinRe) / (W - 1.f);
-    double Im_factor = (MaxIm - MinIm) / (H - 1.f);
-    float maxIterations = NB_MAX_ITERATIONS + si.pathTracingIteration;
-    float c_im = (float)(MaxIm - y * Im_factor);
-    float c_re = MinRe + x * Re_factor;
-    float Z_re = c_re;
-    float Z_im = c_im;
-    bool isInside = true;
-    unsigned n;
-    for (n = 0; isInside && n < maxIterations; ++n)
+    const float w = (float)mc.textureMapping.x, h = (float)mc.textureMapping.y;
+    const float left = -2.f, right = 1.f, bottom = -1.2f;
+    const float top = bottom + (right - left) * h / w;
+    const float pitchRe = (right - left) / (w - 1.f);
+    const double pitchIm = (top - bottom) / (h - 1.f); /* (a binary32 quotient, widened) */
+    const float limit = NB_MAX_ITERATIONS + si.pathTracingIteration;
+    Complex32 c;
+    c.im = (float)(top - y * pitchIm);
+    c.re = left + x * pitchRe;
+    Complex32 z = c;
+    unsigned steps = 0;
+    for (bool inside = true; inside && steps < limit; ++steps)
     {
-        float Z_re2 = Z_re * Z_re;
-        float Z_im2 = Z_im * Z_im;
-        if (Z_re2 + Z_im2 > 4.f)
-            isInside = false;
-        Z_im = 2.f * Z_re * Z_im + c_im;
-        Z_re = Z_re2 - Z_im2 + c_re;
+        inside = !escaped(z);
+        z = squaredPlus(z, c);
     }
-    color.x = 1.f - color.x * (n / maxIterations);
-    color.y = 1.f - color.y * (n / maxIterations);
-    color.z = 1.f - color.z * (n / maxIterations);
-    color.w = 1.f - (n / maxIterations);
+    escapeShade(color, (float)steps, limit);
 }
 
 /* TM:354-447 (non-Kinect build) */

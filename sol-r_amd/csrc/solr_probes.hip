@@ -23,6 +23,10 @@ namespace solrprobe
 {
 int residentScene(const SceneInfo &sceneInfo, bool exactNodes, SceneArgs *S, int *features, int *deepList, hipStream_t *stream);
 void fail(int code, const char *what);
+int ticketOfSerial(long long serial, int *slot, long long *period);
+long long imageSerial(long long setTo);
+int postProcess(const SceneInfo &sceneInfo, const PostProcessingInfo &ppInfo, const PostProcessingBuffer *frame,
+                unsigned char *bitmapOut);
 } // namespace solrprobe
 
 namespace
@@ -253,6 +257,42 @@ __global__ __launch_bounds__(64) void k_probeShadow(const SceneArgs SA, const Sc
     }
 }
 
+/* ---- primitiveShader, once per element --------------------------------------------------------------------------
+ * The renderer calls it with the whole wave (the lamp loop is wave-uniform, the shadow walk inside it wave-synchronous)
+ * and a bounce number per lane (the deferred reflection ray of phase 1 is shaded as bounce `reflectedRays`): so does
+ * this kernel, 64 unrelated elements per wave. */
+template <int FEAT>
+__global__ __launch_bounds__(64) void k_probeShader(const SceneArgs SA, const SceneInfo si, int n, const int *index,
+                                                   const float *origins, const int *objectId, const float *intersections,
+                                                   const float *areas, const int *iteration, float *normal,
+                                                   float *closestColor, float *totalBlinn, float *attributes, float *returned,
+                                                   float *shadowIntensity)
+{
+    const Scene S = makeScene(SA);
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    const bool active = e < n;
+    const int q = active ? e : 0;
+    Counters cnt;
+    memset(&cnt, 0, sizeof(cnt));
+    v3 nrm = at3(normal, q), cc = at3(closestColor, q), tb = at3(totalBlinn, q);
+    float4 attr = make_float4(attributes[4 * q], attributes[4 * q + 1], attributes[4 * q + 2], attributes[4 * q + 3]);
+    float shadow = 0.f;
+    const v3 r = primitiveShader<false, FEAT>(S, active, index[q], si, at3(origins, q), nrm, objectId[q], at3(intersections, q),
+                                              at3(areas, q), cc, iteration[q], shadow, tb, attr, cnt);
+    if (active)
+    {
+        put3(normal, e, nrm);
+        put3(closestColor, e, cc);
+        put3(totalBlinn, e, tb);
+        attributes[4 * e] = attr.x;
+        attributes[4 * e + 1] = attr.y;
+        attributes[4 * e + 2] = attr.z;
+        attributes[4 * e + 3] = attr.w;
+        put3(returned, e, r);
+        shadowIntensity[e] = shadow;
+    }
+}
+
 /* ---- plain per-element functions ------------------------------------------------------------------------------ */
 __global__ __launch_bounds__(64) void k_probeVectors(int n, const float *incident, const float *normals, const float *n1,
                                                     const float *n2, float *refracted, float *reflected)
@@ -462,6 +502,42 @@ int solr_hip_probe_shadow(const SceneInfo *sceneInfo, int n, const float *lampCe
     PROBE_DISPATCH(k_probeShadow, features, waves(n), stream, S, *sceneInfo, n, dL, dO, dLight, dObject, dIt, dR, dC);
     return a.finish(stream) ? features : -1;
 }
+
+int solr_hip_probe_shader(const SceneInfo *sceneInfo, int n, const int *index, const float *origins, const int *objectId,
+                          const float *intersections, const float *areas, const int *iteration, int features, int exactNodes,
+                          float *normal, float *closestColor, float *totalBlinn, float *attributes, float *returned,
+                          float *shadowIntensity)
+{
+    SceneArgs S;
+    int need, deep;
+    hipStream_t stream;
+    if (n <= 0 || solrprobe::residentScene(*sceneInfo, exactNodes != 0, &S, &need, &deep, &stream) != 0)
+        return -1;
+    features = chooseFeatures(features, need, deep);
+    Arrays a;
+    const int *dIndex = a.in(index, n), *dObject = a.in(objectId, n), *dIt = a.in(iteration, n);
+    const float *dO = a.in(origins, 3 * (size_t)n), *dI = a.in(intersections, 3 * (size_t)n), *dA = a.in(areas, 3 * (size_t)n);
+    float *dN = a.out(normal, 3 * (size_t)n), *dC = a.out(closestColor, 3 * (size_t)n), *dB = a.out(totalBlinn, 3 * (size_t)n);
+    float *dAttr = a.out(attributes, 4 * (size_t)n), *dR = a.out(returned, 3 * (size_t)n), *dS = a.out(shadowIntensity, n);
+    if (a.failed)
+        return -1;
+    PROBE_DISPATCH(k_probeShader, features, waves(n), stream, S, *sceneInfo, n, dIndex, dO, dObject, dI, dA, dIt, dN, dC, dB,
+                   dAttr, dR, dS);
+    return a.finish(stream) ? features : -1;
+}
+
+int solr_hip_probe_postprocess(const SceneInfo *sceneInfo, const PostProcessingInfo *postProcessingInfo,
+                               const PostProcessingBuffer *frame, unsigned char *bitmap)
+{
+    return solrprobe::postProcess(*sceneInfo, *postProcessingInfo, frame, bitmap) == 0 ? 1 : -1;
+}
+
+int solr_hip_probe_ticket(long long serial, int *slot, long long *period)
+{
+    return solrprobe::ticketOfSerial(serial, slot, period);
+}
+
+long long solr_hip_probe_image_serial(long long setTo) { return solrprobe::imageSerial(setTo); }
 
 int solr_hip_probe_vectors(int n, const float *incident, const float *normals, const float *n1, const float *n2,
                            float *refracted, float *reflected)

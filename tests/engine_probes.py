@@ -17,6 +17,7 @@ f32, i32 = np.float32, np.int32
 F_SPHERE, F_PROC, F_CYL, F_ELL, F_TRI, F_PLANE, F_TEX, F_FULL, F_DEEP = 1, 2, 4, 8, 16, 32, 64, 128, 256
 EVERYTHING = (255 & ~F_FULL) | F_DEEP
 NOBODY = -12345          # a Primitive.index no primitive has
+MAX_BITMAP_SIZE = 1920 * 1080   # Consts.h:39-41
 
 
 class TextureInfo(C.Structure):
@@ -38,13 +39,19 @@ def declare(hip):
     hip.solr_hip_probe_primitive.argtypes = [v, i, v, v, v, i, v, v, v, v, v]
     hip.solr_hip_probe_closest.argtypes = [v, i, v, v, v, v, i, i, v, v, v, v, v]
     hip.solr_hip_probe_shadow.argtypes = [v, i, v, v, v, v, v, i, i, v, v]
+    hip.solr_hip_probe_shader.argtypes = [v, i, v, v, v, v, v, v, i, i, v, v, v, v, v, v]
+    hip.solr_hip_probe_postprocess.argtypes = [v, v, v, v]
+    hip.solr_hip_h2d_randoms_sized.argtypes = [v, C.c_long]
+    hip.solr_hip_probe_ticket.argtypes = [C.c_longlong, v, v]
+    hip.solr_hip_probe_image_serial.argtypes = [C.c_longlong]
+    hip.solr_hip_probe_image_serial.restype = C.c_longlong
     hip.solr_hip_probe_vectors.argtypes = [i, v, v, v, v, v, v]
     hip.solr_hip_probe_make_color.argtypes = [v, i, v, v]
     hip.solr_hip_probe_skybox.argtypes = [v, i, v, v, v]
     hip.solr_hip_probe_intersection_shader.argtypes = [v, i, v, v, v, v, v, v, v]
     hip.h2d_textures.argtypes = [C.c_uint64, i, v]
-    for name in ("box", "box_walk", "primitive", "closest", "shadow", "vectors", "make_color", "skybox",
-                 "intersection_shader"):
+    for name in ("box", "box_walk", "primitive", "closest", "shadow", "shader", "postprocess", "ticket", "vectors",
+                 "make_color", "skybox", "intersection_shader"):
         getattr(hip, "solr_hip_probe_" + name).restype = i
     del P
 
@@ -61,7 +68,7 @@ def _check(hip, status, what):
 class Resident:
     """a scene made resident through the C ABI alone; `with Resident(...) as r:` finalizes the engine afterwards"""
 
-    def __init__(self, solr, si, boxes, prims, materials, textures=None, lights=None, nb_lamps=0):
+    def __init__(self, solr, si, boxes, prims, materials, textures=None, lights=None, nb_lamps=0, randoms=None):
         self.solr, self.hip = solr, solr.hip_lib()
         declare(self.hip)
         hip = self.hip
@@ -84,6 +91,10 @@ class Resident:
             li = np.ascontiguousarray(lights)
             self.keep.append(li)
             hip.h2d_lightInformation(0, _p(li), len(li))
+        if randoms is not None and len(randoms):
+            rnd = np.ascontiguousarray(randoms, f32)
+            self.keep.append(rnd)
+            hip.solr_hip_h2d_randoms_sized(_p(rnd), len(rnd))
         _check(hip, 0, "upload")
 
     def __enter__(self):
@@ -158,11 +169,63 @@ def engine_outputs(solr, case, features=0, exact=0):
                               "probe_closest")
                 return dict(hit=hit, primitive=prim, intersection=inter, normal=normal, areas=areas, features=used)
             result, color = np.zeros(n, f32), np.zeros((n, 3), f32)
-            nobody = np.full(n, NOBODY, i32)      # the reference's probe (the OpenCL engine) leaves out the lamp only
+            # the reference's probe (the OpenCL engine) leaves out the lamp only; the renderer's call also the primitive
+            # the point lies on (GI:829) - the cases that name it (`shaded`) are probed the renderer's way
+            nobody = case["shaded"] if "shaded" in case else np.full(n, NOBODY, i32)
             used = _check(hip, hip.solr_hip_probe_shadow(C.byref(si), n, _p(case["lamps"]), _p(case["origins"]),
                                                          _p(case["object_id"]), _p(nobody), _p(case["iteration"]), features,
                                                          exact, _p(result), _p(color)), "probe_shadow")
             return dict(result=result, color=color, features=used)
+    if name == "shader":
+        s = case["scene"]
+        n = len(case["origins"])
+        normal, cc, tb = case["normal"].copy(), case["closest_color"].copy(), case["total_blinn"].copy()
+        at = case["attributes"].copy()
+        ret, shadow = np.zeros((n, 3), f32), np.zeros(n, f32)
+        with Resident(solr, si, s.boxes, s.prims, s.materials, s.textures, s.lights, s.nb_lamps, s.randoms):
+            used = _check(hip, hip.solr_hip_probe_shader(C.byref(si), n, _p(case["index"]), _p(case["origins"]),
+                                                         _p(case["object_id"]), _p(case["inter"]), _p(case["areas"]),
+                                                         _p(case["iteration"]), features, exact, _p(normal), _p(cc), _p(tb),
+                                                         _p(at), _p(ret), _p(shadow)), "probe_shader")
+        return dict(returned=ret, shadow=shadow, normal=normal, closest_color=cc, total_blinn=tb, attributes=at,
+                    features=used)
+    if name == "launch":
+        # the case's rays are the camera rays of k_standardRenderer for this eye / look-at point and no rotation
+        # (oracle.probes.case_launch): the frame goes through the renderer itself, pass 0
+        s = case["scene"]
+        w, h = case["width"], case["height"]
+        eye, look = case["origins"][0].copy(), np.array([57.0, 23.0, 0.0], f32)
+        angles = np.array([0.0, 0.0, 0.0, 6400.0], f32)
+        assert (case["origins"] == eye).all() and case["targets"][(h // 2) * w + w // 2].tolist() == look.tolist()
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        with Resident(solr, si, s.boxes, s.prims, s.materials, s.textures, s.lights, s.nb_lamps, s.randoms):
+            hip.solr_hip_set_variant(4 if features == EVERYTHING else (3 if exact else 0))
+            try:
+                objects = solr.Vec4i(len(s.boxes), len(s.prims), s.nb_lamps, len(s.lights))
+                hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(case["ppi"]), fp(eye), fp(look), fp(angles))
+                _check(hip, 0, "render")
+                pp = np.zeros((h, w, 8), f32)
+                ids = np.zeros((h, w, 4), i32)
+                rgb = np.zeros((h, w, 3), np.uint8)
+                hip.solr_hip_d2h_postprocessing(C.c_void_p(pp.ctypes.data))
+                hip.solr_hip_d2h(C.byref(si), C.c_void_p(rgb.ctypes.data), C.c_void_p(ids.ctypes.data))
+                _check(hip, 0, "read-back")
+            finally:
+                hip.solr_hip_set_variant(0)
+        pp = pp.reshape(-1, 8)
+        return dict(color=pp[:, :3].copy(), depth=pp[:, 3].copy(), ids=ids.reshape(-1, 4).copy(), bitmap=rgb.reshape(-1))
+    if name == "post":
+        w, h = case["width"], case["height"]
+        bitmap = np.zeros(w * h * 3, np.uint8)
+        prims = np.zeros(1, solr.PRIMITIVE_DTYPE)
+        prims["size"][:, 0] = 1.0
+        materials = np.zeros(2, solr.MATERIAL_DTYPE)
+        randoms = np.zeros(max(len(case["randoms"]), MAX_BITMAP_SIZE), f32)     # (the upload wants the reference's size)
+        randoms[: len(case["randoms"])] = case["randoms"]
+        with Resident(solr, si, one_leaf(solr, prims), prims, materials, randoms=randoms):
+            _check(hip, hip.solr_hip_probe_postprocess(C.byref(si), C.byref(case["ppi"]), _p(case["pp"]), _p(bitmap)),
+                   "probe_postprocess")
+        return dict(bitmap=bitmap)
     if name == "vectors":
         n = len(case["incident"])
         refracted, reflected = np.zeros((n, 3), f32), np.zeros((n, 3), f32)
@@ -195,4 +258,5 @@ def engine_outputs(solr, case, features=0, exact=0):
     raise KeyError(name)
 
 
-ENGINE_CASES = ("box", "primitive", "closest", "shadow", "vectors", "make_color", "skybox", "intersection_shader")
+ENGINE_CASES = ("box", "primitive", "closest", "shadow", "shader", "launch", "post", "vectors", "make_color", "skybox",
+                "intersection_shader")

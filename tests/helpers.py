@@ -48,13 +48,19 @@ def assert_parity(res, max_ulp=1, rgb_max_diff=0, depth_ulp=0):
     assert res["rgb_max_diff"] <= rgb_max_diff, res
 
 
-def assert_parity_pinned(gpu, ora, misround, max_exceptions, what=""):
+def assert_parity_pinned(gpu, ora, misround, max_exceptions, what="", marked_bounds=(2, 1)):
     """The bar against the oracle AS PINNED (libm's binary32 powf / sinf / cosf / atan2f / asinf, not switched to
     the engine's correctly rounded forms): primitive ids, depth exact; float colour <= 1 ULP and RGB8 exact on
     every pixel except a COUNTED set, each member of which (a) is at most 2 ULP / one RGB8 step off and (b) went,
     in the oracle, through a libm result that is not the correctly rounded value - `misround`, filled by
     oracle.render(misround=...), which evaluates the same call in binary64 at the call and rounds once, which is
-    what the engine does.  Returns the figures with the number of such pixels."""
+    what the engine does.  Returns the figures with the number of such pixels.
+    marked_bounds = (ULPs, RGB8 steps) a marked pixel may be off; None for a figure that has no bound: a powf result
+    one ULP off stays a colour one or two ULP off (the default), but a mis-rounded sinf / cosf moves a procedural
+    sphere's hit point, and a mis-rounded atan2f / asinf that lands on the other side of a texel boundary selects the
+    NEIGHBOURING texel of every map of the material (diffuse, normal, bump ...: TextureMapping.cuh:30-116 fetches them
+    all at the diffuse map's index) - what such a pixel shows is another texel's shading, not a rounding of this one's.
+    Those tests say so, pass None and keep the count."""
     gpu_pp, gpu_ids, gpu_rgb = gpu
     ora_pp, ora_ids, ora_rgb = ora
     res = compare_frames(gpu_pp, gpu_ids, gpu_rgb, ora_pp, ora_ids, ora_rgb)
@@ -70,9 +76,21 @@ def assert_parity_pinned(gpu, ora, misround, max_exceptions, what=""):
     unexplained = outside & (misround == 0)
     assert not unexplained.any(), (res, "pixels outside the bar that met no mis-rounded libm result",
                                    np.argwhere(unexplained)[:8].tolist())
-    assert (ulp[outside] <= 2).all() and (rgb[outside] <= 1).all(), res
+    if marked_bounds[0] is not None:
+        assert (ulp[outside] <= marked_bounds[0]).all(), res
+    if marked_bounds[1] is not None:
+        assert (rgb[outside] <= marked_bounds[1]).all(), res
     assert res["pixels_outside_the_bar"] <= max_exceptions, res
     return res
+
+
+def assert_frame_pinned(k, oracle, gpu, max_exceptions, what="", marked_bounds=(2, 1)):
+    """the engine's frame `gpu` = (pp, ids, rgb) of kernel k against the oracle as pinned (assert_parity_pinned)"""
+    misround = np.zeros(gpu[0].shape[:2], np.uint8)
+    assert not oracle.lib().oracle_get_rounded_transcendentals()
+    opp, oids, orgb, _, status = oracle_frame(k, oracle, misround=misround)
+    assert status == 0, "the oracle read outside the random buffer"
+    return assert_parity_pinned(gpu, (opp, oids, orgb), misround, max_exceptions, what, marked_bounds)
 
 
 def gpu_frame(k):

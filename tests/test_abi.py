@@ -96,3 +96,32 @@ def test_the_short_ray_list_switch_is_state_only(solr):
             assert lib.solr_hip_short_ray_lists() == 0
     finally:
         lib.solr_hip_set_short_ray_lists(-1)
+
+
+def test_read_back_tickets_are_positive_for_ever(solr):
+    """ a ticket of solr_hip_d2h_image_async is (serial mod period) x 6 + slot: a positive int for
+    every 64-bit serial - the old (int)(serial x 6 + slot) went negative after 2^31 / 6 frames, under four hours of an
+    eight-rank job - with the slot in its low part, the generation above it, and no two of any 2 x 6 consecutive
+    serials alike.  Plain arithmetic: no GPU"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import engine_probes as E
+    hip = solr.hip_lib()
+    E.declare(hip)
+    slot, period = C.c_int(), C.c_longlong()
+    limit = (1 << 31) // 6
+    for base in (1, 5, limit - 20, limit, (1 << 31) - 7, (1 << 40), (3 << 40) + 12345, (1 << 62) + 99):
+        tickets = []
+        for serial in range(base, base + 12):
+            t = hip.solr_hip_probe_ticket(C.c_longlong(serial), C.byref(slot), C.byref(period))
+            assert 0 <= t < (1 << 31), (serial, t)
+            assert slot.value == serial % 6 == t % 6
+            assert t // 6 == serial % period.value
+            tickets.append(t)
+        assert len(set(tickets)) == 12
+    assert period.value % 6 == 0 and (period.value + 6) * 6 <= (1 << 31) - 1 and period.value > (1 << 31) // 6 // 2 // 3
+    # the generation is the process's own serial, never reset (not by solr_hip_image_share either): two tickets of one
+    # process are alike only a whole period - 357 million tickets - apart
+    a = hip.solr_hip_probe_ticket(C.c_longlong(1234567), None, None)
+    assert hip.solr_hip_probe_ticket(C.c_longlong(1234567 + period.value), None, None) == a
+    assert all(hip.solr_hip_probe_ticket(C.c_longlong(1234567 + d), None, None) != a for d in (6, 600, 6000006, period.value - 6))

@@ -39,6 +39,35 @@ def test_a_launchers_environment_is_respected(solr, have_gpu):
     assert res.returncode == 2 and "WORLD_SIZE=1" in res.stderr
 
 
+def test_a_wrong_frame_or_a_wrong_ray_count_is_seen(solr, oracle):
+    """(CPU) bench.prove_frames - what bench.py runs on the image its last timed step delivered: the oracle's own frame
+    passes, a stub engine's frame with sixteen wrong pixels does not, nor does a census that is one ray off"""
+    import importlib
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    k = solr.Kernel(engine="host-only", deterministic_seed=1)
+    solr.scenes.cornell(k, width=96, height=64, iterations=3)
+    flat = k.flat_scene()
+    si, ppi, eye, direction, angles = k.frame_parameters()
+    _, _, orgb, counts, status = oracle.render(flat, si, ppi, eye, direction, angles)
+    k.finalize()
+    rays = int(counts[0]) + int(counts[1])
+    assert status == 0 and rays > 96 * 64
+    good = bench.prove_frames(flat, si, ppi, eye, direction, angles, orgb, rays)
+    assert good["delivered_frame_equals_oracle"] is True and good["rays_equal_oracle_count"] is True
+    assert good["oracle_rays_per_frame"] == rays and good["frame_check"]["pixels_differing"] == 0
+    wrong = orgb.copy()
+    wrong[32, 40:56] ^= 0x40
+    bad = bench.prove_frames(flat, si, ppi, eye, direction, angles, wrong, rays + 1)
+    assert bad["delivered_frame_equals_oracle"] is False and bad["rays_equal_oracle_count"] is False
+    assert bad["frame_check"]["pixels_differing"] == 16
+    # one RGB8 step on a pixel the oracle did not mark is a wrong frame too
+    nudged = orgb.copy()
+    nudged[10, 10, 0] = nudged[10, 10, 0] + 1 if nudged[10, 10, 0] < 255 else 254
+    assert bench.prove_frames(flat, si, ppi, eye, direction, angles, nudged, rays)["delivered_frame_equals_oracle"] is False
+
+
 def _rehearse(extra, timeout, **more_env):
     from test_multi_rank_gpu import build_loopback
     directory = tempfile.mkdtemp(prefix="solr_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -194,3 +223,23 @@ def test_the_one_gpu_line_keeps_the_contract(solr):
     assert line["value"] == pytest.approx(line["config"]["rays_per_frame"] / (line["ms_per_step"] * 1e-3) / 1e6, rel=2e-3)
     assert sp["timed_seconds_in_all"] >= 0.15                      # the GPU was busy long enough to be seen
     assert line["config"]["frames_delivered"] >= line["regions"] * 20
+    # the line proves what it timed: the last delivered image is the oracle's frame, the census the oracle's count
+    cfg = line["config"]
+    assert cfg["delivered_frame_equals_oracle"] is True and cfg["rays_equal_oracle_count"] is True
+    assert cfg["rays_per_frame"] == cfg["oracle_rays_per_frame"] == cfg["engine_census_rays_per_frame"]
+    assert cfg["frame_check"]["of_which_not_behind_a_misrounded_libm_result"] == 0
+
+
+@pytest.mark.gpu
+def test_a_job_that_delivers_a_wrong_frame_fails(solr):
+    """SOLR_BENCH_TAMPER=1 damages sixteen pixels of the delivered image before the check: the line is still printed,
+    says so, and the exit code is not 0"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(SOLR_BENCH_TAMPER="1", SOLR_BENCH_REGIONS="3")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-walk-bound", "--width", "640", "--height", "360"], env=env,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 4, (res.returncode, res.stderr[-2000:])
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["config"]["delivered_frame_equals_oracle"] is False and line["config"]["rays_equal_oracle_count"] is True
+    assert line["config"]["frame_check"]["pixels_differing"] == 16

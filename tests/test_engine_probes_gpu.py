@@ -23,10 +23,29 @@ CUDA engine's):
   skyboxMapping, vectorRefraction /          every element
     vectorReflection, makeColor RGB / BGR
 
+  primitiveShader (solr_hip_probe_shader)    every output of every element on which no dialect statement can show (below):
+                                               94 % of the Cornell room's, 100 % of the three "moot" cases'; the Blinn sum
+                                               within the library pow's ULPs
+  launchRayTracing: the frames rendered by   ids, depth, colour of every pixel on which no dialect statement can show
+    k_standardRenderer ITSELF (pass 0)
+  k_default, k_depthOfField,                 the RGB8 image: every pixel of k_default (plain and accumulated); the two
+    k_ambientOcclusion over a frame buffer     others where the dialects agree
+
 Where a switch applies the engine must equal the oracle's CUDA dialect on those elements (and does on ALL elements of
 every case: asserted as well) - that is the residue that rests on the reading of the CUDA text
-(tests/cuda_text_model.py).  processShadows sits under three switches (14-16: node test from 0, the shaded primitive
-left out, the transparent-shadow factor) and is compared with the CUDA dialect only.
+(tests/cuda_text_model.py).
+
+THE SWITCH-OBSERVABILITY MASK (round 5).  processShadows sits under three of the 36 statements (14-16), primitiveShader
+under four more (18-21), launchRayTracing under ten (22-31): no structural mask like "not a triangle" separates their
+elements.  But most of those statements cannot be SEEN on most inputs (one lamp: 19; innerIllumination.x == 0: 18, 21;
+pass < 10: 20; no transparent occluder: 16; nothing of the point's own primitive in the way: 15; no occluder within 5 %
+of the way to the lamp: 14).  oracle.probes.dialects_agree runs the oracle in BOTH dialects on the case's inputs: an
+output on which the two return the same bits is one on which the reference's own (OpenCL, source-order) output IS the
+CUDA engine's answer, and the engine is held to it there bit for bit (the Blinn term: within the ULPs of the library
+pow) - for every case of every kind, next to the structural masks above; the covered fraction is printed per output.
+The "moot" cases (oracle.probes.case_shadow / case_shader with moot=True: opaque occluders, one lamp, no emissive
+material but the lamp's, pass < 10, elements selected for agreement) are covered on EVERY element, and are probed the
+way the renderer calls the walk (the shaded primitive left out, GI:829).
 """
 import os
 import sys
@@ -36,6 +55,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import engine_probes as E  # noqa: E402
+from helpers import ulp_distance  # noqa: E402
 
 FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_probes.npz")
 ptTriangle, ptSphere, ptCone = 2, 0, 12
@@ -67,8 +87,59 @@ def _rows_equal(probes, a, b):
 
 def _names():
     from oracle import probes as module
-    return [n for n in module.CASES if n.split("_")[0] in ("box", "primitive", "closest", "shadow", "vectors", "make",
-                                                           "skybox", "intersection")]
+    return [n for n in module.CASES if n.split("_")[0] in ("box", "primitive", "closest", "shadow", "shader", "launch",
+                                                           "post", "vectors", "make", "skybox", "intersection")]
+
+
+def _columns(out):
+    """a pixel's four id words are judged one by one (the emissive word may be under a switch where the primitive is not)"""
+    flat = {}
+    for key, value in out.items():
+        if key == "ids":
+            for c, word in enumerate("xyzw"):
+                flat["ids." + word] = value[:, c]
+        elif key == "bitmap":
+            flat[key] = np.asarray(value).reshape(-1, 3)
+        elif key != "features":
+            flat[key] = value
+    return flat
+
+
+# engine against the REFERENCE where no dialect statement shows: bit for bit, but for the two outputs the library pow of
+# the Blinn term reaches (RayTracer.cl:1761 - OCML's, within 2 ULP of glibc's; the engine rounds a binary64 pow once)
+POW_ULPS = {"total_blinn": 4, "color": 3}
+COVERAGE = {}
+
+
+def _held_to_the_reference(probes, name, label, case, out, ref, cuda, cl):
+    """the switch-observability mask: per output, the elements on which the oracle's two dialects agree; engine ==
+    reference there.  Returns {output: (covered fraction, elements)}"""
+    mine, theirs, a, b = _columns(out), _columns(ref), _columns(cuda), _columns(cl)
+    covered = {}
+    # what a test or a walk leaves in its outputs on a miss is nobody's business (in/out locals of the caller)
+    found = None
+    if case["name"] in ("primitive", "closest"):
+        found = (mine["hit"] != 0) & (theirs["hit"] != 0)
+        if "primitive" in mine:
+            found &= mine["primitive"] == theirs["primitive"]
+    for key in a:
+        if key not in mine or key not in theirs:
+            continue
+        agree = _rows_equal(probes, a[key], b[key])
+        if found is not None and key not in ("hit", "primitive"):
+            agree &= found
+        what = "%s (%s) %s vs the reference where the dialects agree" % (name, label, key)
+        if key in POW_ULPS and case["name"] in ("shader", "launch"):
+            # (two library pows differ in the last bit on some 9 % of the arguments; a pixel's colour keeps that on < 3 %)
+            u = ulp_distance(mine[key], theirs[key]).reshape(len(agree), -1).max(axis=1)
+            assert (u[agree] <= POW_ULPS[key]).all(), (what, int(u[agree].max()))
+            if key == "color" and agree.any():
+                assert (u[agree] > 0).mean() <= 0.03, (what, float((u[agree] > 0).mean()))
+        else:
+            _all_equal(probes, what, mine[key], theirs[key], agree)
+        covered[key] = (float(agree.mean()), int(agree.sum()))
+    COVERAGE.setdefault(name, covered)
+    return covered
 
 
 def _all_equal(probes, what, mine, theirs, where=None):
@@ -79,7 +150,7 @@ def _all_equal(probes, what, mine, theirs, where=None):
 
 
 def _variants(case):
-    if case["name"] in ("closest", "shadow"):
+    if case["name"] in ("closest", "shadow", "shader", "launch"):
         return [("the renderer's instantiation, walk-order + order-free lists", 0, 0),
                 ("the renderer's instantiation, the reference's own list", 0, 1),
                 ("all-features instantiation", E.EVERYTHING, 0)]
@@ -92,12 +163,17 @@ def _variants(case):
 @pytest.mark.parametrize("name", _names())
 def test_engine_functions_reproduce_the_reference_functions(solr, probes, oracle, fixture, name):
     case, ref = _load(probes, fixture, name)
-    cuda = probes._oracle_outputs(oracle.lib(), case)            # the oracle's CUDA dialect: only where a switch applies
+    if "renderer" in ref or not ref:                            # the post-processing kernels ran as they are
+        ref = {k.split("/")[2]: fixture[k] for k in fixture.files if k.startswith(name + "/renderer/")}
+    cuda, cl = probes.both_dialects(case)                        # the oracle's CUDA dialect: only where a switch applies
     assert oracle.lib().oracle_get_dialect() == 0
     kind = case["name"]
     for label, features, exact in _variants(case):
         out = E.engine_outputs(solr, case, features=features, exact=exact)
         what = "%s (%s)" % (name, label)
+        covered = _held_to_the_reference(probes, name, label, case, out, ref, cuda, cl)
+        print("%-28s %-62s held to the reference's output on: %s" % (
+            name, label, ", ".join("%s %.3f" % (k, v[0]) for k, v in covered.items())))
         if kind == "box":
             no_zero = (case["directions"] != 0).all(axis=1)
             near0 = case["t0"] == 0
@@ -148,12 +224,39 @@ def test_engine_functions_reproduce_the_reference_functions(solr, probes, oracle
                 _all_equal(probes, what + " %s vs the CUDA dialect" % key, out[key], cuda[key],
                            None if key == "hit" else (out["hit"] != 0) & (cuda["hit"] != 0))
         elif kind == "shadow":
-            # three switches in this one function: the CUDA dialect is what there is to compare with.  (The reference's
-            # probe leaves out the lamp only; so does this call: engine_probes passes an index nobody has.)
-            nobody_cuda = cuda
-            _all_equal(probes, what + " result vs the CUDA dialect", out["result"], nobody_cuda["result"])
-            _all_equal(probes, what + " colour vs the CUDA dialect", out["color"], nobody_cuda["color"])
-            assert 0.05 < (out["result"] > 0).mean() < 0.95
+            # three switches in this one function: the CUDA dialect everywhere, the reference where they do not show
+            # (_held_to_the_reference above).  The reference's probe leaves out the lamp only; so does this call, except
+            # in the moot cases, which name the shaded primitive and are probed the way the renderer calls the walk.
+            _all_equal(probes, what + " result vs the CUDA dialect", out["result"], cuda["result"])
+            _all_equal(probes, what + " colour vs the CUDA dialect", out["color"], cuda["color"])
+            assert 0.02 < (out["result"] > 0).mean() < 0.95
+            assert covered["result"][0] > 0.8 and covered["color"][0] > 0.85
+            if "shaded" in case:
+                assert covered["result"][0] == 1.0 and covered["color"][0] == 1.0, covered
+        elif kind == "shader":
+            # engine == the oracle's CUDA dialect on every element: bit for bit, but for the Blinn sum (the oracle as
+            # pinned takes glibc's powf, within 1 ULP of the power; the engine the power rounded once)
+            for key in ("returned", "shadow", "normal", "closest_color", "attributes"):
+                _all_equal(probes, what + " %s vs the CUDA dialect" % key, out[key], cuda[key])
+            u = ulp_distance(out["total_blinn"], cuda["total_blinn"]).max(axis=1)
+            assert u.max() <= 2 and (u > 0).mean() <= 0.02, (what, int(u.max()), float((u > 0).mean()))
+            assert (out["total_blinn"] > 0).any()
+            if case["si"].graphicsLevel > 3 and "triangles" not in name:
+                assert (out["shadow"] > 0).mean() > 0.02           # shadow rays were traced and met occluders
+            if name.endswith("_moot"):
+                assert all(v[0] == 1.0 for v in covered.values()), covered
+        elif kind == "launch":
+            # the frame as k_standardRenderer renders it against the oracle's CUDA dialect: the bar of every parity test
+            assert np.array_equal(out["ids"], cuda["ids"]), what
+            _all_equal(probes, what + " depth vs the CUDA dialect", out["depth"], cuda["depth"])
+            u = ulp_distance(out["color"], cuda["color"]).max(axis=1)
+            assert u.max() <= 2 and (u > 1).sum() <= 2, (what, int(u.max()), int((u > 1).sum()))
+            assert (out["ids"][:, 0] >= 0).mean() > 0.2
+        elif kind == "post":
+            _all_equal(probes, what + " bitmap vs the CUDA dialect", out["bitmap"].reshape(-1, 3), cuda["bitmap"].reshape(-1, 3))
+            if case["ppi"].type == 0 or name.endswith("_moot"):
+                # k_default is under no switch; nor is k_depthOfField once the random buffer repeats every 900 values
+                assert covered["bitmap"][0] == 1.0, covered
         elif kind == "intersection_shader":
             sphere = case["prims"]["type"] == ptSphere
             for key in ("color", "bump", "advanced", "attributes"):
@@ -165,6 +268,20 @@ def test_engine_functions_reproduce_the_reference_functions(solr, probes, oracle
             for key, value in out.items():
                 if key != "features":
                     _all_equal(probes, what + " " + key, value, ref[key])
+
+
+@pytest.mark.gpu
+def test_coverage_of_the_reference_pin_per_function(solr, probes, oracle, fixture):
+    """(runs after the cases above) DESIGN.md section 2.4's table: per function, the fraction of the fixture's elements
+    on which the engine was held to the reference's own output directly"""
+    if not COVERAGE:
+        pytest.skip("the cases did not run in this session")
+    for name, covered in COVERAGE.items():
+        print("%-30s %s" % (name, ", ".join("%s %.1f %% of %d" % (k, 100 * v[0], round(v[1] / max(v[0], 1e-9)))
+                                            for k, v in covered.items())))
+    for name in ("shadow_cornell_opaque_moot", "shader_cornell_opaque_moot"):
+        if name in COVERAGE:
+            assert all(v[0] == 1.0 for v in COVERAGE[name].values())
 
 
 @pytest.mark.gpu
@@ -184,6 +301,6 @@ def test_the_probe_entry_points_are_exported(solr):
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "solr_hip_probes.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = sorted(set(re.findall(r"\b(solr_hip_probe_\w+)\s*\(", text)))
-    assert len(names) == 9
+    assert len(names) == 13
     hip = solr.hip_lib()
     assert all(hasattr(hip, n) for n in names), [n for n in names if not hasattr(hip, n)]

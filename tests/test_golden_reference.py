@@ -1,4 +1,11 @@
-"""The oracle against golden frames rendered by THE REFERENCE'S OWN renderer - runs on CPU.
+"""A SMOKE ALARM, NOT THE PIN: the oracle against golden frames rendered by THE REFERENCE'S OWN renderer - runs on CPU.
+
+What pins the oracle to reference output is tests/test_reference_probes.py (the reference's own functions over
+arrays of inputs, bit for bit; tests/golden/reference_probes.npz), and what holds the ENGINE to reference output is
+tests/test_engine_probes_gpu.py.  This file only compares whole frames of the reference's renderer AS BUILT - fused
+dot products, approximate reciprocal square roots, the OpenCL engine's own statements where the two engines differ -
+with the oracle's CUDA dialect, statistically (the fractions below): it would notice an oracle or a builder that went
+badly wrong, and nothing finer.
 
 tests/golden/reference_*.npz hold the outputs of the reference's OpenCL k_standardRenderer + k_default
 (compiled for gfx950 from the reference tree, run on an MI355X by tests/golden/make_reference_fixtures.py)

@@ -1,16 +1,20 @@
-"""GPU parity tests: the HIP path (host mirror -> C-ABI -> kernels) against the CPU oracle on the
+"""GPU parity tests: the HIP path (host mirror -> C-ABI -> kernels) against the CPU oracle AS PINNED on the
 same flattened scene.  The bar (BASELINE.json north_star): primitive ids exact, RGB8 exact, float
-colour channels <= 1 ULP.  Where a frame evaluates libm transcendentals whose binary32 results the
-GPU reproduces through binary64 (pow in every lit pixel; sin/cos of procedural spheres; atan2/asin of
-sphere and skybox UVs) a 1-ULP colour difference may move an RGB8 value by one, and for UV lookups
-may select the neighbouring texel; those tests say so explicitly."""
+colour channels <= 1 ULP.  The oracle's transcendentals are libm's binary32 routines (what the reference's host
+build calls); the engine evaluates them in binary64 and rounds once.  libm's results are within an ULP of that but
+not always equal to it: where a frame depends on more than pow (sin / cos of procedural spheres; atan2 / asin of
+sphere and skybox UVs) the comparison is helpers.assert_frame_pinned - every pixel at the bar except a COUNTED
+handful, each of which the oracle itself marks as having gone through a libm result that is not the correctly rounded
+value (oracle_set_misround_mask); a pixel outside the bar without that mark fails.  No test here switches the oracle
+to the engine's transcendentals."""
 import importlib
 
 import numpy as np
 import pytest
 
 import scenes_extra as X
-from helpers import assert_parity, assert_pass_parity, compare_frames, device_frame, gpu_frame, oracle_frame
+from helpers import (assert_frame_pinned, assert_parity, assert_pass_parity, compare_frames, device_frame, gpu_frame,
+                     oracle_frame)
 
 pytestmark = pytest.mark.gpu
 solr_mod = importlib.import_module("sol-r_amd")
@@ -39,32 +43,20 @@ def test_image_sizes_that_do_not_fill_the_8x8_tiles(solr, oracle, size):
     assert_parity(res)
 
 
-@pytest.fixture
-def rounded_transcendentals(oracle):
-    """the oracle evaluates powf / sinf / cosf / atan2f / asinf in binary64 and rounds once, as the engine does
-    (libm's binary32 routines are specified to an error bound only and differ from that in a few results per
-    frame): frames that depend on them compare exactly"""
-    lib = oracle.lib()
-    lib.oracle_set_rounded_transcendentals(1)
-    yield
-    lib.oracle_set_rounded_transcendentals(0)
+# pixels of the 96 x 64 every-primitive frame that may lie outside the bar, each marked by the oracle: the procedural
+# sphere's surface is displaced by cos / sin of the hit point (GI:235-246), a sinf / cosf result one ULP off moves the
+# normal and the bounce ray by an ULP - the colour by a few ULP, RGB8 by at most two steps.  Measured: 9.
+PROCEDURAL_EXCEPTIONS = 12
 
 
-def test_every_primitive_type(solr, oracle, rounded_transcendentals):
-    # procedural sphere: cos / sin of the hit point move its centre
-    k, res, _ = both(solr, oracle, X.primitives_mix)
+def test_every_primitive_type(solr, oracle):
+    k = solr.Kernel(engine="hip")
+    X.primitives_mix(k)
+    frame = gpu_frame(k)
+    res = assert_frame_pinned(k, oracle, frame, PROCEDURAL_EXCEPTIONS, "every primitive type", marked_bounds=(None, 2))
     k.finalize()
     print(res)
-    assert_parity(res)
-    assert res["depth_max_ulp"] == 0
-
-
-def test_every_primitive_type_with_libm_binary32_trigonometry(solr, oracle):
-    # the same frame against glibc's sinf / cosf: a handful of pixels on the procedural sphere's surface may differ
-    k, res, _ = both(solr, oracle, X.primitives_mix)
-    k.finalize()
-    assert res["pixels_over_1ulp"] <= 12 and res["rgb_max_diff"] <= 2, res
-    assert res["depth_max_ulp"] == 0
+    assert res["depth_max_ulp"] == 0 and res["pixels_with_a_misrounded_libm_result"] > 0
 
 
 def test_every_primitive_type_without_the_procedural_sphere(solr, oracle):
@@ -125,29 +117,21 @@ def test_scene_info_modes(solr, oracle, info):
     assert_parity(compare_frames(pp, ids, rgb, opp, oids, orgb))
 
 
-def test_textures(solr, oracle, rounded_transcendentals):
-    # sphere and skybox UVs use atan2 / asin: evaluated the same way on both sides, every texel is the same one
-    k, res, _ = both(solr, oracle, X.textured)
+# pixels of the 96 x 64 textured frame that may show the neighbouring texel (helpers.assert_parity_pinned, marked_bounds):
+# sphere and skybox UVs are atan2 / asin of the hit point, and glibc's atan2f / asinf land on the other side of a texel
+# boundary on a few pixels of a frame.  Measured: 5 with the textured skybox, 2 without.
+TEXEL_EXCEPTIONS = 8
+
+
+@pytest.mark.parametrize("skybox", [True, False], ids=["with-skybox", "without-skybox"])
+def test_textures(solr, oracle, skybox):
+    k = solr.Kernel(engine="hip")
+    X.textured(k, skybox=skybox)
+    frame = gpu_frame(k)
+    res = assert_frame_pinned(k, oracle, frame, TEXEL_EXCEPTIONS, "textured scene", marked_bounds=(None, None))
     k.finalize()
     print(res)
     assert res["ids_all_equal"] and res["depth_max_ulp"] == 0
-    assert_parity(res)
-
-
-def test_textures_with_libm_binary32_trigonometry(solr, oracle):
-    # against glibc's atan2f / asinf a 1-ULP difference can select the neighbouring texel
-    k, res, _ = both(solr, oracle, X.textured)
-    k.finalize()
-    assert res["ids_all_equal"] and res["depth_max_ulp"] == 0
-    assert res["pixels_over_1ulp"] <= 8, res
-
-
-def test_textures_without_sphere_uv(solr, oracle, rounded_transcendentals):
-    k, res, _ = both(solr, oracle, X.textured, skybox=False)
-    k.finalize()
-    print(res)
-    assert res["ids_all_equal"] and res["depth_max_ulp"] == 0
-    assert_parity(res)
 
 
 def progressive(solr, oracle, build, passes, **info):
@@ -660,13 +644,10 @@ def test_short_paths_of_plain_primitives_change_nothing(solr, oracle, scene):
                 build(k)
             pp, ids, rgb = gpu_frame(k)
             if not no_kinds:
-                opp, oids, orgb, _, status = oracle_frame(k, oracle)
-                assert status == 0
-                res = compare_frames(pp, ids, rgb, opp, oids, orgb)
                 if scene == "cornell":
-                    assert_parity(res)
+                    assert_frame_pinned(k, oracle, (pp, ids, rgb), 2, scene)
                 else:   # libm's binary32 sinf / cosf on the procedural sphere: test_every_primitive_type
-                    assert res["pixels_over_1ulp"] <= 12 and res["rgb_max_diff"] <= 2, res
+                    assert_frame_pinned(k, oracle, (pp, ids, rgb), PROCEDURAL_EXCEPTIONS, scene, marked_bounds=(None, 2))
             frames.append((np.array(pp, copy=True), np.array(ids, copy=True), np.array(rgb, copy=True)))
             k.finalize()
         finally:

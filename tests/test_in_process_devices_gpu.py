@@ -16,9 +16,20 @@ import os
 import numpy as np
 import pytest
 
-os.environ.setdefault("SOLR_HIP_VIRTUAL_DEVICES", "4")
-
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def four_virtual_devices():
+    """SOLR_HIP_VIRTUAL_DEVICES for THIS module's tests only (the library reads it at every initialize_scene): set at
+    import it used to reach every test of the session and every subprocess they start"""
+    before = os.environ.get("SOLR_HIP_VIRTUAL_DEVICES")
+    os.environ["SOLR_HIP_VIRTUAL_DEVICES"] = "4"
+    yield
+    if before is None:
+        os.environ.pop("SOLR_HIP_VIRTUAL_DEVICES", None)
+    else:
+        os.environ["SOLR_HIP_VIRTUAL_DEVICES"] = before
 W, H = 200, 148          # 148 rows: not a multiple of 3 devices, nor of the 8-pixel tiles within a strip
 
 
@@ -167,6 +178,63 @@ def test_a_stale_ticket_is_an_error_not_another_frames_image(solr):
         assert hip.solr_hip_d2h_image_async() >= 0
         assert not hip.solr_hip_image_wait(keep)
         hip.solr_hip_clear_error()
+    finally:
+        hip.solr_hip_clear_error()
+        k.finalize()
+
+
+# ---- ADVICE.md, round 4 -----------------------------------------------------------------------------------------
+def test_tickets_stay_positive_across_two_to_the_thirty_one_frames(solr):
+    """a ticket used to be (int)(serial * 6 + slot): negative - read as an error code - after 2^31 / 6 frames, 27 hours
+    at the one-GPU rate, under four at the eight-rank rate.  The engine's serial counter is put 40 frames before that
+    point and 100 frames are delivered across it, two in flight: every ticket positive, no two live ones alike, every
+    image the frame's, a stale one still refused"""
+    import engine_probes as E
+    hip = solr.hip_lib()
+    E.declare(hip)
+    hip.solr_hip_image_wait.restype = C.c_void_p
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=1)
+    try:
+        expected = k.render().copy()
+        hip.solr_hip_probe_image_serial(C.c_longlong((1 << 31) // 6 - 40))
+        tickets, seen = [], []
+        for i in range(100):
+            k.render()
+            t = hip.solr_hip_d2h_image_async()
+            assert 0 <= t < (1 << 31), (i, t)
+            tickets.append(t)
+            if len(tickets) >= 3:
+                ptr = hip.solr_hip_image_wait(tickets[-3])
+                assert ptr, (i, _error(hip))
+                image = np.ctypeslib.as_array((C.c_ubyte * (W * H * 3)).from_address(ptr)).reshape(H, W, 3)
+                assert np.array_equal(image, expected), i
+                seen.append(tickets[-3])
+        assert len(set(tickets)) == 100
+        assert hip.solr_hip_probe_image_serial(C.c_longlong(-1)) == (1 << 31) // 6 + 60
+        assert not hip.solr_hip_image_wait(tickets[10])                 # long handed out again: refused
+        hip.solr_hip_clear_error()
+        k.check(0, "frames across the old limit")
+    finally:
+        hip.solr_hip_clear_error()
+        k.finalize()
+
+
+def test_a_changed_device_count_after_initialize_scene_is_noted_not_fatal(solr):
+    """the reference reads occupancyParameters.x in every call; a host that hands initialize_scene 2 and a later call 1
+    still gets its frames (it used to get a sticky error and no frame at all)"""
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=2)
+    try:
+        reference = _frame(k)
+        assert k.set_gpu_count(2) == 2
+        _same(_frame(k), reference, "two devices")
+        flat = k.flat_scene()
+        one = C.c_uint64(1 | (1 << 32))                                # vec2i {1, 1} by value
+        hip.h2d_randoms(one, C.c_void_p(flat.randoms.ctypes.data))     # occupancyParameters.x = 1, not the 2 of the set-up
+        k.check(0, "a call with another device count")
+        _same(_frame(k), reference, "after the call with another count")
     finally:
         hip.solr_hip_clear_error()
         k.finalize()
