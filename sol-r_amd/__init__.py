@@ -102,7 +102,9 @@ PP_DTYPE = np.dtype({"names": ["colorInfo", "sceneInfo"], "formats": [(f4, 4), (
 
 def build(verbose=False):
     """Compile both native libraries for gfx950 (hipcc cross-compiles without a GPU)."""
-    res = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    # (the renderer's instantiations are one object per row of the launch table: built side by side)
+    jobs = str(max(1, min(8, len(os.sched_getaffinity(0)))))
+    res = subprocess.run(["make", "-C", _HERE, "-j", jobs, "all"], capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])

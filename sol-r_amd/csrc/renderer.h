@@ -1,0 +1,94 @@
+/*
+ * renderer.h - what the host side of the engine (solr_hip.hip) and the translation units that hold the renderer's
+ * instantiations (the files under csrc/rows) share: the frame's arguments, the kernel's signature, and one look-up per row of
+ * renderImpl's table.  The kernel template itself is renderer_kernel.h, included by the row files only - so that an
+ * experiment on one instantiation rebuilds one object (make -j: eight objects side by side instead of one 70-second
+ * translation unit).  gfx950 only.
+ */
+#ifndef SOLR_RENDERER_H
+#define SOLR_RENDERER_H
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/solr_hip.h"
+#include "rt_device.h"
+
+using namespace solrdev;
+
+struct FrameArgs
+{
+    SceneInfo si;
+    PostProcessingInfo ppi;
+    float ox, oy, oz;     /* camera position */
+    float dx, dy, dz;     /* camera look-at */
+    float ax, ay, az, aw; /* camera angles, w = field scale */
+    Trig trig;            /* cos/sin of the angles, evaluated on the host */
+    float stepx, stepy;   /* the pixel pitch of the perspective cameras (CRT:490-492): the same three binary32 operations, once */
+    int firstRow;         /* first image row of this process's strip */
+    int nbRows;           /* rows in the strip */
+    int tilesX;
+    unsigned tileMagic;   /* tile / tilesX = (tile * tileMagic) >> (32 + tileShift) for every tile of the frame (checked on the host) */
+    int tileShift;
+    int fuseDefault;      /* 1: write the RGB bitmap from the renderer */
+    int stackSlots;       /* colour-stack slots per lane in LDS */
+    float focusDepth;     /* ctVR: depth of the focus pixel before this frame (k_3DVisionRenderer) */
+    unsigned long long *tileClock; /* diagnostics: {start, end} of every tile in 100 MHz ticks, or null */
+    /* cost-ordered launch (see TileScheduling below); all null when off */
+    unsigned *tileCost;        /* out: duration of every tile of this frame, 100 MHz ticks */
+    const unsigned *tileOrder; /* in: workgroup -> order entry (see ORDER_* below), most expensive tiles first */
+    int nbTiles;               /* tiles of the frame; the ordered launch has 3 * SPLIT_TILES_MAX workgroups more */
+};
+
+/* An entry of the launch order: the tile in bits 0-27, and in bits 28-30 which part of it this wave renders -
+ * 0 the whole 8 x 8 tile, 1-4 one of its 4 x 4 quadrants (the few most expensive tiles are rendered by four
+ * waves, see k_orderTiles).  ORDER_NOTHING pads the list to its fixed length. */
+#define ORDER_TILE_MASK 0x03ffffffu
+#define ORDER_PART_SHIFT 26
+/* a split tile is rendered by (2^SOLR_SPLIT_LOG2)^2 waves: 1 = four 4 x 4 quadrants, 2 = sixteen 2 x 2 blocks (experiments) */
+#ifndef SOLR_SPLIT_LOG2
+#define SOLR_SPLIT_LOG2 1
+#endif
+#define SPLIT_PARTS (1 << (2 * SOLR_SPLIT_LOG2))
+#define ORDER_NOTHING 0xffffffffu
+#define SOLR_TIMING_SLOTS (160000ul) /* timing build: workgroups of the largest frame it is used on (3840 x 2160 + split tiles) */
+#define SPLIT_TILES_MAX 256
+
+#define TILE 8
+#define WAVE 64
+
+/* device view of PostProcessingBuffer (same 32-byte layout, HIP vector types) */
+struct PixelRecord
+{
+    float4 colorInfo;
+    float4 sceneInfo;
+};
+static_assert(sizeof(PixelRecord) == sizeof(PostProcessingBuffer), "PixelRecord layout");
+
+
+/* the renderer kernel and the replay of its walks (renderer_kernel.h), as the host launches them */
+typedef void (*RendererFn)(const SceneArgs, const FrameArgs, PixelRecord *, int4 *, unsigned char *, unsigned long long *);
+typedef void (*WalkBoundFn)(const SceneArgs, const char *, unsigned *, unsigned *);
+
+namespace solrrows
+{
+/* k_standardRenderer<count, features, volume>, or null when no row file instantiates it.  count: 0 a frame, 1 the ray
+ * census, 2 a frame that records its walks (the four lean rows only).  features: enum Feature of rt_device.h, with
+ * F_DEEP where the three-bank node loop is wanted. */
+RendererFn renderer(int count, int features, bool volume);
+/* k_walkBound<features> of lean row `row` of renderImpl's table (0 ... 3), or null */
+WalkBoundFn walkBound(int row, int features);
+/* one look-up per row file (each returns null for what it does not hold) */
+RendererFn spherePlane(int count, int features);
+RendererFn sphereTriangle(int count, int features);
+RendererFn sphereCylinder(int count, int features);
+RendererFn untexturedMix(int count, int features);
+RendererFn textured(int count, int features);
+RendererFn specialCameras(int count, int features);
+RendererFn everything(int count, int features, bool volume);
+WalkBoundFn walkBoundRow0(int features);
+WalkBoundFn walkBoundRow1(int features);
+WalkBoundFn walkBoundRow2(int features);
+WalkBoundFn walkBoundRow3(int features);
+} // namespace solrrows
+
+#endif

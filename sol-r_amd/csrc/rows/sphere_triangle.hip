@@ -1,0 +1,29 @@
+/*
+ * rows/sphere_triangle.hip - the lean kernel of spheres + triangles (meshes)
+ * (one object per row of renderImpl's table: see renderer.h).  gfx950 only.
+ */
+#include "../renderer_kernel.h"
+
+namespace solrrows
+{
+RendererFn sphereTriangle(int count, int features)
+{
+    if ((features & ~F_DEEP) != (F_SPHERE | F_TRI))
+        return nullptr;
+    const bool deep = (features & F_DEEP) != 0;
+    if (count == 0)
+        return deep ? k_standardRenderer<0, (F_SPHERE | F_TRI) | F_DEEP> : k_standardRenderer<0, (F_SPHERE | F_TRI)>;
+    if (count == 2)
+        return deep ? k_standardRenderer<2, (F_SPHERE | F_TRI) | F_DEEP> : k_standardRenderer<2, (F_SPHERE | F_TRI)>;
+    return nullptr;
+}
+
+/* (each lean row file answers for its own row; the others return null) */
+WalkBoundFn walkBoundRow1(int features)
+{
+    const int row = 1;
+    if (row == 1)
+        return (features & F_DEEP) ? k_walkBound<(F_SPHERE | F_TRI) | F_DEEP> : k_walkBound<(F_SPHERE | F_TRI)>;
+    return nullptr;
+}
+} // namespace solrrows

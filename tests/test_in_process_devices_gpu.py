@@ -143,11 +143,14 @@ def test_more_devices_than_there_are_and_what_does_not_combine(solr, capfd):
         code, text = _error(hip)
         assert code == -1 and "communicator" in text
         hip.solr_hip_clear_error()
-        # the other nine calls must be given what initialize_scene was given (or nothing: values below 1)
-        hip.h2d_randoms(C.c_uint64(2), np.zeros(1920 * 1080, np.float32).ctypes.data)
+        # one of the other nine calls with another count than initialize_scene's (the reference reads the count in
+        # every call): noted once on stderr, served by the devices that were set up - not a sticky error
+        capfd.readouterr()
+        flat = k.flat_scene()
+        hip.h2d_randoms(C.c_uint64(2), flat.randoms.ctypes.data)
         code, text = _error(hip)
-        assert code == -1 and "not what initialize_scene was given" in text
-        hip.solr_hip_clear_error()
+        assert code == 0, text
+        assert "noted once" in capfd.readouterr().err
         _same(_frame(k), reference, "after the refusals")
         k.check(0, "refusals")
     finally:
