@@ -31,6 +31,8 @@ struct FrameArgs
     int tileShift;
     int fuseDefault;      /* 1: write the RGB bitmap from the renderer */
     int stackSlots;       /* colour-stack slots per lane in LDS */
+    float4 *deepStack;    /* F_STACK instantiations: the slots beyond them, [slot - stackSlots][pixel of the strip] */
+    long deepStride;      /* float4s between two slots of a pixel = pixels of the strip */
     float focusDepth;     /* ctVR: depth of the focus pixel before this frame (k_3DVisionRenderer) */
     unsigned long long *tileClock; /* diagnostics: {start, end} of every tile in 100 MHz ticks, or null */
     /* cost-ordered launch (see TileScheduling below); all null when off */

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
     cs.base = ldsStack + lane;
     cs.stride = WAVE;
     cs.cold = 4 * F.stackSlots;
+    cs.ldsSlots = F.stackSlots;
+    cs.deep = (FEAT & F_STACK) ? F.deepStack + index0 : nullptr;
+    cs.deepStride = F.deepStride;
 
     Counters cnt = {};
     if (COUNT == 2) /* a frame whose walks are recorded (rt_device.h recordWalk): `counters` is the record buffer */

@@ -8,9 +8,13 @@ namespace solrrows
 {
 RendererFn sphereCylinder(int count, int features)
 {
-    if ((features & ~F_DEEP) != (F_SPHERE | F_CYL))
+    if ((features & ~(F_DEEP | F_STACK)) != (F_SPHERE | F_CYL))
         return nullptr;
     const bool deep = (features & F_DEEP) != 0;
+    if (count == 0 && (features & F_STACK)) /* a frame that may bounce deeper than the LDS stack holds */
+        return deep ? k_standardRenderer<0, (F_SPHERE | F_CYL) | F_DEEP | F_STACK> : k_standardRenderer<0, (F_SPHERE | F_CYL) | F_STACK>;
+    if (features & F_STACK)
+        return nullptr;
     if (count == 0)
         return deep ? k_standardRenderer<0, (F_SPHERE | F_CYL) | F_DEEP> : k_standardRenderer<0, (F_SPHERE | F_CYL)>;
     if (count == 2)

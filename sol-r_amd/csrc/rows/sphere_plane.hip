@@ -8,9 +8,13 @@ namespace solrrows
 {
 RendererFn spherePlane(int count, int features)
 {
-    if ((features & ~F_DEEP) != (F_SPHERE | F_PLANE))
+    if ((features & ~(F_DEEP | F_STACK)) != (F_SPHERE | F_PLANE))
         return nullptr;
     const bool deep = (features & F_DEEP) != 0;
+    if (count == 0 && (features & F_STACK)) /* a frame that may bounce deeper than the LDS stack holds */
+        return deep ? k_standardRenderer<0, (F_SPHERE | F_PLANE) | F_DEEP | F_STACK> : k_standardRenderer<0, (F_SPHERE | F_PLANE) | F_STACK>;
+    if (features & F_STACK)
+        return nullptr;
     if (count == 0)
         return deep ? k_standardRenderer<0, (F_SPHERE | F_PLANE) | F_DEEP> : k_standardRenderer<0, (F_SPHERE | F_PLANE)>;
     if (count == 2)

@@ -576,8 +576,15 @@ enum Feature
     F_TEX = 64,     /* textured materials, ptCamera planes, textured skybox */
     F_FULL = 128,   /* global illumination + box-debug view */
     F_ALL = 255,
-    F_DEEP = 256    /* not a feature of the scene but of its node list: walk it with the three-bank loop (advanceTidy) */
+    F_DEEP = 256,   /* not a feature of the scene but of its node list: walk it with the three-bank loop (advanceTidy) */
+    F_STACK = 512   /* nor of the scene but of the frame: more bounces than colour-stack slots are kept in LDS
+                     * (SOLR_LDS_STACK_SLOTS) - the deeper slots live in a per-pixel buffer in HBM (ColorStack) */
 };
+/* Colour-stack slots (4 dwords each) a lane keeps in LDS.  With the 27-dword cold record that is 39 dwords per lane: what
+ * 16 waves per CU - 4 per SIMD, the kernel's register budget - leave each lane of the 160 KB.  A frame that may bounce
+ * deeper (the accumulation passes: up to NB_MAX_ITERATIONS = 10) used to size the LDS stack for it - 67 dwords, 9 waves
+ * per CU - although hardly a ray goes that deep. */
+#define SOLR_LDS_STACK_SLOTS 3
 
 struct Hit
 {
@@ -2462,6 +2469,11 @@ struct ColorStack
     float *base;  /* &lds[lane] */
     int stride;   /* floats between consecutive (slot, component) cells = block size */
     int cold;     /* first cell of the cold record = 4 * stack slots */
+    /* F_STACK instantiations: slots ldsSlots, ldsSlots + 1 ... of this lane's pixel, one float4 each, `deepStride`
+     * float4s apart (a plane of the strip per slot: the 8 pixels of a tile row are 128 contiguous bytes) */
+    float4 *deep;
+    long deepStride;
+    int ldsSlots;
     SOLR_DEV float &coldf(int field) const { return base[(cold + field) * stride]; }
     SOLR_DEV int &coldi(int field) const { return *(int *)&base[(cold + field) * stride]; }
     SOLR_DEV float &at(int slot, int c) const { return base[(slot * 4 + c) * stride]; }
@@ -2472,6 +2484,42 @@ struct ColorStack
         at(slot, 2) = v.z;
     }
     SOLR_DEV v3 get(int slot) const { return V(at(slot, 0), at(slot, 1), at(slot, 2)); }
+    /* the same three with a slot that may lie beyond the LDS ones (SP: an F_STACK instantiation; otherwise the code
+     * above, unchanged).  A lane only ever reads back what it wrote itself: program order is all that is needed. */
+    template <bool SP>
+    SOLR_DEV void put(int slot, v3 v, float k) const
+    {
+        if (SP && slot >= ldsSlots)
+            deep[(long)(slot - ldsSlots) * deepStride] = make_float4(v.x, v.y, v.z, k);
+        else
+        {
+            set(slot, v);
+            at(slot, 3) = k;
+        }
+    }
+    template <bool SP>
+    SOLR_DEV float4 take(int slot) const
+    {
+        if (SP && slot >= ldsSlots)
+            return deep[(long)(slot - ldsSlots) * deepStride];
+        return make_float4(at(slot, 0), at(slot, 1), at(slot, 2), at(slot, 3));
+    }
+    template <bool SP>
+    SOLR_DEV void add(int slot, v3 d) const
+    {
+        if (SP && slot >= ldsSlots)
+        {
+            float4 &cell = deep[(long)(slot - ldsSlots) * deepStride];
+            const float4 was = cell;
+            cell = make_float4(was.x + d.x, was.y + d.y, was.z + d.z, was.w);
+        }
+        else
+        {
+            at(slot, 0) += d.x;
+            at(slot, 1) += d.y;
+            at(slot, 2) += d.z;
+        }
+    }
 };
 
 /* three consecutive cold fields used like a v3 */
@@ -2526,8 +2574,14 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
     currentMaxIteration = (currentMaxIteration > NB_MAX_ITERATIONS) ? NB_MAX_ITERATIONS : currentMaxIteration;
 
     /* slots 0 .. currentMaxIteration-1 are the ones ever written or read (the reference's array
-     * has one more, CRT:92) */
-    for (int s = 0; s < (currentMaxIteration > 1 ? currentMaxIteration : 1); ++s)
+     * has one more, CRT:92).  (The slots beyond the LDS ones of an F_STACK frame need no zero: every slot below a lane's
+     * `lastIteration` is written by the trip that made it - hit or background - before the deferred reflection adds to
+     * it and the blend reads it; only slot 0 can be read unwritten, by a lane that never ran.) */
+    constexpr bool SP = (FEAT & F_STACK) != 0;
+    int zeroSlots = currentMaxIteration > 1 ? currentMaxIteration : 1;
+    if (SP && zeroSlots > cs.ldsSlots)
+        zeroSlots = cs.ldsSlots;
+    for (int s = 0; s < zeroSlots; ++s)
     {
         cs.at(s, 0) = 0.f;
         cs.at(s, 1) = 0.f;
@@ -2750,8 +2804,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                     /* the reference keeps the previous bounce's reflectedTarget
                      * here; the ray it builds from it is never traced */
                 }
-                cs.set(iteration, colorIt);
-                cs.at(iteration, 3) = contribution;
+                cs.template put<SP>(iteration, colorIt, contribution);
 
                 rBlinn.x /= (float)(iteration + 1);
                 rBlinn.y /= (float)(iteration + 1);
@@ -2794,8 +2847,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
                 }
                 else
                     c = V(si.backgroundColor.x, si.backgroundColor.y, si.backgroundColor.z);
-                cs.set(iteration, c);
-                cs.at(iteration, 3) = 1.f;
+                cs.template put<SP>(iteration, c, 1.f);
             }
             if (running)
                 lastIteration = iteration + 1;
@@ -2805,9 +2857,7 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
         {
             if (hitLane)
             {
-                cs.at(reflectedRays, 0) += shaded.x * reflectedRatio;
-                cs.at(reflectedRays, 1) += shaded.y * reflectedRatio;
-                cs.at(reflectedRays, 2) += shaded.z * reflectedRatio;
+                cs.template add<SP>(reflectedRays, V(shaded.x * reflectedRatio, shaded.y * reflectedRatio, shaded.z * reflectedRatio));
                 idW = (int)(shadowIntensity * 255);
             }
             if (!giPass)
@@ -2833,17 +2883,25 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
         }
     }
 
+    int iterationsOut = 0;
     if (active)
     {
         const int iterations = lastIteration;
+        iterationsOut = iterations;
         if (test)
         {
-            /* back-to-front blend, CRT:382-386 */
-            v3 next = cs.get(iterations >= 1 ? iterations - 1 : 0);
+            /* back-to-front blend, CRT:382-386.  (The lane's column of the stack from the base as it is held here,
+             * through a value the compiler cannot trace back to the lane number: it would otherwise keep threadIdx.x
+             * alive through the whole trace - in scratch - just to form these addresses again.) */
+            ColorStack bs = cs;
+            asm volatile("" : "+v"(bs.base));
+            const float4 last = bs.template take<SP>(iterations >= 1 ? iterations - 1 : 0);
+            v3 next = V(last.x, last.y, last.z);
             for (int i = iterations - 2; i >= 0; --i)
             {
-                v3 ci = cs.get(i);
-                float k = cs.at(i, 3);
+                const float4 cell = bs.template take<SP>(i);
+                v3 ci = V(cell.x, cell.y, cell.z);
+                float k = cell.w;
                 next.x = ci.x * (1.f - k) + next.x * k;
                 next.y = ci.y * (1.f - k) + next.y * k;
                 next.z = ci.z * (1.f - k) + next.z * k;
@@ -2867,13 +2925,16 @@ SOLR_DEV v3 launchRayTracing(const Scene &S, bool active, int index, v3 rayO, v3
             intersectionColor.y = intersectionColor.y * b + si.backgroundColor.y * (1.f - b);
             intersectionColor.z = intersectionColor.z * b + si.backgroundColor.z * (1.f - b);
         }
-        primitiveXYId.y = iterations;
         intersectionColor.x -= colorBox.x;
         intersectionColor.y -= colorBox.y;
         intersectionColor.z -= colorBox.z;
     }
     depthOfField = dofCold;
+    /* all four words are written, whether the lane owns a pixel or not (the caller stores the ids of active lanes only):
+     * nothing of the record the caller came in with has to stay alive - in a register, in practice in scratch - through
+     * the whole trace */
     primitiveXYId.x = idX;
+    primitiveXYId.y = iterationsOut;
     primitiveXYId.z = idZ;
     primitiveXYId.w = idW;
     SOLR_T(cnt.tTrace += SOLR_NOW() - tTrace0;)

@@ -51,8 +51,8 @@ namespace solrrows
 {
 RendererFn renderer(int count, int features, bool volume)
 {
-    if (volume || (features & ~F_DEEP) == F_ALL)
-        return everything(count, features, volume);
+    if (volume || (features & ~(F_DEEP | F_STACK)) == F_ALL)
+        return (features & F_STACK) ? nullptr : everything(count, features, volume);
     RendererFn fn = nullptr;
     if (!(fn = spherePlane(count, features)) && !(fn = sphereTriangle(count, features)) && !(fn = sphereCylinder(count, features)) &&
         !(fn = untexturedMix(count, features)) && !(fn = textured(count, features)))
@@ -1148,6 +1148,7 @@ struct Engine
     /* every buffer set has a second RGB image ("side") for the time a copy still reads the first: a refinement or
      * accumulation pass stays on the set of the pass before it, and would otherwise wait for that pass's copy */
     DeviceBuffer bitmapAlt[MAX_FLIGHTS];
+    DeviceBuffer deepStack[MAX_FLIGHTS]; /* F_STACK frames: the colour-stack slots beyond the LDS ones, per buffer set */
     int bitmapSide[MAX_FLIGHTS] = {0, 0, 0, 0};
     int flightCopy[MAX_FLIGHTS][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}; /* slot whose copy reads that image, or -1 */
 
@@ -2167,7 +2168,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     }
     /* SOLR_HIP_LDS_PAD (bytes, experiments): more LDS per wave = fewer waves per SIMD; what occupancy is worth */
     static const size_t ldsPad = getenv("SOLR_HIP_LDS_PAD") ? (size_t)atol(getenv("SOLR_HIP_LDS_PAD")) : 0;
-    const size_t ldsBytes = ((size_t)F.stackSlots * 4 + COLD_FIELDS) * WAVE * sizeof(float) + ldsPad;
+    size_t ldsBytes = ((size_t)F.stackSlots * 4 + COLD_FIELDS) * WAVE * sizeof(float) + ldsPad;
 
     const dim3 grid(F.tilesX * tilesY), block(WAVE);
     if (g.tileClocks)
@@ -2303,6 +2304,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     const bool deepList = S.nbBoxes > 1024;
     const bool volumeCamera = sceneInfo.cameraType == ctVolumeRendering;
     KernelFn fn = solrrows::renderer(1, F_ALL, volumeCamera);
+    int deepSlots = 0; /* colour-stack slots of this frame kept in HBM (F_STACK) */
     if (!counting)
     {
         fn = solrrows::renderer(0, F_ALL | F_DEEP, volumeCamera);
@@ -2311,7 +2313,16 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         {
             if ((need & ~v.features) == 0 && g.variant != 4 && !volumeCamera)
             {
-                fn = solrrows::renderer(0, v.features | ((deepList || !v.bothLoops) ? F_DEEP : 0), false);
+                const int mask = v.features | ((deepList || !v.bothLoops) ? F_DEEP : 0);
+                fn = solrrows::renderer(0, mask, false);
+                /* more bounces than colour-stack slots fit the LDS of 16 waves per CU: the lean rows have an
+                 * instantiation that keeps the deeper slots in HBM (rt_device.h ColorStack, F_STACK) */
+                if (maxIt > SOLR_LDS_STACK_SLOTS && !g.recordNext && g.variant != 7)
+                    if (KernelFn spilling = solrrows::renderer(0, mask | F_STACK, false))
+                    {
+                        fn = spilling;
+                        deepSlots = maxIt - SOLR_LDS_STACK_SLOTS;
+                    }
                 chosen = row;
                 break;
             }
@@ -2354,6 +2365,19 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         g.recordDeep = deepList || g.recordVariant == 3;
         g.recordScene = S;
         g.recorded = true;
+    }
+    if (deepSlots > 0)
+    {
+        /* an F_STACK instantiation: SOLR_LDS_STACK_SLOTS slots in LDS - 16 waves per CU whatever the bounce limit - and
+         * the rest of this buffer set's frame in HBM, a plane of the strip per slot (3840 x 2160 x 7 slots: 0.9 GB of
+         * the 288; touched only by the rays that go that deep) */
+        F.stackSlots = SOLR_LDS_STACK_SLOTS;
+        ldsBytes = ((size_t)F.stackSlots * 4 + COLD_FIELDS) * WAVE * sizeof(float) + ldsPad;
+        F.deepStride = (long)sceneInfo.size.x * F.nbRows;
+        reserve(g.deepStack[flight], (size_t)deepSlots * (size_t)F.deepStride * sizeof(float4));
+        if (!ok())
+            return;
+        F.deepStack = (float4 *)g.deepStack[flight].ptr;
     }
     {
         HostSpan launch("  of which the kernel launch");
@@ -2750,6 +2774,7 @@ static void finalizeOne()
         release(*b);
     for (int f = 0; f < MAX_FLIGHTS; ++f)
     {
+        release(g.deepStack[f]);
         release(g.haloAbove[f]);
         release(g.haloBelow[f]);
         release(g.haloSendTop[f]);
@@ -4918,6 +4943,8 @@ void solr_hip_memory_usage(unsigned long long bytes[4])
     bytes[3] = g.pp.bytes + g.ids.bytes + g.bitmap.bytes + g.randoms.bytes;
     for (int f = 0; f < MAX_FLIGHTS - 1; ++f)
         bytes[3] += g.ppX[f].bytes + g.idsX[f].bytes + g.bitmapX[f].bytes;
+    for (int f = 0; f < MAX_FLIGHTS; ++f)
+        bytes[3] += g.deepStack[f].bytes;
 }
 
 /* ---- multi-GPU from the C ABI: row strips gathered with RCCL, no torch ---------------------------------------

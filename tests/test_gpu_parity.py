@@ -860,3 +860,46 @@ def test_frames_in_flight_through_the_frame_protocol(solr, flights):
     finally:
         L.SolRx_SetFramesInFlight(1)
         k.finalize()
+
+
+def test_deep_bounces_keep_three_stack_slots_in_lds_and_the_rest_in_hbm(solr, oracle):
+    """A frame that may bounce more than SOLR_LDS_STACK_SLOTS = 3 times (ten here: what every accumulation pass asks for)
+    used to size the per-lane colour stack in LDS for it - 67 dwords, nine waves per CU.  The lean kernels now have an
+    instantiation (F_STACK) that keeps three slots in LDS and the deeper ones in a per-pixel buffer in HBM: the same
+    frame bit for bit as with the whole stack in LDS (variant 7), the oracle's frame, with two frames in flight (a
+    buffer per set) and on strips"""
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=200, height=136, iterations=10)
+    try:
+        hip.solr_hip_set_variant(0)
+        frame = [np.array(a, copy=True) for a in gpu_frame(k)]
+        deep = int((frame[1][..., 1] > 3).sum())
+        assert deep > 50, "hardly a ray of this frame goes beyond the LDS slots (%d)" % deep
+        assert_frame_pinned(k, oracle, frame, 2, "ten bounces, deep slots in HBM")
+        hip.solr_hip_set_variant(7)
+        whole = [np.array(a, copy=True) for a in gpu_frame(k)]
+        hip.solr_hip_set_variant(0)
+        assert np.array_equal(frame[0].view(np.uint32), whole[0].view(np.uint32))
+        assert np.array_equal(frame[1], whole[1]) and np.array_equal(frame[2], whole[2])
+        # two frames in flight: every buffer set has deep slots of its own
+        hip.solr_hip_set_frames_in_flight(2)
+        for i in range(6):
+            again = gpu_frame(k)
+            assert np.array_equal(again[0].view(np.uint32), frame[0].view(np.uint32)), i
+            assert np.array_equal(again[2], frame[2]), i
+        hip.solr_hip_set_frames_in_flight(1)
+        # a strip: the deep buffer is the strip's
+        hip.solr_hip_set_strip(40, 56)
+        k.render()
+        k.check(0, "strip")
+        pp = np.zeros((56, 200, 8), np.float32)
+        import ctypes as C
+        hip.solr_hip_d2h_postprocessing(C.c_void_p(pp.ctypes.data))
+        assert np.array_equal(pp.view(np.uint32), frame[0][40:96].view(np.uint32))
+        hip.solr_hip_set_strip(0, -1)
+    finally:
+        hip.solr_hip_set_variant(0)
+        hip.solr_hip_set_frames_in_flight(1)
+        hip.solr_hip_set_strip(0, -1)
+        k.finalize()
