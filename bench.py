@@ -90,8 +90,10 @@ def parse():
     # accepted for the command lines of earlier rounds: both are the default now
     ap.add_argument("--balanced-strips", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--native-gather", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--delivery", default="strips", choices=["strips", "gathered"],
-                    help="N > 1, how the frame reaches the host: 'strips' - every rank copies its strip over its own PCIe "
+    ap.add_argument("--delivery", default="auto", choices=["auto", "strips", "gathered"],
+                    help="N > 1, how the frame reaches the host ('auto', the default: both are timed in short segments, with "
+                         "one communicator and with one per frame in flight, and the headline runs on the fastest "
+                         "combination whose frame equals the one-GPU frame - config.mode_sweep): 'strips' - every rank copies its strip over its own PCIe "
                          "link into one page-locked image the ranks' processes share (solr_hip_image_share; the reference's "
                          "d2h_bitmap does the same with the devices of its one process) - or 'gathered': rank 0 copies the "
                          "frame the RCCL gather assembled in its HBM (one PCIe link for the whole frame).  The gather over "
@@ -312,22 +314,43 @@ def main():
 
     rccl_ranks = comm_count = None
     delivery_fallback = None
-    if native:
-        # the communicator: rank 0's id to everybody over the control plane, then ncclCommInitRank in the library
+    mode = {"per_flight": None, "delivery": None}      # what is up right now
+
+    def engine_error():
+        buf = C.create_string_buffer(512)
+        hip.solr_hip_last_error(buf, 512)
+        return buf.value.decode(errors="replace")
+
+    def comm_up(per_flight):
+        """(every rank) the communicator - rank 0's id to everybody over the control plane, then ncclCommInitRank in the
+        library - with one communicator for everything or one per frame in flight (None: as the library / the
+        environment says).  False, on every rank alike and with the engine's error cleared, when it did not come up."""
+        if per_flight is not None:
+            hip.solr_hip_comm_set_per_flight(1 if per_flight else 0)
         uid = C.create_string_buffer(128)
-        if rank == 0 and hip.solr_hip_comm_unique_id(uid) != 0:
-            k.check(-1, "solr_hip_comm_unique_id")
+        fine = not (rank == 0 and hip.solr_hip_comm_unique_id(uid) != 0)
         box = [uid.raw]
         dist.broadcast_object_list(box, src=0)
         uid = C.create_string_buffer(box[0], 128)
-        if hip.solr_hip_comm_init(rank, world, uid) != 0:
-            k.check(-1, "solr_hip_comm_init")
-        rccl_ranks = int(hip.solr_hip_comm_ranks())
-        comm_count = int(hip.solr_hip_comm_count())
-        if args.delivery == "strips":
-            # one host image for all ranks: rank 0 creates the segment, the others open it.  A box that does not let
-            # the processes share page-locked memory (no /dev/shm, a registration the driver refuses) must not void the
-            # job: all ranks then fall back, together, to rank 0 copying the gathered frame - and the line says so
+        fine = fine and hip.solr_hip_comm_init(rank, world, uid) == 0
+        if agree(dist, torch, not fine):
+            if rank == 0:
+                print("bench.py: the communicator did not come up (per flight: %s): %s" % (per_flight, engine_error() or
+                                                                                          "on another rank"), file=sys.stderr, flush=True)
+            hip.solr_hip_clear_error()
+            hip.solr_hip_comm_finalize()
+            return False
+        mode["per_flight"] = int(hip.solr_hip_comm_count()) > 1
+        return True
+
+    def delivery_up(route):
+        """(every rank) 'strips': one host image for all ranks - rank 0 creates the segment, the others open it.  A box
+        that does not let the processes share page-locked memory (no /dev/shm, a registration the driver refuses) must
+        not void the job: all ranks then fall back, together, to rank 0 copying the gathered frame.  Returns the route
+        that is up and, when it is not the one asked for, why."""
+        hip.solr_hip_image_unshare()
+        why = None
+        if route == "strips":
             name = ("/solr_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getuid())).encode()
             mine = 0
             if os.environ.get("SOLR_BENCH_FAIL_SHARE") == "1" and rank == world - 1:
@@ -338,18 +361,45 @@ def main():
             if rank != 0:
                 mine = hip.solr_hip_image_share(name, rank, world)
             if agree(dist, torch, mine != 0):
-                buf = C.create_string_buffer(512)
-                hip.solr_hip_last_error(buf, 512)
-                delivery_fallback = "solr_hip_image_share failed on some rank (%s): --delivery gathered instead" % \
-                    (buf.value.decode(errors="replace") or "on another rank")
+                why = "solr_hip_image_share failed on some rank (%s): --delivery gathered instead" % \
+                    (engine_error() or "on another rank")
                 hip.solr_hip_clear_error()
                 hip.solr_hip_image_unshare()
-                args.delivery = "gathered"
+                route = "gathered"
                 if rank == 0:
-                    print("bench.py: " + delivery_fallback, file=sys.stderr, flush=True)
+                    print("bench.py: " + why, file=sys.stderr, flush=True)
             dist.barrier()
             # every rank has the segment mapped: its NAME can go (a job that dies later leaves nothing in /dev/shm)
             hip.solr_hip_image_share_sealed()
+        mode["delivery"] = route
+        return route, why
+
+    alone = None
+    sweep_routes = [args.delivery] if args.delivery != "auto" else ["strips", "gathered"]
+    env_per_flight = os.environ.get("SOLR_HIP_COMM_PER_FLIGHT")
+    sweep_comms = [env_per_flight[0] != "0"] if env_per_flight else [False, True]
+    if args.delivery == "auto":
+        args.delivery = "strips"
+    if native:
+        if not cfg4 and not args.no_check:
+            # the frame a rank renders ALONE, whole, before there is a communicator: what every assembled frame of the
+            # job is compared with (config.mode_sweep).  Every rank renders it - the ranks run the same program, frame
+            # for frame: the engine deals its buffer sets (and, with one communicator per frame in flight, its
+            # communicators) out by frame number - and rank 0 keeps it
+            import numpy as np
+            hip.solr_hip_set_strip(0, -1)
+            render()
+            if rank == 0:
+                alone = np.zeros((H, W, 3), np.uint8)
+                hip.solr_hip_d2h(C.byref(si), C.c_void_p(alone.ctypes.data), None)
+            hip.solr_hip_synchronize()
+            k.check(0, "the frame on one GPU")
+            hip.solr_hip_set_strip(first_row, nb_rows)
+        if not comm_up(None if env_per_flight else sweep_comms[0]):
+            raise SystemExit("bench.py rank %d: no communicator" % rank)
+        rccl_ranks = int(hip.solr_hip_comm_ranks())
+        comm_count = int(hip.solr_hip_comm_count())
+        args.delivery, delivery_fallback = delivery_up(args.delivery)
 
     def frame():
         # N = 1: the renderer alone.  N > 1: the renderer writes RGB8 straight into a strip buffer and the
@@ -469,7 +519,7 @@ def main():
             pipe.frame(render)
             return
         frame()
-        tickets.append(hip.solr_hip_d2h_gathered_async() if (native and args.delivery == "gathered")
+        tickets.append(hip.solr_hip_d2h_gathered_async() if (native and mode["delivery"] == "gathered")
                        else hip.solr_hip_d2h_image_async())
         if tickets[-1] == -1:
             k.check(-1, "read-back of the frame")
@@ -585,6 +635,88 @@ def main():
         for _ in range(PREROLL_FRAMES // 2):
             step()
         drain()
+    # ---- N > 1: which communicator mode, which delivery route?  Nobody has run this on eight GPUs: RCCL orders the
+    # operations of ONE communicator whatever streams they are enqueued on (one per frame in flight avoids that, at
+    # the price of four communicators), and the frame can reach the host over every rank's own PCIe link (one shared
+    # host image) or over rank 0's alone (the gathered frame).  So the job times all of them - short segments, the same
+    # loop as the headline - checks each one's delivered frame against the frame rank 0 rendered alone, and runs the
+    # headline on the fastest that passed.  A combination that fails is reported and left out, not fatal.
+    mode_sweep = None
+    combos = [(c, r) for c in sweep_comms for r in sweep_routes]
+    want_sweep = os.environ.get("SOLR_BENCH_SWEEP", "1" if world > 1 else "0") == "1"
+    if native and not cfg4 and len(combos) > 1 and want_sweep:
+        import numpy as np
+        mode_sweep = {}
+
+        def configure(per_flight, route):
+            """(every rank) tear down what is up, bring this combination up, re-cut the strips; None or why not"""
+            if mode["per_flight"] != per_flight:
+                sync()
+                barrier()
+                hip.solr_hip_image_unshare()
+                hip.solr_hip_comm_finalize()
+                hip.solr_hip_set_strip(first_row, nb_rows)
+                mode["delivery"] = None
+                if not comm_up(per_flight):
+                    return "the communicator did not come up"
+                if balanced and hip.solr_hip_balance_strips() != 0:
+                    why = engine_error()
+                    hip.solr_hip_clear_error()
+                    return "solr_hip_balance_strips: " + why
+            if mode["delivery"] != route:
+                sync()
+                got, why = delivery_up(route)
+                if got != route:
+                    return why
+            for _ in range(PREROLL_FRAMES // 2):
+                step()
+            drain()
+            return None
+
+        def label(per_flight, route):
+            return "%s_%s" % ("communicator_per_flight" if per_flight else "one_communicator",
+                              "strips_over_every_ranks_link" if route == "strips" else "gathered_frame_over_rank0s_link")
+
+        for per_flight, route in combos:
+            name = label(per_flight, route)
+            arm("mode sweep: " + name)
+            entry = {}
+            try:
+                why = configure(per_flight, route)
+                if why:
+                    entry["skipped"] = why
+                else:
+                    seg = timed(args.steps, args.warmup, max(regions // 5, 5))
+                    t = torch.tensor([median(seg["regions"])], dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    entry["ms_per_step"] = round(float(t[0]) / args.steps * 1e3, 5)
+                    same = True
+                    if rank == 0 and alone is not None:
+                        same = seg["last_image"] is not None and bool(np.array_equal(seg["last_image"], alone))
+                    entry["frame_equals_single_gpu"] = not agree(dist, torch, not same)
+                    entry["rccl_communicators"] = int(hip.solr_hip_comm_count())
+            except solr.SolrError as e:            # the engine's error state: reported, cleared, the job goes on
+                entry["error"] = str(e)[:300]
+            failed = agree(dist, torch, "error" in entry)
+            if failed:
+                entry.setdefault("error", "on another rank")
+                hip.solr_hip_clear_error()
+                tickets.clear()
+            mode_sweep[name] = entry
+        usable = {n: e for n, e in mode_sweep.items() if "ms_per_step" in e and e.get("frame_equals_single_gpu") and "error" not in e}
+        if not usable:
+            raise SystemExit("bench.py rank %d: no communicator mode / delivery route delivered the one-GPU frame: %s"
+                             % (rank, json.dumps(mode_sweep)))
+        best = min(usable, key=lambda n: usable[n]["ms_per_step"])
+        for per_flight, route in combos:
+            if label(per_flight, route) == best:
+                arm("mode sweep: back to " + best)
+                why = configure(per_flight, route)
+                if why:
+                    raise SystemExit("bench.py rank %d: %s did not come up a second time: %s" % (rank, best, why))
+        mode_sweep["headline_runs_on"] = best
+        comm_count = int(hip.solr_hip_comm_count())
+        args.delivery = mode["delivery"]
     arm("the timed regions")
     main_run = timed(args.steps, args.warmup, regions)
     short_ray_lists = int(hip.solr_hip_short_ray_lists())   # what the engine chose for the delivered frames
@@ -851,8 +983,9 @@ def main():
         slowest = max(per_rank, key=lambda r: r["ms_per_step_until_own_frames_delivered"])
         out["config"].update({
             "rccl_ranks": rccl_ranks, "rccl_communicators": comm_count,
-            "rccl_communicator_mode": ("one per frame in flight (SOLR_HIP_COMM_PER_FLIGHT=1)" if comm_count and comm_count > 1
-                                       else "one for everything (default; SOLR_HIP_COMM_PER_FLIGHT=1 for the A/B)"),
+            "rccl_communicator_mode": ("one per frame in flight" if comm_count and comm_count > 1 else "one for everything") +
+                                      (" (the fastest of config.mode_sweep)" if mode_sweep else
+                                       " (SOLR_HIP_COMM_PER_FLIGHT=0|1 / --delivery chose it: no sweep)"),
             "per_rank": per_rank, "slowest_rank": slowest["rank"],
             # the end barrier of a region belongs to the control plane (gloo over TCP) and is not charged to the region:
             # a region's time is the MAX over ranks of each rank's own time from the start barrier to its last delivery
@@ -867,6 +1000,14 @@ def main():
             "gathered_equals_single_gpu": check,
             "rates_mrays_per_s": {("balanced_strips" if balanced else "equal_strips") +
                                   ("_native_gather" if native else "_torch_gather"): round(mrays, 1)}})
+        if mode_sweep:
+            # every communicator mode x delivery route, timed in short segments of the same loop before the headline
+            # (which ran on the fastest whose frame equals the one-GPU frame); a combination that failed says why
+            out["config"]["mode_sweep"] = mode_sweep
+            for name, entry in mode_sweep.items():
+                if isinstance(entry, dict) and "ms_per_step" in entry:
+                    entry["mrays_per_s"] = round(rays_total / (entry["ms_per_step"] * 1e-3) / 1e6, 1)
+                    out["config"]["rates_mrays_per_s"]["sweep_" + name] = entry["mrays_per_s"]
         if second_out:
             out["config"]["rates_mrays_per_s"]["equal_strips_native_gather"] = round(rays_total * args.steps / second_out / 1e6, 1)
             out["config"]["rates_note"] = {"equal_strips_native_gather": "the reference's equal split, same loop, timed "

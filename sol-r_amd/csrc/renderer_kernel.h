@@ -451,6 +451,8 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_walkBound(const Sce
             W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
             W.nbBoxes = S.nbBoxesFree;
         }
+        if (__builtin_amdgcn_readfirstlane(h.w)) /* the walk took the thin copy of its list (rt_device.h tightRay) */
+            W.offBoxes += __builtin_amdgcn_readfirstlane(h.y) ? 16u * (unsigned)S.nbBoxesFree + 2u : 2u * (unsigned)S.nbBoxes + 2u;
         const PackedRay pr = packRay(r);
         const float cutOff = a.w;
         int cursor = took_part ? 0 : SOLR_CURSOR_DONE;

@@ -1037,7 +1037,7 @@ enum WalkKind
     WALK_GENERAL = 2 /* not through the node loop (a list that is not nested, non-finite rays): not replayed */
 };
 SOLR_DEV void recordWalk(Counters &cnt, int kind, bool freeList, int octant, bool took_part, const WalkRay &r, float cutOff,
-                         int doneAfter)
+                         int doneAfter, bool tight = false)
 {
     const unsigned j = cnt.ordinal++;
     if (j >= SOLR_WALK_SLOTS || !cnt.record)
@@ -1047,7 +1047,7 @@ SOLR_DEV void recordWalk(Counters &cnt, int kind, bool freeList, int octant, boo
     lanes[0] = make_float4(r.o.x, r.o.y, r.o.z, cutOff);
     lanes[1] = make_float4(r.d.x, r.d.y, r.d.z, __int_as_float(took_part ? doneAfter : -1));
     if (lane == 0)
-        ((int4 *)cnt.record)[1 + j] = make_int4(kind, freeList ? 1 : 0, octant, 0);
+        ((int4 *)cnt.record)[1 + j] = make_int4(kind, freeList ? 1 : 0, octant, tight ? 1 : 0);
 }
 
 /* What a walk holds of the primitive it is testing.  The first primitive of a leaf comes with the leaf's record
@@ -1524,6 +1524,32 @@ SOLR_DEV bool longRay(v3 d)
     return dd >= 4.f && dd <= 1.0e24f;
 }
 
+/* TIGHT LEAVES.  The reference's builder gives a plane the box p0 +- size in all three axes (GPUKernel.cpp:762-830) - a
+ * wall of the Cornell room, size (w, h, d), gets half the room - so every ray of that frame entered all six walls'
+ * leaves and made six plane tests (two divisions each) to find the one wall it can reach: 19 leaf entries per pixel,
+ * 15 of them walls.  A test that misses has no effect on a walk (what the order-free cut-off already relies on), so a
+ * leaf need only be entered by the rays that can HIT one of its primitives.  Behind the walk-order list and the
+ * order-free lists lies a copy of their node rows (solr_hip.hip tightenList) in which a leaf that holds nothing but
+ * plain axis planes (KIND_PLANE_*: the test is `(front || rear) && |I.u - p0.u| < size.u && |I.v - p0.v| < size.v`,
+ * GI:424-567) is the planes' rectangle, a margin m thick and m wider, cut with the reference's box; inner nodes are the
+ * unions of their leaves.  A ray that hits such a plane crosses the rectangle's plane at t* > 0 inside the rectangle,
+ * so all three slab intervals of the thin box contain t* - up to rounding, which the margin covers: every quantity of
+ * the plane test and of the slab test is bounded by M = |o| + |p0| + |size| (the hit point lies inside the rectangle),
+ * each operation loses at most 2^-24 of that, a handful of operations - against m = 2^-10 of the scene's extent E with
+ * |o| <= viewDistance <= 64 E demanded below (M <= 66 E: a slack of some 2^8).  Demanded of the ray, because the
+ * argument needs them: no zero direction component (the reference gives a zero component the reciprocal 1, GI:39-41,
+ * and its slab test on ITS boxes then decides by values that mean nothing - reproducible only with its boxes);
+ * |direction| >= 2, so that the reference's cut-off - slab parameter against closest DISTANCE - cannot hide a box the
+ * hit lies in (for the bounce rays, |direction| = 0.95, which box is entered FIRST decides: the thin copy is not for
+ * them); the origin within viewDistance of zero.  The host offers the copy (S.tightLists) only with extended geometry
+ * (without it a plane record is tested as a triangle) and viewDistance <= 64 E.  Same frames bit for bit
+ * (solr_hip_set_variant(8) walks the reference's boxes; tests/test_gpu_parity.py), 0.2865 -> see DESIGN.md section 5. */
+SOLR_DEV bool tightRay(const WalkRay &r, const SceneInfo &si)
+{
+    return longRay(r.d) && r.d.x != 0.f && r.d.y != 0.f && r.d.z != 0.f && fabsf(r.o.x) <= si.viewDistance &&
+           fabsf(r.o.y) <= si.viewDistance && fabsf(r.o.z) <= si.viewDistance;
+}
+
 template <int COUNT, int FEAT>
 SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v3 origin, v3 target, int iteration,
                              int currentMaterialId, int &closestPrimitive, v3 &closestIntersection,
@@ -1552,6 +1578,27 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
      * rays qualify (|direction| is thousands); bounce rays are unit vectors and walk the reference's order. */
     const bool freeOrder =
         tidy && S.nbBoxesFree > 0 && ballot(active && !longRay(r.d)) == 0ull;
+    /* the thin copy of the list this walk takes (tightRay above) */
+    const bool tight = tidy && S.tightLists && ballot(active && !tightRay(r, si)) == 0ull;
+    /* ... and the SHORT rays (the bounce rays, |direction| = L = 1 - rayEpsilon) in the reference's order: for them the
+     * reference's cut-off - slab parameter t against closest DISTANCE - decides by WHEN a box is entered, and a thin
+     * leaf is entered later than the reference's fat one.  The reference tests the primitives of leaf l iff its own box
+     * passes [0, closest so far); so does this walk, literally: it runs over the thin copy with the cut-off widened to
+     * far' = 1.002 closest / min(L, 1) + slack (a hit at distance D < closest has t* = D / L < far': its thin leaf is
+     * entered), and at every leaf it enters it makes the reference's own test on the reference's own box with the
+     * reference's cut-off (`fatCheck` below).  What it skips is a leaf the reference enters and the thin test does not:
+     * no ray-rectangle crossing at all, or one at t* >= far' - a distance of at least 1.001 closest, which the
+     * reference rejects (GI:751) - and a test that misses leaves no trace.  Leaves that are no thinner than the
+     * reference's pass the thin test whenever they pass the reference's (far' >= far).  Same order, same tests that
+     * count, same closest-so-far after every leaf: by induction the same result. */
+    const float ddShort = dot(r.d, r.d);
+    const bool shortTightLane = ddShort >= 0.25f && ddShort < 4.f && r.d.x != 0.f && r.d.y != 0.f && r.d.z != 0.f &&
+                                fabsf(r.o.x) <= si.viewDistance && fabsf(r.o.y) <= si.viewDistance &&
+                                fabsf(r.o.z) <= si.viewDistance;
+    const bool tightShort = tidy && S.tightLists && !tight && !freeOrder && !(COUNT != 1 && (FEAT & F_DEEP) && (FEAT & F_TRI)) &&
+                            ballot(active && !shortTightLane) == 0ull;
+    const float shortFarScale = 1.002f / fminf(sqrtf(ddShort) * (1.f - 1.0e-5f), 1.f);
+    const float shortFarOffset = 2.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
     /* Short rays (the bounce rays: |direction| = 1 - rayEpsilon, CudaRayTracer.cu:322-323) in the order-free lists,
      * CHECKED.  The reference culls a box when its slab parameter t = (entry distance) / |direction| reaches the closest
      * DISTANCE so far.  For |direction| = L <= 1 that hides boxes whose entry lies between L x and 1 x the closest
@@ -1605,6 +1652,11 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
             W.nbBoxes = S.nbBoxesFree;
         }
+        if (tight) /* the same nodes, leaf records and start indices: only the bounds differ */
+            W.offBoxes += freeList ? 16u * (unsigned)S.nbBoxesFree + 2u : 2u * (unsigned)S.nbBoxes + 2u;
+        const bool fatCheck = tightShort && !freeList;
+        if (fatCheck)
+            W.offBoxes += 2u * (unsigned)S.nbBoxes + 2u;
         /* The reference's cut-off never culls for such rays (a slab parameter of order 1 against a distance of
          * thousands).  The order-free walk may cull by the TRUE distance: a box whose entry point lies farther than the
          * closest hit so far holds nothing that could replace it, not even on a tie.  The margins cover the rounding
@@ -1641,12 +1693,22 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             SOLR_T(unsigned long long ta = SOLR_NOW();)
             if (tidy)
             {
-                leaf = advanceTidy<FEAT>(W, pr, freeList ? minDistance * farScale + farOffset : minDistance, cursor,
-                                         cur, nbPrimitives, entered);
+                leaf = advanceTidy<FEAT>(W, pr,
+                                         freeList ? minDistance * farScale + farOffset
+                                                  : (fatCheck ? minDistance * shortFarScale + shortFarOffset : minDistance),
+                                         cursor, cur, nbPrimitives, entered);
                 SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;
                        if (attempt == 0) ++cnt.nAdvanceFirst; else ++cnt.nAdvanceAgain;)
                 if (leaf < 0)
                     break;
+                if (fatCheck)
+                {
+                    /* the reference's own entry test of this leaf: its box, its cut-off (see tightShort) */
+                    const Row2 fat = boxNode(S, uniform(leaf));
+                    entered = entered && boxIntersectionFast(nodeLo(fat), nodeHi(fat), r, 0.f, minDistance);
+                    if (ballot(entered) == 0ull)
+                        continue;
+                }
             }
             else
             {
@@ -1900,7 +1962,9 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         }
         if (COUNT == 2) /* this attempt, for the walk's own ceiling: the cut-off it ended with */
             recordWalk(cnt, tidy ? WALK_CLOSEST : WALK_GENERAL, freeList, octant, lanesNow, r,
-                       freeList ? minDistance * farScale + farOffset : minDistance, SOLR_CURSOR_DONE);
+                       freeList ? minDistance * farScale + farOffset
+                                : (fatCheck ? minDistance * shortFarScale + shortFarOffset : minDistance),
+                       SOLR_CURSOR_DONE, tight || fatCheck);
         SOLR_T(if (attempt == 1) cnt.tAgain += SOLR_NOW() - tAttempt;)
         if (!checked)
             break;
@@ -1963,6 +2027,10 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         W.nbBoxes = S.nbBoxesFree;
         farFree = 1.0002f + 1.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z)) / lengthOL;
     }
+    /* the thin copy of that list (tightRay: a shadow ray reaches from the point to the lamp, thousands of units) */
+    const bool tight = tidy && S.tightLists && ballot(active && !tightRay(r, si)) == 0ull;
+    if (tight)
+        W.offBoxes += freeOrder ? 16u * (unsigned)S.nbBoxesFree + 2u : 2u * (unsigned)S.nbBoxes + 2u;
     const int nbBoxes = W.nbBoxes;
     const PackedRay pr = packRay(r);
     int cursor = (active && result < si.shadowIntensity) ? 0 : SOLR_CURSOR_DONE;
@@ -2127,7 +2195,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     }
     if (COUNT == 2)
         recordWalk(cnt, tidy ? WALK_SHADOW : WALK_GENERAL, freeOrder, octant, walked, r, freeOrder ? farFree : minDistance,
-                   doneAfter);
+                   doneAfter, tight);
     result = fmaxf(0.f, fminf(result, si.shadowIntensity));
     SOLR_T(cnt.tShadow += SOLR_NOW() - tw0;)
     return result;

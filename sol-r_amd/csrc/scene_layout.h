@@ -156,6 +156,10 @@ struct SceneArgs
     int nbBoxesFree;
     int opaqueShadows; /* no primitive is transparent or a textured plane: any occluder saturates a shadow */
     int shortRayLists; /* bounce rays (shorter than 1) take the order-free lists, checked (rt_device.h closestHitWalk) */
+    /* behind the walk-order list and behind the eight order-free lists lies a copy of their node rows in which every
+     * leaf that holds nothing but plain axis planes is as thin as its planes (solr_hip.hip tightenList): long rays with
+     * no zero direction component walk the copy (rt_device.h tightRay) */
+    int tightLists;
 };
 
 /* Device view: everything is read through the CONSTANT address space.  The
@@ -192,6 +196,7 @@ struct Scene
     int nbBoxesFree;
     int opaqueShadows;
     int shortRayLists;
+    int tightLists;
 };
 
 __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
@@ -219,6 +224,7 @@ __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
     s.nbBoxesFree = a.nbBoxesFree;
     s.opaqueShadows = a.opaqueShadows;
     s.shortRayLists = a.shortRayLists;
+    s.tightLists = a.tightLists;
     return s;
 }
 

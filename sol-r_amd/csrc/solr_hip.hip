@@ -401,6 +401,9 @@ __device__ __forceinline__ bool aoDepthAt(const PixelRecord *__restrict__ pp, co
         depth = pp[yy * W + xx].colorInfo.w;
     return true;
 }
+/* tiles a workgroup renders one after the other (a run along x): what does not depend on the tile - the tap pairs,
+ * their reach and, inside one binade, the deduped offsets - is made once per run instead of once per 256 pixels */
+#define AO_TILES_PER_GROUP 8
 __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
                                                           const PixelRecord *__restrict__ pp,
                                                           const float *__restrict__ randoms, long nbRandoms,
@@ -412,21 +415,23 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
      * threads evaluate one tap's pair each - the same expressions, the two correctly rounded divisions
      * included - and every pixel then adds them to its coordinates: 2 divisions per thread instead of 512.
      *
-     * A workgroup is a 32 x 8 tile of pixels.  Every tap of every pixel of the tile lands within
-     * rx = max |tapX| + 1 columns and ry = max |tapY| + 1 rows of the tile: that window of depths (colorInfo.w
-     * of the 32-byte frame-buffer records) is read once into LDS - 2 772 four-byte reads for taps of up to 16 pixels
-     * (432 for cfg4's, which reach one) instead of 65 536 - and the 256 comparisons of a pixel read LDS, consecutive lanes consecutive
-     * words.  Same comparisons on the same values, counted in floats that stay exact integers: the order of the
-     * additions does not matter.  A window that does not fit (taps that reach beyond about 40 pixels) is gathered from memory as
-     * before. */
+     * A tile is 32 x 8 pixels.  Every tap of every pixel of the tile lands within rx = max |tapX| + 1 columns and
+     * ry = max |tapY| + 1 rows of the tile: that window of depths (colorInfo.w of the 32-byte frame-buffer records) is
+     * read once into LDS - 2 772 four-byte reads for taps of up to 16 pixels (432 for cfg4's, which reach one) instead
+     * of 65 536 - and the comparisons of a pixel read LDS, consecutive lanes consecutive words.  Same comparisons on the
+     * same values, counted in integers: the order of the additions does not matter.  A window that does not fit (taps
+     * that reach beyond about 40 pixels) is gathered from memory as before. */
     __shared__ float tapX[256], tapY[256];
     __shared__ int reach[2];
     __shared__ float window[AO_WINDOW_FLOATS];
+    __shared__ int tapOffset[256];
+    __shared__ unsigned table[512];
+    __shared__ int distinctOffset[256], distinctWeight[256];
+    __shared__ int nbDistinct;
     const int W = si.size.x;
     const int wh = W * si.size.y; /* the frame's, also when this rank renders a strip of it */
     const int tilesX = (W + AO_TILE_W - 1) / AO_TILE_W;
-    const int x0 = (int)(blockIdx.x % (unsigned)tilesX) * AO_TILE_W;
-    const int y0 = (int)(blockIdx.x / (unsigned)tilesX) * AO_TILE_H;
+    const int nbTiles = tilesX * ((nbRows + AO_TILE_H - 1) / AO_TILE_H);
     if (threadIdx.x < 2)
         reach[threadIdx.x] = 0;
     __syncthreads();
@@ -444,137 +449,200 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
         /* (int)(x + t) stays within ceil(|t|) + 1 of x for an integer x below 2^23; anything else (NaN, huge)
          * sends the tile down the gather path */
         const float ax = fabsf(tx), ay = fabsf(ty);
-        const int cx = (ax < 1.0e6f) ? (int)ax + 2 : (1 << 20);
-        const int cy = (ay < 1.0e6f) ? (int)ay + 2 : (1 << 20);
-        atomicMax(&reach[0], cx);
-        atomicMax(&reach[1], cy);
+        int cx = (ax < 1.0e6f) ? (int)ax + 2 : (1 << 20);
+        int cy = (ay < 1.0e6f) ? (int)ay + 2 : (1 << 20);
+        for (int off = 32; off > 0; off >>= 1) /* (a wave's maximum first: 8 atomics on one word instead of 512) */
+        {
+            cx = max(cx, __shfl_xor(cx, off, 64));
+            cy = max(cy, __shfl_xor(cy, off, 64));
+        }
+        if ((i & 63) == 0)
+        {
+            atomicMax(&reach[0], cx);
+            atomicMax(&reach[1], cy);
+        }
     }
     __syncthreads();
     const int rx = reach[0], ry = reach[1];
     const int ww = AO_TILE_W + 2 * rx, wrows = AO_TILE_H + 2 * ry;
     const bool tiled = rx < 4096 && ry < 4096 && ww * wrows <= AO_WINDOW_FLOATS;
-    const int wx0 = x0 - rx, wy0 = y0 - ry;
-    if (tiled)
+    int tableKey = 0; /* the binades (of x and of the frame's y) the deduped offsets in LDS were made for; 0: none */
+    for (int run = 0; run < AO_TILES_PER_GROUP; ++run)
     {
-        for (int i = threadIdx.x; i < ww * wrows; i += 256)
+        const int tile = (int)blockIdx.x * AO_TILES_PER_GROUP + run;
+        if (tile >= nbTiles)
+            break;
+        const int x0 = (tile % tilesX) * AO_TILE_W;
+        const int y0 = (tile / tilesX) * AO_TILE_H;
+        const int wx0 = x0 - rx, wy0 = y0 - ry;
+        const int x = x0 + (int)(threadIdx.x % AO_TILE_W);
+        const int y = y0 + (int)(threadIdx.x / AO_TILE_W);
+        const bool mine = x < W && y < nbRows;
+        const int index = mine ? y * W + x : 0;
+        const float4 local = pp[index].colorInfo; /* (asked for before the window: the two waits overlap) */
+        if (tiled)
+            for (int i = threadIdx.x; i < ww * wrows; i += 256)
+            {
+                const int gx = wx0 + i % ww, gy = wy0 + i / ww;
+                float d = 0.f;
+                aoDepthAt(pp, halo, W, nbRows, gx, gy, d);
+                window[i] = d;
+            }
+        /* Steady taps.  (int)(x + t) - x is the same for every x of the tile when x and all the sums x + t lie in one
+         * binade: x is a multiple of that binade's ulp U (a power of two below 1, so x / U is even and ties round the
+         * same way), hence RN(x + t) = x + RN_U(t), and the sums are positive, so the truncation is a floor.  Then a
+         * tap is ONE integer offset into the window for the whole tile - evaluated once per tap, on the tile's first
+         * column and row, with the reference's own expression - and the same for every tile of those two binades.
+         * Tiles that straddle a power of two in x or in the frame's y, or whose window leaves the frame, take the
+         * per-pixel evaluation below.
+         *
+         * ... and the taps that land on the same depth are one comparison.  cfg4's taps (param2 = 10, randoms of
+         * +-0.005) reach one pixel: 256 taps, FOUR distinct offsets.  The count is an integer sum, so it is taken over
+         * the distinct offsets with their multiplicities: the workgroup dedupes its 256 offsets (a 512-slot hash
+         * table: key and count in one word, atomicCAS to claim, atomicAdd to count) and a pixel then makes one read
+         * and one compare per DISTINCT offset - and never more than before: beyond 128 distinct offsets the plain loop
+         * runs. */
+        bool steady = false;
+        if (tiled)
         {
-            const int gx = wx0 + i % ww, gy = wy0 + i / ww;
-            float d = 0.f;
-            aoDepthAt(pp, halo, W, nbRows, gx, gy, d);
-            window[i] = d;
+            const int xlo = x0 - rx, xhi = x0 + AO_TILE_W - 1 + rx;
+            const int ylo = y0 + firstRow - ry, yhi = y0 + firstRow + AO_TILE_H - 1 + ry;
+            steady = wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow && xlo >= 1 &&
+                     ylo >= 1 && __clz(xlo) == __clz(xhi) && __clz(ylo) == __clz(yhi);
+            const int key = steady ? (1 << 16) | (__clz(xlo) << 8) | __clz(ylo) : 0;
+            if (steady && key != tableKey)
+            {
+                const int i = threadIdx.x;
+                const int dx = (int)((float)x0 + tapX[i]) - x0;
+                const int dy = (int)((float)(y0 + firstRow) + tapY[i]) - (y0 + firstRow);
+                const int off = dy * ww + dx; /* |off| < ww * wrows <= AO_WINDOW_FLOATS: inside the window */
+                tapOffset[i] = off;
+                if (i == 0)
+                    nbDistinct = 0;
+                table[i] = 0u;
+                table[i + 256] = 0u;
+                __syncthreads();
+                const unsigned tag = (unsigned)(off + AO_WINDOW_FLOATS) + 1u; /* 1 ... 2 x 8192: 0 is an empty slot */
+                unsigned h = (tag * 2654435761u) >> 23;
+                for (;;)
+                {
+                    const unsigned before = atomicCAS(&table[h], 0u, tag << 9);
+                    if (before == 0u || (before >> 9) == tag)
+                    {
+                        atomicAdd(&table[h], 1u); /* at most 256 taps: the count stays below the key's bits */
+                        break;
+                    }
+                    h = (h + 1u) & 511u;
+                }
+                __syncthreads();
+                for (int slot = i; slot < 512; slot += 256)
+                {
+                    const unsigned entry = table[slot];
+                    if (entry != 0u)
+                    {
+                        const int at = atomicAdd(&nbDistinct, 1);
+                        distinctOffset[at] = (int)(entry >> 9) - 1 - AO_WINDOW_FLOATS;
+                        distinctWeight[at] = (int)(entry & 511u);
+                    }
+                }
+            }
+            tableKey = steady ? key : tableKey;
         }
-        __syncthreads();
-    }
-    /* Steady taps.  (int)(x + t) - x is the same for every x of the tile when x and all the sums x + t lie in one
-     * binade: x is a multiple of that binade's ulp U (a power of two below 1, so x / U is even and ties round the
-     * same way), hence RN(x + t) = x + RN_U(t), and the sums are positive, so the truncation is a floor.  Then a
-     * tap is ONE integer offset into the window for the whole tile - evaluated here once per tap, on the tile's
-     * first column and row, with the reference's own expression - and the 256 comparisons of a pixel are an add,
-     * a read and a compare each.  Tiles that straddle a power of two in x or in the frame's y, or whose window
-     * leaves the frame, take the per-pixel evaluation below. */
-    __shared__ int tapOffset[256];
-    bool steady = false;
-    if (tiled)
-    {
-        const int xlo = x0 - rx, xhi = x0 + AO_TILE_W - 1 + rx;
-        const int ylo = y0 + firstRow - ry, yhi = y0 + firstRow + AO_TILE_H - 1 + ry;
-        steady = wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow && xlo >= 1 &&
-                 ylo >= 1 && __clz(xlo) == __clz(xhi) && __clz(ylo) == __clz(yhi);
-        if (steady)
+        __syncthreads(); /* the window is in LDS, and so are the offsets */
+        if (mine)
         {
-            const int i = threadIdx.x;
-            const int dx = (int)((float)x0 + tapX[i]) - x0;
-            const int dy = (int)((float)(y0 + firstRow) + tapY[i]) - (y0 + firstRow);
-            tapOffset[i] = dy * ww + dx;
-            __syncthreads();
-        }
-    }
-    const int x = x0 + (int)(threadIdx.x % AO_TILE_W);
-    const int y = y0 + (int)(threadIdx.x / AO_TILE_W);
-    if (x >= W || y >= nbRows)
-        return;
-    const int index = y * W + x;
-    float occ = 0.f;
-    float4 local = pp[index].colorInfo;
-    float depth = local.w;
-    float c = 0.f;
-    if (tiled)
-    {
-        /* a tile whose window lies inside the frame needs no bounds test per tap */
-        const bool inside = wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow;
-        /* counted in an integer (at most 256: the float sum of the reference is the same number) */
-        /* a strip is rows [firstRow, firstRow + nbRows) of the frame: the tap's row is evaluated with the frame's y
-         * (the float addition rounds, and truncates towards zero, by the row's position in the frame) */
-        const int origin = -((wy0 + firstRow) * ww + wx0);
-        const float fx = (float)x, fy = (float)(y + firstRow);
-        int count = 0;
-        if (steady)
-        {
-            const float *centre = window + ((y - wy0) * ww + (x - wx0));
+            float occ = 0.f;
+            const float depth = local.w;
+            float c = 0.f;
+            if (tiled)
+            {
+                /* a tile whose window lies inside the frame needs no bounds test per tap */
+                const bool inside = wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow;
+                /* counted in an integer (at most 256: the float sum of the reference is the same number) */
+                /* a strip is rows [firstRow, firstRow + nbRows) of the frame: the tap's row is evaluated with the frame's y
+                 * (the float addition rounds, and truncates towards zero, by the row's position in the frame) */
+                const int origin = -((wy0 + firstRow) * ww + wx0);
+                const float fx = (float)x, fy = (float)(y + firstRow);
+                int count = 0;
+                if (steady)
+                {
+                    const float *centre = window + ((y - wy0) * ww + (x - wx0));
+                    const int distinct = nbDistinct;
+                    if (distinct <= 128)
+                    {
+                        for (int i = 0; i < distinct; ++i)
+                            count += (centre[distinctOffset[i]] >= depth) ? distinctWeight[i] : 0;
+                    }
+                    else
+                    {
 #pragma unroll 16
-            for (int i = 0; i < 256; ++i)
-                count += (centre[tapOffset[i]] >= depth) ? 1 : 0;
-        }
-        else if (inside)
-        {
+                        for (int i = 0; i < 256; ++i)
+                            count += (centre[tapOffset[i]] >= depth) ? 1 : 0;
+                    }
+                }
+                else if (inside)
+                {
 #pragma unroll 8
-            for (int i = 0; i < 256; ++i)
-            {
-                const int xx = (int)(fx + tapX[i]);
-                const int yy = (int)(fy + tapY[i]);
-                count += (window[__mul24(yy, ww) + xx + origin] >= depth) ? 1 : 0;
-            }
-        }
-        else
-        {
-            for (int i = 0; i < 256; ++i)
-            {
-                const int xx = (int)(fx + tapX[i]);
-                const int yy = (int)(fy + tapY[i]);
-                if (xx >= 0 && xx < W && yy - firstRow >= -halo.nbAbove && yy - firstRow < nbRows + halo.nbBelow)
-                    count += (window[__mul24(yy, ww) + xx + origin] >= depth) ? 1 : 0;
+                    for (int i = 0; i < 256; ++i)
+                    {
+                        const int xx = (int)(fx + tapX[i]);
+                        const int yy = (int)(fy + tapY[i]);
+                        count += (window[__mul24(yy, ww) + xx + origin] >= depth) ? 1 : 0;
+                    }
+                }
                 else
-                    count += 1;
-            }
-        }
-        occ = (float)count;
-        c = 256.f;
-    }
-    else
-    {
-        for (int i = 0; i < 256; ++i)
-        {
-            c += 1.f;
-            int xx = (int)(x + tapX[i]);
-            int yy = (int)((y + firstRow) + tapY[i]) - firstRow;
-            float tap;
-            if (aoDepthAt(pp, halo, W, nbRows, xx, yy, tap))
-            {
-                if (tap >= depth)
-                    occ += 1.f;
+                {
+                    for (int i = 0; i < 256; ++i)
+                    {
+                        const int xx = (int)(fx + tapX[i]);
+                        const int yy = (int)(fy + tapY[i]);
+                        if (xx >= 0 && xx < W && yy - firstRow >= -halo.nbAbove && yy - firstRow < nbRows + halo.nbBelow)
+                            count += (window[__mul24(yy, ww) + xx + origin] >= depth) ? 1 : 0;
+                        else
+                            count += 1;
+                    }
+                }
+                occ = (float)count;
+                c = 256.f;
             }
             else
-                occ += 1.f;
+            {
+                for (int i = 0; i < 256; ++i)
+                {
+                    c += 1.f;
+                    int xx = (int)(x + tapX[i]);
+                    int yy = (int)((y + firstRow) + tapY[i]) - firstRow;
+                    float tap;
+                    if (aoDepthAt(pp, halo, W, nbRows, xx, yy, tap))
+                    {
+                        if (tap >= depth)
+                            occ += 1.f;
+                    }
+                    else
+                        occ += 1.f;
+                }
+            }
+            occ /= (float)c;
+            occ += 0.3f;
+            v3 col = V(local.x, local.y, local.z);
+            if (occ < 1.f)
+            {
+                col.x *= occ;
+                col.y *= occ;
+                col.z *= occ;
+            }
+            if (si.pathTracingIteration > NB_MAX_ITERATIONS)
+            {
+                float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
+                col.x /= d;
+                col.y /= d;
+                col.z /= d;
+            }
+            saturate3(col);
+            makeColor(si, col, bitmap, index);
         }
+        __syncthreads(); /* the next tile's window goes where this one's is still being read */
     }
-    occ /= (float)c;
-    occ += 0.3f;
-    v3 col = V(local.x, local.y, local.z);
-    if (occ < 1.f)
-    {
-        col.x *= occ;
-        col.y *= occ;
-        col.z *= occ;
-    }
-    if (si.pathTracingIteration > NB_MAX_ITERATIONS)
-    {
-        float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
-        col.x /= d;
-        col.y /= d;
-        col.z /= d;
-    }
-    saturate3(col);
-    makeColor(si, col, bitmap, index);
 }
 
 /* CRT:1081-1120 */
@@ -786,6 +854,86 @@ __global__ __launch_bounds__(256) void k_buildLeafRecords(float4 *__restrict__ a
     out[1] = r1;
     out[2] = r2;
     out[3] = r3;
+}
+
+/* The thin copy of a node list (rt_device.h tightRay; scene_layout.h SceneArgs::tightLists): leaf by leaf.  A leaf
+ * whose primitives are all plain axis planes becomes the union of their rectangles, `margin` thick and `margin` wider,
+ * cut with the reference's box (never larger than it: a ray the thin box lets in, the reference's let in as well);
+ * every other node is copied.  k_tightenInner then makes the inner nodes the unions of the leaves below them. */
+__global__ __launch_bounds__(256) void k_tightenLeaves(float4 *__restrict__ arena, unsigned offNodes, unsigned offTight,
+                                                      unsigned offStart, unsigned offPrims, int nbNodes, float margin)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbNodes)
+        return;
+    float4 row0 = arena[offNodes + 2u * (unsigned)i], row1 = arena[offNodes + 2u * (unsigned)i + 1u];
+    const int nb = __float_as_int(row1.z);
+    if (nb > 0)
+    {
+        const int start = ((const int *)arena)[offStart + (unsigned)i];
+        float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+        bool plain = true;
+        for (int k = 0; k < nb && plain; ++k)
+        {
+            const float4 *prim = arena + offPrims + 8u * (unsigned)(start + k);
+            const float4 p = prim[ROW_P0_TYPE], s = prim[ROW_SIZE_MAT];
+            const int kind = (__float_as_int(p.w) >> PRIM_KIND_SHIFT) & 15;
+            plain = kind == KIND_PLANE_XY || kind == KIND_PLANE_YZ || kind == KIND_PLANE_XZ;
+            /* (a size is compared with a distance: its sign cannot make the rectangle larger than |size|) */
+            const float ex = kind == KIND_PLANE_YZ ? margin : fabsf(s.x) + margin;
+            const float ey = kind == KIND_PLANE_XZ ? margin : fabsf(s.y) + margin;
+            const float ez = kind == KIND_PLANE_XY ? margin : fabsf(s.z) + margin;
+            lx = fminf(lx, p.x - ex), hx = fmaxf(hx, p.x + ex);
+            ly = fminf(ly, p.y - ey), hy = fmaxf(hy, p.y + ey);
+            lz = fminf(lz, p.z - ez), hz = fmaxf(hz, p.z + ez);
+        }
+        /* (finite, ordered bounds only: anything else keeps the reference's box) */
+        plain = plain && lx <= hx && ly <= hy && lz <= hz && fabsf(lx) < 3.0e38f && fabsf(hx) < 3.0e38f && fabsf(ly) < 3.0e38f &&
+                fabsf(hy) < 3.0e38f && fabsf(lz) < 3.0e38f && fabsf(hz) < 3.0e38f;
+        if (plain)
+        {
+            const float nlx = fmaxf(row0.x, lx), nly = fmaxf(row0.y, ly), nlz = fmaxf(row0.z, lz);
+            const float nhx = fminf(row1.x, hx), nhy = fminf(row1.y, hy), nhz = fminf(row0.w, hz);
+            if (nlx <= nhx && nly <= nhy && nlz <= nhz)
+            {
+                row0 = make_float4(nlx, nly, nlz, nhz);
+                row1 = make_float4(nhx, nhy, row1.z, row1.w);
+            }
+        }
+    }
+    arena[offTight + 2u * (unsigned)i] = row0;
+    arena[offTight + 2u * (unsigned)i + 1u] = row1;
+}
+
+/* inner node i of the thin copy: the union of the leaves of its subtree (nodes i + 1 ... i + skip - 1: skip pointers
+ * are nested intervals), cut with its own box.  A group still passes whenever one of its members does. */
+__global__ __launch_bounds__(256) void k_tightenInner(float4 *__restrict__ arena, unsigned offTight, int nbNodes, int listLength)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbNodes)
+        return;
+    const float4 row0 = arena[offTight + 2u * (unsigned)i], row1 = arena[offTight + 2u * (unsigned)i + 1u];
+    const int nb = __float_as_int(row1.z), skip = __float_as_int(row1.w);
+    if (nb > 0 || skip <= 1)
+        return;
+    const int listEnd = (i / listLength + 1) * listLength; /* (several lists one behind the other: stay in this one) */
+    const int end = min(i + skip, listEnd);
+    float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+    for (int j = i + 1; j < end; ++j)
+    {
+        const float4 b = arena[offTight + 2u * (unsigned)j + 1u];
+        if (__float_as_int(b.z) <= 0)
+            continue;
+        const float4 a = arena[offTight + 2u * (unsigned)j];
+        lx = fminf(lx, a.x), ly = fminf(ly, a.y), lz = fminf(lz, a.z);
+        hx = fmaxf(hx, b.x), hy = fmaxf(hy, b.y), hz = fmaxf(hz, a.w);
+    }
+    const float nlx = fmaxf(row0.x, lx), nly = fmaxf(row0.y, ly), nlz = fmaxf(row0.z, lz);
+    const float nhx = fminf(row1.x, hx), nhy = fminf(row1.y, hy), nhz = fminf(row0.w, hz);
+    if (!(nlx <= nhx && nly <= nhy && nlz <= nhz))
+        return; /* no leaf below it, or bounds that are not numbers: the reference's box stays */
+    arena[offTight + 2u * (unsigned)i] = make_float4(nlx, nly, nlz, nhz);
+    arena[offTight + 2u * (unsigned)i + 1u] = make_float4(nhx, nhy, row1.z, row1.w);
 }
 
 /* maybeBuildOrderFreeLists' precondition, for the exact list as the arena holds it: every inner node holds its
@@ -1038,6 +1186,10 @@ struct Engine
     bool freeStale = false;     /* rotated on the device since it was built: not refitted, not walked */
     bool primsContained = false; /* every primitive lies inside its leaf's box (retagPrimitives) */
     bool opaqueShadows = false;  /* no transparent primitive, no textured plane (retagPrimitives) */
+    /* the thin copies of the walk-order list and of the order-free lists (tightenList; rt_device.h tightRay) */
+    bool plainPlanes = false;    /* the scene holds a plain axis plane: thin copies are worth making (retagPrimitives) */
+    float sceneExtent = 1.f;     /* max |coordinate| + |size| over the primitives, at least 1 */
+    bool tightCompact = false, tightFree = false; /* the copy behind that list is up to date */
     /* bounce rays on the order-free lists, checked (rt_device.h closestHitWalk): -1 the engine decides per frame
      * (shortRayListsChoice: with frames in flight), 0 / 1 forced */
     int shortRayListsMode = -1;
@@ -1604,10 +1756,15 @@ void retagPrimitives()
     const size_t n = g.hostPrims.size() / PRIM_ROWS;
     const bool noKinds = getenv("SOLR_HIP_NO_KINDS") != nullptr; /* tests: every primitive through the general tests */
     int features = 0;
-    bool contained = true, opaque = true;
+    bool contained = true, opaque = true, planes = false;
+    float extent = 1.f;
     for (size_t i = 0; i < n; ++i)
     {
         float4 *r = &g.hostPrims[PRIM_ROWS * i];
+        for (int row : {(int)ROW_P0_TYPE, (int)ROW_P1_INDEX, (int)ROW_P2})
+            for (float c : {r[row].x, r[row].y, r[row].z})
+                if (fabsf(c) < 3.0e38f) /* (a comparison with NaN is false: the extent stays a number) */
+                    extent = std::max(extent, fabsf(c));
         int tag, mat;
         memcpy(&tag, &r[ROW_P0_TYPE].w, 4);
         memcpy(&mat, &r[ROW_SIZE_MAT].w, 4);
@@ -1627,6 +1784,7 @@ void retagPrimitives()
         else if (type == ptCylinder || type == ptCone)
             kind = KIND_CYLINDER;
         r[ROW_P0_TYPE].w = bitsf(type | facts | (kind << PRIM_KIND_SHIFT));
+        planes = planes || kind == KIND_PLANE_XY || kind == KIND_PLANE_YZ || kind == KIND_PLANE_XZ;
         /* inside the box the reference's builder gives its leaf (GPUKernel.cpp:762-830: the vertices of a triangle,
          * p0 +- radius of a sphere, min / max (p0, p1) +- radius of a cylinder, p0 +- size of a plane; a cone's box
          * is built around p0 alone, a procedural sphere's surface is displaced, the others are not bounded by
@@ -1663,10 +1821,37 @@ void retagPrimitives()
         if (facts & PRIM_TEXTURED)
             features |= F_TEX;
     }
+    /* |p0| + |size| of the largest primitive, at least: the scale the thin leaves' margin is a 2^-10 of */
+    float reach = 0.f;
+    for (size_t i = 0; i < n; ++i)
+        for (float c : {g.hostPrims[PRIM_ROWS * i + ROW_SIZE_MAT].x, g.hostPrims[PRIM_ROWS * i + ROW_SIZE_MAT].y,
+                        g.hostPrims[PRIM_ROWS * i + ROW_SIZE_MAT].z})
+            if (fabsf(c) < 3.0e38f)
+                reach = std::max(reach, fabsf(c));
+    g.sceneExtent = extent + reach;
+    g.plainPlanes = planes;
     g.sceneFeatures = features;
     g.primsContained = contained && n > 0;
     g.opaqueShadows = opaque && n > 0;
     g.geometryDirty = true;
+}
+
+/* The thin copy of a node list behind it (rows offNodes + 2 n + 2 ...; rt_device.h tightRay): made where the scene has
+ * plain axis planes at all and the list is short enough for an inner node's thread to read its whole subtree (the
+ * room of a 100 k-triangle model keeps the reference's boxes).  false: there is no copy to walk. */
+bool tightenList(unsigned offNodes, unsigned offStart, int nbNodes, int listLength)
+{
+    static const bool off = getenv("SOLR_HIP_NO_TIGHT_LEAVES") != nullptr;
+    if (off || !g.plainPlanes || nbNodes <= 0 || listLength <= 0 || listLength > 65536 || !ok())
+        return false;
+    float4 *arena = (float4 *)g.geometry.ptr;
+    const unsigned offTight = offNodes + 2u * (unsigned)nbNodes + 2u;
+    const float margin = g.sceneExtent * (1.f / 1024.f);
+    const dim3 grid((unsigned)((nbNodes + 255) / 256));
+    hipLaunchKernelGGL(k_tightenLeaves, grid, dim3(256), 0, g.stream, arena, offNodes, offTight, offStart, g.offPrims, nbNodes, margin);
+    hipLaunchKernelGGL(k_tightenInner, grid, dim3(256), 0, g.stream, arena, offTight, nbNodes, listLength);
+    HIPCHECK(hipGetLastError());
+    return ok();
 }
 
 /* the leaf records of both node lists from the primitive records as the arena holds them now */
@@ -1687,6 +1872,9 @@ void buildLeafRecords()
         hipLaunchKernelGGL(k_buildLeafRecords, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, arena,
                            g.offBoxesFree, g.offBoxStartFree, g.offPrims, g.offLeafFree, nf);
     HIPCHECK(hipGetLastError());
+    /* the thin copies follow the bounds and the primitives they were made from (an upload, a rotation on the device) */
+    g.tightCompact = tightenList(g.offBoxesCompact, g.offBoxStartCompact, nc, nc);
+    g.tightFree = nf > 0 && !g.freeStale && tightenList(g.offBoxesFree, g.offBoxStartFree, nf, nf / 8);
     HIPCHECK(hipStreamSynchronize(g.stream));
 }
 
@@ -1694,7 +1882,7 @@ void buildLeafRecords()
 static unsigned layoutFreeLists(unsigned row)
 {
     g.offBoxesFree = row;
-    row += (unsigned)g.freeRows + 2u; /* (one pad record, as behind every node list) */
+    row += 2u * ((unsigned)g.freeRows + 2u); /* (one pad record, as behind every node list; then the thin copy, padded alike) */
     g.offBoxStartFree = row * 4;
     row += (unsigned)((g.freeRows / 2 + 3) / 4);
     row = (row + 3u) & ~3u; /* leaf records: one 64-byte line per node */
@@ -1730,6 +1918,7 @@ static void appendFreeLists()
         hipLaunchKernelGGL(k_buildLeafRecords, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, (float4 *)g.geometry.ptr,
                            g.offBoxesFree, g.offBoxStartFree, g.offPrims, g.offLeafFree, nf);
     HIPCHECK(hipGetLastError());
+    g.tightFree = nf > 0 && tightenList(g.offBoxesFree, g.offBoxStartFree, nf, nf / 8);
     HIPCHECK(hipStreamSynchronize(g.stream));
     phase.mark("geometry: lists appended");
     if (ok())
@@ -1761,7 +1950,7 @@ void flushGeometry()
     g.offBoxes = row;
     row += (unsigned)g.hostBoxes.size() + 2u;
     g.offBoxesCompact = row;
-    row += (unsigned)g.hostBoxesCompact.size() + 2u;
+    row += 2u * ((unsigned)g.hostBoxesCompact.size() + 2u); /* ... and its thin copy (tightenList), padded alike */
     row = (row + 3u) & ~3u; /* primitive records start on a 64-byte line */
     g.offPrims = row;
     row += (unsigned)g.hostPrims.size();
@@ -1871,7 +2060,19 @@ SceneArgs makeScene(bool exactNodes)
         S.opaqueShadows = g.opaqueShadows ? 1 : 0;
         S.shortRayLists = shortRayListsChoice() ? 1 : 0;
     }
+    /* the thin copies behind the lists this frame walks (set by tightListsFor: they also depend on the frame) */
+    S.tightLists = 0;
     return S;
+}
+
+/* may the walks of a frame with this SceneInfo take the thin copies of the lists S names (rt_device.h tightRay)? */
+int tightListsFor(const SceneArgs &S, const SceneInfo &sceneInfo, bool exactNodes)
+{
+    if (exactNodes || g.variant == 8 || !g.tightCompact || !sceneInfo.extendedGeometry)
+        return 0;
+    if (S.nbBoxesFree > 0 && !g.tightFree)
+        return 0;
+    return (sceneInfo.viewDistance > 0.f && sceneInfo.viewDistance <= 64.f * g.sceneExtent) ? 1 : 0;
 }
 
 /* The texel fetch (rt_device.h fetchTexel, skyboxMapping) indexes the atlas with textureOffset + index % texels
@@ -1975,7 +2176,8 @@ void launchPostProcess(const SceneInfo &sceneInfo, const PostProcessingInfo &ppI
         }
         if (ok())
             hipLaunchKernelGGL(k_ambientOcclusion,
-                               dim3(((sceneInfo.size.x + AO_TILE_W - 1) / AO_TILE_W) * ((nbRows + AO_TILE_H - 1) / AO_TILE_H)),
+                               dim3((((sceneInfo.size.x + AO_TILE_W - 1) / AO_TILE_W) * ((nbRows + AO_TILE_H - 1) / AO_TILE_H) +
+                                     AO_TILES_PER_GROUP - 1) / AO_TILES_PER_GROUP),
                                pblock, 0, stream, sceneInfo, ppInfo, nbRows,
                                (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
                                g.randoms.ptr ? g.nbRandoms : 0L, bitmap, halo, firstRow);
@@ -2076,6 +2278,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     if (!ok())
         return;
     SceneArgs S = makeScene(exactNodes);
+    S.tightLists = tightListsFor(S, sceneInfo, exactNodes);
     if (exactNodes)
         S.nbBoxes = objects.x;
     S.nbPrimitives = objects.y;
@@ -2494,6 +2697,7 @@ int residentScene(const SceneInfo &sceneInfo, bool exactNodes, SceneArgs *S, int
     if (!ok())
         return -1;
     *S = makeScene(exactNodes);
+    S->tightLists = tightListsFor(*S, sceneInfo, exactNodes);
     *features = neededFeatures(sceneInfo, false);
     *deepList = S->nbBoxes > 1024;
     *stream = flightStream(0);

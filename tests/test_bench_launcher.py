@@ -96,16 +96,28 @@ def test_two_rank_rehearsal_of_the_default_job(solr):
     assert rows[0][0] == 0 and rows[0][1] + rows[1][1] == 360 and rows[1][0] == rows[0][1] and rows[0][1] % 8 == 0
     assert [r["equal_strips"]["rows"] for r in cfg["per_rank"]] == [[0, 180], [180, 180]]
     assert cfg["slowest_rank"] in (0, 1) and cfg["gather_only_ms"] > 0
-    assert set(cfg["rates_mrays_per_s"]) == {"balanced_strips_native_gather", "equal_strips_native_gather"}
+    assert {"balanced_strips_native_gather", "equal_strips_native_gather"} <= set(cfg["rates_mrays_per_s"])
     assert cfg["rates_mrays_per_s"]["balanced_strips_native_gather"] == pytest.approx(line["value"], rel=1e-3)
+    # the default job times both communicator modes and both delivery routes in short segments, checks each one's frame
+    # against the one-GPU frame, and runs the headline on the fastest that passed
+    sweep = cfg["mode_sweep"]
+    combos = [n for n in sweep if n != "headline_runs_on"]
+    assert len(combos) == 4 and all(sweep[n]["frame_equals_single_gpu"] is True and sweep[n]["ms_per_step"] > 0 for n in combos)
+    assert sweep["headline_runs_on"] == min(combos, key=lambda n: sweep[n]["ms_per_step"])
+    assert {sweep[n]["rccl_communicators"] for n in combos} == {1, 4}
+    assert all("sweep_" + n in cfg["rates_mrays_per_s"] for n in combos)
     assert "rehearsal" in cfg and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
     assert cfg["step_ms_spread"]["min"] <= cfg["step_ms_spread"]["median"] <= cfg["step_ms_spread"]["max"]
     # ms_per_step IS the median region, the spread its fastest and slowest: it brackets the headline by construction
     assert line["regions"] == 3 == cfg["step_ms_spread"]["regions"]
     assert cfg["step_ms_spread"]["median"] == pytest.approx(line["ms_per_step"], rel=1e-3)
-    # every frame of the timed regions was delivered to rank 0's host memory (the gathered frame, pipelined)
-    assert "one image the ranks' processes share" in cfg["delivery"] and cfg["frames_delivered"] >= 3 * 12
-    assert cfg["rccl_communicators"] == 1 and "one for everything" in cfg["rccl_communicator_mode"]
+    # every frame of the timed regions was delivered to rank 0's host memory
+    assert cfg["frames_delivered"] >= 3 * 12
+    if "strips" in sweep["headline_runs_on"]:
+        assert "one image the ranks' processes share" in cfg["delivery"]
+    else:
+        assert "gather on rank 0" in cfg["delivery"]
+    assert cfg["rccl_communicators"] == (4 if "per_flight" in sweep["headline_runs_on"] else 1)
 
 
 @pytest.mark.gpu
@@ -116,6 +128,9 @@ def test_two_rank_rehearsal_with_one_communicator_per_flight(solr):
     cfg = line["config"]
     assert cfg["rccl_ranks"] == 2 and cfg["rccl_communicators"] == 4 and "one per frame in flight" in cfg["rccl_communicator_mode"]
     assert cfg["gathered_equals_single_gpu"] is True
+    # the environment fixed the communicator mode: only the delivery routes were swept
+    assert len([n for n in cfg["mode_sweep"] if n != "headline_runs_on"]) == 2
+    assert all("communicator_per_flight" in n for n in cfg["mode_sweep"] if n != "headline_runs_on")
 
 
 @pytest.mark.gpu
@@ -135,6 +150,10 @@ def test_a_box_that_cannot_share_the_host_image_falls_back_to_the_gathered_frame
     cfg = line["config"]
     assert "solr_hip_image_share failed" in cfg["delivery_fallback"] and "gather on rank 0" in cfg["delivery"]
     assert cfg["gathered_equals_single_gpu"] is True and cfg["frames_delivered"] >= 3 * 12
+    # the routes that wanted the shared image say why they were left out; the job ran on a gathered one
+    sweep = cfg["mode_sweep"]
+    assert "gathered" in sweep["headline_runs_on"]
+    assert all("skipped" in sweep[n] for n in sweep if "strips" in n and n != "headline_runs_on")
 
 
 @pytest.mark.gpu
@@ -147,6 +166,29 @@ def test_two_rank_rehearsal_of_cfg4(solr):
     assert line["n_gpus"] == 2 and cfg["gathered_equals_single_gpu"] is True and cfg["rccl_ranks"] == 2
     rows = [r["rows"] for r in cfg["per_rank"]]
     assert rows[0][1] + rows[1][1] == 2160
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_the_whole_job_over_real_rccl_where_the_box_has_the_gpus(solr, world):
+    """`python bench.py --gpus N` as the driver starts it, on N REAL GPUs over the real RCCL - runs by itself on the first
+    box that has them (the test boxes have one GPU: skipped): the four combinations of the mode sweep, the frame of
+    every one of them equal to the one-GPU frame, the headline on the fastest"""
+    if solr.hip_lib().solr_hip_device_count() < world:
+        pytest.skip("needs %d GPUs" % world)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SOLR_BENCH_SHARE_GPU",
+                                                            "SOLR_HIP_RCCL_LIBRARY")}
+    env.update(SOLR_BENCH_REGIONS="5", MASTER_PORT=str(29650 + world))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "5",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == world and cfg["rccl_ranks"] == world and cfg["gathered_equals_single_gpu"] is True
+    assert cfg["delivered_frame_equals_oracle"] is True and cfg["rays_equal_oracle_count"] is True
+    sweep = cfg["mode_sweep"]
+    assert all(sweep[n].get("frame_equals_single_gpu") is True for n in sweep if n != "headline_runs_on"), sweep
+    assert "rehearsal" not in cfg
 
 
 @pytest.mark.gpu

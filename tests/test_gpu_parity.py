@@ -201,6 +201,23 @@ def test_post_processing(solr, oracle, pp):
     assert_parity(compare_frames(pp_, ids, rgb, opp, oids, orgb))
 
 
+@pytest.mark.parametrize("param2", [10.0, 120.0, 500.0, 2500.0])
+def test_ambient_occlusion_taps_that_share_a_depth_are_one_comparison(solr, oracle, param2):
+    """k_ambientOcclusion on a frame wide enough for tiles whose 256 tap offsets are the same for every pixel (x and y
+    inside one binade): the workgroup dedupes the offsets and a pixel compares once per DISTINCT offset, weighted by
+    the number of taps that share it - four offsets for param2 = 10 (cfg4's), dozens for 120 and 500, the plain loop
+    beyond 128 (2500).  The count is an integer either way: the oracle's image, every pixel"""
+    k = solr.Kernel(engine="hip")
+    k.set_post_processing(type=solr_mod.ppe_ambientOcclusion, param1=0.0, param2=param2, param3=0)
+    solr.scenes.cornell(k, width=640, height=208, iterations=1)
+    pp_, ids, rgb = gpu_frame(k)
+    opp, oids, orgb, counts, status = oracle_frame(k, oracle)
+    k.finalize()
+    assert status == 0
+    assert_parity(compare_frames(pp_, ids, rgb, opp, oids, orgb))
+    assert len(np.unique(rgb.reshape(-1, 3), axis=0)) > 50
+
+
 def test_row_strips_equal_the_full_frame(solr, oracle):
     """what each rank of a multi-GPU run renders: rows [first, first+count) with its own buffers"""
     W, H = 96, 70
@@ -902,4 +919,63 @@ def test_deep_bounces_keep_three_stack_slots_in_lds_and_the_rest_in_hbm(solr, or
         hip.solr_hip_set_variant(0)
         hip.solr_hip_set_frames_in_flight(1)
         hip.solr_hip_set_strip(0, -1)
+        k.finalize()
+
+
+def _room_with_a_view(k, width=200, height=136, iterations=3, angles=(0.0, 0.0, 0.0), eye=(0.0, 0.0, -15000.0), **info):
+    """the Cornell room seen from `eye` with the camera turned by `angles`"""
+    solr_mod.scenes.cornell(k, width=width, height=height, iterations=iterations, **info)
+    k.set_camera(eye, angles=angles)
+
+
+@pytest.mark.parametrize("view", ["straight", "turned", "from-a-corner", "outside-the-room", "deep"],)
+def test_thin_leaves_of_plain_planes_change_nothing(solr, oracle, view):
+    """The reference gives a wall the box p0 +- size in all three axes - half the room - and every ray entered all six
+    walls.  Long rays without a zero direction component walk a copy of the lists in which such leaves are as thin as
+    their planes (rt_device.h tightRay): the frame is the frame on the reference's boxes (variant 8) bit for bit, and
+    the oracle's - straight on (a column and a row of rays have a zero component: those waves take the reference's
+    boxes), turned, from a corner of the room, from outside it, ten bounces deep."""
+    hip = solr.hip_lib()
+    kw = {"straight": dict(), "turned": dict(angles=(0.21, -0.37, 0.11)),
+          "from-a-corner": dict(eye=(-17000.0, 30000.0, -17000.0), angles=(0.5, 0.7, 0.0)),
+          "outside-the-room": dict(eye=(3000.0, 2000.0, -45000.0)), "deep": dict(iterations=10, angles=(0.1, 0.2, 0.0))}[view]
+    k = solr.Kernel(engine="hip")
+    _room_with_a_view(k, **kw)
+    try:
+        hip.solr_hip_set_variant(0)
+        thin = [np.array(a, copy=True) for a in gpu_frame(k)]
+        assert_frame_pinned(k, oracle, thin, 2, "thin leaves, " + view)
+        hip.solr_hip_set_variant(8)
+        fat = [np.array(a, copy=True) for a in gpu_frame(k)]
+        assert np.array_equal(thin[0].view(np.uint32), fat[0].view(np.uint32))
+        assert np.array_equal(thin[1], fat[1]) and np.array_equal(thin[2], fat[2])
+        # ... and the thin copies were there to be walked (the census counts leaf tests on the reference's list: the
+        # walk record says which list a walk took)
+        hip.solr_hip_set_variant(0)
+    finally:
+        hip.solr_hip_set_variant(0)
+        k.finalize()
+
+
+def test_thin_leaves_follow_a_rotation_on_the_device(solr, oracle):
+    """device-side rotations refit the lists and rebuild the leaf records: the thin copies are made again from the
+    rotated planes (a rotated axis plane is still tested as an axis plane at its new p0)"""
+    import ctypes as C
+    hip = solr.hip_lib()
+    k = solr.Kernel(engine="hip")
+    _room_with_a_view(k, angles=(0.1, 0.3, 0.0))
+    try:
+        k.render()
+        for step in range(3):
+            k.rotate_primitives((0.0, 1000.0, 0.0), (0.02 * (step + 1), 0.05, -0.03))
+            hip.solr_hip_set_variant(0)
+            thin = [np.array(a, copy=True) for a in gpu_frame(k)]
+            hip.solr_hip_set_variant(8)
+            fat = [np.array(a, copy=True) for a in gpu_frame(k)]
+            hip.solr_hip_set_variant(0)
+            assert np.array_equal(thin[0].view(np.uint32), fat[0].view(np.uint32)), step
+            assert np.array_equal(thin[1], fat[1]) and np.array_equal(thin[2], fat[2]), step
+        assert_frame_pinned(k, oracle, thin, 2, "thin leaves after rotations")
+    finally:
+        hip.solr_hip_set_variant(0)
         k.finalize()

@@ -87,11 +87,24 @@ def test_ranks_with_one_communicator_per_flight(solr):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_ranks_over_rccl_assemble_the_one_gpu_frame(solr, world):
+    """the same worker over the REAL library, one GPU per rank: runs by itself - no flag - on the first box that has the
+    GPUs (the test boxes have one: skipped there)"""
     if solr.hip_lib().solr_hip_device_count() < world:
         pytest.skip("needs %d GPUs: RCCL refuses two ranks on one device" % world)
     check_partitions(run_ranks(world, "rccl"))
+
+
+@pytest.mark.gpu
+def test_ranks_over_rccl_with_one_communicator_per_flight(solr):
+    """ncclCommSplit per frame in flight and grouped send / receive on several streams over the real library"""
+    world = min(4, solr.hip_lib().solr_hip_device_count())
+    if world < 2:
+        pytest.skip("needs 2 GPUs: RCCL refuses two ranks on one device")
+    reports = run_ranks(world, "rccl", SOLR_HIP_COMM_PER_FLIGHT="1")
+    check_partitions(reports)
+    assert all(rep["communicators"] == 4 for rep in reports), reports
 
 
 # ---- the stand-in transport itself, on CPU (host buffers) --------------------------------------------------------
