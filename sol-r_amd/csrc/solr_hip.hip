@@ -404,11 +404,12 @@ __device__ __forceinline__ bool aoDepthAt(const PixelRecord *__restrict__ pp, co
 /* tiles a workgroup renders one after the other (a run along x): what does not depend on the tile - the tap pairs,
  * their reach and, inside one binade, the deduped offsets - is made once per run instead of once per 256 pixels */
 #define AO_TILES_PER_GROUP 8
+#define AO_AHEAD 4 /* window depths a thread holds for the next tile: windows of up to 256 x AO_AHEAD floats are asked for a tile ahead */
 __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
                                                           const PixelRecord *__restrict__ pp,
                                                           const float *__restrict__ randoms, long nbRandoms,
                                                           unsigned char *__restrict__ bitmap, const DepthHalo halo,
-                                                          int firstRow)
+                                                          int firstRow, int windowFloats)
 {
     /* The 256 taps of a pixel sit at x + X * param2 * randoms[i % wh] / 10.f, y + Y * param2 * randoms[(i + 100)
      * % wh] / 10.f (CRT:1146-1153): the offsets depend on the tap, not on the pixel.  The workgroup's 256
@@ -423,11 +424,16 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
      * that reach beyond about 40 pixels) is gathered from memory as before. */
     __shared__ float tapX[256], tapY[256];
     __shared__ int reach[2];
-    __shared__ float window[AO_WINDOW_FLOATS];
+    /* (dynamic: the host sizes the window for the reach the random buffer and param2 allow - 432 floats for cfg4's
+     * taps instead of 32 KB - so that eight workgroups share a CU instead of four: a tile's work is a chain of waits) */
+    extern __shared__ float window[];
     __shared__ int tapOffset[256];
-    __shared__ unsigned table[512];
-    __shared__ int distinctOffset[256], distinctWeight[256];
+    __shared__ unsigned block[1024]; /* the hash table and the deduped offsets of a steady tile, or the four histograms of a tile in two binades */
+    unsigned *const table = block;
+    int *const distinctOffset = (int *)block + 512, *const distinctWeight = (int *)block + 768;
     __shared__ int nbDistinct;
+    __shared__ int cls[8];       /* a tile in two binades: {smallest, largest exponent of its regular columns, a column of each; the same for rows} */
+    __shared__ float tapRange[16]; /* per wave: min / max of tapX, min / max of tapY */
     const int W = si.size.x;
     const int wh = W * si.size.y; /* the frame's, also when this rank renders a strip of it */
     const int tilesX = (W + AO_TILE_W - 1) / AO_TILE_W;
@@ -451,25 +457,57 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
         const float ax = fabsf(tx), ay = fabsf(ty);
         int cx = (ax < 1.0e6f) ? (int)ax + 2 : (1 << 20);
         int cy = (ay < 1.0e6f) ? (int)ay + 2 : (1 << 20);
+        float lowX = tx, highX = tx, lowY = ty, highY = ty;
         for (int off = 32; off > 0; off >>= 1) /* (a wave's maximum first: 8 atomics on one word instead of 512) */
         {
             cx = max(cx, __shfl_xor(cx, off, 64));
             cy = max(cy, __shfl_xor(cy, off, 64));
+            lowX = fminf(lowX, __shfl_xor(lowX, off, 64)), highX = fmaxf(highX, __shfl_xor(highX, off, 64));
+            lowY = fminf(lowY, __shfl_xor(lowY, off, 64)), highY = fmaxf(highY, __shfl_xor(highY, off, 64));
         }
         if ((i & 63) == 0)
         {
             atomicMax(&reach[0], cx);
             atomicMax(&reach[1], cy);
+            tapRange[4 * (i >> 6)] = lowX, tapRange[4 * (i >> 6) + 1] = highX;
+            tapRange[4 * (i >> 6) + 2] = lowY, tapRange[4 * (i >> 6) + 3] = highY;
         }
     }
     __syncthreads();
     const int rx = reach[0], ry = reach[1];
     const int ww = AO_TILE_W + 2 * rx, wrows = AO_TILE_H + 2 * ry;
-    const bool tiled = rx < 4096 && ry < 4096 && ww * wrows <= AO_WINDOW_FLOATS;
+    const bool tiled = rx < 4096 && ry < 4096 && ww * wrows <= windowFloats && ww * wrows <= AO_WINDOW_FLOATS;
+    /* (a NaN among the taps makes fminf / fmaxf skip it; such a buffer has an enormous reach and is not tiled) */
+    const float tapLowX = fminf(fminf(tapRange[0], tapRange[4]), fminf(tapRange[8], tapRange[12]));
+    const float tapHighX = fmaxf(fmaxf(tapRange[1], tapRange[5]), fmaxf(tapRange[9], tapRange[13]));
+    const float tapLowY = fminf(fminf(tapRange[2], tapRange[6]), fminf(tapRange[10], tapRange[14]));
+    const float tapHighY = fmaxf(fmaxf(tapRange[3], tapRange[7]), fmaxf(tapRange[11], tapRange[15]));
+    const int binsX = 2 * rx + 1, binsY = 2 * ry + 1;
     int tableKey = 0; /* the binades (of x and of the frame's y) the deduped offsets in LDS were made for; 0: none */
+    const bool pipelined = tiled && ww * wrows <= 256 * AO_AHEAD;
+    float aheadDepth[AO_AHEAD];
+    float4 aheadLocal = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ahead = [&](int t) { /* this thread's share of tile t's window, and its own pixel's record */
+        const int tx0 = (t % tilesX) * AO_TILE_W, ty0 = (t / tilesX) * AO_TILE_H;
+#pragma unroll
+        for (int k = 0; k < AO_AHEAD; ++k)
+        {
+            const int i = (int)threadIdx.x + 256 * k;
+            float d = 0.f;
+            if (i < ww * wrows)
+                aoDepthAt(pp, halo, W, nbRows, tx0 - rx + i % ww, ty0 - ry + i / ww, d);
+            aheadDepth[k] = d;
+        }
+        const int px = tx0 + (int)(threadIdx.x % AO_TILE_W), py = ty0 + (int)(threadIdx.x / AO_TILE_W);
+        aheadLocal = pp[(px < W && py < nbRows) ? py * W + px : 0].colorInfo;
+    };
     for (int run = 0; run < AO_TILES_PER_GROUP; ++run)
     {
-        const int tile = (int)blockIdx.x * AO_TILES_PER_GROUP + run;
+        /* tile `run` of this workgroup: a stride of the grid apart, not side by side.  The tiles of the frame's first
+         * tile row and column (x or y below the tile's size: regular columns of up to five binades) take the per-pixel
+         * loop, 30 times the cost of a tile - side by side they were eight of them in one workgroup, and that
+         * workgroup was the kernel: 0.52 ms whatever the other 4 000 did */
+        const int tile = (int)blockIdx.x + run * (int)gridDim.x;
         if (tile >= nbTiles)
             break;
         const int x0 = (tile % tilesX) * AO_TILE_W;
@@ -479,15 +517,31 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
         const int y = y0 + (int)(threadIdx.x / AO_TILE_W);
         const bool mine = x < W && y < nbRows;
         const int index = mine ? y * W + x : 0;
-        const float4 local = pp[index].colorInfo; /* (asked for before the window: the two waits overlap) */
-        if (tiled)
-            for (int i = threadIdx.x; i < ww * wrows; i += 256)
-            {
-                const int gx = wx0 + i % ww, gy = wy0 + i / ww;
-                float d = 0.f;
-                aoDepthAt(pp, halo, W, nbRows, gx, gy, d);
-                window[i] = d;
-            }
+        /* A window of up to 1 024 depths (taps that reach 12 pixels) is asked for ONE TILE AHEAD, into registers, behind
+         * the barrier below: the loads of tile n + 1 are in flight while tile n is compared and stored, and a tile is
+         * no longer two memory latencies long. */
+        if (pipelined && run == 0)
+            ahead(tile);
+        float4 local;
+        if (pipelined)
+        {
+            local = aheadLocal;
+            for (int k = 0; k < AO_AHEAD; ++k)
+                if ((int)threadIdx.x + 256 * k < ww * wrows)
+                    window[threadIdx.x + 256 * k] = aheadDepth[k];
+        }
+        else
+        {
+            local = pp[index].colorInfo; /* (asked for before the window: the two waits overlap) */
+            if (tiled)
+                for (int i = threadIdx.x; i < ww * wrows; i += 256)
+                {
+                    const int gx = wx0 + i % ww, gy = wy0 + i / ww;
+                    float d = 0.f;
+                    aoDepthAt(pp, halo, W, nbRows, gx, gy, d);
+                    window[i] = d;
+                }
+        }
         /* Steady taps.  (int)(x + t) - x is the same for every x of the tile when x and all the sums x + t lie in one
          * binade: x is a multiple of that binade's ulp U (a power of two below 1, so x / U is even and ties round the
          * same way), hence RN(x + t) = x + RN_U(t), and the sums are positive, so the truncation is a floor.  Then a
@@ -548,7 +602,76 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
             }
             tableKey = steady ? key : tableKey;
         }
+        /* A tile in TWO binades (it straddles a power of two in x, in the frame's y, or both: a fifth of a 4K frame's
+         * tiles - and until this was here 80 % of the kernel's time, 256 float additions and conversions per pixel).  A
+         * pixel's column is REGULAR when x, x + the smallest tap and x + the largest tap lie in one binade (the sums
+         * are monotonic in the tap): for such columns of one binade (int)(x + t) - x is the same, by the argument
+         * above; likewise rows.  A tile has regular columns of at most two binades and regular rows of at most two:
+         * four histograms of tap offsets, made once per tile with the reference's own expression on one column and one
+         * row of each class, serve every pixel whose column and row are regular - one read and one compare per bin
+         * (25 for cfg4's taps) instead of 256 evaluations.  The pixels of the irregular columns and rows (cfg4: the one
+         * column AT the power of two, whose sums with negative taps fall into the binade below) keep the per-pixel loop. */
+        const int e0x = (int)(__float_as_uint((float)x) >> 23), e0y = (int)(__float_as_uint((float)(y + firstRow)) >> 23);
+        const bool regularX = x >= 1 && (int)(__float_as_uint((float)x + tapLowX) >> 23) == e0x &&
+                              (int)(__float_as_uint((float)x + tapHighX) >> 23) == e0x;
+        const bool regularY = y + firstRow >= 1 && (int)(__float_as_uint((float)(y + firstRow) + tapLowY) >> 23) == e0y &&
+                              (int)(__float_as_uint((float)(y + firstRow) + tapHighY) >> 23) == e0y;
+        const bool windowInside = tiled && wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow;
+        bool classed = tiled && !steady && binsX * binsY <= 256;
+        if (classed)
+        {
+            const int i = threadIdx.x;
+            tableKey = 0; /* (the histograms take the place of the steady tiles' table) */
+            if (i < 8)
+                cls[i] = (i == 0 || i == 2 || i == 4 || i == 6) ? 0x7fffffff : -1;
+            block[i] = block[i + 256] = block[i + 512] = block[i + 768] = 0u;
+            if (i < binsX * binsY)
+                tapOffset[i] = (i / binsX - ry) * ww + (i % binsX - rx);
+            __syncthreads();
+            /* (thread i of the first row of the tile speaks for column i, thread 32 r for row r) */
+            if (i < AO_TILE_W && regularX)
+            {
+                atomicMin(&cls[0], e0x);
+                atomicMax(&cls[1], e0x);
+            }
+            if (i % AO_TILE_W == 0 && regularY)
+            {
+                atomicMin(&cls[4], e0y);
+                atomicMax(&cls[5], e0y);
+            }
+            __syncthreads();
+            if (i < AO_TILE_W && regularX)
+            {
+                if (e0x == cls[0])
+                    atomicMin(&cls[2], x);
+                if (e0x == cls[1])
+                    atomicMax(&cls[3], x);
+            }
+            if (i % AO_TILE_W == 0 && regularY)
+            {
+                if (e0y == cls[4])
+                    atomicMin(&cls[6], y + firstRow);
+                if (e0y == cls[5])
+                    atomicMax(&cls[7], y + firstRow);
+            }
+            __syncthreads();
+            classed = cls[1] >= 0 && cls[5] >= 0 && cls[1] - cls[0] <= 1 && cls[5] - cls[4] <= 1;
+            if (classed)
+            {
+                int dx[2], dy[2];
+                for (int c = 0; c < 2; ++c)
+                {
+                    const int xr = c ? cls[3] : cls[2], yr = c ? cls[7] : cls[6];
+                    dx[c] = (int)((float)xr + tapX[i]) - xr;
+                    dy[c] = (int)((float)yr + tapY[i]) - yr;
+                }
+                for (int c = 0; c < 4; ++c)
+                    atomicAdd(&block[c * 256 + (dy[c & 1] + ry) * binsX + (dx[c >> 1] + rx)], 1u);
+            }
+        }
         __syncthreads(); /* the window is in LDS, and so are the offsets */
+        if (pipelined && run + 1 < AO_TILES_PER_GROUP && tile + (int)gridDim.x < nbTiles)
+            ahead(tile + (int)gridDim.x);
         if (mine)
         {
             float occ = 0.f;
@@ -580,6 +703,28 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
                             count += (centre[tapOffset[i]] >= depth) ? 1 : 0;
                     }
                 }
+                else if (classed && regularX && regularY)
+                {
+                    const float *centre = window + ((y - wy0) * ww + (x - wx0));
+                    const unsigned *hist = block + 256 * ((e0x == cls[0] ? 0 : 2) + (e0y == cls[4] ? 0 : 1));
+                    const int bins = binsX * binsY;
+                    if (windowInside)
+                        for (int b = 0; b < bins; ++b)
+                        {
+                            const int weight = (int)hist[b];
+                            if (weight)
+                                count += (centre[tapOffset[b]] >= depth) ? weight : 0;
+                        }
+                    else /* a tile at the frame's edge: a tap that lands outside the frame (or the strip's halo) counts, CRT:1164-1165 */
+                        for (int b = 0; b < bins; ++b)
+                        {
+                            const int weight = (int)hist[b];
+                            const int xx = x + b % binsX - rx, yy = y + b / binsX - ry;
+                            const bool in = xx >= 0 && xx < W && yy >= -halo.nbAbove && yy < nbRows + halo.nbBelow;
+                            if (weight)
+                                count += (!in || centre[tapOffset[b]] >= depth) ? weight : 0;
+                        }
+                }
                 else if (inside)
                 {
 #pragma unroll 8
@@ -592,14 +737,16 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
                 }
                 else
                 {
+                    /* (branch-free, so that the loop unrolls and its LDS reads overlap: a tap outside the frame reads cell 0
+                     * of the window and counts whatever it holds) */
+#pragma unroll 8
                     for (int i = 0; i < 256; ++i)
                     {
                         const int xx = (int)(fx + tapX[i]);
                         const int yy = (int)(fy + tapY[i]);
-                        if (xx >= 0 && xx < W && yy - firstRow >= -halo.nbAbove && yy - firstRow < nbRows + halo.nbBelow)
-                            count += (window[__mul24(yy, ww) + xx + origin] >= depth) ? 1 : 0;
-                        else
-                            count += 1;
+                        const bool in = xx >= 0 && xx < W && yy - firstRow >= -halo.nbAbove && yy - firstRow < nbRows + halo.nbBelow;
+                        const float tap = window[in ? __mul24(yy, ww) + xx + origin : 0];
+                        count += (!in || tap >= depth) ? 1 : 0;
                     }
                 }
                 occ = (float)count;
@@ -2174,13 +2321,19 @@ void launchPostProcess(const SceneInfo &sceneInfo, const PostProcessingInfo &ppI
                                   nbRows, sceneInfo.size.y, wanted, &halo);
             }
         }
+        /* the window the taps of this random buffer and this param2 can need (the kernel takes its own, exact reach and
+         * gathers from memory if this should ever be too small): |tap| <= 16 |param2| max|random| / 10 */
+        const float aoReach = 16.f * fabsf(ppInfo.param2) * g.randomsReach / 10.f;
+        const int aoR = aoReach < 4096.f ? (int)aoReach + 3 : 4096;
+        const long aoCells = (long)(AO_TILE_W + 2 * aoR) * (AO_TILE_H + 2 * aoR);
+        const int aoWindow = (int)std::min<long>(std::max<long>(aoCells, 64), AO_WINDOW_FLOATS);
         if (ok())
             hipLaunchKernelGGL(k_ambientOcclusion,
                                dim3((((sceneInfo.size.x + AO_TILE_W - 1) / AO_TILE_W) * ((nbRows + AO_TILE_H - 1) / AO_TILE_H) +
                                      AO_TILES_PER_GROUP - 1) / AO_TILES_PER_GROUP),
-                               pblock, 0, stream, sceneInfo, ppInfo, nbRows,
+                               pblock, (size_t)aoWindow * sizeof(float), stream, sceneInfo, ppInfo, nbRows,
                                (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
-                               g.randoms.ptr ? g.nbRandoms : 0L, bitmap, halo, firstRow);
+                               g.randoms.ptr ? g.nbRandoms : 0L, bitmap, halo, firstRow, aoWindow);
     }
     else if (ppInfo.type == ppe_depthOfField)
         hipLaunchKernelGGL(k_depthOfField, pgrid, pblock, 0, stream, sceneInfo, ppInfo, nbRows,
