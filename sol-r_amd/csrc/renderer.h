@@ -67,6 +67,14 @@ struct PixelRecord
 static_assert(sizeof(PixelRecord) == sizeof(PostProcessingBuffer), "PixelRecord layout");
 
 
+/* depths of the rows next to a strip that belong to the ranks above and below (multi-GPU frames: §6 of
+ * DESIGN.md): `above` holds the nbAbove rows just above the strip, `below` the nbBelow rows just below it */
+struct DepthHalo
+{
+    const float *above, *below;
+    int nbAbove, nbBelow;
+};
+
 /* the renderer kernel and the replay of its walks (renderer_kernel.h), as the host launches them */
 typedef void (*RendererFn)(const SceneArgs, const FrameArgs, PixelRecord *, int4 *, unsigned char *, unsigned long long *);
 typedef void (*WalkBoundFn)(const SceneArgs, const char *, unsigned *, unsigned *);

@@ -45,6 +45,9 @@ using namespace solrdev;
 /* ======================================================================= */
 
 #include "renderer.h"
+#include "engine.h"
+
+using namespace solreng;
 
 /* the renderer's instantiations live in the files under csrc/rows (one object per row of renderImpl's table) */
 namespace solrrows
@@ -72,869 +75,12 @@ WalkBoundFn walkBound(int row, int features)
 }
 } // namespace solrrows
 
-/* CRT:1057-1073 */
-__global__ __launch_bounds__(256) void k_default(const SceneInfo si, int nbPixels,
-                                                 const PixelRecord *__restrict__ pp,
-                                                 unsigned char *__restrict__ bitmap)
-{
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= nbPixels)
-        return;
-    float4 c4 = pp[index].colorInfo;
-    v3 c = V(c4.x, c4.y, c4.z);
-    if (si.pathTracingIteration > NB_MAX_ITERATIONS)
-    {
-        float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
-        c.x /= d;
-        c.y /= d;
-        c.z /= d;
-    }
-    makeColor(si, c, bitmap, index);
-}
-
-/* CRT:1189-1228; gathers stay inside this process's strip */
-__global__ __launch_bounds__(256) void k_radiosity(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
-                                                   const PixelRecord *__restrict__ pp, const int4 *__restrict__ ids,
-                                                   const float *__restrict__ randoms, long nbRandoms,
-                                                   unsigned char *__restrict__ bitmap)
-{
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
-    const int W = si.size.x;
-    const int wh = W * nbRows;
-    if (index >= wh)
-        return;
-    const int x = index % W;
-    const int y = index / W;
-    const int div = (si.pathTracingIteration > NB_MAX_ITERATIONS) ? (si.pathTracingIteration - NB_MAX_ITERATIONS + 1) : 1;
-    const float4 own = pp[index].colorInfo;
-    v3 local = V(0.f, 0.f, 0.f);
-    for (int i = 0; i < ppi.param3; ++i)
-    {
-        const int ix = (i + si.pathTracingIteration) % wh;
-        const int iy = (i + 100 + si.pathTracingIteration) % wh;
-        const float rx = (ix >= 0 && ix < nbRandoms) ? randoms[ix] : 0.f;
-        const float ry = (iy >= 0 && iy < nbRandoms) ? randoms[iy] : 0.f;
-        const int xx = (int)((float)x + rx * ppi.param2);
-        const int yy = (int)((float)y + ry * ppi.param2);
-        local.x += own.x;
-        local.y += own.y;
-        local.z += own.z;
-        if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
-        {
-            const int localIndex = yy * W + xx;
-            const float4 light = pp[localIndex].colorInfo;
-            const float w = (float)ids[localIndex].z;
-            local.x += light.x * w / 256.f;
-            local.y += light.y * w / 256.f;
-            local.z += light.z * w / 256.f;
-        }
-    }
-    local.x /= (float)ppi.param3;
-    local.y /= (float)ppi.param3;
-    local.z /= (float)ppi.param3;
-    local.x /= (float)div;
-    local.y /= (float)div;
-    local.z /= (float)div;
-    saturate3(local);
-    makeColor(si, local, bitmap, index);
-}
-
-/* CRT:1236-1333: six convolution filters selected by param3, wrapping around the strip */
-__device__ const int FILTER_SIZE[6][2] = {{3, 3}, {5, 5}, {3, 3}, {3, 3}, {5, 5}, {5, 5}};
-__device__ const float FILTER_FACTORS[6][2] = {{1.f, 128.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {0.2f, 0.f}, {0.125f, 0.f}};
-__device__ const float FILTER_INFO[6][5][5] = {
-    {{-1.f, -1.f, 0.f, 0.f, 0.f}, {-1.f, 0.f, 1.f, 0.f, 0.f}, {0.f, 1.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
-    {{0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {-1.f, -1.f, 2.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
-    {{-1.f, -1.f, -1.f, 0.f, 0.f}, {-1.f, 9.f, -1.f, 0.f, 0.f}, {-1.f, -1.f, -1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
-    {{0.f, 0.2f, 0.f, 0.f, 0.f}, {0.2f, 0.2f, 0.2f, 0.f, 0.f}, {0.f, 0.2f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}},
-    {{1.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 1.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 1.f}},
-    {{-1.f, -1.f, -1.f, -1.f, -1.f}, {-1.f, 2.f, 2.f, 2.f, -1.f}, {-1.f, 2.f, 8.f, 2.f, -1.f}, {-1.f, 2.f, 2.f, 2.f, -1.f}, {-1.f, -1.f, -1.f, -1.f, -1.f}}};
-
-__global__ __launch_bounds__(256) void k_filter(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
-                                                const PixelRecord *__restrict__ pp, unsigned char *__restrict__ bitmap)
-{
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
-    const int W = si.size.x;
-    if (index >= W * nbRows)
-        return;
-    const int x = index % W;
-    const int y = index / W;
-    v3 local = V(0.f, 0.f, 0.f);
-    v3 color = V(0.f, 0.f, 0.f);
-    const int f = ppi.param3;
-    if (f >= 0 && f < 6)
-    {
-        for (int filterX = 0; filterX < FILTER_SIZE[f][0]; filterX++)
-            for (int filterY = 0; filterY < FILTER_SIZE[f][1]; filterY++)
-            {
-                const int imageX = (x - FILTER_SIZE[f][0] / 2 + filterX + W) % W;
-                const int imageY = (y - FILTER_SIZE[f][1] / 2 + filterY + nbRows) % nbRows;
-                const float4 p = pp[imageY * W + imageX].colorInfo;
-                v3 c = V(p.x, p.y, p.z);
-                if (si.pathTracingIteration > NB_MAX_ITERATIONS)
-                {
-                    const float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
-                    c.x /= d;
-                    c.y /= d;
-                    c.z /= d;
-                }
-                local.x += c.x * FILTER_INFO[f][filterX][filterY];
-                local.y += c.y * FILTER_INFO[f][filterX][filterY];
-                local.z += c.z * FILTER_INFO[f][filterX][filterY];
-            }
-        color.x += fminf(fmaxf(FILTER_FACTORS[f][0] * local.x + FILTER_FACTORS[f][1] / 255.f, 0.f), 1.f);
-        color.y += fminf(fmaxf(FILTER_FACTORS[f][0] * local.y + FILTER_FACTORS[f][1] / 255.f, 0.f), 1.f);
-        color.z += fminf(fmaxf(FILTER_FACTORS[f][0] * local.z + FILTER_FACTORS[f][1] / 255.f, 0.f), 1.f);
-    }
-    saturate3(color);
-    makeColor(si, color, bitmap, index);
-}
-
-/* CRT:1341-1358: depth shown as grey */
-__global__ __launch_bounds__(256) void k_cartoon(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
-                                                 const PixelRecord *__restrict__ pp, unsigned char *__restrict__ bitmap)
-{
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= si.size.x * nbRows)
-        return;
-    const float depth = si.viewDistance / fabsf(pp[index].colorInfo.w - ppi.param1);
-    v3 color = V(depth, depth, depth);
-    saturate3(color);
-    makeColor(si, color, bitmap, index);
-}
-
-/* TileScheduling.  A frame is tens of thousands of one-wave workgroups whose costs differ by an
- * order of magnitude (a tile of sky against a tile of mesh seen at a grazing angle) and the
- * dispatcher hands them out in launch order, so an expensive tile that happens to be launched late
- * runs on alone while the rest of the chip idles (profiles/r1/tile_timeline_*.txt: 23 % of the
- * 100k-triangle frame).  Consecutive frames of a renderer see nearly the same picture: every wave
- * records what its tile cost (one store); this kernel - one workgroup - reduces the costs to their
- * maximum and sum for the host (every sixteenth frame) and, when the
- * host has seen a heavy tail (max > 2 x mean), sorts the tiles by cost with a counting sort in LDS
- * (64 cost classes) so that the following frames are launched most-expensive-first; the order is
- * refreshed every sixteenth frame.  Only the order of work changes,
- * never a result.  (Per-wave atomics for max / sum were tried first: 32 400 same-address device-scope
- * atomics per frame serialise at the memory side and tripled the frame time.) */
-__device__ unsigned orderSerial = 0u;
-
-/* Frames in flight: the frame on the other stream may still be storing its tiles' costs while this kernel
- * runs.  Every cost is therefore read from `cost` exactly ONCE, into `snapshot` (private to the sort, written
- * and read by this workgroup only); maximum, histogram and scatter all work on that one stable copy, so the
- * histogram and the scatter agree and `order` is a permutation of 0..n-1 whatever is being stored meanwhile. */
-/* The tiles that are the frame's critical path (criterion below), at most SPLIT_TILES_MAX of them, are launched
- * as four quadrant waves each, first of all: a frame is as long as its longest wave (the 100k-triangle mesh: one tile
- * seen at a grazing angle took the whole 0.78 ms of the frame), and a 4 x 4 quadrant of such a tile takes
- * about 0.6 of the tile's time.  `order` therefore holds n + 3 * SPLIT_TILES_MAX entries: 4 per split tile,
- * one per other tile, ORDER_NOTHING to the end. */
-__global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsigned *__restrict__ snapshot,
-                                                      unsigned *__restrict__ order, int n,
-                                                      volatile unsigned *hostStats, int sort)
-{
-    __shared__ unsigned nbSplit;
-    __shared__ unsigned splitClass;
-    __shared__ unsigned bins[1024];
-    __shared__ unsigned scan[1024];
-    __shared__ unsigned maxCost;
-    __shared__ unsigned long long sumCost;
-    const int t = threadIdx.x;
-    const int BATCH = 8; /* independent loads in flight per thread: the passes are latency bound */
-    bins[t] = 0u;
-    if (t == 0)
-    {
-        maxCost = 0u;
-        sumCost = 0ull;
-    }
-    __syncthreads();
-    unsigned m = 0u;
-    unsigned long long sum = 0ull;
-    for (int base = 0; base < n; base += BATCH * 1024)
-    {
-        unsigned c[BATCH];
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k)
-        {
-            const int i = base + k * 1024 + t;
-            c[k] = (i < n) ? __builtin_nontemporal_load(&cost[i]) : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k)
-        {
-            const int i = base + k * 1024 + t;
-            if (sort && i < n)
-                snapshot[i] = c[k]; /* re-read below by the thread that wrote it */
-            m = max(m, c[k]);
-            sum += c[k];
-        }
-    }
-    atomicMax(&maxCost, m);
-    atomicAdd(&sumCost, sum);
-    __syncthreads();
-    if (t == 0) /* {max, sum lo, sum hi, tiles, serial}: the host reads them without synchronising */
-    {
-        hostStats[0] = maxCost;
-        hostStats[1] = (unsigned)sumCost;
-        hostStats[2] = (unsigned)(sumCost >> 32);
-        hostStats[3] = (unsigned)n;
-        hostStats[4] = ++orderSerial;
-    }
-    if (!sort)
-        return;
-    /* 64 cost classes x 16 sub-bins picked by the tile index: tiles of similar cost are the common
-     * case and would otherwise all contend for one LDS counter */
-    const float toClass = 64.f / ((float)maxCost + 1.f); /* the same expression in both passes */
-    for (int base = 0; base < n; base += BATCH * 1024)
-    {
-        unsigned c[BATCH];
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k)
-        {
-            const int i = base + k * 1024 + t;
-            c[k] = (i < n) ? snapshot[i] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k)
-        {
-            const int i = base + k * 1024 + t;
-            if (i < n)
-                atomicAdd(&bins[(min(63u, (unsigned)((float)c[k] * toClass)) << 4) | ((unsigned)i & 15u)], 1u);
-        }
-    }
-    __syncthreads();
-    /* exclusive prefix over bins in DESCENDING bin order (Hillis-Steele on the reversed array) */
-    const unsigned mine = bins[1023 - t];
-    scan[t] = mine;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1)
-    {
-        const unsigned add = (t >= off) ? scan[t - off] : 0u;
-        __syncthreads();
-        scan[t] += add;
-        __syncthreads();
-    }
-    bins[1023 - t] = scan[t] - mine; /* first slot of this bin */
-    /* which classes are split: those above the class of twice the mean cost, as far down as SPLIT_TILES_MAX
-     * tiles go (whole classes only: the split tiles are then a prefix of the order) */
-    if (t == 0)
-    {
-        nbSplit = 0u;
-        splitClass = 64u;
-    }
-    __syncthreads();
-    if (t < 64)
-    {
-        /* tiles in classes >= c = inclusive scan at the end of class c in descending order: bin (c << 4) is the
-         * last of class c's sixteen sub-bins there, scan[1023 - (c << 4)] counts everything up to and including it */
-        /* worth splitting: a tile that alone takes more than 0.8 of what the whole frame would take if its
-         * work were spread evenly over the chip's 4096 wave slots (256 CUs x 16 resident waves of this
-         * kernel) - such a tile IS the frame's critical path - and more than twice the mean.  A frame whose
-         * longest tile is short against that (Cornell: 0.1 ms of 0.35; the molecule: 0.5 of 1.0) is bound by
-         * throughput, and there the 3.2 x work of four quadrant waves is a loss.  Frames in flight (sort = how
-         * many) hide a critical path behind the next frames: the bar is that many times higher - which no tile
-         * of a whole 1080p frame passes, but the horizon tile of the mesh in a 1/8 strip does (a rank of an
-         * eight-GPU frame: its strip is as slow as that one wave however many frames overlap). */
-        const unsigned c = (unsigned)t;
-        const float mean = (float)sumCost / (float)max(n, 1);
-        const float critical = fmaxf(2.f * mean, (float)sort * (float)sumCost / 5120.f);
-        const unsigned above = min(63u, (unsigned)(critical * toClass)) + 1u;
-        const unsigned upTo = scan[1023 - (c << 4)];
-        if (c >= above && c < 64u && upTo <= (unsigned)SPLIT_TILES_MAX)
-            atomicMin(&splitClass, c);
-    }
-    __syncthreads();
-    if (t == 0)
-        nbSplit = splitClass < 64u ? scan[1023 - (splitClass << 4)] : 0u;
-    __syncthreads();
-    const unsigned split = nbSplit;
-    for (int i = n + (SPLIT_PARTS - 1) * (int)split + t; i < n + (SPLIT_PARTS - 1) * SPLIT_TILES_MAX; i += 1024)
-        order[i] = ORDER_NOTHING;
-    for (int base = 0; base < n; base += BATCH * 1024)
-    {
-        unsigned c[BATCH];
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k)
-        {
-            const int i = base + k * 1024 + t;
-            c[k] = (i < n) ? snapshot[i] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k)
-        {
-            const int i = base + k * 1024 + t;
-            if (i < n)
-            {
-                const unsigned b = (min(63u, (unsigned)((float)c[k] * toClass)) << 4) | ((unsigned)i & 15u);
-                const unsigned at = atomicAdd(&bins[b], 1u); /* position in descending order of cost */
-                if (at < split)
-                    for (unsigned q = 0; q < (unsigned)SPLIT_PARTS; ++q)
-                        order[(unsigned)SPLIT_PARTS * at + q] = (unsigned)i | ((q + 1u) << ORDER_PART_SHIFT);
-                else
-                    order[at + (unsigned)(SPLIT_PARTS - 1) * split] = (unsigned)i;
-            }
-        }
-    }
-}
-
-/* CRT:1128-1181; gathers stay inside this process's strip */
-#define AO_TILE_W 32
-#define AO_TILE_H 8
-#define AO_WINDOW_FLOATS 8192 /* LDS window of a tile: (AO_TILE_W + 2 rx) x (AO_TILE_H + 2 ry) depths */
-/* depths of the rows next to a strip that belong to the ranks above and below (multi-GPU frames: §6 of
- * DESIGN.md): `above` holds the nbAbove rows just above the strip, `below` the nbBelow rows just below it */
-struct DepthHalo
-{
-    const float *above, *below;
-    int nbAbove, nbBelow;
-};
-/* the depth a tap reads: the strip's own frame buffer, or a neighbour's row out of the halo; rows that are in
- * neither are outside the frame (occluded, CRT:1164-1165) - or beyond the halo, which the host sizes by the reach
- * of the taps */
-__device__ __forceinline__ bool aoDepthAt(const PixelRecord *__restrict__ pp, const DepthHalo &halo, int W, int nbRows,
-                                          int xx, int yy, float &depth)
-{
-    if (xx < 0 || xx >= W || yy < -halo.nbAbove || yy >= nbRows + halo.nbBelow)
-        return false;
-    if (yy < 0)
-        depth = halo.above[(yy + halo.nbAbove) * W + xx];
-    else if (yy >= nbRows)
-        depth = halo.below[(yy - nbRows) * W + xx];
-    else
-        depth = pp[yy * W + xx].colorInfo.w;
-    return true;
-}
-/* tiles a workgroup renders one after the other (a run along x): what does not depend on the tile - the tap pairs,
- * their reach and, inside one binade, the deduped offsets - is made once per run instead of once per 256 pixels */
-#define AO_TILES_PER_GROUP 8
-#define AO_AHEAD 4 /* window depths a thread holds for the next tile: windows of up to 256 x AO_AHEAD floats are asked for a tile ahead */
-__global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
-                                                          const PixelRecord *__restrict__ pp,
-                                                          const float *__restrict__ randoms, long nbRandoms,
-                                                          unsigned char *__restrict__ bitmap, const DepthHalo halo,
-                                                          int firstRow, int windowFloats)
-{
-    /* The 256 taps of a pixel sit at x + X * param2 * randoms[i % wh] / 10.f, y + Y * param2 * randoms[(i + 100)
-     * % wh] / 10.f (CRT:1146-1153): the offsets depend on the tap, not on the pixel.  The workgroup's 256
-     * threads evaluate one tap's pair each - the same expressions, the two correctly rounded divisions
-     * included - and every pixel then adds them to its coordinates: 2 divisions per thread instead of 512.
-     *
-     * A tile is 32 x 8 pixels.  Every tap of every pixel of the tile lands within rx = max |tapX| + 1 columns and
-     * ry = max |tapY| + 1 rows of the tile: that window of depths (colorInfo.w of the 32-byte frame-buffer records) is
-     * read once into LDS - 2 772 four-byte reads for taps of up to 16 pixels (432 for cfg4's, which reach one) instead
-     * of 65 536 - and the comparisons of a pixel read LDS, consecutive lanes consecutive words.  Same comparisons on the
-     * same values, counted in integers: the order of the additions does not matter.  A window that does not fit (taps
-     * that reach beyond about 40 pixels) is gathered from memory as before. */
-    __shared__ float tapX[256], tapY[256];
-    __shared__ int reach[2];
-    /* (dynamic: the host sizes the window for the reach the random buffer and param2 allow - 432 floats for cfg4's
-     * taps instead of 32 KB - so that eight workgroups share a CU instead of four: a tile's work is a chain of waits) */
-    extern __shared__ float window[];
-    __shared__ int tapOffset[256];
-    __shared__ unsigned block[1024]; /* the hash table and the deduped offsets of a steady tile, or the four histograms of a tile in two binades */
-    unsigned *const table = block;
-    int *const distinctOffset = (int *)block + 512, *const distinctWeight = (int *)block + 768;
-    __shared__ int nbDistinct;
-    __shared__ int cls[8];       /* a tile in two binades: {smallest, largest exponent of its regular columns, a column of each; the same for rows} */
-    __shared__ float tapRange[16]; /* per wave: min / max of tapX, min / max of tapY */
-    const int W = si.size.x;
-    const int wh = W * si.size.y; /* the frame's, also when this rank renders a strip of it */
-    const int tilesX = (W + AO_TILE_W - 1) / AO_TILE_W;
-    const int nbTiles = tilesX * ((nbRows + AO_TILE_H - 1) / AO_TILE_H);
-    if (threadIdx.x < 2)
-        reach[threadIdx.x] = 0;
-    __syncthreads();
-    {
-        const int i = threadIdx.x; /* tap i: X = -16 + 2 * (i / 16), Y = -16 + 2 * (i % 16), in loop order */
-        const int X = -16 + 2 * (i >> 4), Y = -16 + 2 * (i & 15);
-        const int ix = i % wh;
-        const int iy = (i + 100) % wh;
-        const float rx = (ix < nbRandoms) ? randoms[ix] : 0.f;
-        const float ry = (iy < nbRandoms) ? randoms[iy] : 0.f;
-        const float tx = X * ppi.param2 * rx / 10.f;
-        const float ty = Y * ppi.param2 * ry / 10.f;
-        tapX[i] = tx;
-        tapY[i] = ty;
-        /* (int)(x + t) stays within ceil(|t|) + 1 of x for an integer x below 2^23; anything else (NaN, huge)
-         * sends the tile down the gather path */
-        const float ax = fabsf(tx), ay = fabsf(ty);
-        int cx = (ax < 1.0e6f) ? (int)ax + 2 : (1 << 20);
-        int cy = (ay < 1.0e6f) ? (int)ay + 2 : (1 << 20);
-        float lowX = tx, highX = tx, lowY = ty, highY = ty;
-        for (int off = 32; off > 0; off >>= 1) /* (a wave's maximum first: 8 atomics on one word instead of 512) */
-        {
-            cx = max(cx, __shfl_xor(cx, off, 64));
-            cy = max(cy, __shfl_xor(cy, off, 64));
-            lowX = fminf(lowX, __shfl_xor(lowX, off, 64)), highX = fmaxf(highX, __shfl_xor(highX, off, 64));
-            lowY = fminf(lowY, __shfl_xor(lowY, off, 64)), highY = fmaxf(highY, __shfl_xor(highY, off, 64));
-        }
-        if ((i & 63) == 0)
-        {
-            atomicMax(&reach[0], cx);
-            atomicMax(&reach[1], cy);
-            tapRange[4 * (i >> 6)] = lowX, tapRange[4 * (i >> 6) + 1] = highX;
-            tapRange[4 * (i >> 6) + 2] = lowY, tapRange[4 * (i >> 6) + 3] = highY;
-        }
-    }
-    __syncthreads();
-    const int rx = reach[0], ry = reach[1];
-    const int ww = AO_TILE_W + 2 * rx, wrows = AO_TILE_H + 2 * ry;
-    const bool tiled = rx < 4096 && ry < 4096 && ww * wrows <= windowFloats && ww * wrows <= AO_WINDOW_FLOATS;
-    /* (a NaN among the taps makes fminf / fmaxf skip it; such a buffer has an enormous reach and is not tiled) */
-    const float tapLowX = fminf(fminf(tapRange[0], tapRange[4]), fminf(tapRange[8], tapRange[12]));
-    const float tapHighX = fmaxf(fmaxf(tapRange[1], tapRange[5]), fmaxf(tapRange[9], tapRange[13]));
-    const float tapLowY = fminf(fminf(tapRange[2], tapRange[6]), fminf(tapRange[10], tapRange[14]));
-    const float tapHighY = fmaxf(fmaxf(tapRange[3], tapRange[7]), fmaxf(tapRange[11], tapRange[15]));
-    const int binsX = 2 * rx + 1, binsY = 2 * ry + 1;
-    int tableKey = 0; /* the binades (of x and of the frame's y) the deduped offsets in LDS were made for; 0: none */
-    const bool pipelined = tiled && ww * wrows <= 256 * AO_AHEAD;
-    float aheadDepth[AO_AHEAD];
-    float4 aheadLocal = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ahead = [&](int t) { /* this thread's share of tile t's window, and its own pixel's record */
-        const int tx0 = (t % tilesX) * AO_TILE_W, ty0 = (t / tilesX) * AO_TILE_H;
-#pragma unroll
-        for (int k = 0; k < AO_AHEAD; ++k)
-        {
-            const int i = (int)threadIdx.x + 256 * k;
-            float d = 0.f;
-            if (i < ww * wrows)
-                aoDepthAt(pp, halo, W, nbRows, tx0 - rx + i % ww, ty0 - ry + i / ww, d);
-            aheadDepth[k] = d;
-        }
-        const int px = tx0 + (int)(threadIdx.x % AO_TILE_W), py = ty0 + (int)(threadIdx.x / AO_TILE_W);
-        aheadLocal = pp[(px < W && py < nbRows) ? py * W + px : 0].colorInfo;
-    };
-    for (int run = 0; run < AO_TILES_PER_GROUP; ++run)
-    {
-        /* tile `run` of this workgroup: a stride of the grid apart, not side by side.  The tiles of the frame's first
-         * tile row and column (x or y below the tile's size: regular columns of up to five binades) take the per-pixel
-         * loop, 30 times the cost of a tile - side by side they were eight of them in one workgroup, and that
-         * workgroup was the kernel: 0.52 ms whatever the other 4 000 did */
-        const int tile = (int)blockIdx.x + run * (int)gridDim.x;
-        if (tile >= nbTiles)
-            break;
-        const int x0 = (tile % tilesX) * AO_TILE_W;
-        const int y0 = (tile / tilesX) * AO_TILE_H;
-        const int wx0 = x0 - rx, wy0 = y0 - ry;
-        const int x = x0 + (int)(threadIdx.x % AO_TILE_W);
-        const int y = y0 + (int)(threadIdx.x / AO_TILE_W);
-        const bool mine = x < W && y < nbRows;
-        const int index = mine ? y * W + x : 0;
-        /* A window of up to 1 024 depths (taps that reach 12 pixels) is asked for ONE TILE AHEAD, into registers, behind
-         * the barrier below: the loads of tile n + 1 are in flight while tile n is compared and stored, and a tile is
-         * no longer two memory latencies long. */
-        if (pipelined && run == 0)
-            ahead(tile);
-        float4 local;
-        if (pipelined)
-        {
-            local = aheadLocal;
-            for (int k = 0; k < AO_AHEAD; ++k)
-                if ((int)threadIdx.x + 256 * k < ww * wrows)
-                    window[threadIdx.x + 256 * k] = aheadDepth[k];
-        }
-        else
-        {
-            local = pp[index].colorInfo; /* (asked for before the window: the two waits overlap) */
-            if (tiled)
-                for (int i = threadIdx.x; i < ww * wrows; i += 256)
-                {
-                    const int gx = wx0 + i % ww, gy = wy0 + i / ww;
-                    float d = 0.f;
-                    aoDepthAt(pp, halo, W, nbRows, gx, gy, d);
-                    window[i] = d;
-                }
-        }
-        /* Steady taps.  (int)(x + t) - x is the same for every x of the tile when x and all the sums x + t lie in one
-         * binade: x is a multiple of that binade's ulp U (a power of two below 1, so x / U is even and ties round the
-         * same way), hence RN(x + t) = x + RN_U(t), and the sums are positive, so the truncation is a floor.  Then a
-         * tap is ONE integer offset into the window for the whole tile - evaluated once per tap, on the tile's first
-         * column and row, with the reference's own expression - and the same for every tile of those two binades.
-         * Tiles that straddle a power of two in x or in the frame's y, or whose window leaves the frame, take the
-         * per-pixel evaluation below.
-         *
-         * ... and the taps that land on the same depth are one comparison.  cfg4's taps (param2 = 10, randoms of
-         * +-0.005) reach one pixel: 256 taps, FOUR distinct offsets.  The count is an integer sum, so it is taken over
-         * the distinct offsets with their multiplicities: the workgroup dedupes its 256 offsets (a 512-slot hash
-         * table: key and count in one word, atomicCAS to claim, atomicAdd to count) and a pixel then makes one read
-         * and one compare per DISTINCT offset - and never more than before: beyond 128 distinct offsets the plain loop
-         * runs. */
-        bool steady = false;
-        if (tiled)
-        {
-            const int xlo = x0 - rx, xhi = x0 + AO_TILE_W - 1 + rx;
-            const int ylo = y0 + firstRow - ry, yhi = y0 + firstRow + AO_TILE_H - 1 + ry;
-            steady = wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow && xlo >= 1 &&
-                     ylo >= 1 && __clz(xlo) == __clz(xhi) && __clz(ylo) == __clz(yhi);
-            const int key = steady ? (1 << 16) | (__clz(xlo) << 8) | __clz(ylo) : 0;
-            if (steady && key != tableKey)
-            {
-                const int i = threadIdx.x;
-                const int dx = (int)((float)x0 + tapX[i]) - x0;
-                const int dy = (int)((float)(y0 + firstRow) + tapY[i]) - (y0 + firstRow);
-                const int off = dy * ww + dx; /* |off| < ww * wrows <= AO_WINDOW_FLOATS: inside the window */
-                tapOffset[i] = off;
-                if (i == 0)
-                    nbDistinct = 0;
-                table[i] = 0u;
-                table[i + 256] = 0u;
-                __syncthreads();
-                const unsigned tag = (unsigned)(off + AO_WINDOW_FLOATS) + 1u; /* 1 ... 2 x 8192: 0 is an empty slot */
-                unsigned h = (tag * 2654435761u) >> 23;
-                for (;;)
-                {
-                    const unsigned before = atomicCAS(&table[h], 0u, tag << 9);
-                    if (before == 0u || (before >> 9) == tag)
-                    {
-                        atomicAdd(&table[h], 1u); /* at most 256 taps: the count stays below the key's bits */
-                        break;
-                    }
-                    h = (h + 1u) & 511u;
-                }
-                __syncthreads();
-                for (int slot = i; slot < 512; slot += 256)
-                {
-                    const unsigned entry = table[slot];
-                    if (entry != 0u)
-                    {
-                        const int at = atomicAdd(&nbDistinct, 1);
-                        distinctOffset[at] = (int)(entry >> 9) - 1 - AO_WINDOW_FLOATS;
-                        distinctWeight[at] = (int)(entry & 511u);
-                    }
-                }
-            }
-            tableKey = steady ? key : tableKey;
-        }
-        /* A tile in TWO binades (it straddles a power of two in x, in the frame's y, or both: a fifth of a 4K frame's
-         * tiles - and until this was here 80 % of the kernel's time, 256 float additions and conversions per pixel).  A
-         * pixel's column is REGULAR when x, x + the smallest tap and x + the largest tap lie in one binade (the sums
-         * are monotonic in the tap): for such columns of one binade (int)(x + t) - x is the same, by the argument
-         * above; likewise rows.  A tile has regular columns of at most two binades and regular rows of at most two:
-         * four histograms of tap offsets, made once per tile with the reference's own expression on one column and one
-         * row of each class, serve every pixel whose column and row are regular - one read and one compare per bin
-         * (25 for cfg4's taps) instead of 256 evaluations.  The pixels of the irregular columns and rows (cfg4: the one
-         * column AT the power of two, whose sums with negative taps fall into the binade below) keep the per-pixel loop. */
-        const int e0x = (int)(__float_as_uint((float)x) >> 23), e0y = (int)(__float_as_uint((float)(y + firstRow)) >> 23);
-        const bool regularX = x >= 1 && (int)(__float_as_uint((float)x + tapLowX) >> 23) == e0x &&
-                              (int)(__float_as_uint((float)x + tapHighX) >> 23) == e0x;
-        const bool regularY = y + firstRow >= 1 && (int)(__float_as_uint((float)(y + firstRow) + tapLowY) >> 23) == e0y &&
-                              (int)(__float_as_uint((float)(y + firstRow) + tapHighY) >> 23) == e0y;
-        const bool windowInside = tiled && wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow;
-        bool classed = tiled && !steady && binsX * binsY <= 256;
-        if (classed)
-        {
-            const int i = threadIdx.x;
-            tableKey = 0; /* (the histograms take the place of the steady tiles' table) */
-            if (i < 8)
-                cls[i] = (i == 0 || i == 2 || i == 4 || i == 6) ? 0x7fffffff : -1;
-            block[i] = block[i + 256] = block[i + 512] = block[i + 768] = 0u;
-            if (i < binsX * binsY)
-                tapOffset[i] = (i / binsX - ry) * ww + (i % binsX - rx);
-            __syncthreads();
-            /* (thread i of the first row of the tile speaks for column i, thread 32 r for row r) */
-            if (i < AO_TILE_W && regularX)
-            {
-                atomicMin(&cls[0], e0x);
-                atomicMax(&cls[1], e0x);
-            }
-            if (i % AO_TILE_W == 0 && regularY)
-            {
-                atomicMin(&cls[4], e0y);
-                atomicMax(&cls[5], e0y);
-            }
-            __syncthreads();
-            if (i < AO_TILE_W && regularX)
-            {
-                if (e0x == cls[0])
-                    atomicMin(&cls[2], x);
-                if (e0x == cls[1])
-                    atomicMax(&cls[3], x);
-            }
-            if (i % AO_TILE_W == 0 && regularY)
-            {
-                if (e0y == cls[4])
-                    atomicMin(&cls[6], y + firstRow);
-                if (e0y == cls[5])
-                    atomicMax(&cls[7], y + firstRow);
-            }
-            __syncthreads();
-            classed = cls[1] >= 0 && cls[5] >= 0 && cls[1] - cls[0] <= 1 && cls[5] - cls[4] <= 1;
-            if (classed)
-            {
-                int dx[2], dy[2];
-                for (int c = 0; c < 2; ++c)
-                {
-                    const int xr = c ? cls[3] : cls[2], yr = c ? cls[7] : cls[6];
-                    dx[c] = (int)((float)xr + tapX[i]) - xr;
-                    dy[c] = (int)((float)yr + tapY[i]) - yr;
-                }
-                for (int c = 0; c < 4; ++c)
-                    atomicAdd(&block[c * 256 + (dy[c & 1] + ry) * binsX + (dx[c >> 1] + rx)], 1u);
-            }
-        }
-        __syncthreads(); /* the window is in LDS, and so are the offsets */
-        if (pipelined && run + 1 < AO_TILES_PER_GROUP && tile + (int)gridDim.x < nbTiles)
-            ahead(tile + (int)gridDim.x);
-        if (mine)
-        {
-            float occ = 0.f;
-            const float depth = local.w;
-            float c = 0.f;
-            if (tiled)
-            {
-                /* a tile whose window lies inside the frame needs no bounds test per tap */
-                const bool inside = wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow;
-                /* counted in an integer (at most 256: the float sum of the reference is the same number) */
-                /* a strip is rows [firstRow, firstRow + nbRows) of the frame: the tap's row is evaluated with the frame's y
-                 * (the float addition rounds, and truncates towards zero, by the row's position in the frame) */
-                const int origin = -((wy0 + firstRow) * ww + wx0);
-                const float fx = (float)x, fy = (float)(y + firstRow);
-                int count = 0;
-                if (steady)
-                {
-                    const float *centre = window + ((y - wy0) * ww + (x - wx0));
-                    const int distinct = nbDistinct;
-                    if (distinct <= 128)
-                    {
-                        for (int i = 0; i < distinct; ++i)
-                            count += (centre[distinctOffset[i]] >= depth) ? distinctWeight[i] : 0;
-                    }
-                    else
-                    {
-#pragma unroll 16
-                        for (int i = 0; i < 256; ++i)
-                            count += (centre[tapOffset[i]] >= depth) ? 1 : 0;
-                    }
-                }
-                else if (classed && regularX && regularY)
-                {
-                    const float *centre = window + ((y - wy0) * ww + (x - wx0));
-                    const unsigned *hist = block + 256 * ((e0x == cls[0] ? 0 : 2) + (e0y == cls[4] ? 0 : 1));
-                    const int bins = binsX * binsY;
-                    if (windowInside)
-                        for (int b = 0; b < bins; ++b)
-                        {
-                            const int weight = (int)hist[b];
-                            if (weight)
-                                count += (centre[tapOffset[b]] >= depth) ? weight : 0;
-                        }
-                    else /* a tile at the frame's edge: a tap that lands outside the frame (or the strip's halo) counts, CRT:1164-1165 */
-                        for (int b = 0; b < bins; ++b)
-                        {
-                            const int weight = (int)hist[b];
-                            const int xx = x + b % binsX - rx, yy = y + b / binsX - ry;
-                            const bool in = xx >= 0 && xx < W && yy >= -halo.nbAbove && yy < nbRows + halo.nbBelow;
-                            if (weight)
-                                count += (!in || centre[tapOffset[b]] >= depth) ? weight : 0;
-                        }
-                }
-                else if (inside)
-                {
-#pragma unroll 8
-                    for (int i = 0; i < 256; ++i)
-                    {
-                        const int xx = (int)(fx + tapX[i]);
-                        const int yy = (int)(fy + tapY[i]);
-                        count += (window[__mul24(yy, ww) + xx + origin] >= depth) ? 1 : 0;
-                    }
-                }
-                else
-                {
-                    /* (branch-free, so that the loop unrolls and its LDS reads overlap: a tap outside the frame reads cell 0
-                     * of the window and counts whatever it holds) */
-#pragma unroll 8
-                    for (int i = 0; i < 256; ++i)
-                    {
-                        const int xx = (int)(fx + tapX[i]);
-                        const int yy = (int)(fy + tapY[i]);
-                        const bool in = xx >= 0 && xx < W && yy - firstRow >= -halo.nbAbove && yy - firstRow < nbRows + halo.nbBelow;
-                        const float tap = window[in ? __mul24(yy, ww) + xx + origin : 0];
-                        count += (!in || tap >= depth) ? 1 : 0;
-                    }
-                }
-                occ = (float)count;
-                c = 256.f;
-            }
-            else
-            {
-                for (int i = 0; i < 256; ++i)
-                {
-                    c += 1.f;
-                    int xx = (int)(x + tapX[i]);
-                    int yy = (int)((y + firstRow) + tapY[i]) - firstRow;
-                    float tap;
-                    if (aoDepthAt(pp, halo, W, nbRows, xx, yy, tap))
-                    {
-                        if (tap >= depth)
-                            occ += 1.f;
-                    }
-                    else
-                        occ += 1.f;
-                }
-            }
-            occ /= (float)c;
-            occ += 0.3f;
-            v3 col = V(local.x, local.y, local.z);
-            if (occ < 1.f)
-            {
-                col.x *= occ;
-                col.y *= occ;
-                col.z *= occ;
-            }
-            if (si.pathTracingIteration > NB_MAX_ITERATIONS)
-            {
-                float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
-                col.x /= d;
-                col.y /= d;
-                col.z /= d;
-            }
-            saturate3(col);
-            makeColor(si, col, bitmap, index);
-        }
-        __syncthreads(); /* the next tile's window goes where this one's is still being read */
-    }
-}
-
-/* CRT:1081-1120 */
-/* the depths of rows [row0, row0 + n) of a strip, packed for the neighbour that needs them */
-__global__ __launch_bounds__(256) void k_packDepthRows(const PixelRecord *__restrict__ pp, int W, int row0, int n,
-                                                       float *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < W * n)
-        out[i] = pp[row0 * W + i].colorInfo.w;
-}
-
-__global__ __launch_bounds__(256) void k_depthOfField(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
-                                                      const PixelRecord *__restrict__ pp,
-                                                      const float *__restrict__ randoms, long nbRandoms,
-                                                      unsigned char *__restrict__ bitmap)
-{
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
-    const int W = si.size.x;
-    const int wh = W * nbRows;
-    if (index >= wh)
-        return;
-    const int x = index % W;
-    const int y = index / W;
-    v3 local = V(0.f, 0.f, 0.f);
-    const float4 own = pp[index].colorInfo;
-    float depth = fabsf(own.w - ppi.param1) / si.viewDistance;
-    for (int i = 0; i < ppi.param3; ++i)
-    {
-        int ix = i % wh;
-        int iy = (i + 1000) % wh;
-        float rx = (ix < nbRandoms) ? randoms[ix] : 0.f;
-        float ry = (iy < nbRandoms) ? randoms[iy] : 0.f;
-        int xx = (int)(x + depth * rx * ppi.param2);
-        int yy = (int)(y + depth * ry * ppi.param2);
-        if (xx >= 0 && xx < W && yy >= 0 && yy < nbRows)
-        {
-            int localIndex = yy * W + xx;
-            if (localIndex >= 0 && localIndex < wh)
-            {
-                float4 o = pp[localIndex].colorInfo;
-                local.x += o.x;
-                local.y += o.y;
-                local.z += o.z;
-            }
-        }
-        else
-        {
-            local.x += own.x;
-            local.y += own.y;
-            local.z += own.z;
-        }
-    }
-    local.x /= (float)ppi.param3;
-    local.y /= (float)ppi.param3;
-    local.z /= (float)ppi.param3;
-    if (si.pathTracingIteration > NB_MAX_ITERATIONS)
-    {
-        float d = (float)(si.pathTracingIteration - NB_MAX_ITERATIONS + 1);
-        local.x /= d;
-        local.y /= d;
-        local.z /= d;
-    }
-    makeColor(si, local, bitmap, index);
-}
-
 /* ======================================================================= */
 /* Host layer                                                               */
 /* ======================================================================= */
 
-namespace
+namespace solreng
 {
-/* SOLR_HIP_DEBUG_TIMING=1: where the host side of an upload spends its time (stderr) */
-/* SOLR_HIP_HOST_PROFILE=1 (diagnostics): what the HOST spends per call inside the entry points of a frame - at eight
- * GPUs a strip takes 0.04 ms and the host's own 0.04-0.05 ms per step is what bounds the frame rate.  Totals go to stderr
- * at finalize_scene. */
-struct HostProfile
-{
-    const bool on = getenv("SOLR_HIP_HOST_PROFILE") != nullptr;
-    struct Entry
-    {
-        const char *name;
-        double seconds;
-        long calls;
-    } entries[16] = {};
-    int used = 0;
-    Entry *find(const char *name)
-    {
-        for (int i = 0; i < used; ++i)
-            if (entries[i].name == name)
-                return &entries[i];
-        if (used < 16)
-        {
-            entries[used].name = name;
-            return &entries[used++];
-        }
-        return nullptr;
-    }
-    void report()
-    {
-        if (!on)
-            return;
-        for (int i = 0; i < used; ++i)
-            fprintf(stderr, "solr_hip host: %-34s %9.3f us per call over %ld calls\n", entries[i].name,
-                    1e6 * entries[i].seconds / (entries[i].calls ? entries[i].calls : 1), entries[i].calls);
-        used = 0;
-    }
-    ~HostProfile() { report(); } /* (a host that never finalizes: at exit) */
-};
-HostProfile gHostProfile;
-struct HostSpan
-{
-    const char *name;
-    std::chrono::steady_clock::time_point t0;
-    explicit HostSpan(const char *n) : name(n)
-    {
-        if (gHostProfile.on)
-            t0 = std::chrono::steady_clock::now();
-    }
-    ~HostSpan()
-    {
-        if (!gHostProfile.on)
-            return;
-        if (HostProfile::Entry *e = gHostProfile.find(name))
-        {
-            e->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            e->calls++;
-        }
-    }
-};
-
-struct PhaseTimer
-{
-    const bool on = getenv("SOLR_HIP_DEBUG_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
-    void mark(const char *what)
-    {
-        if (!on)
-            return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "solr_hip: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
-        last = now;
-    }
-};
-
 /* ---- animated scenes: rotate + refit on the device ---------------------------------------------------
  * The reference animates a scene by GPUKernel::rotatePrimitives + compactBoxes(false) on the host and a
  * full upload, every frame (MoleculeScene.cpp:75-81; GPUKernel.cpp:1378-1460 rotates the primitives of
@@ -1284,357 +430,13 @@ __global__ __launch_bounds__(256) void k_refitNodes(float4 *__restrict__ arena, 
     rows[2 * node + 1] = make_float4(hx, hy, row1.z, row1.w);
 }
 
-struct DeviceBuffer
-{
-    void *ptr = nullptr;
-    size_t bytes = 0;
-};
-
-/* frames in flight at most (per-pixel buffer sets and streams).  Whole 1080p frames gain nothing beyond three, a
- * 1/8 strip - one round of waves, as slow as its longest - up to four; six and eight were tried (the mesh's
- * slowest strip: 0.114 ms with three, 0.089 with four, 0.12 and 0.11 with six and eight). */
-const int MAX_FLIGHTS = 4;
-/* head of the shared segment of solr_hip_image_share; the images follow, page-aligned.  done[r][slot]: the serial of
- * the last copy of rank r into that slot that has landed; consumed: the last serial the root has handed to its host. */
-struct SharedRing
-{
-    std::atomic<long> done[64][MAX_FLIGHTS + 2];
-    std::atomic<long> consumed;
-    long frameBytes, imageStride;
-};
-struct Engine
-{
-    bool initialized = false;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool ownStream = false;
-    int errorCode = 0;
-    std::string errorText;
-
-    /* scene planes */
-    /* two arenas (scene_layout.h) and their host images */
-    DeviceBuffer geometry, materials, textures, randoms, lamps;
-    std::vector<float4> hostBoxes, hostBoxesCompact, hostPrims, hostLights;
-    std::vector<int> hostBoxStart, hostBoxStartCompact, hostOriginCompact;
-    int freeCountdown = 0; /* renders until the order-free lists are built (0: not scheduled) */
-    /* the order-free list: the leaves of the scene under a surface-area hierarchy of our own (buildFreeOrderList) */
-    std::vector<float4> hostBoxesFree;
-    std::vector<int> hostBoxStartFree;
-    /* lists built on the device stay there: `freeRows` float4 rows (16 per node of a list) that go into the arena with
-     * a device-to-device copy (freeStage, until the next flushGeometry); the host images above are filled from the
-     * arena when somebody needs them (ensureHostFreeLists: the refit plan of a rotated scene, a second layout) */
-    size_t freeRows = 0;
-    bool freeHostValid = true;
-    bool freeDirty = false;  /* the staged lists are to be added to an arena that is otherwise up to date */
-    unsigned rowsFixed = 0;  /* rows of the arena in front of the order-free lists */
-    SolrDeviceLists freeStage;
-    unsigned offBoxesFree = 0, offBoxStartFree = 0, offLeafFree = 0;
-    int nbBoxesFree = 0;        /* nodes per list; there are eight, one per direction octant */
-    bool freeStale = false;     /* rotated on the device since it was built: not refitted, not walked */
-    bool primsContained = false; /* every primitive lies inside its leaf's box (retagPrimitives) */
-    bool opaqueShadows = false;  /* no transparent primitive, no textured plane (retagPrimitives) */
-    /* the thin copies of the walk-order list and of the order-free lists (tightenList; rt_device.h tightRay) */
-    bool plainPlanes = false;    /* the scene holds a plain axis plane: thin copies are worth making (retagPrimitives) */
-    float sceneExtent = 1.f;     /* max |coordinate| + |size| over the primitives, at least 1 */
-    bool tightCompact = false, tightFree = false; /* the copy behind that list is up to date */
-    /* bounce rays on the order-free lists, checked (rt_device.h closestHitWalk): -1 the engine decides per frame
-     * (shortRayListsChoice: with frames in flight), 0 / 1 forced */
-    int shortRayListsMode = -1;
-    std::vector<int> materialTags; /* PRIM_* bits per material id */
-    /* texture tables of the textured materials and the size of the uploaded atlas: checked against each other
-     * before the first frame that follows either upload (checkTextureTables) */
-    struct TextureUse
-    {
-        int material;
-        long texels;      /* bytes of the diffuse map: x * y * depth */
-        long offsets[7];  /* diffuse, normal, bump, specular, reflection, transparency, ambient occlusion; -1 unused */
-    };
-    std::vector<TextureUse> textureUses;
-    size_t atlasBytes = 0;
-    bool textureTablesChecked = false;
-    std::vector<float> materialAverage; /* (r + g + b) / 3.f per material id (plane colour key, GI:561) */
-    int sceneFeatures = F_ALL & ~F_FULL; /* rt_device.h enum Feature, recomputed with the tags */
-    unsigned offBoxes = 0, offBoxesCompact = 0, offBoxStart = 0, offBoxStartCompact = 0, offPrims = 0, offLights = 0;
-    unsigned offLeaf = 0, offLeafCompact = 0; /* leaf records of the two node lists (scene_layout.h) */
-    unsigned offMatCold = 0;
-    bool geometryDirty = true;
-    int nbBoxesCompact = 0;
-    int orderedExact = 0, orderedCompact = 0; /* sign-free slab test allowed on that node list */
-    int nbBoxes = 0, nbPrimitives = 0, nbLights = 0, nbLamps = 0, nbMaterials = 0;
-    int nested = 1;
-    long nbRandoms = 0;
-
-    /* per-pixel buffers of the strip */
-    DeviceBuffer pp, ids, bitmap, counters, tileClock, tileCost, tileCostSnapshot, tileOrder;
-    /* ambient occlusion across strips: the depths of the neighbours' rows next to this rank's strip */
-    DeviceBuffer haloAbove[MAX_FLIGHTS], haloBelow[MAX_FLIGHTS], haloSendTop[MAX_FLIGHTS], haloSendBottom[MAX_FLIGHTS]; /* per frame in flight */
-    DeviceBuffer haloGivenAbove, haloGivenBelow; /* solr_hip_set_depth_halo */
-    int haloSuppliedAbove = 0, haloSuppliedBelow = 0; /* rows handed over by solr_hip_set_depth_halo (0: none) */
-    float randomsReach = 0.f;                          /* max |randoms[i]|, i < 356: what the 256 taps can read */
-    int haloWanted = -1; /* rows beyond a strip the last frame's post-processing reached (0: none; -1: no frame here) */
-    /* Frames in flight (solr_hip_set_frames_in_flight): with n > 1, consecutive first-pass frames rotate
-     * over n streams and n sets of per-pixel buffers, so that the tail of one frame - a few long waves
-     * on an otherwise idle chip - overlaps the start of the next.  Set 0 is the members above. */
-    int flights = 1;
-    hipStream_t extraStream[MAX_FLIGHTS - 1] = {}; /* streams of sets 1 .. MAX_FLIGHTS - 1 */
-    bool callerStreams = false; /* the streams belong to the caller (solr_hip_set_flight_streams) */
-    DeviceBuffer ppX[MAX_FLIGHTS - 1], idsX[MAX_FLIGHTS - 1], bitmapX[MAX_FLIGHTS - 1], tileOrder2;
-    int current = 0;           /* set / stream of the last render */
-    unsigned frameSerial = 0;
-    hipEvent_t orderEvent = nullptr; /* completion of the last tile sort */
-    bool orderWait[MAX_FLIGHTS] = {}; /* that stream has not yet waited for it */
-    int orderBuffer = 0;       /* which of tileOrder / tileOrder2 holds the valid order */
-    /* cost-ordered launch: 0 off, 1 automatic (default), 2 always */
-    int tileScheduling = 1;
-    unsigned *hostStats = nullptr;    /* mapped host memory, 8 words */
-    unsigned *hostStatsDev = nullptr; /* its device address */
-    long costKey[6] = {0, 0, 0, 0, 0, 0}; /* the frame geometry the recorded costs belong to */
-    int costFrames = 0;               /* frames rendered with that geometry */
-    bool reorder = false;             /* current decision of the automatic mode */
-    bool orderValid = false;          /* tileOrder holds an order for the current geometry */
-    unsigned lastSerial = 0;
-    bool tileClocks = false; /* diagnostics, solr_hip_enable_tile_clocks */
-    int nbTilesTimed = 0;
-    void *boundBitmap = nullptr;
-    int width = 0, height = 0;       /* full image */
-    int firstRow = 0, nbRows = -1;   /* strip; nbRows < 0 -> full frame, 0 -> this process renders no row */
-    int allocW = 0, allocRows = 0;
-
-    /* timing */
-    int timing = 0; /* 0 off, n: every n-th launch is bracketed with events */
-    unsigned timingTick = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    double timedMs = 0.0;
-    int timedLaunches = 0;
-    std::vector<float> kernelSamples, intervalSamples; /* per timed launch: its duration; end-to-end gap to the one before */
-
-    /* pipelined read-back (solr_hip_d2h_image_async): a ring of page-locked host images, a copy stream, and per
-     * slot the event that says its copy has landed */
-    static const int IMAGE_RING = MAX_FLIGHTS + 2; /* MAX_FLIGHTS tickets outstanding, the image on show, one spare */
-    hipStream_t copyStream = nullptr;
-    BitmapBuffer *pinnedImage[IMAGE_RING] = {};
-    size_t pinnedBytes = 0;
-    hipEvent_t imageDone[IMAGE_RING] = {};
-    hipEvent_t frameRendered = nullptr;
-    /* a ticket is (serial mod TICKET_PERIOD) * IMAGE_RING + slot - a positive int whatever the age of the process (the
-     * serial itself is 64 bits, counts every ticket this process ever handed out and is never reset or reduced: 0.04 ms
-     * per frame of an eight-rank job is 2^31 / 6 tickets in four hours) - and the serial tells a ticket whose slot has
-     * been handed out again (or whose ring was re-allocated for a larger frame, or shared / unshared since) from a live
-     * one: two tickets of one process are alike only 357 million tickets apart */
-    static const long TICKET_PERIOD = ((long)0x7fffffff / IMAGE_RING / IMAGE_RING - 1) * IMAGE_RING;
-    static int ticketOf(long serial, int slot) { return (int)((serial % TICKET_PERIOD) * IMAGE_RING + slot); }
-    long imageSerial = 0;
-    long slotSerial[IMAGE_RING] = {};
-    /* A ring the ranks of a job share (solr_hip_image_share) is addressed by a sequence number of its own, counted
-     * from the share on every rank alike (the ranks run the same program): it picks the slot and is what `done` /
-     * `consumed` of the segment's head hold; the ticket's generation stays this process's own serial */
-    long shareSeq = 0;
-    long slotShareSeq[IMAGE_RING] = {};
-    long lastWaitedSeq = 0;               /* sequence number of the newest ticket solr_hip_image_wait was asked for */
-    long sharePublished[IMAGE_RING] = {}; /* the sequence number this rank has reported as landed, per slot */
-    /* the ring in memory that several processes share (solr_hip_image_share): every rank's strip lands, over that
-     * rank's own PCIe link, at its rows of ONE host image */
-    struct SharedRing *sharedRing = nullptr;
-    size_t sharedBytes = 0;
-    std::string sharedName;
-    int shareRank = 0, shareWorld = 0;
-    bool slotOfStrips[IMAGE_RING] = {}; /* that slot's ticket was for every rank's strip (not the root's gathered frame) */
-    long lastHandedOut = 0;             /* root: the serial of the image its last solr_hip_image_wait returned */
-    bool copyOnRenderStream = false;    /* solr_hip_set_copy_route */
-    /* the reciprocal of tilesX that was verified for a frame geometry (renderImpl) */
-    int tileCheckedX = 0, tileCheckedTiles = 0, tileCheckedShift = 0;
-    unsigned tileCheckedMagic = 0;
-    /* every buffer set has a second RGB image ("side") for the time a copy still reads the first: a refinement or
-     * accumulation pass stays on the set of the pass before it, and would otherwise wait for that pass's copy */
-    DeviceBuffer bitmapAlt[MAX_FLIGHTS];
-    DeviceBuffer deepStack[MAX_FLIGHTS]; /* F_STACK frames: the colour-stack slots beyond the LDS ones, per buffer set */
-    int bitmapSide[MAX_FLIGHTS] = {0, 0, 0, 0};
-    int flightCopy[MAX_FLIGHTS][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}; /* slot whose copy reads that image, or -1 */
-
-    /* device-side rotation (solr_hip_rotate_primitives): what to refit, in which order */
-    DeviceBuffer movable, refitPlan;
-    int nbMovable = -1;                 /* flags uploaded for that many primitives, -1: none */
-    std::vector<int> refitLevels;       /* exact list: [offset, count] per height, offsets into refitPlan (ints) */
-    std::vector<int> refitWalkLevels;   /* walk-order list, same form */
-    std::vector<int> refitFreeLevels;   /* the eight order-free lists as one forest, same form */
-    bool refitReady = false;
-    bool refitPlanPending = false;      /* the lists changed: the plan is made when the first rotation asks (ensureRefitPlan) */
-    std::vector<int> hostOriginFree;    /* per node of the order-free lists: the node of the reference's list it is, -1: ours */
-    bool exactStale = false;            /* the exact list has not been refitted since the last rotation */
-    float exactStaleViewDistance = 0.f;
-    bool deviceAhead = false;           /* the arena has moved on from the host images */
-    int nbDeviceRotations = 0;
-
-    int variant = 0;
-    bool grouping = true; /* groupSiblings(); variant 5 turns it off for A/B measurements */
-
-    /* the walk's own ceiling (solr_hip_walk_bound): the next frame records its walks; how that frame was launched */
-    DeviceBuffer walkRecords, walkVisits;
-    bool recordNext = false;
-    bool recorded = false;
-    unsigned recordGrid = 0;
-    size_t recordLds = 0;
-    int recordVariant = -1; /* row of renderImpl's table */
-    bool recordDeep = false;
-    SceneArgs recordScene;
-};
-
-/* One Engine per device this process renders on.  The reference drives occupancyParameters.x devices from ONE host
- * thread - per-device allocations and uploads (CudaRayTracer.cu:1404-1480, 1536-1625), one launch per device on an
- * equal row strip (:1694-1696, 1709-1815), every device's strip copied to its place in the host arrays (:1647-1672) -
- * and so does this library when initialize_scene is handed occupancyParameters.x > 1: the ten entry points of the
- * boundary then run once per engine (the wrappers at the end of the C ABI), each engine on its own device with its
- * own streams, buffers and error state, the scene replicated, the frame shared out in equal row strips.  Engine 0
- * always exists and is the engine of every one-device process (all the multi-process machinery: strips, RCCL).
- * `g` is the engine a function works on. */
+/* (the engine's state - struct Engine, one per device of this process - and the helpers every part shares: engine.h) */
 Engine gFirst;
 Engine *gEngines[SOLR_MAX_GPU_COUNT] = {&gFirst};
-int gDevices = 1;   /* engines in use since initialize_scene: min(occupancyParameters.x, devices visible) */
-int gRequested = 1; /* occupancyParameters.x as initialize_scene was given it */
+int gDevices = 1;
+int gRequested = 1;
 Engine *gCurrent = &gFirst;
-#define g (*gCurrent)
-template <class F>
-void onEveryDevice(F &&f)
-{
-    for (int d = 0; d < gDevices; ++d)
-    {
-        gCurrent = gEngines[d];
-        if (gDevices > 1)
-            (void)hipSetDevice(g.device); /* (allocations and launches go to the calling thread's device) */
-        f(d);
-    }
-    gCurrent = &gFirst;
-    if (gDevices > 1)
-        (void)hipSetDevice(g.device);
-}
-
-/* how many frames may really be in flight: what was asked for, as far as streams exist */
-int activeFlights()
-{
-    if (g.flights < 2 || !(g.ownStream || g.callerStreams))
-        return 1;
-    int n = 1;
-    while (n < g.flights && n < MAX_FLIGHTS && g.extraStream[n - 1])
-        ++n;
-    return n;
-}
-bool twoFlights() { return activeFlights() > 1; }
-hipStream_t flightStream(int f) { return f ? g.extraStream[f - 1] : g.stream; }
-DeviceBuffer &flightPp(int f) { return f ? g.ppX[f - 1] : g.pp; }
-DeviceBuffer &flightIds(int f) { return f ? g.idsX[f - 1] : g.ids; }
-DeviceBuffer &flightBitmap(int f) { return g.bitmapSide[f] ? g.bitmapAlt[f] : (f ? g.bitmapX[f - 1] : g.bitmap); }
-/* nothing may touch scene or frame buffers while a frame is still in flight on the other stream */
-void quiesce()
-{
-    for (hipStream_t extra : g.extraStream)
-        if (extra)
-            (void)hipStreamSynchronize(extra);
-    if (g.stream)
-        (void)hipStreamSynchronize(g.stream);
-    if (g.copyStream)
-        (void)hipStreamSynchronize(g.copyStream);
-}
-
-void setError(int code, const char *what, const char *file, int line)
-{
-    if (g.errorCode != 0)
-        return;
-    g.errorCode = code;
-    char buf[512];
-    snprintf(buf, sizeof(buf), "%s (%s:%d)", what, file, line);
-    g.errorText = buf;
-    fprintf(stderr, "solr_hip: error %d: %s\n", code, buf);
-    const char *fatal = getenv("SOLR_HIP_FATAL");
-    if (fatal && fatal[0] == '1')
-        exit(EXIT_FAILURE); /* the reference's behaviour, helper_cuda.h:749-763 */
-}
-
-#define HIPCHECK(expr)                                                                                           \
-    do                                                                                                           \
-    {                                                                                                            \
-        hipError_t e_ = (expr);                                                                                  \
-        if (e_ != hipSuccess)                                                                                    \
-        {                                                                                                        \
-            std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);                                  \
-            setError((int)e_, m_.c_str(), __FILE__, __LINE__);                                                   \
-        }                                                                                                        \
-    } while (0)
-
-#define ARGCHECK(cond, msg)                                                                                      \
-    do                                                                                                           \
-    {                                                                                                            \
-        if (!(cond))                                                                                             \
-            setError(-1, msg, __FILE__, __LINE__);                                                               \
-    } while (0)
-
-bool ok()
-{
-    return g.errorCode == 0;
-}
-
-bool ready(const char *who)
-{
-    if (!ok())
-        return false;
-    if (!g.initialized)
-    {
-        setError(-1, (std::string(who) + ": initialize_scene has not been called").c_str(), __FILE__, __LINE__);
-        return false;
-    }
-    return true;
-}
-
-void release(DeviceBuffer &b)
-{
-    if (b.ptr)
-        (void)hipFree(b.ptr);
-    b.ptr = nullptr;
-    b.bytes = 0;
-}
-
-/* grow-only device allocation */
-void reserve(DeviceBuffer &b, size_t bytes)
-{
-    if (bytes < 16)
-        bytes = 16;
-    if (b.ptr && b.bytes >= bytes)
-        return;
-    release(b);
-    HIPCHECK(hipMalloc(&b.ptr, bytes));
-    if (ok())
-        b.bytes = bytes;
-}
-
-template <class T>
-void upload(DeviceBuffer &b, const std::vector<T> &host)
-{
-    reserve(b, host.size() * sizeof(T));
-    if (ok() && !host.empty())
-    {
-        /* pageable source: the copy is complete for the caller when this returns */
-        HIPCHECK(hipMemcpyAsync(b.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, g.stream));
-        HIPCHECK(hipStreamSynchronize(g.stream));
-    }
-}
-
-inline int bitsi(float v)
-{
-    int i;
-    memcpy(&i, &v, sizeof(i));
-    return i;
-}
-inline float bitsf(int v)
-{
-    float f;
-    memcpy(&f, &v, 4);
-    return f;
-}
-
-int stripRows()
-{
-    return g.nbRows >= 0 ? g.nbRows : g.height;
-}
-
+HostProfile gHostProfile;
 void allocateFrame()
 {
     const int rows = stripRows();
@@ -2252,11 +1054,7 @@ void checkTextureTables()
 /* (defined with the list builders further down) */
 void maybeBuildOrderFreeLists();
 
-/* (defined with the RCCL layer at the end of this file) */
-void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
-                       int wanted, DepthHalo *halo);
-int agreedHaloRows(const PostProcessingInfo &ppInfo);
-bool haveCommunicator();
+/* exchangeDepthHalo, agreedHaloRows, haveCommunicator: solr_rccl.hip (engine.h) */
 
 /* A frame with the ambient-occlusion post-process on a rank of a communicator owes its neighbours the boundary rows
  * of its strip, whatever becomes of the frame on this rank: when renderImpl leaves before it got there (an argument
@@ -2295,8 +1093,6 @@ int neededFeatures(const SceneInfo &sceneInfo, bool full)
 void launchPostProcess(const SceneInfo &sceneInfo, const PostProcessingInfo &ppInfo, int flight, hipStream_t stream, int firstRow,
                        int nbRows, unsigned char *bitmap, HaloDebt &debt)
 {
-    const int nbPixels = sceneInfo.size.x * nbRows;
-    const dim3 pgrid((nbPixels + 255) / 256), pblock(256);
     if (ppInfo.type == ppe_ambientOcclusion)
     {
         /* a strip's taps reach into the rows of the ranks above and below: their depths come from the host
@@ -2321,34 +1117,22 @@ void launchPostProcess(const SceneInfo &sceneInfo, const PostProcessingInfo &ppI
                                   nbRows, sceneInfo.size.y, wanted, &halo);
             }
         }
-        /* the window the taps of this random buffer and this param2 can need (the kernel takes its own, exact reach and
-         * gathers from memory if this should ever be too small): |tap| <= 16 |param2| max|random| / 10 */
-        const float aoReach = 16.f * fabsf(ppInfo.param2) * g.randomsReach / 10.f;
-        const int aoR = aoReach < 4096.f ? (int)aoReach + 3 : 4096;
-        const long aoCells = (long)(AO_TILE_W + 2 * aoR) * (AO_TILE_H + 2 * aoR);
-        const int aoWindow = (int)std::min<long>(std::max<long>(aoCells, 64), AO_WINDOW_FLOATS);
         if (ok())
-            hipLaunchKernelGGL(k_ambientOcclusion,
-                               dim3((((sceneInfo.size.x + AO_TILE_W - 1) / AO_TILE_W) * ((nbRows + AO_TILE_H - 1) / AO_TILE_H) +
-                                     AO_TILES_PER_GROUP - 1) / AO_TILES_PER_GROUP),
-                               pblock, (size_t)aoWindow * sizeof(float), stream, sceneInfo, ppInfo, nbRows,
-                               (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
-                               g.randoms.ptr ? g.nbRandoms : 0L, bitmap, halo, firstRow, aoWindow);
+            solrpost::ambientOcclusion(stream, sceneInfo, ppInfo, nbRows, (const PixelRecord *)flightPp(flight).ptr,
+                                       (const float *)g.randoms.ptr, g.randoms.ptr ? g.nbRandoms : 0L, bitmap, halo, firstRow,
+                                       g.randomsReach);
     }
     else if (ppInfo.type == ppe_depthOfField)
-        hipLaunchKernelGGL(k_depthOfField, pgrid, pblock, 0, stream, sceneInfo, ppInfo, nbRows,
-                           (const PixelRecord *)flightPp(flight).ptr, (const float *)g.randoms.ptr,
-                           g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
+        solrpost::depthOfField(stream, sceneInfo, ppInfo, nbRows, (const PixelRecord *)flightPp(flight).ptr,
+                               (const float *)g.randoms.ptr, g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
     else if (ppInfo.type == ppe_radiosity)
-        hipLaunchKernelGGL(k_radiosity, pgrid, pblock, 0, stream, sceneInfo, ppInfo, nbRows,
-                           (const PixelRecord *)flightPp(flight).ptr, (const int4 *)flightIds(flight).ptr,
-                           (const float *)g.randoms.ptr, g.randoms.ptr ? g.nbRandoms : 0L, bitmap);
+        solrpost::radiosity(stream, sceneInfo, ppInfo, nbRows, (const PixelRecord *)flightPp(flight).ptr,
+                            (const int4 *)flightIds(flight).ptr, (const float *)g.randoms.ptr, g.randoms.ptr ? g.nbRandoms : 0L,
+                            bitmap);
     else if (ppInfo.type == ppe_filter)
-        hipLaunchKernelGGL(k_filter, pgrid, pblock, 0, stream, sceneInfo, ppInfo, nbRows,
-                           (const PixelRecord *)flightPp(flight).ptr, bitmap);
+        solrpost::filter(stream, sceneInfo, ppInfo, nbRows, (const PixelRecord *)flightPp(flight).ptr, bitmap);
     else
-        hipLaunchKernelGGL(k_cartoon, pgrid, pblock, 0, stream, sceneInfo, ppInfo, nbRows,
-                           (const PixelRecord *)flightPp(flight).ptr, bitmap);
+        solrpost::cartoon(stream, sceneInfo, ppInfo, nbRows, (const PixelRecord *)flightPp(flight).ptr, bitmap);
     HIPCHECK(hipGetLastError());
 }
 
@@ -2593,9 +1377,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
              * the sort before its next frame picks that buffer up */
             const int target = sort ? (g.orderBuffer ^ 1) : g.orderBuffer;
             DeviceBuffer &orderOut = target ? g.tileOrder2 : g.tileOrder;
-            hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, stream, (const unsigned *)g.tileCost.ptr,
-                               (unsigned *)g.tileCostSnapshot.ptr, (unsigned *)orderOut.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev,
-                               sort ? activeFlights() : 0);
+            solrpost::orderTiles(stream, (const unsigned *)g.tileCost.ptr, (unsigned *)g.tileCostSnapshot.ptr,
+                                 (unsigned *)orderOut.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev, sort ? activeFlights() : 0);
             HIPCHECK(hipGetLastError());
             if (sort)
             {
@@ -2758,46 +1541,6 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     }
 }
 
-void releaseImageRing()
-{
-    if (g.copyStream)
-        (void)hipStreamSynchronize(g.copyStream);
-    for (int i = 0; i < Engine::IMAGE_RING; ++i)
-    {
-        if (g.pinnedImage[i] && !g.sharedRing)
-            (void)hipHostFree(g.pinnedImage[i]);
-        g.pinnedImage[i] = nullptr;
-        if (g.imageDone[i])
-            (void)hipEventDestroy(g.imageDone[i]);
-        g.imageDone[i] = nullptr;
-    }
-    if (g.frameRendered)
-        (void)hipEventDestroy(g.frameRendered);
-    g.frameRendered = nullptr;
-    if (g.copyStream)
-        (void)hipStreamDestroy(g.copyStream);
-    g.copyStream = nullptr;
-    g.pinnedBytes = 0;
-    for (long &serial : g.slotSerial)
-        serial = -1;
-    if (g.sharedRing)
-    {
-        (void)hipHostUnregister(g.sharedRing);
-        (void)munmap(g.sharedRing, g.sharedBytes);
-        if (g.shareRank == 0 && !g.sharedName.empty())
-            (void)shm_unlink(g.sharedName.c_str());
-        g.sharedName.clear();
-        g.sharedRing = nullptr;
-        g.sharedBytes = 0;
-    }
-    for (int f = 0; f < MAX_FLIGHTS; ++f)
-    {
-        g.flightCopy[f][0] = g.flightCopy[f][1] = -1;
-        g.bitmapSide[f] = 0;
-        release(g.bitmapAlt[f]);
-    }
-}
-
 void collectEvents()
 {
     hipEvent_t before = nullptr;
@@ -2824,7 +1567,7 @@ void collectEvents()
         (void)hipEventDestroy(before);
     g.events.clear();
 }
-} // namespace
+} // namespace solreng
 
 /* For csrc/solr_probes.hip (the test-only entry points of include/solr_hip_probes.h): the resident scene exactly as
  * renderImpl hands it to the renderer - pending uploads flushed, the order-free lists built when they are due - the
@@ -2857,24 +1600,6 @@ int residentScene(const SceneInfo &sceneInfo, bool exactNodes, SceneArgs *S, int
     return 0;
 }
 void fail(int code, const char *what) { setError(code, what, __FILE__, __LINE__); }
-
-/* the read-back ticket of the serial-th frame (no engine needed: plain arithmetic), and the serial counter itself, so
- * that a test can put a running engine a few frames before 2^31 / IMAGE_RING tickets and go across */
-int ticketOfSerial(long long serial, int *slot, long long *period)
-{
-    const int s = (int)(serial % Engine::IMAGE_RING); /* (a ring of this process's own; a shared ring counts its slots itself) */
-    if (slot)
-        *slot = s;
-    if (period)
-        *period = Engine::TICKET_PERIOD;
-    return Engine::ticketOf((long)serial, s);
-}
-long long imageSerial(long long setTo)
-{
-    if (setTo >= 0)
-        gFirst.imageSerial = (long)setTo;
-    return gFirst.imageSerial;
-}
 
 /* The post-processing stage of cudaRender (CRT:1857-1890) over a float frame buffer of the caller's: the buffer goes
  * into the engine's current buffer set, launchPostProcess - what renderImpl launches behind the renderer - runs over
@@ -2911,8 +1636,7 @@ int postProcess(const SceneInfo &sceneInfo, const PostProcessingInfo &ppInfo, co
     }
     else
     {
-        hipLaunchKernelGGL(k_default, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, sceneInfo, (int)pixels,
-                           (const PixelRecord *)flightPp(flight).ptr, bitmap);
+        solrpost::defaultConversion(stream, sceneInfo, (int)pixels, (const PixelRecord *)flightPp(flight).ptr, bitmap);
         HIPCHECK(hipGetLastError());
     }
     HIPCHECK(hipMemcpyAsync(bitmapOut, bitmap, pixels * SOLR_COLOR_DEPTH, hipMemcpyDeviceToHost, stream));
@@ -3666,7 +2390,8 @@ static int buildFreeOrderLists(const std::vector<float4> &rows, const std::vecto
  * holds its primitives (the reference's builder makes it so, GPUKernel.cpp:741-830; another host's boxes are
  * taken at their word only after this check; the types whose extent is not what the builder adds around p0 -
  * cones, ellipsoids ... - are sorted out by retagPrimitives). */
-namespace
+} // extern "C"
+namespace solreng
 {
 void maybeBuildOrderFreeLists()
 {
@@ -3836,7 +2561,8 @@ void maybeBuildOrderFreeLists()
     else
         g.geometryDirty = true;
 }
-} // namespace
+} // namespace solreng
+extern "C" {
 
 /* Grouping nodes.  The reference's grid builder produces wide levels - 31 sibling leaves under the root of
  * the Cornell scene, 134 top-level cells for the 100k-primitive molecule - and a walk tests every sibling
@@ -4459,10 +3185,6 @@ static void h2dMaterialsOne(Material *materials, int nbActiveMaterials)
     }
 }
 
-namespace
-{
-bool shareRandoms(); /* (with the RCCL layer at the end of this file) */
-}
 static void noteRandomsReach(const std::vector<float> &r)
 {
     /* the ambient-occlusion taps read randoms[i] and randoms[i + 100], i < 256 (CRT:1146-1153) */
@@ -4597,370 +3319,6 @@ static void d2hBitmapWait()
 {
     if (g.initialized && ok())
         HIPCHECK(hipStreamSynchronize(flightStream(g.current)));
-}
-
-/* Pipelined read-back of the image (SURVEY.md 8d defines the metric over cudaRender + d2h_bitmap; d2h_bitmap waits
- * for the frame and then for the copy, CudaRayTracer.cu:1647-1672, and nothing renders meanwhile).  Called after
- * cudaRender, solr_hip_d2h_image_async enqueues the copy of the RGB image of the frame rendered last - this
- * process's strip at its place in a full-size image, like d2h_bitmap - into a page-locked host image of the
- * engine's, on a copy stream of its own behind that frame's kernel, and returns a ticket at once; the render
- * streams are free for the next frames (solr_hip_set_frames_in_flight), whose kernels overlap the copy.
- * solr_hip_image_wait(ticket) waits for that one copy and returns the host image; it stays valid until
- * MAX_FLIGHTS more tickets have been handed out.  The ids stay on the device until d2h_bitmap asks for them. */
-namespace
-{
-/* the copy stream of the current engine and its events (one per slot of the ring) */
-void ensureCopyStream()
-{
-    if (g.copyStream)
-        return;
-    /* (at the render streams' priority.  Measured, profiles/r3/readback_probe.txt: with one or two render streams
-     * the copies cost nothing - 0.286 ms per Cornell frame with the image against 0.285 without; with three the
-     * frame takes 0.45 ms whatever the host's lag - the runtime's hardware queues are dealt out in turn and a
-     * render stream ends up sharing one with this stream; a stream of the highest priority, which gets queues of
-     * its own, was slower in every combination (0.33 at best).  HipKernel::setFramesInFlight therefore keeps
-     * the engine at two buffer sets and puts the rest of the depth into the host's lag.) */
-    HIPCHECK(hipStreamCreateWithFlags(&g.copyStream, hipStreamNonBlocking));
-    HIPCHECK(hipEventCreateWithFlags(&g.frameRendered, hipEventDisableTiming));
-    for (int i = 0; i < Engine::IMAGE_RING && ok(); ++i)
-        HIPCHECK(hipEventCreateWithFlags(&g.imageDone[i], hipEventDisableTiming));
-}
-
-/* the ring of page-locked images lives in engine 0 (every in-process device copies its strip into the same image) */
-bool ensureImageRing()
-{
-    Engine &e = gFirst;
-    const size_t frameBytes = (size_t)e.width * e.height * SOLR_COLOR_DEPTH;
-    if (e.pinnedBytes >= frameBytes)
-        return true;
-    if (e.sharedRing)
-    {
-        setError(-1, "the frame has grown beyond the host image the ranks share (solr_hip_image_share): share again", __FILE__, __LINE__);
-        return false;
-    }
-    Engine *const was = gCurrent;
-    gCurrent = &gFirst;
-    releaseImageRing(); /* (outstanding tickets are void from here on: their serial no longer matches) */
-    for (int i = 0; i < Engine::IMAGE_RING && ok(); ++i)
-    {
-        HIPCHECK(hipHostMalloc((void **)&g.pinnedImage[i], frameBytes, hipHostMallocPortable));
-        if (ok())
-            memset(g.pinnedImage[i], 0, frameBytes);
-    }
-    if (ok())
-        g.pinnedBytes = frameBytes;
-    const bool fine = ok();
-    gCurrent = was;
-    return fine;
-}
-
-/* the current engine's strip of the frame it rendered last -> its rows of `image`, on the engine's copy stream behind
- * that frame's kernel; `slot` names the event that says the copy has landed */
-void copyStripBehindFrame(BitmapBuffer *image, int slot)
-{
-    if (!ok())
-        return;
-    HIPCHECK(hipSetDevice(g.device));
-    ensureCopyStream();
-    if (!ok())
-        return;
-    const int flight = g.current;
-    const int rows = stripRows();
-    const int first = g.nbRows >= 0 ? g.firstRow : 0;
-    const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr;
-    /* The copy on the frame's own stream instead of the copy stream (solr_hip_set_copy_route; SOLR_HIP_COPY_INLINE=0/1
-     * overrides): it then delays that stream's next frame, not the other streams'.  Measured, profiles/r4/readback_routes.txt:
-     * a whole 1080p frame is best served by two buffer sets and the copy stream (0.272 ms; three sets and their own
-     * streams 0.280), a 1/8 strip - one round of waves, as slow as its slowest - by three sets and their own streams
-     * (0.038 ms against 0.045). */
-    static const char *forced = getenv("SOLR_HIP_COPY_INLINE");
-    const bool inlineCopy = forced && forced[0] ? forced[0] == '1' : gFirst.copyOnRenderStream;
-    const hipStream_t copyOn = inlineCopy ? flightStream(flight) : g.copyStream;
-    if (!inlineCopy)
-    {
-        HIPCHECK(hipEventRecord(g.frameRendered, flightStream(flight)));
-        HIPCHECK(hipStreamWaitEvent(g.copyStream, g.frameRendered, 0));
-    }
-    if (rows > 0 && src)
-        HIPCHECK(hipMemcpyAsync(image + (size_t)g.width * first * SOLR_COLOR_DEPTH, src,
-                                (size_t)g.width * rows * SOLR_COLOR_DEPTH, hipMemcpyDeviceToHost, copyOn));
-    HIPCHECK(hipEventRecord(g.imageDone[slot], copyOn));
-    if (!g.boundBitmap)
-        g.flightCopy[flight][g.bitmapSide[flight]] = slot;
-}
-
-/* hands out the next slot of the ring; the ticket is (serial mod TICKET_PERIOD) * IMAGE_RING + slot: positive for ever
- * (`(int)(serial * IMAGE_RING + slot)` went negative after 2^31 / 6 tickets and read as an error code) */
-int nextTicket(int *slot)
-{
-    Engine &e = gFirst;
-    const long serial = ++e.imageSerial;
-    if (e.sharedRing)
-    {
-        const long seq = ++e.shareSeq;
-        *slot = (int)(seq % Engine::IMAGE_RING);
-        e.slotShareSeq[*slot] = seq;
-    }
-    else
-        *slot = (int)(serial % Engine::IMAGE_RING);
-    e.slotSerial[*slot] = serial;
-    return Engine::ticketOf(serial, *slot);
-}
-
-/* the slot of a ticket whose image is still the one it was handed out for (the slot's full serial says so; generations
- * are compared modulo the ticket's period) */
-bool liveTicket(int ticket, int *slot)
-{
-    if (ticket < 0)
-        return false;
-    *slot = ticket % Engine::IMAGE_RING;
-    const long held = gFirst.slotSerial[*slot];
-    return gFirst.pinnedImage[*slot] != nullptr && held >= 0 && held % Engine::TICKET_PERIOD == (long)(ticket / Engine::IMAGE_RING);
-}
-
-/* shared ring: report, for every slot, the newest copy of this rank that has LANDED (its event has fired) - at every
- * call of the read-back API, not only when this rank's host asks for that image: a rank whose host never calls
- * solr_hip_image_wait must not keep the root waiting */
-void publishLanded()
-{
-    Engine &e = gFirst;
-    if (!e.sharedRing)
-        return;
-    for (int slot = 0; slot < Engine::IMAGE_RING; ++slot)
-    {
-        const long seq = e.slotShareSeq[slot];
-        if (seq <= e.sharePublished[slot] || !e.imageDone[slot] || !e.slotOfStrips[slot])
-            continue;
-        if (hipEventQuery(e.imageDone[slot]) != hipSuccess)
-            continue;
-        e.sharedRing->done[e.shareRank][slot].store(seq, std::memory_order_release);
-        e.sharePublished[slot] = seq;
-    }
-}
-} // namespace
-
-/* 0 (default): the pipelined read-back copies on a stream of its own behind the frame's kernel; 1: on the frame's own
- * stream (what to choose: see copyStripBehindFrame) */
-void solr_hip_set_copy_route(int onTheFramesOwnStream)
-{
-    gFirst.copyOnRenderStream = onTheFramesOwnStream != 0;
-}
-
-int solr_hip_d2h_image_async(void)
-{
-    HostSpan whole("solr_hip_d2h_image_async");
-    if (!ready("solr_hip_d2h_image_async"))
-        return -1;
-    ARGCHECK(g.width > 0 && g.height > 0, "solr_hip_d2h_image_async: no frame was rendered");
-    if (!ok())
-        return -1;
-    HIPCHECK(hipSetDevice(g.device));
-    if (!ensureImageRing())
-        return -1;
-    if (g.sharedRing)
-    {
-        publishLanded();
-        /* the slot's last frame must have been handed to the root's host before this rank overwrites its rows (ranks
-         * are a few frames apart at most: normally no wait at all).  The root gives an image back when it asks for the
-         * NEXT one, so a host that lets IMAGE_RING - 1 tickets pile up without asking for any would wait for itself:
-         * refused up front, with the limit, before a ticket is taken (the ranks' ticket sequences stay alike) */
-        const long serial = g.shareSeq + 1; /* (the ring's sequence number of the ticket about to be taken) */
-        ARGCHECK(serial - 1 - g.lastWaitedSeq < Engine::IMAGE_RING - 1,
-                 "solr_hip_d2h_image_async: 5 tickets of the shared image ring are outstanding (IMAGE_RING - 1): ask for "
-                 "the oldest one (solr_hip_image_wait) before the next frame is read back");
-        if (!ok())
-            return -1;
-        const auto t0 = std::chrono::steady_clock::now();
-        while (g.sharedRing->consumed.load(std::memory_order_acquire) < serial - Engine::IMAGE_RING)
-        {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
-            {
-                setError(-1, "solr_hip_d2h_image_async: the root has not taken the frame this slot of the shared image ring "
-                             "still holds (60 s)", __FILE__, __LINE__);
-                return -1;
-            }
-            sched_yield();
-        }
-    }
-    int slot = 0;
-    const int ticket = nextTicket(&slot);
-    g.slotOfStrips[slot] = g.sharedRing != nullptr;
-    BitmapBuffer *const image = gFirst.pinnedImage[slot];
-    onEveryDevice([&](int) { copyStripBehindFrame(image, slot); });
-    return solr_hip_last_error(nullptr, 0) == 0 ? ticket : -1;
-}
-
-/* back to a ring of this process's own (after solr_hip_image_share; outstanding tickets are void) */
-void solr_hip_image_unshare(void)
-{
-    if (!g.initialized || !g.sharedRing)
-        return;
-    quiesce();
-    (void)hipSetDevice(g.device);
-    releaseImageRing();
-}
-
-/* One host image for all ranks of a multi-process job.  The reference copies every device's strip to its place in
- * the host bitmap over that device's own link (d2h_bitmap, CudaRayTracer.cu:1647-1672); with one process per GPU the
- * strips meet in memory the processes share: the ring of page-locked images of solr_hip_d2h_image_async becomes a
- * POSIX shared-memory segment `name` (rank 0 creates it - call it there first, e.g. before a barrier - the others
- * open it), registered with the HIP runtime in every process.  From then on every rank's solr_hip_d2h_image_async
- * copies its strip to its rows of the same image, and solr_hip_image_wait on the ROOT (rank 0) returns when every
- * rank's strip of that frame has landed: the assembled frame on the host at the bandwidth of N PCIe links, not one.
- * The ranks run the same program (the same sequence of tickets).  After initialize_scene / reshape_scene (the frame
- * size is the segment's); undone by finalize_scene.  0, or -1 with the error set. */
-int solr_hip_image_share(const char *name, int rank, int world)
-{
-    if (!ready("solr_hip_image_share"))
-        return -1;
-    ARGCHECK(name && name[0] == '/' && rank >= 0 && world >= 1 && world <= 64 && rank < world && gDevices == 1,
-             "solr_hip_image_share: a name like /solr_frame, 0 <= rank < world <= 64, one device per process");
-    ARGCHECK(g.width > 0 && g.height > 0, "solr_hip_image_share: no frame size yet (reshape_scene)");
-    if (!ok())
-        return -1;
-    quiesce();
-    HIPCHECK(hipSetDevice(g.device));
-    releaseImageRing();
-    const size_t frameBytes = (size_t)g.width * g.height * SOLR_COLOR_DEPTH;
-    const size_t stride = (frameBytes + 4095) & ~(size_t)4095;
-    const size_t head = (sizeof(SharedRing) + 4095) & ~(size_t)4095;
-    const size_t bytes = head + stride * Engine::IMAGE_RING;
-    int fd = -1;
-    if (rank == 0)
-    {
-        (void)shm_unlink(name);
-        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd >= 0 && ftruncate(fd, (off_t)bytes) != 0)
-        {
-            close(fd);
-            fd = -1;
-        }
-    }
-    else
-    {
-        const auto t0 = std::chrono::steady_clock::now();
-        struct stat st;
-        while ((fd = shm_open(name, O_RDWR, 0600)) < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < bytes)
-        {
-            if (fd >= 0)
-                close(fd);
-            fd = -1;
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-                break;
-            usleep(2000);
-        }
-    }
-    void *base = fd >= 0 ? mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
-    if (fd >= 0)
-        close(fd);
-    if (base == MAP_FAILED)
-    {
-        if (rank == 0)
-            (void)shm_unlink(name); /* (created but not mapped: no name is left behind) */
-        setError(-1, "solr_hip_image_share: the shared segment could not be created / opened", __FILE__, __LINE__);
-        return -1;
-    }
-    SharedRing *ring = (SharedRing *)base;
-    if (rank == 0)
-    {
-        memset(base, 0, head);
-        ring->frameBytes = (long)frameBytes;
-        ring->imageStride = (long)stride;
-        ring->consumed.store(0, std::memory_order_release);
-    }
-    HIPCHECK(hipHostRegister(base, bytes, hipHostRegisterPortable));
-    if (!ok())
-    {
-        (void)munmap(base, bytes);
-        if (rank == 0)
-            (void)shm_unlink(name);
-        return -1;
-    }
-    g.sharedRing = ring;
-    g.sharedBytes = bytes;
-    g.sharedName = name;
-    g.shareRank = rank;
-    g.shareWorld = world;
-    for (int i = 0; i < Engine::IMAGE_RING; ++i)
-    {
-        g.pinnedImage[i] = (BitmapBuffer *)base + head + stride * i;
-        g.sharePublished[i] = g.slotShareSeq[i] = 0;
-    }
-    g.pinnedBytes = frameBytes;
-    /* the ranks count the ring's slots alike from here (shareSeq); the tickets' generation - this process's own serial -
-     * goes on counting: a ticket from before the share never names a slot of the shared ring (the serial
-     * used to be reset to 0 here, and an old ticket with the same serial then returned a new frame's image) */
-    g.shareSeq = 0;
-    g.lastHandedOut = 0;
-    g.lastWaitedSeq = 0;
-    return ok() ? 0 : -1;
-}
-
-/* Once EVERY rank has opened the segment (after a barrier of the caller's) the root takes the name away: the mappings
- * stay, and a job that dies from here on leaves nothing behind in /dev/shm (150 MB per crashed 4K run).
- * Harmless on the other ranks and without a shared ring. */
-void solr_hip_image_share_sealed(void)
-{
-    if (g.initialized && g.sharedRing && g.shareRank == 0 && !g.sharedName.empty())
-    {
-        (void)shm_unlink(g.sharedName.c_str());
-        g.sharedName.clear();
-    }
-}
-
-/* Waits for the copy (every in-process device's strip) behind `ticket` and returns the host image.  A ticket is good
- * until IMAGE_RING - 1 more have been handed out, or the frame grew and the ring with it: after that it names a
- * frame that is gone, and asking for it is an error - not, silently, a newer frame's image. */
-const BitmapBuffer *solr_hip_image_wait(int ticket)
-{
-    HostSpan whole("solr_hip_image_wait");
-    if (!ready("solr_hip_image_wait"))
-        return nullptr;
-    int slot = 0;
-    ARGCHECK(liveTicket(ticket, &slot), "solr_hip_image_wait: no such ticket, or one so old that its image has been "
-                                        "handed out again (or re-allocated for a larger frame, or shared since)");
-    if (!ok())
-        return nullptr;
-    onEveryDevice([&](int) {
-        if (g.imageDone[slot])
-            HIPCHECK(hipEventSynchronize(g.imageDone[slot]));
-    });
-    if (g.sharedRing && ok())
-    {
-        /* this rank's strip of that frame has landed; the root returns when everybody's has */
-        const long serial = g.slotShareSeq[slot]; /* (the shared ring's sequence number of that frame) */
-        if (serial > g.lastWaitedSeq)
-            g.lastWaitedSeq = serial;
-        SharedRing &ring = *g.sharedRing;
-        if (g.slotOfStrips[slot] && serial > g.sharePublished[slot])
-        {
-            ring.done[g.shareRank][slot].store(serial, std::memory_order_release);
-            g.sharePublished[slot] = serial;
-        }
-        publishLanded();
-        if (g.shareRank == 0)
-        {
-            /* asking for the next image gives the last one back: only now may the other ranks overwrite its rows (a
-             * rank can be frames ahead of the root's host - a transport that buffers its sends lets it) */
-            if (ring.consumed.load(std::memory_order_relaxed) < g.lastHandedOut)
-                ring.consumed.store(g.lastHandedOut, std::memory_order_release);
-            const auto t0 = std::chrono::steady_clock::now();
-            /* (a ticket of solr_hip_d2h_gathered_async is the root's own copy of the assembled frame: nobody to wait for) */
-            for (int r = 1; r < g.shareWorld && g.slotOfStrips[slot]; ++r)
-                while (ring.done[r][slot].load(std::memory_order_acquire) < serial)
-                {
-                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
-                    {
-                        setError(-1, "solr_hip_image_wait: a rank's strip of this frame has not landed in the shared image (60 s)",
-                                 __FILE__, __LINE__);
-                        return nullptr;
-                    }
-                    sched_yield();
-                }
-            g.lastHandedOut = serial;
-        }
-    }
-    return solr_hip_last_error(nullptr, 0) == 0 ? gFirst.pinnedImage[slot] : nullptr;
 }
 
 /* the float frame buffer of the strip rendered last (strip-sized host buffer; with several in-process devices the
@@ -5304,382 +3662,6 @@ void solr_hip_memory_usage(unsigned long long bytes[4])
         bytes[3] += g.deepStack[f].bytes;
 }
 
-/* ---- multi-GPU from the C ABI: row strips gathered with RCCL, no torch ---------------------------------------
- * The reference splits the frame over the GPUs of one process inside cudaRender (CudaRayTracer.cu:1709-1815)
- * and assembles it with per-device copies in d2h_bitmap (:1647-1672).  Here it is one process per GPU: every
- * process sets its strip (solr_hip_set_strip with the rows of solr_hip_strip_rows), renders, and
- * solr_hip_gather_strips sends the strip to the root with RCCL - one grouped ncclSend / ncclRecv per peer over
- * xGMI - ENQUEUED ON THE STREAM THAT RENDERED THE FRAME, right behind the kernel: no event, no host wait; with
- * several frames in flight each flight has its own assembled-frame buffer on the root.  RCCL is loaded at run
- * time (dlopen; the copy a framework already mapped is reused), so the library needs it only when these entry
- * points are called.  The 128-byte id of ncclGetUniqueId travels from rank 0 to the others by whatever channel
- * the host application has (a file, a socket, MPI, torch's store: INTEGRATION.md). */
-namespace
-{
-typedef struct ncclComm *ncclComm_t;
-typedef struct
-{
-    char internal[128];
-} ncclUniqueId;
-struct Rccl
-{
-    void *lib = nullptr;
-    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*CommCount)(const ncclComm_t, int *) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    int (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr; /* (optional: one communicator per flight) */
-    ncclComm_t comm = nullptr;
-    /* One communicator per frame in flight (SOLR_HIP_COMM_PER_FLIGHT=1 / solr_hip_comm_set_per_flight).  RCCL orders
-     * the operations of ONE communicator, whatever streams they are enqueued on: with frames in flight on several
-     * streams, the gather of frame n + 1 (stream B) then waits for the gather of frame n (stream A) and the frames
-     * partly serialise.  Communicators split off the first one (ncclCommSplit, same ranks) do not order against each
-     * other; flightComm[f] carries the per-frame transfers of flight f (strip gather, depth halo), `comm` the blocking
-     * collectives and flight 0.  Off by default until an N > 1 run has measured both (bench.py prints the mode). */
-    ncclComm_t flightComm[MAX_FLIGHTS] = {};
-    bool perFlight = false;
-    int rank = 0, world = 0;
-    DeviceBuffer frame[MAX_FLIGHTS]; /* root: the assembled RGB8 frame of each flight */
-    int frameCopy[MAX_FLIGHTS] = {-1, -1, -1, -1}; /* the slot of the image ring whose copy still reads that frame, or -1 */
-    DeviceBuffer idsFrame;           /* root: the assembled primitive ids (solr_hip_gather_ids) */
-    int idsFlight = 0;               /* the flight whose stream carried that gather */
-    DeviceBuffer zeros;              /* what a rank sends when it cannot send its own rows (see joinWith) */
-    DeviceBuffer scratch;            /* the few floats of the blocking all-reduces */
-    int lastFlight = 0;
-    /* the rows of a neighbour's strip the ambient-occlusion taps reach, AGREED over the communicator (the maximum of
-     * what the ranks derive from their own parameters and random buffers); -1: not agreed yet */
-    int haloAgreed = -1;
-    bool haloStale = true;  /* something it depends on was uploaded since (or nothing was agreed yet) */
-    int haloParam2Bits = 0; /* PostProcessingInfo.param2 of the agreement */
-    unsigned sharedSeed = 0; /* rank 0's draw at solr_hip_comm_init, the same on every rank (solr_hip_comm_shared_seed) */
-} rccl;
-const int RCCL_UINT8 = 1; /* ncclUint8, rccl.h:460 */
-const int RCCL_INT32 = 2; /* ncclInt32 */
-const int RCCL_FLOAT32 = 7; /* ncclFloat32 */
-const int RCCL_SUM = 0, RCCL_MAX = 2; /* ncclSum, ncclMax */
-
-bool loadRccl()
-{
-    if (rccl.lib)
-        return true;
-    /* SOLR_HIP_RCCL_LIBRARY: another build of the library (a site's own RCCL; tests/loopback_rccl.c, which lets
-     * several ranks share the one GPU of a test box) */
-    const char *named = getenv("SOLR_HIP_RCCL_LIBRARY");
-    if (named && named[0])
-    {
-        if (!(rccl.lib = dlopen(named, RTLD_NOW | RTLD_GLOBAL)))
-        {
-            setError(-1, (std::string("SOLR_HIP_RCCL_LIBRARY=") + named + " could not be loaded: " + dlerror()).c_str(), __FILE__,
-                     __LINE__);
-            return false;
-        }
-    }
-    else
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
-                break;
-    if (!rccl.lib)
-    {
-        setError(-1, "RCCL (librccl.so) could not be loaded", __FILE__, __LINE__);
-        return false;
-    }
-    rccl.GetUniqueId = (decltype(rccl.GetUniqueId))dlsym(rccl.lib, "ncclGetUniqueId");
-    rccl.CommInitRank = (decltype(rccl.CommInitRank))dlsym(rccl.lib, "ncclCommInitRank");
-    rccl.CommDestroy = (decltype(rccl.CommDestroy))dlsym(rccl.lib, "ncclCommDestroy");
-    rccl.CommCount = (decltype(rccl.CommCount))dlsym(rccl.lib, "ncclCommCount");
-    rccl.GroupStart = (decltype(rccl.GroupStart))dlsym(rccl.lib, "ncclGroupStart");
-    rccl.GroupEnd = (decltype(rccl.GroupEnd))dlsym(rccl.lib, "ncclGroupEnd");
-    rccl.Send = (decltype(rccl.Send))dlsym(rccl.lib, "ncclSend");
-    rccl.Recv = (decltype(rccl.Recv))dlsym(rccl.lib, "ncclRecv");
-    rccl.AllReduce = (decltype(rccl.AllReduce))dlsym(rccl.lib, "ncclAllReduce");
-    rccl.GetErrorString = (decltype(rccl.GetErrorString))dlsym(rccl.lib, "ncclGetErrorString");
-    rccl.CommSplit = (decltype(rccl.CommSplit))dlsym(rccl.lib, "ncclCommSplit");
-    if (!rccl.GetUniqueId || !rccl.CommInitRank || !rccl.CommDestroy || !rccl.GroupStart || !rccl.GroupEnd ||
-        !rccl.Send || !rccl.Recv || !rccl.AllReduce)
-    {
-        setError(-1, "librccl.so lacks an entry point the strip gather needs", __FILE__, __LINE__);
-        dlclose(rccl.lib);
-        rccl.lib = nullptr;
-        return false;
-    }
-    return true;
-}
-
-bool rcclOk(int result, const char *what)
-{
-    if (result == 0)
-        return true;
-    std::string text = std::string(what) + ": " + (rccl.GetErrorString ? rccl.GetErrorString(result) : "RCCL error");
-    setError(-1, text.c_str(), __FILE__, __LINE__);
-    return false;
-}
-
-/* the communicator that carries the per-frame transfers of `flight` */
-ncclComm_t commOf(int flight)
-{
-    return (rccl.perFlight && flight >= 0 && flight < MAX_FLIGHTS && rccl.flightComm[flight]) ? rccl.flightComm[flight] : rccl.comm;
-}
-
-/* ---- collectives that every rank joins ---------------------------------------------------------------------------
- * The ranks of a communicator run the same host program (the same sequence of C-ABI calls on
- * every rank).  A collective that one rank leaves out - because an argument check failed on it alone, because it is
- * in an error state, because its strip is not the one the others think it has - leaves the others waiting for
- * ever.  So nothing rank-local decides WHETHER a rank takes part, only WHAT it contributes:
- *   - the blocking all-reduces carry a failure slot: a rank in trouble contributes zeros and raises it, and all
- *     ranks fail together after the sum;
- *   - the point-to-point transfers behind a frame (strip gather, depth-halo exchange) have their sizes fixed by the
- *     strip table and the agreed halo height - facts every rank holds alike - and a rank that cannot send its own rows
- *     sends that many bytes of zeros, records its error and returns -1: the frame is wrong and says so, nobody hangs. */
-
-/* a device allocation that does not depend on (or change) the engine's error state */
-bool reserveQuietly(DeviceBuffer &b, size_t bytes, bool zero)
-{
-    bytes = std::max(bytes, (size_t)16);
-    if (b.ptr && b.bytes >= bytes)
-        return true;
-    if (b.ptr)
-        (void)hipFree(b.ptr);
-    b.ptr = nullptr;
-    b.bytes = 0;
-    if (hipMalloc(&b.ptr, bytes) != hipSuccess)
-    {
-        b.ptr = nullptr;
-        return false;
-    }
-    b.bytes = bytes;
-    if (zero)
-        (void)hipMemset(b.ptr, 0, bytes);
-    return true;
-}
-
-/* `bytes` of zeros in HBM (the stand-in payload) */
-const void *zeroPayload(size_t bytes)
-{
-    return reserveQuietly(rccl.zeros, bytes, true) ? rccl.zeros.ptr : nullptr;
-}
-
-/* blocking all-reduce (sum or max) of a few floats, in place, on the engine's first stream; every rank, same count.
- * Works in an error state too - that is the point. */
-bool allReduceFloats(float *values, size_t n, int op, const char *what)
-{
-    if (!rccl.comm)
-        return false;
-    (void)hipSetDevice(g.device);
-    const hipStream_t stream = flightStream(0);
-    bool fine = reserveQuietly(rccl.scratch, n * sizeof(float), false);
-    /* (a rank that cannot even allocate the few floats still has to show up: it reduces in the zero buffer) */
-    void *buffer = fine ? rccl.scratch.ptr : (void *)zeroPayload(n * sizeof(float));
-    if (!buffer)
-    {
-        setError(-1, (std::string(what) + ": no device memory for the all-reduce; the other ranks are left waiting").c_str(),
-                 __FILE__, __LINE__);
-        return false;
-    }
-    if (fine)
-        fine = hipMemcpyAsync(buffer, values, n * sizeof(float), hipMemcpyHostToDevice, stream) == hipSuccess;
-    const int result = rccl.AllReduce(buffer, buffer, n, RCCL_FLOAT32, op, rccl.comm, stream);
-    if (result != 0)
-    {
-        (void)rcclOk(result, what);
-        return false;
-    }
-    if (hipMemcpyAsync(values, buffer, n * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess)
-        fine = false;
-    if (!fine)
-        setError(-1, (std::string(what) + ": a copy around the all-reduce failed").c_str(), __FILE__, __LINE__);
-    return fine;
-}
-
-/* The rows of the neighbouring strips the 256 ambient-occlusion taps of a pixel can reach (CRT:1146-1153: 16 * param2
- * * |random| / 10 pixels), as ALL ranks will use it for the exchange below.  Each rank derives a figure from its own
- * post-processing parameters and random buffer; hosts seed their random buffers differently unless told otherwise
- * (GPUKernel.cpp:89, fillRandoms: srand(time(0))), and where 16 * param2 * reach / 10 straddles an integer two
- * neighbours would post sends and receives of different sizes.  So the figure is agreed - one all-reduce (max) -
- * whenever something it depends on was uploaded (communicator, random buffer) or param2 differs from the last
- * agreement's: events of the host program, the same on every rank, not values.  Called by every rank at the top of
- * every cudaRender with the ambient-occlusion post-process, whatever state the rank is in. */
-int agreedHaloRows(const PostProcessingInfo &ppInfo)
-{
-    const float reach = 16.f * fabsf(ppInfo.param2) * g.randomsReach / 10.f;
-    const int wanted = reach < 4096.f ? (int)reach + 2 : 4096;
-    if (!rccl.comm || rccl.world < 2)
-        return wanted;
-    if (rccl.haloStale || rccl.haloAgreed < 0 || bitsi(ppInfo.param2) != rccl.haloParam2Bits)
-    {
-        float v[2] = {(float)wanted, ok() ? 0.f : 1.f};
-        if (!allReduceFloats(v, 2, RCCL_MAX, "ncclAllReduce (rows of the depth halo)"))
-            return wanted;
-        rccl.haloAgreed = (int)v[0];
-        rccl.haloStale = false;
-        rccl.haloParam2Bits = bitsi(ppInfo.param2);
-        if (v[1] > 0.f && ok())
-            setError(-1, "cudaRender: another rank of the communicator is in an error state", __FILE__, __LINE__);
-    }
-    return rccl.haloAgreed;
-}
-
-/* Rank 0's random buffer to every rank (the buffer feeds the taps of the ambient-occlusion kernel, the depth of field
- * and the jitter of accumulation passes: strips rendered from different buffers do not assemble to the frame one GPU
- * renders).  With a communicator, rank 0's buffer is THE buffer: solr_hip_comm_init and every h2d_randoms after it
- * end with this.  Blocking; every rank. */
-bool shareRandoms()
-{
-    if (!rccl.comm || rccl.world < 2)
-        return true;
-    rccl.haloStale = true;
-    const long n = g.randoms.ptr ? g.nbRandoms : 0;
-    /* the same count everywhere?  (two 16-bit halves: a float holds them exactly) */
-    /* (two more slots: a seed of rank 0's, in 16-bit halves, for what the hosts draw per frame - see
-     * solr_hip_comm_shared_seed) */
-    unsigned draw = 0;
-    if (rccl.rank == 0)
-    {
-        draw = (unsigned)std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u;
-        draw = (draw ^ (draw >> 15)) | 1u;
-    }
-    float v[8] = {(float)(n >> 16), -(float)(n >> 16), (float)(n & 0xffff), -(float)(n & 0xffff), ok() ? 0.f : 1.f,
-                  rccl.rank == 0 ? g.randomsReach : 0.f, (float)(draw >> 16), (float)(draw & 0xffffu)};
-    if (!allReduceFloats(v, 8, RCCL_MAX, "ncclAllReduce (size of the random buffer)"))
-        return false;
-    if (rccl.sharedSeed == 0)
-        rccl.sharedSeed = ((unsigned)v[6] << 16) | (unsigned)v[7];
-    if (v[0] != -v[1] || v[2] != -v[3])
-    {
-        setError(-1, "the ranks of the communicator hold random buffers of different sizes (h2d_randoms on some only?)",
-                 __FILE__, __LINE__);
-        return false;
-    }
-    if (v[4] > 0.f)
-    {
-        if (ok())
-            setError(-1, "another rank of the communicator is in an error state", __FILE__, __LINE__);
-        return false; /* every rank leaves here */
-    }
-    if (n == 0)
-        return true;
-    (void)hipSetDevice(g.device);
-    const hipStream_t stream = flightStream(0);
-    bool fine = rcclOk(rccl.GroupStart(), "ncclGroupStart");
-    if (fine && rccl.rank == 0)
-        for (int r = 1; r < rccl.world && fine; ++r)
-            fine = rcclOk(rccl.Send(g.randoms.ptr, (size_t)n, RCCL_FLOAT32, r, rccl.comm, stream), "ncclSend (random buffer)");
-    else if (fine)
-        fine = rcclOk(rccl.Recv(g.randoms.ptr, (size_t)n, RCCL_FLOAT32, 0, rccl.comm, stream), "ncclRecv (random buffer)");
-    if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd"))
-        fine = false;
-    if (hipStreamSynchronize(stream) != hipSuccess)
-        fine = false;
-    if (fine)
-        g.randomsReach = v[5];
-    return fine;
-}
-
-/* The strips of all ranks when they are not the equal ones of solr_hip_strip_rows (solr_hip_set_strip_table) */
-struct StripTable
-{
-    std::vector<int> first, count;
-    int height = 0;
-} stripTable;
-void stripOf(int rank, int world, int height, int *first, int *count)
-{
-    if ((int)stripTable.first.size() == world && stripTable.height == height && rank >= 0 && rank < world)
-    {
-        if (first)
-            *first = stripTable.first[rank];
-        if (count)
-            *count = stripTable.count[rank];
-        return;
-    }
-    solr_hip_strip_rows(rank, world, height, first, count, nullptr);
-}
-
-/* Ambient occlusion on a strip: the 256 taps of a pixel reach up to `wanted` rows into the strips of the ranks above
- * and below ("exchange a 16-row halo").  Every rank packs the depths of its first and last
- * `wanted` rows and trades them with its neighbours - one grouped ncclSend / ncclRecv pair per neighbour, on the
- * stream that rendered the strip, between the renderer and the post-processing kernel - so that the assembled frame
- * is the one a single GPU renders.  The sizes follow from the strip table and from `wanted` = agreedHaloRows alone,
- * so neighbours always post matching transfers; pp == nullptr (a rank that returned early from cudaRender, or whose
- * strip is not the table's) sends zeros and sets the error. */
-void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
-                       int wanted, DepthHalo *halo)
-{
-    if (!rccl.comm || rccl.world < 2 || wanted < 1 || W < 1 || frameRows < 1)
-        return;
-    int first = 0, count = 0;
-    stripOf(rccl.rank, rccl.world, frameRows, &first, &count);
-    if (count < 1)
-        return; /* no row of the frame is this rank's: its neighbours know and trade nothing with it */
-    int upRows = 0, downRows = 0;
-    if (rccl.rank > 0)
-        stripOf(rccl.rank - 1, rccl.world, frameRows, nullptr, &upRows);
-    if (rccl.rank + 1 < rccl.world)
-        stripOf(rccl.rank + 1, rccl.world, frameRows, nullptr, &downRows);
-    const int mine = std::min(wanted, count);
-    const int recvAbove = std::min(wanted, upRows), recvBelow = std::min(wanted, downRows);
-    const int sendUp = upRows > 0 ? mine : 0, sendDown = downRows > 0 ? mine : 0;
-    if (!(recvAbove || recvBelow || sendUp || sendDown))
-        return;
-    const size_t mineBytes = (size_t)mine * W * sizeof(float);
-    bool own = pp != nullptr && ok() && first == firstRow && count == nbRows;
-    if (pp != nullptr && ok() && !own)
-        setError(-1, "cudaRender: this process's strip is not the one solr_hip_strip_rows (or the table of "
-                     "solr_hip_set_strip_table) gives its rank; its neighbours received zeros for its boundary rows",
-                 __FILE__, __LINE__);
-    const bool room = reserveQuietly(g.haloAbove[flight], (size_t)std::max(recvAbove, 1) * W * sizeof(float), false) &&
-                      reserveQuietly(g.haloBelow[flight], (size_t)std::max(recvBelow, 1) * W * sizeof(float), false);
-    if (own && !(reserveQuietly(g.haloSendTop[flight], mineBytes, false) && reserveQuietly(g.haloSendBottom[flight], mineBytes, false)))
-        own = false;
-    const void *top = own ? g.haloSendTop[flight].ptr : zeroPayload(mineBytes);
-    const void *bottom = own ? g.haloSendBottom[flight].ptr : top;
-    if (!room || !top)
-    {
-        setError(-1, "cudaRender: no device memory for the depth-halo exchange; the neighbouring ranks are left waiting",
-                 __FILE__, __LINE__);
-        return;
-    }
-    if (own)
-    {
-        const dim3 grid((unsigned)((mine * W + 255) / 256)), block(256);
-        if (sendUp)
-            hipLaunchKernelGGL(k_packDepthRows, grid, block, 0, stream, pp, W, 0, mine, (float *)g.haloSendTop[flight].ptr);
-        if (sendDown)
-            hipLaunchKernelGGL(k_packDepthRows, grid, block, 0, stream, pp, W, nbRows - mine, mine,
-                               (float *)g.haloSendBottom[flight].ptr);
-        HIPCHECK(hipGetLastError());
-    }
-    bool fine = rcclOk(rccl.GroupStart(), "ncclGroupStart");
-    if (fine && sendUp)
-        fine = rcclOk(rccl.Send(top, (size_t)mine * W, RCCL_FLOAT32, rccl.rank - 1, commOf(flight), stream), "ncclSend (depth rows, up)");
-    if (fine && sendDown)
-        fine = rcclOk(rccl.Send(bottom, (size_t)mine * W, RCCL_FLOAT32, rccl.rank + 1, commOf(flight), stream),
-                      "ncclSend (depth rows, down)");
-    if (fine && recvAbove)
-        fine = rcclOk(rccl.Recv(g.haloAbove[flight].ptr, (size_t)recvAbove * W, RCCL_FLOAT32, rccl.rank - 1, commOf(flight), stream),
-                      "ncclRecv (depth rows, above)");
-    if (fine && recvBelow)
-        fine = rcclOk(rccl.Recv(g.haloBelow[flight].ptr, (size_t)recvBelow * W, RCCL_FLOAT32, rccl.rank + 1, commOf(flight), stream),
-                      "ncclRecv (depth rows, below)");
-    if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd") || !fine || !own || !halo)
-        return;
-    halo->above = (const float *)g.haloAbove[flight].ptr;
-    halo->below = (const float *)g.haloBelow[flight].ptr;
-    halo->nbAbove = recvAbove;
-    halo->nbBelow = recvBelow;
-}
-
-/* (for renderImpl, which is defined before this layer) */
-bool haveCommunicator()
-{
-    return rccl.comm != nullptr && rccl.world > 1;
-}
-} // namespace
 
 /* Extension: the depths (PostProcessingBuffer.colorInfo.w) of the rows next to this process's strip that other
  * processes rendered - nbAbove rows of `width` floats just above it, nbBelow just below - for hosts that move them
@@ -5698,554 +3680,6 @@ extern "C" int solr_hip_order_free_nodes(void)
 extern "C" int solr_hip_order_free_shadows(void)
 {
     return (g.initialized && orderFreeListsUsable() && g.opaqueShadows) ? 1 : 0;
-}
-
-extern "C" void solr_hip_set_depth_halo(const float *above, int nbAbove, const float *below, int nbBelow)
-{
-    if (!ready("solr_hip_set_depth_halo"))
-        return;
-    ARGCHECK(nbAbove >= 0 && nbBelow >= 0 && (nbAbove == 0 || above) && (nbBelow == 0 || below) && nbAbove <= 4096 &&
-                 nbBelow <= 4096,
-             "solr_hip_set_depth_halo: bad arguments");
-    if (!ok())
-        return;
-    quiesce();
-    HIPCHECK(hipSetDevice(g.device));
-    g.haloSuppliedAbove = g.haloSuppliedBelow = 0;
-    if (nbAbove)
-    {
-        std::vector<float> rows(above, above + (size_t)nbAbove * g.width);
-        upload(g.haloGivenAbove, rows);
-    }
-    if (nbBelow)
-    {
-        std::vector<float> rows(below, below + (size_t)nbBelow * g.width);
-        upload(g.haloGivenBelow, rows);
-    }
-    if (ok())
-    {
-        g.haloSuppliedAbove = nbAbove;
-        g.haloSuppliedBelow = nbBelow;
-    }
-}
-
-/* rows [first, first + count) of a `height`-row image for rank `rank` of `world`, and the common strip height:
- * contiguous strips like the reference's (CudaRayTracer.cu:1694-1696), the last one absorbing the remainder;
- * trailing ranks get no row when there are more ranks than rows to share out (solr_hip_set_strip(first, 0)) */
-void solr_hip_strip_rows(int rank, int world, int height, int *first, int *count, int *rowsPerRank)
-{
-    const int per = world > 0 ? (height + world - 1) / world : height;
-    const int f = rank * per;
-    int c = height - f;
-    c = c < 0 ? 0 : (c > per ? per : c);
-    if (first)
-        *first = f;
-    if (count)
-        *count = c;
-    if (rowsPerRank)
-        *rowsPerRank = per;
-}
-
-/* Cost-balanced strips.  Equal strips share out rows, not work: of the 100k-triangle mesh the strip at the
- * horizon takes 0.22 ms, the one at the bottom 0.012 (profiles/r2/strip_throughput_height_field.txt), and the
- * frame is as slow as its slowest rank.  rowCost[y] is what row y costs (any unit; solr_hip_strip_row_costs,
- * summed over the ranks by the host's control plane or solr_hip_balance_strips): contiguous strips whose
- * boundaries are multiples of `align` rows (8 = the tiles' height: a tile's cost then belongs to one strip)
- * chosen where the running sum is nearest to r / world of the total.  Every rank keeps at least `align` rows
- * while there are enough; rows without a cost count as a thousandth of the mean, so a frame that has not been
- * rendered yet gives the equal split.  Pure host arithmetic, the same on every rank. */
-int solr_hip_balanced_strips(const float *rowCost, int height, int world, int align, int *firstRows, int *nbRows)
-{
-    if (!rowCost || height < 1 || world < 1 || align < 1 || !firstRows || !nbRows)
-        return -1;
-    const int blocks = (height + align - 1) / align;
-    std::vector<double> prefix((size_t)blocks + 1, 0.0);
-    double total = 0.0;
-    for (int y = 0; y < height; ++y)
-        if (rowCost[y] > 0.f && rowCost[y] < 1e30f)
-            total += rowCost[y];
-    const double floor = total > 0.0 ? 1e-3 * total / height : 1.0;
-    for (int b = 0; b < blocks; ++b)
-    {
-        double sum = 0.0;
-        for (int y = b * align; y < std::min(height, (b + 1) * align); ++y)
-            sum += floor + ((rowCost[y] > 0.f && rowCost[y] < 1e30f) ? (double)rowCost[y] : 0.0);
-        prefix[(size_t)b + 1] = prefix[b] + sum;
-    }
-    const double all = prefix[blocks];
-    std::vector<int> cut((size_t)world + 1, 0); /* in blocks */
-    cut[world] = blocks;
-    int at = 0;
-    for (int r = 1; r < world; ++r)
-    {
-        const double target = all * r / world;
-        while (at < blocks && prefix[(size_t)at + 1] <= target)
-            ++at; /* prefix[at] <= target < prefix[at + 1] */
-        int best = (at < blocks && prefix[(size_t)at + 1] - target < target - prefix[at]) ? at + 1 : at;
-        /* at least one block for every rank if there are that many (else whoever the sums leave without) */
-        const bool room = blocks >= world;
-        best = std::max(best, cut[r - 1] + (room ? 1 : 0));
-        best = std::min(best, room ? blocks - (world - r) : blocks);
-        cut[r] = best;
-    }
-    for (int r = 0; r < world; ++r)
-    {
-        const int from = std::min(height, cut[r] * align), to = std::min(height, cut[r + 1] * align);
-        firstRows[r] = from;
-        nbRows[r] = std::max(0, to - from);
-    }
-    return 0;
-}
-
-/* The strips of all ranks, when they are not solr_hip_strip_rows' (balanced ones): what solr_hip_gather_strips
- * and the depth-halo exchange take the other ranks' rows from.  Contiguous, in rank order, covering the frame;
- * world = 0 forgets the table.  This process's own strip is still set with solr_hip_set_strip. */
-int solr_hip_set_strip_table(const int *firstRows, const int *nbRows, int world, int height)
-{
-    if (world == 0 || !firstRows || !nbRows)
-    {
-        stripTable.first.clear();
-        stripTable.count.clear();
-        stripTable.height = 0;
-        return 0;
-    }
-    int next = 0;
-    bool fine = world > 0 && height > 0;
-    for (int r = 0; fine && r < world; ++r)
-    {
-        fine = nbRows[r] >= 0 && (nbRows[r] == 0 || firstRows[r] == next);
-        next += nbRows[r];
-    }
-    if (!fine || next != height)
-    {
-        setError(1, "solr_hip_set_strip_table: the strips are not contiguous, in rank order and covering the frame",
-                 __FILE__, __LINE__);
-        return -1;
-    }
-    stripTable.first.assign(firstRows, firstRows + world);
-    stripTable.count.assign(nbRows, nbRows + world);
-    stripTable.height = height;
-    return 0;
-}
-
-/* What the rows of this process's strip cost in the frame rendered last: rowCost[y] for the rows of the strip
- * (frame coordinates; a tile's measured duration shared out over its rows), 0 elsewhere.  Needs tile scheduling
- * (solr_hip_set_tile_scheduling 1 or 2, the default) and a frame; waits for the frames in flight. */
-int solr_hip_strip_row_costs(float *rowCost, int height)
-{
-    if (!ready("solr_hip_strip_row_costs"))
-        return -1;
-    ARGCHECK(rowCost != nullptr && height == g.height, "solr_hip_strip_row_costs: rowCost[height of the frame]");
-    ARGCHECK(g.tileCost.ptr != nullptr && g.costFrames > 0 && g.costKey[0] > 0 && g.costKey[1] > 0,
-             "solr_hip_strip_row_costs: no frame has recorded tile costs (tile scheduling off?)");
-    if (!ok())
-        return -1;
-    quiesce();
-    const int nbTiles = (int)g.costKey[0], tilesX = (int)g.costKey[1], firstRow = (int)g.costKey[2], nbRows = (int)g.costKey[3];
-    std::vector<unsigned> cost((size_t)nbTiles);
-    HIPCHECK(hipMemcpy(cost.data(), g.tileCost.ptr, cost.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (!ok())
-        return -1;
-    for (int y = 0; y < height; ++y)
-        rowCost[y] = 0.f;
-    for (int t = 0; t < nbTiles; ++t)
-    {
-        const int y0 = (t / tilesX) * TILE, y1 = std::min(nbRows, y0 + TILE);
-        for (int y = y0; y < y1; ++y)
-            if (firstRow + y < height)
-                rowCost[firstRow + y] += (float)cost[t] / (float)(y1 - y0);
-    }
-    return 0;
-}
-
-/* Every rank, between frames, after a few frames on the current strips: the rows' costs of all ranks summed
- * (one ncclAllReduce of `height` floats), balanced strips from them, the table for the gather and this
- * process's own strip set - the next cudaRender renders it.  A host without a control plane of its own needs
- * nothing else; one that has (torch.distributed in bench.py) can do the sum there and call
- * solr_hip_balanced_strips + solr_hip_set_strip_table + solr_hip_set_strip itself.
- * Two all-reduces, and every rank that has a communicator takes part in both whatever its own state: first the
- * maximum of {rows the ambient-occlusion taps reach beyond a strip, a failure flag, the frame height and its
- * negative} - the halo exchange delivers rows of the next rank only, so no strip may be lower than the LARGEST reach
- * any rank has seen, every rank must cut with the same `align`, and ranks that disagree about the frame must not meet
- * in a sum of different lengths - then, if nobody failed, the sum of the rows' costs. */
-int solr_hip_balance_strips(void)
-{
-    if (!g.initialized || !rccl.comm)
-    {
-        /* the same on every rank of a correct program: nobody is waiting */
-        if (ok())
-            setError(-1, !g.initialized ? "solr_hip_balance_strips: initialize_scene has not been called"
-                                        : "solr_hip_balance_strips: no communicator (solr_hip_comm_init)",
-                     __FILE__, __LINE__);
-        return -1;
-    }
-    bool mine = ok();
-    const int height = g.height;
-    std::vector<float> cost((size_t)std::max(height, 1), 0.f);
-    /* a rank that has nothing to report (an empty strip, tile scheduling off, no frame yet) contributes zeros */
-    const bool recorded = mine && height > 0 && stripRows() > 0 && g.tileCost.ptr != nullptr && g.costFrames > 0 && g.costKey[0] > 0;
-    if (recorded && solr_hip_strip_row_costs(cost.data(), height) != 0)
-    {
-        mine = false;
-        std::fill(cost.begin(), cost.end(), 0.f);
-    }
-    quiesce();
-    float head[4] = {(float)std::max(g.haloWanted, 0), mine ? 0.f : 1.f, (float)height, -(float)height};
-    if (!allReduceFloats(head, 4, RCCL_MAX, "ncclAllReduce (balance: reach, failures, frame height)"))
-        return -1;
-    if (head[1] > 0.f || head[2] != -head[3] || height < 1)
-    {
-        if (ok())
-            setError(-1, head[1] > 0.f ? "solr_hip_balance_strips: another rank could not report its rows' costs"
-                                       : "solr_hip_balance_strips: the ranks do not render frames of the same height",
-                     __FILE__, __LINE__);
-        return -1; /* on every rank */
-    }
-    if (!allReduceFloats(cost.data(), (size_t)height, RCCL_SUM, "ncclAllReduce (balance: rows' costs)"))
-        return -1;
-    const int reach = (int)head[0];
-    const int align = std::max(TILE, (reach + TILE - 1) / TILE * TILE);
-    std::vector<int> first((size_t)rccl.world), count((size_t)rccl.world);
-    if (solr_hip_balanced_strips(cost.data(), height, rccl.world, align, first.data(), count.data()) != 0 ||
-        solr_hip_set_strip_table(first.data(), count.data(), rccl.world, height) != 0)
-        return -1;
-    solr_hip_set_strip(first[rccl.rank], count[rccl.rank]);
-    return ok() ? 0 : -1;
-}
-
-int solr_hip_comm_unique_id(void *id128)
-{
-    if (!id128 || !loadRccl())
-        return -1;
-    ncclUniqueId id;
-    if (!rcclOk(rccl.GetUniqueId(&id), "ncclGetUniqueId"))
-        return -1;
-    memcpy(id128, id.internal, sizeof(id.internal));
-    return 0;
-}
-
-/* Joins the communicator and, when it has more than one rank, makes rank 0's random buffer everybody's (see
- * shareRandoms; hosts seed theirs from the clock unless told otherwise).  Every rank, after initialize_scene and
- * after the uploads of its first frame. */
-int solr_hip_comm_init(int rank, int world, const void *id128)
-{
-    if (gDevices > 1)
-    {
-        setError(-1, "solr_hip_comm_init: this process renders on several devices (occupancyParameters.x > 1); a "
-                     "communicator belongs to the one-process-per-GPU model", __FILE__, __LINE__);
-        return -1;
-    }
-    if (!ready("solr_hip_comm_init") || !loadRccl())
-        return -1;
-    ARGCHECK(id128 != nullptr && world >= 1 && rank >= 0 && rank < world, "solr_hip_comm_init: bad arguments");
-    ARGCHECK(rccl.comm == nullptr, "solr_hip_comm_init: a communicator exists already");
-    if (!ok())
-        return -1;
-    HIPCHECK(hipSetDevice(g.device));
-    ncclUniqueId id;
-    memcpy(id.internal, id128, sizeof(id.internal));
-    if (!rcclOk(rccl.CommInitRank(&rccl.comm, world, id, rank), "ncclCommInitRank"))
-    {
-        rccl.comm = nullptr;
-        return -1;
-    }
-    rccl.rank = rank;
-    rccl.world = world;
-    rccl.haloAgreed = -1;
-    rccl.haloStale = true;
-    for (ncclComm_t &c : rccl.flightComm)
-        c = nullptr;
-    for (int &slot : rccl.frameCopy)
-        slot = -1;
-    const char *env = getenv("SOLR_HIP_COMM_PER_FLIGHT");
-    if (env && env[0])
-        rccl.perFlight = env[0] != '0';
-    if (rccl.perFlight)
-    {
-        /* every rank, in the same order: the split is a collective of the parent communicator */
-        if (!rccl.CommSplit)
-        {
-            setError(-1, "solr_hip_comm_init: one communicator per flight was asked for and this RCCL has no ncclCommSplit",
-                     __FILE__, __LINE__);
-            return -1;
-        }
-        rccl.flightComm[0] = rccl.comm;
-        for (int f = 1; f < MAX_FLIGHTS; ++f)
-            if (!rcclOk(rccl.CommSplit(rccl.comm, 0, rank, &rccl.flightComm[f], nullptr), "ncclCommSplit"))
-            {
-                rccl.flightComm[f] = nullptr;
-                return -1;
-            }
-    }
-    quiesce();
-    if (!shareRandoms())
-        return -1;
-    return ok() ? 0 : -1;
-}
-
-/* before solr_hip_comm_init: 1 = one communicator per frame in flight (see struct Rccl), 0 = one for everything (the
- * default; SOLR_HIP_COMM_PER_FLIGHT in the environment overrides either).  Every rank alike. */
-void solr_hip_comm_set_per_flight(int on)
-{
-    rccl.perFlight = on != 0;
-}
-
-/* communicators this process holds: 0 without one, 1, or one per possible flight */
-int solr_hip_comm_count(void)
-{
-    if (!rccl.comm)
-        return 0;
-    int n = 1;
-    for (int f = 1; f < MAX_FLIGHTS; ++f)
-        if (rccl.perFlight && rccl.flightComm[f])
-            ++n;
-    return n;
-}
-
-/* A number every rank of the communicator holds alike (rank 0 drew it at solr_hip_comm_init), 0 without a
- * communicator of more than one rank.  What a host draws per frame - GPUKernel::render_begin takes the frame's
- * timestamp from rand() (GPUKernel.cpp:2712-2727), and the timestamp indexes the random buffer in the shader, the
- * depth of field and the procedural spheres - has to be the same on every rank or the strips do not assemble to one
- * frame: hosts seed a generator of their own with this (sol-r_amd/host/HipKernel.cpp does) instead of talking to
- * each other every frame. */
-unsigned solr_hip_comm_shared_seed(void)
-{
-    return (rccl.comm && rccl.world > 1) ? rccl.sharedSeed : 0u;
-}
-
-/* ranks of the communicator as the library itself reports them (ncclCommCount), 0 without one */
-int solr_hip_comm_ranks(void)
-{
-    if (!rccl.comm)
-        return 0;
-    int n = rccl.world;
-    if (rccl.CommCount && rccl.CommCount(rccl.comm, &n) != 0)
-        return -1;
-    return n;
-}
-
-namespace
-{
-/* One gather: rows [first, first + count) of this rank -> `root`, `rowBytes` per row, on `stream`; the root receives
- * every rank's rows at their place in `assembled`.  Sizes come from the strip table alone; `own` == nullptr (this
- * rank cannot send its own rows) sends zeros. */
-bool gatherRows(int root, const void *own, void *assembled, size_t rowBytes, int datatype, size_t perByte, hipStream_t stream,
-                ncclComm_t comm, const char *what)
-{
-    int first = 0, count = 0;
-    stripOf(rccl.rank, rccl.world, g.height, &first, &count);
-    if (rccl.world == 1) /* one process: the strip is whatever was set, the "gather" a copy into the frame */
-    {
-        first = g.nbRows >= 0 ? g.firstRow : 0;
-        count = stripRows();
-    }
-    const void *payload = own;
-    if (!payload && count > 0 && !(payload = zeroPayload((size_t)count * rowBytes)))
-    {
-        setError(-1, (std::string(what) + ": no device memory; the other ranks are left waiting").c_str(), __FILE__, __LINE__);
-        return false;
-    }
-    bool fine = rcclOk(rccl.GroupStart(), "ncclGroupStart");
-    if (fine && rccl.rank == root && assembled)
-        for (int r = 0; r < rccl.world && fine; ++r)
-        {
-            int rf = first, rc = count;
-            if (rccl.world > 1)
-                stripOf(r, rccl.world, g.height, &rf, &rc);
-            if (rc > 0)
-                fine = rcclOk(rccl.Recv((char *)assembled + (size_t)rf * rowBytes, (size_t)rc * rowBytes / perByte, datatype, r,
-                                        comm, stream),
-                              "ncclRecv");
-        }
-    if (fine && count > 0)
-        fine = rcclOk(rccl.Send(payload, (size_t)count * rowBytes / perByte, datatype, root, comm, stream), "ncclSend");
-    if (!rcclOk(rccl.GroupEnd(), "ncclGroupEnd"))
-        fine = false;
-    return fine;
-}
-
-/* this process's strip is the one its rank has in the eyes of the others */
-bool stripIsTheTables()
-{
-    if (rccl.world == 1)
-        return true;
-    int first = 0, count = 0;
-    stripOf(rccl.rank, rccl.world, g.height, &first, &count);
-    return stripRows() == count && (count == 0 || (g.nbRows >= 0 ? g.firstRow : 0) == first);
-}
-
-int gatherImpl(int root, bool ids, const char *who)
-{
-    HostSpan whole("solr_hip_gather_strips / _ids");
-    if (!g.initialized || !rccl.comm || root < 0 || root >= rccl.world || g.width < 1 || g.height < 1)
-    {
-        /* program errors, the same on every rank: nobody is waiting */
-        if (ok())
-            setError(-1, (std::string(who) + (!g.initialized ? ": initialize_scene has not been called"
-                                              : !rccl.comm   ? ": no communicator (solr_hip_comm_init)"
-                                              : g.width < 1  ? ": no frame was rendered"
-                                                             : ": no such root")).c_str(),
-                     __FILE__, __LINE__);
-        return -1;
-    }
-    (void)hipSetDevice(g.device);
-    const int flight = g.current;
-    const hipStream_t stream = flightStream(flight);
-    const size_t rowBytes = (size_t)g.width * (ids ? sizeof(PrimitiveXYIdBuffer) : (size_t)SOLR_COLOR_DEPTH);
-    /* rank-local trouble decides what is sent, not whether (see the note on collectives above) */
-    bool mine = ok();
-    if (mine && !stripIsTheTables())
-    {
-        setError(-1, (std::string(who) + ": this process's strip is not the one solr_hip_strip_rows (or the table of "
-                                         "solr_hip_set_strip_table) gives its rank; the root received zeros for its rows").c_str(),
-                 __FILE__, __LINE__);
-        mine = false;
-    }
-    const void *src = ids ? flightIds(flight).ptr : (g.boundBitmap ? g.boundBitmap : flightBitmap(flight).ptr);
-    if (!src)
-        mine = false;
-    DeviceBuffer &assembled = ids ? rccl.idsFrame : rccl.frame[flight];
-    if (rccl.rank == root && !reserveQuietly(assembled, (size_t)g.height * rowBytes, true))
-    {
-        setError(-1, (std::string(who) + ": no device memory for the assembled frame; the other ranks are left waiting").c_str(),
-                 __FILE__, __LINE__);
-        return -1;
-    }
-    if (!ids && rccl.rank == root && rccl.frameCopy[flight] >= 0)
-    {
-        /* a pipelined read-back (solr_hip_d2h_gathered_async) may still be copying the frame this flight assembled
-         * last: the gather that overwrites it goes behind that copy */
-        if (gFirst.imageDone[rccl.frameCopy[flight]])
-            (void)hipStreamWaitEvent(stream, gFirst.imageDone[rccl.frameCopy[flight]], 0);
-        rccl.frameCopy[flight] = -1;
-    }
-    const bool fine = gatherRows(root, mine ? src : nullptr, rccl.rank == root ? assembled.ptr : nullptr, rowBytes,
-                                 ids ? RCCL_INT32 : RCCL_UINT8, ids ? 4 : 1, stream, commOf(flight), who);
-    if (!ids)
-        rccl.lastFlight = flight;
-    else
-        rccl.idsFlight = flight;
-    return (fine && mine && ok()) ? 0 : -1;
-}
-} // namespace
-
-/* the strip of the frame rendered last -> `root`, on that frame's stream.  Every rank calls it once per frame,
- * in the same order of frames.  Returns immediately. */
-int solr_hip_gather_strips(int root)
-{
-    return gatherImpl(root, false, "solr_hip_gather_strips");
-}
-
-/* Picking on an N-GPU frame (GPUKernel::getPrimitiveAt, GPUKernel.cpp:729-739, reads primitivesXYIds of the whole
- * frame; the reference's d2h_bitmap copies every device's strip of them after every frame, CudaRayTracer.cu:1664-1670):
- * the PrimitiveXYIdBuffer strips of the frame rendered last -> `root`, 16 bytes per pixel - five times the image, so
- * on demand, when picking asks, not per frame.  Every rank calls it; solr_hip_d2h_gathered_ids on the root waits and
- * copies the assembled height x width records to the host. */
-int solr_hip_gather_ids(int root)
-{
-    return gatherImpl(root, true, "solr_hip_gather_ids");
-}
-
-/* root: the assembled frame of the gather issued last (device memory, height x width x 3; valid once the
- * stream has run the gather - solr_hip_d2h_gathered waits for it) */
-void *solr_hip_gathered_frame(void)
-{
-    return rccl.frame[rccl.lastFlight].ptr;
-}
-
-int solr_hip_d2h_gathered(BitmapBuffer *hostBitmap)
-{
-    if (!ready("solr_hip_d2h_gathered"))
-        return -1;
-    ARGCHECK(hostBitmap != nullptr && rccl.frame[rccl.lastFlight].ptr != nullptr,
-             "solr_hip_d2h_gathered: nothing was gathered on this rank");
-    if (!ok())
-        return -1;
-    const hipStream_t stream = flightStream(rccl.lastFlight);
-    HIPCHECK(hipMemcpyAsync(hostBitmap, rccl.frame[rccl.lastFlight].ptr, (size_t)g.height * g.width * SOLR_COLOR_DEPTH,
-                            hipMemcpyDeviceToHost, stream));
-    HIPCHECK(hipStreamSynchronize(stream));
-    return ok() ? 0 : -1;
-}
-
-/* The delivered frame of an N-GPU job, pipelined: on the root, the assembled frame of the gather issued last is copied
- * to a page-locked host image on the engine's copy stream, behind that gather, and a ticket comes back at once
- * (solr_hip_image_wait(ticket) waits for it and returns the image) - the read-back of frame n overlaps the rendering
- * and the gather of frames n + 1 ..., like solr_hip_d2h_image_async does on one GPU.  The next gather into the same
- * flight's frame waits for the copy.  On the other ranks: nothing to deliver, returns -2 (no error). */
-int solr_hip_d2h_gathered_async(void)
-{
-    if (!ready("solr_hip_d2h_gathered_async"))
-        return -1;
-    if (!rccl.comm || !rccl.frame[rccl.lastFlight].ptr)
-    {
-        if (!g.sharedRing)
-            return -2;
-        /* with a ring the ranks share (solr_hip_image_share) every rank takes the ticket, so that the ranks keep
-         * counting alike; only the root has something to copy */
-        int slot = 0;
-        const int ticket = nextTicket(&slot);
-        g.slotOfStrips[slot] = false;
-        return ticket;
-    }
-    HIPCHECK(hipSetDevice(g.device));
-    if (!ensureImageRing())
-        return -1;
-    ensureCopyStream();
-    if (!ok())
-        return -1;
-    const int flight = rccl.lastFlight;
-    int slot = 0;
-    const int ticket = nextTicket(&slot);
-    HIPCHECK(hipEventRecord(g.frameRendered, flightStream(flight)));
-    HIPCHECK(hipStreamWaitEvent(g.copyStream, g.frameRendered, 0));
-    HIPCHECK(hipMemcpyAsync(g.pinnedImage[slot], rccl.frame[flight].ptr, (size_t)g.height * g.width * SOLR_COLOR_DEPTH,
-                            hipMemcpyDeviceToHost, g.copyStream));
-    HIPCHECK(hipEventRecord(g.imageDone[slot], g.copyStream));
-    g.slotOfStrips[slot] = false;
-    rccl.frameCopy[flight] = slot;
-    return ok() ? ticket : -1;
-}
-
-int solr_hip_d2h_gathered_ids(PrimitiveXYIdBuffer *hostIds)
-{
-    if (!ready("solr_hip_d2h_gathered_ids"))
-        return -1;
-    ARGCHECK(hostIds != nullptr && rccl.idsFrame.ptr != nullptr, "solr_hip_d2h_gathered_ids: nothing was gathered on this rank");
-    if (!ok())
-        return -1;
-    const hipStream_t stream = flightStream(rccl.idsFlight);
-    HIPCHECK(hipMemcpyAsync(hostIds, rccl.idsFrame.ptr, (size_t)g.height * g.width * sizeof(PrimitiveXYIdBuffer),
-                            hipMemcpyDeviceToHost, stream));
-    HIPCHECK(hipStreamSynchronize(stream));
-    return ok() ? 0 : -1;
-}
-
-void solr_hip_comm_finalize(void)
-{
-    solr_hip_set_strip_table(nullptr, nullptr, 0, 0); /* the table was that communicator's */
-    if (rccl.comm)
-    {
-        (void)hipDeviceSynchronize();
-        for (int f = 1; f < MAX_FLIGHTS; ++f)
-            if (rccl.flightComm[f] && rccl.flightComm[f] != rccl.comm)
-                (void)rccl.CommDestroy(rccl.flightComm[f]);
-        (void)rccl.CommDestroy(rccl.comm);
-        rccl.comm = nullptr;
-    }
-    for (ncclComm_t &c : rccl.flightComm)
-        c = nullptr;
-    for (int &slot : rccl.frameCopy)
-        slot = -1;
-    for (DeviceBuffer &b : rccl.frame)
-        release(b);
-    release(rccl.idsFrame);
-    release(rccl.zeros);
-    release(rccl.scratch);
-    rccl.world = 0;
-    rccl.haloAgreed = -1;
-    rccl.haloStale = true;
-    rccl.sharedSeed = 0;
 }
 
 #ifdef SOLR_TIMING
@@ -6390,7 +3824,7 @@ void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, 
     int use = asked;
     if (asked > 1)
     {
-        if (rccl.comm)
+        if (communicatorUp())
         {
             setError(-1, "initialize_scene: occupancyParameters.x > 1 asks for several devices in this process, which has "
                          "joined a communicator (one process per GPU): the two do not combine", __FILE__, __LINE__);

@@ -304,7 +304,7 @@ void HipKernel::setFramesInFlight(int n)
     flushFrames();
     m_flights = n < 1 ? 1 : (n > 4 ? 4 : n);
     /* the engine's own buffer sets: one while the host lags a single frame, two beyond - a third render stream
-     * ends up sharing a hardware queue with the copy stream (sol-r_amd/csrc/solr_hip.hip, solr_hip_d2h_image_async);
+     * ends up sharing a hardware queue with the copy stream (sol-r_amd/csrc/solr_image_ring.hip, solr_hip_d2h_image_async);
      * the depth beyond that is host lag, which the second RGB image of every set absorbs */
     solr_hip_set_frames_in_flight(m_flights <= 2 ? 1 : 2);
     if (m_flights == 1)

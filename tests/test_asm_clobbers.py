@@ -21,7 +21,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCE = os.path.join(ROOT, "sol-r_amd", "csrc", "solr_hip.hip")
+SOURCE = os.path.join(ROOT, "sol-r_amd", "csrc", "rows", "everything.hip")  # rt_device.h + renderer_kernel.h
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 

@@ -207,3 +207,80 @@ def test_loopback_transport_on_host_buffers(world):
         assert not left, left     # rank 0 swept the communicator's files
     finally:
         shutil.rmtree(directory, ignore_errors=True)
+
+
+_SHARING_RANK = r'''
+import ctypes as C, importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+name, what = sys.argv[2].encode(), sys.argv[3]
+solr = importlib.import_module("sol-r_amd")
+hip = solr.hip_lib()
+hip.solr_hip_image_wait.restype = C.c_void_p
+W, H = 96, 64
+k = solr.Kernel(engine="hip", device=0, deterministic_seed=5)
+solr.scenes.cornell(k, width=W, height=H, iterations=2)
+k.render(); k.check(0, "first frame")
+plain = np.zeros((H, W, 3), np.uint8)
+si = k.frame_parameters()[0]
+hip.solr_hip_d2h(C.byref(si), C.c_void_p(plain.ctypes.data), None)
+assert hip.solr_hip_image_share(name, 0, 1) == 0, "solr_hip_image_share"
+if what == "sealed":
+    hip.solr_hip_image_share_sealed()
+k.render()
+ticket = hip.solr_hip_d2h_image_async()
+ptr = hip.solr_hip_image_wait(ticket)
+assert ptr, "solr_hip_image_wait"
+got = np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3)
+assert np.array_equal(got, plain), "the shared ring's image is not the frame"
+print("SHARING", flush=True)
+if what == "finish":
+    k.finalize()
+    print("FINISHED", flush=True)
+else:
+    time.sleep(300)       # the parent kills this process where it stands
+'''
+
+
+@pytest.mark.gpu
+def test_a_killed_job_cannot_stop_the_next_one_and_a_sealed_one_leaves_nothing():
+    """VERDICT r4 6(c) / ADVICE r4: the ring of host images shared by a job's ranks is a POSIX shared-memory segment
+    (150 MB at 4K).  (1) a stale name - here garbage of the wrong size, then the segment of a job killed before it
+    sealed - does not stop the next job: rank 0 replaces it; (2) once sealed (bench.py does it behind the barrier
+    that follows the opening) the name is gone while the job still runs, so SIGKILL leaves nothing; (3) a job that
+    finalizes takes an unsealed name with it."""
+    if not os.path.isdir("/dev/shm"):
+        pytest.skip("no /dev/shm to look at")
+    name = "/solr_crash_test_%d" % os.getpid()
+    path = "/dev/shm" + name
+    root = os.path.dirname(HERE)
+
+    def start(what):
+        p = subprocess.Popen([sys.executable, "-c", _SHARING_RANK, root, name, what], stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, text=True)
+        lines = []
+        for line in p.stdout:
+            lines.append(line)
+            if line.startswith("SHARING"):
+                return p, lines
+        p.wait()
+        pytest.fail("the job did not get as far as sharing (%s):\n%s" % (what, "".join(lines)[-3000:]))
+
+    try:
+        with open(path, "wb") as f:
+            f.write(b"left by something else")
+        p, _ = start("crash")                      # (1a) garbage under the name: replaced
+        assert os.path.exists(path) and os.path.getsize(path) > 6 * 96 * 64 * 3
+        p.kill(); p.wait()
+        assert os.path.exists(path), "an unsealed segment outlives a killed job (what sealing is for)"
+        p, _ = start("sealed")                     # (1b) the killed job's segment: replaced, (2) and sealed
+        assert not os.path.exists(path), "sealed: the name is gone while the job runs"
+        p.kill(); p.wait()
+        assert not os.path.exists(path)
+        p, _ = start("finish")                     # (3)
+        out = p.communicate(timeout=60)[0]
+        assert p.returncode == 0 and "FINISHED" in out, out[-2000:]
+        assert not os.path.exists(path), "finalize_scene takes the segment's name with it"
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
