@@ -55,7 +55,13 @@ struct FrameArgs
 #define SOLR_TIMING_SLOTS (160000ul) /* timing build: workgroups of the largest frame it is used on (3840 x 2160 + split tiles) */
 #define SPLIT_TILES_MAX 256
 
-#define TILE 8
+/* a wave's 64 pixels: TILE_W x TILE_H (8 x 8; -DSOLR_TILE_W_LOG2=4 is 16 x 4 ... an experiment) */
+#ifndef SOLR_TILE_W_LOG2
+#define SOLR_TILE_W_LOG2 3
+#endif
+#define TILE_W (1 << SOLR_TILE_W_LOG2)
+#define TILE_H (64 >> SOLR_TILE_W_LOG2)
+#define TILE 8 /* rows the strips of a multi-process job are aligned to */
 #define WAVE 64
 
 /* device view of PostProcessingBuffer (same 32-byte layout, HIP vector types) */

@@ -46,12 +46,13 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
      * multiplication) */
     const int ty = F.tileMagic ? (int)(__umulhi((unsigned)tile, F.tileMagic) >> F.tileShift) : tile;
     const int tx = tile - ty * F.tilesX;
-    const int x = tx * TILE + (lane & (TILE - 1));
-    const int yLocal = ty * TILE + (lane >> 3);
+    const int x = tx * TILE_W + (lane & (TILE_W - 1));
+    const int yLocal = ty * TILE_H + (lane >> SOLR_TILE_W_LOG2);
     const int W = si.size.x;
     /* a quadrant wave: only the lanes of its quadrant take part; every lane's path is its own (the walks are
      * wave-synchronous, not wave-dependent), so the pixels come out the same whichever wave renders them */
-    const bool mine = part == 0 || ((((lane & 7) >> (3 - SOLR_SPLIT_LOG2)) | ((lane >> 3) >> (3 - SOLR_SPLIT_LOG2)) << SOLR_SPLIT_LOG2)) == part - 1;
+    const bool mine = part == 0 || ((((lane & (TILE_W - 1)) >> (SOLR_TILE_W_LOG2 - SOLR_SPLIT_LOG2)) |
+                                     ((lane >> SOLR_TILE_W_LOG2) >> (6 - SOLR_TILE_W_LOG2 - SOLR_SPLIT_LOG2)) << SOLR_SPLIT_LOG2)) == part - 1;
 #ifdef SOLR_PRIORITY_FOR_SPLIT_TILES
     /* experiment (profiles/r4/wave_priority.txt): the waves of a split tile - the frame's critical path - ask the SIMD's
      * arbiter for priority over the waves they share it with */
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
     int tileAgain = tile, partAgain = part, laneAgain = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+s"(tileAgain), "+s"(partAgain), "+v"(laneAgain));
     const int tyAgain = F.tileMagic ? (int)(__umulhi((unsigned)tileAgain, F.tileMagic) >> F.tileShift) : tileAgain;
-    const int xAgain = (tileAgain - tyAgain * F.tilesX) * TILE + (laneAgain & (TILE - 1));
-    const int yAgain = tyAgain * TILE + (laneAgain >> 3);
+    const int xAgain = (tileAgain - tyAgain * F.tilesX) * TILE_W + (laneAgain & (TILE_W - 1));
+    const int yAgain = tyAgain * TILE_H + (laneAgain >> SOLR_TILE_W_LOG2);
     const int index = ((xAgain < si.size.x) && (yAgain < F.nbRows)) ? yAgain * si.size.x + xAgain : 0;
     const int gindexAgain = (F.firstRow + yAgain) * si.size.x + xAgain;
 

@@ -1579,7 +1579,8 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     const bool freeOrder =
         tidy && S.nbBoxesFree > 0 && ballot(active && !longRay(r.d)) == 0ull;
     /* the thin copy of the list this walk takes (tightRay above) */
-    const bool tight = tidy && S.tightLists && ballot(active && !tightRay(r, si)) == 0ull;
+    constexpr bool thinLeaves = (FEAT & F_PLANE) != 0; /* (thin copies exist for leaves of plain axis planes only) */
+    const bool tight = thinLeaves && tidy && S.tightLists && ballot(active && !tightRay(r, si)) == 0ull;
     /* ... and the SHORT rays (the bounce rays, |direction| = L = 1 - rayEpsilon) in the reference's order: for them the
      * reference's cut-off - slab parameter t against closest DISTANCE - decides by WHEN a box is entered, and a thin
      * leaf is entered later than the reference's fat one.  The reference tests the primitives of leaf l iff its own box
@@ -1595,7 +1596,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     const bool shortTightLane = ddShort >= 0.25f && ddShort < 4.f && r.d.x != 0.f && r.d.y != 0.f && r.d.z != 0.f &&
                                 fabsf(r.o.x) <= si.viewDistance && fabsf(r.o.y) <= si.viewDistance &&
                                 fabsf(r.o.z) <= si.viewDistance;
-    const bool tightShort = tidy && S.tightLists && !tight && !freeOrder && !(COUNT != 1 && (FEAT & F_DEEP) && (FEAT & F_TRI)) &&
+    const bool tightShort = thinLeaves && tidy && S.tightLists && !tight && !freeOrder && !(COUNT != 1 && (FEAT & F_DEEP) && (FEAT & F_TRI)) &&
                             ballot(active && !shortTightLane) == 0ull;
     const float shortFarScale = 1.002f / fminf(sqrtf(ddShort) * (1.f - 1.0e-5f), 1.f);
     const float shortFarOffset = 2.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
@@ -2028,7 +2029,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         farFree = 1.0002f + 1.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z)) / lengthOL;
     }
     /* the thin copy of that list (tightRay: a shadow ray reaches from the point to the lamp, thousands of units) */
-    const bool tight = tidy && S.tightLists && ballot(active && !tightRay(r, si)) == 0ull;
+    const bool tight = (FEAT & F_PLANE) && tidy && S.tightLists && ballot(active && !tightRay(r, si)) == 0ull;
     if (tight)
         W.offBoxes += freeOrder ? 16u * (unsigned)S.nbBoxesFree + 2u : 2u * (unsigned)S.nbBoxes + 2u;
     const int nbBoxes = W.nbBoxes;

@@ -1250,8 +1250,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     F.trig.sz = sinf(angles[2]);
     F.firstRow = g.nbRows >= 0 ? g.firstRow : 0;
     F.nbRows = stripRows();
-    F.tilesX = (sceneInfo.size.x + TILE - 1) / TILE;
-    const int tilesY = (F.nbRows + TILE - 1) / TILE;
+    F.tilesX = (sceneInfo.size.x + TILE_W - 1) / TILE_W;
+    const int tilesY = (F.nbRows + TILE_H - 1) / TILE_H;
     {
         /* the reciprocal of tilesX for the kernel's tile -> (column, row): exact for every tile of this frame
          * (round-up multiplier of ceil(log2) + 16 extra bits; verified below, once per frame geometry) */

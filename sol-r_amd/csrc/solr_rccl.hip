@@ -549,7 +549,7 @@ int solr_hip_strip_row_costs(float *rowCost, int height)
         rowCost[y] = 0.f;
     for (int t = 0; t < nbTiles; ++t)
     {
-        const int y0 = (t / tilesX) * TILE, y1 = std::min(nbRows, y0 + TILE);
+        const int y0 = (t / tilesX) * TILE_H, y1 = std::min(nbRows, y0 + TILE_H);
         for (int y = y0; y < y1; ++y)
             if (firstRow + y < height)
                 rowCost[firstRow + y] += (float)cost[t] / (float)(y1 - y0);
