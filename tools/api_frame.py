@@ -25,28 +25,42 @@ if a.scene == "cornell":
     kw["iterations"] = 3
 getattr(solr.scenes, a.scene)(k, **kw)
 image = np.zeros((a.height, a.width, 3), np.uint8)
+BLOCKS = 5      # blocks of a.frames frames; the median block is reported (the host thread is what is measured here)
+
+
+def report(name, times):
+    times = sorted(times)
+    print("%-44s %.3f ms per frame (%s %dx%d, median of %d blocks of %d frames: %.3f ... %.3f)" % (
+        name, 1e3 * times[len(times) // 2] / a.frames, a.scene, a.width, a.height, len(times), a.frames,
+        1e3 * times[0] / a.frames, 1e3 * times[-1] / a.frames))
+
+
 for _ in range(5):
     k.L.SolR_RunKernel(0.0, image.ctypes.data)
 for name, call in (("SolRx_Render (render_begin + render_end)", lambda: k.L.SolRx_Render(0.0)),
                    ("SolR_RunKernel (+ image to the caller)", lambda: k.L.SolR_RunKernel(0.0, image.ctypes.data))):
-    hip.solr_hip_synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.frames):
-        call()
-    dt = time.perf_counter() - t0
-    print("%-44s %.3f ms per frame (%s %dx%d, %d frames)" % (name, 1e3 * dt / a.frames, a.scene, a.width, a.height, a.frames))
+    times = []
+    for _ in range(BLOCKS):
+        hip.solr_hip_synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.frames):
+            call()
+        times.append(time.perf_counter() - t0)
+    report(name, times)
 for flights in (2, 3):
     k.L.SolRx_SetFramesInFlight(flights)
     for name, call in (("SolRx_Render, %d frames in flight" % flights, lambda: k.L.SolRx_Render(0.0)),
                        ("SolR_RunKernel, %d frames in flight" % flights, lambda: k.L.SolR_RunKernel(0.0, image.ctypes.data))):
-        for _ in range(8):
-            call()
-        t0 = time.perf_counter()
-        for _ in range(a.frames):
-            call()
-        k.L.SolRx_FlushFrames()
-        dt = time.perf_counter() - t0
-        print("%-44s %.3f ms per frame (%s %dx%d, %d frames)" % (name, 1e3 * dt / a.frames, a.scene, a.width, a.height, a.frames))
+        times = []
+        for _ in range(BLOCKS):
+            for _ in range(8):
+                call()
+            t0 = time.perf_counter()
+            for _ in range(a.frames):
+                call()
+            k.L.SolRx_FlushFrames()
+            times.append(time.perf_counter() - t0)
+        report(name, times)
 k.L.SolRx_SetFramesInFlight(1)
 t0 = time.perf_counter()
 k.primitive_at(10, 10)
