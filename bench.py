@@ -96,8 +96,8 @@ def parse():
                          "combination whose frame equals the one-GPU frame - config.mode_sweep): 'strips' - every rank copies its strip over its own PCIe "
                          "link into one page-locked image the ranks' processes share (solr_hip_image_share; the reference's "
                          "d2h_bitmap does the same with the devices of its one process) - or 'gathered': rank 0 copies the "
-                         "frame the RCCL gather assembled in its HBM (one PCIe link for the whole frame).  The gather over "
-                         "xGMI runs behind every frame either way")
+                         "frame the RCCL gather assembled in its HBM (one PCIe link for the whole frame).  The sweep also "
+                         "times 'strips' with no RCCL call per frame at all (SOLR_BENCH_COLLECTIVE=0|1 fixes that choice)")
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the comparison of the gathered frame with the frame rank 0 renders alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -314,7 +314,9 @@ def main():
 
     rccl_ranks = comm_count = None
     delivery_fallback = None
-    mode = {"per_flight": None, "delivery": None}      # what is up right now
+    # what is up right now; "collective": the RCCL gather runs behind every frame (False: the strips meet in the one host
+    # image the ranks' processes share and nothing else moves per frame - SOLR_BENCH_COLLECTIVE=0|1 fixes it, else swept)
+    mode = {"per_flight": None, "delivery": None, "collective": os.environ.get("SOLR_BENCH_COLLECTIVE", "1") != "0"}
 
     def engine_error():
         buf = C.create_string_buffer(512)
@@ -380,6 +382,8 @@ def main():
     sweep_comms = [env_per_flight[0] != "0"] if env_per_flight else [False, True]
     if args.delivery == "auto":
         args.delivery = "strips"
+    if args.delivery == "gathered":
+        mode["collective"] = True       # (that route delivers what the gather assembled)
     if native:
         if not cfg4 and not args.no_check:
             # the frame a rank renders ALONE, whole, before there is a communicator: what every assembled frame of the
@@ -407,7 +411,7 @@ def main():
         # the frame's stream, or StripPipeline)
         if native:
             render()
-            if hip.solr_hip_gather_strips(0) != 0:
+            if mode["collective"] and hip.solr_hip_gather_strips(0) != 0:
                 k.check(-1, "solr_hip_gather_strips")
         elif pipe is None:
             render()
@@ -642,13 +646,22 @@ def main():
     # loop as the headline - checks each one's delivered frame against the frame rank 0 rendered alone, and runs the
     # headline on the fastest that passed.  A combination that fails is reported and left out, not fatal.
     mode_sweep = None
-    combos = [(c, r) for c in sweep_comms for r in sweep_routes]
+    combos = [(c, r, True) for c in sweep_comms for r in sweep_routes]
+    if "strips" in sweep_routes and "SOLR_BENCH_COLLECTIVE" not in os.environ:
+        # ... and the strips route with NO collective in the data path: the reference assembles the frame in the host
+        # bitmap and nowhere else (d2h_bitmap, CudaRayTracer.cu:1647-1672); the shared host image is that, and the RCCL
+        # gather behind every frame then only costs (11 us of host work and 8 us of GPU per step on a 136-row strip,
+        # profiles/r4/readback_routes.txt).  The communicator stays up: strips are balanced through it, ambient-occlusion
+        # frames trade their boundary rows through it, and the check after the timed regions gathers once.
+        combos.append((sweep_comms[0], "strips", False))
+    elif not mode["collective"]:
+        combos = [(sweep_comms[0], "strips", False)]
     want_sweep = os.environ.get("SOLR_BENCH_SWEEP", "1" if world > 1 else "0") == "1"
     if native and not cfg4 and len(combos) > 1 and want_sweep:
         import numpy as np
         mode_sweep = {}
 
-        def configure(per_flight, route):
+        def configure(per_flight, route, collective):
             """(every rank) tear down what is up, bring this combination up, re-cut the strips; None or why not"""
             if mode["per_flight"] != per_flight:
                 sync()
@@ -668,21 +681,24 @@ def main():
                 got, why = delivery_up(route)
                 if got != route:
                     return why
+            mode["collective"] = collective
             for _ in range(PREROLL_FRAMES // 2):
                 step()
             drain()
             return None
 
-        def label(per_flight, route):
+        def label(per_flight, route, collective):
+            if not collective:
+                return "no_collective_strips_over_every_ranks_link"
             return "%s_%s" % ("communicator_per_flight" if per_flight else "one_communicator",
                               "strips_over_every_ranks_link" if route == "strips" else "gathered_frame_over_rank0s_link")
 
-        for per_flight, route in combos:
-            name = label(per_flight, route)
+        for per_flight, route, collective in combos:
+            name = label(per_flight, route, collective)
             arm("mode sweep: " + name)
             entry = {}
             try:
-                why = configure(per_flight, route)
+                why = configure(per_flight, route, collective)
                 if why:
                     entry["skipped"] = why
                 else:
@@ -695,6 +711,7 @@ def main():
                         same = seg["last_image"] is not None and bool(np.array_equal(seg["last_image"], alone))
                     entry["frame_equals_single_gpu"] = not agree(dist, torch, not same)
                     entry["rccl_communicators"] = int(hip.solr_hip_comm_count())
+                    entry["rccl_calls_per_frame"] = 1 if collective else 0
             except solr.SolrError as e:            # the engine's error state: reported, cleared, the job goes on
                 entry["error"] = str(e)[:300]
             failed = agree(dist, torch, "error" in entry)
@@ -708,10 +725,10 @@ def main():
             raise SystemExit("bench.py rank %d: no communicator mode / delivery route delivered the one-GPU frame: %s"
                              % (rank, json.dumps(mode_sweep)))
         best = min(usable, key=lambda n: usable[n]["ms_per_step"])
-        for per_flight, route in combos:
-            if label(per_flight, route) == best:
+        for per_flight, route, collective in combos:
+            if label(per_flight, route, collective) == best:
                 arm("mode sweep: back to " + best)
-                why = configure(per_flight, route)
+                why = configure(per_flight, route, collective)
                 if why:
                     raise SystemExit("bench.py rank %d: %s did not come up a second time: %s" % (rank, best, why))
         mode_sweep["headline_runs_on"] = best
@@ -816,6 +833,8 @@ def main():
     # ---- N > 1 extras (untimed): the gather alone, and the assembled frame against the frame one GPU renders
     gather_only_ms = None
     check = None
+    headline_collective = mode["collective"]      # (what the timed regions ran with; the extras below gather)
+    mode["collective"] = True
     if native:
         arm("the gather alone and the one-GPU check")
         import numpy as np
@@ -953,8 +972,9 @@ def main():
                                 "(d2h_bitmap when picking asks)" %
                                 (("gather on rank 0 (the assembled frame over rank 0's PCIe link)" if args.delivery == "gathered"
                                   else "kernel on every rank: each strip over its rank's own PCIe link into one image the "
-                                       "ranks' processes share (solr_hip_image_share), rank 0 waits for all of them; the "
-                                       "RCCL gather assembles the same frame in rank 0's HBM") if native else "kernel",
+                                       "ranks' processes share (solr_hip_image_share), rank 0 waits for all of them" +
+                                       ("; the RCCL gather assembles the same frame in rank 0's HBM" if headline_collective
+                                        else "; nothing else moves per frame")) if native else "kernel",
                                  lag, engine_sets)) + ("; copies on the frames' own streams" if copy_inline else ""),
                    "frames_delivered": delivered[0], "delivery_fallback": delivery_fallback,
                    # nodes per order-free list when long rays' walks use them, else 0
@@ -963,7 +983,11 @@ def main():
                    # choice per frame, include/solr_hip.h solr_hip_set_short_ray_lists; nothing to choose for other scenes)
                    "short_ray_lists": short_ray_lists,
                    "gather": ("none (one GPU)" if not distributed else
-                              "RCCL from the engine's C ABI (solr_hip_gather_strips), on the stream that rendered the frame"
+                              ("RCCL from the engine's C ABI (solr_hip_gather_strips), on the stream that rendered the frame"
+                               if headline_collective else
+                               "none in the data path: the strips meet in the host image the ranks' processes share (the "
+                               "reference's d2h_bitmap assembles the frame there and nowhere else); RCCL balanced the strips "
+                               "and assembled one frame in rank 0's HBM for gathered_equals_single_gpu, outside the timed regions")
                               if native else "torch.distributed gather (RCCL)"),
                    "strips": strips,
                    "parallelism": "tile%d" % world},

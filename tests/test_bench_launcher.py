@@ -98,11 +98,13 @@ def test_two_rank_rehearsal_of_the_default_job(solr):
     assert cfg["slowest_rank"] in (0, 1) and cfg["gather_only_ms"] > 0
     assert {"balanced_strips_native_gather", "equal_strips_native_gather"} <= set(cfg["rates_mrays_per_s"])
     assert cfg["rates_mrays_per_s"]["balanced_strips_native_gather"] == pytest.approx(line["value"], rel=1e-3)
-    # the default job times both communicator modes and both delivery routes in short segments, checks each one's frame
-    # against the one-GPU frame, and runs the headline on the fastest that passed
+    # the default job times both communicator modes and both delivery routes - and the strips route with no RCCL call per
+    # frame at all - in short segments, checks each one's frame against the one-GPU frame, and runs the headline on the
+    # fastest that passed
     sweep = cfg["mode_sweep"]
     combos = [n for n in sweep if n != "headline_runs_on"]
-    assert len(combos) == 4 and all(sweep[n]["frame_equals_single_gpu"] is True and sweep[n]["ms_per_step"] > 0 for n in combos)
+    assert "no_collective_strips_over_every_ranks_link" in combos and sweep["no_collective_strips_over_every_ranks_link"]["rccl_calls_per_frame"] == 0
+    assert len(combos) == 5 and all(sweep[n]["frame_equals_single_gpu"] is True and sweep[n]["ms_per_step"] > 0 for n in combos)
     assert sweep["headline_runs_on"] == min(combos, key=lambda n: sweep[n]["ms_per_step"])
     assert {sweep[n]["rccl_communicators"] for n in combos} == {1, 4}
     assert all("sweep_" + n in cfg["rates_mrays_per_s"] for n in combos)
@@ -117,6 +119,7 @@ def test_two_rank_rehearsal_of_the_default_job(solr):
         assert "one image the ranks' processes share" in cfg["delivery"]
     else:
         assert "gather on rank 0" in cfg["delivery"]
+    assert ("none in the data path" in cfg["gather"]) == sweep["headline_runs_on"].startswith("no_collective")
     assert cfg["rccl_communicators"] == (4 if "per_flight" in sweep["headline_runs_on"] else 1)
 
 
@@ -129,8 +132,8 @@ def test_two_rank_rehearsal_with_one_communicator_per_flight(solr):
     assert cfg["rccl_ranks"] == 2 and cfg["rccl_communicators"] == 4 and "one per frame in flight" in cfg["rccl_communicator_mode"]
     assert cfg["gathered_equals_single_gpu"] is True
     # the environment fixed the communicator mode: only the delivery routes were swept
-    assert len([n for n in cfg["mode_sweep"] if n != "headline_runs_on"]) == 2
-    assert all("communicator_per_flight" in n for n in cfg["mode_sweep"] if n != "headline_runs_on")
+    assert len([n for n in cfg["mode_sweep"] if n != "headline_runs_on"]) == 3
+    assert all("communicator_per_flight" in n or n.startswith("no_collective") for n in cfg["mode_sweep"] if n != "headline_runs_on")
 
 
 @pytest.mark.gpu
@@ -172,7 +175,7 @@ def test_two_rank_rehearsal_of_cfg4(solr):
 @pytest.mark.parametrize("world", [2, 8])
 def test_the_whole_job_over_real_rccl_where_the_box_has_the_gpus(solr, world):
     """`python bench.py --gpus N` as the driver starts it, on N REAL GPUs over the real RCCL - runs by itself on the first
-    box that has them (the test boxes have one GPU: skipped): the four combinations of the mode sweep, the frame of
+    box that has them (the test boxes have one GPU: skipped): the five combinations of the mode sweep, the frame of
     every one of them equal to the one-GPU frame, the headline on the fastest"""
     if solr.hip_lib().solr_hip_device_count() < world:
         pytest.skip("needs %d GPUs" % world)
