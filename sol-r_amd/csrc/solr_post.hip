@@ -337,7 +337,9 @@ __device__ __forceinline__ bool aoDepthAt(const PixelRecord *__restrict__ pp, co
 }
 /* tiles a workgroup renders one after the other (a run along x): what does not depend on the tile - the tap pairs,
  * their reach and, inside one binade, the deduped offsets - is made once per run instead of once per 256 pixels */
+#ifndef AO_TILES_PER_GROUP
 #define AO_TILES_PER_GROUP 8
+#endif
 #define AO_AHEAD 4 /* window depths a thread holds for the next tile: windows of up to 256 x AO_AHEAD floats are asked for a tile ahead */
 __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
                                                           const PixelRecord *__restrict__ pp,

@@ -28,7 +28,7 @@ using namespace solreng;
  * time (dlopen; the copy a framework already mapped is reused), so the library needs it only when these entry
  * points are called.  The 128-byte id of ncclGetUniqueId travels from rank 0 to the others by whatever channel
  * the host application has (a file, a socket, MPI, torch's store: INTEGRATION.md). */
-namespace solreng
+namespace /* this file's own: the library handle, the communicators, the strip table */
 {
 typedef struct ncclComm *ncclComm_t;
 typedef struct
@@ -219,6 +219,9 @@ bool allReduceFloats(float *values, size_t n, int op, const char *what)
  * whenever something it depends on was uploaded (communicator, random buffer) or param2 differs from the last
  * agreement's: events of the host program, the same on every rank, not values.  Called by every rank at the top of
  * every cudaRender with the ambient-occlusion post-process, whatever state the rank is in. */
+} // namespace
+namespace solreng /* (engine.h) */
+{
 int agreedHaloRows(const PostProcessingInfo &ppInfo)
 {
     const float reach = 16.f * fabsf(ppInfo.param2) * g.randomsReach / 10.f;
@@ -238,11 +241,17 @@ int agreedHaloRows(const PostProcessingInfo &ppInfo)
     }
     return rccl.haloAgreed;
 }
+} // namespace solreng
+namespace
+{
 
 /* Rank 0's random buffer to every rank (the buffer feeds the taps of the ambient-occlusion kernel, the depth of field
  * and the jitter of accumulation passes: strips rendered from different buffers do not assemble to the frame one GPU
  * renders).  With a communicator, rank 0's buffer is THE buffer: solr_hip_comm_init and every h2d_randoms after it
  * end with this.  Blocking; every rank. */
+} // namespace
+namespace solreng /* (engine.h) */
+{
 bool shareRandoms()
 {
     if (!rccl.comm || rccl.world < 2)
@@ -294,6 +303,9 @@ bool shareRandoms()
         g.randomsReach = v[5];
     return fine;
 }
+} // namespace solreng
+namespace
+{
 
 /* The strips of all ranks when they are not the equal ones of solr_hip_strip_rows (solr_hip_set_strip_table) */
 struct StripTable
@@ -321,6 +333,9 @@ void stripOf(int rank, int world, int height, int *first, int *count)
  * is the one a single GPU renders.  The sizes follow from the strip table and from `wanted` = agreedHaloRows alone,
  * so neighbours always post matching transfers; pp == nullptr (a rank that returned early from cudaRender, or whose
  * strip is not the table's) sends zeros and sets the error. */
+} // namespace
+namespace solreng /* (engine.h) */
+{
 void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
                        int wanted, DepthHalo *halo)
 {
@@ -385,17 +400,32 @@ void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, in
     halo->nbAbove = recvAbove;
     halo->nbBelow = recvBelow;
 }
+} // namespace solreng
+namespace
+{
 
 /* (for renderImpl, which is defined before this layer) */
+} // namespace
+namespace solreng /* (engine.h) */
+{
 bool haveCommunicator()
 {
     return rccl.comm != nullptr && rccl.world > 1;
 }
+} // namespace solreng
+namespace
+{
+} // namespace
+namespace solreng /* (engine.h) */
+{
 bool communicatorUp()
 {
     return rccl.comm != nullptr;
 }
 } // namespace solreng
+namespace
+{
+} // namespace
 
 extern "C" {
 
