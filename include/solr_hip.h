@@ -366,7 +366,8 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
  * h2d_scene); 6 = no order-free lists (every walk in the reference's order); 7 = the whole colour stack in LDS
  * however deep a frame may bounce (as before round 5: nine waves per CU for ten bounces; otherwise three slots in LDS,
  * the deeper ones in HBM); 8 = every walk on the reference's own leaf boxes (no thin copies of the leaves that hold
- * plain axis planes, rt_device.h tightRay).  Every setting renders the same frame. */
+ * plain axis planes, rt_device.h tightRay); 9 = k_ambientOcclusion with a fixed stride of tiles per workgroup instead of
+ * the frame's heavy tiles first (solr_post.hip).  Every setting renders the same frame. */
 void solr_hip_set_variant(int variant);
 /* Bounce rays (|direction| = 1 - rayEpsilon) of the long-list triangle kernels on the order-free lists, checked: lanes
  * whose hit has a rival the reference's cut-off could have preferred are walked again in the reference's order

@@ -474,7 +474,7 @@ namespace solrpost
 void defaultConversion(hipStream_t stream, const SceneInfo &si, int nbPixels, const PixelRecord *pp, unsigned char *bitmap);
 void ambientOcclusion(hipStream_t stream, const SceneInfo &si, const PostProcessingInfo &ppi, int nbRows, const PixelRecord *pp,
                       const float *randoms, long nbRandoms, unsigned char *bitmap, const DepthHalo &halo, int firstRow,
-                      float randomsReach);
+                      float randomsReach, bool heavyFirst);
 void depthOfField(hipStream_t stream, const SceneInfo &si, const PostProcessingInfo &ppi, int nbRows, const PixelRecord *pp,
                   const float *randoms, long nbRandoms, unsigned char *bitmap);
 void radiosity(hipStream_t stream, const SceneInfo &si, const PostProcessingInfo &ppi, int nbRows, const PixelRecord *pp,

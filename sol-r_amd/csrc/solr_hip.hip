@@ -1120,7 +1120,7 @@ void launchPostProcess(const SceneInfo &sceneInfo, const PostProcessingInfo &ppI
         if (ok())
             solrpost::ambientOcclusion(stream, sceneInfo, ppInfo, nbRows, (const PixelRecord *)flightPp(flight).ptr,
                                        (const float *)g.randoms.ptr, g.randoms.ptr ? g.nbRandoms : 0L, bitmap, halo, firstRow,
-                                       g.randomsReach);
+                                       g.randomsReach, g.variant != 9);
     }
     else if (ppInfo.type == ppe_depthOfField)
         solrpost::depthOfField(stream, sceneInfo, ppInfo, nbRows, (const PixelRecord *)flightPp(flight).ptr,

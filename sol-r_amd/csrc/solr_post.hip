@@ -341,11 +341,16 @@ __device__ __forceinline__ bool aoDepthAt(const PixelRecord *__restrict__ pp, co
 #define AO_TILES_PER_GROUP 8
 #endif
 #define AO_AHEAD 4 /* window depths a thread holds for the next tile: windows of up to 256 x AO_AHEAD floats are asked for a tile ahead */
-__global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
+#ifndef AO_WAVES_PER_SIMD
+#define AO_WAVES_PER_SIMD 8 /* 64 registers, 14 of them spilled: a tile is a chain of waits, and eight workgroups a CU hide more of
+                             * them than the spills cost (6: 80 registers, none spilled, 5 % slower; the compiler's own choice, 108
+                             * registers and four workgroups a CU: 25 % slower) */
+#endif
+__global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(const SceneInfo si, const PostProcessingInfo ppi, int nbRows,
                                                           const PixelRecord *__restrict__ pp,
                                                           const float *__restrict__ randoms, long nbRandoms,
                                                           unsigned char *__restrict__ bitmap, const DepthHalo halo,
-                                                          int firstRow, int windowFloats)
+                                                          int firstRow, int windowFloats, int heavyFirst)
 {
     /* The 256 taps of a pixel sit at x + X * param2 * randoms[i % wh] / 10.f, y + Y * param2 * randoms[(i + 100)
      * % wh] / 10.f (CRT:1146-1153): the offsets depend on the tap, not on the pixel.  The workgroup's 256
@@ -437,15 +442,113 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
         const int px = tx0 + (int)(threadIdx.x % AO_TILE_W), py = ty0 + (int)(threadIdx.x / AO_TILE_W);
         aheadLocal = pp[(px < W && py < nbRows) ? py * W + px : 0].colorInfo;
     };
-    for (int run = 0; run < AO_TILES_PER_GROUP; ++run)
+#ifdef SOLR_AO_DEBUG
+    const unsigned long long groupClock0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    /* Which tiles, in which order?  A tile that straddles a binade costs four to twelve times a steady one
+     * (tools/ao_paths.py: 12 - 40 us against 3.2) and whole tile rows and columns of a frame are such: with any fixed
+     * share of the frame per workgroup the kernel was as long as its unluckiest workgroup - 0.3 ms of which the chip
+     * stood half empty for 0.13.  "Steady" factorises - a tile is steady iff its tile ROW is light (window inside the
+     * strip and its halo, the rows and their taps' sums in one binade) and its tile COLUMN is light - so the workgroup
+     * lists the heavy and the light rows and columns once (LDS, 256 threads: a row or column each), and the frame's
+     * tiles are taken in the order [heavy rows x all columns, light rows x heavy columns, light rows x light columns],
+     * item blockIdx.x + k gridDim.x for k = 0, 1, ...: every workgroup gets its share of the heavy tiles, to within
+     * one, and gets them FIRST - the tail of the kernel is made of steady tiles.  The grid is the workgroups the chip
+     * holds at once.  (heavyFirst == 0: tile `run` of this workgroup is a stride of the grid further, AO_TILES_PER_GROUP
+     * of them - solr_hip_set_variant(9), the probes of the paths.) */
+    __shared__ unsigned short rowList[1024], colList[512]; /* heavy ones first */
+    __shared__ int listCount[4];                           /* [0] heavy rows, [2] heavy columns */
+    const int tilesY = (nbRows + AO_TILE_H - 1) / AO_TILE_H;
+    const bool ordered = heavyFirst != 0 && tiled && tilesY <= 1024 && tilesX <= 512;
+    if (ordered)
     {
-        /* tile `run` of this workgroup: a stride of the grid apart, not side by side.  The tiles of the frame's first
-         * tile row and column (x or y below the tile's size: regular columns of up to five binades) take the per-pixel
-         * loop, 30 times the cost of a tile - side by side they were eight of them in one workgroup, and that
-         * workgroup was the kernel: 0.52 ms whatever the other 4 000 did */
-        const int tile = (int)blockIdx.x + run * (int)gridDim.x;
-        if (tile >= nbTiles)
+        auto rowLight = [&](int ty) {
+            const int y0_ = ty * AO_TILE_H, wy = y0_ - ry;
+            const int ylo = y0_ + firstRow - ry, yhi = y0_ + firstRow + AO_TILE_H - 1 + ry;
+            return wy >= -halo.nbAbove && wy + wrows <= nbRows + halo.nbBelow && ylo >= 1 && __clz(ylo) == __clz(yhi);
+        };
+        auto colLight = [&](int tx) {
+            const int x0_ = tx * AO_TILE_W, wx = x0_ - rx;
+            const int xlo = x0_ - rx, xhi = x0_ + AO_TILE_W - 1 + rx;
+            return wx >= 0 && wx + ww <= W && xlo >= 1 && __clz(xlo) == __clz(xhi);
+        };
+        /* the heavy ones take the front of each list, the light ones the rest, both in ascending order - EVERY workgroup
+         * must make the same lists (they share out one order of the frame's tiles): one wave compacts them with
+         * ballots, 64 rows or columns a step */
+        if (threadIdx.x < 64)
+        {
+            const int lane = (int)threadIdx.x;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int count = 0;
+            for (int sweep = 0; sweep < 2; ++sweep)
+            {
+                for (int base = 0; base < tilesY; base += 64)
+                {
+                    const int ty = base + lane;
+                    const bool take = ty < tilesY && rowLight(ty) == (sweep == 1);
+                    const unsigned long long taken = __ballot(take);
+                    if (take)
+                        rowList[count + __popcll(taken & below)] = (unsigned short)ty;
+                    count += __popcll(taken);
+                }
+                if (sweep == 0 && lane == 0)
+                    listCount[0] = count;
+            }
+            count = 0;
+            for (int sweep = 0; sweep < 2; ++sweep)
+            {
+                for (int base = 0; base < tilesX; base += 64)
+                {
+                    const int tx = base + lane;
+                    const bool take = tx < tilesX && colLight(tx) == (sweep == 1);
+                    const unsigned long long taken = __ballot(take);
+                    if (take)
+                        colList[count + __popcll(taken & below)] = (unsigned short)tx;
+                    count += __popcll(taken);
+                }
+                if (sweep == 0 && lane == 0)
+                    listCount[2] = count;
+            }
+        }
+        __syncthreads();
+    }
+    const int heavyRows = ordered ? listCount[0] : 0, heavyCols = ordered ? listCount[2] : 0;
+    const int lightCols = tilesX - heavyCols;
+    const int firstBlock = heavyRows * tilesX, secondBlock = (tilesY - heavyRows) * heavyCols;
+    auto tileOf = [&](int item) { /* item of the ordered list -> tile index (row-major) */
+        int ty, tx;
+        if (item < firstBlock)
+        {
+            ty = rowList[item / tilesX];
+            tx = item - (item / tilesX) * tilesX;
+        }
+        else if (item < firstBlock + secondBlock)
+        {
+            const int k = item - firstBlock;
+            ty = rowList[heavyRows + k / heavyCols];
+            tx = colList[k - (k / heavyCols) * heavyCols];
+        }
+        else
+        {
+            const int k = item - firstBlock - secondBlock;
+            ty = rowList[heavyRows + k / lightCols];
+            tx = colList[heavyCols + k - (k / lightCols) * lightCols];
+        }
+        return ty * tilesX + tx;
+    };
+    const bool persistent = heavyFirst != 0; /* the launch's grid: the workgroups the chip holds, each until the frame is done */
+    for (int run = 0; persistent || run < AO_TILES_PER_GROUP; ++run)
+    {
+        const int item = (int)blockIdx.x + run * (int)gridDim.x;
+        if (item >= nbTiles)
             break;
+        const int tile = ordered ? tileOf(item) : item;
+        /* the tile after this one (the window of its depths is asked for while this one is compared) */
+        const int itemAfter = (persistent || run + 1 < AO_TILES_PER_GROUP) ? item + (int)gridDim.x : nbTiles;
+        const int tileAfter = itemAfter < nbTiles ? (ordered ? tileOf(itemAfter) : itemAfter) : nbTiles;
+#ifdef SOLR_AO_DEBUG
+        const unsigned long long tileClock0 = __builtin_amdgcn_s_memrealtime(); /* (tools/ao_paths.py) */
+#endif
         const int x0 = (tile % tilesX) * AO_TILE_W;
         const int y0 = (tile / tilesX) * AO_TILE_H;
         const int wx0 = x0 - rx, wy0 = y0 - ry;
@@ -606,8 +709,8 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
             }
         }
         __syncthreads(); /* the window is in LDS, and so are the offsets */
-        if (pipelined && run + 1 < AO_TILES_PER_GROUP && tile + (int)gridDim.x < nbTiles)
-            ahead(tile + (int)gridDim.x);
+        if (pipelined && tileAfter < nbTiles)
+            ahead(tileAfter);
         if (mine)
         {
             float occ = 0.f;
@@ -723,9 +826,37 @@ __global__ __launch_bounds__(256) void k_ambientOcclusion(const SceneInfo si, co
             }
             saturate3(col);
             makeColor(si, col, bitmap, index);
+#ifdef SOLR_AO_DEBUG
+            /* development build (tools/ao_paths.py): the image holds, per pixel, the path its tile took, the tile's time
+             * in units of 0.64 us (100 MHz ticks / 64) and the tile's place in its workgroup's run */
+            const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - tileClock0;
+            bitmap[3 * index + 0] = (unsigned char)(!tiled ? 5 : steady ? 1 : (classed && regularX && regularY) ? 2 : classed ? 3 : windowInside ? 4 : 6);
+            bitmap[3 * index + 1] = (unsigned char)min(255ull, ticks / 64ull);
+            bitmap[3 * index + 2] = (unsigned char)run;
+#endif
         }
         __syncthreads(); /* the next tile's window goes where this one's is still being read */
     }
+#ifdef SOLR_AO_DEBUG
+    /* ... and the first three pixels of the workgroup's first tile: when the workgroup began its tiles and when it ended
+     * them (24 bits of the 100 MHz clock each) and where it ran (HW_ID: wave, SIMD, CU, SH, SE; XCC_ID) */
+    if (threadIdx.x == 0 && (int)blockIdx.x < nbTiles && !ordered) /* (the fixed-stride order: its first tile is tile blockIdx.x) */
+    {
+        const int first = ((int)blockIdx.x / tilesX) * AO_TILE_H * W + ((int)blockIdx.x % tilesX) * AO_TILE_W;
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned hw = 0u, xcc = 0u;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned where = ((xcc & 15u) << 16) | (((hw >> 13) & 7u) << 8) | ((hw >> 8) & 15u); /* XCC, SE, CU */
+        const unsigned words[3] = {(unsigned)groupClock0 & 0xffffffu, (unsigned)t1 & 0xffffffu, where};
+        for (int k = 0; k < 3; ++k)
+        {
+            bitmap[3 * (first + k) + 0] = (unsigned char)(words[k] & 255u);
+            bitmap[3 * (first + k) + 1] = (unsigned char)((words[k] >> 8) & 255u);
+            bitmap[3 * (first + k) + 2] = (unsigned char)((words[k] >> 16) & 255u);
+        }
+    }
+#endif
 }
 
 /* CRT:1081-1120 */
@@ -803,7 +934,7 @@ void defaultConversion(hipStream_t stream, const SceneInfo &si, int nbPixels, co
 
 void ambientOcclusion(hipStream_t stream, const SceneInfo &si, const PostProcessingInfo &ppi, int nbRows, const PixelRecord *pp,
                       const float *randoms, long nbRandoms, unsigned char *bitmap, const DepthHalo &halo, int firstRow,
-                      float randomsReach)
+                      float randomsReach, bool heavyFirst)
 {
     /* the window the taps of this random buffer and this param2 can need (the kernel takes its own, exact reach and
      * gathers from memory if this should ever be too small): |tap| <= 16 |param2| max|random| / 10 */
@@ -812,9 +943,24 @@ void ambientOcclusion(hipStream_t stream, const SceneInfo &si, const PostProcess
     const long aoCells = (long)(AO_TILE_W + 2 * aoR) * (AO_TILE_H + 2 * aoR);
     const int aoWindow = (int)std::min<long>(std::max<long>(aoCells, 64), AO_WINDOW_FLOATS);
     const int tiles = ((si.size.x + AO_TILE_W - 1) / AO_TILE_W) * ((nbRows + AO_TILE_H - 1) / AO_TILE_H);
-    hipLaunchKernelGGL(k_ambientOcclusion, dim3((unsigned)((tiles + AO_TILES_PER_GROUP - 1) / AO_TILES_PER_GROUP)), dim3(256),
-                       (size_t)aoWindow * sizeof(float), stream, si, ppi, nbRows, pp, randoms, nbRandoms, bitmap, halo, firstRow,
-                       aoWindow);
+    /* heavy tiles first: the workgroups the chip holds at once (AO_WAVES_PER_SIMD of them per CU, a wave on each SIMD),
+     * or fewer when the frame has fewer tiles */
+    unsigned groups = (unsigned)((tiles + AO_TILES_PER_GROUP - 1) / AO_TILES_PER_GROUP);
+    if (heavyFirst)
+    {
+        static int cus = 0;
+        if (cus == 0)
+        {
+            int device = 0, n = 0;
+            (void)hipGetDevice(&device);
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
+                n = 256;
+            cus = n;
+        }
+        groups = std::max(1u, std::min((unsigned)tiles, (unsigned)(cus * AO_WAVES_PER_SIMD)));
+    }
+    hipLaunchKernelGGL(k_ambientOcclusion, dim3(groups), dim3(256), (size_t)aoWindow * sizeof(float), stream, si, ppi, nbRows, pp,
+                       randoms, nbRandoms, bitmap, halo, firstRow, aoWindow, heavyFirst ? 1 : 0);
 }
 
 static dim3 pixelsGrid(const SceneInfo &si, int nbRows) { return dim3((unsigned)((si.size.x * nbRows + 255) / 256)); }

@@ -201,21 +201,42 @@ def test_post_processing(solr, oracle, pp):
     assert_parity(compare_frames(pp_, ids, rgb, opp, oids, orgb))
 
 
-@pytest.mark.parametrize("param2", [10.0, 120.0, 500.0, 2500.0])
+@pytest.mark.parametrize("param2", [10.0, 120.0, 500.0, 2500.0, 6000.0])
 def test_ambient_occlusion_taps_that_share_a_depth_are_one_comparison(solr, oracle, param2):
     """k_ambientOcclusion on a frame wide enough for tiles whose 256 tap offsets are the same for every pixel (x and y
     inside one binade): the workgroup dedupes the offsets and a pixel compares once per DISTINCT offset, weighted by
     the number of taps that share it - four offsets for param2 = 10 (cfg4's), dozens for 120 and 500, the plain loop
-    beyond 128 (2500).  The count is an integer either way: the oracle's image, every pixel"""
+    beyond 128 (2500); 6000: taps that reach 48 pixels, a window that does not fit LDS - every tap gathered from memory.
+    The count is an integer either way: the oracle's image, every pixel"""
     k = solr.Kernel(engine="hip")
     k.set_post_processing(type=solr_mod.ppe_ambientOcclusion, param1=0.0, param2=param2, param3=0)
     solr.scenes.cornell(k, width=640, height=208, iterations=1)
     pp_, ids, rgb = gpu_frame(k)
     opp, oids, orgb, counts, status = oracle_frame(k, oracle)
+    # ... and the order the workgroups take the tiles in (the frame's heavy tiles first; variant 9: a fixed stride of
+    # tiles per workgroup) changes no pixel
+    solr.hip_lib().solr_hip_set_variant(9)
+    _, _, rgb_stride = gpu_frame(k)
+    solr.hip_lib().solr_hip_set_variant(0)
     k.finalize()
     assert status == 0
     assert_parity(compare_frames(pp_, ids, rgb, opp, oids, orgb))
+    assert np.array_equal(rgb, rgb_stride)
     assert len(np.unique(rgb.reshape(-1, 3), axis=0)) > 50
+
+
+def test_ambient_occlusion_tile_order_on_a_tall_and_a_wide_frame(solr, oracle):
+    """the lists of heavy and light tile rows / columns (k_ambientOcclusion): frames with more tile rows than threads
+    of a workgroup would list at once (2 100 rows: 263 tile rows), with one tile column, and with one tile row"""
+    for W, H in ((40, 2100), (1500, 8), (32, 8)):
+        k = solr.Kernel(engine="hip")
+        k.set_post_processing(type=solr_mod.ppe_ambientOcclusion, param1=0.0, param2=10.0, param3=0)
+        solr.scenes.cornell(k, width=W, height=H, iterations=1)
+        pp_, ids, rgb = gpu_frame(k)
+        opp, oids, orgb, counts, status = oracle_frame(k, oracle)
+        k.finalize()
+        assert status == 0, (W, H)
+        assert np.array_equal(rgb, orgb), (W, H)
 
 
 def test_row_strips_equal_the_full_frame(solr, oracle):
