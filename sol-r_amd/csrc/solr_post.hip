@@ -340,6 +340,9 @@ __device__ __forceinline__ bool aoDepthAt(const PixelRecord *__restrict__ pp, co
 #ifndef AO_TILES_PER_GROUP
 #define AO_TILES_PER_GROUP 8
 #endif
+#ifndef AO_IRREGULAR_TOGETHER
+#define AO_IRREGULAR_TOGETHER 40 /* irregular pixels of a tile in two binades that the workgroup takes together (256 threads a pixel's 256 taps) */
+#endif
 #define AO_AHEAD 4 /* window depths a thread holds for the next tile: windows of up to 256 x AO_AHEAD floats are asked for a tile ahead */
 #ifndef AO_WAVES_PER_SIMD
 #define AO_WAVES_PER_SIMD 8 /* 64 registers, 14 of them spilled: a tile is a chain of waits, and eight workgroups a CU hide more of
@@ -373,6 +376,11 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
     unsigned *const table = block;
     int *const distinctOffset = (int *)block + 512, *const distinctWeight = (int *)block + 768;
     __shared__ int nbDistinct;
+    /* the irregular pixels of a tile in two binades (below), taken together: which threads, their depths, their counts */
+    __shared__ unsigned short irregularPixel[256];
+    __shared__ float irregularDepth[256];
+    __shared__ int irregularCount[256];
+    __shared__ int nbIrregular;
     __shared__ int cls[8];       /* a tile in two binades: {smallest, largest exponent of its regular columns, a column of each; the same for rows} */
     __shared__ float tapRange[16]; /* per wave: min / max of tapX, min / max of tapY */
     const int W = si.size.x;
@@ -663,6 +671,9 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
             tableKey = 0; /* (the histograms take the place of the steady tiles' table) */
             if (i < 8)
                 cls[i] = (i == 0 || i == 2 || i == 4 || i == 6) ? 0x7fffffff : -1;
+            if (i == 0)
+                nbIrregular = 0;
+            irregularCount[i] = 0;
             block[i] = block[i + 256] = block[i + 512] = block[i + 768] = 0u;
             if (i < binsX * binsY)
                 tapOffset[i] = (i / binsX - ry) * ww + (i % binsX - rx);
@@ -708,9 +719,44 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
                     atomicAdd(&block[c * 256 + (dy[c & 1] + ry) * binsX + (dx[c >> 1] + rx)], 1u);
             }
         }
+        /* The pixels of the irregular columns and rows of such a tile - cfg4: the one column AT the power of two, eight
+         * pixels - used to take the 256-tap loop inside their waves, and a wave is as long as its slowest lane: every
+         * wave of every tile that straddles a power of two in x ran the whole loop for one lane in thirty-two (17 000
+         * waves of a 4K frame: 0.11 ms of the kernel's 0.22).  They are taken TOGETHER instead: each registers (thread,
+         * depth), and for one such pixel after the other the workgroup's 256 threads evaluate one tap each - the
+         * reference's expression for that pixel and that tap - and count by ballot: eight trips of a dozen instructions
+         * for the column, not 256 trips in every wave.  (Up to AO_IRREGULAR_TOGETHER pixels; a tile with more - whole
+         * rows of them - keeps the loop in the waves that hold them.) */
+        int irregularSlot = -1;
+        if (classed && mine && !(regularX && regularY))
+        {
+            irregularSlot = atomicAdd(&nbIrregular, 1);
+            irregularPixel[irregularSlot] = (unsigned short)threadIdx.x;
+            irregularDepth[irregularSlot] = local.w;
+        }
         __syncthreads(); /* the window is in LDS, and so are the offsets */
         if (pipelined && tileAfter < nbTiles)
             ahead(tileAfter);
+        const int together = classed ? nbIrregular : 0;
+        const bool takenTogether = together > 0 && together <= AO_IRREGULAR_TOGETHER;
+        if (takenTogether)
+        {
+            const int origin = -((wy0 + firstRow) * ww + wx0);
+            const float tx = tapX[threadIdx.x], ty = tapY[threadIdx.x];
+            for (int j = 0; j < together; ++j)
+            {
+                const int p = irregularPixel[j];
+                const float fx = (float)(x0 + p % AO_TILE_W), fy = (float)(y0 + p / AO_TILE_W + firstRow);
+                const int xx = (int)(fx + tx);
+                const int yy = (int)(fy + ty);
+                const bool in = xx >= 0 && xx < W && yy - firstRow >= -halo.nbAbove && yy - firstRow < nbRows + halo.nbBelow;
+                const float tap = window[in ? __mul24(yy, ww) + xx + origin : 0];
+                const unsigned long long hits = __ballot(!in || tap >= irregularDepth[j]);
+                if ((threadIdx.x & 63) == 0)
+                    atomicAdd(&irregularCount[j], (int)__popcll(hits));
+            }
+            __syncthreads();
+        }
         if (mine)
         {
             float occ = 0.f;
@@ -742,6 +788,8 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
                             count += (centre[tapOffset[i]] >= depth) ? 1 : 0;
                     }
                 }
+                else if (takenTogether && irregularSlot >= 0)
+                    count = irregularCount[irregularSlot];
                 else if (classed && regularX && regularY)
                 {
                     const float *centre = window + ((y - wy0) * ww + (x - wx0));
@@ -838,18 +886,19 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
         __syncthreads(); /* the next tile's window goes where this one's is still being read */
     }
 #ifdef SOLR_AO_DEBUG
-    /* ... and the first three pixels of the workgroup's first tile: when the workgroup began its tiles and when it ended
+    /* ... and the first four pixels of the workgroup's first tile (the fourth: a mark the tool finds them by): when the workgroup began its tiles and when it ended
      * them (24 bits of the 100 MHz clock each) and where it ran (HW_ID: wave, SIMD, CU, SH, SE; XCC_ID) */
-    if (threadIdx.x == 0 && (int)blockIdx.x < nbTiles && !ordered) /* (the fixed-stride order: its first tile is tile blockIdx.x) */
+    if (threadIdx.x == 0 && (int)blockIdx.x < nbTiles)
     {
-        const int first = ((int)blockIdx.x / tilesX) * AO_TILE_H * W + ((int)blockIdx.x % tilesX) * AO_TILE_W;
+        const int mark = ordered ? tileOf((int)blockIdx.x) : (int)blockIdx.x; /* this workgroup's first tile */
+        const int first = (mark / tilesX) * AO_TILE_H * W + (mark % tilesX) * AO_TILE_W;
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         unsigned hw = 0u, xcc = 0u;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         const unsigned where = ((xcc & 15u) << 16) | (((hw >> 13) & 7u) << 8) | ((hw >> 8) & 15u); /* XCC, SE, CU */
-        const unsigned words[3] = {(unsigned)groupClock0 & 0xffffffu, (unsigned)t1 & 0xffffffu, where};
-        for (int k = 0; k < 3; ++k)
+        const unsigned words[4] = {(unsigned)groupClock0 & 0xffffffu, (unsigned)t1 & 0xffffffu, where, 0xefcdabu};
+        for (int k = 0; k < 4; ++k)
         {
             bitmap[3 * (first + k) + 0] = (unsigned char)(words[k] & 255u);
             bitmap[3 * (first + k) + 1] = (unsigned char)((words[k] >> 8) & 255u);

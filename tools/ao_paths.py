@@ -21,25 +21,24 @@ if os.environ.get("AO_STATIC") == "1":
 out = E.engine_outputs(solr, case)["bitmap"].reshape(H, W, 3)
 STATIC = os.environ.get("AO_STATIC") == "1"    # solr_hip_set_variant(9): a fixed stride of tiles per workgroup, with the workgroups' clocks
 # the workgroups' own clocks sit in the first three pixels of their first tiles: take them out before the statistics
-if STATIC:
-    groups_n = (W // 32) * (H // 8) // 8
-    marks = []
-    for g in range(groups_n):
-        yy, xx = (g // (W // 32)) * 8, (g % (W // 32)) * 32
-        w = [int(out[yy, xx + k, 0]) | int(out[yy, xx + k, 1]) << 8 | int(out[yy, xx + k, 2]) << 16 for k in range(3)]
-        marks.append(w)
-        out[yy, xx:xx + 3] = out[yy, xx + 3]
-    marks = np.array(marks, dtype=np.int64)
-    t_begin = (marks[:, 0] - marks[:, 0].min()) % (1 << 24) * 0.01
-    t_end = (marks[:, 1] - marks[:, 0].min()) % (1 << 24) * 0.01
-    print("workgroups began their tiles between 0 and %.1f us, ended between %.1f and %.1f us; lifetimes (tiles only): median %.1f, max %.1f us" % (
-        t_begin.max(), t_end.min(), t_end.max(), float(np.median(t_end - t_begin)), float((t_end - t_begin).max())))
-    for at in range(0, int(t_end.max()) + 1, 20):
-        alive = int(((t_begin <= at) & (t_end > at)).sum())
-        print("  t = %3d us: %4d workgroups in their tiles (%.1f per CU), %4d not begun" % (at, alive, alive / 256.0, int((t_begin > at).sum())))
-    where = marks[:, 2]
-    cus = len(set(where.tolist()))
-    print("distinct (XCC, SE, CU) triples: %d" % cus)
+# the workgroups' own clocks sit in the first four pixels of their first tiles (the fourth is a mark): take them out
+# before the statistics
+marks = []
+for ty in range(H // 8):
+    for tx in range(W // 32):
+        yy, xx = ty * 8, tx * 32
+        if tuple(int(v) for v in out[yy, xx + 3]) == (0xab, 0xcd, 0xef):
+            marks.append([int(out[yy, xx + k, 0]) | int(out[yy, xx + k, 1]) << 8 | int(out[yy, xx + k, 2]) << 16 for k in range(3)])
+            out[yy, xx:xx + 4] = out[yy, xx + 4]
+marks = np.array(marks, dtype=np.int64)
+t_begin = (marks[:, 0] - marks[:, 0].min()) % (1 << 24) * 0.01
+t_end = (marks[:, 1] - marks[:, 0].min()) % (1 << 24) * 0.01
+print("%d workgroups began their tiles between 0 and %.1f us, ended between %.1f and %.1f us; lifetimes (tiles only): median %.1f, max %.1f us" % (
+    len(marks), t_begin.max(), t_end.min(), t_end.max(), float(np.median(t_end - t_begin)), float((t_end - t_begin).max())))
+for at in range(0, int(t_end.max()) + 1, 20):
+    alive = int(((t_begin <= at) & (t_end > at)).sum())
+    print("  t = %3d us: %4d workgroups in their tiles (%.1f per CU), %4d not begun" % (at, alive, alive / 256.0, int((t_begin > at).sum())))
+print("distinct (XCC, SE, CU) triples: %d" % len(set(marks[:, 2].tolist())))
 names = {1: "steady", 2: "two binades, regular pixel", 3: "two binades, irregular pixel", 4: "per-pixel loop", 5: "not tiled", 6: "window leaves the frame"}
 for k in np.unique(out[..., 0]):
     print("%-32s %9d pixels  %.3f" % (names.get(int(k), k), int((out[..., 0] == k).sum()), float((out[..., 0] == k).mean())))
