@@ -997,11 +997,13 @@ void ambientOcclusion(hipStream_t stream, const SceneInfo &si, const PostProcess
     unsigned groups = (unsigned)((tiles + AO_TILES_PER_GROUP - 1) / AO_TILES_PER_GROUP);
     if (heavyFirst)
     {
-        static int cus = 0;
+        static int cusOf[SOLR_MAX_GPU_COUNT + 1] = {}; /* (per device of this process: asked once) */
+        int device = 0;
+        (void)hipGetDevice(&device);
+        int &cus = cusOf[(device >= 0 && device < SOLR_MAX_GPU_COUNT) ? device : SOLR_MAX_GPU_COUNT];
         if (cus == 0)
         {
-            int device = 0, n = 0;
-            (void)hipGetDevice(&device);
+            int n = 0;
             if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
                 n = 256;
             cus = n;
