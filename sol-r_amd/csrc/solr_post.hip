@@ -434,17 +434,22 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
     const int binsX = 2 * rx + 1, binsY = 2 * ry + 1;
     int tableKey = 0; /* the binades (of x and of the frame's y) the deduped offsets in LDS were made for; 0: none */
     const bool pipelined = tiled && ww * wrows <= 256 * AO_AHEAD;
+    /* cell i < 1 024 of the window -> (i / ww, i % ww) by a multiplication: floor(i m / 2^26) with m = floor(2^26 / ww) + 1
+     * is i / ww exactly while i < 2^10 and ww <= 2^13 (the excess i / 2^26 is below 1 / ww) - a division by a number only
+     * known at run time is thirty instructions, four of them per thread and tile */
+    const unsigned wwMagic = (1u << 26) / (unsigned)max(ww, 1) + 1u;
     float aheadDepth[AO_AHEAD];
     float4 aheadLocal = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ahead = [&](int t) { /* this thread's share of tile t's window, and its own pixel's record */
-        const int tx0 = (t % tilesX) * AO_TILE_W, ty0 = (t / tilesX) * AO_TILE_H;
+    auto ahead = [&](int2 t) { /* this thread's share of the window of tile (column, row), and its own pixel's record */
+        const int tx0 = t.x * AO_TILE_W, ty0 = t.y * AO_TILE_H;
 #pragma unroll
         for (int k = 0; k < AO_AHEAD; ++k)
         {
             const int i = (int)threadIdx.x + 256 * k;
             float d = 0.f;
+            const int row = (int)(((unsigned)i * wwMagic) >> 26);
             if (i < ww * wrows)
-                aoDepthAt(pp, halo, W, nbRows, tx0 - rx + i % ww, ty0 - ry + i / ww, d);
+                aoDepthAt(pp, halo, W, nbRows, tx0 - rx + (i - row * ww), ty0 - ry + row, d);
             aheadDepth[k] = d;
         }
         const int px = tx0 + (int)(threadIdx.x % AO_TILE_W), py = ty0 + (int)(threadIdx.x / AO_TILE_W);
@@ -523,42 +528,53 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
     const int heavyRows = ordered ? listCount[0] : 0, heavyCols = ordered ? listCount[2] : 0;
     const int lightCols = tilesX - heavyCols;
     const int firstBlock = heavyRows * tilesX, secondBlock = (tilesY - heavyRows) * heavyCols;
-    auto tileOf = [&](int item) { /* item of the ordered list -> tile index (row-major) */
-        int ty, tx;
+    /* item of that order (or, unordered, the tile's row-major index) -> the tile's (column, row).  The scalar unit is what
+     * this kernel runs at (profiles/r5/ao_heavy_tiles_first.txt: 485 scalar instructions per wave and tile against 426
+     * vector ones, one scalar unit a CU), and a division by a number only known at run time is some thirty-five of
+     * them - four per tile as this was first written.  k / d for k < 2^20 and d <= 2^10 is floor(k m / 2^40) with
+     * m = floor(2^40 / d) + 1 exactly (the excess k / 2^40 is below 1 / d): one division per divisor and kernel, a 64-bit
+     * multiplication per tile, and the (column, row) pair is kept instead of being divided out of the index again. */
+    auto magicOf = [](int d) { return (1ull << 40) / (unsigned long long)max(d, 1) + 1ull; };
+    const unsigned long long magicTilesX = magicOf(tilesX), magicHeavyCols = magicOf(heavyCols), magicLightCols = magicOf(lightCols);
+    auto over = [](int k, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)k * magic) >> 40); };
+    const bool smallFrame = nbTiles < (1 << 20) && tilesX <= 1024;
+    auto tileOf = [&](int item) {
+        if (!ordered)
+        {
+            const int row = smallFrame ? over(item, magicTilesX) : item / tilesX;
+            return make_int2(item - row * tilesX, row);
+        }
         if (item < firstBlock)
         {
-            ty = rowList[item / tilesX];
-            tx = item - (item / tilesX) * tilesX;
+            const int q = over(item, magicTilesX);
+            return make_int2(item - q * tilesX, (int)rowList[q]);
         }
-        else if (item < firstBlock + secondBlock)
+        if (item < firstBlock + secondBlock)
         {
-            const int k = item - firstBlock;
-            ty = rowList[heavyRows + k / heavyCols];
-            tx = colList[k - (k / heavyCols) * heavyCols];
+            const int k = item - firstBlock, q = over(k, magicHeavyCols);
+            return make_int2((int)colList[k - q * heavyCols], (int)rowList[heavyRows + q]);
         }
-        else
-        {
-            const int k = item - firstBlock - secondBlock;
-            ty = rowList[heavyRows + k / lightCols];
-            tx = colList[heavyCols + k - (k / lightCols) * lightCols];
-        }
-        return ty * tilesX + tx;
+        const int k = item - firstBlock - secondBlock, q = over(k, magicLightCols);
+        return make_int2((int)colList[heavyCols + k - q * lightCols], (int)rowList[heavyRows + q]);
     };
     const bool persistent = heavyFirst != 0; /* the launch's grid: the workgroups the chip holds, each until the frame is done */
+    int2 tileNext = make_int2(0, 0);
     for (int run = 0; persistent || run < AO_TILES_PER_GROUP; ++run)
     {
         const int item = (int)blockIdx.x + run * (int)gridDim.x;
         if (item >= nbTiles)
             break;
-        const int tile = ordered ? tileOf(item) : item;
+        const int2 tileAt = run == 0 ? tileOf(item) : tileNext; /* (column, row) */
         /* the tile after this one (the window of its depths is asked for while this one is compared) */
         const int itemAfter = (persistent || run + 1 < AO_TILES_PER_GROUP) ? item + (int)gridDim.x : nbTiles;
-        const int tileAfter = itemAfter < nbTiles ? (ordered ? tileOf(itemAfter) : itemAfter) : nbTiles;
+        const bool another = itemAfter < nbTiles;
+        if (another)
+            tileNext = tileOf(itemAfter);
 #ifdef SOLR_AO_DEBUG
         const unsigned long long tileClock0 = __builtin_amdgcn_s_memrealtime(); /* (tools/ao_paths.py) */
 #endif
-        const int x0 = (tile % tilesX) * AO_TILE_W;
-        const int y0 = (tile / tilesX) * AO_TILE_H;
+        const int x0 = tileAt.x * AO_TILE_W;
+        const int y0 = tileAt.y * AO_TILE_H;
         const int wx0 = x0 - rx, wy0 = y0 - ry;
         const int x = x0 + (int)(threadIdx.x % AO_TILE_W);
         const int y = y0 + (int)(threadIdx.x / AO_TILE_W);
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
          * the barrier below: the loads of tile n + 1 are in flight while tile n is compared and stored, and a tile is
          * no longer two memory latencies long. */
         if (pipelined && run == 0)
-            ahead(tile);
+            ahead(tileAt);
         float4 local;
         if (pipelined)
         {
@@ -659,10 +675,14 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
          * (25 for cfg4's taps) instead of 256 evaluations.  The pixels of the irregular columns and rows (cfg4: the one
          * column AT the power of two, whose sums with negative taps fall into the binade below) keep the per-pixel loop. */
         const int e0x = (int)(__float_as_uint((float)x) >> 23), e0y = (int)(__float_as_uint((float)(y + firstRow)) >> 23);
-        const bool regularX = x >= 1 && (int)(__float_as_uint((float)x + tapLowX) >> 23) == e0x &&
-                              (int)(__float_as_uint((float)x + tapHighX) >> 23) == e0x;
-        const bool regularY = y + firstRow >= 1 && (int)(__float_as_uint((float)(y + firstRow) + tapLowY) >> 23) == e0y &&
-                              (int)(__float_as_uint((float)(y + firstRow) + tapHighY) >> 23) == e0y;
+        bool regularX = true, regularY = true; /* (every column and row of a steady tile is) */
+        if (!steady)
+        {
+            regularX = x >= 1 && (int)(__float_as_uint((float)x + tapLowX) >> 23) == e0x &&
+                       (int)(__float_as_uint((float)x + tapHighX) >> 23) == e0x;
+            regularY = y + firstRow >= 1 && (int)(__float_as_uint((float)(y + firstRow) + tapLowY) >> 23) == e0y &&
+                       (int)(__float_as_uint((float)(y + firstRow) + tapHighY) >> 23) == e0y;
+        }
         const bool windowInside = tiled && wx0 >= 0 && wy0 >= -halo.nbAbove && wx0 + ww <= W && wy0 + wrows <= nbRows + halo.nbBelow;
         bool classed = tiled && !steady && binsX * binsY <= 256;
         if (classed)
@@ -735,8 +755,8 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
             irregularDepth[irregularSlot] = local.w;
         }
         __syncthreads(); /* the window is in LDS, and so are the offsets */
-        if (pipelined && tileAfter < nbTiles)
-            ahead(tileAfter);
+        if (pipelined && another)
+            ahead(tileNext);
         const int together = classed ? nbIrregular : 0;
         const bool takenTogether = together > 0 && together <= AO_IRREGULAR_TOGETHER;
         if (takenTogether)
@@ -856,7 +876,8 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
                         occ += 1.f;
                 }
             }
-            occ /= (float)c;
+            occ *= 0.00390625f; /* occ / c (CRT:1166) with c == 256 on either path: a division by a power of two is this multiplication, bit for bit */
+            (void)c;
             occ += 0.3f;
             v3 col = V(local.x, local.y, local.z);
             if (occ < 1.f)
@@ -890,8 +911,8 @@ __global__ __launch_bounds__(256, AO_WAVES_PER_SIMD) void k_ambientOcclusion(con
      * them (24 bits of the 100 MHz clock each) and where it ran (HW_ID: wave, SIMD, CU, SH, SE; XCC_ID) */
     if (threadIdx.x == 0 && (int)blockIdx.x < nbTiles)
     {
-        const int mark = ordered ? tileOf((int)blockIdx.x) : (int)blockIdx.x; /* this workgroup's first tile */
-        const int first = (mark / tilesX) * AO_TILE_H * W + (mark % tilesX) * AO_TILE_W;
+        const int2 mark = tileOf((int)blockIdx.x); /* this workgroup's first tile */
+        const int first = mark.y * AO_TILE_H * W + mark.x * AO_TILE_W;
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         unsigned hw = 0u, xcc = 0u;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
