@@ -2679,8 +2679,10 @@ static int groupSiblings(std::vector<float4> &rows, std::vector<int> &start, std
     };
     /* (a list of a few dozen nodes - the Cornell room - gains 2 % from a third round of splits, lists of
      * thousands lose 7 %: profiles/r2/group_sweep.txt) */
+    /* (at least one round: with none a run longer than flatMax would be wrapped in a node around itself, for ever - no
+     * grouping at all is solr_hip_set_variant(5)) */
     const int levels = std::min(
-        4, std::max(0, getenv("SOLR_HIP_GROUP_LEVELS") ? atoi(getenv("SOLR_HIP_GROUP_LEVELS")) : (n <= 64 ? 3 : 2)));
+        4, std::max(1, getenv("SOLR_HIP_GROUP_LEVELS") ? atoi(getenv("SOLR_HIP_GROUP_LEVELS")) : (n <= 64 ? 3 : 2)));
     emit.siblings = [&](const std::vector<int> &sib, int from, int to) {
         if (to - from <= flatMax)
         {
