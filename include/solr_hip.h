@@ -112,6 +112,18 @@ int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const 
  * loop, walks beyond a workgroup's record slots (not classified).  A checked walk that repeats lanes in the reference's
  * order counts once in each. */
 void solr_hip_walk_bound_lists(unsigned long long out[6]);
+/* The record behind solr_hip_walk_bound in the caller's hands (tools/ray_regroup.py: what would a frame's rays sorted by
+ * where they go, or a walk kernel of its own at twice the occupancy, buy the node loop?).  keep(1): the next
+ * solr_hip_walk_bound leaves its records on the device.  info: {workgroups recorded, bytes per workgroup slot, dynamic LDS
+ * of the recorded launch, walk slots per workgroup} (layout: sol-r_amd/csrc/rt_device.h, "the walk's own ceiling").
+ * copy: the first `grid` slots to the host (toDevice == 0) or back.  replay: those slots with nothing but the node loop,
+ * `ldsBytes` of dynamic LDS a wave (< 0: the recorded launch's, i.e. the renderer's occupancy; 0: as many waves as the
+ * replay kernel's 64 registers allow), ms / stats as solr_hip_walk_bound.  release: the buffers given back. */
+void solr_hip_walk_records_keep(int keep);
+int solr_hip_walk_records_info(unsigned long long info[4]);
+int solr_hip_walk_records_copy(void *host, unsigned grid, int toDevice);
+int solr_hip_walk_replay(unsigned grid, long ldsBytes, int repeats, double ms[3], unsigned long long stats[4]);
+void solr_hip_walk_records_release(void);
 
 /* 0 when no error is pending; otherwise the HIP error code (or -1 for an
  * argument/state error) and, if buf != NULL, its text. Does not clear. */

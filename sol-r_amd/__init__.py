@@ -166,6 +166,16 @@ def _declare_hip(L):
     L.solr_hip_walk_bound.restype = C.c_int
     L.solr_hip_walk_bound_lists.argtypes = [P(C.c_ulonglong)]
     L.solr_hip_walk_bound_lists.restype = None
+    L.solr_hip_walk_records_keep.argtypes = [C.c_int]
+    L.solr_hip_walk_records_keep.restype = None
+    L.solr_hip_walk_records_info.argtypes = [P(C.c_ulonglong)]
+    L.solr_hip_walk_records_info.restype = C.c_int
+    L.solr_hip_walk_records_copy.argtypes = [C.c_void_p, C.c_uint, C.c_int]
+    L.solr_hip_walk_records_copy.restype = C.c_int
+    L.solr_hip_walk_replay.argtypes = [C.c_uint, C.c_long, C.c_int, P(C.c_double), P(C.c_ulonglong)]
+    L.solr_hip_walk_replay.restype = C.c_int
+    L.solr_hip_walk_records_release.argtypes = []
+    L.solr_hip_walk_records_release.restype = None
     L.solr_hip_set_short_ray_lists.argtypes = [C.c_int]
     L.solr_hip_set_short_ray_lists.restype = None
     L.solr_hip_short_ray_lists.restype = C.c_int

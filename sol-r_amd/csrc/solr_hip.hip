@@ -3296,6 +3296,64 @@ static void h2dLightInformationOne(LightInformation *lightInformation, int light
 }
 
 /* wait == false: the copies are enqueued and d2hBitmapWait() is owed (several devices copy side by side) */
+/* THE CALLER'S ARRAYS, PAGE-LOCKED ONCE.  d2h_bitmap copies into arrays the host owns (GPUKernel's m_bitmap and
+ * m_hPrimitivesXYIds, CudaKernel.cpp:304-312 - or whatever SolR_RunKernel's caller passed): pageable memory, which the
+ * runtime reaches through its own staging buffers, a host thread copying behind the DMA engine.  The first d2h_bitmap
+ * that sees an array registers it (hipHostRegister, a millisecond, once); the copies after that are one DMA transfer
+ * straight into it.  The registration is dropped with reshape_scene / finalize_scene / initialize_scene - the calls
+ * around which the reference's host re-makes those arrays (GPUKernel::initBuffers, reshape) - and when a fifth array
+ * shows up (the oldest goes).  A range somebody else has registered already is used as it is; a range that cannot be
+ * registered is copied into as before.  SOLR_HIP_PIN_HOST=0: never register (the copies of round 5). */
+struct PinnedRange
+{
+    char *base = nullptr;
+    size_t bytes = 0;
+    bool ours = false; /* registered here (and to be unregistered here) */
+    unsigned long long stamp = 0;
+};
+static PinnedRange gPinned[4];
+static unsigned long long gPinStamp = 0;
+
+static void unpinHostArrays()
+{
+    for (PinnedRange &r : gPinned)
+    {
+        if (r.base && r.ours)
+            (void)hipHostUnregister(r.base); /* (the host may have freed it already: then there is nothing to undo) */
+        r = PinnedRange();
+    }
+    (void)hipGetLastError();
+}
+
+static void pinHostArray(void *base, size_t bytes)
+{
+    static const bool enabled = !(getenv("SOLR_HIP_PIN_HOST") && atoi(getenv("SOLR_HIP_PIN_HOST")) == 0);
+    if (!enabled || !base || bytes < (1u << 16))
+        return;
+    char *p = (char *)base;
+    PinnedRange *oldest = &gPinned[0];
+    for (PinnedRange &r : gPinned)
+    {
+        if (r.base && p >= r.base && p + bytes <= r.base + r.bytes)
+        {
+            r.stamp = ++gPinStamp;
+            return;
+        }
+        if (r.stamp < oldest->stamp)
+            oldest = &r;
+    }
+    if (oldest->base && oldest->ours)
+        (void)hipHostUnregister(oldest->base);
+    *oldest = PinnedRange();
+    /* (a failure is not the frame's failure: the copy goes through the runtime's staging buffers as it used to) */
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    (void)hipGetLastError();
+    oldest->base = p;
+    oldest->bytes = bytes;
+    oldest->ours = (e == hipSuccess);
+    oldest->stamp = ++gPinStamp;
+}
+
 static void d2hBitmapOne(const SceneInfo &sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds, bool wait)
 {
     if (!ready("d2h_bitmap"))
@@ -3308,6 +3366,11 @@ static void d2hBitmapOne(const SceneInfo &sceneInfo, BitmapBuffer *bitmap, Primi
     /* the frame rendered last: its buffer set, on its stream */
     const hipStream_t stream = flightStream(g.current);
     const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(g.current).ptr;
+    const size_t framePixels = (size_t)sceneInfo.size.x * (size_t)sceneInfo.size.y;
+    if (bitmap && src)
+        pinHostArray(bitmap, framePixels * SOLR_COLOR_DEPTH);
+    if (primitivesXYIds && flightIds(g.current).ptr)
+        pinHostArray(primitivesXYIds, framePixels * sizeof(PrimitiveXYIdBuffer));
     if (bitmap && src)
         HIPCHECK(hipMemcpyAsync(bitmap + offset * SOLR_COLOR_DEPTH, src, pixels * SOLR_COLOR_DEPTH,
                                 hipMemcpyDeviceToHost, stream));
@@ -3397,55 +3460,59 @@ void solr_hip_walk_bound_lists(unsigned long long out[6])
         memcpy(out, walkLists, sizeof(walkLists));
 }
 
-int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
-                        const float origin[3], const float direction[3], const float angles[4], int repeats, double ms[3],
-                        unsigned long long stats[4])
+/* a frame whose walks are recorded: the records stay in g.walkRecords (a gigabyte for a 1080p frame) */
+static int recordFrame(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
+                       const float origin[3], const float direction[3], const float angles[4], const char *who)
 {
-    if (!ready("solr_hip_walk_bound"))
-        return -1;
-    ARGCHECK(gDevices == 1, "solr_hip_walk_bound: a diagnostic of one engine; this process renders on several devices");
-    if (!ok())
-        return -1;
     quiesce();
     HIPCHECK(hipSetDevice(g.device));
     g.recorded = false;
     g.recordNext = true;
+    if (!ok())
+        return -1;
+    renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, false, nullptr);
+    g.recordNext = false;
+    HIPCHECK(hipStreamSynchronize(flightStream(g.current)));
+    if (!ok() || !g.recorded)
+    {
+        if (ok())
+            setError(-1, "solr_hip_walk_bound: the frame was not recorded", __FILE__, __LINE__);
+        return -1;
+    }
+    (void)who;
+    return 0;
+}
+
+/* the first `grid` workgroup slots of g.walkRecords replayed `repeats` times with `ldsBytes` of dynamic LDS a wave */
+static int replayRecords(unsigned grid, size_t ldsBytes, int repeats, double ms[3], unsigned long long stats[4], bool lists)
+{
+    typedef WalkBoundFn BoundFn;
+    static const int leanRows[4] = {F_SPHERE | F_PLANE, F_SPHERE | F_TRI, F_SPHERE | F_CYL, F_SPHERE | F_PLANE | F_TRI | F_CYL};
+    ARGCHECK(g.recordVariant >= 0 && g.recordVariant < 4 && g.walkRecords.ptr && grid > 0 &&
+                 (size_t)grid * SOLR_WALK_SLOT_BYTES <= g.walkRecords.bytes,
+             "solr_hip_walk_replay: no recorded frame, or more workgroups than its buffer holds");
+    if (!ok())
+        return -1;
+    const BoundFn fn = solrrows::walkBound(g.recordVariant, leanRows[g.recordVariant] | (g.recordDeep ? F_DEEP : 0));
+    ARGCHECK(fn != nullptr, "solr_hip_walk_bound: no replay instantiation for this row");
+    if (!ok())
+        return -1;
+    reserve(g.walkVisits, (size_t)grid * WAVE * sizeof(unsigned) + 64);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHECK(hipEventCreate(&e0));
     HIPCHECK(hipEventCreate(&e1));
     if (!ok())
         return -1;
-    renderImpl(*sceneInfo, *objects, *postProcessingInfo, origin, direction, angles, false, nullptr);
-    g.recordNext = false;
     const hipStream_t stream = flightStream(g.current);
-    HIPCHECK(hipStreamSynchronize(stream));
-    if (!ok() || !g.recorded)
-    {
-        if (ok())
-            setError(-1, "solr_hip_walk_bound: the frame was not recorded", __FILE__, __LINE__);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        return -1;
-    }
-    typedef WalkBoundFn BoundFn;
-    static const int leanRows[4] = {F_SPHERE | F_PLANE, F_SPHERE | F_TRI, F_SPHERE | F_CYL, F_SPHERE | F_PLANE | F_TRI | F_CYL};
-    const BoundFn fn = solrrows::walkBound(g.recordVariant, leanRows[g.recordVariant] | (g.recordDeep ? F_DEEP : 0));
-    ARGCHECK(fn != nullptr, "solr_hip_walk_bound: no replay instantiation for this row");
-    if (!ok())
-    {
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        return -1;
-    }
     unsigned *visits = (unsigned *)g.walkVisits.ptr;
-    unsigned *skipped = visits + (size_t)g.recordGrid * WAVE;
+    unsigned *skipped = visits + (size_t)grid * WAVE;
     double sum = 0.0, best = 1.0e30;
     repeats = repeats < 1 ? 1 : repeats;
     for (int i = 0; i < repeats + 2 && ok(); ++i)
     {
         HIPCHECK(hipMemsetAsync(skipped, 0, sizeof(unsigned), stream));
         HIPCHECK(hipEventRecord(e0, stream));
-        hipLaunchKernelGGL(fn, dim3(g.recordGrid), dim3(WAVE), g.recordLds, stream, g.recordScene, (const char *)g.walkRecords.ptr,
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(WAVE), ldsBytes, stream, g.recordScene, (const char *)g.walkRecords.ptr,
                            visits, skipped);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(e1, stream));
@@ -3460,16 +3527,16 @@ int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const 
     }
     if (ok() && stats)
     {
-        std::vector<unsigned> v((size_t)g.recordGrid * WAVE + 1);
+        std::vector<unsigned> v((size_t)grid * WAVE + 1);
         HIPCHECK(hipMemcpy(v.data(), visits, v.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-        std::vector<int> heads((size_t)g.recordGrid * 4);
-        HIPCHECK(hipMemcpy2D(heads.data(), 16, g.walkRecords.ptr, SOLR_WALK_SLOT_BYTES, 16, g.recordGrid, hipMemcpyDeviceToHost));
+        std::vector<int> heads((size_t)grid * 4);
+        HIPCHECK(hipMemcpy2D(heads.data(), 16, g.walkRecords.ptr, SOLR_WALK_SLOT_BYTES, 16, grid, hipMemcpyDeviceToHost));
         if (const char *dump = getenv("SOLR_HIP_WALK_BOUND_DUMP"))
         {
             /* diagnostics (tools/longest_wave.py): leaf entries per lane and walks per workgroup of the replay */
             if (FILE *f = fopen(dump, "wb"))
             {
-                const unsigned n = g.recordGrid;
+                const unsigned n = grid;
                 fwrite(&n, sizeof(n), 1, f);
                 fwrite(v.data(), sizeof(unsigned), (size_t)n * WAVE, f);
                 fwrite(heads.data(), sizeof(int), (size_t)n * 4, f);
@@ -3477,16 +3544,17 @@ int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const 
             }
         }
         unsigned long long walks = 0, entries = 0;
-        for (unsigned b = 0; b < g.recordGrid; ++b)
+        for (unsigned b = 0; b < grid; ++b)
             walks += (unsigned long long)heads[4 * (size_t)b];
+        if (lists)
         {
             /* which list each recorded walk took (solr_hip_walk_bound_lists) */
-            std::vector<int> kinds((size_t)g.recordGrid * 4 * (SOLR_WALK_SLOTS + 1));
+            std::vector<int> kinds((size_t)grid * 4 * (SOLR_WALK_SLOTS + 1));
             HIPCHECK(hipMemcpy2D(kinds.data(), 16 * (SOLR_WALK_SLOTS + 1), g.walkRecords.ptr, SOLR_WALK_SLOT_BYTES,
-                                 16 * (SOLR_WALK_SLOTS + 1), g.recordGrid, hipMemcpyDeviceToHost));
+                                 16 * (SOLR_WALK_SLOTS + 1), grid, hipMemcpyDeviceToHost));
             for (int i = 0; i < 6; ++i)
                 walkLists[i] = 0;
-            for (unsigned b = 0; ok() && b < g.recordGrid; ++b)
+            for (unsigned b = 0; ok() && b < grid; ++b)
             {
                 const int *slot = &kinds[(size_t)b * 4 * (SOLR_WALK_SLOTS + 1)];
                 const int n = std::min(slot[0], (int)SOLR_WALK_SLOTS);
@@ -3506,7 +3574,7 @@ int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const 
         stats[0] = walks;
         stats[1] = v.back();
         stats[2] = entries;
-        stats[3] = g.recordGrid;
+        stats[3] = grid;
     }
     if (ms)
     {
@@ -3516,11 +3584,97 @@ int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const 
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    /* the buffers are a gigabyte for a 1080p frame: given back at once */
+    return ok() ? 0 : -1;
+}
+
+static bool keepWalkRecords = false;
+
+int solr_hip_walk_bound(const SceneInfo *sceneInfo, const vec4i *objects, const PostProcessingInfo *postProcessingInfo,
+                        const float origin[3], const float direction[3], const float angles[4], int repeats, double ms[3],
+                        unsigned long long stats[4])
+{
+    if (!ready("solr_hip_walk_bound"))
+        return -1;
+    ARGCHECK(gDevices == 1, "solr_hip_walk_bound: a diagnostic of one engine; this process renders on several devices");
+    if (!ok())
+        return -1;
+    if (recordFrame(sceneInfo, objects, postProcessingInfo, origin, direction, angles, "solr_hip_walk_bound") != 0)
+        return -1;
+    const int rc = replayRecords(g.recordGrid, g.recordLds, repeats, ms, stats, true);
+    if (!keepWalkRecords)
+    {
+        /* the buffers are a gigabyte for a 1080p frame: given back at once */
+        release(g.walkRecords);
+        release(g.walkVisits);
+        g.recorded = false;
+    }
+    return rc;
+}
+
+/* The record behind solr_hip_walk_bound in the caller's hands (tools/ray_regroup.py: what would sorting a frame's rays
+ * by where they go buy the node loop?).  keep(1): the next solr_hip_walk_bound leaves its records on the device.
+ * info: {workgroups recorded, bytes per workgroup slot, dynamic LDS of the recorded launch, walk slots per workgroup}.
+ * copy: the first `grid` slots to (toDevice == 0) or from the host.  replay: those slots with nothing but the node loop,
+ * `ldsBytes` of dynamic LDS a wave (< 0: the recorded launch's; 0: as many waves as the replay kernel's 64 registers
+ * allow).  release: the buffers given back. */
+void solr_hip_walk_records_keep(int keep)
+{
+    keepWalkRecords = keep != 0;
+}
+
+int solr_hip_walk_records_info(unsigned long long info[4])
+{
+    if (!ready("solr_hip_walk_records_info") || !info)
+        return -1;
+    info[0] = g.recorded ? g.recordGrid : 0;
+    info[1] = SOLR_WALK_SLOT_BYTES;
+    info[2] = g.recordLds;
+    info[3] = SOLR_WALK_SLOTS;
+    return 0;
+}
+
+int solr_hip_walk_records_copy(void *host, unsigned grid, int toDevice)
+{
+    if (!ready("solr_hip_walk_records_copy"))
+        return -1;
+    ARGCHECK(host && grid > 0 && g.recorded, "solr_hip_walk_records_copy: no recorded frame");
+    if (!ok())
+        return -1;
+    const size_t bytes = (size_t)grid * SOLR_WALK_SLOT_BYTES;
+    HIPCHECK(hipSetDevice(g.device));
+    if (toDevice)
+    {
+        reserve(g.walkRecords, bytes);
+        if (!ok())
+            return -1;
+        HIPCHECK(hipMemcpy(g.walkRecords.ptr, host, bytes, hipMemcpyHostToDevice));
+    }
+    else
+    {
+        ARGCHECK(bytes <= g.walkRecords.bytes, "solr_hip_walk_records_copy: more workgroups than were recorded");
+        if (!ok())
+            return -1;
+        HIPCHECK(hipMemcpy(host, g.walkRecords.ptr, bytes, hipMemcpyDeviceToHost));
+    }
+    return ok() ? 0 : -1;
+}
+
+int solr_hip_walk_replay(unsigned grid, long ldsBytes, int repeats, double ms[3], unsigned long long stats[4])
+{
+    if (!ready("solr_hip_walk_replay"))
+        return -1;
+    ARGCHECK(g.recorded, "solr_hip_walk_replay: no recorded frame (solr_hip_walk_records_keep(1), then solr_hip_walk_bound)");
+    if (!ok())
+        return -1;
+    HIPCHECK(hipSetDevice(g.device));
+    return replayRecords(grid, ldsBytes < 0 ? g.recordLds : (size_t)ldsBytes, repeats, ms, stats, false);
+}
+
+void solr_hip_walk_records_release(void)
+{
     release(g.walkRecords);
     release(g.walkVisits);
     g.recorded = false;
-    return ok() ? 0 : -1;
 }
 
 void solr_hip_enable_timing(int enable)
@@ -3820,6 +3974,7 @@ void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, 
 {
     if (solr_hip_last_error(nullptr, 0) != 0)
         return;
+    unpinHostArrays();
     int asked = occupancyParameters.x < 1 ? 1 : occupancyParameters.x;
     if (asked > SOLR_MAX_GPU_COUNT)
         asked = SOLR_MAX_GPU_COUNT; /* CudaRayTracer.cu:1415-1416 */
@@ -3880,6 +4035,7 @@ void finalize_scene(vec2i)
     /* every engine that is up, whatever occupancyParameters says by now; afterwards the process is a one-device
      * process again until initialize_scene says otherwise */
     const bool several = gDevices > 1;
+    unpinHostArrays();
     for (int d = 0; d < SOLR_MAX_GPU_COUNT; ++d)
         if (gEngines[d] && gEngines[d]->initialized)
         {
@@ -3899,6 +4055,7 @@ void reshape_scene(vec2i occupancyParameters, SceneInfo sceneInfo)
 {
     if (!sameOccupancy(occupancyParameters, "reshape_scene"))
         return;
+    unpinHostArrays(); /* (the host re-makes its frame arrays around this call) */
     splitRows(sceneInfo.size.y);
     onEveryDevice([&](int) { reshapeOne(sceneInfo); });
 }

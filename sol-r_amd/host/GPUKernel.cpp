@@ -1518,6 +1518,16 @@ void GPUKernel::fillRandoms()
 }
 
 /* reference: GPUKernel.cpp:2712-2727 */
+void GPUKernel::render_end(BitmapBuffer *image)
+{
+    render_end();
+    if (lastError() != 0)
+        return; /* (nothing was rendered: the caller's array is left alone, SolR_RunKernel returns -1) */
+    const BitmapBuffer *bitmap = getBitmap();
+    if (image && bitmap)
+        memcpy(image, bitmap, (size_t)m_sceneInfo.size.x * (size_t)m_sceneInfo.size.y * (size_t)SOLR_COLOR_DEPTH);
+}
+
 void GPUKernel::render_begin(const float)
 {
     if (m_deterministicSeed < 0)

@@ -298,7 +298,16 @@ public:
     virtual void render_end() = 0;
     /* the image of the frame render_end delivered last (with frames in flight - setFramesInFlight - that is the
      * engine's page-locked copy of it, not m_bitmap: nothing is copied twice) */
-    BitmapBuffer *getBitmap() { return m_bitmapView ? m_bitmapView : (m_bitmap.empty() ? nullptr : m_bitmap.data()); }
+    BitmapBuffer *getBitmap()
+    {
+        fetchBitmap();
+        return m_bitmapView ? m_bitmapView : (m_bitmap.empty() ? nullptr : m_bitmap.data());
+    }
+    /* render_end with the frame's image delivered into the CALLER'S array instead of m_bitmap (what SolR_RunKernel is
+     * for, SolRStub.cpp:154-164: the reference copies m_bitmap to the caller afterwards).  An engine with a device
+     * copies from the device straight into `image` and leaves m_bitmap to the next getBitmap() (fetchBitmap); the
+     * default is the reference's two steps. */
+    virtual void render_end(BitmapBuffer *image);
     /* Extension (no reference equivalent; the reference's render_end waits for the frame and then copies it,
      * CudaKernel.cpp:304-312).  n > 1: render_begin also starts the read-back of its frame's image, and render_end
      * delivers the image of the frame n - 1 calls back - the one whose copy has had n - 1 frames' time to land -
@@ -490,6 +499,8 @@ protected:
      * 16 bytes per pixel, five times the image - although only picking ever looks at them; an engine may
      * leave them on the device until then */
     virtual void fetchPrimitiveIds() {}
+    /* m_bitmap brought up to date with the frame rendered last, where render_end(image) left it behind */
+    virtual void fetchBitmap() {}
     /* engine hook: the primitives as the resident scene holds them now, written into the store (the same
      * bits a replay of the pending rotations produces - tests/test_animation_gpu.py - at a cost that does not
      * grow with their number); false = not available, replay */

@@ -65,6 +65,7 @@ void HipKernel::releaseDevice()
 {
     syncHost(); /* rotations that only the device has seen would be lost with it */
     fetchPrimitiveIds(); /* and so would the last frame's ids */
+    fetchBitmap();       /* ... and its image, where only the caller of SolR_RunKernel has it so far */
     flushFrames();
     if (m_bitmapView && !m_bitmap.empty())
     {
@@ -85,6 +86,7 @@ void HipKernel::reshape()
     m_bitmapView = nullptr; /* the engine's images are re-made for the new size */
     GPUKernel::reshape();
     m_idsOnDevice = false; /* the buffers are re-made for the new size */
+    m_bitmapOnDevice = false;
     if (m_deviceInitialized)
         reshape_scene(m_occupancyParameters, m_sceneInfo);
 }
@@ -285,11 +287,37 @@ void HipKernel::render_end()
             m_tickets.pop_front();
         }
         m_idsOnDevice = true;
+        m_bitmapOnDevice = false;
         return;
     }
     m_bitmapView = nullptr;
     d2h_bitmap(m_occupancyParameters, m_sceneInfo, m_bitmap.data(), nullptr);
     m_idsOnDevice = true;
+    m_bitmapOnDevice = false;
+}
+
+/* SolR_RunKernel's frame (SolRStub.cpp:154-164): the reference waits for the frame, copies it to m_bitmap and copies
+ * m_bitmap to the caller.  Here the device's image goes straight into the caller's array - page-locked by the engine
+ * the first time it sees it (d2h_bitmap) - and m_bitmap is brought up to date when somebody asks for it (getBitmap). */
+void HipKernel::render_end(BitmapBuffer *image)
+{
+    if (m_flights > 1 || !image || !m_deviceInitialized)
+    {
+        GPUKernel::render_end(image);
+        return;
+    }
+    m_bitmapView = nullptr;
+    d2h_bitmap(m_occupancyParameters, m_sceneInfo, image, nullptr);
+    m_idsOnDevice = true;
+    m_bitmapOnDevice = true;
+}
+
+void HipKernel::fetchBitmap()
+{
+    if (!m_bitmapOnDevice || !m_deviceInitialized || m_bitmap.empty())
+        return;
+    m_bitmapOnDevice = false;
+    d2h_bitmap(m_occupancyParameters, m_sceneInfo, m_bitmap.data(), nullptr);
 }
 
 void HipKernel::deliver(int ticket)

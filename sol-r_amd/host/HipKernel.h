@@ -37,6 +37,7 @@ public:
     /* reference: CudaKernel.cpp:174-302 / 304-389 */
     void render_begin(const float timer) override;
     void render_end() override;
+    void render_end(BitmapBuffer *image) override;
     int lastError(std::string *message = nullptr) override;
     void setFramesInFlight(int n) override;
     int getFramesInFlight() const override { return m_flights; }
@@ -58,6 +59,7 @@ protected:
     /* rotatePrimitives on the resident scene, solr_hip_rotate_primitives (include/solr_hip.h) */
     bool deviceRotatePrimitives(const vec3f &center, const vec3f &cosA, const vec3f &sinA) override;
     void fetchPrimitiveIds() override;
+    void fetchBitmap() override;
     bool primitivesFromDevice(Frame &f) override;
     int deviceBuildTree(const std::vector<Primitive> &primitives, const std::vector<unsigned char> &emissive,
                         const vec3f &minPos, const vec3f &maxPos, float viewDistance, std::vector<BoundingBox> &boxes,
@@ -68,6 +70,7 @@ private:
     int m_sharedMemSize;
     bool m_deviceInitialized;
     bool m_idsOnDevice = false;
+    bool m_bitmapOnDevice = false; /* render_end(image) delivered to the caller's array: m_bitmap follows when asked */
     unsigned m_sharedSeed = 0, m_sharedState = 0; /* solr_hip_comm_shared_seed and the generator it seeds (render_begin) */
     int m_flights = 1;            /* frames in flight through render_begin / render_end (setFramesInFlight) */
     std::deque<int> m_tickets;    /* read-backs under way, oldest first (solr_hip_d2h_image_async) */

@@ -167,14 +167,16 @@ const BitmapBuffer *SolRx_GetBitmap(void)
 
 int SolR_RunKernel(double timer, BitmapBuffer *image)
 {
-    int status = SolRx_Render(timer);
-    if (status != 0)
-        return status;
-    BitmapBuffer *bitmap = SingletonKernel::kernel()->getBitmap();
-    if (!bitmap || !image)
+    /* reference: SolRStub.cpp:154-164 - render_begin, render_end, then m_bitmap copied to the caller.  render_end(image)
+     * is those last two steps (an engine with a device delivers straight into `image`, GPUKernel.h) */
+    if (!image)
         return -1;
-    memcpy(image, bitmap, (size_t)gSceneInfoStub.size.x * gSceneInfoStub.size.y * SOLR_COLOR_DEPTH);
-    return 0;
+    solr::GPUKernel *kernel = SingletonKernel::kernel();
+    kernel->setSceneInfo(gSceneInfoStub);
+    kernel->setPostProcessingInfo(gPostProcessingInfoStub);
+    kernel->render_begin(static_cast<float>(timer));
+    kernel->render_end(image);
+    return engineStatus();
 }
 
 int SolR_AddPrimitive(int type, int movable)
