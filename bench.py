@@ -341,6 +341,10 @@ def main():
                                                                                           "on another rank"), file=sys.stderr, flush=True)
             hip.solr_hip_clear_error()
             hip.solr_hip_comm_finalize()
+            # nothing is up now: the next configure() must bring a communicator (and a delivery route) up again,
+            # whatever it asks for (a stale `False` here let the next combination run without one)
+            mode["per_flight"] = None
+            mode["delivery"] = None
             return False
         mode["per_flight"] = int(hip.solr_hip_comm_count()) > 1
         return True
@@ -368,6 +372,7 @@ def main():
                 hip.solr_hip_clear_error()
                 hip.solr_hip_image_unshare()
                 route = "gathered"
+                mode["collective"] = True      # (that route delivers what the gather assembled: no gather, no frame)
                 if rank == 0:
                     print("bench.py: " + why, file=sys.stderr, flush=True)
             dist.barrier()
@@ -699,6 +704,10 @@ def main():
             entry = {}
             try:
                 why = configure(per_flight, route, collective)
+                # every rank takes the same way from here: a combination that did not come up on ONE rank is skipped
+                # on all of them (the others would wait in timed()'s barriers for a rank that never came)
+                if agree(dist, torch, why is not None):
+                    why = why or "did not come up on another rank"
                 if why:
                     entry["skipped"] = why
                 else:
@@ -724,18 +733,44 @@ def main():
         if not usable:
             raise SystemExit("bench.py rank %d: no communicator mode / delivery route delivered the one-GPU frame: %s"
                              % (rank, json.dumps(mode_sweep)))
-        best = min(usable, key=lambda n: usable[n]["ms_per_step"])
+        # The headline runs on the route BASELINE.json's north_star names - "a single RCCL gather over xGMI to assemble
+        # the final image": the fastest combination that makes that RCCL call behind every frame.  The fastest of ALL
+        # of them (which may be the shared host image with no collective per frame) is reported beside it
+        # (rates_mrays_per_s.fastest_combination_of_the_sweep), never as `value`.
+        fastest = min(usable, key=lambda n: usable[n]["ms_per_step"])
+        with_rccl = {n: e for n, e in usable.items() if e.get("rccl_calls_per_frame") == 1}
+        if not with_rccl:
+            raise SystemExit("bench.py rank %d: no combination with the RCCL gather behind every frame delivered the "
+                             "one-GPU frame: %s" % (rank, json.dumps(mode_sweep)))
+        best = min(with_rccl, key=lambda n: with_rccl[n]["ms_per_step"])
         for per_flight, route, collective in combos:
             if label(per_flight, route, collective) == best:
                 arm("mode sweep: back to " + best)
                 why = configure(per_flight, route, collective)
-                if why:
+                if agree(dist, torch, why is not None):
                     raise SystemExit("bench.py rank %d: %s did not come up a second time: %s" % (rank, best, why))
         mode_sweep["headline_runs_on"] = best
+        mode_sweep["fastest_combination"] = fastest
         comm_count = int(hip.solr_hip_comm_count())
         args.delivery = mode["delivery"]
+    if native:
+        # `value` at N > 1 is the RCCL-gather route, always: the gather behind every frame, on a communicator of
+        # exactly --gpus ranks (a job whose communicator has another size, or none, is void: exit code 5)
+        if not (os.environ.get("SOLR_BENCH_COLLECTIVE") == "0"):
+            mode["collective"] = True
+        if int(hip.solr_hip_comm_count()) < 1 and not comm_up(False):
+            raise SystemExit("bench.py rank %d: no communicator for the headline" % rank)
+        rccl_ranks = int(hip.solr_hip_comm_ranks())
+        comm_count = int(hip.solr_hip_comm_count())
+        if agree(dist, torch, rccl_ranks != world):
+            if rank == 0:
+                print("bench.py: the communicator has %d rank(s), --gpus is %d: the job is void" % (rccl_ranks, world),
+                      file=sys.stderr, flush=True)
+            sys.exit(5)
     arm("the timed regions")
     main_run = timed(args.steps, args.warmup, regions)
+    if native and mode["collective"] and world > 1 and agree(dist, torch, rank == 0 and delivered[0] == 0):
+        raise SystemExit("bench.py rank %d: the timed regions delivered no frame to rank 0's host" % rank)
     short_ray_lists = int(hip.solr_hip_short_ray_lists())   # what the engine chose for the delivered frames
     t_issued_ms = main_run["issued"] / args.steps * 1e3
     strips = "balanced by cost" if balanced else "equal rows"
@@ -949,6 +984,13 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
+        # which of config.rates_mrays_per_s `value` is: the frame DELIVERED (its image on the host every frame, the host
+        # `frames in flight - 1` frames behind the renderer; N > 1: behind the RCCL gather of the strips on every frame) -
+        # not the reference's one-frame-at-a-time protocol (rates: one_frame_at_a_time, cudaRender_plus_image,
+        # cudaRender_plus_d2h_bitmap) and not frames left in HBM (pipelined_device_resident)
+        "protocol": "delivered_pipelined" if not distributed else (
+            "delivered_pipelined_behind_the_rccl_gather" if (native and headline_collective) else
+            ("delivered_pipelined_no_collective (SOLR_BENCH_COLLECTIVE=0)" if native else "torch_gather_device_resident")),
         "dtype": "f32",
         "data": "synthetic" if args.scene not in ("irt_model", "obj_model", "swc_morphology", "pdb_molecule") else "the reference's sample scene file",
         "config": {"workload": "%s%s %dx%d, %d bounces + shadow rays, %d boxes / %d primitives, %s" %
@@ -1008,7 +1050,7 @@ def main():
         out["config"].update({
             "rccl_ranks": rccl_ranks, "rccl_communicators": comm_count,
             "rccl_communicator_mode": ("one per frame in flight" if comm_count and comm_count > 1 else "one for everything") +
-                                      (" (the fastest of config.mode_sweep)" if mode_sweep else
+                                      (" (the fastest combination of config.mode_sweep that gathers with RCCL behind every frame)" if mode_sweep else
                                        " (SOLR_HIP_COMM_PER_FLIGHT=0|1 / --delivery chose it: no sweep)"),
             "per_rank": per_rank, "slowest_rank": slowest["rank"],
             # the end barrier of a region belongs to the control plane (gloo over TCP) and is not charged to the region:

@@ -74,7 +74,7 @@ int solr_hip_probe_postprocess(const SceneInfo *sceneInfo, const PostProcessingI
                                const PostProcessingBuffer *frame, unsigned char *bitmap);
 
 /* The read-back tickets of solr_hip_d2h_image_async (include/solr_hip.h): the ticket the serial-th frame of a process
- * gets - always a positive int: (serial mod period) x ring + slot - with its slot and the period (no GPU needed); and
+ * gets - never negative (0 once a period): (serial mod period) x ring + slot - with its slot and the period (no GPU needed); and
  * the engine's serial counter, returned, and set first when setTo >= 0 (to put a running engine just before 2^31 / 6
  * tickets - 27 hours of frames - and render across) */
 int solr_hip_probe_ticket(long long serial, int *slot, long long *period);

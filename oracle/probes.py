@@ -435,6 +435,13 @@ SCENES = {
     "triangles": lambda: SceneData(_extra().triangles_only),
     "triangles_flat": lambda: SceneData(_extra().triangles_only, extendedGeometry=0),
     "textured": lambda: SceneData(_extra().textured, width=96, height=64),
+    # BASELINE configs[2] / [3] in small, shaped so that none of the statements in which the reference's two engines
+    # differ shows on (nearly) any pixel: one lamp, nothing transparent or emissive in view, a pass below 10, colours
+    # inside [0, 1] (no final saturate), a backdrop behind the sticks (no ray misses: the depth word of a miss)
+    "mesh_100": lambda: SceneData(_extra().triangles_only, n=7, dim=0.6),
+    "sticks_backdrop": lambda: SceneData(_extra().sticks, backdrop=True, dim=0.6),
+    # every primitive type under ONE lamp (the lamp loop differs only with several)
+    "mix_one_lamp": lambda: SceneData(_extra().primitives_mix, width=96, height=64, lamps=1),
 }
 
 
@@ -604,7 +611,8 @@ def case_launch(scene_name, seed=20, width=80, height=56, **si_changes):
                 width=width, height=height)
 
 
-def case_post(seed=21, width=96, height=64, pp_type=0, iteration=0, param1=0.0, param2=0.0, param3=0, period=0):
+def case_post(seed=21, width=96, height=64, pp_type=0, iteration=0, param1=0.0, param2=0.0, param3=0, period=0,
+              plateaus=0):
     """the reference's own post-processing kernels on a synthetic frame buffer with depth discontinuities.
     period: the random buffer repeats with that period - with 900, randoms[i + 100] == randoms[i + 1000], the one
     statement in which the two engines' k_depthOfField differ (CRT:1101 / CL:2968) cannot show, and the reference's
@@ -618,6 +626,10 @@ def case_post(seed=21, width=96, height=64, pp_type=0, iteration=0, param1=0.0, 
     scale = (iteration - 10 + 1) if iteration > 10 else 1
     pp["colorInfo"][:, :3] = (colour * scale * rng.uniform(0.7, 1.3, (n, 3))).astype(f32)
     depth = 8000.0 + 4000.0 * ((xs // 12 + ys // 9) % 3) + rng.uniform(-50, 50, (height, width))
+    if plateaus:
+        # plateaus of one depth, `plateaus` pixels wide: a pixel whose taps all land on its own plateau, or on farther
+        # ones, is occluded by nothing - there the two engines' k_ambientOcclusion leave the colour alone and agree
+        depth = 8000.0 + 4000.0 * ((xs // plateaus + ys // (3 * plateaus // 4)) % 3) + 0.0 * depth
     pp["colorInfo"][:, 3] = depth.reshape(-1).astype(f32)
     randoms = rng.uniform(-1.0, 1.0, max(n, 4096)).astype(f32)
     if period:
@@ -974,9 +986,13 @@ CASES = {
     "launch_textured": lambda: case_launch("textured"),
     "launch_cornell_opaque": lambda: case_launch("cornell_opaque", nbRayIterations=1),
     "launch_sticks": lambda: case_launch("sticks"),
+    "launch_mesh_100": lambda: case_launch("mesh_100"),
+    "launch_sticks_backdrop": lambda: case_launch("sticks_backdrop"),
+    "launch_mix_one_lamp": lambda: case_launch("mix_one_lamp"),
     "post_default": lambda: case_post(pp_type=0),
     "post_default_accumulated": lambda: case_post(pp_type=0, iteration=13),
     "post_depth_of_field": lambda: case_post(pp_type=1, param1=9000.0, param2=300.0, param3=16),
     "post_depth_of_field_moot": lambda: case_post(pp_type=1, param1=9000.0, param2=300.0, param3=16, period=900),
     "post_ambient_occlusion": lambda: case_post(pp_type=2, param2=40.0),
+    "post_ambient_occlusion_plateaus": lambda: case_post(pp_type=2, param2=10.0, width=256, height=192, plateaus=64),
 }

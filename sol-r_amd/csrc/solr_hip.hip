@@ -1517,6 +1517,10 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         if (!ok())
             return;
         F.deepStack = (float4 *)g.deepStack[flight].ptr;
+        /* the deep slots are never zeroed: every slot a lane reads was written by the trip that made it (rt_device.h
+         * launchRayTracing).  Variant 10 proves it: NaNs in every slot before the launch, the same frame after */
+        if (g.variant == 10)
+            HIPCHECK(hipMemsetAsync(F.deepStack, 0xff, (size_t)deepSlots * (size_t)F.deepStride * sizeof(float4), stream));
     }
     {
         HostSpan launch("  of which the kernel launch");
@@ -3296,64 +3300,6 @@ static void h2dLightInformationOne(LightInformation *lightInformation, int light
 }
 
 /* wait == false: the copies are enqueued and d2hBitmapWait() is owed (several devices copy side by side) */
-/* THE CALLER'S ARRAYS, PAGE-LOCKED ONCE.  d2h_bitmap copies into arrays the host owns (GPUKernel's m_bitmap and
- * m_hPrimitivesXYIds, CudaKernel.cpp:304-312 - or whatever SolR_RunKernel's caller passed): pageable memory, which the
- * runtime reaches through its own staging buffers, a host thread copying behind the DMA engine.  The first d2h_bitmap
- * that sees an array registers it (hipHostRegister, a millisecond, once); the copies after that are one DMA transfer
- * straight into it.  The registration is dropped with reshape_scene / finalize_scene / initialize_scene - the calls
- * around which the reference's host re-makes those arrays (GPUKernel::initBuffers, reshape) - and when a fifth array
- * shows up (the oldest goes).  A range somebody else has registered already is used as it is; a range that cannot be
- * registered is copied into as before.  SOLR_HIP_PIN_HOST=0: never register (the copies of round 5). */
-struct PinnedRange
-{
-    char *base = nullptr;
-    size_t bytes = 0;
-    bool ours = false; /* registered here (and to be unregistered here) */
-    unsigned long long stamp = 0;
-};
-static PinnedRange gPinned[4];
-static unsigned long long gPinStamp = 0;
-
-static void unpinHostArrays()
-{
-    for (PinnedRange &r : gPinned)
-    {
-        if (r.base && r.ours)
-            (void)hipHostUnregister(r.base); /* (the host may have freed it already: then there is nothing to undo) */
-        r = PinnedRange();
-    }
-    (void)hipGetLastError();
-}
-
-static void pinHostArray(void *base, size_t bytes)
-{
-    static const bool enabled = !(getenv("SOLR_HIP_PIN_HOST") && atoi(getenv("SOLR_HIP_PIN_HOST")) == 0);
-    if (!enabled || !base || bytes < (1u << 16))
-        return;
-    char *p = (char *)base;
-    PinnedRange *oldest = &gPinned[0];
-    for (PinnedRange &r : gPinned)
-    {
-        if (r.base && p >= r.base && p + bytes <= r.base + r.bytes)
-        {
-            r.stamp = ++gPinStamp;
-            return;
-        }
-        if (r.stamp < oldest->stamp)
-            oldest = &r;
-    }
-    if (oldest->base && oldest->ours)
-        (void)hipHostUnregister(oldest->base);
-    *oldest = PinnedRange();
-    /* (a failure is not the frame's failure: the copy goes through the runtime's staging buffers as it used to) */
-    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
-    (void)hipGetLastError();
-    oldest->base = p;
-    oldest->bytes = bytes;
-    oldest->ours = (e == hipSuccess);
-    oldest->stamp = ++gPinStamp;
-}
-
 static void d2hBitmapOne(const SceneInfo &sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds, bool wait)
 {
     if (!ready("d2h_bitmap"))
@@ -3366,11 +3312,6 @@ static void d2hBitmapOne(const SceneInfo &sceneInfo, BitmapBuffer *bitmap, Primi
     /* the frame rendered last: its buffer set, on its stream */
     const hipStream_t stream = flightStream(g.current);
     const void *src = g.boundBitmap ? g.boundBitmap : flightBitmap(g.current).ptr;
-    const size_t framePixels = (size_t)sceneInfo.size.x * (size_t)sceneInfo.size.y;
-    if (bitmap && src)
-        pinHostArray(bitmap, framePixels * SOLR_COLOR_DEPTH);
-    if (primitivesXYIds && flightIds(g.current).ptr)
-        pinHostArray(primitivesXYIds, framePixels * sizeof(PrimitiveXYIdBuffer));
     if (bitmap && src)
         HIPCHECK(hipMemcpyAsync(bitmap + offset * SOLR_COLOR_DEPTH, src, pixels * SOLR_COLOR_DEPTH,
                                 hipMemcpyDeviceToHost, stream));
@@ -3974,7 +3915,6 @@ void initialize_scene(vec2i occupancyParameters, SceneInfo sceneInfo, int, int, 
 {
     if (solr_hip_last_error(nullptr, 0) != 0)
         return;
-    unpinHostArrays();
     int asked = occupancyParameters.x < 1 ? 1 : occupancyParameters.x;
     if (asked > SOLR_MAX_GPU_COUNT)
         asked = SOLR_MAX_GPU_COUNT; /* CudaRayTracer.cu:1415-1416 */
@@ -4035,7 +3975,6 @@ void finalize_scene(vec2i)
     /* every engine that is up, whatever occupancyParameters says by now; afterwards the process is a one-device
      * process again until initialize_scene says otherwise */
     const bool several = gDevices > 1;
-    unpinHostArrays();
     for (int d = 0; d < SOLR_MAX_GPU_COUNT; ++d)
         if (gEngines[d] && gEngines[d]->initialized)
         {
@@ -4055,7 +3994,6 @@ void reshape_scene(vec2i occupancyParameters, SceneInfo sceneInfo)
 {
     if (!sameOccupancy(occupancyParameters, "reshape_scene"))
         return;
-    unpinHostArrays(); /* (the host re-makes its frame arrays around this call) */
     splitRows(sceneInfo.size.y);
     onEveryDevice([&](int) { reshapeOne(sceneInfo); });
 }

@@ -12,8 +12,9 @@ def _light(k, pos=(6000.0, 7000.0, -9000.0), intensity=2.0):
     return S.add_light(k, position=pos, intensity=intensity)
 
 
-def primitives_mix(k, width=96, height=64, iterations=3, **info):
-    """Every primitive type the walks dispatch on, plus the material switches they look at."""
+def primitives_mix(k, width=96, height=64, iterations=3, lamps=2, **info):
+    """Every primitive type the walks dispatch on, plus the material switches they look at.  lamps=1: without the second
+    lamp (the lamp loop of primitiveShader differs between the reference's two engines only when there are several)."""
     rng = S.LCG(7)
     k.initialize(width=width, height=height, nbRayIterations=iterations, **info)
     plain = k.add_material(0.7, 0.3, 0.2, specValue=0.5, specPower=50.0)
@@ -48,7 +49,8 @@ def primitives_mix(k, width=96, height=64, iterations=3, **info):
     k.add_primitive(solr.ptXZPlane, (0, 6000, 3000), size=(9000, 0, 6000), material=wire1)
     k.add_primitive(solr.ptCheckboard, (0, -4500, 2000), size=(9000, 0, 7000), material=noisy)
     _light(k)
-    _light(k, pos=(-7000.0, 5000.0, -6000.0), intensity=1.0)
+    if lamps > 1:
+        _light(k, pos=(-7000.0, 5000.0, -6000.0), intensity=1.0)
     k.compact_boxes(True)
     k.set_camera((200.0, 300.0, -14000.0), look_at=(0.0, 0.0, 0.0), angles=(0.05, -0.1, 0.02))
     return k
@@ -97,11 +99,11 @@ def textured(k, width=96, height=64, iterations=2, skybox=True, **info):
     return k
 
 
-def triangles_only(k, width=80, height=60, iterations=2, **info):
-    """Small height field: the all-triangle code path (extendedGeometry may be switched off)."""
+def triangles_only(k, width=80, height=60, iterations=2, n=6, dim=1.0, **info):
+    """Small height field: the all-triangle code path (extendedGeometry may be switched off).  n=7: 98 triangles and the
+    lamp - BASELINE configs[2] in small; dim < 1: darker materials, no pixel's colour leaves [0, 1]."""
     k.initialize(width=width, height=height, nbRayIterations=iterations, **info)
-    n = 6
-    m = [k.add_material(0.3 + 0.1 * i, 0.5, 0.8 - 0.1 * i, reflection=0.3 * (i % 2)) for i in range(4)]
+    m = [k.add_material(dim * (0.3 + 0.1 * i), dim * 0.5, dim * (0.8 - 0.1 * i), reflection=0.3 * (i % 2)) for i in range(4)]
     def pt(i, j):
         return ((i / n - 0.5) * 9000.0, 900.0 * math.sin(1.7 * i) * math.cos(1.3 * j) - 1500.0, (j / n - 0.5) * 9000.0)
     for i in range(n):
@@ -143,11 +145,12 @@ def layered_terrain(k, n=36, layers=3, gap=40.0, width=160, height=120, iteratio
     return k
 
 
-def sticks(k, width=80, height=60, iterations=2, **info):
-    """Molecule-like: spheres joined by cylinders."""
+def sticks(k, width=80, height=60, iterations=2, backdrop=False, dim=1.0, **info):
+    """Molecule-like: spheres joined by cylinders.  backdrop: a wall behind them, so that no camera ray misses; dim < 1:
+    darker materials with a smaller highlight, so that no pixel's colour leaves [0, 1] (BASELINE configs[3] in small)."""
     rng = S.LCG(99)
     k.initialize(width=width, height=height, nbRayIterations=iterations, **info)
-    mats = [k.add_material(*S._wall_color(rng), specValue=0.8, specPower=100.0) for _ in range(6)]
+    mats = [k.add_material(*[dim * c for c in S._wall_color(rng)], specValue=0.8 * dim, specPower=100.0) for _ in range(6)]
     prev = None
     for a in range(40):
         p = (3500.0 * math.cos(0.5 * a) + rng.uniform(-200, 200), -3000.0 + 150.0 * a, 3500.0 * math.sin(0.5 * a))
@@ -155,6 +158,9 @@ def sticks(k, width=80, height=60, iterations=2, **info):
         if prev:
             k.add_primitive(solr.ptCylinder, prev, p, size=(80.0, 0, 0), material=mats[(a + 1) % 6])
         prev = p
+    if backdrop:
+        k.add_primitive(solr.ptXYPlane, (0, 0, 9000), size=(30000, 30000, 0),
+                        material=k.add_material(0.3 * dim, 0.35 * dim, 0.4 * dim, specValue=0.1, specPower=50.0))
     _light(k, pos=(-5000.0, 5000.0, -15000.0))
     k.compact_boxes(True)
     k.set_camera((0.0, 0.0, -14000.0))

@@ -900,6 +900,46 @@ def test_frames_in_flight_through_the_frame_protocol(solr, flights):
         k.finalize()
 
 
+@pytest.mark.gpu
+def test_run_kernel_delivers_into_the_callers_array_and_getbitmap_follows(solr):
+    """SolR_RunKernel (SolRStub.cpp:154-164: render, copy to m_bitmap, copy m_bitmap to the caller) delivers the device's
+    image straight into the caller's array; m_bitmap - what getBitmap / SolRx_GetBitmap return - is brought up to date
+    when somebody asks.  Same bytes in both as the two-step protocol gives, frame after frame, through a reshape, and
+    when the device goes away with the newest image only in the caller's hands."""
+    import ctypes as C
+    W, H = 200, 136
+    k = solr.Kernel(engine="hip")
+    solr.scenes.cornell(k, width=W, height=H, iterations=2)
+    L = k.L
+
+    def bitmap(w, h):
+        ptr = L.SolRx_GetBitmap()
+        return np.frombuffer((C.c_ubyte * (w * h * 3)).from_address(ptr), np.uint8).reshape(h, w, 3).copy()
+
+    try:
+        for i in range(4):
+            k.set_camera((250.0 * i, 0.0, -15000.0))
+            assert L.SolRx_Render(0.0) == 0
+            two_steps = bitmap(W, H)
+            caller = np.full((H, W, 3), 7, np.uint8)
+            assert L.SolR_RunKernel(0.0, caller.ctypes.data) == 0
+            assert np.array_equal(caller, two_steps), i
+            if i % 2:                        # asked at once, or only after the next frame
+                assert np.array_equal(bitmap(W, H), two_steps), i
+        assert two_steps.any()
+        # the caller holds the only copy when the device is released: m_bitmap is fetched before it goes
+        k.set_camera((900.0, 0.0, -15000.0))
+        caller = np.zeros((H, W, 3), np.uint8)
+        assert L.SolR_RunKernel(0.0, caller.ctypes.data) == 0
+        assert not np.array_equal(caller, two_steps)
+        k.L.SolRx_SetGpuCount(1)             # (a no-op for one device; getBitmap below is what fetches)
+        assert np.array_equal(bitmap(W, H), caller)
+        assert L.SolR_RunKernel(0.0, None) == -1
+        k.check(0, "SolR_RunKernel")
+    finally:
+        k.finalize()
+
+
 def test_deep_bounces_keep_three_stack_slots_in_lds_and_the_rest_in_hbm(solr, oracle):
     """A frame that may bounce more than SOLR_LDS_STACK_SLOTS = 3 times (ten here: what every accumulation pass asks for)
     used to size the per-lane colour stack in LDS for it - 67 dwords, nine waves per CU.  The lean kernels now have an
@@ -920,6 +960,13 @@ def test_deep_bounces_keep_three_stack_slots_in_lds_and_the_rest_in_hbm(solr, or
         hip.solr_hip_set_variant(0)
         assert np.array_equal(frame[0].view(np.uint32), whole[0].view(np.uint32))
         assert np.array_equal(frame[1], whole[1]) and np.array_equal(frame[2], whole[2])
+        # the deep slots are never zeroed: with NaNs in all of them before the launch (variant 10) the frame is the same -
+        # no lane reads a slot the frame has not written
+        hip.solr_hip_set_variant(10)
+        poisoned = [np.array(a, copy=True) for a in gpu_frame(k)]
+        hip.solr_hip_set_variant(0)
+        assert np.array_equal(frame[0].view(np.uint32), poisoned[0].view(np.uint32))
+        assert np.array_equal(frame[1], poisoned[1]) and np.array_equal(frame[2], poisoned[2])
         # two frames in flight: every buffer set has deep slots of its own
         hip.solr_hip_set_frames_in_flight(2)
         for i in range(6):

@@ -22,7 +22,10 @@ solr = importlib.import_module("sol-r_amd")
 from oracle import loader
 from helpers import assert_frame_pinned, gpu_frame
 out = {}
+# (ten bounces: the lean rows answer with their F_STACK instantiation - three colour-stack slots in LDS, the deeper ones
+# in HBM - the other rows with the whole stack in LDS)
 for name, build, kw in (("cornell", solr.scenes.cornell, dict(width=96, height=64, iterations=3)),
+                        ("cornell, ten bounces", solr.scenes.cornell, dict(width=96, height=64, iterations=10)),
                         ("molecule", solr.scenes.molecule, dict(atoms=400, width=96, height=64))):
     k = solr.Kernel(engine="hip")
     build(k, **kw)
