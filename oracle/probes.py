@@ -438,7 +438,7 @@ SCENES = {
     # BASELINE configs[2] / [3] in small, shaped so that none of the statements in which the reference's two engines
     # differ shows on (nearly) any pixel: one lamp, nothing transparent or emissive in view, a pass below 10, colours
     # inside [0, 1] (no final saturate), a backdrop behind the sticks (no ray misses: the depth word of a miss)
-    "mesh_100": lambda: SceneData(_extra().triangles_only, n=7, dim=0.6),
+    "mesh_100": lambda: SceneData(_extra().triangles_only, n=7, dim=0.6, backdrop=True),
     "sticks_backdrop": lambda: SceneData(_extra().sticks, backdrop=True, dim=0.6),
     # every primitive type under ONE lamp (the lamp loop differs only with several)
     "mix_one_lamp": lambda: SceneData(_extra().primitives_mix, width=96, height=64, lamps=1),

@@ -26,7 +26,7 @@ def primitives_mix(k, width=96, height=64, iterations=3, lamps=2, **info):
     wire2 = k.add_material(0.2, 1.0, 1.0, wireframe=True, wireframeWidth=30)
     fast = k.add_material(0.8, 0.2, 0.8, transparency=0.5, refraction=1.0, fastTransparency=True)
     noisy = k.add_material(0.6, 0.6, 0.6, noise=0.02)
-    glow = k.add_material(1.0, 0.9, 0.6, innerIllumination=0.4)
+    glow = k.add_material(1.0, 0.9, 0.6, innerIllumination=0.4 if lamps > 1 else 0.0)   # (an emissive wall is a lamp too)
     k.add_primitive(solr.ptSphere, (-3000, 500, 0), size=(1500, 0, 0), material=mirror)
     k.add_primitive(solr.ptSphere, (800, -500, -2500), size=(1100, 0, 0), material=glass)
     k.add_primitive(solr.ptSphere, (3200, 900, 500), size=(1300, 0, 0), material=proc)
@@ -48,7 +48,7 @@ def primitives_mix(k, width=96, height=64, iterations=3, lamps=2, **info):
     k.add_primitive(solr.ptYZPlane, (9000, 0, 3000), size=(0, 6000, 6000), material=glow)
     k.add_primitive(solr.ptXZPlane, (0, 6000, 3000), size=(9000, 0, 6000), material=wire1)
     k.add_primitive(solr.ptCheckboard, (0, -4500, 2000), size=(9000, 0, 7000), material=noisy)
-    _light(k)
+    _light(k, intensity=2.0 if lamps > 1 else 0.8)
     if lamps > 1:
         _light(k, pos=(-7000.0, 5000.0, -6000.0), intensity=1.0)
     k.compact_boxes(True)
@@ -99,7 +99,7 @@ def textured(k, width=96, height=64, iterations=2, skybox=True, **info):
     return k
 
 
-def triangles_only(k, width=80, height=60, iterations=2, n=6, dim=1.0, **info):
+def triangles_only(k, width=80, height=60, iterations=2, n=6, dim=1.0, backdrop=False, **info):
     """Small height field: the all-triangle code path (extendedGeometry may be switched off).  n=7: 98 triangles and the
     lamp - BASELINE configs[2] in small; dim < 1: darker materials, no pixel's colour leaves [0, 1]."""
     k.initialize(width=width, height=height, nbRayIterations=iterations, **info)
@@ -112,6 +112,10 @@ def triangles_only(k, width=80, height=60, iterations=2, n=6, dim=1.0, **info):
             t = k.add_primitive(solr.ptTriangle, a, b, c, material=m[(i + j) % 4])
             k.set_normals(t, (0, 1, 0), (0.2, 1, 0), (0.2, 1, 0.2))
             k.add_primitive(solr.ptTriangle, a, c, d, material=m[(i + j) % 4])
+    if backdrop:   # (two triangles: no camera ray misses, and the frame stays with the lean kernel of triangles)
+        wall = k.add_material(0.3 * dim, 0.35 * dim, 0.4 * dim)
+        k.add_primitive(solr.ptTriangle, (-40000, -30000, 9000), (40000, -30000, 9000), (40000, 40000, 9000), material=wall)
+        k.add_primitive(solr.ptTriangle, (-40000, -30000, 9000), (40000, 40000, 9000), (-40000, 40000, 9000), material=wall)
     lm = k.add_material(1, 1, 1, innerIllumination=2.0)
     k.add_primitive(solr.ptTriangle, (5000, 6000, -5000), (5300, 6000, -5000), (5000, 6300, -5000), material=lm)
     k.compact_boxes(True)
@@ -158,8 +162,8 @@ def sticks(k, width=80, height=60, iterations=2, backdrop=False, dim=1.0, **info
         if prev:
             k.add_primitive(solr.ptCylinder, prev, p, size=(80.0, 0, 0), material=mats[(a + 1) % 6])
         prev = p
-    if backdrop:
-        k.add_primitive(solr.ptXYPlane, (0, 0, 9000), size=(30000, 30000, 0),
+    if backdrop:   # (a sphere: the frame stays with the lean kernel of spheres + cylinders)
+        k.add_primitive(solr.ptSphere, (0, 0, 40000), size=(30000, 0, 0),
                         material=k.add_material(0.3 * dim, 0.35 * dim, 0.4 * dim, specValue=0.1, specPower=50.0))
     _light(k, pos=(-5000.0, 5000.0, -15000.0))
     k.compact_boxes(True)

@@ -61,6 +61,24 @@ __global__ __launch_bounds__(64) void read_linear_16_bytes_per_lane(const int4 *
     if (v.x + v.y + v.z + v.w == 0x7fffffff)
         sink[0] = 1;
 }
+// the walks' node records (rt_device.h: one s_load_dwordx8 of a 32-B record per node, the index wave-uniform): 64
+// dependent scalar loads a wave, at pseudo-random places of a 265 MB table (every load a line nobody else has fetched)
+__global__ __launch_bounds__(64) void read_scalar_32_byte_records(const float4 *__restrict__ table, int *__restrict__ sink)
+{
+    const unsigned records = (unsigned)((size_t)W * H);   // 32-B records in the table
+    unsigned at = __builtin_amdgcn_readfirstlane(blockIdx.x * 2654435761u);
+    float acc = 0.f;
+    for (int i = 0; i < 64; ++i)
+    {
+        at = (at * 1664525u + 1013904223u);
+        const unsigned r = __builtin_amdgcn_readfirstlane(at % records);
+        const float4 a = table[2 * (size_t)r], b = table[2 * (size_t)r + 1];
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+        at += (unsigned)__builtin_amdgcn_readfirstlane((int)(acc == 12345.f)); // (the next index depends on the load)
+    }
+    if (acc == 54321.f)
+        sink[0] = 1;
+}
 // the stores of a pass: ids (16 B), the record (2 x 16 B), the RGB image (3 single bytes per lane)
 __global__ __launch_bounds__(64) void write_ids_pp_rgb_per_pixel(int4 *__restrict__ ids, Record *__restrict__ pp,
                                                                 unsigned char *__restrict__ rgb, float seed)
@@ -101,6 +119,8 @@ int main()
         hipLaunchKernelGGL(read_depth_4_of_32_bytes, grid, block, 0, 0, pp, sink);
         CHECK(hipMemset(flush, round + 3, flushBytes));
         hipLaunchKernelGGL(read_linear_16_bytes_per_lane, grid, block, 0, 0, ids, sink);
+        CHECK(hipMemset(flush, round + 5, flushBytes));
+        hipLaunchKernelGGL(read_scalar_32_byte_records, dim3(32768), block, 0, 0, (const float4 *)pp, sink);
         CHECK(hipMemset(flush, round + 4, flushBytes));
         hipLaunchKernelGGL(write_ids_pp_rgb_per_pixel, grid, block, 0, 0, ids, pp, rgb, (float)round);
         CHECK(hipDeviceSynchronize());

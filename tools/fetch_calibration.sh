@@ -16,7 +16,7 @@ import sys, glob, csv, collections
 out = sys.argv[1]
 known = {"read_ids_int4_per_pixel": 3840 * 2160 * 16, "read_pp_two_float4_per_pixel": 3840 * 2160 * 32,
          "read_depth_4_of_32_bytes": 3840 * 2160 * 32, "read_linear_16_bytes_per_lane": 3840 * 2160 * 16,
-         "write_ids_pp_rgb_per_pixel": 3840 * 2160 * 51}
+         "read_scalar_32_byte_records": 32768 * 64 * 32, "write_ids_pp_rgb_per_pixel": 3840 * 2160 * 51}
 agg = collections.defaultdict(list)
 for f in glob.glob(out + "/calib_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
