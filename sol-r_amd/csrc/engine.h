@@ -1,6 +1,6 @@
 /*
  * engine.h - the state of the MI355X rendering engine and the helpers every part of its host side uses: what
- * solr_hip.hip (scene upload, list builders, the renderer's launch, the boundary), solr_image_ring.hip (the pipelined
+ * solr_hip.hip (the boundary), solr_scene.hip (scene upload, list builders), solr_launch.hip (the renderer's launch), solr_diag.hip (knobs and diagnostics), solr_image_ring.hip (the pipelined
  * read-back), solr_rccl.hip (strips, communicator, gather, halo) and solr_post.hip (the post-processing kernels) share.
  * One Engine per device this process renders on; `g` is the engine a function works on.  gfx950 only.
  */
@@ -449,11 +449,33 @@ inline int stripRows()
 
 
 /* ---- what the parts ask of each other (defined in the file named) ---------------------------------------------------- */
-/* solr_hip.hip */
+/* solr_scene.hip: the resident scene - uploads (one engine's share of the boundary's h2d_* calls), its lists, rotation */
+void h2dSceneOne(BoundingBox *boundingBoxes, int nbActiveBoxes, Primitive *primitives, int nbPrimitives, Lamp *lamps, int nbLamps);
+void h2dMaterialsOne(Material *materials, int nbActiveMaterials);
+void h2dRandomsOne(float *randoms);
+void h2dRandomsSizedOne(const float *randoms, long count);
+void h2dTexturesOne(int activeTextures, TextureInfo *textureInfos);
+void h2dLightInformationOne(LightInformation *lightInformation, int lightInformationSize);
+void setMovableOne(const unsigned char *flags, int nbPrimitives);
+bool canRotateOne(const float center[3], const float cosAngles[3], const float sinAngles[3], float viewDistance);
+int rotatePrimitivesOne(const float center[3], const float cosAngles[3], const float sinAngles[3], float viewDistance);
+void checkTextureTables();
+void maybeBuildOrderFreeLists();
+void flushGeometry();
+void refreshExactList();
+void dropFreeStage(bool originToo);
+bool orderFreeListsUsable();
+bool shortRayListsChoice();
+SceneArgs makeScene(bool exactNodes);
+int tightListsFor(const SceneArgs &S, const SceneInfo &sceneInfo, bool exactNodes);
+/* solr_launch.hip: a frame - buffers, the launch, post-processing, read-back */
 void allocateFrame();
+int neededFeatures(const SceneInfo &sceneInfo, bool full);
 void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProcessingInfo &ppInfo, const float origin[3],
                 const float direction[3], const float angles[4], bool counting, unsigned long long counts[8]);
 void collectEvents();
+void d2hBitmapOne(const SceneInfo &sceneInfo, BitmapBuffer *bitmap, PrimitiveXYIdBuffer *primitivesXYIds, bool wait);
+void d2hBitmapWait();
 /* solr_image_ring.hip: the ring of page-locked host images behind solr_hip_d2h_image_async */
 void releaseImageRing();
 void ensureCopyStream();
@@ -466,6 +488,23 @@ int agreedHaloRows(const PostProcessingInfo &ppInfo);
 void exchangeDepthHalo(int flight, hipStream_t stream, const PixelRecord *pp, int W, int firstRow, int nbRows, int frameRows,
                        int wanted, DepthHalo *halo);
 bool shareRandoms(); /* every rank takes rank 0's seed for the random sequence (solr_hip_comm_shared_seed) */
+
+/* A frame with the ambient-occlusion post-process on a rank of a communicator owes its neighbours the boundary rows
+ * of its strip, whatever becomes of the frame on this rank: when renderImpl leaves before it got there (an argument
+ * check, an error state, a strip it holds no row of), the exchange is posted with zeros on the way out. */
+struct HaloDebt
+{
+    bool owed = false;
+    int wanted = 0, width = 0, frameRows = 0;
+    ~HaloDebt()
+    {
+        if (owed)
+            exchangeDepthHalo(g.current, flightStream(g.current), nullptr, width, 0, 0, frameRows, wanted, nullptr);
+    }
+};
+/* solr_launch.hip: the neighbourhood post-processing of a frame (also what the test-only solr_hip_probe_postprocess runs) */
+void launchPostProcess(const SceneInfo &sceneInfo, const PostProcessingInfo &ppInfo, int flight, hipStream_t stream, int firstRow,
+                       int nbRows, unsigned char *bitmap, HaloDebt &debt);
 } // namespace solreng
 
 /* solr_post.hip: the post-processing kernels of cudaRender (CRT:1057-1358) and the tile sort, behind plain launchers */

@@ -23,6 +23,6 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
                                     std::vector<float4> &outRows, std::vector<int> &outStart, std::vector<int> &outOrigin,
                                     int *nbPruned, hipStream_t stream, SolrDeviceLists *stay = nullptr);
 
-/* pruneInnerNodes' decisions (solr_hip.hip) for a nested node list: keep[i] = 0 for the inner nodes that are left
+/* pruneInnerNodes' decisions (solr_scene.hip) for a nested node list: keep[i] = 0 for the inner nodes that are left
  * out.  Returns how many, or -1 when left to the host. */
 int solrPruneDecisionsOnDevice(const float4 *rows, int n, double threshold, std::vector<char> &keep, hipStream_t stream);

@@ -1,5 +1,5 @@
 /*
- * renderer.h - what the host side of the engine (solr_hip.hip) and the translation units that hold the renderer's
+ * renderer.h - what the host side of the engine (solr_launch.hip) and the translation units that hold the renderer's
  * instantiations (the files under csrc/rows) share: the frame's arguments, the kernel's signature, and one look-up per row of
  * renderImpl's table.  The kernel template itself is renderer_kernel.h, included by the row files only - so that an
  * experiment on one instantiation rebuilds one object (make -j: eight objects side by side instead of one 70-second

@@ -1019,7 +1019,7 @@ SOLR_DEV int waveMinInt(int v)
 
 /* ---- the walk's own ceiling ("achieved Mrays/s vs a measured empty-traversal upper bound") ----------
  * A frame rendered with COUNT == 2 leaves, per workgroup, a record of every walk its wave made: which list, and per
- * lane the ray, the cut-off and when the lane dropped out.  k_walkBound (solr_hip.hip) then replays the frame's walks
+ * lane the ray, the cut-off and when the lane dropped out.  k_walkBound (renderer_kernel.h; solr_diag.hip) then replays the frame's walks
  * with NOTHING BUT THE NODE LOOP: the same waves, the same 64 rays together, the same lists, advanceTidy and nothing
  * else - no leaf record, no primitive test, no shading, no camera, no frame buffer.  Shadow walks replay exactly (their
  * cut-off is constant, and a lane leaves after the leaf visit it left after in the frame); a closest-hit walk is
@@ -1103,7 +1103,7 @@ SOLR_DEV PrimRec leafPrimitive(const Scene &S, const SceneInfo &si, const Row4 &
     return r;
 }
 
-/* Instantiations without F_TRI are only launched with extended geometry (solr_hip.hip, the choice of the
+/* Instantiations without F_TRI are only launched with extended geometry (solr_launch.hip, the choice of the
  * instantiation): there the flag is a compile-time fact. */
 template <int FEAT>
 SOLR_DEV bool extendedGeometry(const SceneInfo &si)
@@ -1529,7 +1529,7 @@ SOLR_DEV bool longRay(v3 d)
  * leaves and made six plane tests (two divisions each) to find the one wall it can reach: 19 leaf entries per pixel,
  * 15 of them walls.  A test that misses has no effect on a walk (what the order-free cut-off already relies on), so a
  * leaf need only be entered by the rays that can HIT one of its primitives.  Behind the walk-order list and the
- * order-free lists lies a copy of their node rows (solr_hip.hip tightenList) in which a leaf that holds nothing but
+ * order-free lists lies a copy of their node rows (solr_scene.hip tightenList) in which a leaf that holds nothing but
  * plain axis planes (KIND_PLANE_*: the test is `(front || rear) && |I.u - p0.u| < size.u && |I.v - p0.v| < size.v`,
  * GI:424-567) is the planes' rectangle, a margin m thick and m wider, cut with the reference's box; inner nodes are the
  * unions of their leaves.  A ray that hits such a plane crosses the rectangle's plane at t* > 0 inside the rectangle,
@@ -1569,7 +1569,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
     const bool fastBoxes = S.orderedBoxes && (ballot(active && !finiteRay(r)) == 0ull);
     const bool showBoxes = (FEAT & F_FULL) && si.renderBoxes != 0;
     const bool tidy = COUNT != 1 && fastBoxes && S.nested && !showBoxes;
-    /* The order-free list (solr_hip.hip, buildFreeOrderList): the same leaves under a hierarchy of our own, in an
+    /* The order-free list (solr_scene.hip, buildFreeOrderLists): the same leaves under a hierarchy of our own, in an
      * order of our own.  The reference's result does not depend on the order in which the leaves are visited when
      * (a) ties go to the smaller flattened index - the primitive the reference visits first - and (b) the cut-off
      * `slab parameter < closest distance so far` never hides a nearer hit: the parameter is in units of the
@@ -1620,7 +1620,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
      * in every accept). */
     constexpr bool CHECKED_BUILD = COUNT != 1 && (FEAT & F_DEEP) != 0 && (FEAT & F_TRI) != 0;
     const float dd = dot(r.d, r.d);
-    /* (S.shortRayLists: the host's choice, solr_hip.hip - the repeated lanes lengthen a frame's longest tiles, so a frame
+    /* (S.shortRayLists: the host's choice, solr_scene.hip shortRayListsChoice - the repeated lanes lengthen a frame's longest tiles, so a frame
      * that is as long as its longest tile keeps the reference's order for such rays; either way the same bits.  Rays
      * within rounding of length 1 need no more than the rounding margins and always qualify.) */
     const float shortest = S.shortRayLists ? 0.25f : 0.9998f;

@@ -157,7 +157,7 @@ struct SceneArgs
     int opaqueShadows; /* no primitive is transparent or a textured plane: any occluder saturates a shadow */
     int shortRayLists; /* bounce rays (shorter than 1) take the order-free lists, checked (rt_device.h closestHitWalk) */
     /* behind the walk-order list and behind the eight order-free lists lies a copy of their node rows in which every
-     * leaf that holds nothing but plain axis planes is as thin as its planes (solr_hip.hip tightenList): long rays with
+     * leaf that holds nothing but plain axis planes is as thin as its planes (solr_scene.hip tightenList): long rays with
      * no zero direction component walk the copy (rt_device.h tightRay) */
     int tightLists;
 };

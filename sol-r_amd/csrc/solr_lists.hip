@@ -1,5 +1,5 @@
 /*
- * solr_lists.hip - the order-free node lists (solr_hip.hip, buildFreeOrderLists) built on the device.
+ * solr_lists.hip - the order-free node lists (solr_scene.hip, buildFreeOrderLists) built on the device.
  *
  * What is built is the engine's own hierarchy over the reference's leaves, not anything of the reference's: a
  * binary surface-area tree (binned SAH, sixteen bins, over the leaf boxes' centres), the inner nodes that hardly
@@ -349,7 +349,7 @@ __device__ inline double areaOf(const float *lo, const float *hi)
     return x * y + y * z + z * x;
 }
 
-/* the host's cost loop (solr_hip.hip buildFreeOrderLists), one thread per open node */
+/* the host's cost loop (solr_scene.hip buildFreeOrderLists), one thread per open node */
 __global__ void k_split(Node *nodes, const BinSet *bins, int levelFirst, int count, int nextFree, int *splitting)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -476,7 +476,7 @@ __global__ void k_scatter(const Node *nodes, const int *nodeOf, const int *order
     orderOut[to] = order[i];
 }
 
-/* Which inner nodes stay (solr_hip.hip pruneInnerNodes on the octant-0 flattening): one workgroup per node of the
+/* Which inner nodes stay (solr_scene.hip pruneInnerNodes on the octant-0 flattening): one workgroup per node of the
  * level, top-down, so that the nearest kept ancestor is known.  The leaves of a node in octant-0 order are the
  * positions [from, to) of the final leaf order. */
 __global__ __launch_bounds__(256) void k_prune(Node *nodes, const int *order, const float *llo, const float *lhi, int levelFirst,
@@ -802,7 +802,7 @@ int solrBuildOrderFreeListsOnDevice(const float4 *rows, const int *start, const 
 }
 
 
-/* ---- pruneInnerNodes' decisions for a node list with skip pointers (solr_hip.hip), on the device ------------------------
+/* ---- pruneInnerNodes' decisions for a node list with skip pointers (solr_scene.hip), on the device ------------------------
  * The host walks the list once and, for every inner node, samples up to 8 000 leaf centres of its nearest kept
  * ancestor: 13 + 8 ms of h2d_scene for the 100k-primitive scenes.  The decisions of one depth of the list are
  * independent of each other once the depths above are decided, so: parents and depths on the host (one pass with a

@@ -2,7 +2,7 @@
  * solr_post.hip - the kernels that run behind the renderer: the stand-alone float -> RGB8 conversion (k_default), the five
  * post-processing effects of cudaRender's switch (CudaRayTracer.cu:1057-1358), the sort of the tiles by cost for the
  * next frames' launch order, and the packing of a strip's boundary depths for the neighbouring ranks.  The host side
- * (solr_hip.hip, solr_rccl.hip) sees plain launchers (engine.h, namespace solrpost).  gfx950 only.
+ * (solr_launch.hip, solr_rccl.hip) sees plain launchers (engine.h, namespace solrpost).  gfx950 only.
  */
 #include <hip/hip_runtime.h>
 

@@ -18,7 +18,7 @@
 
 using namespace solrdev;
 
-/* solr_hip.hip: the resident scene as renderImpl hands it to the renderer */
+/* solr_diag.hip: the resident scene as renderImpl hands it to the renderer */
 namespace solrprobe
 {
 int residentScene(const SceneInfo &sceneInfo, bool exactNodes, SceneArgs *S, int *features, int *deepList, hipStream_t *stream);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64) void k_probeIntersectionShader(const SceneArgs 
 }
 
 /* ---- which instantiation ----------------------------------------------------------------------------------------
- * The lean instantiations the renderer launches for untextured scenes of the usual primitives (solr_hip.hip,
+ * The lean instantiations the renderer launches for untextured scenes of the usual primitives (solr_launch.hip,
  * renderImpl's table, first four rows, each with the two-bank and the three-bank node loop) and the all-features one
  * that covers everything else here (the renderer has three more textured / special-camera rows between them). */
 constexpr int LEAN[4] = {F_SPHERE | F_PLANE, F_SPHERE | F_TRI, F_SPHERE | F_CYL, F_SPHERE | F_PLANE | F_TRI | F_CYL};

@@ -1,5 +1,5 @@
 """Every instantiation of the renderer kernel on the same scene: the host launches the smallest one that covers a
-scene's primitive types, textures and camera (solr_hip.hip, the `variants` ladder), so a plain scene only ever runs
+scene's primitive types, textures and camera (solr_launch.hip, the `variants` ladder), so a plain scene only ever runs
 the lean ones.  SOLR_HIP_FORCE_FEATURES=mask (read once per process) makes the engine choose as if the scene had
 those features too: the Cornell box and a molecule through each step of the ladder must be the frame the oracle AS
 PINNED renders - ids exact, RGB8 exact, float colour <= 1 ULP but for at most two pixels behind a mis-rounded powf

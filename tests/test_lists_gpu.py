@@ -1,5 +1,5 @@
 """The order-free node lists built on the device (sol-r_amd/csrc/solr_lists.hip) against the host builder
-(solr_hip.hip buildFreeOrderLists): the eight lists - bounds, primitive counts, skip pointers, the inner nodes that
+(solr_scene.hip buildFreeOrderLists): the eight lists - bounds, primitive counts, skip pointers, the inner nodes that
 were left out - must be the host's bit for bit, on BASELINE's scenes at their full size, on scenes whose leaves
 coincide (twins: the split that halves by position, which only a stable partition on both sides makes the same),
 and after the frames rendered from them equal the ones of the reference-order walks (variant 6)."""

@@ -1,5 +1,5 @@
 #!/bin/bash
-# sweep of the grouping knobs of groupSiblings (solr_hip.hip) over the bench scenes: ms per 1080p frame
+# sweep of the grouping knobs of groupSiblings (solr_scene.hip) over the bench scenes: ms per 1080p frame
 for scene in cornell height_field molecule irt_model pdb_molecule swc_morphology; do
   for flat in 2 4 8; do
     for levels in 1 2 3; do
