@@ -110,3 +110,93 @@ def test_operands_do_not_ask_for_fixed_registers(statements):
     """nothing binds an operand to a register by name (register asm variables would bypass the list)"""
     text = open(os.path.join(ROOT, "sol-r_amd", "csrc", "rt_device.h")).read()
     assert not re.search(r"register\s+\w+\s+\w+\s+asm\s*\(", text)
+
+
+# ---- what the COMPILER makes of the statements (a ROCm upgrade must fail here, not in a frame) ------------------------
+ROW = os.path.join(ROOT, "sol-r_amd", "csrc", "rows", "sphere_plane.hip")     # the Cornell box's kernels: both loop forms
+
+
+def _makefile_flags():
+    text = open(os.path.join(ROOT, "sol-r_amd", "Makefile")).read().replace("\\\n", " ")
+    numeric = re.search(r"^NUMERIC\s*=\s*(.*)$", text, re.M).group(1).split()
+    flags = re.search(r"^HIPFLAGS\s*=\s*(.*)$", text, re.M).group(1)
+    flags = flags.replace("$(NUMERIC)", " ".join(numeric)).replace("$(ARCH)", "gfx950")
+    return [f for f in flags.split() if f not in ("-fPIC",)]
+
+
+@pytest.fixture(scope="module")
+def generated(tmp_path_factory):
+    """the device assembly of one row file, built with the Makefile's own flags"""
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = str(tmp_path_factory.mktemp("isa") / "row.s")
+    subprocess.run([HIPCC] + _makefile_flags() + ["--cuda-device-only", "-S", "-o", out, ROW], check=True,
+                   stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernels(text):
+    """{mangled name: body} of the k_standardRenderer instantiations"""
+    out = {}
+    for m in re.finditer(r"^(_Z18k_standardRenderer\w+):\s*;", text, re.M):
+        end = text.index(".Lfunc_end", m.end())
+        out[m.group(1)] = text[m.end():end]
+    return out
+
+
+def _loop_bodies(body):
+    """the instruction lines of every node-loop statement the compiler emitted into a kernel: from the `s_mov_b64 ..., exec`
+    that opens a statement to its LX_ label (the labels carry the statement's unique number)"""
+    loops = []
+    for m in re.finditer(r"^LX_(\d+):", body, re.M):
+        number = m.group(1)
+        first = body.index("LWA_%s:" % number)
+        opening = body.rfind("s_mov_b64 s[", 0, first)
+        lines = [l.strip() for l in body[opening:m.start()].split("\n")]
+        loops.append([l for l in lines if l and not l.startswith(";") and not l.startswith(".") and not l.startswith("//")])
+    return loops
+
+
+def test_the_compiler_emits_every_loop_whole_and_apart(statements, generated):
+    """Each inlined walk has a node loop of its own, emitted verbatim: the same instruction sequence as the template (the
+    operands bound), one per walk and never merged with the other walk's - whatever a later compiler's passes make of two
+    identical `asm volatile` statements.  (The Makefile's -mllvm -simplifycfg-sink-common=false is not about these: that
+    pass merged stores to different fields of a hit record into one store through a selected address and pinned the
+    record in scratch; the scratch check below is what notices it coming back.)"""
+    templates = {}
+    for template, _o, _i, _c in statements:
+        if "s_load_dwordx8" not in template:
+            continue
+        lines = [l.strip() for l in template.split("\n") if l.strip()]
+        lines = lines[:lines.index("LX_%=:")]                    # (as _loop_bodies cuts the generated code)
+        opcodes = [l.split()[0] for l in lines if not l.endswith(":")]
+        templates[len(opcodes)] = opcodes
+    assert len(templates) == 2                                   # the two-bank and the three-bank form
+    kernels = _kernels(generated)
+    assert len(kernels) >= 4, list(kernels)
+    for name, body in kernels.items():
+        loops = _loop_bodies(body)
+        # a closest-hit walk and a shadow walk at least (the census kernels walk without the loop: none)
+        census = "ILi1E" in name
+        assert (len(loops) == 0) if census else (len(loops) >= 2), (name, len(loops))
+        for loop in loops:
+            opcodes = [l.split()[0] for l in loop if not l.endswith(":")]
+            assert len(opcodes) in templates, (name, len(opcodes), sorted(templates))
+            assert opcodes == templates[len(opcodes)], name
+
+
+def test_the_fixed_registers_exist_in_every_kernel(generated):
+    """s64 ... s94 and v58 ... v63 are named by number: a kernel compiled for fewer registers than that (a launch bound, an
+    occupancy attribute) would let the assembler use registers the allocator never reserved"""
+    meta = re.findall(r"\.name:\s+(_Z18k_standardRenderer\w+)\n(?:.*\n)*?\s+\.sgpr_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)",
+                      generated)
+    assert len(meta) >= 4
+    for name, sgprs, vgprs in meta:
+        if "ILi1E" in name:
+            continue
+        assert int(sgprs) >= 95 + 6, (name, sgprs)               # s0 ... s94 and vcc / flat_scratch / xnack
+        assert int(vgprs) >= 64, (name, vgprs)
+    # ... and nothing of the loops went to scratch: the lean kernels hold their state in registers and LDS
+    for name, spill in re.findall(r"\.name:\s+(_Z18k_standardRenderer\w+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", generated):
+        if "ILi0E" in name and "ILi33E" in name:
+            assert int(spill) == 0, (name, spill)
