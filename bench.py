@@ -1036,9 +1036,11 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_taken_at_commit": traffic_commit,
-                     "traffic_note": "read from a committed rocprofv3 --pmc profile of this same command, not measured "
-                                     "by this run (a process cannot profile itself); null when the workload differs "
-                                     "from the profiled one",
+                     "traffic_note": "read from a committed rocprofv3 --pmc profile of this same command (separate FETCH_SIZE / "
+                                     "WRITE_SIZE passes, corrected by the factors measured on known byte counts in the "
+                                     "renderer's own access patterns: profiles/r6/fetch_calibration.txt), not measured by "
+                                     "this run (a process cannot profile itself); null when the workload differs from "
+                                     "the profiled one",
                      "kernel": "k_standardRenderer", "kernel_ms": round(kernel_avg_ms, 5), "kernel_ms_basis": kernel_basis,
                      "kernel_ms_spread": kernel_spread,
                      "algorithmic_bytes": algo_bytes, "algorithmic_bytes_per_pixel": round(per_pixel, 2),
