@@ -20,10 +20,12 @@ the fastest and the slowest region, which bracket it by construction.  At N > 1 
 of each rank's own time from the start barrier to its last delivered frame (the end barrier itself is the control
 plane's - gloo over TCP - and is reported, not charged).
 
-N > 1: row strips re-cut by measured cost (solr_hip_balance_strips), gathered to rank 0 with RCCL called from the
-engine's C ABI on the stream that rendered the frame; the reference's equal split is timed as a second segment, the
-assembled frame is compared with the frame rank 0 renders alone, per-rank times and the gather alone are reported,
-and which communicator mode ran (one for everything, or SOLR_HIP_COMM_PER_FLIGHT=1: one per frame in flight).
+N > 1 (the launcher, the control plane, the communicator, the delivery routes and the sweep over them live in
+bench_dist.py): row strips re-cut by measured cost (solr_hip_balance_strips), gathered to rank 0 with RCCL called from
+the engine's C ABI on the stream that rendered the frame - `value` is always a combination that makes that RCCL call
+behind every frame, on a communicator of exactly --gpus ranks (exit code 5 otherwise); the reference's equal split is
+timed as a second segment, the assembled frame is compared with the frame rank 0 renders alone, per-rank times and the
+gather alone are reported, and which communicator mode ran (one for everything, or one per frame in flight).
 
 Rank 0 prints ONE JSON line.  `value` = (closest-hit walks + shadow walks of the whole
 frame) * steps / the median region's wall time / 1e6, summed over all ranks, max wall time over ranks.
@@ -44,6 +46,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+import bench_dist  # noqa: E402  (the N > 1 side: launcher, control plane, communicator, delivery route, mode sweep)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 PREROLL_FRAMES = 48    # untimed setup frames before the W warmup steps
@@ -119,58 +123,6 @@ def parse():
     return args
 
 
-def launch(args):
-    """`python bench.py --gpus N` started bare: this process becomes the launcher - it never touches the GPU - and
-    starts N fresh rank processes of this same command (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
-    environment, exactly what torch.distributed.run would set).  Rank 0's stdout is relayed (its last line is the
-    JSON line), the other ranks' goes to stderr.  Any rank that ends with an error ends the job: the others get ten
-    seconds, then are killed by pid, and the launcher exits with that rank's code."""
-    import socket
-    import subprocess
-    import threading
-    n = args.gpus
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    share = os.environ.get("SOLR_BENCH_SHARE_GPU") == "1"
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    lines = []
-    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
-    reader.start()
-    deadline = time.time() + float(os.environ.get("SOLR_BENCH_TIMEOUT", "1500"))
-    failed = None
-    while any(p.poll() is None for p in procs):
-        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
-        if bad or time.time() > deadline:
-            failed = bad[0] if bad else (-1, 124)
-            grace = time.time() + 10.0
-            while time.time() < grace and any(p.poll() is None for p in procs):
-                time.sleep(0.1)
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-            break
-        time.sleep(0.05)
-    for p in procs:
-        p.wait()
-    reader.join(timeout=5.0)
-    sys.stdout.write("".join(x.decode(errors="replace") if isinstance(x, bytes) else x for x in lines))
-    sys.stdout.flush()
-    bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
-    if failed or bad:
-        r, code = failed or bad[0]
-        print("bench.py: %s; the job is void" % ("rank %d ended with code %s" % (r, code) if r >= 0 else
-                                                   "no result within SOLR_BENCH_TIMEOUT"), file=sys.stderr)
-        return code if isinstance(code, int) and 0 < code < 256 else 1
-    return 0
-
-
 def spread(samples, divide=1.0, window=1):
     """min / median / max of a list of milliseconds (the error bar of a short timed region).  window > 1: of the mean
     over every run of `window` consecutive samples - with frames in flight the launches end in bursts, and only a run
@@ -190,31 +142,11 @@ def median(xs):
     return xs[len(xs) // 2]
 
 
-def reduce_over_ranks(dist, torch, region_times, second_times, kernel_ms, rays_local, device="cpu"):
-    """What the ranks of an N > 1 job agree on after the timed regions: every region's time is the SLOWEST rank's
-    (MAX over ranks, region by region - the frame is delivered when the last strip is), the kernel time the slowest
-    rank's, the rays the sum.  Returns (region_times, second_times, kernel_ms, rays_total)."""
-    t = torch.tensor(list(region_times) + list(second_times) + [kernel_ms], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    n, m = len(region_times), len(second_times)
-    r = torch.tensor([float(rays_local)], dtype=torch.float64, device=device)
-    dist.all_reduce(r, op=dist.ReduceOp.SUM)
-    return [float(x) for x in t[:n]], [float(x) for x in t[n:n + m]], float(t[-1]), int(r[0])
-
-
-def agree(dist, torch, failed_here, device="cpu"):
-    """True when ANY rank reports a failure: a decision every rank takes alike (e.g. the delivery route when one of
-    them cannot open the shared host image)"""
-    flag = torch.tensor([1.0 if failed_here else 0.0], dtype=torch.float64, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    return float(flag[0]) > 0
-
-
 def main():
     args = parse()
     # bare `python bench.py --gpus N` (no launcher's environment): become the launcher, before anything of the GPU
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch(args))
+        sys.exit(bench_dist.launch(args, __file__))
     cfg4 = args.config == "cfg4"
     if os.environ.get("SOLR_BENCH_DEBUG"):
         import faulthandler
@@ -314,73 +246,11 @@ def main():
 
     rccl_ranks = comm_count = None
     delivery_fallback = None
-    # what is up right now; "collective": the RCCL gather runs behind every frame (False: the strips meet in the one host
-    # image the ranks' processes share and nothing else moves per frame - SOLR_BENCH_COLLECTIVE=0|1 fixes it, else swept)
-    mode = {"per_flight": None, "delivery": None, "collective": os.environ.get("SOLR_BENCH_COLLECTIVE", "1") != "0"}
-
-    def engine_error():
-        buf = C.create_string_buffer(512)
-        hip.solr_hip_last_error(buf, 512)
-        return buf.value.decode(errors="replace")
-
-    def comm_up(per_flight):
-        """(every rank) the communicator - rank 0's id to everybody over the control plane, then ncclCommInitRank in the
-        library - with one communicator for everything or one per frame in flight (None: as the library / the
-        environment says).  False, on every rank alike and with the engine's error cleared, when it did not come up."""
-        if per_flight is not None:
-            hip.solr_hip_comm_set_per_flight(1 if per_flight else 0)
-        uid = C.create_string_buffer(128)
-        fine = not (rank == 0 and hip.solr_hip_comm_unique_id(uid) != 0)
-        box = [uid.raw]
-        dist.broadcast_object_list(box, src=0)
-        uid = C.create_string_buffer(box[0], 128)
-        fine = fine and hip.solr_hip_comm_init(rank, world, uid) == 0
-        if agree(dist, torch, not fine):
-            if rank == 0:
-                print("bench.py: the communicator did not come up (per flight: %s): %s" % (per_flight, engine_error() or
-                                                                                          "on another rank"), file=sys.stderr, flush=True)
-            hip.solr_hip_clear_error()
-            hip.solr_hip_comm_finalize()
-            # nothing is up now: the next configure() must bring a communicator (and a delivery route) up again,
-            # whatever it asks for (ADVICE r5: a stale `False` here let the next combination run without one)
-            mode["per_flight"] = None
-            mode["delivery"] = None
-            return False
-        mode["per_flight"] = int(hip.solr_hip_comm_count()) > 1
-        return True
-
-    def delivery_up(route):
-        """(every rank) 'strips': one host image for all ranks - rank 0 creates the segment, the others open it.  A box
-        that does not let the processes share page-locked memory (no /dev/shm, a registration the driver refuses) must
-        not void the job: all ranks then fall back, together, to rank 0 copying the gathered frame.  Returns the route
-        that is up and, when it is not the one asked for, why."""
-        hip.solr_hip_image_unshare()
-        why = None
-        if route == "strips":
-            name = ("/solr_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getuid())).encode()
-            mine = 0
-            if os.environ.get("SOLR_BENCH_FAIL_SHARE") == "1" and rank == world - 1:
-                name = b"no-leading-slash"          # (tests: the last rank cannot open the segment)
-            if rank == 0:
-                mine = hip.solr_hip_image_share(name, rank, world)
-            dist.barrier()
-            if rank != 0:
-                mine = hip.solr_hip_image_share(name, rank, world)
-            if agree(dist, torch, mine != 0):
-                why = "solr_hip_image_share failed on some rank (%s): --delivery gathered instead" % \
-                    (engine_error() or "on another rank")
-                hip.solr_hip_clear_error()
-                hip.solr_hip_image_unshare()
-                route = "gathered"
-                mode["collective"] = True      # (that route delivers what the gather assembled: no gather, no frame)
-                if rank == 0:
-                    print("bench.py: " + why, file=sys.stderr, flush=True)
-            dist.barrier()
-            # every rank has the segment mapped: its NAME can go (a job that dies later leaves nothing in /dev/shm)
-            hip.solr_hip_image_share_sealed()
-        mode["delivery"] = route
-        return route, why
-
+    # what is up right now (bench_dist.Ranks): mode["collective"] - the RCCL gather runs behind every frame (False: the
+    # strips meet in the one host image the ranks' processes share and nothing else moves per frame -
+    # SOLR_BENCH_COLLECTIVE=0|1 fixes it, else swept; never the headline's)
+    R = bench_dist.Ranks(dist, torch, hip, rank, world, collective=os.environ.get("SOLR_BENCH_COLLECTIVE", "1") != "0")
+    mode, comm_up, delivery_up = R.mode, R.comm_up, R.delivery_up
     alone = None
     sweep_routes = [args.delivery] if args.delivery != "auto" else ["strips", "gathered"]
     env_per_flight = os.environ.get("SOLR_HIP_COMM_PER_FLIGHT")
@@ -644,132 +514,35 @@ def main():
         for _ in range(PREROLL_FRAMES // 2):
             step()
         drain()
-    # ---- N > 1: which communicator mode, which delivery route?  Nobody has run this on eight GPUs: RCCL orders the
-    # operations of ONE communicator whatever streams they are enqueued on (one per frame in flight avoids that, at
-    # the price of four communicators), and the frame can reach the host over every rank's own PCIe link (one shared
-    # host image) or over rank 0's alone (the gathered frame).  So the job times all of them - short segments, the same
-    # loop as the headline - checks each one's delivered frame against the frame rank 0 rendered alone, and runs the
-    # headline on the fastest that passed.  A combination that fails is reported and left out, not fatal.
+    # ---- N > 1: which communicator mode, which delivery route? (bench_dist.mode_sweep: every combination timed in short
+    # segments of this same loop, its frame checked against the one-GPU frame; the headline runs on the fastest that
+    # passed AND makes the RCCL call behind every frame)
     mode_sweep = None
     combos = [(c, r, True) for c in sweep_comms for r in sweep_routes]
     if "strips" in sweep_routes and "SOLR_BENCH_COLLECTIVE" not in os.environ:
         # ... and the strips route with NO collective in the data path: the reference assembles the frame in the host
-        # bitmap and nowhere else (d2h_bitmap, CudaRayTracer.cu:1647-1672); the shared host image is that, and the RCCL
-        # gather behind every frame then only costs (11 us of host work and 8 us of GPU per step on a 136-row strip,
-        # profiles/r4/readback_routes.txt).  The communicator stays up: strips are balanced through it, ambient-occlusion
+        # bitmap and nowhere else (d2h_bitmap, CudaRayTracer.cu:1647-1672); the shared host image is that.  Timed and
+        # reported, never the headline.  The communicator stays up: strips are balanced through it, ambient-occlusion
         # frames trade their boundary rows through it, and the check after the timed regions gathers once.
         combos.append((sweep_comms[0], "strips", False))
     elif not mode["collective"]:
         combos = [(sweep_comms[0], "strips", False)]
     want_sweep = os.environ.get("SOLR_BENCH_SWEEP", "1" if world > 1 else "0") == "1"
     if native and not cfg4 and len(combos) > 1 and want_sweep:
-        import numpy as np
-        mode_sweep = {}
-
-        def configure(per_flight, route, collective):
-            """(every rank) tear down what is up, bring this combination up, re-cut the strips; None or why not"""
-            if mode["per_flight"] != per_flight:
-                sync()
-                barrier()
-                hip.solr_hip_image_unshare()
-                hip.solr_hip_comm_finalize()
-                hip.solr_hip_set_strip(first_row, nb_rows)
-                mode["delivery"] = None
-                if not comm_up(per_flight):
-                    return "the communicator did not come up"
-                if balanced and hip.solr_hip_balance_strips() != 0:
-                    why = engine_error()
-                    hip.solr_hip_clear_error()
-                    return "solr_hip_balance_strips: " + why
-            if mode["delivery"] != route:
-                sync()
-                got, why = delivery_up(route)
-                if got != route:
-                    return why
-            mode["collective"] = collective
-            for _ in range(PREROLL_FRAMES // 2):
-                step()
-            drain()
-            return None
-
-        def label(per_flight, route, collective):
-            if not collective:
-                return "no_collective_strips_over_every_ranks_link"
-            return "%s_%s" % ("communicator_per_flight" if per_flight else "one_communicator",
-                              "strips_over_every_ranks_link" if route == "strips" else "gathered_frame_over_rank0s_link")
-
-        for per_flight, route, collective in combos:
-            name = label(per_flight, route, collective)
-            arm("mode sweep: " + name)
-            entry = {}
-            try:
-                why = configure(per_flight, route, collective)
-                # every rank takes the same way from here: a combination that did not come up on ONE rank is skipped
-                # on all of them (ADVICE r5: the others would wait in timed()'s barriers for a rank that never came)
-                if agree(dist, torch, why is not None):
-                    why = why or "did not come up on another rank"
-                if why:
-                    entry["skipped"] = why
-                else:
-                    seg = timed(args.steps, args.warmup, max(regions // 5, 5))
-                    t = torch.tensor([median(seg["regions"])], dtype=torch.float64)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    entry["ms_per_step"] = round(float(t[0]) / args.steps * 1e3, 5)
-                    same = True
-                    if rank == 0 and alone is not None:
-                        same = seg["last_image"] is not None and bool(np.array_equal(seg["last_image"], alone))
-                    entry["frame_equals_single_gpu"] = not agree(dist, torch, not same)
-                    entry["rccl_communicators"] = int(hip.solr_hip_comm_count())
-                    entry["rccl_calls_per_frame"] = 1 if collective else 0
-            except solr.SolrError as e:            # the engine's error state: reported, cleared, the job goes on
-                entry["error"] = str(e)[:300]
-            failed = agree(dist, torch, "error" in entry)
-            if failed:
-                entry.setdefault("error", "on another rank")
-                hip.solr_hip_clear_error()
-                tickets.clear()
-            mode_sweep[name] = entry
-        usable = {n: e for n, e in mode_sweep.items() if "ms_per_step" in e and e.get("frame_equals_single_gpu") and "error" not in e}
-        if not usable:
-            raise SystemExit("bench.py rank %d: no communicator mode / delivery route delivered the one-GPU frame: %s"
-                             % (rank, json.dumps(mode_sweep)))
-        # The headline runs on the route BASELINE.json's north_star names - "a single RCCL gather over xGMI to assemble
-        # the final image": the fastest combination that makes that RCCL call behind every frame.  The fastest of ALL
-        # of them (which may be the shared host image with no collective per frame) is reported beside it
-        # (rates_mrays_per_s.fastest_combination_of_the_sweep), never as `value`.
-        fastest = min(usable, key=lambda n: usable[n]["ms_per_step"])
-        with_rccl = {n: e for n, e in usable.items() if e.get("rccl_calls_per_frame") == 1}
-        if not with_rccl:
-            raise SystemExit("bench.py rank %d: no combination with the RCCL gather behind every frame delivered the "
-                             "one-GPU frame: %s" % (rank, json.dumps(mode_sweep)))
-        best = min(with_rccl, key=lambda n: with_rccl[n]["ms_per_step"])
-        for per_flight, route, collective in combos:
-            if label(per_flight, route, collective) == best:
-                arm("mode sweep: back to " + best)
-                why = configure(per_flight, route, collective)
-                if agree(dist, torch, why is not None):
-                    raise SystemExit("bench.py rank %d: %s did not come up a second time: %s" % (rank, best, why))
-        mode_sweep["headline_runs_on"] = best
-        mode_sweep["fastest_combination"] = fastest
-        comm_count = int(hip.solr_hip_comm_count())
+        from types import SimpleNamespace
+        loop = SimpleNamespace(step=step, drain=drain, sync=sync, barrier=barrier, timed=timed, tickets=tickets)
+        mode_sweep = bench_dist.mode_sweep(R, loop, combos, steps=args.steps, warmup=args.warmup, regions=regions, alone=alone,
+                                           balanced=balanced, strip=(first_row, nb_rows), arm=arm, engine_failure=solr.SolrError)
         args.delivery = mode["delivery"]
     if native:
         # `value` at N > 1 is the RCCL-gather route, always: the gather behind every frame, on a communicator of
         # exactly --gpus ranks (a job whose communicator has another size, or none, is void: exit code 5)
         if not (os.environ.get("SOLR_BENCH_COLLECTIVE") == "0"):
             mode["collective"] = True
-        if int(hip.solr_hip_comm_count()) < 1 and not comm_up(False):
-            raise SystemExit("bench.py rank %d: no communicator for the headline" % rank)
-        rccl_ranks = int(hip.solr_hip_comm_ranks())
-        comm_count = int(hip.solr_hip_comm_count())
-        if agree(dist, torch, rccl_ranks != world):
-            if rank == 0:
-                print("bench.py: the communicator has %d rank(s), --gpus is %d: the job is void" % (rccl_ranks, world),
-                      file=sys.stderr, flush=True)
-            sys.exit(5)
+        rccl_ranks, comm_count = R.require_communicator()
     arm("the timed regions")
     main_run = timed(args.steps, args.warmup, regions)
-    if native and mode["collective"] and world > 1 and agree(dist, torch, rank == 0 and delivered[0] == 0):
+    if native and mode["collective"] and world > 1 and R.agree(rank == 0 and delivered[0] == 0):
         raise SystemExit("bench.py rank %d: the timed regions delivered no frame to rank 0's host" % rank)
     short_ray_lists = int(hip.solr_hip_short_ray_lists())   # what the engine chose for the delivered frames
     t_issued_ms = main_run["issued"] / args.steps * 1e3
@@ -921,7 +694,7 @@ def main():
     second_times = list(second["regions"]) if second else []
     if distributed:
         # every region's time is the slowest rank's (MAX over ranks, region by region); rays are summed
-        region_times, second_times, kernel_avg_ms, rays_total = reduce_over_ranks(
+        region_times, second_times, kernel_avg_ms, rays_total = bench_dist.reduce_over_ranks(
             dist, torch, region_times, second_times, kernel_avg_ms, rays_local, "cpu" if native else "cuda")
         mine = {"rank": rank, "rows": main_run["strip"], "ms_per_step_until_own_frames_delivered":
                 round(median(main_run["regions"]) / args.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issued_ms, 4),

@@ -207,7 +207,7 @@ def _bench_worker(rank, world, port, out_path):
     import json
     import torch
     import torch.distributed as dist
-    import bench
+    import bench_dist as bench
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
