@@ -380,8 +380,9 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
  * the deeper ones in HBM); 8 = every walk on the reference's own leaf boxes (no thin copies of the leaves that hold
  * plain axis planes, rt_device.h tightRay); 9 = k_ambientOcclusion with a fixed stride of tiles per workgroup instead of
  * the frame's heavy tiles first (solr_post.hip); 10 = the colour-stack slots an F_STACK frame keeps in HBM filled with
- * NaNs before every launch (they are never zeroed: no slot is read before the frame has written it).  Every setting
- * renders the same frame. */
+ * NaNs before every launch (they are never zeroed: no slot is read before the frame has written it); 12 = no walk takes
+ * the copies of the order-free lists with sorted bounds (the node loop without its min / max, rt_device.h
+ * SOLR_ORDER_SORTED).  Every setting renders the same frame. */
 void solr_hip_set_variant(int variant);
 /* Bounce rays (|direction| = 1 - rayEpsilon) of the long-list triangle kernels on the order-free lists, checked: lanes
  * whose hit has a rival the reference's cut-off could have preferred are walked again in the reference's order

@@ -149,6 +149,7 @@ struct Engine
     bool plainPlanes = false;    /* the scene holds a plain axis plane: thin copies are worth making (retagPrimitives) */
     float sceneExtent = 1.f;     /* max |coordinate| + |size| over the primitives, at least 1 */
     bool tightCompact = false, tightFree = false; /* the copy behind that list is up to date */
+    bool sortedFree = false;                      /* the copy of the order-free lists with sorted bounds is up to date */
     /* bounce rays on the order-free lists, checked (rt_device.h closestHitWalk): -1 the engine decides per frame
      * (shortRayListsChoice: with frames in flight), 0 / 1 forced */
     int shortRayListsMode = -1;

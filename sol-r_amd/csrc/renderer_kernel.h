@@ -452,8 +452,12 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_walkBound(const Sce
             W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
             W.nbBoxes = S.nbBoxesFree;
         }
-        if (__builtin_amdgcn_readfirstlane(h.w)) /* the walk took the thin copy of its list (rt_device.h tightRay) */
+        if (__builtin_amdgcn_readfirstlane(h.w) & 1) /* the walk took the thin copy of its list (rt_device.h tightRay) */
             W.offBoxes += __builtin_amdgcn_readfirstlane(h.y) ? 16u * (unsigned)S.nbBoxesFree + 2u : 2u * (unsigned)S.nbBoxes + 2u;
+        /* the form of the node loop the recorded walk took (rt_device.h walkOrder: bits 1-2 of the record's fourth word) */
+        const int order = (FEAT & F_DEEP) ? (__builtin_amdgcn_readfirstlane(h.w) >> 1) & 3 : 0;
+        if (order)
+            W.offBoxes += 32u * (unsigned)S.nbBoxesFree + 4u;
         const PackedRay pr = packRay(r);
         const float cutOff = a.w;
         int cursor = took_part ? 0 : SOLR_CURSOR_DONE;
@@ -464,7 +468,13 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_walkBound(const Sce
                 break;
             int nbPrimitives;
             bool entered;
-            const int leaf = advanceTidy<FEAT>(W, pr, cutOff, cursor, cur, nbPrimitives, entered);
+            int leaf;
+            if ((FEAT & F_DEEP) && order == 1)
+                leaf = advanceTidyDeepSorted(W, pr, cutOff, cursor, cur, nbPrimitives, entered);
+            else if ((FEAT & F_DEEP) && order == 2)
+                leaf = advanceTidyDeepReversed(W, pr, cutOff, cursor, cur, nbPrimitives, entered);
+            else
+                leaf = advanceTidy<FEAT>(W, pr, cutOff, cursor, cur, nbPrimitives, entered);
             if (leaf < 0)
                 break;
             ++visit;

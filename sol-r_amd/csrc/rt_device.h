@@ -1025,7 +1025,8 @@ SOLR_DEV int waveMinInt(int v)
  * cut-off is constant, and a lane leaves after the leaf visit it left after in the frame); a closest-hit walk is
  * replayed with its FINAL cut-off in place from the first node - the fewest nodes any walk that finds that hit can
  * visit.  The replay's time is what the walk structure alone costs this frame: rays / that time is the ceiling.
- * Slot layout: int4 head[SOLR_WALK_SLOTS + 1] (head[0].x = walks recorded; head[1 + j] = {kind, free list?, octant, 0}),
+ * Slot layout: int4 head[SOLR_WALK_SLOTS + 1] (head[0].x = walks recorded; head[1 + j] = {kind, free list?, octant, thin copy? |
+ * form of the node loop << 1}),
  * then float4 lanes[SOLR_WALK_SLOTS][64][2] = {origin.xyz, cut-off} {direction.xyz, bits: leaf visit after which the
  * lane is done, 0x7fffffff never, -1 the lane took no part}. */
 #define SOLR_WALK_SLOTS 16
@@ -1037,7 +1038,7 @@ enum WalkKind
     WALK_GENERAL = 2 /* not through the node loop (a list that is not nested, non-finite rays): not replayed */
 };
 SOLR_DEV void recordWalk(Counters &cnt, int kind, bool freeList, int octant, bool took_part, const WalkRay &r, float cutOff,
-                         int doneAfter, bool tight = false)
+                         int doneAfter, bool tight = false, int order = 0)
 {
     const unsigned j = cnt.ordinal++;
     if (j >= SOLR_WALK_SLOTS || !cnt.record)
@@ -1047,7 +1048,7 @@ SOLR_DEV void recordWalk(Counters &cnt, int kind, bool freeList, int octant, boo
     lanes[0] = make_float4(r.o.x, r.o.y, r.o.z, cutOff);
     lanes[1] = make_float4(r.d.x, r.d.y, r.d.z, __int_as_float(took_part ? doneAfter : -1));
     if (lane == 0)
-        ((int4 *)cnt.record)[1 + j] = make_int4(kind, freeList ? 1 : 0, octant, tight ? 1 : 0);
+        ((int4 *)cnt.record)[1 + j] = make_int4(kind, freeList ? 1 : 0, octant, (tight ? 1 : 0) | (order << 1));
 }
 
 /* What a walk holds of the primitive it is testing.  The first primitive of a leaf comes with the leaf's record
@@ -1401,7 +1402,28 @@ SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDis
  * record: cur + 1 and cur + skip are at most `n`.
  *   LW<x>   test the node in bank x
  *   LE<x>   some lane entered: a leaf with primitives leaves the loop (LL), an inner node goes on at cur + 1 */
-#define SOLR_WALK_BANK(SELF, NEXT1, NEXTS, LOXY, ZZ, HIXY, NB, SKIP, NEXT1_REGS, NEXTS_REGS, TAIL)                    \
+/* ORDER: how the six slab products become the entry and exit parameters.  SOLR_ORDER_ANY orders the two products of every
+ * axis by min / max (any record, any ray: eight instructions).  Where the record already holds, per axis, the bound a ray
+ * of the wave reaches FIRST in its first slot (a copy of an order-free list sorted for its octant, scene_layout.h) and
+ * every lane's direction has that octant's signs, the products are ordered as they come - SOLR_ORDER_SORTED: two
+ * instructions, the same values into the same max3 / min3, bit for bit; for rays of the OPPOSITE octant (the shadow
+ * walks take the lamp's side first) every axis is the other way round - SOLR_ORDER_REVERSED. */
+#define SOLR_ORDER_ANY                                                                                                 \
+    "v_min_f32 %[t], v58, v60\n"                                                                                     \
+    "v_max_f32 v58, v58, v60\n"                                                                                     \
+    "v_min_f32 v60, v59, v61\n"                                                                                     \
+    "v_max_f32 v59, v59, v61\n"                                                                                     \
+    "v_min_f32 v61, v62, v63\n"                                                                                     \
+    "v_max_f32 v62, v62, v63\n"                                                                                     \
+    "v_max3_f32 %[t], %[t], v60, v61\n"                                                                              \
+    "v_min3_f32 v58, v58, v59, v62\n"
+#define SOLR_ORDER_SORTED                                                                                              \
+    "v_max3_f32 %[t], v58, v59, v62\n"                                                                              \
+    "v_min3_f32 v58, v60, v61, v63\n"
+#define SOLR_ORDER_REVERSED                                                                                            \
+    "v_max3_f32 %[t], v60, v61, v63\n"                                                                              \
+    "v_min3_f32 v58, v58, v59, v62\n"
+#define SOLR_WALK_BANK(SELF, NEXT1, NEXTS, LOXY, ZZ, HIXY, NB, SKIP, NEXT1_REGS, NEXTS_REGS, TAIL, ORDER)             \
     "LW" SELF "_%=:\n"                                                                                                 \
     "s_waitcnt lgkmcnt(0)\n"                                                                                           \
     "s_add_i32 s93, %[cur], 1\n"                                                                                       \
@@ -1416,14 +1438,7 @@ SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDis
     "v_pk_mul_f32 v[58:59], %[ixy], v[58:59]\n"                                                                    \
     "v_pk_mul_f32 v[60:61], %[ixy], v[60:61]\n"                                                                    \
     "v_pk_mul_f32 v[62:63], %[izz], v[62:63]\n"                                                                    \
-    "v_min_f32 %[t], v58, v60\n"                                                                                     \
-    "v_max_f32 v58, v58, v60\n"                                                                                     \
-    "v_min_f32 v60, v59, v61\n"                                                                                     \
-    "v_max_f32 v59, v59, v61\n"                                                                                     \
-    "v_min_f32 v61, v62, v63\n"                                                                                     \
-    "v_max_f32 v62, v62, v63\n"                                                                                     \
-    "v_max3_f32 %[t], %[t], v60, v61\n"                                                                              \
-    "v_min3_f32 v58, v58, v59, v62\n"                                                                              \
+    ORDER                                                                                                              \
     "v_cmpx_eq_u32_e32 vcc, %[cur], %[cursor]\n"                                                                       \
     "v_mov_b32 %[cursor], s94\n"                                                                                       \
     "v_cmpx_le_f32_e32 vcc, %[t], v58\n"                                                                              \
@@ -1453,45 +1468,57 @@ SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDis
     "s_mov_b32 %[cur], s93\n"                                                                                          \
     "s_branch LX_%=\n"
 
-SOLR_DEV int advanceTidyDeep(const Scene &S, const PackedRay &p, float farDistance, int &cursor, int &cur,
-                             int &nbPrimitives, bool &entered)
-{
-    const unsigned long base = (unsigned long)S.geo + ((unsigned long)S.offBoxes << 4);
-    int leaf, nb, flag;
-    float t;
-    /* banks: A = s[64:71], B = s[72:79], C = s[80:87]; a node's successors go: A -> (cur+1: B, cur+skip: C),
-     * C -> (A, B), B -> (C, A) */
-    asm volatile("s_mov_b64 s[88:89], exec\n"
-                 "s_lshl_b32 s92, %[cur], 5\n"
-                 "s_load_dwordx8 s[64:71], %[base], s92\n"
-                 SOLR_WALK_BANK("A", "B", "C", "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[72:79]", "s[80:87]", "")
-                 SOLR_WALK_BANK("C", "A", "B", "s[80:81]", "s[82:83]", "s[84:85]", "s86", "s87", "s[64:71]", "s[72:79]", "")
-                 SOLR_WALK_BANK("B", "C", "A", "s[72:73]", "s[74:75]", "s[76:77]", "s78", "s79", "s[80:87]", "s[64:71]",
-                                "s_branch LWA_%=\n")
-                 SOLR_WALK_SIDE("A", "B", "s70")
-                 SOLR_WALK_SIDE("C", "A", "s86")
-                 SOLR_WALK_SIDE("B", "C", "s78")
-                 "LD_%=:\n"
-                 "s_mov_b64 s[90:91], 0\n"
-                 "s_mov_b32 %[leaf], -1\n"
-                 "s_mov_b32 %[nb], 0\n"
-                 "LX_%=:\n"
-                 "s_waitcnt lgkmcnt(0)\n"
-                 "v_cndmask_b32_e64 %[flag], 0, 1, s[90:91]\n"
-                 : [cursor] "+v"(cursor), [cur] "+s"(cur), [leaf] "=&s"(leaf), [nb] "=&s"(nb), [flag] "=&v"(flag),
-                   [t] "=&v"(t)
-                 : [oxy] "v"(p.oxy), [ozz] "v"(p.ozz), [ixy] "v"(p.ixy), [izz] "v"(p.izz), [far] "v"(farDistance),
-                   [base] "s"(base), [n] "s"(S.nbBoxes)
-                 : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
-                   "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
-                   "s90", "s91", "s92", "s93", "s94", "v58", "v59", "v60", "v61", "v62", "v63");
-    /* (readfirstlane: the compiler takes inline-asm results for divergent; where two such statements meet it would
-     * otherwise have to move a "vector" value into the scalar registers the next statement asks for) */
-    nbPrimitives = uniform(nb);
-    cur = uniform(cur);
-    entered = flag != 0;
-    return uniform(leaf);
-}
+#define SOLR_ADVANCE_TIDY_DEEP(NAME, ORDER)                                                                            \
+    SOLR_DEV int NAME(const Scene &S, const PackedRay &p, float farDistance, int &cursor, int &cur, int &nbPrimitives,  \
+                      bool &entered)                                                                                   \
+    {                                                                                                                  \
+        /* (through readfirstlane, which folds away where the compiler knows the address to be uniform: the statement     \
+         * asks for it in scalar registers) */                                                                         \
+        const unsigned long at = (unsigned long)S.geo + ((unsigned long)S.offBoxes << 4);                              \
+        const unsigned long base = ((unsigned long)(unsigned)uniform((int)(at >> 32)) << 32) |                         \
+                                   (unsigned long)(unsigned)uniform((int)at);                                          \
+        int leaf, nb, flag;                                                                                            \
+        float t;                                                                                                       \
+        /* banks: A = s[64:71], B = s[72:79], C = s[80:87]; a node's successors go: A -> (cur+1: B, cur+skip: C),     \
+         * C -> (A, B), B -> (C, A) */                                                                                 \
+        asm volatile("s_mov_b64 s[88:89], exec\n"                                                                     \
+                     "s_lshl_b32 s92, %[cur], 5\n"                                                                    \
+                     "s_load_dwordx8 s[64:71], %[base], s92\n"                                                        \
+                     SOLR_WALK_BANK("A", "B", "C", "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[72:79]",     \
+                                    "s[80:87]", "", ORDER)                                                             \
+                     SOLR_WALK_BANK("C", "A", "B", "s[80:81]", "s[82:83]", "s[84:85]", "s86", "s87", "s[64:71]",     \
+                                    "s[72:79]", "", ORDER)                                                             \
+                     SOLR_WALK_BANK("B", "C", "A", "s[72:73]", "s[74:75]", "s[76:77]", "s78", "s79", "s[80:87]",     \
+                                    "s[64:71]", "s_branch LWA_%=\n", ORDER)                                           \
+                     SOLR_WALK_SIDE("A", "B", "s70")                                                                   \
+                     SOLR_WALK_SIDE("C", "A", "s86")                                                                   \
+                     SOLR_WALK_SIDE("B", "C", "s78")                                                                   \
+                     "LD_%=:\n"                                                                                       \
+                     "s_mov_b64 s[90:91], 0\n"                                                                        \
+                     "s_mov_b32 %[leaf], -1\n"                                                                        \
+                     "s_mov_b32 %[nb], 0\n"                                                                           \
+                     "LX_%=:\n"                                                                                       \
+                     "s_waitcnt lgkmcnt(0)\n"                                                                         \
+                     "v_cndmask_b32_e64 %[flag], 0, 1, s[90:91]\n"                                                    \
+                     : [cursor] "+v"(cursor), [cur] "+s"(cur), [leaf] "=&s"(leaf), [nb] "=&s"(nb), [flag] "=&v"(flag), \
+                       [t] "=&v"(t)                                                                                    \
+                     : [oxy] "v"(p.oxy), [ozz] "v"(p.ozz), [ixy] "v"(p.ixy), [izz] "v"(p.izz), [far] "v"(farDistance), \
+                       [base] "s"(base), [n] "s"(S.nbBoxes)                                                            \
+                     : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74",      \
+                       "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",      \
+                       "s88", "s89", "s90", "s91", "s92", "s93", "s94", "v58", "v59", "v60", "v61", "v62", "v63");     \
+        /* (readfirstlane: the compiler takes inline-asm results for divergent; where two such statements meet it    \
+         * would otherwise have to move a "vector" value into the scalar registers the next statement asks for) */    \
+        nbPrimitives = uniform(nb);                                                                                    \
+        cur = uniform(cur);                                                                                            \
+        entered = flag != 0;                                                                                           \
+        return uniform(leaf);                                                                                          \
+    }
+SOLR_ADVANCE_TIDY_DEEP(advanceTidyDeep, SOLR_ORDER_ANY)
+/* the same loop over a copy of an order-free list whose bounds are sorted for the octant of every ray of the wave, and
+ * for the opposite octant (SOLR_ORDER_* above): 14 vector instructions per node instead of 20 */
+SOLR_ADVANCE_TIDY_DEEP(advanceTidyDeepSorted, SOLR_ORDER_SORTED)
+SOLR_ADVANCE_TIDY_DEEP(advanceTidyDeepReversed, SOLR_ORDER_REVERSED)
 
 /* Which loop: the three-bank form pays one more request and two more scalar instructions per node, and seven more
  * reserved scalar registers, for having the skip target on its way.  That wins where skips are frequent and
@@ -1642,6 +1669,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
         SOLR_T(const unsigned long long tAttempt = SOLR_NOW();)
         Scene W = S;
         int octant = 0;
+        int order = 0; /* the form of the node loop: 0 any record and ray, 1 sorted bounds (SOLR_ORDER_SORTED) */
         if (freeList)
         {
             /* eight flattenings of the same hierarchy, the near child first for a direction of that sign octant: the
@@ -1652,6 +1680,13 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
             W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
             W.nbBoxes = S.nbBoxesFree;
+            /* every ray of the wave points into the list's octant (a tile of primary rays, but for the tiles the
+             * camera's axes run through): the copy with sorted bounds, the node loop without its six min / max */
+            if ((FEAT & F_DEEP) && S.sortedLists && !tight && ballot(lanesNow && signs != octant) == 0ull)
+            {
+                order = 1;
+                W.offBoxes += 32u * (unsigned)S.nbBoxesFree + 4u;
+            }
         }
         if (tight) /* the same nodes, leaf records and start indices: only the bounds differ */
             W.offBoxes += freeList ? 16u * (unsigned)S.nbBoxesFree + 2u : 2u * (unsigned)S.nbBoxes + 2u;
@@ -1694,10 +1729,12 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             SOLR_T(unsigned long long ta = SOLR_NOW();)
             if (tidy)
             {
-                leaf = advanceTidy<FEAT>(W, pr,
-                                         freeList ? minDistance * farScale + farOffset
-                                                  : (fatCheck ? minDistance * shortFarScale + shortFarOffset : minDistance),
-                                         cursor, cur, nbPrimitives, entered);
+                const float far = freeList ? minDistance * farScale + farOffset
+                                           : (fatCheck ? minDistance * shortFarScale + shortFarOffset : minDistance);
+                if ((FEAT & F_DEEP) && order == 1)
+                    leaf = advanceTidyDeepSorted(W, pr, far, cursor, cur, nbPrimitives, entered);
+                else
+                    leaf = advanceTidy<FEAT>(W, pr, far, cursor, cur, nbPrimitives, entered);
                 SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;
                        if (attempt == 0) ++cnt.nAdvanceFirst; else ++cnt.nAdvanceAgain;)
                 if (leaf < 0)
@@ -1965,7 +2002,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             recordWalk(cnt, tidy ? WALK_CLOSEST : WALK_GENERAL, freeList, octant, lanesNow, r,
                        freeList ? minDistance * farScale + farOffset
                                 : (fatCheck ? minDistance * shortFarScale + shortFarOffset : minDistance),
-                       SOLR_CURSOR_DONE, tight || fatCheck);
+                       SOLR_CURSOR_DONE, tight || fatCheck, order);
         SOLR_T(if (attempt == 1) cnt.tAgain += SOLR_NOW() - tAttempt;)
         if (!checked)
             break;
@@ -2018,11 +2055,15 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     Scene W = S;
     float farFree = 0.f;
     int octant = 0;
+    bool reversed = false;
     if (freeOrder)
     {
         const int signs = ((r.d.x < 0.f ? 1 : 0) | (r.d.y < 0.f ? 2 : 0) | (r.d.z < 0.f ? 4 : 0)) ^ 7;
         const int lane = (int)__builtin_ctzll(ballot(active));
         octant = __builtin_amdgcn_readlane(signs, lane);
+        /* every ray of the wave points into the octant OPPOSITE the list's (the points of a tile towards one lamp): the
+         * copy with sorted bounds read the other way round (SOLR_ORDER_REVERSED) */
+        reversed = (FEAT & F_DEEP) && S.sortedLists && ballot(active && signs != octant) == 0ull;
         W.offBoxes = S.offBoxesFree + 2u * (unsigned)(octant * S.nbBoxesFree);
         W.offLeaf = S.offLeafFree + 4u * (unsigned)(octant * S.nbBoxesFree);
         W.nbBoxes = S.nbBoxesFree;
@@ -2032,6 +2073,9 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     const bool tight = (FEAT & F_PLANE) && tidy && S.tightLists && ballot(active && !tightRay(r, si)) == 0ull;
     if (tight)
         W.offBoxes += freeOrder ? 16u * (unsigned)S.nbBoxesFree + 2u : 2u * (unsigned)S.nbBoxes + 2u;
+    reversed = reversed && !tight;
+    if (reversed)
+        W.offBoxes += 32u * (unsigned)S.nbBoxesFree + 4u;
     const int nbBoxes = W.nbBoxes;
     const PackedRay pr = packRay(r);
     int cursor = (active && result < si.shadowIntensity) ? 0 : SOLR_CURSOR_DONE;
@@ -2051,7 +2095,10 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         SOLR_T(unsigned long long ta = SOLR_NOW();)
         if (tidy)
         {
-            leaf = advanceTidy<FEAT>(W, pr, freeOrder ? farFree : minDistance, cursor, cur, nbPrimitives, entered);
+            if ((FEAT & F_DEEP) && reversed)
+                leaf = advanceTidyDeepReversed(W, pr, farFree, cursor, cur, nbPrimitives, entered);
+            else
+                leaf = advanceTidy<FEAT>(W, pr, freeOrder ? farFree : minDistance, cursor, cur, nbPrimitives, entered);
             SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)
             if (leaf < 0)
                 break;
@@ -2196,7 +2243,7 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
     }
     if (COUNT == 2)
         recordWalk(cnt, tidy ? WALK_SHADOW : WALK_GENERAL, freeOrder, octant, walked, r, freeOrder ? farFree : minDistance,
-                   doneAfter, tight);
+                   doneAfter, tight, reversed ? 2 : 0);
     result = fmaxf(0.f, fminf(result, si.shadowIntensity));
     SOLR_T(cnt.tShadow += SOLR_NOW() - tw0;)
     return result;

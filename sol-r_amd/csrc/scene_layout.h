@@ -160,6 +160,12 @@ struct SceneArgs
      * leaf that holds nothing but plain axis planes is as thin as its planes (solr_scene.hip tightenList): long rays with
      * no zero direction component walk the copy (rt_device.h tightRay) */
     int tightLists;
+    /* behind the thin copies lies a third copy of the eight order-free lists' node rows in which every node's bounds
+     * are sorted for the octant its list was flattened for - per axis (the bound a ray of that octant reaches first, the
+     * other one): {n.x, n.y, n.z, f.z} {f.x, f.y, count, skip} (solr_scene.hip sortFreeLists).  A walk whose rays all
+     * have that octant's signs - or all the opposite ones - takes it with a node loop that has no min / max per axis
+     * (rt_device.h SOLR_ORDER_SORTED / _REVERSED).  Row offset: offBoxesFree + 2 (16 nbBoxesFree + 2) */
+    int sortedLists;
 };
 
 /* Device view: everything is read through the CONSTANT address space.  The
@@ -197,6 +203,7 @@ struct Scene
     int opaqueShadows;
     int shortRayLists;
     int tightLists;
+    int sortedLists;
 };
 
 __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
@@ -225,6 +232,7 @@ __device__ __forceinline__ Scene makeScene(const SceneArgs &a)
     s.opaqueShadows = a.opaqueShadows;
     s.shortRayLists = a.shortRayLists;
     s.tightLists = a.tightLists;
+    s.sortedLists = a.sortedLists;
     return s;
 }
 

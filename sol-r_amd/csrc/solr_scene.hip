@@ -708,6 +708,56 @@ bool tightenList(unsigned offNodes, unsigned offStart, int nbNodes, int listLeng
     return ok();
 }
 
+/* The eight order-free lists once more, behind their thin copies: every node's two rows with its bounds as (near, far) per
+ * axis for the octant the list was flattened for (bit 0: x, 1: y, 2: z negative) - {n.x, n.y, n.z, f.z} {f.x, f.y, count,
+ * skip} (scene_layout.h sortedLists; rt_device.h SOLR_ORDER_SORTED).  Made wherever the lists' bounds change. */
+__global__ __launch_bounds__(256) void k_sortNodeBounds(float4 *__restrict__ arena, unsigned offBoxesFree, int nb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned offSorted = offBoxesFree + 32u * (unsigned)nb + 4u;
+    if (i > 8 * nb)
+        return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a; /* (i == 8 nb: the pad record behind the last list) */
+    if (i < 8 * nb)
+    {
+        const int octant = i / nb;
+        a = arena[offBoxesFree + 2u * (unsigned)i];
+        b = arena[offBoxesFree + 2u * (unsigned)i + 1u];
+        if (octant & 1)
+        {
+            const float t = a.x;
+            a.x = b.x;
+            b.x = t;
+        }
+        if (octant & 2)
+        {
+            const float t = a.y;
+            a.y = b.y;
+            b.y = t;
+        }
+        if (octant & 4)
+        {
+            const float t = a.z;
+            a.z = a.w;
+            a.w = t;
+        }
+    }
+    arena[offSorted + 2u * (unsigned)i] = a;
+    arena[offSorted + 2u * (unsigned)i + 1u] = b;
+}
+
+static bool sortFreeLists(int nbRows)
+{
+    static const bool off = getenv("SOLR_HIP_NO_SORTED_LISTS") != nullptr;
+    const int nb = nbRows / 16; /* nodes per list: eight lists of two rows a node */
+    if (off || nb <= 0 || !ok())
+        return false;
+    hipLaunchKernelGGL(k_sortNodeBounds, dim3((unsigned)((8 * nb + 1 + 255) / 256)), dim3(256), 0, g.stream,
+                       (float4 *)g.geometry.ptr, g.offBoxesFree, nb);
+    HIPCHECK(hipGetLastError());
+    return ok();
+}
+
 /* the leaf records of both node lists from the primitive records as the arena holds them now */
 void buildLeafRecords()
 {
@@ -729,6 +779,7 @@ void buildLeafRecords()
     /* the thin copies follow the bounds and the primitives they were made from (an upload, a rotation on the device) */
     g.tightCompact = tightenList(g.offBoxesCompact, g.offBoxStartCompact, nc, nc);
     g.tightFree = nf > 0 && !g.freeStale && tightenList(g.offBoxesFree, g.offBoxStartFree, nf, nf / 8);
+    g.sortedFree = nf > 0 && !g.freeStale && sortFreeLists((int)g.freeRows);
     HIPCHECK(hipStreamSynchronize(g.stream));
 }
 
@@ -736,7 +787,8 @@ void buildLeafRecords()
 static unsigned layoutFreeLists(unsigned row)
 {
     g.offBoxesFree = row;
-    row += 2u * ((unsigned)g.freeRows + 2u); /* (one pad record, as behind every node list; then the thin copy, padded alike) */
+    /* (one pad record, as behind every node list; then the thin copy and the copy with sorted bounds, padded alike) */
+    row += 3u * ((unsigned)g.freeRows + 2u);
     g.offBoxStartFree = row * 4;
     row += (unsigned)((g.freeRows / 2 + 3) / 4);
     row = (row + 3u) & ~3u; /* leaf records: one 64-byte line per node */
@@ -916,6 +968,8 @@ SceneArgs makeScene(bool exactNodes)
     }
     /* the thin copies behind the lists this frame walks (set by tightListsFor: they also depend on the frame) */
     S.tightLists = 0;
+    /* ... and the copies with sorted bounds behind those (variant 12: the walks take the lists as they are) */
+    S.sortedLists = (S.nbBoxesFree > 0 && g.sortedFree && g.variant != 12) ? 1 : 0;
     return S;
 }
 

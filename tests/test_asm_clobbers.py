@@ -82,7 +82,8 @@ def statements(tmp_path_factory):
 
 def test_there_are_the_statements_we_think(statements):
     loops = [s for s in statements if "s_load_dwordx8" in s[0]]
-    assert len(loops) == 2, [s[0][:40] for s in statements]
+    # the two-bank loop, and the three-bank loop in its three forms (any record / sorted bounds / sorted, read in reverse)
+    assert len(loops) == 4, [s[0][:40] for s in statements]
     assert len(statements) >= 3
 
 
@@ -171,7 +172,7 @@ def test_the_compiler_emits_every_loop_whole_and_apart(statements, generated):
         lines = lines[:lines.index("LX_%=:")]                    # (as _loop_bodies cuts the generated code)
         opcodes = [l.split()[0] for l in lines if not l.endswith(":")]
         templates[len(opcodes)] = opcodes
-    assert len(templates) == 2                                   # the two-bank and the three-bank form
+    assert len(templates) == 3                                   # the two-bank form, the three-bank form with and without its min / max
     kernels = _kernels(generated)
     assert len(kernels) >= 4, list(kernels)
     for name, body in kernels.items():

@@ -71,7 +71,7 @@ j = np.arange(SLOTS)[None, :]
 valid = j < nwalks[:, None]                                   # (grid, SLOTS)
 kind = heads[:, 1:, 0]
 free = heads[:, 1:, 1]
-tight = heads[:, 1:, 3]
+tight = heads[:, 1:, 3] & 1
 done = lanes[..., 1, 3].view(np.int32)                       # (grid, SLOTS, 64)
 took_part = done >= 0
 classes = {
@@ -121,6 +121,11 @@ whole = np.zeros((grid, SLOT_BYTES), np.uint8)
 whole[:, :HEAD] = heads.reshape(grid, -1).view(np.uint8)
 whole[:, HEAD:] = lanes.reshape(grid, -1).view(np.uint8)
 report("every walk, as recorded", whole)
+# which walks took the node loop without its six min / max (the copies of the order-free lists with sorted bounds, rt_device.h
+# SOLR_ORDER_SORTED / _REVERSED: bits 1-2 of a record's fourth word)
+form = (heads[:, 1:, 3] >> 1) & 3
+print("  of %d walks %d took the sorted form of the node loop, %d the reversed one" % (
+    int(valid.sum()), int((valid & (form == 1)).sum()), int((valid & (form == 2)).sum())))
 del whole
 
 for name, mask in classes.items():
@@ -151,7 +156,7 @@ for name, mask in classes.items():
     origins = rays[:, 0, :3].astype(np.float64)
     lo, hi = origins.min(axis=0), origins.max(axis=0)
     cells = np.clip(((origins - lo) / np.maximum(hi - lo, 1e-9) * 32.0).astype(np.int64), 0, 31)
-    list_key = (lists[:, 1].astype(np.int64) << 1) | lists[:, 3].astype(np.int64)
+    list_key = (lists[:, 1].astype(np.int64) << 1) | (lists[:, 3].astype(np.int64) & 1)
 
     def pack(order, label):
         r = rays[order]
@@ -174,7 +179,7 @@ for name, mask in classes.items():
             hrow = np.zeros((nw, 4), np.int32)
             hrow[:, 0] = lists[order[a], 0]
             hrow[:, 1] = lists[order[a], 1]
-            hrow[:, 3] = lists[order[a], 3]
+            hrow[:, 3] = lists[order[a], 3] & 1      # (the generic form of the node loop: regrouped rays share no octant)
             # the octant list of each wave's first ray (any of the eight gives the same result)
             hrow[:, 2] = oc[a:e][::64][:nw]
             waves_h.append(hrow)
