@@ -825,6 +825,7 @@ static void appendFreeLists()
                            g.offBoxesFree, g.offBoxStartFree, g.offPrims, g.offLeafFree, nf);
     HIPCHECK(hipGetLastError());
     g.tightFree = nf > 0 && tightenList(g.offBoxesFree, g.offBoxStartFree, nf, nf / 8);
+    g.sortedFree = nf > 0 && sortFreeLists((int)g.freeRows);
     HIPCHECK(hipStreamSynchronize(g.stream));
     phase.mark("geometry: lists appended");
     if (ok())

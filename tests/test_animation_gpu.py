@@ -338,3 +338,34 @@ def test_order_free_lists_built_between_rotations(solr, oracle):
     finally:
         if saved is not None:
             os.environ["SOLR_HIP_FREE_AFTER"] = saved
+
+
+def test_sorted_copies_of_the_order_free_lists_follow_a_rotation(solr, oracle):
+    """A scene whose lists are long enough for the three-bank node loop (more than 1 024 nodes): the copies of the
+    order-free lists with sorted bounds (rt_device.h SOLR_ORDER_SORTED / _REVERSED: the node loop without its min / max
+    where a wave's rays share the list's octant) are made again after a rotation on the device refitted the lists.  After
+    every rotation the frame is, bit for bit, the frame without them (variant 12) - and the frame a fresh upload of the
+    rotated scene renders"""
+    hip = solr.hip_lib()
+    k = _build(solr, ("molecule", dict(atoms=2500, width=160, height=104, iterations=2)), "hip")
+    try:
+        gpu_frame(k)
+        gpu_frame(k)                                 # (the order-free lists arrive with the second frame)
+        assert hip.solr_hip_order_free_nodes() > 1024 // 8
+        for n, (center, angles) in enumerate(STEPS[:3]):
+            k.rotate_primitives(center, angles)
+            hip.solr_hip_set_variant(0)
+            sorted_frame = [np.array(a, copy=True) for a in gpu_frame(k)]
+            hip.solr_hip_set_variant(12)
+            plain = [np.array(a, copy=True) for a in gpu_frame(k)]
+            hip.solr_hip_set_variant(0)
+            assert _same_bits(sorted_frame[0], plain[0]) and np.array_equal(sorted_frame[1], plain[1]), n
+            assert np.array_equal(sorted_frame[2], plain[2]), n
+            assert hip.solr_hip_order_free_nodes() > 0
+        k.flat_scene()                               # the host store replays the rotations
+        fresh = gpu_frame(k)                         # a fresh upload of the rotated scene
+        res = compare_frames(sorted_frame[0], sorted_frame[1], sorted_frame[2], fresh[0], fresh[1], fresh[2])
+        assert res["ids_all_equal"] and res["max_ulp"] == 0 and res["rgb_max_diff"] == 0, res
+    finally:
+        hip.solr_hip_set_variant(0)
+        k.finalize()

@@ -110,6 +110,14 @@ def test_full_size_frames_match_the_oracle_on_every_pixel(solr, oracle, config):
         assert np.array_equal(ordered[1], first[1]) and np.array_equal(ordered[2], first[2])
         assert np.array_equal(ordered[0].view(np.uint32), first[0].view(np.uint32))
 
+        # the order-free lists as they are: no walk takes the copies with sorted bounds (the node loop without its min / max
+        # where a wave's rays share the list's octant, rt_device.h SOLR_ORDER_SORTED / _REVERSED): the same bits
+        hip.solr_hip_set_variant(12)
+        _render(solr, args)
+        unsorted = device_frame(solr, si)
+        assert np.array_equal(unsorted[1], first[1]) and np.array_equal(unsorted[2], first[2]), config + " variant 12"
+        assert np.array_equal(unsorted[0].view(np.uint32), first[0].view(np.uint32)), config + " variant 12"
+
         # the reference's own node list
         hip.solr_hip_set_variant(3)
         _render(solr, args)
