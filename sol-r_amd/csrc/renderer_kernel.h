@@ -457,7 +457,10 @@ __global__ __launch_bounds__(WAVE, SOLR_WAVES_PER_EU) void k_walkBound(const Sce
         /* the form of the node loop the recorded walk took (rt_device.h walkOrder: bits 1-2 of the record's fourth word) */
         const int order = (FEAT & F_DEEP) ? (__builtin_amdgcn_readfirstlane(h.w) >> 1) & 3 : 0;
         if (order)
+        {
             W.offBoxes += 32u * (unsigned)S.nbBoxesFree + 4u;
+            W.nbBoxes = S.nbBoxesFree << 5; /* (such a walk's cursors count bytes: rt_device.h SOLR_NEXT_BY_BYTES) */
+        }
         const PackedRay pr = packRay(r);
         const float cutOff = a.w;
         int cursor = took_part ? 0 : SOLR_CURSOR_DONE;

@@ -1423,15 +1423,26 @@ SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDis
 #define SOLR_ORDER_REVERSED                                                                                            \
     "v_max3_f32 %[t], v60, v61, v63\n"                                                                              \
     "v_min3_f32 v58, v58, v59, v62\n"
-#define SOLR_WALK_BANK(SELF, NEXT1, NEXTS, LOXY, ZZ, HIXY, NB, SKIP, NEXT1_REGS, NEXTS_REGS, TAIL, ORDER)             \
-    "LW" SELF "_%=:\n"                                                                                                 \
-    "s_waitcnt lgkmcnt(0)\n"                                                                                           \
+/* NEXT: how the two successors' records are asked for.  SOLR_NEXT_BY_NUMBER: cursors and skip words count nodes (every
+ * list as the builders leave it), the byte offset is a shift away.  SOLR_NEXT_BY_BYTES: in the copies with sorted bounds
+ * the skip word holds BYTES (32 x the nodes) and so do the wave's and the lanes' cursors for the length of such a walk:
+ * two scalar instructions per node less (11 instead of 13 on a scalar unit that four SIMDs share). */
+#define SOLR_NEXT_BY_NUMBER(SKIP, NEXT1_REGS, NEXTS_REGS)                                                              \
     "s_add_i32 s93, %[cur], 1\n"                                                                                       \
     "s_add_i32 s94, %[cur], " SKIP "\n"                                                                                \
     "s_lshl_b32 s92, s93, 5\n"                                                                                         \
     "s_load_dwordx8 " NEXT1_REGS ", %[base], s92\n"                                                                    \
     "s_lshl_b32 s92, s94, 5\n"                                                                                         \
-    "s_load_dwordx8 " NEXTS_REGS ", %[base], s92\n"                                                                    \
+    "s_load_dwordx8 " NEXTS_REGS ", %[base], s92\n"
+#define SOLR_NEXT_BY_BYTES(SKIP, NEXT1_REGS, NEXTS_REGS)                                                               \
+    "s_add_i32 s93, %[cur], 32\n"                                                                                      \
+    "s_add_i32 s94, %[cur], " SKIP "\n"                                                                                \
+    "s_load_dwordx8 " NEXT1_REGS ", %[base], s93\n"                                                                    \
+    "s_load_dwordx8 " NEXTS_REGS ", %[base], s94\n"
+#define SOLR_WALK_BANK(SELF, NEXT1, NEXTS, LOXY, ZZ, HIXY, NB, SKIP, NEXT1_REGS, NEXTS_REGS, TAIL, ORDER, NEXT)       \
+    "LW" SELF "_%=:\n"                                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                           \
+    NEXT(SKIP, NEXT1_REGS, NEXTS_REGS)                                                                                 \
     "v_pk_add_f32 v[58:59], " LOXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
     "v_pk_add_f32 v[60:61], " HIXY ", %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"                                            \
     "v_pk_add_f32 v[62:63], " ZZ ", %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"                                              \
@@ -1468,7 +1479,7 @@ SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDis
     "s_mov_b32 %[cur], s93\n"                                                                                          \
     "s_branch LX_%=\n"
 
-#define SOLR_ADVANCE_TIDY_DEEP(NAME, ORDER)                                                                            \
+#define SOLR_ADVANCE_TIDY_DEEP(NAME, ORDER, NEXT, ENTRY, S92)                                                          \
     SOLR_DEV int NAME(const Scene &S, const PackedRay &p, float farDistance, int &cursor, int &cur, int &nbPrimitives,  \
                       bool &entered)                                                                                   \
     {                                                                                                                  \
@@ -1482,14 +1493,13 @@ SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDis
         /* banks: A = s[64:71], B = s[72:79], C = s[80:87]; a node's successors go: A -> (cur+1: B, cur+skip: C),     \
          * C -> (A, B), B -> (C, A) */                                                                                 \
         asm volatile("s_mov_b64 s[88:89], exec\n"                                                                     \
-                     "s_lshl_b32 s92, %[cur], 5\n"                                                                    \
-                     "s_load_dwordx8 s[64:71], %[base], s92\n"                                                        \
+                     ENTRY                                                                                             \
                      SOLR_WALK_BANK("A", "B", "C", "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[72:79]",     \
-                                    "s[80:87]", "", ORDER)                                                             \
+                                    "s[80:87]", "", ORDER, NEXT)                                                       \
                      SOLR_WALK_BANK("C", "A", "B", "s[80:81]", "s[82:83]", "s[84:85]", "s86", "s87", "s[64:71]",     \
-                                    "s[72:79]", "", ORDER)                                                             \
+                                    "s[72:79]", "", ORDER, NEXT)                                                       \
                      SOLR_WALK_BANK("B", "C", "A", "s[72:73]", "s[74:75]", "s[76:77]", "s78", "s79", "s[80:87]",     \
-                                    "s[64:71]", "s_branch LWA_%=\n", ORDER)                                           \
+                                    "s[64:71]", "s_branch LWA_%=\n", ORDER, NEXT)                                     \
                      SOLR_WALK_SIDE("A", "B", "s70")                                                                   \
                      SOLR_WALK_SIDE("C", "A", "s86")                                                                   \
                      SOLR_WALK_SIDE("B", "C", "s78")                                                                   \
@@ -1506,7 +1516,7 @@ SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDis
                        [base] "s"(base), [n] "s"(S.nbBoxes)                                                            \
                      : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74",      \
                        "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",      \
-                       "s88", "s89", "s90", "s91", "s92", "s93", "s94", "v58", "v59", "v60", "v61", "v62", "v63");     \
+                       "s88", "s89", "s90", "s91", S92 "s93", "s94", "v58", "v59", "v60", "v61", "v62", "v63");        \
         /* (readfirstlane: the compiler takes inline-asm results for divergent; where two such statements meet it    \
          * would otherwise have to move a "vector" value into the scalar registers the next statement asks for) */    \
         nbPrimitives = uniform(nb);                                                                                    \
@@ -1514,11 +1524,16 @@ SOLR_DEV int advanceTidyShallow(const Scene &S, const PackedRay &p, float farDis
         entered = flag != 0;                                                                                           \
         return uniform(leaf);                                                                                          \
     }
-SOLR_ADVANCE_TIDY_DEEP(advanceTidyDeep, SOLR_ORDER_ANY)
+#define SOLR_CLOBBER_S92 "s92",
+#define SOLR_CLOBBER_NO_S92
+#define SOLR_ENTRY_BY_NUMBER "s_lshl_b32 s92, %[cur], 5\n" "s_load_dwordx8 s[64:71], %[base], s92\n"
+#define SOLR_ENTRY_BY_BYTES "s_load_dwordx8 s[64:71], %[base], %[cur]\n"
+SOLR_ADVANCE_TIDY_DEEP(advanceTidyDeep, SOLR_ORDER_ANY, SOLR_NEXT_BY_NUMBER, SOLR_ENTRY_BY_NUMBER, SOLR_CLOBBER_S92)
 /* the same loop over a copy of an order-free list whose bounds are sorted for the octant of every ray of the wave, and
- * for the opposite octant (SOLR_ORDER_* above): 14 vector instructions per node instead of 20 */
-SOLR_ADVANCE_TIDY_DEEP(advanceTidyDeepSorted, SOLR_ORDER_SORTED)
-SOLR_ADVANCE_TIDY_DEEP(advanceTidyDeepReversed, SOLR_ORDER_REVERSED)
+ * for the opposite octant (SOLR_ORDER_* above): 14 vector instructions per node instead of 20, 11 scalar ones instead of
+ * 13.  cursor, cur, S.nbBoxes and the leaf they return are in BYTES (32 x the node's number, SOLR_NEXT_BY_BYTES). */
+SOLR_ADVANCE_TIDY_DEEP(advanceTidyDeepSorted, SOLR_ORDER_SORTED, SOLR_NEXT_BY_BYTES, SOLR_ENTRY_BY_BYTES, SOLR_CLOBBER_NO_S92)
+SOLR_ADVANCE_TIDY_DEEP(advanceTidyDeepReversed, SOLR_ORDER_REVERSED, SOLR_NEXT_BY_BYTES, SOLR_ENTRY_BY_BYTES, SOLR_CLOBBER_NO_S92)
 
 /* Which loop: the three-bank form pays one more request and two more scalar instructions per node, and seven more
  * reserved scalar registers, for having the skip target on its way.  That wins where skips are frequent and
@@ -1686,6 +1701,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
             {
                 order = 1;
                 W.offBoxes += 32u * (unsigned)S.nbBoxesFree + 4u;
+                W.nbBoxes = S.nbBoxesFree << 5; /* (this walk's cursors count bytes: SOLR_NEXT_BY_BYTES) */
             }
         }
         if (tight) /* the same nodes, leaf records and start indices: only the bounds differ */
@@ -1732,7 +1748,10 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                 const float far = freeList ? minDistance * farScale + farOffset
                                            : (fatCheck ? minDistance * shortFarScale + shortFarOffset : minDistance);
                 if ((FEAT & F_DEEP) && order == 1)
+                {
                     leaf = advanceTidyDeepSorted(W, pr, far, cursor, cur, nbPrimitives, entered);
+                    leaf = leaf < 0 ? leaf : leaf >> 5;
+                }
                 else
                     leaf = advanceTidy<FEAT>(W, pr, far, cursor, cur, nbPrimitives, entered);
                 SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;
@@ -2075,7 +2094,10 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         W.offBoxes += freeOrder ? 16u * (unsigned)S.nbBoxesFree + 2u : 2u * (unsigned)S.nbBoxes + 2u;
     reversed = reversed && !tight;
     if (reversed)
+    {
         W.offBoxes += 32u * (unsigned)S.nbBoxesFree + 4u;
+        W.nbBoxes = S.nbBoxesFree << 5; /* (this walk's cursors count bytes: SOLR_NEXT_BY_BYTES) */
+    }
     const int nbBoxes = W.nbBoxes;
     const PackedRay pr = packRay(r);
     int cursor = (active && result < si.shadowIntensity) ? 0 : SOLR_CURSOR_DONE;
@@ -2096,7 +2118,10 @@ SOLR_DEV float shadowWalk(const Scene &S, const SceneInfo &si, bool active, v3 l
         if (tidy)
         {
             if ((FEAT & F_DEEP) && reversed)
+            {
                 leaf = advanceTidyDeepReversed(W, pr, farFree, cursor, cur, nbPrimitives, entered);
+                leaf = leaf < 0 ? leaf : leaf >> 5;
+            }
             else
                 leaf = advanceTidy<FEAT>(W, pr, freeOrder ? farFree : minDistance, cursor, cur, nbPrimitives, entered);
             SOLR_T(const unsigned long long tb = SOLR_NOW(); cnt.tNode += tb - ta; ++cnt.nAdvance; ta = tb;)

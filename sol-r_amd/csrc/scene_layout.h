@@ -162,7 +162,7 @@ struct SceneArgs
     int tightLists;
     /* behind the thin copies lies a third copy of the eight order-free lists' node rows in which every node's bounds
      * are sorted for the octant its list was flattened for - per axis (the bound a ray of that octant reaches first, the
-     * other one): {n.x, n.y, n.z, f.z} {f.x, f.y, count, skip} (solr_scene.hip sortFreeLists).  A walk whose rays all
+     * other one): {n.x, n.y, n.z, f.z} {f.x, f.y, count, 32 x skip: bytes} (solr_scene.hip sortFreeLists).  A walk whose rays all
      * have that octant's signs - or all the opposite ones - takes it with a node loop that has no min / max per axis
      * (rt_device.h SOLR_ORDER_SORTED / _REVERSED).  Row offset: offBoxesFree + 2 (16 nbBoxesFree + 2) */
     int sortedLists;

@@ -710,7 +710,8 @@ bool tightenList(unsigned offNodes, unsigned offStart, int nbNodes, int listLeng
 
 /* The eight order-free lists once more, behind their thin copies: every node's two rows with its bounds as (near, far) per
  * axis for the octant the list was flattened for (bit 0: x, 1: y, 2: z negative) - {n.x, n.y, n.z, f.z} {f.x, f.y, count,
- * skip} (scene_layout.h sortedLists; rt_device.h SOLR_ORDER_SORTED).  Made wherever the lists' bounds change. */
+ * 32 x skip} (scene_layout.h sortedLists; rt_device.h SOLR_ORDER_SORTED, SOLR_NEXT_BY_BYTES).  Made wherever the lists'
+ * bounds change. */
 __global__ __launch_bounds__(256) void k_sortNodeBounds(float4 *__restrict__ arena, unsigned offBoxesFree, int nb)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -741,6 +742,8 @@ __global__ __launch_bounds__(256) void k_sortNodeBounds(float4 *__restrict__ are
             a.z = a.w;
             a.w = t;
         }
+        /* the skip word in BYTES: the loop that walks this copy keeps its cursors in bytes (rt_device.h SOLR_NEXT_BY_BYTES) */
+        b.w = __int_as_float(__float_as_int(b.w) << 5);
     }
     arena[offSorted + 2u * (unsigned)i] = a;
     arena[offSorted + 2u * (unsigned)i + 1u] = b;
