@@ -900,6 +900,42 @@ def test_frames_in_flight_through_the_frame_protocol(solr, flights):
         k.finalize()
 
 
+@pytest.mark.parametrize("scene", ["molecule-deep-lists", "mesh-with-mirrors", "cornell", "sticks"])
+def test_the_engines_default_state_frame_after_frame(solr, oracle, scene):
+    """tests/conftest.py builds the order-free lists with the FIRST frame of a scene so that one frame per test walks them.
+    Here the engine is left as a host gets it (SOLR_HIP_FREE_AFTER unset: the first frame after an upload walks the
+    reference's order, the lists - and their thin and sorted copies - arrive with the second), and four frames of a scene
+    with a camera move in between are each the oracle's frame: lists long enough for the three-bank node loop, a mesh
+    with mirrors (bounce rays), the Cornell room (thin leaves), spheres and cylinders on a short list"""
+    import os
+    import scenes_extra
+    hip = solr.hip_lib()
+    saved = os.environ.pop("SOLR_HIP_FREE_AFTER", None)
+    try:
+        k = solr.Kernel(engine="hip")
+        if scene == "molecule-deep-lists":
+            solr.scenes.molecule(k, atoms=2500, width=160, height=104, iterations=2)
+        elif scene == "mesh-with-mirrors":
+            solr.scenes.height_field(k, n=40, width=160, height=104)
+        elif scene == "cornell":
+            solr.scenes.cornell(k, width=160, height=104, iterations=3)
+        else:
+            scenes_extra.sticks(k, width=128, height=80)
+        eye = np.array(k.frame_parameters()[2], np.float32)
+        for frame in range(4):
+            if frame == 2:                      # the camera moves: the resident scene and its lists stay
+                k.set_camera((float(eye[0]) + 700.0, float(eye[1]) + 150.0, float(eye[2])))
+            pp, ids, rgb = gpu_frame(k)
+            if scene in ("molecule-deep-lists", "mesh-with-mirrors", "cornell"):
+                assert (hip.solr_hip_order_free_nodes() > 0) == (frame >= 1), frame
+            # (the oracle as pinned: at most two pixels behind a mis-rounded powf outside the bar, helpers)
+            assert_frame_pinned(k, oracle, (pp, ids, rgb), 2, "%s, frame %d of the default state" % (scene, frame))
+        k.finalize()
+    finally:
+        if saved is not None:
+            os.environ["SOLR_HIP_FREE_AFTER"] = saved
+
+
 @pytest.mark.gpu
 def test_run_kernel_delivers_into_the_callers_array_and_getbitmap_follows(solr):
     """SolR_RunKernel (SolRStub.cpp:154-164: render, copy to m_bitmap, copy m_bitmap to the caller) delivers the device's
