@@ -1640,13 +1640,8 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
                                 fabsf(r.o.z) <= si.viewDistance;
     const bool tightShort = thinLeaves && tidy && S.tightLists && !tight && !freeOrder && !(COUNT != 1 && (FEAT & F_DEEP) && (FEAT & F_TRI)) &&
                             ballot(active && !shortTightLane) == 0ull;
-    /* (a square root and a division: only where a walk of this kind follows) */
-    float shortFarScale = 1.f, shortFarOffset = 0.f;
-    if (tightShort)
-    {
-        shortFarScale = 1.002f / fminf(sqrtf(ddShort) * (1.f - 1.0e-5f), 1.f);
-        shortFarOffset = 2.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
-    }
+    const float shortFarScale = 1.002f / fminf(sqrtf(ddShort) * (1.f - 1.0e-5f), 1.f);
+    const float shortFarOffset = 2.0e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
     /* Short rays (the bounce rays: |direction| = 1 - rayEpsilon, CudaRayTracer.cu:322-323) in the order-free lists,
      * CHECKED.  The reference culls a box when its slab parameter t = (entry distance) / |direction| reaches the closest
      * DISTANCE so far.  For |direction| = L <= 1 that hides boxes whose entry lies between L x and 1 x the closest
@@ -1720,9 +1715,7 @@ SOLR_DEV bool closestHitWalk(const Scene &S, const SceneInfo &si, bool active, v
          * of both sides: 2e-4 of the distance for the computed hit distance and the products, 1e-4 of the origin's
          * coordinates for the cancellation in (bound - origin) - a thousand times the half-ulp that subtraction can
          * lose.  With the near child first this is what ends a walk early. */
-        float invLength = 1.f;
-        if (freeList)
-            invLength = 1.f / length(r.d);
+        const float invLength = freeList ? 1.f / length(r.d) : 1.f;
         const float farScale = freeList ? (checked ? rivalScale : 1.0002f) * invLength : 1.f;
         const float farOffset = freeList ? slack * invLength : 0.f;
         int tieIndex = -1; /* the primitive that holds minDistance */
