@@ -972,6 +972,7 @@ CASES = {
     "shader_cornell_accumulation": lambda: case_shader("cornell", pathTracingIteration=12, timestamp=17),
     "shader_mix": lambda: case_shader("mix"),
     "shader_textured": lambda: case_shader("textured"),
+    "shader_mix_one_lamp": lambda: case_shader("mix_one_lamp"),
     "shader_cornell_opaque_moot": lambda: case_shader("cornell_opaque", moot=True),
     "shader_sticks_moot": lambda: case_shader("sticks", moot=True),
     "shader_triangles_moot": lambda: case_shader("triangles", moot=True, pathTracingIteration=3),
