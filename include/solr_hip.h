@@ -292,6 +292,16 @@ const BitmapBuffer *solr_hip_image_wait(int ticket);
  * kernel - best for whole frames with two buffer sets; 1 the frame's own stream (it delays that stream's next frame
  * only) - best for a rank's strip of an N-GPU frame with three buffer sets (profiles/r4/readback_routes.txt) */
 void solr_hip_set_copy_route(int onTheFramesOwnStream);
+/* One frame at a time (the reference's render_begin ... render_end, CudaKernel.cpp:174-312): kernel, then 6 MB over PCIe,
+ * nothing rendering meanwhile.  solr_hip_stream_next_image(1) before a cudaRender makes that frame's waves say when a
+ * band of tile rows is complete (eight bands; sol-r_amd/csrc/renderer.h, ImageStreaming); the solr_hip_d2h_image_async
+ * that follows it then puts every band's copy behind the band's word (hipStreamWaitValue32) instead of behind the kernel,
+ * and the image leaves while the rows below still render: 0.30 instead of 0.40 ms per Cornell frame at 1080p
+ * (profiles/r6/api_frame_cornell.txt).  Same bytes.  Applies to whole frames of one device whose RGB image the renderer
+ * itself writes (no neighbourhood post-process, ftRGB), one frame in flight; any other frame is rendered and read back
+ * as before.  Returns 1 when the device can do it, 0 when not (SOLR_HIP_NO_IMAGE_STREAMING=1 says so too).
+ * HipKernel::render_begin asks for it when it runs one frame at a time: an unchanged host gets it. */
+int solr_hip_stream_next_image(int on);
 /* One host image for all ranks of a multi-process job: the ring of page-locked images becomes a POSIX shared-memory
  * segment `name` ("/something"; rank 0 creates it, the others open it), registered with the HIP runtime in every
  * process.  Every rank's solr_hip_d2h_image_async then copies its strip, over its own PCIe link, to its rows of the

@@ -205,6 +205,7 @@ struct Engine
     int costFrames = 0;               /* frames rendered with that geometry */
     bool reorder = false;             /* current decision of the automatic mode */
     bool orderValid = false;          /* tileOrder holds an order for the current geometry */
+    BandCuts orderCuts = {};          /* ... band after band (ImageStreaming); bands = 0: by cost alone */
     unsigned lastSerial = 0;
     bool tileClocks = false; /* diagnostics, solr_hip_enable_tile_clocks */
     int nbTilesTimed = 0;
@@ -263,6 +264,21 @@ struct Engine
     DeviceBuffer deepStack[MAX_FLIGHTS]; /* F_STACK frames: the colour-stack slots beyond the LDS ones, per buffer set */
     int bitmapSide[MAX_FLIGHTS] = {0, 0, 0, 0};
     int flightCopy[MAX_FLIGHTS][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}; /* slot whose copy reads that image, or -1 */
+
+    /* ImageStreaming (renderer.h): the next whole-frame first-pass-or-later frame with the fused RGB conversion counts its
+     * tiles (solr_hip_stream_next_image), and the read-back that follows goes band by band behind the bands' words */
+    bool streamNext = false;
+    bool streamedValid = false;          /* the frame rendered last counted its tiles: serial, image and bands below */
+    const void *streamedBitmap = nullptr;
+    unsigned streamSerial = 0;           /* streamed frames since the counters were zeroed */
+    long streamKey[3] = {0, 0, 0};       /* tilesX, tile rows, image width the counters belong to */
+    DeviceBuffer streamCounters;         /* rowDone | bandDone | the StreamPlan */
+    StreamPlan streamPlan = {};          /* host image of the plan */
+    int streamBands = 0;
+    hipStream_t bandStream[2] = {};      /* bands go out on the copy stream and these two, in turn */
+    hipEvent_t bandEvent[2] = {};
+    long streamedDelivered = 0;          /* images that left in bands */
+    int streamSupport = -1;              /* hipDeviceAttributeCanUseStreamWaitValue (-1: not asked yet) */
 
     /* device-side rotation (solr_hip_rotate_primitives): what to refit, in which order */
     DeviceBuffer movable, refitPlan;
@@ -339,6 +355,9 @@ inline DeviceBuffer &flightBitmap(int f) { return g.bitmapSide[f] ? g.bitmapAlt[
 /* nothing may touch scene or frame buffers while a frame is still in flight on the other stream */
 inline void quiesce()
 {
+    for (hipStream_t band : g.bandStream)
+        if (band)
+            (void)hipStreamSynchronize(band);
     for (hipStream_t extra : g.extraStream)
         if (extra)
             (void)hipStreamSynchronize(extra);
@@ -479,6 +498,10 @@ void d2hBitmapOne(const SceneInfo &sceneInfo, BitmapBuffer *bitmap, PrimitiveXYI
 void d2hBitmapWait();
 /* solr_image_ring.hip: the ring of page-locked host images behind solr_hip_d2h_image_async */
 void releaseImageRing();
+void releaseImageStreaming();
+bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], int *bands);
+bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream);
+void sealImageStreaming(hipStream_t stream, const StreamPlan *plan);
 void ensureCopyStream();
 bool ensureImageRing();
 int nextTicket(int *slot);
@@ -524,7 +547,7 @@ void filter(hipStream_t stream, const SceneInfo &si, const PostProcessingInfo &p
 void cartoon(hipStream_t stream, const SceneInfo &si, const PostProcessingInfo &ppi, int nbRows, const PixelRecord *pp,
              unsigned char *bitmap);
 void orderTiles(hipStream_t stream, const unsigned *cost, unsigned *snapshot, unsigned *order, int nbTiles,
-                volatile unsigned *hostStats, int flights);
+                volatile unsigned *hostStats, int flights, const BandCuts &cuts);
 void packDepthRows(hipStream_t stream, const PixelRecord *pp, int W, int row0, int n, float *out);
 } // namespace solrpost
 

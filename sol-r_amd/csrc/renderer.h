@@ -39,6 +39,35 @@ struct FrameArgs
     unsigned *tileCost;        /* out: duration of every tile of this frame, 100 MHz ticks */
     const unsigned *tileOrder; /* in: workgroup -> order entry (see ORDER_* below), most expensive tiles first */
     int nbTiles;               /* tiles of the frame; the ordered launch has 3 * SPLIT_TILES_MAX workgroups more */
+    /* ImageStreaming (see StreamPlan below); rowDone null when off */
+    unsigned *rowDone;                    /* one word per tile row, 64 words apart: units of it rendered, over all streamed frames */
+    const struct StreamPlan *streamPlan;  /* bands of tile rows and the words the copy streams wait on */
+    unsigned streamSerial;                /* this frame is the n-th streamed frame since the counters were zeroed */
+};
+
+/* ImageStreaming.  A host that takes one frame at a time waits for the kernel and then for 6 MB over PCIe (0.26 + 0.13 ms
+ * for the Cornell box at 1080p), and nothing renders meanwhile.  The image of such a frame leaves in bands of tile rows
+ * WHILE the kernel renders the rows below: every wave, its pixels stored with device scope and the stores waited for,
+ * counts itself into its tile row (4 units a whole tile, 1 a quadrant wave of a split tile); the wave that completes a
+ * row counts the row into its band, and the wave that completes a band stores the frame's serial into the band's word
+ * of signal memory, which a copy stream is waiting on (hipStreamWaitValue32) with the band's copy behind it
+ * (solr_image_ring.hip, copyStripBehindFrame).  No launch boundary, no second kernel, nobody polls: what was tried
+ * instead is in tools/stream_probe.hip / profiles/r6/stream_probe.txt.  Counters only ever grow; the host zeroes them
+ * when the frame geometry changes or the count nears 2^32. */
+#define SOLR_STREAM_BANDS_MAX 8
+struct StreamPlan
+{
+    unsigned *bandDone;                      /* one word per band, 64 words apart: rows of it complete, over all streamed frames */
+    unsigned *signal[SOLR_STREAM_BANDS_MAX]; /* signal memory: the serial of the newest frame whose band is complete */
+    int bands;
+    int firstRow[SOLR_STREAM_BANDS_MAX + 1]; /* band b is the tile rows firstRow[b] ... firstRow[b + 1] - 1; firstRow[bands] = all of them */
+};
+
+/* the same cuts in tiles, for the sort that launches a streamed frame band after band (k_orderTiles); bands = 0: by cost alone */
+struct BandCuts
+{
+    int bands;
+    int firstTile[SOLR_STREAM_BANDS_MAX + 1];
 };
 
 /* An entry of the launch order: the tile in bits 0-27, and in bits 28-30 which part of it this wave renders -

@@ -348,7 +348,30 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
                 c.y /= d;
                 c.z /= d;
             }
-            makeColor(si, c, bitmap, index);
+            if (F.rowDone)
+                makeColor<true>(si, c, bitmap, index);
+            else
+                makeColor(si, c, bitmap, index);
+        }
+    }
+    if (F.rowDone) /* ImageStreaming (renderer.h): this tile's bytes are out; is its row, is its band? */
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned units = partAgain ? 1u : (unsigned)SPLIT_PARTS;
+        unsigned before = 0u;
+        if (laneAgain == 0)
+            before = __hip_atomic_fetch_add(F.rowDone + 64 * tyAgain, units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        before = (unsigned)__builtin_amdgcn_readfirstlane((int)before);
+        if (before + units == F.streamSerial * (unsigned)(F.tilesX * SPLIT_PARTS) && laneAgain == 0)
+        {
+            const StreamPlan *plan = F.streamPlan;
+            int band = 0;
+            while (band + 1 < plan->bands && tyAgain >= plan->firstRow[band + 1])
+                ++band;
+            const int rows = plan->firstRow[band + 1] - plan->firstRow[band];
+            const unsigned rowsBefore = __hip_atomic_fetch_add(plan->bandDone + 64 * band, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rowsBefore + 1u == F.streamSerial * (unsigned)rows)
+                __hip_atomic_store(plan->signal[band], F.streamSerial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 

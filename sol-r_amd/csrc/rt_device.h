@@ -3210,6 +3210,9 @@ SOLR_DEV v3 launchVolumeRendering(const Scene &S, bool active, int index, v3 ray
 }
 
 /* GS:132-165 */
+/* DEVICE_SCOPE: the three bytes go out with device scope - written through to memory, where the copy engine reads a band
+ * of the image while other tiles still render (renderer.h, ImageStreaming); ftRGB only (the host streams no other) */
+template <bool DEVICE_SCOPE = false>
 SOLR_DEV void makeColor(const SceneInfo &si, v3 color, unsigned char *__restrict__ bitmap, int index)
 {
     color.x = (color.x > 1.f) ? 1.f : color.x;
@@ -3218,6 +3221,14 @@ SOLR_DEV void makeColor(const SceneInfo &si, v3 color, unsigned char *__restrict
     color.x = (color.x < 0.f) ? 0.f : color.x;
     color.y = (color.y < 0.f) ? 0.f : color.y;
     color.z = (color.z < 0.f) ? 0.f : color.z;
+    if (DEVICE_SCOPE)
+    {
+        unsigned char *at = bitmap + (size_t)index * SOLR_COLOR_DEPTH;
+        __hip_atomic_store(at, (unsigned char)(color.x * 255.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(at + 1, (unsigned char)(color.y * 255.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(at + 2, (unsigned char)(color.z * 255.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (si.frameBufferType == ftBGR)
     {
         int y = index / si.size.y;

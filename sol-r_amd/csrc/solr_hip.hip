@@ -274,6 +274,7 @@ static void finalizeOne()
     }
     dropExtraStreams();
     releaseImageRing();
+    releaseImageStreaming();
     if (g.orderEvent)
         (void)hipEventDestroy(g.orderEvent);
     g.orderEvent = nullptr;

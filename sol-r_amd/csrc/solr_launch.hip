@@ -361,6 +361,19 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         F.tileClock = (unsigned long long *)g.tileClock.ptr;
         g.nbTilesTimed = (int)grid.x;
     }
+    /* ImageStreaming (renderer.h): asked for (solr_hip_stream_next_image), and this is a frame whose image the kernel
+     * itself writes, whole, on one device, one frame at a time */
+    g.streamedValid = false;
+    BandCuts streamCuts = {};
+    {
+        int rows[SOLR_STREAM_BANDS_MAX + 1];
+        if (g.streamNext && !counting && !g.recordNext && F.fuseDefault && sceneInfo.frameBufferType != ftBGR && !twoFlights() &&
+            g.nbRows < 0 && gDevices == 1 && !g.boundBitmap && !g.sharedRing && imageStreamingCuts(tilesY, rows, &streamCuts.bands))
+            for (int b = 0; b <= streamCuts.bands; ++b)
+                streamCuts.firstTile[b] = rows[b] * F.tilesX;
+    }
+    g.streamNext = false;
+    bool streamCandidate = streamCuts.bands > 0;
     if (g.tileScheduling > 0 && !counting)
     {
         const long key[6] = {(long)grid.x, F.tilesX, F.firstRow, F.nbRows, sceneInfo.size.x, sceneInfo.size.y};
@@ -404,11 +417,22 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                 g.reorder = true;
             else if (2ull * mx * grid.x < 3ull * sum)
                 g.reorder = false;
+            /* a frame whose longest tile would be rendered by four quadrant waves (k_orderTiles' criterion, for one frame
+             * in flight) keeps the order that puts those first: it is not streamed */
+            const float mean = (float)sum / (float)grid.x;
+            const float critical = fmaxf(2.f * mean, (float)sum / 5120.f);
+            if (g.reorder && (unsigned)(critical * (64.f / ((float)mx + 1.f))) < 63u)
+                streamCandidate = false;
         }
         F.tileCost = (unsigned *)g.tileCost.ptr;
         /* statistics (and, in cost order, a fresh order) every sixteenth frame, and at once when the
          * decision has just changed; in between the last order is reused */
         const bool ordered = g.costFrames > 0 && (g.tileScheduling == 2 || g.reorder);
+        /* a streamed frame takes its tiles band after band (k_orderTiles): an order by cost alone is re-made for it at
+         * once; the other way round the banded order serves until the next regular refresh */
+        const BandCuts cuts = streamCandidate ? streamCuts : BandCuts();
+        if (ordered && g.orderValid && cuts.bands > 0 && memcmp(&g.orderCuts, &cuts, sizeof(cuts)) != 0)
+            g.orderValid = false;
         const bool refresh = g.costFrames > 0 && (g.costFrames % 16 == 1 || (ordered && !g.orderValid));
         const bool sort = ordered && refresh;
         if (!ordered)
@@ -420,11 +444,12 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             const int target = sort ? (g.orderBuffer ^ 1) : g.orderBuffer;
             DeviceBuffer &orderOut = target ? g.tileOrder2 : g.tileOrder;
             solrpost::orderTiles(stream, (const unsigned *)g.tileCost.ptr, (unsigned *)g.tileCostSnapshot.ptr,
-                                 (unsigned *)orderOut.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev, sort ? activeFlights() : 0);
+                                 (unsigned *)orderOut.ptr, (int)grid.x, (volatile unsigned *)g.hostStatsDev, sort ? activeFlights() : 0, cuts);
             HIPCHECK(hipGetLastError());
             if (sort)
             {
                 g.orderValid = true;
+                g.orderCuts = cuts;
                 g.orderBuffer = target;
                 if (twoFlights())
                 {
@@ -564,6 +589,9 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         if (g.variant == 10)
             HIPCHECK(hipMemsetAsync(F.deepStack, 0xff, (size_t)deepSlots * (size_t)F.deepStride * sizeof(float4), stream));
     }
+    /* (tiles in launch order, or band after band: an order by cost alone completes every band at the end) */
+    const bool streamed = streamCandidate && cntPtr == (unsigned long long *)g.counters.ptr &&
+                          (!F.tileOrder || memcmp(&g.orderCuts, &streamCuts, sizeof(streamCuts)) == 0) && armImageStreaming(F, tilesY, stream);
     {
         HostSpan launch("  of which the kernel launch");
         hipLaunchKernelGGL(fn, launchGrid, block, ldsBytes, stream, S, F, ppPtr, idPtr, bitmap, cntPtr);
@@ -573,6 +601,12 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     {
         HIPCHECK(hipEventRecord(e1, stream));
         g.events.push_back(std::make_pair(e0, e1));
+    }
+    if (streamed)
+    {
+        sealImageStreaming(stream, F.streamPlan);
+        g.streamedValid = ok();
+        g.streamedBitmap = bitmap;
     }
 
     g.haloWanted = 0;

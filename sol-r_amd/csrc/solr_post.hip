@@ -158,6 +158,15 @@ __global__ __launch_bounds__(256) void k_cartoon(const SceneInfo si, const PostP
  * atomics per frame serialise at the memory side and tripled the frame time.) */
 __device__ unsigned orderSerial = 0u;
 
+__device__ __forceinline__ unsigned bandOfTile(const BandCuts &cuts, int tile)
+{
+    unsigned band = 0u;
+#pragma unroll
+    for (int b = 1; b < SOLR_STREAM_BANDS_MAX; ++b)
+        band += (b < cuts.bands && tile >= cuts.firstTile[b]) ? 1u : 0u;
+    return band;
+}
+
 /* Frames in flight: the frame on the other stream may still be storing its tiles' costs while this kernel
  * runs.  Every cost is therefore read from `cost` exactly ONCE, into `snapshot` (private to the sort, written
  * and read by this workgroup only); maximum, histogram and scatter all work on that one stable copy, so the
@@ -169,8 +178,13 @@ __device__ unsigned orderSerial = 0u;
  * one per other tile, ORDER_NOTHING to the end. */
 __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsigned *__restrict__ snapshot,
                                                       unsigned *__restrict__ order, int n,
-                                                      volatile unsigned *hostStats, int sort)
+                                                      volatile unsigned *hostStats, int sort, const BandCuts cuts)
 {
+    /* cuts.bands > 0 (ImageStreaming, renderer.h: the image leaves in bands of tile rows while the kernel renders): the
+     * order is band after band - at most eight - and by cost inside a band, so that the bands
+     * complete one after the other and only the last one has a tail to keep short; no tile is split (the host asks for
+     * this order only where none would be).  Bins: band (3 bits, the first band in the highest bins), class (6), and
+     * one bit of the tile index instead of four. */
     __shared__ unsigned nbSplit;
     __shared__ unsigned splitClass;
     __shared__ unsigned bins[1024];
@@ -237,7 +251,11 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
         {
             const int i = base + k * 1024 + t;
             if (i < n)
-                atomicAdd(&bins[(min(63u, (unsigned)((float)c[k] * toClass)) << 4) | ((unsigned)i & 15u)], 1u);
+            {
+                const unsigned cls = min(63u, (unsigned)((float)c[k] * toClass));
+                atomicAdd(&bins[cuts.bands > 0 ? ((7u - bandOfTile(cuts, i)) << 7) | (cls << 1) | ((unsigned)i & 1u)
+                                               : (cls << 4) | ((unsigned)i & 15u)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
     }
     __syncthreads();
     if (t == 0)
-        nbSplit = splitClass < 64u ? scan[1023 - (splitClass << 4)] : 0u;
+        nbSplit = (splitClass < 64u && cuts.bands <= 0) ? scan[1023 - (splitClass << 4)] : 0u;
     __syncthreads();
     const unsigned split = nbSplit;
     for (int i = n + (SPLIT_PARTS - 1) * (int)split + t; i < n + (SPLIT_PARTS - 1) * SPLIT_TILES_MAX; i += 1024)
@@ -303,7 +321,9 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
             const int i = base + k * 1024 + t;
             if (i < n)
             {
-                const unsigned b = (min(63u, (unsigned)((float)c[k] * toClass)) << 4) | ((unsigned)i & 15u);
+                const unsigned cls = min(63u, (unsigned)((float)c[k] * toClass));
+                const unsigned b = cuts.bands > 0 ? ((7u - bandOfTile(cuts, i)) << 7) | (cls << 1) | ((unsigned)i & 1u)
+                                                  : (cls << 4) | ((unsigned)i & 15u);
                 const unsigned at = atomicAdd(&bins[b], 1u); /* position in descending order of cost */
                 if (at < split)
                     for (unsigned q = 0; q < (unsigned)SPLIT_PARTS; ++q)
@@ -1062,9 +1082,9 @@ void cartoon(hipStream_t stream, const SceneInfo &si, const PostProcessingInfo &
 }
 
 void orderTiles(hipStream_t stream, const unsigned *cost, unsigned *snapshot, unsigned *order, int nbTiles,
-                volatile unsigned *hostStats, int flights)
+                volatile unsigned *hostStats, int flights, const BandCuts &cuts)
 {
-    hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, stream, cost, snapshot, order, nbTiles, hostStats, flights);
+    hipLaunchKernelGGL(k_orderTiles, dim3(1), dim3(1024), 0, stream, cost, snapshot, order, nbTiles, hostStats, flights, cuts);
 }
 
 void packDepthRows(hipStream_t stream, const PixelRecord *pp, int W, int row0, int n, float *out)

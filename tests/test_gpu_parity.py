@@ -1083,3 +1083,136 @@ def test_thin_leaves_follow_a_rotation_on_the_device(solr, oracle):
     finally:
         hip.solr_hip_set_variant(0)
         k.finalize()
+
+
+@pytest.mark.gpu
+def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(solr):
+    """render_begin / render_end one frame at a time (solr_hip_stream_next_image; csrc/renderer.h, ImageStreaming): the
+    frame's waves count themselves into tile rows and bands, every band's copy waits for the band's word instead of the
+    kernel.  Same bytes as the frame read back behind the kernel (SolR_RunKernel's route into the caller's array): with
+    a moving camera, through refinement and accumulation passes, around a frame with a neighbourhood post-process (not
+    streamed), through a reshape (new counters), after frames in flight were on and off again, and at 1080p on the
+    cost-ordered launch with its split tiles (the mesh)."""
+    import ctypes as C
+    hip = solr.hip_lib()
+    W, H = 200, 136
+    k = solr.Kernel(engine="hip", deterministic_seed=1)
+    solr.scenes.cornell(k, width=W, height=H, iterations=2, maxPathTracingIterations=40)
+    L = k.L
+
+    def delivered(w, h):
+        ptr = L.SolRx_GetBitmap()
+        return np.frombuffer((C.c_ubyte * (w * h * 3)).from_address(ptr), np.uint8).reshape(h, w, 3).copy()
+
+    def in_bands():
+        return hip.solr_hip_stream_next_image(-2)
+
+    try:
+        if hip.solr_hip_stream_next_image(0) != 1:
+            pytest.skip("no hipStreamWaitValue32 on this device (or SOLR_HIP_NO_IMAGE_STREAMING=1)")
+        assert L.SolRx_Render(0.0) == 0      # (the frame that brings the device up is not streamed)
+        # (a frame whose longest tile the cost-ordered launch would split into quadrant waves is not streamed either -
+        # this small one would be, now and then; the 1080p test below runs with the order as the engine chooses it)
+        hip.solr_hip_set_tile_scheduling(0)
+        # a moving camera; every frame both ways
+        for i in range(6):
+            k.set_camera((250.0 * i, 40.0 * i, -15000.0))
+            k.set_scene_info(pathTracingIteration=0)
+            before = in_bands()
+            assert L.SolRx_Render(0.0) == 0
+            assert in_bands() == before + 1, i
+            streamed = delivered(W, H)
+            k.set_scene_info(pathTracingIteration=0)
+            plain = k.render()
+            assert in_bands() == before + 1, i          # (the caller's array: behind the kernel, as ever)
+            assert np.array_equal(streamed, plain), i
+        assert streamed.any()
+        # refinement and accumulation passes
+        expected = []
+        for i in range(14):
+            k.set_scene_info(pathTracingIteration=i)
+            expected.append(k.render().copy())
+        assert any(not np.array_equal(expected[0], e) for e in expected[1:])
+        before = in_bands()
+        for i in range(14):
+            k.set_scene_info(pathTracingIteration=i)
+            assert L.SolRx_Render(0.0) == 0
+            assert np.array_equal(delivered(W, H), expected[i]), i
+        assert in_bands() == before + 14
+        # a frame whose image a post-process kernel writes is not streamed; the one after it is
+        k.set_scene_info(pathTracingIteration=0)
+        k.set_post_processing(solr.ppe_ambientOcclusion, 0.0, 4000.0, 40)
+        before = in_bands()
+        assert L.SolRx_Render(0.0) == 0
+        assert in_bands() == before
+        ao = delivered(W, H)
+        assert np.array_equal(ao, k.render())
+        k.set_post_processing(solr.ppe_none)
+        assert L.SolRx_Render(0.0) == 0
+        assert in_bands() == before + 1
+        assert np.array_equal(delivered(W, H), expected[0]) and not np.array_equal(ao, expected[0])
+        # frames in flight on, off: one at a time streams again
+        L.SolRx_SetFramesInFlight(2)
+        for _ in range(3):
+            assert L.SolRx_Render(0.0) == 0
+        L.SolRx_SetFramesInFlight(1)
+        before = in_bands()
+        assert L.SolRx_Render(0.0) == 0
+        assert in_bands() == before + 1 and np.array_equal(delivered(W, H), expected[0])
+        # another size: the counters are made anew (and a frame with fewer than sixteen tile rows is not streamed)
+        k.set_scene_info(width=320, height=240)
+        before = in_bands()
+        for i in range(3):
+            k.set_camera((100.0 * i, 0.0, -15000.0))
+            assert L.SolRx_Render(0.0) == 0
+            assert np.array_equal(delivered(320, 240), k.render()), i
+        assert in_bands() == before + 3
+        k.set_scene_info(width=160, height=96)
+        before = in_bands()
+        assert L.SolRx_Render(0.0) == 0
+        assert in_bands() == before and np.array_equal(delivered(160, 96), k.render())
+        k.check(0, "image streaming")
+    finally:
+        hip.solr_hip_set_tile_scheduling(1)
+        L.SolRx_SetFramesInFlight(1)
+        k.finalize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["cornell", "height_field"])
+def test_full_size_frames_leave_in_bands_with_the_same_bytes(solr, scene):
+    """... at 1920x1080, forty frames: the Cornell box under a camera that moves (launched band after band, by cost inside
+    a band) and the 100k-triangle mesh, whose horizon tiles the cost-ordered launch renders as four quadrant waves each
+    and first of all - such a frame keeps that order and is read back behind the kernel"""
+    import ctypes as C
+    hip = solr.hip_lib()
+    W, H = 1920, 1080
+    k = solr.Kernel(engine="hip", deterministic_seed=1)
+    kw = dict(width=W, height=H)
+    if scene == "cornell":
+        kw["iterations"] = 3
+    getattr(solr.scenes, scene)(k, **kw)
+    L = k.L
+    try:
+        if hip.solr_hip_stream_next_image(0) != 1:
+            pytest.skip("no hipStreamWaitValue32 on this device (or SOLR_HIP_NO_IMAGE_STREAMING=1)")
+        before = hip.solr_hip_stream_next_image(-2)
+        different = 0
+        last = None
+        for i in range(40):
+            if scene == "cornell":
+                k.set_camera((40.0 * i, 10.0 * i, -15000.0))
+            assert L.SolRx_Render(0.0) == 0
+            ptr = L.SolRx_GetBitmap()
+            streamed = np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3)
+            plain = k.render()
+            assert np.array_equal(streamed, plain), i
+            if last is not None and not np.array_equal(last, plain):
+                different += 1
+            last = plain
+        in_bands = hip.solr_hip_stream_next_image(-2) - before
+        assert in_bands >= 36 if scene == "cornell" else in_bands <= 8, in_bands
+        assert last.any() and (scene != "cornell" or different > 30)
+        k.check(0, "image streaming at 1080p")
+    finally:
+        k.finalize()
