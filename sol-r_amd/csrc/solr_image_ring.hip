@@ -93,6 +93,17 @@ void releaseImageStreaming()
 /* ImageStreaming, the host's part before a launch (renderImpl): counters, plan and band words for this frame geometry
  * - made, or zeroed, when the geometry changes or the row counts near 2^32 - and the frame's serial.  False: this frame is
  * not streamed (no support for hipStreamWaitValue32, an allocation failed: the read-back then takes the plain route). */
+/* The streams the bands' copies go out on: the copy stream alone.  Streams share the runtime's four hardware queues in
+ * the order they were first used; a second stream of copies shortens a frame by 0.003 ms where it gets a queue of its own
+ * and costs 0.09 ms where it lands on the render stream's - its waits then stand behind the kernel they wait for - and
+ * whichever it lands on, the render streams of the frames-in-flight mode are dealt out differently afterwards (0.39 ms
+ * per frame instead of 0.27 with two in flight; profiles/r6/stream_frame.txt).  SOLR_HIP_STREAM_LANES=2|3: experiments. */
+static int streamLanes()
+{
+    static const int lanes = getenv("SOLR_HIP_STREAM_LANES") ? std::max(1, std::min(3, atoi(getenv("SOLR_HIP_STREAM_LANES")))) : 1;
+    return lanes;
+}
+
 /* the bands of a frame of that many tile rows; false: such a frame is not streamed (a device without
  * hipStreamWaitValue32, SOLR_HIP_NO_IMAGE_STREAMING=1, a frame of fewer than sixteen tile rows) */
 bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], int *bands)
@@ -107,8 +118,8 @@ bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], i
     }
     if (!g.streamSupport || tileRows < 2 * SOLR_STREAM_BANDS_MAX)
         return false;
-    /* Three bands of equal height on two streams.  A wait and a copy cost the command processor and the copy engine 15 us
-     * together, a third stream of copies ends up sharing a hardware queue with the render stream, and the more bands
+    /* Three bands of equal height.  A wait and a copy cost the command processor and the copy engine 15 us together, and
+     * the more bands
      * the order of the launch has to respect, the longer the kernel takes (the molecule: 0.357 ms with three, 0.388
      * with five; profiles/r6/stream_frame.txt).  The copy engine moves rows twice as fast as the Cornell kernel
      * renders them: every band but the last has landed before the next is complete.
@@ -155,7 +166,7 @@ bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream)
             if (ok())
                 HIPCHECK(hipStreamWriteValue32(stream, g.streamPlan.signal[b], 0u, 0));
         }
-        for (int k = 0; k < 2 && ok(); ++k)
+        for (int k = 0; k + 1 < streamLanes() && ok(); ++k)
         {
             if (!g.bandStream[k])
                 HIPCHECK(hipStreamCreateWithFlags(&g.bandStream[k], hipStreamNonBlocking));
@@ -288,15 +299,14 @@ void copyStripBehindFrame(BitmapBuffer *image, int slot)
     if (!inlineCopy && g.streamedValid && src == g.streamedBitmap && g.nbRows < 0 && rows == g.height && g.streamBands > 0)
     {
         /* ImageStreaming (renderer.h): the frame's waves say when a band of tile rows is complete; every band's copy
-         * waits for its word, not for the kernel, and the bands go out on two streams in turn (imageStreamingCuts) */
+         * waits for its word, not for the kernel (streamLanes, imageStreamingCuts) */
         const size_t rowBytes = (size_t)g.width * SOLR_COLOR_DEPTH;
         bool used[2] = {false, false};
         for (int b = 0; b < g.streamBands && ok(); ++b)
         {
             const int firstTileRow = g.streamPlan.firstRow[b], lastTileRow = g.streamPlan.firstRow[b + 1];
             const int y0 = firstTileRow * TILE_H, y1 = std::min(rows, lastTileRow * TILE_H);
-            static const int lanes = getenv("SOLR_HIP_STREAM_LANES") ? std::max(1, std::min(3, atoi(getenv("SOLR_HIP_STREAM_LANES")))) : 2;
-            const int lane = b % lanes;
+            const int lane = b % streamLanes();
             const hipStream_t on = lane == 0 ? g.copyStream : g.bandStream[lane - 1];
             if (lane)
                 used[lane - 1] = true;

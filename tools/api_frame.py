@@ -47,6 +47,7 @@ for name, call in (("SolRx_Render (render_begin + render_end)", lambda: k.L.SolR
             call()
         times.append(time.perf_counter() - t0)
     report(name, times)
+    print("    (images that have left in bands while their kernel rendered so far: %d)" % hip.solr_hip_stream_next_image(-2))
 for flights in (2, 3):
     k.L.SolRx_SetFramesInFlight(flights)
     for name, call in (("SolRx_Render, %d frames in flight" % flights, lambda: k.L.SolRx_Render(0.0)),
