@@ -302,6 +302,9 @@ void solr_hip_set_copy_route(int onTheFramesOwnStream);
  * as before.  Returns 1 when the device can do it, 0 when not (SOLR_HIP_NO_IMAGE_STREAMING=1 says so too).
  * HipKernel::render_begin asks for it when it runs one frame at a time: an unchanged host gets it. */
 int solr_hip_stream_next_image(int on);
+/* ... the same into memory of the caller's, waited for (SolR_RunKernel's array): 1 done, 0 the frame rendered last was
+ * not such a frame and nothing was copied (d2h_bitmap then), -1 error */
+int solr_hip_d2h_streamed_image(BitmapBuffer *image);
 /* One host image for all ranks of a multi-process job: the ring of page-locked images becomes a POSIX shared-memory
  * segment `name` ("/something"; rank 0 creates it, the others open it), registered with the HIP runtime in every
  * process.  Every rank's solr_hip_d2h_image_async then copies its strip, over its own PCIe link, to its rows of the

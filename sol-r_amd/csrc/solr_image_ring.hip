@@ -416,6 +416,38 @@ int solr_hip_stream_next_image(int on)
     return g.streamSupport != 0 ? 1 : 0;
 }
 
+/* ... and into memory of the caller's (SolR_RunKernel's array), waited for: behind a cudaRender that counted its tiles, every
+ * band of the image is copied to its rows of `image` as soon as the band's word says so.  1: done; 0: that frame was not
+ * such a frame and nothing was copied (d2h_bitmap is the way then); -1: error. */
+int solr_hip_d2h_streamed_image(BitmapBuffer *image)
+{
+    HostSpan whole("solr_hip_d2h_streamed_image");
+    if (!ready("solr_hip_d2h_streamed_image"))
+        return -1;
+    ARGCHECK(image != nullptr, "solr_hip_d2h_streamed_image: no image");
+    if (!ok())
+        return -1;
+    const int flight = g.current;
+    const void *src = flightBitmap(flight).ptr;
+    if (!g.streamedValid || src != g.streamedBitmap || g.nbRows >= 0 || g.streamBands <= 0)
+        return 0;
+    HIPCHECK(hipSetDevice(g.device));
+    ensureCopyStream();
+    const size_t rowBytes = (size_t)g.width * SOLR_COLOR_DEPTH;
+    for (int b = 0; b < g.streamBands && ok(); ++b)
+    {
+        const int y0 = g.streamPlan.firstRow[b] * TILE_H, y1 = std::min(g.height, g.streamPlan.firstRow[b + 1] * TILE_H);
+        HIPCHECK(hipStreamWaitValue32(g.copyStream, g.streamPlan.signal[b], g.streamSerial, hipStreamWaitValueGte, 0xffffffffu));
+        if (ok() && y1 > y0)
+            HIPCHECK(hipMemcpyAsync(image + rowBytes * y0, (const char *)src + rowBytes * y0, rowBytes * (y1 - y0), hipMemcpyDeviceToHost,
+                                    g.copyStream));
+    }
+    HIPCHECK(hipStreamSynchronize(g.copyStream));
+    g.streamedValid = false;
+    ++g.streamedDelivered;
+    return ok() ? 1 : -1;
+}
+
 int solr_hip_d2h_image_async(void)
 {
     HostSpan whole("solr_hip_d2h_image_async");

@@ -188,11 +188,12 @@ void HipKernel::render_begin(const float timer)
         /* one frame at a time, the image wanted in the engine's own page-locked memory (render_end, not
          * SolR_RunKernel's array): the frame's waves say when a band of rows is complete and the band leaves for the host
          * while the rows below still render (include/solr_hip.h, solr_hip_stream_next_image) */
-        const bool stream = m_flights == 1 && !m_callerImage && solr_hip_stream_next_image(1) == 1;
+        const bool stream = m_flights == 1 && solr_hip_stream_next_image(1) == 1;
         cudaRender(m_occupancyParameters, m_blockSize, sceneInfo, objects, m_postProcessingInfo, m_viewPos, m_viewDir,
                    m_angles);
         mark("render_begin: cudaRender");
-        if (m_flights > 1 || (stream && solr_hip_stream_next_image(-1) == 1))
+        m_streamedToCaller = stream && m_callerImage && solr_hip_stream_next_image(-1) == 1;
+        if (m_flights > 1 || (stream && !m_callerImage && solr_hip_stream_next_image(-1) == 1))
         {
             /* frames in flight: the image starts for the host behind the kernel, on the engine's copy stream */
             const int ticket = solr_hip_d2h_image_async();
@@ -326,7 +327,10 @@ void HipKernel::render_end(BitmapBuffer *image)
         return;
     }
     m_bitmapView = nullptr;
-    d2h_bitmap(m_occupancyParameters, m_sceneInfo, image, nullptr);
+    /* (the frame's bands have been leaving for the host since they were complete: they land in the caller's array) */
+    if (!(m_streamedToCaller && solr_hip_d2h_streamed_image(image) == 1))
+        d2h_bitmap(m_occupancyParameters, m_sceneInfo, image, nullptr);
+    m_streamedToCaller = false;
     m_idsOnDevice = true;
     m_bitmapOnDevice = true;
 }

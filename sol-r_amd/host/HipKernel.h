@@ -72,6 +72,7 @@ private:
     bool m_deviceInitialized;
     bool m_idsOnDevice = false;
     BitmapBuffer *m_callerImage = nullptr; /* SolR_RunKernel: the frame render_begin is about to launch goes to this array */
+    bool m_streamedToCaller = false;       /* ... and that frame counts its tiles: render_end(image) takes it band by band */
     bool m_bitmapOnDevice = false; /* render_end(image) delivered to the caller's array: m_bitmap follows when asked */
     unsigned m_sharedSeed = 0, m_sharedState = 0; /* solr_hip_comm_shared_seed and the generator it seeds (render_begin) */
     int m_flights = 1;            /* frames in flight through render_begin / render_end (setFramesInFlight) */

@@ -1087,12 +1087,12 @@ def test_thin_leaves_follow_a_rotation_on_the_device(solr, oracle):
 
 @pytest.mark.gpu
 def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(solr):
-    """render_begin / render_end one frame at a time (solr_hip_stream_next_image; csrc/renderer.h, ImageStreaming): the
-    frame's waves count themselves into tile rows and bands, every band's copy waits for the band's word instead of the
-    kernel.  Same bytes as the frame read back behind the kernel (SolR_RunKernel's route into the caller's array): with
-    a moving camera, through refinement and accumulation passes, around a frame with a neighbourhood post-process (not
-    streamed), through a reshape (new counters), after frames in flight were on and off again, and at 1080p on the
-    cost-ordered launch with its split tiles (the mesh)."""
+    """render_begin / render_end and SolR_RunKernel one frame at a time (solr_hip_stream_next_image; csrc/renderer.h,
+    ImageStreaming): the frame's waves count themselves into tile rows and bands, every band's copy waits for the band's
+    word instead of the kernel.  The bytes that arrive - in the engine's page-locked image, in the caller's array - are
+    the device's image as d2h_bitmap reads it after the kernel: with a moving camera, through refinement and
+    accumulation passes, around a frame with a neighbourhood post-process (not streamed), through a reshape (new
+    counters), after frames in flight were on and off again."""
     import ctypes as C
     hip = solr.hip_lib()
     W, H = 200, 136
@@ -1104,6 +1104,14 @@ def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(
         ptr = L.SolRx_GetBitmap()
         return np.frombuffer((C.c_ubyte * (w * h * 3)).from_address(ptr), np.uint8).reshape(h, w, 3).copy()
 
+    def on_device(w, h):
+        """the image of the frame rendered last, read back behind the kernel (d2h_bitmap)"""
+        rgb, ids = np.zeros((h, w, 3), np.uint8), np.zeros((h, w, 4), np.int32)
+        si = k.frame_parameters()[0]
+        hip.solr_hip_d2h(C.byref(si), C.c_void_p(rgb.ctypes.data), C.c_void_p(ids.ctypes.data))
+        k.check(0, "solr_hip_d2h")
+        return rgb
+
     def in_bands():
         return hip.solr_hip_stream_next_image(-2)
 
@@ -1114,31 +1122,37 @@ def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(
         # (a frame whose longest tile the cost-ordered launch would split into quadrant waves is not streamed either -
         # this small one would be, now and then; the 1080p test below runs with the order as the engine chooses it)
         hip.solr_hip_set_tile_scheduling(0)
-        # a moving camera; every frame both ways
-        for i in range(6):
+        # a moving camera; both entry points
+        frames = []
+        for i in range(8):
             k.set_camera((250.0 * i, 40.0 * i, -15000.0))
             k.set_scene_info(pathTracingIteration=0)
             before = in_bands()
-            assert L.SolRx_Render(0.0) == 0
+            if i % 2:
+                caller = np.full((H, W, 3), 7, np.uint8)
+                assert L.SolR_RunKernel(0.0, caller.ctypes.data) == 0
+                streamed = caller
+            else:
+                assert L.SolRx_Render(0.0) == 0
+                streamed = delivered(W, H)
             assert in_bands() == before + 1, i
-            streamed = delivered(W, H)
-            k.set_scene_info(pathTracingIteration=0)
-            plain = k.render()
-            assert in_bands() == before + 1, i          # (the caller's array: behind the kernel, as ever)
-            assert np.array_equal(streamed, plain), i
-        assert streamed.any()
+            assert np.array_equal(streamed, on_device(W, H)), i
+            assert np.array_equal(delivered(W, H), streamed), i      # (getBitmap follows SolR_RunKernel's frame)
+            frames.append(streamed.copy())
+        assert frames[0].any() and not np.array_equal(frames[0], frames[7])
         # refinement and accumulation passes
-        expected = []
-        for i in range(14):
-            k.set_scene_info(pathTracingIteration=i)
-            expected.append(k.render().copy())
-        assert any(not np.array_equal(expected[0], e) for e in expected[1:])
+        passes = []
         before = in_bands()
         for i in range(14):
             k.set_scene_info(pathTracingIteration=i)
             assert L.SolRx_Render(0.0) == 0
-            assert np.array_equal(delivered(W, H), expected[i]), i
+            passes.append(delivered(W, H))
+            assert np.array_equal(passes[i], on_device(W, H)), i
         assert in_bands() == before + 14
+        assert any(not np.array_equal(passes[0], e) for e in passes[1:])
+        for i in range(14):                                            # ... the same passes, the other entry point
+            k.set_scene_info(pathTracingIteration=i)
+            assert np.array_equal(k.render(), passes[i]), i
         # a frame whose image a post-process kernel writes is not streamed; the one after it is
         k.set_scene_info(pathTracingIteration=0)
         k.set_post_processing(solr.ppe_ambientOcclusion, 0.0, 4000.0, 40)
@@ -1146,11 +1160,11 @@ def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(
         assert L.SolRx_Render(0.0) == 0
         assert in_bands() == before
         ao = delivered(W, H)
-        assert np.array_equal(ao, k.render())
+        assert np.array_equal(ao, on_device(W, H))
         k.set_post_processing(solr.ppe_none)
         assert L.SolRx_Render(0.0) == 0
         assert in_bands() == before + 1
-        assert np.array_equal(delivered(W, H), expected[0]) and not np.array_equal(ao, expected[0])
+        assert np.array_equal(delivered(W, H), passes[0]) and not np.array_equal(ao, passes[0])
         # frames in flight on, off: one at a time streams again
         L.SolRx_SetFramesInFlight(2)
         for _ in range(3):
@@ -1158,19 +1172,19 @@ def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(
         L.SolRx_SetFramesInFlight(1)
         before = in_bands()
         assert L.SolRx_Render(0.0) == 0
-        assert in_bands() == before + 1 and np.array_equal(delivered(W, H), expected[0])
+        assert in_bands() == before + 1 and np.array_equal(delivered(W, H), passes[0])
         # another size: the counters are made anew (and a frame with fewer than sixteen tile rows is not streamed)
         k.set_scene_info(width=320, height=240)
         before = in_bands()
         for i in range(3):
             k.set_camera((100.0 * i, 0.0, -15000.0))
             assert L.SolRx_Render(0.0) == 0
-            assert np.array_equal(delivered(320, 240), k.render()), i
+            assert np.array_equal(delivered(320, 240), on_device(320, 240)), i
         assert in_bands() == before + 3
         k.set_scene_info(width=160, height=96)
         before = in_bands()
         assert L.SolRx_Render(0.0) == 0
-        assert in_bands() == before and np.array_equal(delivered(160, 96), k.render())
+        assert in_bands() == before and np.array_equal(delivered(160, 96), on_device(160, 96))
         k.check(0, "image streaming")
     finally:
         hip.solr_hip_set_tile_scheduling(1)
@@ -1179,11 +1193,12 @@ def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene", ["cornell", "height_field"])
+@pytest.mark.parametrize("scene", ["cornell", "height_field", "molecule"])
 def test_full_size_frames_leave_in_bands_with_the_same_bytes(solr, scene):
-    """... at 1920x1080, forty frames: the Cornell box under a camera that moves (launched band after band, by cost inside
-    a band) and the 100k-triangle mesh, whose horizon tiles the cost-ordered launch renders as four quadrant waves each
-    and first of all - such a frame keeps that order and is read back behind the kernel"""
+    """... at 1920x1080, forty frames, both entry points in turn: the Cornell box under a camera that moves and the
+    molecule (launched band after band, by cost inside a band), and the 100k-triangle mesh, whose horizon tiles the
+    cost-ordered launch renders as four quadrant waves each and first of all - such a frame keeps that order and is read
+    back behind the kernel"""
     import ctypes as C
     hip = solr.hip_lib()
     W, H = 1920, 1080
@@ -1199,19 +1214,26 @@ def test_full_size_frames_leave_in_bands_with_the_same_bytes(solr, scene):
         before = hip.solr_hip_stream_next_image(-2)
         different = 0
         last = None
+        plain, ids = np.zeros((H, W, 3), np.uint8), np.zeros((H, W, 4), np.int32)
+        caller = np.zeros((H, W, 3), np.uint8)
         for i in range(40):
             if scene == "cornell":
                 k.set_camera((40.0 * i, 10.0 * i, -15000.0))
-            assert L.SolRx_Render(0.0) == 0
-            ptr = L.SolRx_GetBitmap()
-            streamed = np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3)
-            plain = k.render()
+            if i % 2:
+                assert L.SolR_RunKernel(0.0, caller.ctypes.data) == 0
+                streamed = caller
+            else:
+                assert L.SolRx_Render(0.0) == 0
+                ptr = L.SolRx_GetBitmap()
+                streamed = np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3)
+            si = k.frame_parameters()[0]
+            hip.solr_hip_d2h(C.byref(si), C.c_void_p(plain.ctypes.data), C.c_void_p(ids.ctypes.data))
             assert np.array_equal(streamed, plain), i
             if last is not None and not np.array_equal(last, plain):
                 different += 1
-            last = plain
+            last = plain.copy()
         in_bands = hip.solr_hip_stream_next_image(-2) - before
-        assert in_bands >= 36 if scene == "cornell" else in_bands <= 8, in_bands
+        assert (in_bands <= 8) if scene == "height_field" else (in_bands >= 36), in_bands
         assert last.any() and (scene != "cornell" or different > 30)
         k.check(0, "image streaming at 1080p")
     finally:
