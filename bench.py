@@ -587,6 +587,26 @@ def main():
             frame()
             hip.solr_hip_d2h(C.byref(si), C.c_void_p(host_rgb.ctypes.data), None)
         with_image_d2h = (time.perf_counter() - ta) / n_extra
+        # ... and with the image leaving in bands while the kernel renders (include/solr_hip.h solr_hip_stream_next_image:
+        # what HipKernel's render_begin / render_end and SolR_RunKernel do one frame at a time); frames that cannot be
+        # streamed (a neighbourhood post-process, a tile the launch splits) are read back behind the kernel as above
+        in_bands = None
+        if hip.solr_hip_stream_next_image(0) == 1:
+            def streamed_frame():
+                hip.solr_hip_stream_next_image(1)
+                frame()
+                if hip.solr_hip_d2h_streamed_image(C.c_void_p(host_rgb.ctypes.data)) != 1:
+                    hip.solr_hip_d2h(C.byref(si), C.c_void_p(host_rgb.ctypes.data), None)
+            for _ in range(20):                  # (the launch order of a streamed frame settles)
+                streamed_frame()
+            left_before = hip.solr_hip_stream_next_image(-2)
+            ta = time.perf_counter()
+            for _ in range(n_extra):
+                streamed_frame()
+            in_bands = ((time.perf_counter() - ta) / n_extra, hip.solr_hip_stream_next_image(-2) - left_before)
+            for _ in range(20):                  # ... and the order by cost alone comes back for what follows
+                frame()
+            sync()
         # the frames left in HBM, pipelined over the engine's buffer sets (earlier rounds' headline: nothing delivered)
         device_resident = None
         if not cfg4:
@@ -610,6 +630,10 @@ def main():
                                                 "(the reference's render_begin / render_end, SURVEY.md 8d)"),
                  "cudaRender_plus_image": (with_image_d2h, "render + read-back of the RGB image alone (the ids stay on "
                                            "the device until picking asks: HipKernel::render_end)")}
+        if in_bands:
+            rates["cudaRender_plus_image_in_bands"] = (
+                in_bands[0], "render + the RGB image leaving in bands of tile rows while the kernel renders the rows below "
+                "(%d of %d frames did; HipKernel's render_begin / render_end and SolR_RunKernel, one frame at a time)" % (in_bands[1], n_extra))
         if device_resident:
             rates["pipelined_device_resident"] = (
                 device_resident, "%d frames in flight, the image left in HBM, nothing delivered (what earlier rounds "
