@@ -293,17 +293,20 @@ const BitmapBuffer *solr_hip_image_wait(int ticket);
  * only) - best for a rank's strip of an N-GPU frame with three buffer sets (profiles/r4/readback_routes.txt) */
 void solr_hip_set_copy_route(int onTheFramesOwnStream);
 /* One frame at a time (the reference's render_begin ... render_end, CudaKernel.cpp:174-312): kernel, then 6 MB over PCIe,
- * nothing rendering meanwhile.  solr_hip_stream_next_image(1) before a cudaRender makes that frame's waves say when a
- * band of tile rows is complete (eight bands; sol-r_amd/csrc/renderer.h, ImageStreaming); the solr_hip_d2h_image_async
- * that follows it then puts every band's copy behind the band's word (hipStreamWaitValue32) instead of behind the kernel,
- * and the image leaves while the rows below still render: 0.30 instead of 0.40 ms per Cornell frame at 1080p
+ * nothing rendering meanwhile.  solr_hip_stream_next_image(1) before a cudaRender makes that frame's waves say - in words
+ * of page-locked host memory - when a band of tile rows is complete (three bands; sol-r_amd/csrc/renderer.h,
+ * ImageStreaming); solr_hip_d2h_streamed_image(image) behind it copies every band to its rows of `image` (host memory of
+ * any kind) as soon as its word has come - or the kernel has ended, whichever is first - and returns when the last has
+ * landed: 1 done, 0 the frame rendered last was not such a frame and nothing was copied (d2h_bitmap then), -1 error.
+ * The image leaves while the rows below still render: 0.32 instead of 0.40 ms per Cornell frame at 1080p
  * (profiles/r6/api_frame_cornell.txt).  Same bytes.  Applies to whole frames of one device whose RGB image the renderer
- * itself writes (no neighbourhood post-process, ftRGB), one frame in flight; any other frame is rendered and read back
- * as before.  Returns 1 when the device can do it, 0 when not (SOLR_HIP_NO_IMAGE_STREAMING=1 says so too).
- * HipKernel::render_begin asks for it when it runs one frame at a time: an unchanged host gets it. */
+ * itself writes (no neighbourhood post-process, ftRGB), one frame in flight, no tile that the cost-ordered launch would
+ * render as four quadrant waves (such a frame keeps that order); any other frame is rendered and read back as before.
+ * solr_hip_stream_next_image returns 1 when frames can be streamed, 0 when not (SOLR_HIP_NO_IMAGE_STREAMING=1); on = -1:
+ * was the frame rendered last such a frame (1 / 0); on = -2: how many images have left in bands since initialize_scene.
+ * HipKernel's render_begin / render_end and SolR_RunKernel do this when they run one frame at a time: an unchanged host
+ * gets it. */
 int solr_hip_stream_next_image(int on);
-/* ... the same into memory of the caller's, waited for (SolR_RunKernel's array): 1 done, 0 the frame rendered last was
- * not such a frame and nothing was copied (d2h_bitmap then), -1 error */
 int solr_hip_d2h_streamed_image(BitmapBuffer *image);
 /* One host image for all ranks of a multi-process job: the ring of page-locked images becomes a POSIX shared-memory
  * segment `name` ("/something"; rank 0 creates it, the others open it), registered with the HIP runtime in every
@@ -395,7 +398,8 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
  * the frame's heavy tiles first (solr_post.hip); 10 = the colour-stack slots an F_STACK frame keeps in HBM filled with
  * NaNs before every launch (they are never zeroed: no slot is read before the frame has written it); 12 = no walk takes
  * the copies of the order-free lists with sorted bounds (the node loop without its min / max, rt_device.h
- * SOLR_ORDER_SORTED).  Every setting renders the same frame. */
+ * SOLR_ORDER_SORTED); 13 = a streamed frame (solr_hip_stream_next_image) whose waves do not write the bands' words: the
+ * host goes by the end of the kernel (solr_hip_d2h_streamed_image).  Every setting renders the same frame. */
 void solr_hip_set_variant(int variant);
 /* Bounce rays (|direction| = 1 - rayEpsilon) of the long-list triangle kernels on the order-free lists, checked: lanes
  * whose hit has a rival the reference's cut-off could have preferred are walked again in the reference's order

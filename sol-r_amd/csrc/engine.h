@@ -265,8 +265,8 @@ struct Engine
     int bitmapSide[MAX_FLIGHTS] = {0, 0, 0, 0};
     int flightCopy[MAX_FLIGHTS][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}; /* slot whose copy reads that image, or -1 */
 
-    /* ImageStreaming (renderer.h): the next whole-frame first-pass-or-later frame with the fused RGB conversion counts its
-     * tiles (solr_hip_stream_next_image), and the read-back that follows goes band by band behind the bands' words */
+    /* ImageStreaming (renderer.h): the next frame counts its tiles if it can (solr_hip_stream_next_image), and
+     * solr_hip_d2h_streamed_image then sends its image off band by band as the bands' words come */
     bool streamNext = false;
     bool streamedValid = false;          /* the frame rendered last counted its tiles: serial, image and bands below */
     const void *streamedBitmap = nullptr;
@@ -275,10 +275,10 @@ struct Engine
     DeviceBuffer streamCounters;         /* rowDone | bandDone | the StreamPlan */
     StreamPlan streamPlan = {};          /* host image of the plan */
     int streamBands = 0;
-    hipStream_t bandStream[2] = {};      /* bands go out on the copy stream and these two, in turn */
-    hipEvent_t bandEvent[2] = {};
+    unsigned *streamHostWords = nullptr; /* StreamPlan::hostWord, the host's address */
+    hipEvent_t streamRendered = nullptr; /* behind the kernel of the streamed frame rendered last */
     long streamedDelivered = 0;          /* images that left in bands */
-    int streamSupport = -1;              /* hipDeviceAttributeCanUseStreamWaitValue (-1: not asked yet) */
+    int streamSupport = -1;              /* 1 / 0; -1: not asked yet (SOLR_HIP_NO_IMAGE_STREAMING) */
 
     /* device-side rotation (solr_hip_rotate_primitives): what to refit, in which order */
     DeviceBuffer movable, refitPlan;
@@ -355,9 +355,6 @@ inline DeviceBuffer &flightBitmap(int f) { return g.bitmapSide[f] ? g.bitmapAlt[
 /* nothing may touch scene or frame buffers while a frame is still in flight on the other stream */
 inline void quiesce()
 {
-    for (hipStream_t band : g.bandStream)
-        if (band)
-            (void)hipStreamSynchronize(band);
     for (hipStream_t extra : g.extraStream)
         if (extra)
             (void)hipStreamSynchronize(extra);
@@ -501,7 +498,7 @@ void releaseImageRing();
 void releaseImageStreaming();
 bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], int *bands);
 bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream);
-void sealImageStreaming(hipStream_t stream, const StreamPlan *plan);
+void markStreamedFrame(hipStream_t stream);
 void ensureCopyStream();
 bool ensureImageRing();
 int nextTicket(int *slot);

@@ -41,7 +41,7 @@ struct FrameArgs
     int nbTiles;               /* tiles of the frame; the ordered launch has 3 * SPLIT_TILES_MAX workgroups more */
     /* ImageStreaming (see StreamPlan below); rowDone null when off */
     unsigned *rowDone;                    /* one word per tile row, 64 words apart: units of it rendered, over all streamed frames */
-    const struct StreamPlan *streamPlan;  /* bands of tile rows and the words the copy streams wait on */
+    const struct StreamPlan *streamPlan;  /* bands of tile rows and the words the host watches */
     unsigned streamSerial;                /* this frame is the n-th streamed frame since the counters were zeroed */
 };
 
@@ -50,15 +50,19 @@ struct FrameArgs
  * WHILE the kernel renders the rows below: every wave, its pixels stored with device scope and the stores waited for,
  * counts itself into its tile row (4 units a whole tile, 1 a quadrant wave of a split tile); the wave that completes a
  * row counts the row into its band, and the wave that completes a band stores the frame's serial into the band's word
- * of signal memory, which a copy stream is waiting on (hipStreamWaitValue32) with the band's copy behind it
- * (solr_image_ring.hip, copyStripBehindFrame).  No launch boundary, no second kernel, nobody polls: what was tried
- * instead is in tools/stream_probe.hip / profiles/r6/stream_probe.txt.  Counters only ever grow; the host zeroes them
- * when the frame geometry changes or the count nears 2^32. */
+ * in page-locked host memory.  The host, which would be waiting for the kernel anyway, watches the words and sends a
+ * band's copy off when its word has come - or when the kernel has ended, whichever is first: everything the kernel
+ * wrote is in memory then, so the scheme cannot lose a byte or wait for ever whatever becomes of a word
+ * (solr_image_ring.hip, solr_hip_d2h_streamed_image).  No launch boundary, no second kernel, no queue that waits on
+ * another: what was tried instead - a resident copier kernel, the last wave of a row copying it, the command processor
+ * waiting on the words (hipStreamWaitValue32: 0.334 ms per Cornell frame against 0.318, and a deadlock under a tool that
+ * runs one dispatch at a time over all queues) - is in tools/stream_probe.hip / profiles/r6/stream_probe.txt.  Counters
+ * only ever grow; the host zeroes them when the frame geometry changes or the count nears 2^32. */
 #define SOLR_STREAM_BANDS_MAX 8
 struct StreamPlan
 {
-    unsigned *bandDone;                      /* one word per band, 64 words apart: rows of it complete, over all streamed frames */
-    unsigned *signal[SOLR_STREAM_BANDS_MAX]; /* signal memory: the serial of the newest frame whose band is complete */
+    unsigned *bandDone; /* one word per band, 64 words apart: rows of it complete, over all streamed frames */
+    unsigned *hostWord; /* one word per band in page-locked host memory: the serial of the newest frame whose band is complete */
     int bands;
     int firstRow[SOLR_STREAM_BANDS_MAX + 1]; /* band b is the tile rows firstRow[b] ... firstRow[b + 1] - 1; firstRow[bands] = all of them */
 };

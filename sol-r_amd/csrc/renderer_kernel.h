@@ -371,7 +371,7 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
             const int rows = plan->firstRow[band + 1] - plan->firstRow[band];
             const unsigned rowsBefore = __hip_atomic_fetch_add(plan->bandDone + 64 * band, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (rowsBefore + 1u == F.streamSerial * (unsigned)rows)
-                __hip_atomic_store(plan->signal[band], F.streamSerial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(plan->hostWord + band, F.streamSerial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 

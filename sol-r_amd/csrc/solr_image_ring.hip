@@ -64,72 +64,45 @@ void releaseImageRing()
  * read back may still be counting into them) */
 void releaseImageStreaming()
 {
-    for (int k = 0; k < 2; ++k)
-    {
-        if (g.bandStream[k])
-        {
-            (void)hipStreamSynchronize(g.bandStream[k]);
-            (void)hipStreamDestroy(g.bandStream[k]);
-        }
-        g.bandStream[k] = nullptr;
-        if (g.bandEvent[k])
-            (void)hipEventDestroy(g.bandEvent[k]);
-        g.bandEvent[k] = nullptr;
-    }
-    for (unsigned *&word : g.streamPlan.signal)
-    {
-        if (word)
-            (void)hipFree(word);
-        word = nullptr;
-    }
+    if (g.streamRendered)
+        (void)hipEventDestroy(g.streamRendered);
+    g.streamRendered = nullptr;
+    if (g.streamHostWords)
+        (void)hipHostFree(g.streamHostWords);
+    g.streamHostWords = nullptr;
     release(g.streamCounters);
     g.streamPlan = StreamPlan();
     g.streamBands = 0;
     g.streamSerial = 0;
     g.streamKey[0] = g.streamKey[1] = g.streamKey[2] = 0;
     g.streamedValid = false;
+    g.streamSupport = -1;
 }
 
 /* ImageStreaming, the host's part before a launch (renderImpl): counters, plan and band words for this frame geometry
  * - made, or zeroed, when the geometry changes or the row counts near 2^32 - and the frame's serial.  False: this frame is
  * not streamed (no support for hipStreamWaitValue32, an allocation failed: the read-back then takes the plain route). */
-/* The streams the bands' copies go out on: the copy stream alone.  Streams share the runtime's four hardware queues in
- * the order they were first used; a second stream of copies shortens a frame by 0.003 ms where it gets a queue of its own
- * and costs 0.09 ms where it lands on the render stream's - its waits then stand behind the kernel they wait for - and
- * whichever it lands on, the render streams of the frames-in-flight mode are dealt out differently afterwards (0.39 ms
- * per frame instead of 0.27 with two in flight; profiles/r6/stream_frame.txt).  SOLR_HIP_STREAM_LANES=2|3: experiments. */
-static int streamLanes()
-{
-    static const int lanes = getenv("SOLR_HIP_STREAM_LANES") ? std::max(1, std::min(3, atoi(getenv("SOLR_HIP_STREAM_LANES")))) : 1;
-    return lanes;
-}
-
-/* the bands of a frame of that many tile rows; false: such a frame is not streamed (a device without
- * hipStreamWaitValue32, SOLR_HIP_NO_IMAGE_STREAMING=1, a frame of fewer than sixteen tile rows) */
+/* the bands of a frame of that many tile rows; false: such a frame is not streamed (SOLR_HIP_NO_IMAGE_STREAMING=1, a frame
+ * of fewer than sixteen tile rows) */
 bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], int *bands)
 {
     if (g.streamSupport < 0)
     {
-        int can = 0;
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, g.device) != hipSuccess)
-            can = 0;
         static const char *off = getenv("SOLR_HIP_NO_IMAGE_STREAMING");
-        g.streamSupport = (can && !(off && off[0] == '1')) ? 1 : 0;
+        g.streamSupport = (off && off[0] == '1') ? 0 : 1;
     }
     if (!g.streamSupport || tileRows < 2 * SOLR_STREAM_BANDS_MAX)
         return false;
-    /* Three bands of equal height.  A wait and a copy cost the command processor and the copy engine 15 us together, and
-     * the more bands
-     * the order of the launch has to respect, the longer the kernel takes (the molecule: 0.357 ms with three, 0.388
-     * with five; profiles/r6/stream_frame.txt).  The copy engine moves rows twice as fast as the Cornell kernel
-     * renders them: every band but the last has landed before the next is complete.
-     * SOLR_HIP_STREAM_BANDS / SOLR_HIP_STREAM_LANES (experiments): up to SOLR_STREAM_BANDS_MAX bands, 1 ... 3 streams;
-     * SOLR_HIP_STREAM_EQUAL=0: bands of 3 : 2 : 1 - the last copy, which nothing hides, the shortest - measured no better
-     * on the Cornell box (0.346 ms either way) and worse on the molecule (0.441 against 0.425: the first band is half the
-     * frame, and its order is what the kernel pays for) */
+    /* Three bands of equal height.  The copy engine moves rows twice as fast as the Cornell kernel renders them: every
+     * band but the last has landed before the next is complete, and the last is what the frame waits for behind its
+     * kernel.  More bands make that one shorter - and the kernel longer, because the launch has to respect them
+     * (k_orderTiles: band after band; the molecule's kernel 0.357 ms with three bands, 0.388 with five;
+     * profiles/r6/stream_frame.txt).  SOLR_HIP_STREAM_BANDS (experiments): 1 ... SOLR_STREAM_BANDS_MAX;
+     * SOLR_HIP_STREAM_EQUAL=0: bands of n : n - 1 : ... : 1, the last copy the shortest - no better on the Cornell box,
+     * worse on the molecule (the first band is half the frame, and its order is what the kernel pays for) */
     static const int wanted = getenv("SOLR_HIP_STREAM_BANDS") ? std::max(1, std::min(SOLR_STREAM_BANDS_MAX, atoi(getenv("SOLR_HIP_STREAM_BANDS")))) : 3;
     static const bool equal = !(getenv("SOLR_HIP_STREAM_EQUAL") && getenv("SOLR_HIP_STREAM_EQUAL")[0] == '0');
-    const int total = equal ? wanted : wanted * (wanted + 1) / 2; /* weights n, n - 1 ... 1 */
+    const int total = equal ? wanted : wanted * (wanted + 1) / 2;
     int row = 0, weight = 0;
     for (int b = 0; b < wanted; ++b)
     {
@@ -159,27 +132,21 @@ bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream)
         if (!ok())
             return false;
         HIPCHECK(hipMemset(g.streamCounters.ptr, 0, words * sizeof(unsigned)));
-        for (int b = 0; b < bands && ok(); ++b)
+        if (!g.streamHostWords)
         {
-            if (!g.streamPlan.signal[b])
-                HIPCHECK(hipExtMallocWithFlags((void **)&g.streamPlan.signal[b], 8, hipMallocSignalMemory));
+            HIPCHECK(hipHostMalloc((void **)&g.streamHostWords, SOLR_STREAM_BANDS_MAX * sizeof(unsigned), hipHostMallocMapped));
             if (ok())
-                HIPCHECK(hipStreamWriteValue32(stream, g.streamPlan.signal[b], 0u, 0));
-        }
-        for (int k = 0; k + 1 < streamLanes() && ok(); ++k)
-        {
-            if (!g.bandStream[k])
-                HIPCHECK(hipStreamCreateWithFlags(&g.bandStream[k], hipStreamNonBlocking));
-            if (!g.bandEvent[k] && ok())
-                HIPCHECK(hipEventCreateWithFlags(&g.bandEvent[k], hipEventDisableTiming));
+                HIPCHECK(hipHostGetDevicePointer((void **)&g.streamPlan.hostWord, g.streamHostWords, 0));
         }
         if (!ok())
         {
-            /* a box that hands out no signal memory: the frames are rendered and read back as they always were */
+            /* no page-locked words: the frames are rendered and read back as they always were */
             (void)solr_hip_clear_error();
             g.streamSupport = 0;
             return false;
         }
+        for (int b = 0; b < SOLR_STREAM_BANDS_MAX; ++b)
+            g.streamHostWords[b] = 0u;
         g.streamPlan.bandDone = (unsigned *)g.streamCounters.ptr + (size_t)64 * tileRows;
         g.streamPlan.bands = bands;
         for (int b = 0; b <= bands; ++b)
@@ -198,25 +165,14 @@ bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream)
     return true;
 }
 
-/* ... and behind the launch, on the frame's own stream: every band's word is brought to the serial once more when the
- * kernel has ended.  The waves have done that long before; this is the promise that a copy stream waiting on a word
- * never waits for ever, whatever happened to the launch. */
-__global__ void k_sealBands(const StreamPlan *plan, int bands, unsigned serial)
+/* ... and behind the launch, on the frame's own stream: the event that says the kernel has ended */
+void markStreamedFrame(hipStream_t stream)
 {
-    if ((int)threadIdx.x < bands)
-        __hip_atomic_store(plan->signal[threadIdx.x], serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!g.streamRendered)
+        HIPCHECK(hipEventCreateWithFlags(&g.streamRendered, hipEventDisableTiming));
+    if (ok())
+        HIPCHECK(hipEventRecord(g.streamRendered, stream));
 }
-
-void sealImageStreaming(hipStream_t stream, const StreamPlan *plan)
-{
-    /* (one small launch: eight hipStreamWriteValue32 behind every frame cost the render stream 0.13 ms) */
-    static const char *seal = getenv("SOLR_HIP_STREAM_SEAL");
-    if (seal && seal[0] == '0')
-        return;
-    hipLaunchKernelGGL(k_sealBands, dim3(1), dim3(64), 0, stream, plan, g.streamBands, g.streamSerial);
-    HIPCHECK(hipGetLastError());
-}
-
 } // namespace solreng
 
 /* Pipelined read-back of the image (SURVEY.md 8d defines the metric over cudaRender + d2h_bitmap; d2h_bitmap waits
@@ -296,37 +252,6 @@ void copyStripBehindFrame(BitmapBuffer *image, int slot)
     static const char *forced = getenv("SOLR_HIP_COPY_INLINE");
     const bool inlineCopy = forced && forced[0] ? forced[0] == '1' : gFirst.copyOnRenderStream;
     const hipStream_t copyOn = inlineCopy ? flightStream(flight) : g.copyStream;
-    if (!inlineCopy && g.streamedValid && src == g.streamedBitmap && g.nbRows < 0 && rows == g.height && g.streamBands > 0)
-    {
-        /* ImageStreaming (renderer.h): the frame's waves say when a band of tile rows is complete; every band's copy
-         * waits for its word, not for the kernel (streamLanes, imageStreamingCuts) */
-        const size_t rowBytes = (size_t)g.width * SOLR_COLOR_DEPTH;
-        bool used[2] = {false, false};
-        for (int b = 0; b < g.streamBands && ok(); ++b)
-        {
-            const int firstTileRow = g.streamPlan.firstRow[b], lastTileRow = g.streamPlan.firstRow[b + 1];
-            const int y0 = firstTileRow * TILE_H, y1 = std::min(rows, lastTileRow * TILE_H);
-            const int lane = b % streamLanes();
-            const hipStream_t on = lane == 0 ? g.copyStream : g.bandStream[lane - 1];
-            if (lane)
-                used[lane - 1] = true;
-            HIPCHECK(hipStreamWaitValue32(on, g.streamPlan.signal[b], g.streamSerial, hipStreamWaitValueGte, 0xffffffffu));
-            if (ok() && y1 > y0)
-                HIPCHECK(hipMemcpyAsync(image + rowBytes * y0, (const char *)src + rowBytes * y0, rowBytes * (y1 - y0),
-                                        hipMemcpyDeviceToHost, on));
-        }
-        for (int k = 0; k < 2 && ok(); ++k)
-            if (used[k])
-            {
-                HIPCHECK(hipEventRecord(g.bandEvent[k], g.bandStream[k]));
-                HIPCHECK(hipStreamWaitEvent(g.copyStream, g.bandEvent[k], 0));
-            }
-        HIPCHECK(hipEventRecord(g.imageDone[slot], g.copyStream));
-        g.flightCopy[flight][g.bitmapSide[flight]] = slot;
-        g.streamedValid = false; /* (one read-back per streamed frame: a second one takes the plain route) */
-        ++g.streamedDelivered;
-        return;
-    }
     if (!inlineCopy)
     {
         HIPCHECK(hipEventRecord(g.frameRendered, flightStream(flight)));
@@ -400,10 +325,10 @@ void solr_hip_set_copy_route(int onTheFramesOwnStream)
 }
 
 /* ImageStreaming: the frame the next cudaRender launches counts its tiles, if it is a whole frame of one device with
- * the RGB conversion fused in; solr_hip_d2h_image_async, called behind that cudaRender, then sends its image off band
- * by band while the kernel renders (renderer.h).  One frame at a time only: with frames in flight the next frame hides
- * the copy.  Returns 1 when the device can (hipStreamWaitValue32), 0 when frames will be read back the plain way;
- * on = -1 asks, behind a cudaRender, whether that frame was such a frame; -2 how many images have left in bands so far. */
+ * the RGB conversion fused in, one frame in flight; solr_hip_d2h_streamed_image, called behind that cudaRender, sends
+ * its image off band by band while the kernel renders (renderer.h).  Returns 1 when frames can be streamed, 0 when they
+ * will be read back the plain way; on = -1 asks, behind a cudaRender, whether that frame was such a frame; -2 how many
+ * images have left in bands so far. */
 int solr_hip_stream_next_image(int on)
 {
     if (!ready("solr_hip_stream_next_image"))
@@ -416,9 +341,9 @@ int solr_hip_stream_next_image(int on)
     return g.streamSupport != 0 ? 1 : 0;
 }
 
-/* ... and into memory of the caller's (SolR_RunKernel's array), waited for: behind a cudaRender that counted its tiles, every
- * band of the image is copied to its rows of `image` as soon as the band's word says so.  1: done; 0: that frame was not
- * such a frame and nothing was copied (d2h_bitmap is the way then); -1: error. */
+/* Behind a cudaRender that counted its tiles: every band of the image is copied to its rows of `image` - host memory of
+ * any kind - as soon as the band's word has come, and the call returns when the last has landed.  1: done; 0: that frame
+ * was not such a frame and nothing was copied (d2h_bitmap is the way then); -1: error. */
 int solr_hip_d2h_streamed_image(BitmapBuffer *image)
 {
     HostSpan whole("solr_hip_d2h_streamed_image");
@@ -433,12 +358,19 @@ int solr_hip_d2h_streamed_image(BitmapBuffer *image)
         return 0;
     HIPCHECK(hipSetDevice(g.device));
     ensureCopyStream();
+    /* the host watches the bands' words (page-locked memory the waves write to); a band whose word has not come is copied
+     * when the kernel has ended - everything it wrote is in memory then, whatever became of the word.  (`image` is
+     * pageable as a rule, and a copy into pageable memory returns when it is done: the loop is the pipeline.) */
     const size_t rowBytes = (size_t)g.width * SOLR_COLOR_DEPTH;
+    bool ended = false;
     for (int b = 0; b < g.streamBands && ok(); ++b)
     {
         const int y0 = g.streamPlan.firstRow[b] * TILE_H, y1 = std::min(g.height, g.streamPlan.firstRow[b + 1] * TILE_H);
-        HIPCHECK(hipStreamWaitValue32(g.copyStream, g.streamPlan.signal[b], g.streamSerial, hipStreamWaitValueGte, 0xffffffffu));
-        if (ok() && y1 > y0)
+        volatile unsigned *word = g.streamHostWords + b;
+        while (!ended && (int)(*word - g.streamSerial) < 0)
+            ended = !g.streamRendered || hipEventQuery(g.streamRendered) != hipErrorNotReady;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (y1 > y0)
             HIPCHECK(hipMemcpyAsync(image + rowBytes * y0, (const char *)src + rowBytes * y0, rowBytes * (y1 - y0), hipMemcpyDeviceToHost,
                                     g.copyStream));
     }

@@ -308,8 +308,6 @@ public:
      * copies from the device straight into `image` and leaves m_bitmap to the next getBitmap() (fetchBitmap); the
      * default is the reference's two steps. */
     virtual void render_end(BitmapBuffer *image);
-    /* ... and said before render_begin, so that the engine does not start this frame's image towards its own memory */
-    virtual void setNextImageTarget(BitmapBuffer *) {}
     /* Extension (no reference equivalent; the reference's render_end waits for the frame and then copies it,
      * CudaKernel.cpp:304-312).  n > 1: render_begin also starts the read-back of its frame's image, and render_end
      * delivers the image of the frame n - 1 calls back - the one whose copy has had n - 1 frames' time to land -

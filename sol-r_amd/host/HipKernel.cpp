@@ -185,15 +185,15 @@ void HipKernel::render_begin(const float timer)
         if (m_sceneInfo.draftMode && m_sceneInfo.pathTracingIteration == m_sceneInfo.maxPathTracingIterations)
             sceneInfo.cameraType = ctAntialiazed;
 
-        /* one frame at a time, the image wanted in the engine's own page-locked memory (render_end, not
-         * SolR_RunKernel's array): the frame's waves say when a band of rows is complete and the band leaves for the host
-         * while the rows below still render (include/solr_hip.h, solr_hip_stream_next_image) */
+        /* one frame at a time: the frame's waves say when a band of rows is complete, and render_end sends every band
+         * off to the host - m_bitmap or SolR_RunKernel's array - while the rows below still render (include/solr_hip.h,
+         * solr_hip_stream_next_image) */
         const bool stream = m_flights == 1 && solr_hip_stream_next_image(1) == 1;
         cudaRender(m_occupancyParameters, m_blockSize, sceneInfo, objects, m_postProcessingInfo, m_viewPos, m_viewDir,
                    m_angles);
         mark("render_begin: cudaRender");
-        m_streamedToCaller = stream && m_callerImage && solr_hip_stream_next_image(-1) == 1;
-        if (m_flights > 1 || (stream && !m_callerImage && solr_hip_stream_next_image(-1) == 1))
+        m_streamed = stream && solr_hip_stream_next_image(-1) == 1;
+        if (m_flights > 1)
         {
             /* frames in flight: the image starts for the host behind the kernel, on the engine's copy stream */
             const int ticket = solr_hip_d2h_image_async();
@@ -295,21 +295,11 @@ void HipKernel::render_end()
         m_bitmapOnDevice = false;
         return;
     }
-    if (!m_tickets.empty())
-    {
-        /* render_begin sent this frame's image off in bands while it rendered: it is in the engine's page-locked image
-         * (getBitmap() hands that out, as it does with frames in flight) when its last band has landed */
-        while (!m_tickets.empty())
-        {
-            deliver(m_tickets.front());
-            m_tickets.pop_front();
-        }
-        m_idsOnDevice = true;
-        m_bitmapOnDevice = false;
-        return;
-    }
     m_bitmapView = nullptr;
-    d2h_bitmap(m_occupancyParameters, m_sceneInfo, m_bitmap.data(), nullptr);
+    /* (the frame's bands leave for m_bitmap as they are complete) */
+    if (!(m_streamed && solr_hip_d2h_streamed_image(m_bitmap.data()) == 1))
+        d2h_bitmap(m_occupancyParameters, m_sceneInfo, m_bitmap.data(), nullptr);
+    m_streamed = false;
     m_idsOnDevice = true;
     m_bitmapOnDevice = false;
 }
@@ -320,17 +310,16 @@ void HipKernel::render_end()
  * -> fetchBitmap): 0.39 ms, what render_begin + render_end take (profiles/r6/api_frame_bands.txt). */
 void HipKernel::render_end(BitmapBuffer *image)
 {
-    m_callerImage = nullptr;
-    if (m_flights > 1 || !image || !m_deviceInitialized || !m_tickets.empty())
+    if (m_flights > 1 || !image || !m_deviceInitialized)
     {
         GPUKernel::render_end(image);
         return;
     }
     m_bitmapView = nullptr;
-    /* (the frame's bands have been leaving for the host since they were complete: they land in the caller's array) */
-    if (!(m_streamedToCaller && solr_hip_d2h_streamed_image(image) == 1))
+    /* (the frame's bands leave for the caller's array as they are complete) */
+    if (!(m_streamed && solr_hip_d2h_streamed_image(image) == 1))
         d2h_bitmap(m_occupancyParameters, m_sceneInfo, image, nullptr);
-    m_streamedToCaller = false;
+    m_streamed = false;
     m_idsOnDevice = true;
     m_bitmapOnDevice = true;
 }

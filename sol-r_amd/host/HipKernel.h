@@ -38,7 +38,6 @@ public:
     void render_begin(const float timer) override;
     void render_end() override;
     void render_end(BitmapBuffer *image) override;
-    void setNextImageTarget(BitmapBuffer *image) override { m_callerImage = image; }
     int lastError(std::string *message = nullptr) override;
     void setFramesInFlight(int n) override;
     int getFramesInFlight() const override { return m_flights; }
@@ -71,8 +70,7 @@ private:
     int m_sharedMemSize;
     bool m_deviceInitialized;
     bool m_idsOnDevice = false;
-    BitmapBuffer *m_callerImage = nullptr; /* SolR_RunKernel: the frame render_begin is about to launch goes to this array */
-    bool m_streamedToCaller = false;       /* ... and that frame counts its tiles: render_end(image) takes it band by band */
+    bool m_streamed = false;       /* the frame render_begin launched counts its tiles: render_end takes its image band by band */
     bool m_bitmapOnDevice = false; /* render_end(image) delivered to the caller's array: m_bitmap follows when asked */
     unsigned m_sharedSeed = 0, m_sharedState = 0; /* solr_hip_comm_shared_seed and the generator it seeds (render_begin) */
     int m_flights = 1;            /* frames in flight through render_begin / render_end (setFramesInFlight) */

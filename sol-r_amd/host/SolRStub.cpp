@@ -174,7 +174,6 @@ int SolR_RunKernel(double timer, BitmapBuffer *image)
     solr::GPUKernel *kernel = SingletonKernel::kernel();
     kernel->setSceneInfo(gSceneInfoStub);
     kernel->setPostProcessingInfo(gPostProcessingInfoStub);
-    kernel->setNextImageTarget(image);
     kernel->render_begin(static_cast<float>(timer));
     kernel->render_end(image);
     return engineStatus();

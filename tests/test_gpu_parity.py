@@ -1089,8 +1089,8 @@ def test_thin_leaves_follow_a_rotation_on_the_device(solr, oracle):
 def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(solr):
     """render_begin / render_end and SolR_RunKernel one frame at a time (solr_hip_stream_next_image; csrc/renderer.h,
     ImageStreaming): the frame's waves count themselves into tile rows and bands, every band's copy waits for the band's
-    word instead of the kernel.  The bytes that arrive - in the engine's page-locked image, in the caller's array - are
-    the device's image as d2h_bitmap reads it after the kernel: with a moving camera, through refinement and
+    word instead of the kernel.  The bytes that arrive - in m_bitmap, in the caller's array - are the device's image as
+    d2h_bitmap reads it after the kernel: with a moving camera, through refinement and
     accumulation passes, around a frame with a neighbourhood post-process (not streamed), through a reshape (new
     counters), after frames in flight were on and off again."""
     import ctypes as C
@@ -1117,7 +1117,7 @@ def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(
 
     try:
         if hip.solr_hip_stream_next_image(0) != 1:
-            pytest.skip("no hipStreamWaitValue32 on this device (or SOLR_HIP_NO_IMAGE_STREAMING=1)")
+            pytest.skip("SOLR_HIP_NO_IMAGE_STREAMING=1")
         assert L.SolRx_Render(0.0) == 0      # (the frame that brings the device up is not streamed)
         # (a frame whose longest tile the cost-ordered launch would split into quadrant waves is not streamed either -
         # this small one would be, now and then; the 1080p test below runs with the order as the engine chooses it)
@@ -1210,7 +1210,7 @@ def test_full_size_frames_leave_in_bands_with_the_same_bytes(solr, scene):
     L = k.L
     try:
         if hip.solr_hip_stream_next_image(0) != 1:
-            pytest.skip("no hipStreamWaitValue32 on this device (or SOLR_HIP_NO_IMAGE_STREAMING=1)")
+            pytest.skip("SOLR_HIP_NO_IMAGE_STREAMING=1")
         before = hip.solr_hip_stream_next_image(-2)
         different = 0
         last = None
@@ -1237,4 +1237,54 @@ def test_full_size_frames_leave_in_bands_with_the_same_bytes(solr, scene):
         assert last.any() and (scene != "cornell" or different > 30)
         k.check(0, "image streaming at 1080p")
     finally:
+        k.finalize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["SolRx_Render", "SolR_RunKernel"])
+def test_a_band_whose_word_never_comes_is_copied_when_the_kernel_has_ended(solr, entry):
+    """variant 13: the waves of a streamed frame write no band's word.  The host, which watches the words, also watches the
+    event behind the kernel: when that has fired everything the kernel wrote is in memory, and the bands are copied then -
+    the right bytes, no wait without end, whatever becomes of a word."""
+    import ctypes as C
+    import time
+    hip = solr.hip_lib()
+    W, H = 200, 136
+    k = solr.Kernel(engine="hip", deterministic_seed=1)
+    solr.scenes.cornell(k, width=W, height=H, iterations=2)
+
+    def frame(x):
+        k.set_camera((x, 0.0, -15000.0))
+        if entry == "SolR_RunKernel":
+            out = np.zeros((H, W, 3), np.uint8)
+            assert k.L.SolR_RunKernel(0.0, out.ctypes.data) == 0
+        else:
+            assert k.L.SolRx_Render(0.0) == 0
+            ptr = k.L.SolRx_GetBitmap()
+            out = np.frombuffer((C.c_ubyte * (W * H * 3)).from_address(ptr), np.uint8).reshape(H, W, 3).copy()
+        rgb, ids = np.zeros((H, W, 3), np.uint8), np.zeros((H, W, 4), np.int32)
+        si = k.frame_parameters()[0]
+        hip.solr_hip_d2h(C.byref(si), C.c_void_p(rgb.ctypes.data), C.c_void_p(ids.ctypes.data))
+        assert np.array_equal(out, rgb), x
+        return out
+
+    try:
+        frame(0.0)
+        if hip.solr_hip_stream_next_image(0) != 1:
+            pytest.skip("SOLR_HIP_NO_IMAGE_STREAMING=1")
+        hip.solr_hip_set_tile_scheduling(0)
+        before = hip.solr_hip_stream_next_image(-2)
+        first = frame(100.0)
+        hip.solr_hip_set_variant(13)
+        t0 = time.perf_counter()
+        second = frame(200.0)
+        assert time.perf_counter() - t0 < 2.0
+        hip.solr_hip_set_variant(0)
+        third = frame(300.0)                                             # (the counters are a frame out of step: the same way out)
+        assert hip.solr_hip_stream_next_image(-2) == before + 3
+        assert not np.array_equal(first, second) and not np.array_equal(second, third)
+        k.check(0, "a band without its word")
+    finally:
+        hip.solr_hip_set_variant(0)
+        hip.solr_hip_set_tile_scheduling(1)
         k.finalize()

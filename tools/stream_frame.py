@@ -1,5 +1,5 @@
 """One frame at a time through the C ABI: cudaRender + d2h_bitmap (the reference's protocol) against cudaRender with the
-image leaving in bands (solr_hip_stream_next_image + solr_hip_d2h_image_async + solr_hip_image_wait); kernel time in both.
+image leaving in bands (solr_hip_stream_next_image + solr_hip_d2h_streamed_image); kernel time in both.
 usage: python tools/stream_frame.py [scene] [frames]"""
 import ctypes as C
 import importlib
@@ -53,8 +53,8 @@ def kernel_ms(call, n=32):
 if os.environ.get("TILE_SCHEDULING"):
     hip.solr_hip_set_tile_scheduling(int(os.environ["TILE_SCHEDULING"]))
 before = hip.solr_hip_stream_next_image(-2)
-for name, call in (("SolR_RunKernel: kernel, then the image into the caller's array", lambda: L.SolR_RunKernel(0.0, image.ctypes.data)),
-                   ("SolRx_Render: the image leaves in bands while the kernel renders", lambda: L.SolRx_Render(0.0))):
+for name, call in (("SolR_RunKernel (the image into the caller's array)", lambda: L.SolR_RunKernel(0.0, image.ctypes.data)),
+                   ("SolRx_Render (render_begin + render_end, the image into m_bitmap)", lambda: L.SolRx_Render(0.0))):
     t = block(call)
     print("%-70s %.4f ms per frame (median of 5 blocks of %d; %.4f ... %.4f); the kernel %.4f ms (HIP events)" % (
         name, t[2], frames, t[0], t[-1], kernel_ms(call)))
