@@ -17,7 +17,7 @@ for SCENE in $SCENES; do
   do
     P=$((P+1))
     rm -rf $OUT/wb_${SCENE}_$P
-    rocprofv3 --pmc $SET --output-format csv -d $OUT/wb_${SCENE}_$P -o pmc -- $CMD > $OUT/wb_${SCENE}_$P.log 2>&1
+    timeout 600 rocprofv3 --pmc $SET --output-format csv -d $OUT/wb_${SCENE}_$P -o pmc -- $CMD > $OUT/wb_${SCENE}_$P.log 2>&1
   done
   python3 - "$OUT" "$SCENE" <<'PY'
 import sys, glob, csv, collections
