@@ -7,6 +7,9 @@
 //   2. whether device-scope stores + a wait + a device-scope flag are enough for a wave on ANOTHER XCD to read the bytes
 //      (every frame's host image is compared with what the producer must have written),
 //   3. what the frame costs end to end against kernel + hipMemcpyAsync.
+// ... and, further down, the ways that do without a second kernel: the last wave of a tile row copies it; every wave stores
+// its tile to the host; the copy engine per band behind hipStreamWaitValue32.  What the engine does in the end - the bands'
+// words in page-locked memory, the host watching them - came out of these (profiles/r6/stream_probe.txt).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
