@@ -368,6 +368,7 @@ void solr_hip_set_flight_streams(void *const *streams, int n);
  * whether the last render was launched in cost order. */
 void solr_hip_set_tile_scheduling(int mode);
 int solr_hip_tile_scheduling_active(void);
+int solr_hip_split_tiles(void); /* tiles the current order renders as four quadrant waves each */
 
 /* Load-balance diagnostics: when enabled every render records, per 8x8 tile
  * (one wavefront), the 100 MHz timestamps at which its wave started and ended.

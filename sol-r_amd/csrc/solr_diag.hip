@@ -389,6 +389,12 @@ void solr_hip_set_tile_scheduling(int mode)
     });
 }
 
+/* tiles the current launch order renders as four quadrant waves each (0: none, or no order) */
+int solr_hip_split_tiles(void)
+{
+    return (g.hostStats && g.orderValid) ? (int)g.hostStats[5] : 0;
+}
+
 int solr_hip_tile_scheduling_active(void)
 {
     return (g.tileScheduling == 2 || (g.tileScheduling == 1 && g.reorder)) && g.orderValid ? 1 : 0;

@@ -304,6 +304,8 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
         nbSplit = (splitClass < 64u && cuts.bands <= 0) ? scan[1023 - (splitClass << 4)] : 0u;
     __syncthreads();
     const unsigned split = nbSplit;
+    if (t == 0)
+        hostStats[5] = split; /* (diagnostics: tiles this order renders as quadrant waves) */
     for (int i = n + (SPLIT_PARTS - 1) * (int)split + t; i < n + (SPLIT_PARTS - 1) * SPLIT_TILES_MAX; i += 1024)
         order[i] = ORDER_NOTHING;
     for (int base = 0; base < n; base += BATCH * 1024)

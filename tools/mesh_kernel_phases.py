@@ -19,11 +19,14 @@ frames(600, 3)
 L.SolRx_SetFramesInFlight(1)
 hip.solr_hip_kernel_time(None, 1)
 hip.solr_hip_enable_timing(1)
+splits = []
 for i in range(80):
     L.SolR_RunKernel(0.0, image.ctypes.data)
+    splits.append(hip.solr_hip_split_tiles())
 hip.solr_hip_enable_timing(0)
 samples = (C.c_float * 128)()
 hip.solr_hip_timing_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 got = hip.solr_hip_timing_samples(samples, None, 128)
 print("per-launch ms after switching from 3 frames in flight to 1:", " ".join("%.3f" % samples[i] for i in range(got)))
+print("tiles rendered as four quadrant waves, by the order of that launch:", " ".join(str(v) for v in splits))
 k.finalize()
