@@ -100,6 +100,26 @@ bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], i
      * profiles/r6/stream_frame.txt).  SOLR_HIP_STREAM_BANDS (experiments): 1 ... SOLR_STREAM_BANDS_MAX;
      * SOLR_HIP_STREAM_EQUAL=0: bands of n : n - 1 : ... : 1, the last copy the shortest - no better on the Cornell box,
      * worse on the molecule (the first band is half the frame, and its order is what the kernel pays for) */
+    /* SOLR_HIP_STREAM_CUTS="0.33,0.67,0.89" (experiments): the bands end at these fractions of the frame's tile rows */
+    if (const char *given = getenv("SOLR_HIP_STREAM_CUTS"))
+    {
+        int n = 0;
+        firstRow[0] = 0;
+        for (const char *at = given; *at && n + 1 < SOLR_STREAM_BANDS_MAX;)
+        {
+            char *end = nullptr;
+            const double f = strtod(at, &end);
+            if (end == at)
+                break;
+            const int row = std::max(firstRow[n] + 1, std::min(tileRows - 1, (int)(f * tileRows + 0.5)));
+            if (row > firstRow[n] && row < tileRows)
+                firstRow[++n] = row;
+            at = (*end == ',') ? end + 1 : end;
+        }
+        firstRow[n + 1] = tileRows;
+        *bands = n + 1;
+        return true;
+    }
     static const int wanted = getenv("SOLR_HIP_STREAM_BANDS") ? std::max(1, std::min(SOLR_STREAM_BANDS_MAX, atoi(getenv("SOLR_HIP_STREAM_BANDS")))) : 3;
     static const bool equal = !(getenv("SOLR_HIP_STREAM_EQUAL") && getenv("SOLR_HIP_STREAM_EQUAL")[0] == '0');
     const int total = equal ? wanted : wanted * (wanted + 1) / 2;
