@@ -400,7 +400,8 @@ void solr_hip_render_counting(const SceneInfo *sceneInfo, const vec4i *objects,
  * NaNs before every launch (they are never zeroed: no slot is read before the frame has written it); 12 = no walk takes
  * the copies of the order-free lists with sorted bounds (the node loop without its min / max, rt_device.h
  * SOLR_ORDER_SORTED); 13 = a streamed frame (solr_hip_stream_next_image) whose waves do not write the bands' words: the
- * host goes by the end of the kernel (solr_hip_d2h_streamed_image).  Every setting renders the same frame. */
+ * host goes by the end of the kernel (solr_hip_d2h_streamed_image); 14 = the tile counters of streamed frames are zeroed
+ * every third frame, as they are when a count nears 2^32.  Every setting renders the same frame. */
 void solr_hip_set_variant(int variant);
 /* Bounce rays (|direction| = 1 - rayEpsilon) of the long-list triangle kernels on the order-free lists, checked: lanes
  * whose hit has a rival the reference's cut-off could have preferred are walked again in the reference's order

@@ -143,7 +143,8 @@ bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream)
     const long key[3] = {F.tilesX, tileRows, g.width};
     const unsigned perRow = (unsigned)(F.tilesX * SPLIT_PARTS);
     const bool fresh = memcmp(key, g.streamKey, sizeof(key)) != 0 || !g.streamCounters.ptr;
-    if (fresh || (unsigned long long)(g.streamSerial + 2u) * perRow >= 0xffffffffull)
+    /* (variant 14, tests: as if the row counts neared 2^32 every third frame) */
+    if (fresh || (unsigned long long)(g.streamSerial + 2u) * perRow >= 0xffffffffull || (g.variant == 14 && g.streamSerial >= 3u))
     {
         /* nothing of an earlier streamed frame may be under way: its waves count into these words */
         quiesce();

@@ -1140,6 +1140,17 @@ def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(
             assert np.array_equal(delivered(W, H), streamed), i      # (getBitmap follows SolR_RunKernel's frame)
             frames.append(streamed.copy())
         assert frames[0].any() and not np.array_equal(frames[0], frames[7])
+        # the counters only ever grow and are zeroed when a row's count nears 2^32 (4.4 million 1080p frames): variant 14
+        # zeroes them every third frame
+        hip.solr_hip_set_variant(14)
+        before = in_bands()
+        for i in range(8):
+            k.set_camera((250.0 * i, 40.0 * i, -15000.0))
+            assert L.SolRx_Render(0.0) == 0
+            assert np.array_equal(delivered(W, H), frames[i]), i
+            assert np.array_equal(delivered(W, H), on_device(W, H)), i
+        assert in_bands() == before + 8
+        hip.solr_hip_set_variant(0)
         # refinement and accumulation passes
         passes = []
         before = in_bands()
@@ -1187,6 +1198,7 @@ def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(
         assert in_bands() == before and np.array_equal(delivered(160, 96), on_device(160, 96))
         k.check(0, "image streaming")
     finally:
+        hip.solr_hip_set_variant(0)
         hip.solr_hip_set_tile_scheduling(1)
         L.SolRx_SetFramesInFlight(1)
         k.finalize()
