@@ -1,7 +1,9 @@
 /*
  * solr_image_ring.hip - the pipelined read-back of the engine (include/solr_hip.h: solr_hip_d2h_image_async,
  * solr_hip_image_wait, solr_hip_image_share ...): a ring of page-locked host images, a copy stream, read-back tickets,
- * and the ring as a POSIX shared-memory segment that the ranks of a multi-process job fill together.  gfx950 only.
+ * and the ring as a POSIX shared-memory segment that the ranks of a multi-process job fill together; and the read-back of
+ * a frame taken one at a time, whose image leaves in bands of tile rows while its kernel still renders
+ * (solr_hip_stream_next_image, solr_hip_d2h_streamed_image; renderer.h, ImageStreaming).  gfx950 only.
  */
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
@@ -81,7 +83,7 @@ void releaseImageStreaming()
 
 /* ImageStreaming, the host's part before a launch (renderImpl): counters, plan and band words for this frame geometry
  * - made, or zeroed, when the geometry changes or the row counts near 2^32 - and the frame's serial.  False: this frame is
- * not streamed (no support for hipStreamWaitValue32, an allocation failed: the read-back then takes the plain route). */
+ * not streamed (SOLR_HIP_NO_IMAGE_STREAMING=1, too few tile rows, an allocation failed: the read-back then takes the plain route). */
 /* the bands of a frame of that many tile rows; false: such a frame is not streamed (SOLR_HIP_NO_IMAGE_STREAMING=1, a frame
  * of fewer than sixteen tile rows) */
 bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], int *bands)
