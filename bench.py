@@ -590,7 +590,7 @@ def main():
         # ... and with the image leaving in bands while the kernel renders (include/solr_hip.h solr_hip_stream_next_image:
         # what HipKernel's render_begin / render_end and SolR_RunKernel do one frame at a time); frames that cannot be
         # streamed (a neighbourhood post-process, a tile the launch splits) are read back behind the kernel as above
-        in_bands = None
+        in_bands = in_bands_ids = None
         if hip.solr_hip_stream_next_image(0) == 1:
             def streamed_frame():
                 hip.solr_hip_stream_next_image(1)
@@ -604,6 +604,19 @@ def main():
             for _ in range(n_extra):
                 streamed_frame()
             in_bands = ((time.perf_counter() - ta) / n_extra, hip.solr_hip_stream_next_image(-2) - left_before)
+            # ... and the reference's whole d2h_bitmap - image AND primitive ids, 39 MB of a 1080p frame - in bands
+            def streamed_frame_with_ids():
+                hip.solr_hip_stream_next_image(2)
+                frame()
+                if hip.solr_hip_d2h_streamed(C.c_void_p(host_rgb.ctypes.data), C.c_void_p(host_ids.ctypes.data)) != 1:
+                    hip.solr_hip_d2h(C.byref(si), C.c_void_p(host_rgb.ctypes.data), C.c_void_p(host_ids.ctypes.data))
+            for _ in range(4):
+                streamed_frame_with_ids()
+            left_before = hip.solr_hip_stream_next_image(-2)
+            ta = time.perf_counter()
+            for _ in range(n_extra):
+                streamed_frame_with_ids()
+            in_bands_ids = ((time.perf_counter() - ta) / n_extra, hip.solr_hip_stream_next_image(-2) - left_before)
             for _ in range(20):                  # ... and the order by cost alone comes back for what follows
                 frame()
             sync()
@@ -634,6 +647,10 @@ def main():
             rates["cudaRender_plus_image_in_bands"] = (
                 in_bands[0], "render + the RGB image leaving in bands of tile rows while the kernel renders the rows below "
                 "(%d of %d frames did; HipKernel's render_begin / render_end and SolR_RunKernel, one frame at a time)" % (in_bands[1], n_extra))
+        if in_bands_ids:
+            rates["cudaRender_plus_d2h_bitmap_in_bands"] = (
+                in_bands_ids[0], "render + RGB image and primitive ids leaving in bands while the kernel renders (%d of %d frames did; "
+                "solr_hip_stream_next_image(2) + solr_hip_d2h_streamed)" % (in_bands_ids[1], n_extra))
         if device_resident:
             rates["pipelined_device_resident"] = (
                 device_resident, "%d frames in flight, the image left in HBM, nothing delivered (what earlier rounds "

@@ -308,6 +308,10 @@ void solr_hip_set_copy_route(int onTheFramesOwnStream);
  * gets it. */
 int solr_hip_stream_next_image(int on);
 int solr_hip_d2h_streamed_image(BitmapBuffer *image);
+/* the same with the primitive ids, as d2h_bitmap hands both over (CudaRayTracer.cu:1647-1672: 16 bytes per pixel, five times
+ * the image, every frame): solr_hip_stream_next_image(2) before the cudaRender, then this in place of d2h_bitmap.  The 39 MB of
+ * a 1080p frame take PCIe 0.76 ms whatever the kernel does; in bands they start 0.17 ms earlier (profiles/r6). */
+int solr_hip_d2h_streamed(BitmapBuffer *image, PrimitiveXYIdBuffer *primitivesXYIds);
 /* One host image for all ranks of a multi-process job: the ring of page-locked images becomes a POSIX shared-memory
  * segment `name` ("/something"; rank 0 creates it, the others open it), registered with the HIP runtime in every
  * process.  Every rank's solr_hip_d2h_image_async then copies its strip, over its own PCIe link, to its rows of the

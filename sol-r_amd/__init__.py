@@ -212,6 +212,8 @@ def _declare_hip(L):
     L.solr_hip_stream_next_image.restype = C.c_int
     L.solr_hip_d2h_streamed_image.argtypes = [C.c_void_p]
     L.solr_hip_d2h_streamed_image.restype = C.c_int
+    L.solr_hip_d2h_streamed.argtypes = [C.c_void_p, C.c_void_p]
+    L.solr_hip_d2h_streamed.restype = C.c_int
     L.solr_hip_image_share.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.solr_hip_image_share.restype = C.c_int
     L.solr_hip_d2h_gathered_async.restype = C.c_int

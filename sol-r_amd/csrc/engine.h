@@ -267,7 +267,8 @@ struct Engine
 
     /* ImageStreaming (renderer.h): the next frame counts its tiles if it can (solr_hip_stream_next_image), and
      * solr_hip_d2h_streamed_image then sends its image off band by band as the bands' words come */
-    bool streamNext = false;
+    int streamNext = 0;                  /* 0 no, 1 the image, 2 the image and the primitive ids */
+    bool streamedIds = false;            /* the frame rendered last stored its ids for the bands too */
     bool streamedValid = false;          /* the frame rendered last counted its tiles: serial, image and bands below */
     const void *streamedBitmap = nullptr;
     unsigned streamSerial = 0;           /* streamed frames since the counters were zeroed */

@@ -43,6 +43,7 @@ struct FrameArgs
     unsigned *rowDone;                    /* one word per tile row, 64 words apart: units of it rendered, over all streamed frames */
     const struct StreamPlan *streamPlan;  /* bands of tile rows and the words the host watches */
     unsigned streamSerial;                /* this frame is the n-th streamed frame since the counters were zeroed */
+    int streamIds;                        /* ... and its primitive ids leave with the image: they too are stored with device scope */
 };
 
 /* ImageStreaming.  A host that takes one frame at a time waits for the kernel and then for 6 MB over PCIe (0.26 + 0.13 ms

@@ -336,7 +336,14 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
         }
         pp[index].colorInfo = ppColor;
         pp[index].sceneInfo = ppScene;
-        ids[index] = id;
+        if (F.streamIds) /* (ImageStreaming with the ids: written through to memory, where the copy engine reads the band) */
+        {
+            typedef int FourInts __attribute__((ext_vector_type(4)));
+            const FourInts four = {id.x, id.y, id.z, id.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ids + index), "v"(four) : "memory");
+        }
+        else
+            ids[index] = id;
 
         if (F.fuseDefault)
         {

@@ -360,31 +360,32 @@ int solr_hip_stream_next_image(int on)
         return (int)(g.streamedDelivered & 0x7fffffff);
     if (on < 0) /* (asked behind a cudaRender: did that frame count its tiles?) */
         return g.streamedValid ? 1 : 0;
-    g.streamNext = on != 0;
+    g.streamNext = on >= 2 ? 2 : (on != 0 ? 1 : 0);
     return g.streamSupport != 0 ? 1 : 0;
 }
 
 /* Behind a cudaRender that counted its tiles: every band of the image is copied to its rows of `image` - host memory of
  * any kind - as soon as the band's word has come, and the call returns when the last has landed.  1: done; 0: that frame
  * was not such a frame and nothing was copied (d2h_bitmap is the way then); -1: error. */
-int solr_hip_d2h_streamed_image(BitmapBuffer *image)
+static int streamedReadBack(BitmapBuffer *image, PrimitiveXYIdBuffer *primitiveIds, const char *who)
 {
-    HostSpan whole("solr_hip_d2h_streamed_image");
-    if (!ready("solr_hip_d2h_streamed_image"))
+    HostSpan whole(who);
+    if (!ready(who))
         return -1;
     ARGCHECK(image != nullptr, "solr_hip_d2h_streamed_image: no image");
     if (!ok())
         return -1;
     const int flight = g.current;
     const void *src = flightBitmap(flight).ptr;
-    if (!g.streamedValid || src != g.streamedBitmap || g.nbRows >= 0 || g.streamBands <= 0)
+    if (!g.streamedValid || src != g.streamedBitmap || g.nbRows >= 0 || g.streamBands <= 0 || (primitiveIds && !g.streamedIds))
         return 0;
     HIPCHECK(hipSetDevice(g.device));
     ensureCopyStream();
     /* the host watches the bands' words (page-locked memory the waves write to); a band whose word has not come is copied
      * when the kernel has ended - everything it wrote is in memory then, whatever became of the word.  (`image` is
      * pageable as a rule, and a copy into pageable memory returns when it is done: the loop is the pipeline.) */
-    const size_t rowBytes = (size_t)g.width * SOLR_COLOR_DEPTH;
+    const size_t rowBytes = (size_t)g.width * SOLR_COLOR_DEPTH, rowIds = (size_t)g.width;
+    const PrimitiveXYIdBuffer *srcIds = (const PrimitiveXYIdBuffer *)flightIds(flight).ptr;
     bool ended = false;
     for (int b = 0; b < g.streamBands && ok(); ++b)
     {
@@ -396,11 +397,30 @@ int solr_hip_d2h_streamed_image(BitmapBuffer *image)
         if (y1 > y0)
             HIPCHECK(hipMemcpyAsync(image + rowBytes * y0, (const char *)src + rowBytes * y0, rowBytes * (y1 - y0), hipMemcpyDeviceToHost,
                                     g.copyStream));
+        if (y1 > y0 && primitiveIds && ok())
+            HIPCHECK(hipMemcpyAsync(primitiveIds + rowIds * y0, srcIds + rowIds * y0, rowIds * (y1 - y0) * sizeof(PrimitiveXYIdBuffer),
+                                    hipMemcpyDeviceToHost, g.copyStream));
     }
     HIPCHECK(hipStreamSynchronize(g.copyStream));
     g.streamedValid = false;
     ++g.streamedDelivered;
     return ok() ? 1 : -1;
+}
+
+int solr_hip_d2h_streamed_image(BitmapBuffer *image)
+{
+    return streamedReadBack(image, nullptr, "solr_hip_d2h_streamed_image");
+}
+
+/* ... with the primitive ids of every pixel (16 bytes each: five times the image), as d2h_bitmap hands both over
+ * (CudaRayTracer.cu:1647-1672) - for a frame asked for with solr_hip_stream_next_image(2), whose waves store their ids
+ * with device scope as well */
+int solr_hip_d2h_streamed(BitmapBuffer *image, PrimitiveXYIdBuffer *primitivesXYIds)
+{
+    ARGCHECK(primitivesXYIds != nullptr, "solr_hip_d2h_streamed: no array for the ids");
+    if (!ok())
+        return -1;
+    return streamedReadBack(image, primitivesXYIds, "solr_hip_d2h_streamed");
 }
 
 int solr_hip_d2h_image_async(void)

@@ -377,7 +377,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
             for (int b = 0; b <= streamCuts.bands; ++b)
                 streamCuts.firstTile[b] = rows[b] * F.tilesX;
     }
-    g.streamNext = false;
+    const bool streamIds = g.streamNext == 2;
+    g.streamNext = 0;
     bool streamCandidate = streamCuts.bands > 0;
     if (g.tileScheduling > 0 && !counting)
     {
@@ -597,6 +598,8 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     /* (tiles in launch order, or band after band: an order by cost alone completes every band at the end) */
     const bool streamed = streamCandidate && cntPtr == (unsigned long long *)g.counters.ptr &&
                           (!F.tileOrder || memcmp(&g.orderCuts, &streamCuts, sizeof(streamCuts)) == 0) && armImageStreaming(F, tilesY, stream);
+    F.streamIds = (streamed && streamIds) ? 1 : 0;
+    g.streamedIds = F.streamIds != 0;
     if (streamed && g.variant == 13) /* (tests: the waves write no band's word - the host goes by the end of the kernel) */
         F.streamSerial = 0x7fffff00u;
     {

@@ -1140,6 +1140,30 @@ def test_one_frame_at_a_time_the_image_leaves_in_bands_while_the_kernel_renders(
             assert np.array_equal(delivered(W, H), streamed), i      # (getBitmap follows SolR_RunKernel's frame)
             frames.append(streamed.copy())
         assert frames[0].any() and not np.array_equal(frames[0], frames[7])
+        # the C ABI's own route with the primitive ids (d2h_bitmap hands both over): the same image, the same ids
+        for i in range(4):
+            k.set_camera((250.0 * i, 40.0 * i, -15000.0))
+            k.set_scene_info(pathTracingIteration=0)
+            assert L.SolRx_Render(0.0) == 0                    # (the host protocol's frame: its parameters are what follows)
+            si, ppi, eye, direction, angles = k.frame_parameters()
+            flat = k.flat_scene()
+            objects = solr.Vec4i(len(flat.boxes), len(flat.primitives), flat.nb_lamps, len(flat.lights))
+            fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+            before = in_bands()
+            assert hip.solr_hip_stream_next_image(2) == 1
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+            rgb, ids = np.zeros((H, W, 3), np.uint8), np.full((H, W, 4), -7, np.int32)
+            assert hip.solr_hip_d2h_streamed(C.c_void_p(rgb.ctypes.data), C.c_void_p(ids.ctypes.data)) == 1
+            assert in_bands() == before + 1
+            rgb2, ids2 = np.zeros((H, W, 3), np.uint8), np.zeros((H, W, 4), np.int32)
+            hip.solr_hip_d2h(C.byref(si), C.c_void_p(rgb2.ctypes.data), C.c_void_p(ids2.ctypes.data))
+            assert np.array_equal(rgb, rgb2) and np.array_equal(ids, ids2) and np.array_equal(rgb, frames[i]), i
+            # asked for the image only, the ids are not to be had in bands: 0, nothing copied
+            hip.solr_hip_stream_next_image(1)
+            hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(eye), fp(direction), fp(angles))
+            assert hip.solr_hip_d2h_streamed(C.c_void_p(rgb.ctypes.data), C.c_void_p(ids.ctypes.data)) == 0
+            assert hip.solr_hip_d2h_streamed_image(C.c_void_p(rgb.ctypes.data)) == 1 and np.array_equal(rgb, rgb2)
+        k.check(0, "the ids in bands")
         # the counters only ever grow and are zeroed when a row's count nears 2^32 (4.4 million 1080p frames): variant 14
         # zeroes them every third frame
         hip.solr_hip_set_variant(14)
