@@ -477,7 +477,7 @@ def main():
         if pipe is not None:
             return 0.0, None
         hip.solr_hip_set_frames_in_flight(1)
-        for _ in range(PREROLL_FRAMES):     # the tile-cost feedback settles on the one buffer set (sorted every 16th frame)
+        for _ in range(PREROLL_FRAMES):     # the tile-cost feedback settles on the one buffer set (the order is made anew when the number of frames in flight changes)
             frame()
         sync()
         hip.solr_hip_kernel_time(None, 1)

@@ -367,7 +367,7 @@ void solr_hip_set_flight_streams(void *const *streams, int n);
 
 /* Cost-ordered launch.  Every wave records what its 8x8 tile cost; when recent frames of the same
  * geometry had a heavy tail (the most expensive tile > 2 x the mean) the following frames are launched
- * most-expensive-first (a one-workgroup sorting kernel every sixteenth frame).  Changes the order of work
+ * most-expensive-first (a one-workgroup sorting kernel every 64th frame).  Changes the order of work
  * only.  mode 0: off, 1: automatic (default), 2: always.  solr_hip_tile_scheduling_active() tells
  * whether the last render was launched in cost order. */
 void solr_hip_set_tile_scheduling(int mode);

@@ -114,6 +114,18 @@ struct SharedRing
     std::atomic<long> consumed;
     long frameBytes, imageStride;
 };
+/* Frames between two sorts of the tiles by cost (k_orderTiles: one workgroup, 46 us for the 32 400 tiles of a 1080p frame, on the
+ * frame's own stream: 2.9 us of every Cornell frame at sixteen, which it was until round 6; 64: delivered frames 0.2442 ->
+ * 0.2419 ms, one at a time 0.2734 -> 0.2712.  A decision that changes - cost order on / off, a streamed frame's bands - is
+ * still acted on at once.  On a stream of its own the sort cost the delivered frames a third: one stream more, and the
+ * runtime's four hardware queues are dealt out differently; on the copy stream it delays the images).
+ * SOLR_HIP_SORT_PERIOD (environment): experiments. */
+inline int sortPeriod()
+{
+    static const int period = getenv("SOLR_HIP_SORT_PERIOD") ? std::max(2, atoi(getenv("SOLR_HIP_SORT_PERIOD"))) : 64;
+    return period;
+}
+
 struct Engine
 {
     bool initialized = false;
@@ -279,6 +291,7 @@ struct Engine
     unsigned *streamHostWords = nullptr; /* StreamPlan::hostWord, the host's address */
     hipEvent_t streamRendered = nullptr; /* behind the kernel of the streamed frame rendered last */
     long streamedDelivered = 0;          /* images that left in bands */
+    int lastMask = -1;                   /* features of the lean row the frame before took (-1: another kernel, or none yet) */
     int streamSupport = -1;              /* 1 / 0; -1: not asked yet (SOLR_HIP_NO_IMAGE_STREAMING) */
 
     /* device-side rotation (solr_hip_rotate_primitives): what to refit, in which order */

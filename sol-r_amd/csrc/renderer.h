@@ -29,7 +29,9 @@ struct FrameArgs
     int tilesX;
     unsigned tileMagic;   /* tile / tilesX = (tile * tileMagic) >> (32 + tileShift) for every tile of the frame (checked on the host) */
     int tileShift;
-    int fuseDefault;      /* 1: write the RGB bitmap from the renderer */
+    int fuseDefault;      /* bit 0: write the RGB bitmap from the renderer; bit 1: ImageStreaming, the frame counts its tiles (rowDone,
+                           * streamPlan, streamSerial below); bit 2: ... and its primitive ids leave with the image.  One word that
+                           * the epilogue reads anyway: a frame that is not streamed loads nothing more than it did */
     int stackSlots;       /* colour-stack slots per lane in LDS */
     float4 *deepStack;    /* F_STACK instantiations: the slots beyond them, [slot - stackSlots][pixel of the strip] */
     long deepStride;      /* float4s between two slots of a pixel = pixels of the strip */
@@ -39,11 +41,10 @@ struct FrameArgs
     unsigned *tileCost;        /* out: duration of every tile of this frame, 100 MHz ticks */
     const unsigned *tileOrder; /* in: workgroup -> order entry (see ORDER_* below), most expensive tiles first */
     int nbTiles;               /* tiles of the frame; the ordered launch has 3 * SPLIT_TILES_MAX workgroups more */
-    /* ImageStreaming (see StreamPlan below); rowDone null when off */
+    /* ImageStreaming (see StreamPlan below); read only when fuseDefault says so */
     unsigned *rowDone;                    /* one word per tile row, 64 words apart: units of it rendered, over all streamed frames */
     const struct StreamPlan *streamPlan;  /* bands of tile rows and the words the host watches */
     unsigned streamSerial;                /* this frame is the n-th streamed frame since the counters were zeroed */
-    int streamIds;                        /* ... and its primitive ids leave with the image: they too are stored with device scope */
 };
 
 /* ImageStreaming.  A host that takes one frame at a time waits for the kernel and then for 6 MB over PCIe (0.26 + 0.13 ms

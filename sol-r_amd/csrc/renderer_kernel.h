@@ -336,7 +336,7 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
         }
         pp[index].colorInfo = ppColor;
         pp[index].sceneInfo = ppScene;
-        if (F.streamIds) /* (ImageStreaming with the ids: written through to memory, where the copy engine reads the band) */
+        if ((FEAT & F_STREAM) && (F.fuseDefault & 4)) /* (ImageStreaming with the ids: written through to memory, where the copy engine reads the band) */
         {
             typedef int FourInts __attribute__((ext_vector_type(4)));
             const FourInts four = {id.x, id.y, id.z, id.w};
@@ -355,13 +355,13 @@ __global__ __launch_bounds__(WAVE, (SOLR_GENERIC_WAVES && (FEAT & F_TEX)) ? SOLR
                 c.y /= d;
                 c.z /= d;
             }
-            if (F.rowDone)
+            if ((FEAT & F_STREAM) && (F.fuseDefault & 2))
                 makeColor<true>(si, c, bitmap, index);
             else
                 makeColor(si, c, bitmap, index);
         }
     }
-    if (F.rowDone) /* ImageStreaming (renderer.h): this tile's bytes are out; is its row, is its band? */
+    if ((FEAT & F_STREAM) && (F.fuseDefault & 2)) /* ImageStreaming (renderer.h): this tile's bytes are out; is its row, is its band? */
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned units = partAgain ? 1u : (unsigned)SPLIT_PARTS;

@@ -8,12 +8,15 @@ namespace solrrows
 {
 RendererFn sphereTriangle(int count, int features)
 {
-    if ((features & ~(F_DEEP | F_STACK)) != (F_SPHERE | F_TRI))
+    if ((features & ~(F_DEEP | F_STACK | F_STREAM)) != (F_SPHERE | F_TRI))
         return nullptr;
     const bool deep = (features & F_DEEP) != 0;
+    if (count == 0 && (features & F_STREAM)) /* a frame whose image leaves in bands while it renders (renderer.h) */
+        return (features & F_STACK) ? (deep ? k_standardRenderer<0, (F_SPHERE | F_TRI) | F_DEEP | F_STACK | F_STREAM> : k_standardRenderer<0, (F_SPHERE | F_TRI) | F_STACK | F_STREAM>)
+                                    : (deep ? k_standardRenderer<0, (F_SPHERE | F_TRI) | F_DEEP | F_STREAM> : k_standardRenderer<0, (F_SPHERE | F_TRI) | F_STREAM>);
     if (count == 0 && (features & F_STACK)) /* a frame that may bounce deeper than the LDS stack holds */
         return deep ? k_standardRenderer<0, (F_SPHERE | F_TRI) | F_DEEP | F_STACK> : k_standardRenderer<0, (F_SPHERE | F_TRI) | F_STACK>;
-    if (features & F_STACK)
+    if (features & (F_STACK | F_STREAM))
         return nullptr;
     if (count == 0)
         return deep ? k_standardRenderer<0, (F_SPHERE | F_TRI) | F_DEEP> : k_standardRenderer<0, (F_SPHERE | F_TRI)>;

@@ -577,8 +577,12 @@ enum Feature
     F_FULL = 128,   /* global illumination + box-debug view */
     F_ALL = 255,
     F_DEEP = 256,   /* not a feature of the scene but of its node list: walk it with the three-bank loop (advanceTidy) */
-    F_STACK = 512   /* nor of the scene but of the frame: more bounces than colour-stack slots are kept in LDS
+    F_STACK = 512,  /* nor of the scene but of the frame: more bounces than colour-stack slots are kept in LDS
                      * (SOLR_LDS_STACK_SLOTS) - the deeper slots live in a per-pixel buffer in HBM (ColorStack) */
+    F_STREAM = 1024 /* of the frame: its image leaves in bands while it renders (renderer.h ImageStreaming) - the epilogue
+                     * that counts tiles lives in instantiations of its own, so that every other frame runs the code it
+                     * always ran (an epilogue with the branches in it cost the Cornell kernel 0.5 %: the compiler's
+                     * allocation of the WHOLE kernel changed with it) */
 };
 /* Colour-stack slots (4 dwords each) a lane keeps in LDS.  With the 27-dword cold record that is 39 dwords per lane: what
  * 16 waves per CU - 4 per SIMD, the kernel's register budget - leave each lane of the 160 KB.  A frame that may bounce

@@ -357,8 +357,13 @@ void solr_hip_set_frames_in_flight(int n)
         quiesce();
         if (g.initialized)
             (void)hipSetDevice(g.device);
+        const int before = g.flights;
         g.flights = n < 1 ? 1 : (n > MAX_FLIGHTS ? MAX_FLIGHTS : n);
         g.current = 0;
+        /* (which tiles are worth four quadrant waves depends on how many frames overlap: the launch order is made anew
+         * with the next frame, not at the next regular sort) */
+        if (g.flights != before)
+            g.orderValid = false;
         if (g.initialized && g.width > 0)
             allocateFrame();
     });

@@ -40,8 +40,8 @@ namespace solrrows
 {
 RendererFn renderer(int count, int features, bool volume)
 {
-    if (volume || (features & ~(F_DEEP | F_STACK)) == F_ALL)
-        return (features & F_STACK) ? nullptr : everything(count, features, volume);
+    if (volume || (features & ~(F_DEEP | F_STACK | F_STREAM)) == F_ALL)
+        return (features & (F_STACK | F_STREAM)) ? nullptr : everything(count, features, volume);
     RendererFn fn = nullptr;
     if (!(fn = spherePlane(count, features)) && !(fn = sphereTriangle(count, features)) && !(fn = sphereCylinder(count, features)) &&
         !(fn = untexturedMix(count, features)) && !(fn = textured(count, features)))
@@ -372,8 +372,11 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     BandCuts streamCuts = {};
     {
         int rows[SOLR_STREAM_BANDS_MAX + 1];
+        /* (is there an instantiation that counts tiles for the kernel this scene takes?  Asked of the frame before: the
+         * launch order, made further up than the choice of the kernel, has to know) */
         if (g.streamNext && !counting && !g.recordNext && F.fuseDefault && sceneInfo.frameBufferType != ftBGR && !twoFlights() &&
-            g.nbRows < 0 && gDevices == 1 && !g.boundBitmap && !g.sharedRing && imageStreamingCuts(tilesY, rows, &streamCuts.bands))
+            g.nbRows < 0 && gDevices == 1 && !g.boundBitmap && !g.sharedRing && g.lastMask >= 0 &&
+            solrrows::renderer(0, g.lastMask | F_STREAM, false) != nullptr && imageStreamingCuts(tilesY, rows, &streamCuts.bands))
             for (int b = 0; b <= streamCuts.bands; ++b)
                 streamCuts.firstTile[b] = rows[b] * F.tilesX;
     }
@@ -431,7 +434,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                 streamCandidate = false;
         }
         F.tileCost = (unsigned *)g.tileCost.ptr;
-        /* statistics (and, in cost order, a fresh order) every sixteenth frame, and at once when the
+        /* statistics (and, in cost order, a fresh order) every sortPeriod()-th frame, and at once when the
          * decision has just changed; in between the last order is reused */
         const bool ordered = g.costFrames > 0 && (g.tileScheduling == 2 || g.reorder);
         /* a streamed frame takes its tiles band after band (k_orderTiles): an order by cost alone is re-made for it at
@@ -439,7 +442,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         const BandCuts cuts = streamCandidate ? streamCuts : BandCuts();
         if (ordered && g.orderValid && cuts.bands > 0 && memcmp(&g.orderCuts, &cuts, sizeof(cuts)) != 0)
             g.orderValid = false;
-        const bool refresh = g.costFrames > 0 && (g.costFrames % 16 == 1 || (ordered && !g.orderValid));
+        const bool refresh = g.costFrames > 0 && (g.costFrames % sortPeriod() == 1 || (ordered && !g.orderValid));
         const bool sort = ordered && refresh;
         if (!ordered)
             g.orderValid = false;
@@ -517,10 +520,12 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     const bool volumeCamera = sceneInfo.cameraType == ctVolumeRendering;
     KernelFn fn = solrrows::renderer(1, F_ALL, volumeCamera);
     int deepSlots = 0; /* colour-stack slots of this frame kept in HBM (F_STACK) */
+    int chosenMask = -1; /* features of the row chosen: what an instantiation with another epilogue (F_STREAM) is asked for with */
     if (!counting)
     {
         fn = solrrows::renderer(0, F_ALL | F_DEEP, volumeCamera);
         int row = 0, chosen = -1;
+        chosenMask = -1;
         for (const auto &v : variants)
         {
             if ((need & ~v.features) == 0 && g.variant != 4 && !volumeCamera)
@@ -536,6 +541,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
                         deepSlots = maxIt - SOLR_LDS_STACK_SLOTS;
                     }
                 chosen = row;
+                chosenMask = mask;
                 break;
             }
             ++row;
@@ -595,11 +601,22 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         if (g.variant == 10)
             HIPCHECK(hipMemsetAsync(F.deepStack, 0xff, (size_t)deepSlots * (size_t)F.deepStride * sizeof(float4), stream));
     }
-    /* (tiles in launch order, or band after band: an order by cost alone completes every band at the end) */
-    const bool streamed = streamCandidate && cntPtr == (unsigned long long *)g.counters.ptr &&
-                          (!F.tileOrder || memcmp(&g.orderCuts, &streamCuts, sizeof(streamCuts)) == 0) && armImageStreaming(F, tilesY, stream);
-    F.streamIds = (streamed && streamIds) ? 1 : 0;
-    g.streamedIds = F.streamIds != 0;
+    /* (tiles in launch order, or band after band: an order by cost alone completes every band at the end; the epilogue that
+     * counts tiles is in instantiations of its own - the lean rows have them, rt_device.h F_STREAM) */
+    bool streamed = false;
+    const int streamMask = chosenMask | (deepSlots > 0 ? F_STACK : 0) | F_STREAM;
+    if (streamCandidate && cntPtr == (unsigned long long *)g.counters.ptr && chosenMask >= 0 &&
+        (!F.tileOrder || memcmp(&g.orderCuts, &streamCuts, sizeof(streamCuts)) == 0))
+        if (KernelFn streaming = solrrows::renderer(0, streamMask, false))
+            if (armImageStreaming(F, tilesY, stream))
+            {
+                fn = streaming;
+                streamed = true;
+            }
+    g.lastMask = chosenMask;
+    if (streamed)
+        F.fuseDefault |= streamIds ? 6 : 2;
+    g.streamedIds = streamed && streamIds;
     if (streamed && g.variant == 13) /* (tests: the waves write no band's word - the host goes by the end of the kernel) */
         F.streamSerial = 0x7fffff00u;
     {

@@ -150,10 +150,10 @@ __global__ __launch_bounds__(256) void k_cartoon(const SceneInfo si, const PostP
  * runs on alone while the rest of the chip idles (profiles/r1/tile_timeline_*.txt: 23 % of the
  * 100k-triangle frame).  Consecutive frames of a renderer see nearly the same picture: every wave
  * records what its tile cost (one store); this kernel - one workgroup - reduces the costs to their
- * maximum and sum for the host (every sixteenth frame) and, when the
+ * maximum and sum for the host (every 64th frame: engine.h sortPeriod) and, when the
  * host has seen a heavy tail (max > 2 x mean), sorts the tiles by cost with a counting sort in LDS
  * (64 cost classes) so that the following frames are launched most-expensive-first; the order is
- * refreshed every sixteenth frame.  Only the order of work changes,
+ * refreshed every 64th frame.  Only the order of work changes,
  * never a result.  (Per-wave atomics for max / sum were tried first: 32 400 same-address device-scope
  * atomics per frame serialise at the memory side and tripled the frame time.) */
 __device__ unsigned orderSerial = 0u;

@@ -320,7 +320,7 @@ def test_frames_in_flight_with_a_moving_camera_render_every_tile(solr):
         e = view(i)
         hip.solr_hip_render(C.byref(si), C.byref(objects), C.byref(ppi), fp(e), fp(direction), fp(angles))
 
-    nb = 70   # the order is refreshed every sixteenth frame: several sorts overlap a running frame
+    nb = 200  # the order is refreshed every 64th frame: several sorts overlap a running frame
     try:
         hip.solr_hip_set_tile_scheduling(0)
         hip.solr_hip_set_frames_in_flight(1)

@@ -1,4 +1,4 @@
-"""The mesh kernel launch by launch, one frame at a time, after 600 frames with three in flight: the order of the launch is\nre-made every sixteenth frame from the costs the tiles reported, and with it the set of tiles rendered as four quadrant waves -\nthe kernel takes 0.40 or 0.46 ms by turns (and 0.61 for the first eight, before the first order for one frame in flight).\nusage: python tools/mesh_kernel_phases.py  -> profiles/r6/mesh_kernel_per_launch.txt"""
+"""The mesh kernel launch by launch, one frame at a time, after 600 frames with three in flight: the order of the launch is\nre-made every 64th frame (sixteenth, when this was recorded) from the costs the tiles reported, and with it the set of tiles rendered as four quadrant waves -\nthe kernel takes 0.40 or 0.46 ms by turns (and 0.61 for the first eight, before the first order for one frame in flight).\nusage: python tools/mesh_kernel_phases.py  -> profiles/r6/mesh_kernel_per_launch.txt"""
 import ctypes as C, importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
