@@ -437,10 +437,10 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         /* statistics (and, in cost order, a fresh order) every sortPeriod()-th frame, and at once when the
          * decision has just changed; in between the last order is reused */
         const bool ordered = g.costFrames > 0 && (g.tileScheduling == 2 || g.reorder);
-        /* a streamed frame takes its tiles band after band (k_orderTiles): an order by cost alone is re-made for it at
-         * once; the other way round the banded order serves until the next regular refresh */
+        /* a streamed frame takes its tiles band after band (k_orderTiles), any other by cost alone: the order is re-made
+         * at once when the frame at hand is of the other kind */
         const BandCuts cuts = streamCandidate ? streamCuts : BandCuts();
-        if (ordered && g.orderValid && cuts.bands > 0 && memcmp(&g.orderCuts, &cuts, sizeof(cuts)) != 0)
+        if (ordered && g.orderValid && memcmp(&g.orderCuts, &cuts, sizeof(cuts)) != 0)
             g.orderValid = false;
         const bool refresh = g.costFrames > 0 && (g.costFrames % sortPeriod() == 1 || (ordered && !g.orderValid));
         const bool sort = ordered && refresh;
