@@ -294,11 +294,11 @@ const BitmapBuffer *solr_hip_image_wait(int ticket);
 void solr_hip_set_copy_route(int onTheFramesOwnStream);
 /* One frame at a time (the reference's render_begin ... render_end, CudaKernel.cpp:174-312): kernel, then 6 MB over PCIe,
  * nothing rendering meanwhile.  solr_hip_stream_next_image(1) before a cudaRender makes that frame's waves say - in words
- * of page-locked host memory - when a band of tile rows is complete (four bands; sol-r_amd/csrc/renderer.h,
+ * of page-locked host memory - when a band of tile rows is complete (five bands; sol-r_amd/csrc/renderer.h,
  * ImageStreaming); solr_hip_d2h_streamed_image(image) behind it copies every band to its rows of `image` (host memory of
  * any kind) as soon as its word has come - or the kernel has ended, whichever is first - and returns when the last has
  * landed: 1 done, 0 the frame rendered last was not such a frame and nothing was copied (d2h_bitmap then), -1 error.
- * The image leaves while the rows below still render: 0.31 instead of 0.39 ms per Cornell frame at 1080p
+ * The image leaves while the rows below still render: 0.30 instead of 0.39 ms per Cornell frame at 1080p
  * (profiles/r6/api_frame_cornell.txt).  Same bytes.  Applies to whole frames of one device whose RGB image the renderer
  * itself writes (no neighbourhood post-process, ftRGB), one frame in flight, no tile that the cost-ordered launch would
  * render as four quadrant waves (such a frame keeps that order); any other frame is rendered and read back as before.

@@ -73,6 +73,7 @@ struct StreamPlan
 struct BandCuts
 {
     int bands;
+    int heavyShare; /* the heaviest n / heavyShare tiles go first, wherever they lie (k_orderTiles) */
     int firstTile[SOLR_STREAM_BANDS_MAX + 1];
 };
 

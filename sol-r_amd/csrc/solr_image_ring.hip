@@ -95,14 +95,15 @@ bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], i
     }
     if (!g.streamSupport || tileRows < 2 * SOLR_STREAM_BANDS_MAX)
         return false;
-    /* Four bands of equal height.  The copy engine moves rows twice as fast as the Cornell kernel renders them: every
+    /* Five bands of equal height.  The copy engine moves rows twice as fast as the Cornell kernel renders them: every
      * band but the last has landed before the next is complete, and the last is what the frame waits for behind its
-     * kernel.  More bands make that one shorter - and the kernel longer, because the launch has to respect them
-     * (k_orderTiles: band after band).  Per frame, Cornell / molecule (profiles/r6/stream_frame.txt): 2 bands 0.346 /
-     * 0.414 ms, 3: 0.314 / 0.397, 4: 0.306 / 0.405, 5: 0.306 / 0.412, 6: 0.327 / 0.438, 8: 0.432 / 0.489 (the host's
-     * calls no longer keep up); read back behind the kernel 0.394 / 0.485.
+     * kernel.  More bands make that one shorter - and cost the host more calls and the kernel its order: the launch has
+     * to respect the bands (k_orderTiles: the heaviest eighth of the tiles first wherever they lie, the others band after
+     * band).  Per frame, Cornell / molecule (profiles/r6/stream_frame.txt): 3 bands 0.313 / 0.398 ms, 4: 0.304 / 0.388,
+     * 5: 0.301 / 0.385, 6: 0.387 / 0.432 (the host's calls no longer keep up); read back behind the kernel 0.394 / 0.483.
      * SOLR_HIP_STREAM_BANDS (experiments): 1 ... SOLR_STREAM_BANDS_MAX; SOLR_HIP_STREAM_EQUAL=0: bands of n : n - 1 : ... : 1,
-     * the last copy the shortest (3 : 2 : 1: 0.311 / 0.421) */
+     * the last copy the shortest; SOLR_HIP_STREAM_HEAVY=h: the heaviest 1 / h of the tiles first (8; with none first the
+     * molecule's frame is 0.412 ms, with half of them 0.42 and the Cornell box's 0.54) */
     /* SOLR_HIP_STREAM_CUTS="0.33,0.67,0.89" (experiments): the bands end at these fractions of the frame's tile rows */
     if (const char *given = getenv("SOLR_HIP_STREAM_CUTS"))
     {
@@ -123,7 +124,7 @@ bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], i
         *bands = n + 1;
         return true;
     }
-    static const int wanted = getenv("SOLR_HIP_STREAM_BANDS") ? std::max(1, std::min(SOLR_STREAM_BANDS_MAX, atoi(getenv("SOLR_HIP_STREAM_BANDS")))) : 4;
+    static const int wanted = getenv("SOLR_HIP_STREAM_BANDS") ? std::max(1, std::min(SOLR_STREAM_BANDS_MAX, atoi(getenv("SOLR_HIP_STREAM_BANDS")))) : 5;
     static const bool equal = !(getenv("SOLR_HIP_STREAM_EQUAL") && getenv("SOLR_HIP_STREAM_EQUAL")[0] == '0');
     const int total = equal ? wanted : wanted * (wanted + 1) / 2;
     int row = 0, weight = 0;

@@ -377,8 +377,12 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
         if (g.streamNext && !counting && !g.recordNext && F.fuseDefault && sceneInfo.frameBufferType != ftBGR && !twoFlights() &&
             g.nbRows < 0 && gDevices == 1 && !g.boundBitmap && !g.sharedRing && g.lastMask >= 0 &&
             solrrows::renderer(0, g.lastMask | F_STREAM, false) != nullptr && imageStreamingCuts(tilesY, rows, &streamCuts.bands))
+        {
             for (int b = 0; b <= streamCuts.bands; ++b)
                 streamCuts.firstTile[b] = rows[b] * F.tilesX;
+            static const int share = getenv("SOLR_HIP_STREAM_HEAVY") ? std::max(1, atoi(getenv("SOLR_HIP_STREAM_HEAVY"))) : 8;
+            streamCuts.heavyShare = share;
+        }
     }
     const bool streamIds = g.streamNext == 2;
     g.streamNext = 0;

@@ -181,10 +181,14 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
                                                       volatile unsigned *hostStats, int sort, const BandCuts cuts)
 {
     /* cuts.bands > 0 (ImageStreaming, renderer.h: the image leaves in bands of tile rows while the kernel renders): the
-     * order is band after band - at most eight - and by cost inside a band, so that the bands
-     * complete one after the other and only the last one has a tail to keep short; no tile is split (the host asks for
-     * this order only where none would be).  Bins: band (3 bits, the first band in the highest bins), class (6), and
+     * heaviest eighth of the tiles first, by cost - they are the frame's critical path wherever they lie, and a band
+     * whose heavy tiles started first completes when its light ones have; then the others band after band - at most
+     * eight - and by cost inside a band, so that the bands complete one after the other.  No tile is split (the host asks
+     * for this order only where none would be).  Bins: band (3 bits, the first band in the highest bins), class (6), and
      * one bit of the tile index instead of four. */
+    __shared__ unsigned classCount[64];
+    __shared__ unsigned classFirst[64];
+    __shared__ unsigned firstHeavy, nbHeavy;
     __shared__ unsigned nbSplit;
     __shared__ unsigned splitClass;
     __shared__ unsigned bins[1024];
@@ -259,6 +263,78 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
         }
     }
     __syncthreads();
+    if (cuts.bands > 0)
+    {
+        if (t < 64)
+        {
+            unsigned total = 0u;
+            for (unsigned band = 0; band < 8u; ++band)
+                total += bins[(band << 7) | ((unsigned)t << 1)] + bins[(band << 7) | ((unsigned)t << 1) | 1u];
+            classCount[t] = total;
+        }
+        __syncthreads();
+        if (t == 0)
+        {
+            /* whole classes from the top down, as many as hold an eighth of the tiles at most; their places in descending
+             * order of class */
+            unsigned upTo = 0u, first = 64u;
+            for (int c = 63; c >= 1; --c)
+            {
+                if (upTo + classCount[c] > (unsigned)n / (unsigned)max(cuts.heavyShare, 1))
+                    break;
+                classFirst[c] = upTo;
+                upTo += classCount[c];
+                first = (unsigned)c;
+            }
+            firstHeavy = first;
+            nbHeavy = upTo;
+        }
+        __syncthreads();
+        const unsigned heavyFrom = firstHeavy, heavy = nbHeavy;
+        if (t == 0)
+            hostStats[5] = 0u;
+        if (((unsigned)t >> 1 & 63u) >= heavyFrom) /* those tiles take their places from classFirst, not from a bin */
+            bins[t] = 0u;
+        __syncthreads();
+        const unsigned own = bins[1023 - t];
+        scan[t] = own;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1)
+        {
+            const unsigned add = (t >= off) ? scan[t - off] : 0u;
+            __syncthreads();
+            scan[t] += add;
+            __syncthreads();
+        }
+        bins[1023 - t] = scan[t] - own;
+        __syncthreads();
+        for (int i = n + t; i < n + (SPLIT_PARTS - 1) * SPLIT_TILES_MAX; i += 1024)
+            order[i] = ORDER_NOTHING;
+        for (int base = 0; base < n; base += BATCH * 1024)
+        {
+            unsigned c[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k)
+            {
+                const int i = base + k * 1024 + t;
+                c[k] = (i < n) ? snapshot[i] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k)
+            {
+                const int i = base + k * 1024 + t;
+                if (i < n)
+                {
+                    const unsigned cls = min(63u, (unsigned)((float)c[k] * toClass));
+                    if (cls >= heavyFrom)
+                        order[atomicAdd(&classFirst[cls], 1u)] = (unsigned)i;
+                    else
+                        order[heavy + atomicAdd(&bins[((7u - bandOfTile(cuts, i)) << 7) | (cls << 1) | ((unsigned)i & 1u)], 1u)] = (unsigned)i;
+                }
+            }
+        }
+        return;
+    }
     /* exclusive prefix over bins in DESCENDING bin order (Hillis-Steele on the reversed array) */
     const unsigned mine = bins[1023 - t];
     scan[t] = mine;
@@ -301,7 +377,7 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
     }
     __syncthreads();
     if (t == 0)
-        nbSplit = (splitClass < 64u && cuts.bands <= 0) ? scan[1023 - (splitClass << 4)] : 0u;
+        nbSplit = splitClass < 64u ? scan[1023 - (splitClass << 4)] : 0u;
     __syncthreads();
     const unsigned split = nbSplit;
     if (t == 0)
@@ -323,9 +399,7 @@ __global__ __launch_bounds__(1024) void k_orderTiles(const unsigned *cost, unsig
             const int i = base + k * 1024 + t;
             if (i < n)
             {
-                const unsigned cls = min(63u, (unsigned)((float)c[k] * toClass));
-                const unsigned b = cuts.bands > 0 ? ((7u - bandOfTile(cuts, i)) << 7) | (cls << 1) | ((unsigned)i & 1u)
-                                                  : (cls << 4) | ((unsigned)i & 15u);
+                const unsigned b = (min(63u, (unsigned)((float)c[k] * toClass)) << 4) | ((unsigned)i & 15u);
                 const unsigned at = atomicAdd(&bins[b], 1u); /* position in descending order of cost */
                 if (at < split)
                     for (unsigned q = 0; q < (unsigned)SPLIT_PARTS; ++q)
