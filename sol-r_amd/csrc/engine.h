@@ -284,7 +284,7 @@ struct Engine
     bool streamedValid = false;          /* the frame rendered last counted its tiles: serial, image and bands below */
     const void *streamedBitmap = nullptr;
     unsigned streamSerial = 0;           /* streamed frames since the counters were zeroed */
-    long streamKey[3] = {0, 0, 0};       /* tilesX, tile rows, image width the counters belong to */
+    long streamKey[3] = {0, 0, 0};       /* tilesX, tile rows (+ 100000 x the number of bands), image width the counters belong to */
     DeviceBuffer streamCounters;         /* rowDone | bandDone | the StreamPlan */
     StreamPlan streamPlan = {};          /* host image of the plan */
     int streamBands = 0;
@@ -510,8 +510,8 @@ void d2hBitmapWait();
 /* solr_image_ring.hip: the ring of page-locked host images behind solr_hip_d2h_image_async */
 void releaseImageRing();
 void releaseImageStreaming();
-bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], int *bands);
-bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream);
+bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], int *bands, bool withIds);
+bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream, bool withIds);
 void markStreamedFrame(hipStream_t stream);
 void ensureCopyStream();
 bool ensureImageRing();

@@ -86,7 +86,7 @@ void releaseImageStreaming()
  * not streamed (SOLR_HIP_NO_IMAGE_STREAMING=1, too few tile rows, an allocation failed: the read-back then takes the plain route). */
 /* the bands of a frame of that many tile rows; false: such a frame is not streamed (SOLR_HIP_NO_IMAGE_STREAMING=1, a frame
  * of fewer than sixteen tile rows) */
-bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], int *bands)
+bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], int *bands, bool withIds)
 {
     if (g.streamSupport < 0)
     {
@@ -124,7 +124,10 @@ bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], i
         *bands = n + 1;
         return true;
     }
-    static const int wanted = getenv("SOLR_HIP_STREAM_BANDS") ? std::max(1, std::min(SOLR_STREAM_BANDS_MAX, atoi(getenv("SOLR_HIP_STREAM_BANDS")))) : 5;
+    /* (with the primitive ids - 39 MB a frame, PCIe busy from the first band to the last - three: every band is two copies,
+     * and five cost 0.943 ms a Cornell frame where three cost 0.873; behind the kernel 1.0) */
+    static const int asked = getenv("SOLR_HIP_STREAM_BANDS") ? std::max(1, std::min(SOLR_STREAM_BANDS_MAX, atoi(getenv("SOLR_HIP_STREAM_BANDS")))) : 0;
+    const int wanted = asked ? asked : (withIds ? 3 : 5);
     static const bool equal = !(getenv("SOLR_HIP_STREAM_EQUAL") && getenv("SOLR_HIP_STREAM_EQUAL")[0] == '0');
     const int total = equal ? wanted : wanted * (wanted + 1) / 2;
     int row = 0, weight = 0;
@@ -139,12 +142,12 @@ bool imageStreamingCuts(int tileRows, int firstRow[SOLR_STREAM_BANDS_MAX + 1], i
     return true;
 }
 
-bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream)
+bool armImageStreaming(FrameArgs &F, int tileRows, hipStream_t stream, bool withIds)
 {
     int cuts[SOLR_STREAM_BANDS_MAX + 1], bands = 0;
-    if (!imageStreamingCuts(tileRows, cuts, &bands))
+    if (!imageStreamingCuts(tileRows, cuts, &bands, withIds))
         return false;
-    const long key[3] = {F.tilesX, tileRows, g.width};
+    const long key[3] = {F.tilesX, tileRows + 100000l * bands, g.width};
     const unsigned perRow = (unsigned)(F.tilesX * SPLIT_PARTS);
     const bool fresh = memcmp(key, g.streamKey, sizeof(key)) != 0 || !g.streamCounters.ptr;
     /* (variant 14, tests: as if the row counts neared 2^32 every third frame) */

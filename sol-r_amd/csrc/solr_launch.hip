@@ -376,7 +376,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
          * launch order, made further up than the choice of the kernel, has to know) */
         if (g.streamNext && !counting && !g.recordNext && F.fuseDefault && sceneInfo.frameBufferType != ftBGR && !twoFlights() &&
             g.nbRows < 0 && gDevices == 1 && !g.boundBitmap && !g.sharedRing && g.lastMask >= 0 &&
-            solrrows::renderer(0, g.lastMask | F_STREAM, false) != nullptr && imageStreamingCuts(tilesY, rows, &streamCuts.bands))
+            solrrows::renderer(0, g.lastMask | F_STREAM, false) != nullptr && imageStreamingCuts(tilesY, rows, &streamCuts.bands, g.streamNext == 2))
         {
             for (int b = 0; b <= streamCuts.bands; ++b)
                 streamCuts.firstTile[b] = rows[b] * F.tilesX;
@@ -614,7 +614,7 @@ void renderImpl(const SceneInfo &sceneInfo, const vec4i &objects, const PostProc
     if (streamCandidate && cntPtr == (unsigned long long *)g.counters.ptr && chosenMask >= 0 &&
         (!F.tileOrder || memcmp(&g.orderCuts, &streamCuts, sizeof(streamCuts)) == 0))
         if (KernelFn streaming = solrrows::renderer(0, streamMask, false))
-            if (armImageStreaming(F, tilesY, stream))
+            if (armImageStreaming(F, tilesY, stream, streamIds))
             {
                 fn = streaming;
                 streamed = true;
